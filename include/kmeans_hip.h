@@ -1,0 +1,156 @@
+/*
+ * kmeans_hip.h -- C ABI of libkmeans_hip.so: the MI355X (gfx950) implementation of the
+ * Lloyd-iteration hot path of redwarp/kmeans-gpu (per-pixel CIE94 assignment, per-cluster
+ * sum/count reduction + centroid update, ordered-dither / replace output pass).
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the
+ * reference repository).  The high-level calls take HOST buffers exactly like the reference
+ * crate's `ImageProcessor` (core/src/lib.rs:24-165); the `kmg_dev_*` / `kmg_lloyd_*` calls take
+ * DEVICE pointers and an explicit hipStream_t so a host runtime (one process per GPU) can
+ * shard an image, run the exchange step of the update itself (RCCL all-reduce of the k
+ * accumulators) and keep everything resident in HBM.
+ *
+ * Conventions
+ *  - images: tightly packed row-major RGBA8, 4 bytes per pixel, no row padding
+ *    (core/src/image.rs:20-48); alpha is ignored on input and 255 on output.
+ *  - centroid tables: k x 4 floats (L, a, b, 1.0) -- the `vec4<f32>` array of the reference's
+ *    CentroidsBuffer (core/src/structures.rs:501-521) without its 16-byte count header.
+ *  - accumulators: k x 4 int64 = (sum qL, sum qa, sum qb, count), q = rint(Lab * 2^20).
+ *    Integer sums are order independent, so results are identical for any tiling or GPU count.
+ *  - all functions return KMG_OK (0) or a negative kmg_status; kmg_last_error() gives the
+ *    thread-local message of the last failure.
+ *  - every entry point is re-entrant on one kmg_processor (per-call workspace + stream), like
+ *    the reference's Send+Sync ImageProcessor (core/examples/parallel.rs:36-50).
+ *  - there is NO CPU fallback: without a usable HIP device kmg_processor_create fails.
+ */
+#ifndef KMEANS_HIP_H
+#define KMEANS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KMG_API __attribute__((visibility("default")))
+
+typedef enum kmg_status {
+    KMG_OK = 0,
+    KMG_ERR_INVALID_ARGUMENT = -1, /* null pointer, zero-sized image, color_count == 0 ... */
+    KMG_ERR_NO_DEVICE = -2,        /* no HIP device / device init failed                    */
+    KMG_ERR_HIP = -3,              /* a HIP runtime call failed (message has the detail)    */
+    KMG_ERR_OUT_OF_MEMORY = -4,
+    KMG_ERR_UNSUPPORTED = -5       /* e.g. Algorithm::Octree (CPU algorithm, out of scope)  */
+} kmg_status;
+
+/* core/src/lib.rs:215-219 `enum Algorithm` */
+typedef enum kmg_algorithm { KMG_ALGO_KMEANS = 0, KMG_ALGO_OCTREE = 1 } kmg_algorithm;
+/* core/src/lib.rs:234-239 `enum ReduceMode` */
+typedef enum kmg_reduce_mode { KMG_MODE_REPLACE = 0, KMG_MODE_DITHER = 1, KMG_MODE_MELD = 2 } kmg_reduce_mode;
+
+#define KMG_FIX_SHIFT 20
+#define KMG_MAX_K 4096u
+
+/* Compile-time constants of the reference exposed as options (defaults = reference values). */
+typedef struct kmg_options {
+    uint32_t struct_size;     /* sizeof(kmg_options)                                           */
+    int32_t  device;          /* HIP device ordinal, -1 = current device                       */
+    uint32_t shrink_max_dim;  /* MAX_IMAGE_DIMENSION = 256 (core/src/structures.rs:23); 0 = off */
+    uint32_t max_iterations;  /* MAX_ITERATION = 128 (core/src/modules.rs:765)                  */
+    uint32_t check_period;    /* MAX_ITERATION_BEFORE_CONVERGENCE_CHECK = 8 (modules.rs:766)    */
+    float    convergence;     /* ColorSpace::Lab.convergence() = 1.0 (core/src/lib.rs:189-194)  */
+} kmg_options;
+
+typedef struct kmg_processor kmg_processor;
+typedef struct kmg_lloyd kmg_lloyd;
+
+KMG_API const char *kmg_last_error(void);
+KMG_API const char *kmg_version(void);
+KMG_API void kmg_default_options(kmg_options *opt);
+
+/* ---- ImageProcessor::new  (core/src/lib.rs:38-65) ------------------------------------- */
+KMG_API int kmg_processor_create(kmg_processor **out);
+KMG_API int kmg_processor_create_ex(const kmg_options *opt, kmg_processor **out);
+KMG_API void kmg_processor_destroy(kmg_processor *p);
+
+/* ---- ImageProcessor::palette  (core/src/lib.rs:67-77, 255-286) -------------------------
+ * out_rgba: capacity color_count*4 bytes; *out_count receives the number of colours
+ * (== color_count for k-means), sorted ascending by Lab L.                                 */
+KMG_API int kmg_palette(kmg_processor *p, const uint8_t *rgba, uint32_t width, uint32_t height,
+                        uint32_t color_count, int algo, uint8_t *out_rgba, uint32_t *out_count);
+
+/* ---- ImageProcessor::find  (core/src/lib.rs:79-114) ------------------------------------ */
+KMG_API int kmg_find(kmg_processor *p, const uint8_t *rgba, uint32_t width, uint32_t height,
+                     const uint8_t *palette_rgba, uint32_t n_colors, int mode, uint8_t *out_rgba);
+
+/* ---- ImageProcessor::reduce  (core/src/lib.rs:116-164) --------------------------------- */
+KMG_API int kmg_reduce(kmg_processor *p, const uint8_t *rgba, uint32_t width, uint32_t height,
+                       uint32_t color_count, int algo, int mode, uint8_t *out_rgba);
+
+/* ---- host-side colour helpers the reference takes from the `palette` crate -------------
+ * CentroidsBuffer::fixed_centroids (core/src/structures.rs:523-553): sRGB8 -> Lab (L,a,b,1)  */
+KMG_API int kmg_palette_to_centroids(const uint8_t *palette_rgba, uint32_t n_colors, float *centroids4);
+/* CentroidsBuffer::pull_values (core/src/structures.rs:581-617): Lab -> sRGB8 (alpha 255)    */
+KMG_API int kmg_centroids_to_palette(const float *centroids4, uint32_t k, uint8_t *out_rgba);
+
+/* ======================= device-pointer API (hot path building blocks) ================== */
+/* `stream` is a hipStream_t (NULL = the default stream).  Calls only enqueue work unless the
+ * comment says they synchronise.                                                            */
+
+/* ColorConverterModule, rgb_to_lab.wgsl:66-80: RGBA8 -> Lab, 3 floats per pixel.            */
+KMG_API int kmg_dev_rgb_to_lab(kmg_processor *p, const uint8_t *d_rgba, uint64_t n_pixels,
+                               float *d_lab3, void *stream);
+
+/* InputTexture::resized (core/src/structures.rs:76-182, resize.wgsl:7-18).                   */
+KMG_API void kmg_resized_dims(uint32_t width, uint32_t height, uint32_t max_size,
+                              uint32_t *new_width, uint32_t *new_height);
+KMG_API int kmg_dev_resize(kmg_processor *p, const uint8_t *d_rgba, uint32_t width, uint32_t height,
+                           uint32_t new_width, uint32_t new_height, uint8_t *d_out_rgba, void *stream);
+
+/* One Lloyd problem = one image (or one row band of it) with k centroids.
+ * ChooseCentroidModule + FindCentroidModule state (core/src/modules.rs:452-761).             */
+KMG_API int kmg_lloyd_create(kmg_processor *p, uint32_t k, kmg_lloyd **out);
+KMG_API void kmg_lloyd_destroy(kmg_lloyd *s);
+/* centroid table up/down (synchronise `stream`) */
+KMG_API int kmg_lloyd_set_centroids(kmg_lloyd *s, const float *centroids4, void *stream);
+KMG_API int kmg_lloyd_get_centroids(kmg_lloyd *s, float *centroids4, void *stream);
+
+/* PlusPlusInitModule::compute (core/src/modules.rs:946-1246, plus_plus_init.wgsl,
+ * kmeans++_calc_diff.wgsl): deterministic farthest-point initialisation on the device.       */
+KMG_API int kmg_lloyd_init_centroids(kmg_lloyd *s, const uint8_t *d_rgba, uint32_t width,
+                                     uint32_t height, void *stream);
+
+/* FindCentroidModule::dispatch (find_centroid.wgsl:15-44) fused with the masked sums of
+ * choose_centroid.wgsl:75-178: labels for every pixel AND the k x 4 int64 accumulators of this
+ * pixel range, one pass over the RGBA8 data.  d_acc4 may be NULL (assignment only);
+ * d_labels may be NULL (sums only).                                                          */
+KMG_API int kmg_lloyd_assign_accumulate(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n_pixels,
+                                        uint32_t *d_labels, int64_t *d_acc4, void *stream);
+
+/* choose_centroid.wgsl:180-206 `pick` for all k at once: centroid <- sum/count, convergence
+ * flags.  d_acc4 holds the (all-reduced) accumulators.                                        */
+KMG_API int kmg_lloyd_update(kmg_lloyd *s, const int64_t *d_acc4, void *stream);
+/* convergence[K] of choose_centroid.wgsl:196-202 after the last update (synchronises).       */
+KMG_API int kmg_lloyd_converged_count(kmg_lloyd *s, uint32_t *count, void *stream);
+
+/* ChooseCentroidModule::compute (core/src/modules.rs:763-840): the whole loop on one device.
+ * Expects the centroid table initialised.  Synchronises.  *iterations = the reference's
+ * `current_iteration` when the loop stopped.                                                  */
+KMG_API int kmg_lloyd_run(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n_pixels,
+                          uint32_t *d_labels, uint32_t *iterations, void *stream);
+
+/* find_colors / dither_colors (core/src/operations.rs:99-155,215-271; find_centroid.wgsl,
+ * swap.wgsl, mix_colors.wgsl main_dither, lab_to_rgb.wgsl) on a row band: `row0` is the image
+ * row of the band's first pixel (the Bayer index uses image coordinates).  centroids4 is a
+ * HOST table.  Output RGBA8 in d_out_rgba.                                                    */
+KMG_API int kmg_dev_apply(kmg_processor *p, const uint8_t *d_rgba, uint32_t width, uint32_t rows,
+                          uint32_t row0, const float *centroids4, uint32_t k, int mode,
+                          uint8_t *d_out_rgba, void *stream);
+
+/* mix_colors.wgsl:53-67: the dither threshold of a centroid table (host helper).             */
+KMG_API int kmg_dither_threshold(const float *centroids4, uint32_t k, float *threshold);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KMEANS_HIP_H */

@@ -1,0 +1,563 @@
+// kmg_api.hip -- the C ABI of libkmeans_hip.so (include/kmeans_hip.h): argument checking,
+// per-call workspaces and the host sequencing of the reference's operations.rs / modules.rs on
+// top of the gfx950 kernels.  There is no CPU data path in this file: every per-pixel step is a
+// kernel launch, and without a HIP device the processor cannot be created.
+
+#include "../../include/kmeans_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "kmg_color.h"
+#include "kmg_kernels.h"
+
+using namespace kmg;
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    if (const char *lv = getenv("KMG_LOG"))
+        if (!strcmp(lv, "debug") || !strcmp(lv, "error")) fprintf(stderr, "[kmeans_hip] error %d: %s\n", code, g_err);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(e_ == hipErrorOutOfMemory ? KMG_ERR_OUT_OF_MEMORY : KMG_ERR_HIP,       \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+static bool log_debug()
+{
+    const char *lv = getenv("KMG_LOG");
+    return lv && !strcmp(lv, "debug");
+}
+
+extern "C" const char *kmg_last_error(void) { return g_err; }
+extern "C" const char *kmg_version(void) { return "kmeans_hip 0.1 (gfx950)"; }
+
+extern "C" void kmg_default_options(kmg_options *opt)
+{
+    if (!opt) return;
+    opt->struct_size = sizeof(kmg_options);
+    opt->device = -1;
+    opt->shrink_max_dim = 256;   // structures.rs:23
+    opt->max_iterations = 128;   // modules.rs:765
+    opt->check_period = 8;       // modules.rs:766
+    opt->convergence = 1.0f;     // lib.rs:189-194
+}
+
+// ---------------------------------------------------------------------------------------------
+// processor
+// ---------------------------------------------------------------------------------------------
+struct kmg_processor {
+    int device;
+    kmg_options opt;
+    float *d_lut;   // 256 x f32: sRGB decode * 100
+};
+
+struct kmg_lloyd {
+    kmg_processor *p;
+    uint32_t k;
+    Centroid *d_cent;            // k
+    int64_t *d_partials;         // 2048 x k x 4
+    int64_t *d_acc;              // k x 4 (used by kmg_lloyd_run)
+    uint32_t *d_nconv;           // 1
+    unsigned long long *d_key;   // 1 (init arg-max)
+    float *d_dist;               // init distance map, grown on demand
+    uint64_t dist_cap;
+};
+
+extern "C" int kmg_processor_create(kmg_processor **out) { return kmg_processor_create_ex(nullptr, out); }
+
+extern "C" int kmg_processor_create_ex(const kmg_options *opt, kmg_processor **out)
+{
+    if (!out) return fail(KMG_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    kmg_options o;
+    kmg_default_options(&o);
+    if (opt) {
+        if (opt->struct_size != sizeof(kmg_options))
+            return fail(KMG_ERR_INVALID_ARGUMENT, "kmg_options.struct_size mismatch");
+        o = *opt;
+        if (o.max_iterations == 0 || o.check_period == 0)
+            return fail(KMG_ERR_INVALID_ARGUMENT, "max_iterations and check_period must be > 0");
+    }
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(KMG_ERR_NO_DEVICE, "no HIP device available (%s); libkmeans_hip has no CPU path",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    int dev = o.device;
+    if (dev < 0) {
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    }
+    if (dev >= count) return fail(KMG_ERR_NO_DEVICE, "device %d out of range (%d devices)", dev, count);
+    HIP_TRY(hipSetDevice(dev));
+    kmg_processor *p = new (std::nothrow) kmg_processor();
+    if (!p) return fail(KMG_ERR_OUT_OF_MEMORY, "host allocation failed");
+    p->device = dev;
+    p->opt = o;
+    p->d_lut = nullptr;
+    float lut[256];
+    build_srgb_lut100(lut);
+    hipError_t e1 = hipMalloc((void **)&p->d_lut, sizeof lut);
+    if (e1 == hipSuccess) e1 = hipMemcpy(p->d_lut, lut, sizeof lut, hipMemcpyHostToDevice);
+    if (e1 != hipSuccess) {
+        if (p->d_lut) (void)hipFree(p->d_lut);
+        delete p;
+        return fail(KMG_ERR_HIP, "processor setup failed: %s", hipGetErrorString(e1));
+    }
+    *out = p;
+    return KMG_OK;
+}
+
+extern "C" void kmg_processor_destroy(kmg_processor *p)
+{
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    if (p->d_lut) (void)hipFree(p->d_lut);
+    delete p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host colour helpers
+// ---------------------------------------------------------------------------------------------
+extern "C" int kmg_palette_to_centroids(const uint8_t *palette_rgba, uint32_t n, float *c4)
+{
+    if (!palette_rgba || !c4 || n == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad palette arguments");
+    for (uint32_t i = 0; i < n; ++i) {
+        crate_srgb8_to_lab(palette_rgba + 4 * i, c4 + 4 * i);
+        c4[4 * i + 3] = 1.0f;
+    }
+    return KMG_OK;
+}
+
+extern "C" int kmg_centroids_to_palette(const float *c4, uint32_t k, uint8_t *out)
+{
+    if (!c4 || !out || k == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad centroid arguments");
+    for (uint32_t i = 0; i < k; ++i) {
+        crate_lab_to_srgb8(c4 + 4 * i, out + 4 * i);
+        out[4 * i + 3] = 255;
+    }
+    return KMG_OK;
+}
+
+extern "C" int kmg_dither_threshold(const float *c4, uint32_t k, float *thr)
+{
+    if (!c4 || !thr || k < 2) return fail(KMG_ERR_INVALID_ARGUMENT, "dither threshold needs k >= 2");
+    *thr = dither_threshold(c4, k);
+    return KMG_OK;
+}
+
+extern "C" void kmg_resized_dims(uint32_t w, uint32_t h, uint32_t max_size, uint32_t *nw, uint32_t *nh)
+{
+    // structures.rs:79-89
+    uint32_t a, b;
+    if (w > h) {
+        uint32_t v = (uint32_t)((float)h * (float)max_size / (float)w);
+        a = max_size; b = v > 1 ? v : 1;
+    } else {
+        uint32_t v = (uint32_t)((float)w * (float)max_size / (float)h);
+        a = v > 1 ? v : 1; b = max_size;
+    }
+    if (nw) *nw = a;
+    if (nh) *nh = b;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device-pointer API
+// ---------------------------------------------------------------------------------------------
+static inline hipStream_t S(void *s) { return (hipStream_t)s; }
+
+extern "C" int kmg_dev_rgb_to_lab(kmg_processor *p, const uint8_t *d_rgba, uint64_t n, float *d_lab3, void *stream)
+{
+    if (!p || !d_rgba || !d_lab3 || n == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad rgb_to_lab arguments");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(launch_rgb_to_lab((const uint32_t *)d_rgba, n, p->d_lut, d_lab3, S(stream)));
+    return KMG_OK;
+}
+
+extern "C" int kmg_dev_resize(kmg_processor *p, const uint8_t *d_rgba, uint32_t w, uint32_t h, uint32_t nw,
+                              uint32_t nh, uint8_t *d_out, void *stream)
+{
+    if (!p || !d_rgba || !d_out || !w || !h || !nw || !nh) return fail(KMG_ERR_INVALID_ARGUMENT, "bad resize arguments");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(launch_resize((const uint32_t *)d_rgba, w, h, nw, nh, (uint32_t *)d_out, S(stream)));
+    return KMG_OK;
+}
+
+extern "C" int kmg_lloyd_create(kmg_processor *p, uint32_t k, kmg_lloyd **out)
+{
+    if (!p || !out) return fail(KMG_ERR_INVALID_ARGUMENT, "bad lloyd_create arguments");
+    *out = nullptr;
+    if (k == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "k must be an integer higher than 0");  // args.rs:160-171
+    if (k > KMG_MAX_K) return fail(KMG_ERR_UNSUPPORTED, "k = %u exceeds KMG_MAX_K = %u", k, KMG_MAX_K);
+    HIP_TRY(hipSetDevice(p->device));
+    kmg_lloyd *s = new (std::nothrow) kmg_lloyd();
+    if (!s) return fail(KMG_ERR_OUT_OF_MEMORY, "host allocation failed");
+    memset(s, 0, sizeof *s);
+    s->p = p;
+    s->k = k;
+    hipError_t e = hipMalloc((void **)&s->d_cent, sizeof(Centroid) * k);
+    if (e == hipSuccess) e = hipMemset(s->d_cent, 0, sizeof(Centroid) * k);   // structures.rs:501-521
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_partials, sizeof(int64_t) * 4ull * k * 2048ull);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_acc, sizeof(int64_t) * 4ull * k);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_nconv, sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(s->d_nconv, 0, sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_key, sizeof(unsigned long long));
+    if (e != hipSuccess) {
+        kmg_lloyd_destroy(s);
+        return fail(e == hipErrorOutOfMemory ? KMG_ERR_OUT_OF_MEMORY : KMG_ERR_HIP,
+                    "lloyd workspace allocation failed: %s", hipGetErrorString(e));
+    }
+    *out = s;
+    return KMG_OK;
+}
+
+extern "C" void kmg_lloyd_destroy(kmg_lloyd *s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->p->device);
+    if (s->d_cent) (void)hipFree(s->d_cent);
+    if (s->d_partials) (void)hipFree(s->d_partials);
+    if (s->d_acc) (void)hipFree(s->d_acc);
+    if (s->d_nconv) (void)hipFree(s->d_nconv);
+    if (s->d_key) (void)hipFree(s->d_key);
+    if (s->d_dist) (void)hipFree(s->d_dist);
+    delete s;
+}
+
+extern "C" int kmg_lloyd_set_centroids(kmg_lloyd *s, const float *c4, void *stream)
+{
+    if (!s || !c4) return fail(KMG_ERR_INVALID_ARGUMENT, "bad set_centroids arguments");
+    HIP_TRY(hipSetDevice(s->p->device));
+    std::vector<Centroid> h(s->k);
+    for (uint32_t i = 0; i < s->k; ++i) {
+        h[i].L = c4[4 * i]; h[i].a = c4[4 * i + 1]; h[i].b = c4[4 * i + 2];
+        h[i].C = chroma(h[i].a, h[i].b);
+    }
+    HIP_TRY(hipMemcpyAsync(s->d_cent, h.data(), sizeof(Centroid) * s->k, hipMemcpyHostToDevice, S(stream)));
+    HIP_TRY(hipStreamSynchronize(S(stream)));
+    return KMG_OK;
+}
+
+extern "C" int kmg_lloyd_get_centroids(kmg_lloyd *s, float *c4, void *stream)
+{
+    if (!s || !c4) return fail(KMG_ERR_INVALID_ARGUMENT, "bad get_centroids arguments");
+    HIP_TRY(hipSetDevice(s->p->device));
+    std::vector<Centroid> h(s->k);
+    HIP_TRY(hipMemcpyAsync(h.data(), s->d_cent, sizeof(Centroid) * s->k, hipMemcpyDeviceToHost, S(stream)));
+    HIP_TRY(hipStreamSynchronize(S(stream)));
+    for (uint32_t i = 0; i < s->k; ++i) {
+        c4[4 * i] = h[i].L; c4[4 * i + 1] = h[i].a; c4[4 * i + 2] = h[i].b; c4[4 * i + 3] = 1.0f;
+    }
+    return KMG_OK;
+}
+
+extern "C" int kmg_lloyd_init_centroids(kmg_lloyd *s, const uint8_t *d_rgba, uint32_t w, uint32_t h, void *stream)
+{
+    if (!s || !d_rgba || !w || !h) return fail(KMG_ERR_INVALID_ARGUMENT, "bad init_centroids arguments");
+    HIP_TRY(hipSetDevice(s->p->device));
+    const uint64_t n = (uint64_t)w * h;
+    if (n > 0xFFFFFFFFull) return fail(KMG_ERR_UNSUPPORTED, "image has more than 2^32-1 pixels");
+    // plus_plus_init.wgsl:161-168: rand(42) = 0.5625, rand(12) = 0.93359375 in IEEE binary32
+    const int32_t x0 = (int32_t)((float)w * 0.5625f);
+    const int32_t y0 = (int32_t)((float)h * 0.93359375f);
+    const uint64_t i0 = (uint64_t)y0 * w + (uint64_t)x0;
+    const uint32_t *rgba = (const uint32_t *)d_rgba;
+    HIP_TRY(launch_init_first(rgba, i0, s->p->d_lut, s->d_cent, s->d_key, S(stream)));
+    if (s->k > 1) {
+        if (s->dist_cap < n) {
+            if (s->d_dist) { HIP_TRY(hipStreamSynchronize(S(stream))); HIP_TRY(hipFree(s->d_dist)); s->d_dist = nullptr; s->dist_cap = 0; }
+            HIP_TRY(hipMalloc((void **)&s->d_dist, sizeof(float) * n));
+            s->dist_cap = n;
+        }
+        for (uint32_t j = 1; j < s->k; ++j) {   // modules.rs:1211-1246
+            HIP_TRY(launch_init_pass(rgba, n, s->p->d_lut, s->d_cent, j, s->d_dist, s->d_key, S(stream)));
+            HIP_TRY(launch_init_pick(rgba, s->p->d_lut, s->d_key, s->d_cent, j, S(stream)));
+        }
+    }
+    return KMG_OK;
+}
+
+extern "C" int kmg_lloyd_assign_accumulate(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_t *d_labels,
+                                           int64_t *d_acc4, void *stream)
+{
+    if (!s || !d_rgba || n == 0 || (!d_labels && !d_acc4))
+        return fail(KMG_ERR_INVALID_ARGUMENT, "bad assign_accumulate arguments");
+    HIP_TRY(hipSetDevice(s->p->device));
+    HIP_TRY(launch_assign((const uint32_t *)d_rgba, n, s->d_cent, s->k, s->p->d_lut, d_labels,
+                          d_acc4 ? s->d_partials : nullptr, S(stream)));
+    if (d_acc4) HIP_TRY(launch_reduce_partials(s->d_partials, assign_grid(n), s->k, d_acc4, S(stream)));
+    return KMG_OK;
+}
+
+extern "C" int kmg_lloyd_update(kmg_lloyd *s, const int64_t *d_acc4, void *stream)
+{
+    if (!s || !d_acc4) return fail(KMG_ERR_INVALID_ARGUMENT, "bad update arguments");
+    HIP_TRY(hipSetDevice(s->p->device));
+    HIP_TRY(launch_update(d_acc4, s->k, s->p->opt.convergence, s->d_cent, s->d_nconv, S(stream)));
+    return KMG_OK;
+}
+
+extern "C" int kmg_lloyd_converged_count(kmg_lloyd *s, uint32_t *count, void *stream)
+{
+    if (!s || !count) return fail(KMG_ERR_INVALID_ARGUMENT, "bad converged_count arguments");
+    HIP_TRY(hipSetDevice(s->p->device));
+    HIP_TRY(hipMemcpyAsync(count, s->d_nconv, sizeof(uint32_t), hipMemcpyDeviceToHost, S(stream)));
+    HIP_TRY(hipStreamSynchronize(S(stream)));
+    return KMG_OK;
+}
+
+extern "C" int kmg_lloyd_run(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_t *d_labels,
+                             uint32_t *iterations, void *stream)
+{
+    if (!s || !d_rgba || n == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad lloyd_run arguments");
+    const kmg_options &o = s->p->opt;
+    int rc;
+    // operations.rs:75-83 initial assignment (fused with the sums the first update needs)
+    if ((rc = kmg_lloyd_assign_accumulate(s, d_rgba, n, d_labels, s->d_acc, stream)) != KMG_OK) return rc;
+    uint32_t it = 0;
+    for (it = 0; it < o.max_iterations; ++it) {                       // modules.rs:769
+        if ((rc = kmg_lloyd_update(s, s->d_acc, stream)) != KMG_OK) return rc;           // :773-788
+        if ((rc = kmg_lloyd_assign_accumulate(s, d_rgba, n, d_labels, s->d_acc, stream)) != KMG_OK) return rc;  // :793-800
+        if (it > 0 && it % o.check_period == 0) {                    // :802
+            uint32_t conv = 0;
+            if ((rc = kmg_lloyd_converged_count(s, &conv, stream)) != KMG_OK) return rc;
+            if (conv >= s->k) {                                      // :826-831
+                if (log_debug()) fprintf(stderr, "[kmeans_hip] We have convergence, checked at iteration %u\n", it);
+                break;
+            }
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(S(stream)));
+    if (iterations) *iterations = it < o.max_iterations ? it : o.max_iterations - 1;
+    return KMG_OK;
+}
+
+extern "C" int kmg_dev_apply(kmg_processor *p, const uint8_t *d_rgba, uint32_t w, uint32_t rows, uint32_t row0,
+                             const float *c4, uint32_t k, int mode, uint8_t *d_out, void *stream)
+{
+    if (!p || !d_rgba || !d_out || !c4 || !w || !rows || k == 0)
+        return fail(KMG_ERR_INVALID_ARGUMENT, "bad apply arguments");
+    if (k > KMG_MAX_K) return fail(KMG_ERR_UNSUPPORTED, "k = %u exceeds KMG_MAX_K = %u", k, KMG_MAX_K);
+    if (mode == KMG_MODE_MELD) return fail(KMG_ERR_UNSUPPORTED, "ReduceMode::Meld is not implemented yet");
+    if (mode != KMG_MODE_REPLACE && mode != KMG_MODE_DITHER) return fail(KMG_ERR_INVALID_ARGUMENT, "unknown mode %d", mode);
+    HIP_TRY(hipSetDevice(p->device));
+
+    // per-centroid work on the host: (L,a,b,C) table, RGBA8 palette (lab_to_rgb.wgsl), threshold
+    std::vector<Centroid> hc(k);
+    std::vector<uint32_t> pal(k + 1);
+    for (uint32_t i = 0; i < k; ++i) {
+        hc[i].L = c4[4 * i]; hc[i].a = c4[4 * i + 1]; hc[i].b = c4[4 * i + 2];
+        hc[i].C = chroma(hc[i].a, hc[i].b);
+        uint8_t px[4];
+        shader_lab_to_rgba8(c4 + 4 * i, px);
+        memcpy(&pal[i], px, 4);
+    }
+    {
+        const float sentinel[3] = {10000.0f, 10000.0f, 10000.0f};     // mix_colors.wgsl:73
+        uint8_t px[4];
+        shader_lab_to_rgba8(sentinel, px);
+        memcpy(&pal[k], px, 4);
+    }
+    bool dither = (mode == KMG_MODE_DITHER) && k > 1;                 // mix_colors.wgsl:104-108
+    float thr = dither ? dither_threshold(c4, k) : 0.0f;
+
+    Centroid *d_cent = nullptr;
+    uint32_t *d_pal = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_cent, sizeof(Centroid) * k));
+    hipError_t e = hipMalloc((void **)&d_pal, sizeof(uint32_t) * (k + 1));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_cent, hc.data(), sizeof(Centroid) * k, hipMemcpyHostToDevice, S(stream));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_pal, pal.data(), sizeof(uint32_t) * (k + 1), hipMemcpyHostToDevice, S(stream));
+    if (e == hipSuccess)
+        e = launch_apply((const uint32_t *)d_rgba, w, rows, row0, d_cent, k, p->d_lut, d_pal, dither, thr,
+                         (uint32_t *)d_out, S(stream));
+    // the staging vectors and the two small device tables die with this call
+    hipError_t e2 = hipStreamSynchronize(S(stream));
+    (void)hipFree(d_cent);
+    if (d_pal) (void)hipFree(d_pal);
+    if (e != hipSuccess) return fail(KMG_ERR_HIP, "apply failed: %s", hipGetErrorString(e));
+    if (e2 != hipSuccess) return fail(KMG_ERR_HIP, "apply failed: %s", hipGetErrorString(e2));
+    return KMG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-buffer API (ImageProcessor::{palette, find, reduce})
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct DevBuf {
+    void *ptr = nullptr;
+    ~DevBuf() { if (ptr) (void)hipFree(ptr); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&ptr, bytes); }
+};
+
+struct StreamGuard {
+    hipStream_t st = nullptr;
+    ~StreamGuard() { if (st) (void)hipStreamDestroy(st); }
+};
+
+struct LloydGuard {
+    kmg_lloyd *s = nullptr;
+    ~LloydGuard() { kmg_lloyd_destroy(s); }
+};
+
+int check_image(const kmg_processor *p, const uint8_t *rgba, uint32_t w, uint32_t h)
+{
+    if (!p) return fail(KMG_ERR_INVALID_ARGUMENT, "processor is NULL");
+    if (!rgba) return fail(KMG_ERR_INVALID_ARGUMENT, "image pointer is NULL");
+    if (w == 0 || h == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "image has zero width or height");
+    if ((uint64_t)w * h > 0xFFFFFFFFull) return fail(KMG_ERR_UNSUPPORTED, "image has more than 2^32-1 pixels");
+    return KMG_OK;
+}
+
+// operations.rs:15-88 extract_palette_kmeans on a device-resident image -> host centroid table
+int extract_palette_kmeans(kmg_processor *p, const uint8_t *d_rgba, uint32_t w, uint32_t h, uint32_t k,
+                           hipStream_t st, float *c4)
+{
+    int rc;
+    const uint8_t *src = d_rgba;
+    uint32_t sw = w, sh = h;
+    DevBuf small;
+    const uint32_t m = p->opt.shrink_max_dim;
+    if (m && (w > m || h > m)) {                                       // structures.rs:67-74
+        kmg_resized_dims(w, h, m, &sw, &sh);
+        HIP_TRY(small.alloc((size_t)sw * sh * 4));
+        if ((rc = kmg_dev_resize(p, d_rgba, w, h, sw, sh, (uint8_t *)small.ptr, st)) != KMG_OK) return rc;
+        src = (const uint8_t *)small.ptr;
+    }
+    LloydGuard g;
+    if ((rc = kmg_lloyd_create(p, k, &g.s)) != KMG_OK) return rc;
+    if ((rc = kmg_lloyd_init_centroids(g.s, src, sw, sh, st)) != KMG_OK) return rc;   // operations.rs:73
+    if (log_debug()) {
+        std::vector<float> c(4 * k);
+        if (kmg_lloyd_get_centroids(g.s, c.data(), st) == KMG_OK) {
+            fprintf(stderr, "[kmeans_hip] == Initial centroids: ==\n");
+            for (uint32_t i = 0; i < k; ++i)
+                fprintf(stderr, "[kmeans_hip] Centroid %u = [%g, %g, %g, %g]\n", i, c[4 * i], c[4 * i + 1], c[4 * i + 2], c[4 * i + 3]);
+        }
+    }
+    uint32_t it = 0;
+    if ((rc = kmg_lloyd_run(g.s, src, (uint64_t)sw * sh, nullptr, &it, st)) != KMG_OK) return rc;  // operations.rs:85
+    if ((rc = kmg_lloyd_get_centroids(g.s, c4, st)) != KMG_OK) return rc;
+    if (log_debug()) {
+        fprintf(stderr, "[kmeans_hip] == Final centroids at iteration %u: ==\n", it);
+        for (uint32_t i = 0; i < k; ++i)
+            fprintf(stderr, "[kmeans_hip] Centroid %u = [%g, %g, %g, %g]\n", i, c4[4 * i], c4[4 * i + 1], c4[4 * i + 2], c4[4 * i + 3]);
+    }
+    return KMG_OK;
+}
+
+int upload_image(const uint8_t *rgba, uint32_t w, uint32_t h, hipStream_t st, DevBuf &buf)
+{
+    const size_t bytes = (size_t)w * h * 4;
+    HIP_TRY(buf.alloc(bytes));
+    HIP_TRY(hipMemcpyAsync(buf.ptr, rgba, bytes, hipMemcpyHostToDevice, st));   // structures.rs:31-65
+    return KMG_OK;
+}
+
+// find_colors / dither_colors + OutputTexture::pull_image (structures.rs:441-470)
+int apply_and_download(kmg_processor *p, const uint8_t *d_rgba, uint32_t w, uint32_t h, const float *c4,
+                       uint32_t k, int mode, hipStream_t st, uint8_t *out_rgba)
+{
+    int rc;
+    DevBuf out;
+    const size_t bytes = (size_t)w * h * 4;
+    HIP_TRY(out.alloc(bytes));
+    if ((rc = kmg_dev_apply(p, d_rgba, w, h, 0, c4, k, mode, (uint8_t *)out.ptr, st)) != KMG_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(out_rgba, out.ptr, bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return KMG_OK;
+}
+
+}  // namespace
+
+extern "C" int kmg_find(kmg_processor *p, const uint8_t *rgba, uint32_t w, uint32_t h, const uint8_t *palette_rgba,
+                        uint32_t n_colors, int mode, uint8_t *out_rgba)
+{
+    int rc;
+    if ((rc = check_image(p, rgba, w, h)) != KMG_OK) return rc;
+    if (!palette_rgba || n_colors == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "palette is empty");
+    if (!out_rgba) return fail(KMG_ERR_INVALID_ARGUMENT, "output pointer is NULL");
+    HIP_TRY(hipSetDevice(p->device));
+    StreamGuard sg;
+    HIP_TRY(hipStreamCreateWithFlags(&sg.st, hipStreamNonBlocking));
+    std::vector<float> c4(4 * (size_t)n_colors);
+    if ((rc = kmg_palette_to_centroids(palette_rgba, n_colors, c4.data())) != KMG_OK) return rc;  // lib.rs:86-87
+    DevBuf img;
+    if ((rc = upload_image(rgba, w, h, sg.st, img)) != KMG_OK) return rc;
+    return apply_and_download(p, (const uint8_t *)img.ptr, w, h, c4.data(), n_colors, mode, sg.st, out_rgba);
+}
+
+extern "C" int kmg_reduce(kmg_processor *p, const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t color_count,
+                          int algo, int mode, uint8_t *out_rgba)
+{
+    int rc;
+    if ((rc = check_image(p, rgba, w, h)) != KMG_OK) return rc;
+    if (color_count == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "k must be an integer higher than 0");
+    if (!out_rgba) return fail(KMG_ERR_INVALID_ARGUMENT, "output pointer is NULL");
+    if (algo == KMG_ALGO_OCTREE) return fail(KMG_ERR_UNSUPPORTED, "Algorithm::Octree is a CPU algorithm outside the accelerated path");
+    if (algo != KMG_ALGO_KMEANS) return fail(KMG_ERR_INVALID_ARGUMENT, "unknown algorithm %d", algo);
+    if (mode < KMG_MODE_REPLACE || mode > KMG_MODE_MELD) return fail(KMG_ERR_INVALID_ARGUMENT, "unknown mode %d", mode);
+    HIP_TRY(hipSetDevice(p->device));
+    StreamGuard sg;
+    HIP_TRY(hipStreamCreateWithFlags(&sg.st, hipStreamNonBlocking));
+    DevBuf img;
+    if ((rc = upload_image(rgba, w, h, sg.st, img)) != KMG_OK) return rc;
+    std::vector<float> c4(4 * (size_t)color_count);
+    if ((rc = extract_palette_kmeans(p, (const uint8_t *)img.ptr, w, h, color_count, sg.st, c4.data())) != KMG_OK) return rc;
+    return apply_and_download(p, (const uint8_t *)img.ptr, w, h, c4.data(), color_count, mode, sg.st, out_rgba);
+}
+
+extern "C" int kmg_palette(kmg_processor *p, const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t color_count,
+                           int algo, uint8_t *out_rgba, uint32_t *out_count)
+{
+    int rc;
+    if ((rc = check_image(p, rgba, w, h)) != KMG_OK) return rc;
+    if (color_count == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "k must be an integer higher than 0");
+    if (!out_rgba || !out_count) return fail(KMG_ERR_INVALID_ARGUMENT, "output pointer is NULL");
+    if (algo == KMG_ALGO_OCTREE) return fail(KMG_ERR_UNSUPPORTED, "Algorithm::Octree is a CPU algorithm outside the accelerated path");
+    if (algo != KMG_ALGO_KMEANS) return fail(KMG_ERR_INVALID_ARGUMENT, "unknown algorithm %d", algo);
+    HIP_TRY(hipSetDevice(p->device));
+    StreamGuard sg;
+    HIP_TRY(hipStreamCreateWithFlags(&sg.st, hipStreamNonBlocking));
+    DevBuf img;
+    if ((rc = upload_image(rgba, w, h, sg.st, img)) != KMG_OK) return rc;
+    std::vector<float> c4(4 * (size_t)color_count);
+    if ((rc = extract_palette_kmeans(p, (const uint8_t *)img.ptr, w, h, color_count, sg.st, c4.data())) != KMG_OK) return rc;
+    // lib.rs:255-286: pull_values (palette-crate Lab -> sRGB8) then sort ascending by Lab L
+    struct Entry { float L; uint8_t px[4]; };
+    std::vector<Entry> e(color_count);
+    for (uint32_t i = 0; i < color_count; ++i) {
+        uint8_t rgb[3];
+        float lab[3];
+        crate_lab_to_srgb8(&c4[4 * i], rgb);
+        e[i].px[0] = rgb[0]; e[i].px[1] = rgb[1]; e[i].px[2] = rgb[2]; e[i].px[3] = 255;
+        crate_srgb8_to_lab(rgb, lab);
+        e[i].L = lab[0];
+    }
+    std::stable_sort(e.begin(), e.end(), [](const Entry &a, const Entry &b) { return a.L < b.L; });
+    for (uint32_t i = 0; i < color_count; ++i) memcpy(out_rgba + 4 * i, e[i].px, 4);
+    *out_count = color_count;
+    return KMG_OK;
+}

@@ -1,0 +1,53 @@
+// kmg_kernels.h -- launchers of the gfx950 kernels (internal to libkmeans_hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace kmg {
+
+// Device centroid entry: (L, a, b, C = sqrt(a^2 + b^2)).  C is hoisted out of the per-pixel loop
+// (delta_e.wgsl:9 recomputes it for every pixel-centroid pair).
+struct alignas(16) Centroid { float L, a, b, C; };
+
+constexpr int kBlock = 256;          // threads per workgroup (4 waves of 64)
+constexpr int kPixelsPerThread = 4;  // one 16-byte RGBA8 load per thread
+constexpr int kTile = kBlock * kPixelsPerThread;
+
+// Number of workgroups the assign/accumulate pass uses for n pixels (also the number of rows of
+// the per-workgroup partial-sum slab).
+uint32_t assign_grid(uint64_t n_pixels);
+
+hipError_t launch_rgb_to_lab(const uint32_t *rgba, uint64_t n, const float *lut, float *lab3,
+                             hipStream_t st);
+
+// labels and/or partial sums.  partials: [assign_grid(n)][k][4] int64, fully overwritten.
+hipError_t launch_assign(const uint32_t *rgba, uint64_t n, const Centroid *cent, uint32_t k,
+                         const float *lut, uint32_t *labels, int64_t *partials, hipStream_t st);
+
+// acc[k][4] = sum over rows of partials
+hipError_t launch_reduce_partials(const int64_t *partials, uint32_t rows, uint32_t k,
+                                  int64_t *acc, hipStream_t st);
+
+// choose_centroid.wgsl `pick` for all k
+hipError_t launch_update(const int64_t *acc, uint32_t k, float convergence, Centroid *cent,
+                         uint32_t *n_converged, hipStream_t st);
+
+// farthest-point init
+hipError_t launch_init_first(const uint32_t *rgba, uint64_t index, const float *lut,
+                             Centroid *cent, unsigned long long *key, hipStream_t st);
+hipError_t launch_init_pass(const uint32_t *rgba, uint64_t n, const float *lut,
+                            const Centroid *cent, uint32_t j, float *dist,
+                            unsigned long long *key, hipStream_t st);
+hipError_t launch_init_pick(const uint32_t *rgba, const float *lut, unsigned long long *key,
+                            Centroid *cent, uint32_t j, hipStream_t st);
+
+hipError_t launch_resize(const uint32_t *rgba, uint32_t w, uint32_t h, uint32_t nw, uint32_t nh,
+                         uint32_t *out, hipStream_t st);
+
+// replace / dither output pass.  pal: k+1 RGBA8 words (entry k = the converted sentinel).
+hipError_t launch_apply(const uint32_t *rgba, uint32_t w, uint32_t rows, uint32_t row0,
+                        const Centroid *cent, uint32_t k, const float *lut, const uint32_t *pal,
+                        bool dither, float threshold, uint32_t *out, hipStream_t st);
+
+}  // namespace kmg

@@ -1,0 +1,506 @@
+// kmg_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the Lloyd hot path.
+//
+// Data layout in HBM
+//   pixels     : RGBA8, 4 B/px, row-major, read with one 16-byte load per thread (4 px)
+//   labels     : u32 per pixel (find_centroid.wgsl:43 writes an r32uint texel per pixel)
+//   centroids  : k x (L, a, b, C) f32 -- uniform across a wave, fetched with scalar loads
+//   partials   : [workgroup][k][4] int64 -- per-workgroup exact sums, no float atomics
+//   acc        : [k][4] int64
+// Lab is never materialised: every pass re-derives it from the 4-byte pixel (the sRGB decode is a
+// 256-entry LDS table), so a Lloyd iteration moves 4 B/px in and 4 B/px out.
+//
+// Compile with -ffp-contract=off: arithmetic must match kmg_math.h operation for operation.
+
+#include "kmg_kernels.h"
+#include "kmg_math.h"
+
+namespace kmg {
+
+namespace {
+
+__device__ __forceinline__ void px_to_lab(const float *s_lut, uint32_t px, float &L, float &a, float &b)
+{
+    linear100_to_lab(s_lut[px & 255u], s_lut[(px >> 8) & 255u], s_lut[(px >> 16) & 255u], L, a, b);
+}
+
+// 4 consecutive pixels of this thread; `full16` = all four in range and the address 16-B aligned.
+__device__ __forceinline__ void load4(const uint32_t *rgba, uint64_t i0, uint64_t n, bool aligned,
+                                      uint32_t px[4])
+{
+    if (aligned && i0 + 4 <= n) {
+        uint4 v = *reinterpret_cast<const uint4 *>(rgba + i0);
+        px[0] = v.x; px[1] = v.y; px[2] = v.z; px[3] = v.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) px[j] = (i0 + j < n) ? rgba[i0 + j] : 0u;
+    }
+}
+
+__device__ __forceinline__ void store4(uint32_t *out, uint64_t i0, uint64_t n, bool aligned,
+                                       const uint32_t v[4])
+{
+    if (aligned && i0 + 4 <= n) {
+        *reinterpret_cast<uint4 *>(out + i0) = make_uint4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (i0 + j < n) out[i0 + j] = v[j];
+    }
+}
+
+}  // namespace
+
+uint32_t assign_grid(uint64_t n)
+{
+    uint64_t tiles = (n + kTile - 1) / kTile;
+    if (tiles < 1) tiles = 1;
+    return (uint32_t)(tiles < 2048 ? tiles : 2048);
+}
+
+// ------------------------------------------------------------------------------------------
+// RGBA8 -> Lab  (rgb_to_lab.wgsl:66-80).  Only used by tests / callers that want Lab itself.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_rgb_to_lab(const uint32_t *__restrict__ rgba, uint64_t n,
+                                                       const float *__restrict__ lut,
+                                                       float *__restrict__ lab3)
+{
+    __shared__ float s_lut[256];
+    s_lut[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        float L, a, b;
+        px_to_lab(s_lut, rgba[i], L, a, b);
+        lab3[3 * i] = L; lab3[3 * i + 1] = a; lab3[3 * i + 2] = b;
+    }
+}
+
+hipError_t launch_rgb_to_lab(const uint32_t *rgba, uint64_t n, const float *lut, float *lab3,
+                             hipStream_t st)
+{
+    uint64_t blocks = (n + kBlock - 1) / kBlock;
+    uint32_t grid = (uint32_t)(blocks < 4096 ? (blocks ? blocks : 1) : 4096);
+    hipLaunchKernelGGL(k_rgb_to_lab, dim3(grid), dim3(kBlock), 0, st, rgba, n, lut, lab3);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// assign (+ accumulate): find_centroid.wgsl:15-44 fused with the masked sums of
+// choose_centroid.wgsl:97-104.  One workgroup = 4 waves; each thread owns 4 consecutive pixels
+// and walks the centroid table once (uniform index -> scalar loads, broadcast to the wave).
+// Sums go to per-workgroup int64 bins in LDS (ds_add_u64), flushed once per workgroup.
+// ------------------------------------------------------------------------------------------
+template <bool ACCUM>
+__global__ __launch_bounds__(kBlock) void k_assign(const uint32_t *__restrict__ rgba, uint64_t n,
+                                                   const Centroid *__restrict__ cent, uint32_t k,
+                                                   const float *__restrict__ lut,
+                                                   uint32_t *__restrict__ labels,
+                                                   int64_t *__restrict__ partials, int aligned)
+{
+    extern __shared__ unsigned long long smem[];
+    unsigned long long *bins = smem;                                   // [k][4] (ACCUM only)
+    float *s_lut = reinterpret_cast<float *>(smem + (ACCUM ? 4ull * k : 0ull));
+
+    s_lut[threadIdx.x] = lut[threadIdx.x];
+    if (ACCUM)
+        for (uint32_t i = threadIdx.x; i < 4 * k; i += kBlock) bins[i] = 0ull;
+    __syncthreads();
+
+    const uint64_t tiles = (n + kTile - 1) / kTile;
+    for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const uint64_t i0 = tile * kTile + (uint64_t)threadIdx.x * kPixelsPerThread;
+        uint32_t px[4];
+        load4(rgba, i0, n, aligned != 0, px);
+
+        float L[4], A[4], B[4];
+        PixelTerms pt[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            px_to_lab(s_lut, px[p], L[p], A[p], B[p]);
+            pt[p] = pixel_terms(L[p], A[p], B[p]);
+        }
+
+        // find_centroid.wgsl:29-41: min_distance = 100000.0 (squared here), found_index = 0,
+        // strict '<' so the first minimum wins.
+        float best[4];
+        uint32_t idx[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { best[p] = 1.0e10f; idx[p] = 0u; }
+
+#pragma unroll 2
+        for (uint32_t j = 0; j < k; ++j) {
+            const Centroid c = cent[j];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                float d = cie94_key(pt[p], c.L, c.a, c.b, c.C);
+                bool lt = d < best[p];
+                best[p] = lt ? d : best[p];
+                idx[p] = lt ? j : idx[p];
+            }
+        }
+
+        if (labels) store4(labels, i0, n, aligned != 0, idx);
+
+        if (ACCUM) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                if (i0 + p < n) {
+                    unsigned long long *bin = bins + 4ull * idx[p];
+                    atomicAdd(bin + 0, (unsigned long long)(long long)lab_fix(L[p]));
+                    atomicAdd(bin + 1, (unsigned long long)(long long)lab_fix(A[p]));
+                    atomicAdd(bin + 2, (unsigned long long)(long long)lab_fix(B[p]));
+                    atomicAdd(bin + 3, 1ull);
+                }
+            }
+        }
+    }
+
+    if (ACCUM) {
+        __syncthreads();
+        unsigned long long *row = reinterpret_cast<unsigned long long *>(partials) +
+                                  (uint64_t)blockIdx.x * 4ull * k;
+        for (uint32_t i = threadIdx.x; i < 4 * k; i += kBlock) row[i] = bins[i];
+    }
+}
+
+hipError_t launch_assign(const uint32_t *rgba, uint64_t n, const Centroid *cent, uint32_t k,
+                         const float *lut, uint32_t *labels, int64_t *partials, hipStream_t st)
+{
+    const uint32_t grid = assign_grid(n);
+    const int aligned = ((reinterpret_cast<uintptr_t>(rgba) & 15u) == 0 &&
+                         (labels == nullptr || (reinterpret_cast<uintptr_t>(labels) & 15u) == 0))
+                            ? 1 : 0;
+    if (partials) {
+        size_t lds = sizeof(unsigned long long) * 4ull * k + 256 * sizeof(float);
+        hipLaunchKernelGGL(k_assign<true>, dim3(grid), dim3(kBlock), lds, st, rgba, n, cent, k, lut,
+                           labels, partials, aligned);
+    } else {
+        hipLaunchKernelGGL(k_assign<false>, dim3(grid), dim3(kBlock), 256 * sizeof(float), st, rgba,
+                           n, cent, k, lut, labels, partials, aligned);
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// acc[c][0..3] = sum over workgroup rows of partials[row][c][0..3].  One workgroup per cluster.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_reduce_partials(const int64_t *__restrict__ partials,
+                                                            uint32_t rows, uint32_t k,
+                                                            int64_t *__restrict__ acc)
+{
+    __shared__ long long s[4][kBlock / 64];
+    const uint32_t c = blockIdx.x;
+    long long v[4] = {0, 0, 0, 0};
+    for (uint32_t r = threadIdx.x; r < rows; r += kBlock) {
+        const long long *src = reinterpret_cast<const long long *>(partials) + ((uint64_t)r * k + c) * 4ull;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += src[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        for (int off = 32; off > 0; off >>= 1) v[j] += __shfl_down(v[j], off, 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0)
+        for (int j = 0; j < 4; ++j) s[j][wave] = v[j];
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        long long t = 0;
+        for (int w = 0; w < kBlock / 64; ++w) t += s[threadIdx.x][w];
+        acc[4ull * c + threadIdx.x] = t;
+    }
+}
+
+hipError_t launch_reduce_partials(const int64_t *partials, uint32_t rows, uint32_t k, int64_t *acc,
+                                  hipStream_t st)
+{
+    hipLaunchKernelGGL(k_reduce_partials, dim3(k), dim3(kBlock), 0, st, partials, rows, k, acc);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// choose_centroid.wgsl:180-206 `pick`, all clusters in one launch.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_update(const int64_t *__restrict__ acc, uint32_t k,
+                                                   float convergence, Centroid *__restrict__ cent,
+                                                   uint32_t *__restrict__ n_converged)
+{
+    __shared__ uint32_t s_count;
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (uint32_t c = threadIdx.x; c < k; c += kBlock) {
+        const long long count = acc[4ull * c + 3];
+        if (count > 0) {                                         // :185
+            float nw[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                double mean = ((double)acc[4ull * c + j] / (double)count) * (1.0 / 1048576.0);
+                nw[j] = (float)mean;                             // :186
+            }
+            const Centroid prev = cent[c];
+            Centroid nc;
+            nc.L = nw[0]; nc.a = nw[1]; nc.b = nw[2]; nc.C = chroma(nw[1], nw[2]);
+            cent[c] = nc;
+            // :191 distance_cie94(new, previous) < settings.convergence
+            if (cie94(nw[0], nw[1], nw[2], prev.L, prev.a, prev.b) < convergence) mine += 1;
+        }                                                        // :192-194 empty: unchanged, 0
+    }
+    if (mine) atomicAdd(&s_count, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) *n_converged = s_count;                // :196-202
+}
+
+hipError_t launch_update(const int64_t *acc, uint32_t k, float convergence, Centroid *cent,
+                         uint32_t *n_converged, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_update, dim3(1), dim3(kBlock), 0, st, acc, k, convergence, cent, n_converged);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Farthest-point init (plus_plus_init.wgsl, kmeans++_calc_diff.wgsl).
+// The arg-max tie rule of the reference's scan (earliest maximum inside a thread's 16 pixels,
+// latest thread across threads) is encoded in a 64-bit key whose maximum is the winner:
+//   [ distance bits : 32 ][ index / 16 : 28 ][ 15 - index % 16 : 4 ]
+// A key whose distance is 0 means "every distance was 0" -> Candidate(0, 0.0) -> index 0.
+// ------------------------------------------------------------------------------------------
+__global__ void k_init_first(const uint32_t *__restrict__ rgba, uint64_t index,
+                             const float *__restrict__ lut, Centroid *__restrict__ cent,
+                             unsigned long long *__restrict__ key)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        // plus_plus_init.wgsl:161-168 `initial`
+        uint32_t px = rgba[index];
+        float L, a, b;
+        linear100_to_lab(lut[px & 255u], lut[(px >> 8) & 255u], lut[(px >> 16) & 255u], L, a, b);
+        Centroid c; c.L = L; c.a = a; c.b = b; c.C = chroma(a, b);
+        cent[0] = c;
+        *key = 0ull;
+    }
+}
+
+hipError_t launch_init_first(const uint32_t *rgba, uint64_t index, const float *lut, Centroid *cent,
+                             unsigned long long *key, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_init_first, dim3(1), dim3(64), 0, st, rgba, index, lut, cent, key);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(kBlock) void k_init_pass(const uint32_t *__restrict__ rgba, uint64_t n,
+                                                      const float *__restrict__ lut,
+                                                      const Centroid *__restrict__ cent, uint32_t j,
+                                                      float *__restrict__ dist,
+                                                      unsigned long long *__restrict__ key)
+{
+    __shared__ float s_lut[256];
+    __shared__ unsigned long long s_key[kBlock / 64];
+    s_lut[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    const Centroid c = cent[j - 1];
+    unsigned long long best = 0ull;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        float L, a, b;
+        px_to_lab(s_lut, rgba[i], L, a, b);
+        // kmeans++_calc_diff.wgsl:26-30; the running minimum equals the recomputed one
+        float d = cie94(L, a, b, c.L, c.a, c.b);
+        float m = fminf(j == 1 ? 1000000.0f : dist[i], d);
+        dist[i] = m;
+        unsigned long long kk = ((unsigned long long)float_to_bits(m) << 32) |
+                                (unsigned long long)(((uint32_t)(i >> 4) << 4) | (15u - (uint32_t)(i & 15u)));
+        best = kk > best ? kk : best;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned long long o = __shfl_down(best, off, 64);
+        best = o > best ? o : best;
+    }
+    if ((threadIdx.x & 63) == 0) s_key[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; ++w) best = s_key[w] > best ? s_key[w] : best;
+        atomicMax(key, best);
+    }
+}
+
+hipError_t launch_init_pass(const uint32_t *rgba, uint64_t n, const float *lut, const Centroid *cent,
+                            uint32_t j, float *dist, unsigned long long *key, hipStream_t st)
+{
+    uint64_t blocks = (n + kBlock - 1) / kBlock;
+    uint32_t grid = (uint32_t)(blocks < 2048 ? (blocks ? blocks : 1) : 2048);
+    hipLaunchKernelGGL(k_init_pass, dim3(grid), dim3(kBlock), 0, st, rgba, n, lut, cent, j, dist, key);
+    return hipGetLastError();
+}
+
+__global__ void k_init_pick(const uint32_t *__restrict__ rgba, const float *__restrict__ lut,
+                            unsigned long long *__restrict__ key, Centroid *__restrict__ cent,
+                            uint32_t j)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        // plus_plus_init.wgsl:172-181 `pick`
+        const unsigned long long kk = *key;
+        uint32_t index = 0;
+        if ((kk >> 32) != 0ull) {
+            uint32_t low = (uint32_t)kk;
+            index = (low & ~15u) | (15u - (low & 15u));
+        }
+        uint32_t px = rgba[index];
+        float L, a, b;
+        linear100_to_lab(lut[px & 255u], lut[(px >> 8) & 255u], lut[(px >> 16) & 255u], L, a, b);
+        Centroid c; c.L = L; c.a = a; c.b = b; c.C = chroma(a, b);
+        cent[j] = c;
+        *key = 0ull;
+    }
+}
+
+hipError_t launch_init_pick(const uint32_t *rgba, const float *lut, unsigned long long *key,
+                            Centroid *cent, uint32_t j, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_init_pick, dim3(1), dim3(64), 0, st, rgba, lut, key, cent, j);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Bilinear shrink (resize.wgsl:7-18 + the sampler of structures.rs:121-131): uv = gid / dims,
+// clamp-to-edge, linear filter with exact f32 weights, x first then y, rgba8unorm store.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t unorm8(float v)
+{
+    v = v > 0.0f ? v : 0.0f;
+    v = v > 1.0f ? 1.0f : v;
+    return (uint32_t)rintf(v * 255.0f);
+}
+
+__global__ __launch_bounds__(kBlock) void k_resize(const uint32_t *__restrict__ rgba, uint32_t w,
+                                                   uint32_t h, uint32_t nw, uint32_t nh,
+                                                   uint32_t *__restrict__ out)
+{
+    const uint64_t total = (uint64_t)nw * nh;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += stride) {
+        const uint32_t gx = (uint32_t)(i % nw), gy = (uint32_t)(i / nw);
+        const float u = (float)gx / (float)nw, v = (float)gy / (float)nh;
+        const float tx = u * (float)w - 0.5f, ty = v * (float)h - 0.5f;
+        const float fx0 = floorf(tx), fy0 = floorf(ty);
+        const float wx = tx - fx0, wy = ty - fy0;
+        long long x0 = (long long)fx0, y0 = (long long)fy0;
+        long long x1 = x0 + 1, y1 = y0 + 1;
+        x0 = x0 < 0 ? 0 : (x0 > (long long)w - 1 ? (long long)w - 1 : x0);
+        x1 = x1 < 0 ? 0 : (x1 > (long long)w - 1 ? (long long)w - 1 : x1);
+        y0 = y0 < 0 ? 0 : (y0 > (long long)h - 1 ? (long long)h - 1 : y0);
+        y1 = y1 < 0 ? 0 : (y1 > (long long)h - 1 ? (long long)h - 1 : y1);
+        const uint32_t p00 = rgba[(uint64_t)y0 * w + x0], p10 = rgba[(uint64_t)y0 * w + x1];
+        const uint32_t p01 = rgba[(uint64_t)y1 * w + x0], p11 = rgba[(uint64_t)y1 * w + x1];
+        uint32_t o = 0;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            const float t00 = (float)((p00 >> (8 * ch)) & 255u) / 255.0f;
+            const float t10 = (float)((p10 >> (8 * ch)) & 255u) / 255.0f;
+            const float t01 = (float)((p01 >> (8 * ch)) & 255u) / 255.0f;
+            const float t11 = (float)((p11 >> (8 * ch)) & 255u) / 255.0f;
+            const float top = fmaf(wx, t10 - t00, t00);
+            const float bot = fmaf(wx, t11 - t01, t01);
+            o |= unorm8(fmaf(wy, bot - top, top)) << (8 * ch);
+        }
+        out[i] = o;
+    }
+}
+
+hipError_t launch_resize(const uint32_t *rgba, uint32_t w, uint32_t h, uint32_t nw, uint32_t nh,
+                         uint32_t *out, hipStream_t st)
+{
+    uint64_t blocks = ((uint64_t)nw * nh + kBlock - 1) / kBlock;
+    uint32_t grid = (uint32_t)(blocks < 4096 ? (blocks ? blocks : 1) : 4096);
+    hipLaunchKernelGGL(k_resize, dim3(grid), dim3(kBlock), 0, st, rgba, w, h, nw, nh, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Output pass at full resolution: find_centroid + swap + lab_to_rgb (replace), or
+// mix_colors.wgsl main_dither + lab_to_rgb (dither).  Only k (+1 sentinel) distinct output colours
+// exist, so the Lab->sRGB8 conversion is done once per centroid on the host (pal[]).
+// ------------------------------------------------------------------------------------------
+__constant__ const float c_bayer[16] = {0, 8, 2, 10, 12, 4, 14, 6, 3, 11, 1, 9, 15, 7, 13, 5};
+
+template <bool DITHER>
+__global__ __launch_bounds__(kBlock) void k_apply(const uint32_t *__restrict__ rgba, uint32_t w,
+                                                  uint64_t n, uint32_t row0,
+                                                  const Centroid *__restrict__ cent, uint32_t k,
+                                                  const float *__restrict__ lut,
+                                                  const uint32_t *__restrict__ pal, float threshold,
+                                                  uint32_t *__restrict__ out, int aligned)
+{
+    __shared__ float s_lut[256];
+    __shared__ float s_off[16];
+    s_lut[threadIdx.x] = lut[threadIdx.x];
+    if (DITHER && threadIdx.x < 16) {
+        // mix_colors.wgsl:21-27,70,72: threshold * (M[x%4 + 4*(y%4)] / 16 - 0.5)
+        float iv = c_bayer[threadIdx.x] / 16.0f - 0.5f;
+        s_off[threadIdx.x] = threshold * iv;
+    }
+    __syncthreads();
+
+    const uint64_t tiles = (n + kTile - 1) / kTile;
+    for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const uint64_t i0 = tile * kTile + (uint64_t)threadIdx.x * kPixelsPerThread;
+        uint32_t px[4];
+        load4(rgba, i0, n, aligned != 0, px);
+
+        PixelTerms pt[4];
+        float best[4];
+        uint32_t idx[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            float L, a, b;
+            px_to_lab(s_lut, px[p], L, a, b);
+            if (DITHER) {
+                const uint64_t i = i0 + p;
+                const uint32_t x = (uint32_t)(i % w), y = row0 + (uint32_t)(i / w);
+                const float off = s_off[(x & 3u) + ((y & 3u) << 2)];
+                L = L + off; a = a + off; b = b + off;             // :72
+            }
+            pt[p] = pixel_terms(L, a, b);
+            if (DITHER) {
+                // :73 closest = vec3(10000.0): running minimum starts at the sentinel's distance
+                best[p] = cie94_key(pt[p], 10000.0f, 10000.0f, 10000.0f, chroma(10000.0f, 10000.0f));
+                idx[p] = k;
+            } else {
+                best[p] = 1.0e10f;
+                idx[p] = 0u;
+            }
+        }
+#pragma unroll 2
+        for (uint32_t j = 0; j < k; ++j) {
+            const Centroid c = cent[j];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                float d = cie94_key(pt[p], c.L, c.a, c.b, c.C);
+                bool lt = d < best[p];
+                best[p] = lt ? d : best[p];
+                idx[p] = lt ? j : idx[p];
+            }
+        }
+        uint32_t o[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) o[p] = pal[idx[p]];
+        store4(out, i0, n, aligned != 0, o);
+    }
+}
+
+hipError_t launch_apply(const uint32_t *rgba, uint32_t w, uint32_t rows, uint32_t row0,
+                        const Centroid *cent, uint32_t k, const float *lut, const uint32_t *pal,
+                        bool dither, float threshold, uint32_t *out, hipStream_t st)
+{
+    const uint64_t n = (uint64_t)w * rows;
+    const uint32_t grid = assign_grid(n);
+    const int aligned = ((reinterpret_cast<uintptr_t>(rgba) & 15u) == 0 &&
+                         (reinterpret_cast<uintptr_t>(out) & 15u) == 0) ? 1 : 0;
+    if (dither)
+        hipLaunchKernelGGL(k_apply<true>, dim3(grid), dim3(kBlock), 0, st, rgba, w, n, row0, cent, k,
+                           lut, pal, threshold, out, aligned);
+    else
+        hipLaunchKernelGGL(k_apply<false>, dim3(grid), dim3(kBlock), 0, st, rgba, w, n, row0, cent, k,
+                           lut, pal, threshold, out, aligned);
+    return hipGetLastError();
+}
+
+}  // namespace kmg

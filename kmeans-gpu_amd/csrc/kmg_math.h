@@ -1,0 +1,119 @@
+// kmg_math.h -- scalar colour arithmetic shared by the gfx950 kernels and the (O(k)) host
+// control code of libkmeans_hip.  Every function states the IEEE-754 binary32 operation order;
+// translation units including this header MUST be compiled with -ffp-contract=off so that the
+// only fused operations are the explicit fmaf()/fma() calls.
+//
+// References (relative to the reference repository):
+//   core/shaders/converters/rgb_to_lab.wgsl, core/shaders/functions/delta_e.wgsl
+#pragma once
+
+#include <stdint.h>
+#include <math.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define KMG_HD __host__ __device__ __forceinline__
+#else
+#define KMG_HD inline
+#endif
+
+#define KMG_FIX_SCALE 1048576.0f   // 2^20, see include/kmeans_hip.h KMG_FIX_SHIFT
+
+namespace kmg {
+
+KMG_HD float bits_to_float(uint32_t u) { union { uint32_t u; float f; } c; c.u = u; return c.f; }
+KMG_HD uint32_t float_to_bits(float f) { union { uint32_t u; float f; } c; c.f = f; return c.u; }
+
+// Correctly rounded binary32 cube root for x in [1e-3, 2] (exhaustively verified against
+// libm on that range, tests/test_host_math.py; the Lab conversion only feeds it
+// t in (0.008856, 1.01]).  rgb_to_lab.wgsl:45,50,55 `pow(t, 1.0/3.0)`.
+//   1. r ~ x^(-1/3): bit-level seed, three Newton steps r <- r*(4/3 - (x/3) r^3) in f32
+//   2. y0 = x r^2, g = r^2/3 ~ 1/(3 y^2)
+//   3. two Newton steps y <- y + (x - y^3) g in f64, round once to f32
+KMG_HD float cbrt_cr(float x)
+{
+    uint32_t ir = 0x54A21D2Au - float_to_bits(x) / 3u;
+    float r = bits_to_float(ir);
+    float xt = x * 0.33333334f;
+    for (int i = 0; i < 3; ++i) {
+        float r3 = r * r * r;
+        r = r * fmaf(-xt, r3, 1.3333334f);
+    }
+    float rr = r * r;
+    double yd = (double)(x * rr);
+    double gd = (double)(rr * 0.33333334f);
+    double xd = (double)x;
+    for (int i = 0; i < 2; ++i) {
+        double res = fma(-yd * yd, yd, xd);
+        yd = fma(res, gd, yd);
+    }
+    return (float)yd;
+}
+
+// rgb_to_lab.wgsl:44-58
+KMG_HD float lab_f(float t)
+{
+    return t > 0.008856f ? cbrt_cr(t) : fmaf(7.787f, t, 16.0f / 116.0f);
+}
+
+// rgb_to_lab.wgsl:11-64.  r,g,b are the (sRGB-decoded * 100) table values of the three bytes.
+KMG_HD void linear100_to_lab(float r, float g, float b, float &L, float &A, float &B)
+{
+    float X = fmaf(0.1804375f, b, fmaf(0.3575761f, g, 0.4124564f * r));
+    float Y = fmaf(0.0721750f, b, fmaf(0.7151522f, g, 0.2126729f * r));
+    float Z = fmaf(0.9503041f, b, fmaf(0.1191920f, g, 0.0193339f * r));
+    float fx = lab_f(X / 95.0489f);
+    float fy = lab_f(Y / 100.0f);
+    float fz = lab_f(Z / 108.8840f);
+    L = fmaf(116.0f, fy, -16.0f);
+    A = 500.0f * (fx - fy);
+    B = 200.0f * (fy - fz);
+}
+
+// delta_e.wgsl:8-9
+KMG_HD float chroma(float a, float b) { return sqrtf(a * a + b * b); }
+
+// delta_e.wgsl:1-22, literal form (no fused operations).  Asymmetric in its arguments.
+KMG_HD float cie94(float L1, float a1, float b1, float L2, float a2, float b2)
+{
+    float dL = L1 - L2, da = a1 - a2, db = b1 - b2;
+    float C1 = chroma(a1, b1);
+    float C2 = chroma(a2, b2);
+    float dC = C1 - C2;
+    float dH = sqrtf(fmaxf((da * da) + (db * db) - (dC * dC), 0.0f));
+    float SC = 1.0f + 0.045f * C1;
+    float SH = 1.0f + 0.015f * C1;
+    float tL = dL / 1.0f, tC = dC / SC, tH = dH / SH;
+    return sqrtf(tL * tL + tC * tC + tH * tH);
+}
+
+// Per-pixel terms of the arg-min key (hoisted out of the centroid loop).
+struct PixelTerms { float L, a, b, C, wC, wH; };
+
+KMG_HD PixelTerms pixel_terms(float L, float a, float b)
+{
+    PixelTerms p;
+    p.L = L; p.a = a; p.b = b;
+    p.C = chroma(a, b);
+    float SC = 1.0f + 0.045f * p.C;
+    float SH = 1.0f + 0.015f * p.C;
+    float iSC = 1.0f / SC, iSH = 1.0f / SH;
+    p.wC = iSC * iSC;
+    p.wH = iSH * iSH;
+    return p;
+}
+
+// Squared CIE94 used only for ordering: dL^2 + dC^2 wC + max(da^2 + db^2 - dC^2, 0) wH.
+KMG_HD float cie94_key(const PixelTerms &p, float L2, float a2, float b2, float C2)
+{
+    float dL = p.L - L2, da = p.a - a2, db = p.b - b2, dC = p.C - C2;
+    float dC2 = dC * dC;
+    float t = fmaf(db, db, da * da);
+    float h = fmaxf(t - dC2, 0.0f);
+    return fmaf(h, p.wH, fmaf(dC2, p.wC, dL * dL));
+}
+
+// Lab -> fixed point for the exact integer accumulators.
+KMG_HD int32_t lab_fix(float x) { return (int32_t)rintf(x * KMG_FIX_SCALE); }
+
+}  // namespace kmg

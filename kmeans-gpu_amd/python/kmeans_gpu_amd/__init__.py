@@ -1,0 +1,295 @@
+"""kmeans_gpu_amd -- Python host binding of libkmeans_hip.so (ctypes over the C ABI of
+include/kmeans_hip.h).
+
+It mirrors the reference crate's public surface (core/src/lib.rs:24-165):
+
+    ImageProcessor().palette(color_count, image, algo)  -> list of RGBA8
+    ImageProcessor().find(image, colors, reduce_mode)   -> image
+    ImageProcessor().reduce(color_count, image, algo, reduce_mode) -> image
+
+Images are numpy uint8 arrays of shape (height, width, 4) (tightly packed RGBA8,
+core/src/image.rs:20-48).  `Lloyd` exposes the device-pointer building blocks used by the
+sharded (one process per GPU) driver in `kmeans_gpu_amd.sharded` and by bench.py; PyTorch only
+supplies device memory, streams and torch.distributed there.
+
+There is no CPU fallback: if the shared library is missing or no HIP device is usable, the
+constructors raise.
+"""
+import ctypes as C
+import enum
+import os
+
+import numpy as np
+
+__all__ = ["ImageProcessor", "Algorithm", "ReduceMode", "Lloyd", "KmgError", "lib", "library_path",
+           "resized_dims", "palette_to_centroids", "centroids_to_palette", "dither_threshold",
+           "default_options", "Options"]
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PKG_ROOT = os.path.dirname(os.path.dirname(_HERE))          # .../kmeans-gpu_amd
+_LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libkmeans_hip.so")
+
+
+class KmgError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"kmeans_hip error {status}: {message}")
+        self.status = status
+
+
+class Algorithm(enum.IntEnum):          # core/src/lib.rs:215-219
+    Kmeans = 0
+    Octree = 1
+
+
+class ReduceMode(enum.IntEnum):         # core/src/lib.rs:234-239
+    Replace = 0
+    Dither = 1
+    Meld = 2
+
+
+class Options(C.Structure):             # include/kmeans_hip.h kmg_options
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("shrink_max_dim", C.c_uint32),
+                ("max_iterations", C.c_uint32), ("check_period", C.c_uint32), ("convergence", C.c_float)]
+
+
+def library_path():
+    return _LIB_PATH
+
+
+_lib = None
+
+# every symbol include/kmeans_hip.h declares
+SYMBOLS = [
+    "kmg_last_error", "kmg_version", "kmg_default_options", "kmg_processor_create",
+    "kmg_processor_create_ex", "kmg_processor_destroy", "kmg_palette", "kmg_find", "kmg_reduce",
+    "kmg_palette_to_centroids", "kmg_centroids_to_palette", "kmg_dev_rgb_to_lab", "kmg_resized_dims",
+    "kmg_dev_resize", "kmg_lloyd_create", "kmg_lloyd_destroy", "kmg_lloyd_set_centroids",
+    "kmg_lloyd_get_centroids", "kmg_lloyd_init_centroids", "kmg_lloyd_assign_accumulate",
+    "kmg_lloyd_update", "kmg_lloyd_converged_count", "kmg_lloyd_run", "kmg_dev_apply",
+    "kmg_dither_threshold",
+]
+
+
+def lib():
+    """Load libkmeans_hip.so (built in-tree by `make -C kmeans-gpu_amd`).  Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError(f"{_LIB_PATH} not found: build it with `make -C {_PKG_ROOT}` "
+                          "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+                          "There is no fallback implementation.")
+    L = C.CDLL(_LIB_PATH)
+    vp, u8p, u32p, f32p, i64p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
+    L.kmg_last_error.restype = C.c_char_p
+    L.kmg_version.restype = C.c_char_p
+    L.kmg_default_options.argtypes = [C.POINTER(Options)]
+    L.kmg_default_options.restype = None
+    L.kmg_processor_create.argtypes = [C.POINTER(vp)]
+    L.kmg_processor_create_ex.argtypes = [C.POINTER(Options), C.POINTER(vp)]
+    L.kmg_processor_destroy.argtypes = [vp]
+    L.kmg_processor_destroy.restype = None
+    L.kmg_palette.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, u8p, C.POINTER(C.c_uint32)]
+    L.kmg_find.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, u8p, C.c_uint32, C.c_int, u8p]
+    L.kmg_reduce.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, u8p]
+    L.kmg_palette_to_centroids.argtypes = [u8p, C.c_uint32, f32p]
+    L.kmg_centroids_to_palette.argtypes = [f32p, C.c_uint32, u8p]
+    L.kmg_dev_rgb_to_lab.argtypes = [vp, u8p, C.c_uint64, f32p, vp]
+    L.kmg_resized_dims.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.kmg_resized_dims.restype = None
+    L.kmg_dev_resize.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u8p, vp]
+    L.kmg_lloyd_create.argtypes = [vp, C.c_uint32, C.POINTER(vp)]
+    L.kmg_lloyd_destroy.argtypes = [vp]
+    L.kmg_lloyd_destroy.restype = None
+    L.kmg_lloyd_set_centroids.argtypes = [vp, f32p, vp]
+    L.kmg_lloyd_get_centroids.argtypes = [vp, f32p, vp]
+    L.kmg_lloyd_init_centroids.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, vp]
+    L.kmg_lloyd_assign_accumulate.argtypes = [vp, u8p, C.c_uint64, u32p, i64p, vp]
+    L.kmg_lloyd_update.argtypes = [vp, i64p, vp]
+    L.kmg_lloyd_converged_count.argtypes = [vp, C.POINTER(C.c_uint32), vp]
+    L.kmg_lloyd_run.argtypes = [vp, u8p, C.c_uint64, u32p, C.POINTER(C.c_uint32), vp]
+    L.kmg_dev_apply.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, C.c_uint32, f32p, C.c_uint32, C.c_int, u8p, vp]
+    L.kmg_dither_threshold.argtypes = [f32p, C.c_uint32, C.POINTER(C.c_float)]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise KmgError(rc, lib().kmg_last_error().decode("utf-8", "replace"))
+
+
+def _np_ptr(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+def default_options():
+    o = Options()
+    lib().kmg_default_options(C.byref(o))
+    return o
+
+
+def resized_dims(width, height, max_size=256):
+    """InputTexture::resized dimension rule (core/src/structures.rs:79-89)."""
+    nw, nh = C.c_uint32(), C.c_uint32()
+    lib().kmg_resized_dims(width, height, max_size, C.byref(nw), C.byref(nh))
+    return nw.value, nh.value
+
+
+def palette_to_centroids(colors):
+    """CentroidsBuffer::fixed_centroids (core/src/structures.rs:523-553): RGBA8 -> (L,a,b,1)."""
+    pal = np.ascontiguousarray(colors, np.uint8).reshape(-1, 4)
+    out = np.empty((pal.shape[0], 4), np.float32)
+    _check(lib().kmg_palette_to_centroids(_np_ptr(pal), pal.shape[0], _np_ptr(out)))
+    return out
+
+
+def centroids_to_palette(centroids4):
+    """CentroidsBuffer::pull_values (core/src/structures.rs:581-617)."""
+    c = np.ascontiguousarray(centroids4, np.float32).reshape(-1, 4)
+    out = np.empty((c.shape[0], 4), np.uint8)
+    _check(lib().kmg_centroids_to_palette(_np_ptr(c), c.shape[0], _np_ptr(out)))
+    return out
+
+
+def dither_threshold(centroids4):
+    c = np.ascontiguousarray(centroids4, np.float32).reshape(-1, 4)
+    t = C.c_float()
+    _check(lib().kmg_dither_threshold(_np_ptr(c), c.shape[0], C.byref(t)))
+    return t.value
+
+
+def _image(image):
+    a = np.ascontiguousarray(image, dtype=np.uint8)
+    if a.ndim != 3 or a.shape[2] != 4:
+        raise ValueError("image must be a (height, width, 4) uint8 RGBA array")
+    return a
+
+
+class ImageProcessor:
+    """Mirror of `kmeans_color_gpu::ImageProcessor` (core/src/lib.rs:24-165)."""
+
+    def __init__(self, device=-1, shrink_max_dim=256, max_iterations=128, check_period=8,
+                 convergence=1.0):
+        self._h = C.c_void_p()
+        o = default_options()
+        o.device = device
+        o.shrink_max_dim = shrink_max_dim
+        o.max_iterations = max_iterations
+        o.check_period = check_period
+        o.convergence = convergence
+        _check(lib().kmg_processor_create_ex(C.byref(o), C.byref(self._h)))
+        self.options = o
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().kmg_processor_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def handle(self):
+        return self._h
+
+    # lib.rs:67-77
+    def palette(self, color_count, image, algo=Algorithm.Kmeans):
+        img = _image(image)
+        h, w = img.shape[:2]
+        out = np.empty((max(int(color_count), 1), 4), np.uint8)
+        cnt = C.c_uint32()
+        _check(lib().kmg_palette(self._h, _np_ptr(img), w, h, int(color_count), int(algo), _np_ptr(out), C.byref(cnt)))
+        return out[:cnt.value].copy()
+
+    # lib.rs:79-114
+    def find(self, image, colors, reduce_mode=ReduceMode.Replace):
+        img = _image(image)
+        h, w = img.shape[:2]
+        pal = np.ascontiguousarray(colors, np.uint8).reshape(-1, 4)
+        out = np.empty_like(img)
+        _check(lib().kmg_find(self._h, _np_ptr(img), w, h, _np_ptr(pal), pal.shape[0], int(reduce_mode), _np_ptr(out)))
+        return out
+
+    # lib.rs:116-164
+    def reduce(self, color_count, image, algo=Algorithm.Kmeans, reduce_mode=ReduceMode.Replace):
+        img = _image(image)
+        h, w = img.shape[:2]
+        out = np.empty_like(img)
+        _check(lib().kmg_reduce(self._h, _np_ptr(img), w, h, int(color_count), int(algo), int(reduce_mode), _np_ptr(out)))
+        return out
+
+    # ---- device-pointer helpers (torch tensors supply the memory) -------------------------
+    def rgb_to_lab(self, d_rgba, n_pixels, d_lab3, stream=0):
+        _check(lib().kmg_dev_rgb_to_lab(self._h, C.c_void_p(d_rgba), n_pixels, C.c_void_p(d_lab3), C.c_void_p(stream)))
+
+    def resize(self, d_rgba, width, height, new_width, new_height, d_out, stream=0):
+        _check(lib().kmg_dev_resize(self._h, C.c_void_p(d_rgba), width, height, new_width, new_height,
+                                    C.c_void_p(d_out), C.c_void_p(stream)))
+
+    def apply(self, d_rgba, width, rows, row0, centroids4, mode, d_out, stream=0):
+        c = np.ascontiguousarray(centroids4, np.float32).reshape(-1, 4)
+        _check(lib().kmg_dev_apply(self._h, C.c_void_p(d_rgba), width, rows, row0, _np_ptr(c), c.shape[0],
+                                   int(mode), C.c_void_p(d_out), C.c_void_p(stream)))
+
+
+class Lloyd:
+    """One Lloyd problem (an image or a row band of it) on one device: kmg_lloyd_* of the C ABI.
+    Pointers are raw device addresses (e.g. torch.Tensor.data_ptr()); `stream` a hipStream_t."""
+
+    def __init__(self, processor, k):
+        self._p = processor
+        self.k = int(k)
+        self._h = C.c_void_p()
+        _check(lib().kmg_lloyd_create(processor.handle, self.k, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().kmg_lloyd_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_centroids(self, centroids4, stream=0):
+        c = np.ascontiguousarray(centroids4, np.float32).reshape(self.k, 4)
+        _check(lib().kmg_lloyd_set_centroids(self._h, _np_ptr(c), C.c_void_p(stream)))
+
+    def get_centroids(self, stream=0):
+        out = np.empty((self.k, 4), np.float32)
+        _check(lib().kmg_lloyd_get_centroids(self._h, _np_ptr(out), C.c_void_p(stream)))
+        return out
+
+    def init_centroids(self, d_rgba, width, height, stream=0):
+        _check(lib().kmg_lloyd_init_centroids(self._h, C.c_void_p(d_rgba), width, height, C.c_void_p(stream)))
+
+    def assign_accumulate(self, d_rgba, n_pixels, d_labels, d_acc4, stream=0):
+        _check(lib().kmg_lloyd_assign_accumulate(self._h, C.c_void_p(d_rgba), n_pixels,
+                                                 C.c_void_p(d_labels or None), C.c_void_p(d_acc4 or None),
+                                                 C.c_void_p(stream)))
+
+    def update(self, d_acc4, stream=0):
+        _check(lib().kmg_lloyd_update(self._h, C.c_void_p(d_acc4), C.c_void_p(stream)))
+
+    def converged_count(self, stream=0):
+        n = C.c_uint32()
+        _check(lib().kmg_lloyd_converged_count(self._h, C.byref(n), C.c_void_p(stream)))
+        return n.value
+
+    def run(self, d_rgba, n_pixels, d_labels=0, stream=0):
+        it = C.c_uint32()
+        _check(lib().kmg_lloyd_run(self._h, C.c_void_p(d_rgba), n_pixels, C.c_void_p(d_labels or None),
+                                   C.byref(it), C.c_void_p(stream)))
+        return it.value

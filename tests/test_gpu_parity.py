@@ -1,0 +1,202 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+Integer outputs (labels, accumulators, RGBA8) must be bit-exact; centroids are compared
+bit-exactly as well because the sums are exact integers and the update uses the same IEEE ops."""
+import numpy as np
+import pytest
+
+from conftest import load_rgba, sorted_palette
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _stream(torch):
+    return torch.cuda.current_stream().cuda_stream
+
+
+def test_library_is_native(processor):
+    import kmeans_gpu_amd as kg
+    assert kg.lib().kmg_version().decode().startswith("kmeans_hip")
+
+
+def test_lab_all_16m_colours(torch_cuda, processor, oracle):
+    """S1: every 24-bit colour converts to exactly the oracle's Lab (rgb_to_lab.wgsl)."""
+    torch = torch_cuda
+    n = 1 << 24
+    idx = np.arange(n, dtype=np.uint32)
+    rgba = np.empty((n, 4), np.uint8)
+    rgba[:, 0] = idx & 255; rgba[:, 1] = (idx >> 8) & 255; rgba[:, 2] = (idx >> 16) & 255; rgba[:, 3] = 255
+    d = _dev(torch, rgba)
+    lab = torch.empty((n, 3), dtype=torch.float32, device="cuda")
+    processor.rgb_to_lab(d.data_ptr(), n, lab.data_ptr(), _stream(torch))
+    torch.cuda.synchronize()
+    got = lab.cpu().numpy()
+    want = oracle.rgb_to_lab(rgba)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("n,k,seed", [(1, 1, 1), (5, 3, 2), (1023, 16, 3), (1024, 16, 4), (4099, 7, 5),
+                                      (300_000, 16, 0x5EED0002), (200_003, 256, 0x5EED0003)])
+def test_assign_accumulate_matches_oracle(torch_cuda, processor, oracle, n, k, seed):
+    """S2 + S4: labels bit-exact, int64 accumulators bit-exact, incl. ragged tails."""
+    import kmeans_gpu_amd as kg
+    torch = torch_cuda
+    rgba = oracle.synth_uniform(seed, n)
+    lab = oracle.rgb_to_lab(rgba)
+    cent = oracle.centroids4(lab[(np.arange(k) * (n // k)) % n])
+    want_labels, want_acc = oracle.assign_accumulate_rgba(rgba, cent)
+    d = _dev(torch, rgba)
+    labels = torch.full((n,), 0xFFFFFFFF, dtype=torch.int64, device="cuda").to(torch.int32)
+    labels = torch.zeros(n, dtype=torch.int32, device="cuda")
+    acc = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
+    s = kg.Lloyd(processor, k)
+    s.set_centroids(cent)
+    s.assign_accumulate(d.data_ptr(), n, labels.data_ptr(), acc.data_ptr(), _stream(torch))
+    torch.cuda.synchronize()
+    assert np.array_equal(labels.cpu().numpy().view(np.uint32), want_labels)
+    assert np.array_equal(acc.cpu().numpy(), want_acc)
+    # labels only / sums only variants
+    labels2 = torch.zeros(n, dtype=torch.int32, device="cuda")
+    s.assign_accumulate(d.data_ptr(), n, labels2.data_ptr(), 0, _stream(torch))
+    acc2 = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
+    s.assign_accumulate(d.data_ptr(), n, 0, acc2.data_ptr(), _stream(torch))
+    torch.cuda.synchronize()
+    assert torch.equal(labels, labels2) and torch.equal(acc, acc2)
+    s.close()
+
+
+def test_assign_unaligned_band(torch_cuda, processor, oracle):
+    """a row band whose first pixel is not 16-byte aligned takes the scalar-load path"""
+    import kmeans_gpu_amd as kg
+    torch = torch_cuda
+    n, k = 10_001, 5
+    rgba = oracle.synth_uniform(77, n + 3)
+    lab = oracle.rgb_to_lab(rgba)
+    cent = oracle.centroids4(lab[:k])
+    d = _dev(torch, rgba)
+    labels = torch.zeros(n + 3, dtype=torch.int32, device="cuda")
+    acc = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
+    s = kg.Lloyd(processor, k)
+    s.set_centroids(cent)
+    for off in (1, 2, 3):
+        s.assign_accumulate(d.data_ptr() + 4 * off, n, labels.data_ptr() + 4 * off, acc.data_ptr(), _stream(torch))
+        torch.cuda.synchronize()
+        wl, wa = oracle.assign_accumulate_rgba(rgba[off:off + n], cent)
+        assert np.array_equal(labels.cpu().numpy().view(np.uint32)[off:off + n], wl)
+        assert np.array_equal(acc.cpu().numpy(), wa)
+    s.close()
+
+
+def test_update_and_lloyd_loop(torch_cuda, processor, oracle, tokyo):
+    """S5 + S6 on the reference-sized problem: tokyo shrunk to 256x171, k = 8."""
+    import kmeans_gpu_amd as kg
+    torch = torch_cuda
+    nw, nh = oracle.resized_dims(tokyo.shape[1], tokyo.shape[0])
+    small = oracle.resize(tokyo, nw, nh)
+    lab = oracle.rgb_to_lab(small)
+    k = 8
+    init = oracle.init_centroids(lab, nw, nh, k)
+    want_c, want_labels, want_it = oracle.lloyd(lab, init)
+    d = _dev(torch, small)
+    n = nw * nh
+    labels = torch.zeros(n, dtype=torch.int32, device="cuda")
+    s = kg.Lloyd(processor, k)
+    s.set_centroids(init)
+    it = s.run(d.data_ptr(), n, labels.data_ptr(), _stream(torch))
+    got_c = s.get_centroids()
+    assert it == want_it
+    assert np.array_equal(got_c.view(np.uint32), want_c.view(np.uint32))
+    assert np.array_equal(labels.cpu().numpy().view(np.uint32), want_labels)
+    s.close()
+
+
+@pytest.mark.parametrize("k", [1, 2, 8, 33])
+def test_init_centroids(torch_cuda, processor, oracle, tokyo, k):
+    """S12 farthest-point init incl. its arg-max tie rule"""
+    import kmeans_gpu_amd as kg
+    torch = torch_cuda
+    nw, nh = oracle.resized_dims(tokyo.shape[1], tokyo.shape[0])
+    small = oracle.resize(tokyo, nw, nh)
+    want = oracle.init_centroids(oracle.rgb_to_lab(small), nw, nh, k)
+    d = _dev(torch, small)
+    s = kg.Lloyd(processor, k)
+    s.init_centroids(d.data_ptr(), nw, nh, _stream(torch))
+    got = s.get_centroids(_stream(torch))
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    s.close()
+
+
+def test_init_ties_flat_image(torch_cuda, processor, oracle):
+    """few distinct colours -> many exact ties in the distance map"""
+    import kmeans_gpu_amd as kg
+    torch = torch_cuda
+    w, h, k = 67, 41, 6
+    rng = np.random.default_rng(5)
+    pal = rng.integers(0, 256, (4, 4), dtype=np.uint8); pal[:, 3] = 255
+    img = pal[rng.integers(0, 4, (h, w))]
+    want = oracle.init_centroids(oracle.rgb_to_lab(img), w, h, k)
+    d = _dev(torch, img)
+    s = kg.Lloyd(processor, k)
+    s.init_centroids(d.data_ptr(), w, h, _stream(torch))
+    got = s.get_centroids(_stream(torch))
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    s.close()
+
+
+@pytest.mark.parametrize("shape", [(513, 768), (300, 1000), (1000, 300), (257, 256), (17, 4000)])
+def test_resize(torch_cuda, processor, oracle, shape):
+    """S11 shrink to <= 256"""
+    import kmeans_gpu_amd as kg
+    torch = torch_cuda
+    h, w = shape
+    img = oracle.synth_uniform(h * 1000 + w, h * w).reshape(h, w, 4)
+    nw, nh = kg.resized_dims(w, h)
+    assert (nw, nh) == oracle.resized_dims(w, h)
+    want = oracle.resize(img, nw, nh)
+    d = _dev(torch, img)
+    out = torch.zeros((nh, nw, 4), dtype=torch.uint8, device="cuda")
+    processor.resize(d.data_ptr(), w, h, nw, nh, out.data_ptr(), _stream(torch))
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want)
+
+
+def test_find_goldens(processor, tokyo):
+    """the reference's three committed `find` outputs (samples.sh:6-8), bit-exact"""
+    import kmeans_gpu_amd as kg
+    pal3 = np.array([[5, 5, 5, 255], [255, 255, 255, 255], [255, 0, 0, 255]], np.uint8)
+    out = processor.find(tokyo, pal3, kg.ReduceMode.Replace)
+    assert np.array_equal(out, load_rgba("tokyo-find-replace-dark-white-red.png"))
+    out = processor.find(tokyo, pal3, kg.ReduceMode.Dither)
+    assert np.array_equal(out, load_rgba("tokyo-find-dither-dark-white-red.png"))
+    out = processor.find(tokyo, sorted_palette("apollo-1x.png"), kg.ReduceMode.Dither)
+    assert np.array_equal(out, load_rgba("tokyo-find-dither-apollo.png"))
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("k", [1, 2, 8, 16])
+def test_reduce_matches_oracle(processor, oracle, tokyo, k, mode):
+    """ImageProcessor::reduce end to end (shrink, init, Lloyd, output pass) == oracle, bit-exact"""
+    got = processor.reduce(k, tokyo, reduce_mode=mode)
+    want = oracle.reduce(tokyo, k, mode)
+    assert np.array_equal(got, want)
+
+
+def test_reduce_golden_colours(processor, tokyo):
+    """reduce -c 8 lands on the golden's 8 colours within 1 LSB (samples.sh:3)"""
+    got = processor.reduce(8, tokyo)
+    g = load_rgba("tokyo-reduce-c8-kmeans-replace.png")
+    c1 = np.unique(got.reshape(-1, 4), axis=0).astype(int)
+    c2 = np.unique(g.reshape(-1, 4), axis=0).astype(int)
+    assert c1.shape == c2.shape == (8, 4)
+    assert np.abs(c1 - c2).max() <= 1
+
+
+def test_palette_matches_oracle(processor, oracle, tokyo):
+    got = processor.palette(8, tokyo)
+    want = oracle.palette(tokyo, 8)
+    assert np.array_equal(got, want)
+    gold = load_rgba("tokyo-palette-c8-kmeans-s40.png")[0, ::40, :]
+    assert np.abs(got.astype(int) - gold.astype(int)).max() <= 1
