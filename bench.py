@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the Lloyd-iteration hot path on MI355X.
+
+Metric (BASELINE.json): pixels/sec per Lloyd iteration at 8192x8192, k = 256, plus the fraction of
+the HBM roofline.  A "step" is ONE Lloyd iteration over the whole (sharded) image: centroid update
+from the global accumulators, per-pixel CIE94 assignment fused with the per-cluster sums, partial
+sum reduction and -- for N > 1 -- the RCCL all-reduce of the k x 4 int64 accumulators.
+
+N = 1: synthetic 8192x8192 RGBA (splitmix64 seed 0x5EED0003), k = 256.
+N > 1: weak scaling -- the image is 8192 x (8192*N), row-sharded so every rank owns one 8192x8192
+band; the iteration is still ONE k-means problem (one all-reduce per iteration).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "kmeans-gpu_amd", "python"))
+
+WIDTH = 8192
+ROWS_PER_GPU = 8192
+K = 256
+ALGORITHMIC_BYTES_PER_PIXEL = 8          # 4 B RGBA8 read + 4 B u32 label write
+HBM_PEAK_GBPS = 8000.0                   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+
+
+def cpu_baseline(k, centroids4, seed, target_seconds=12.0):
+    """The CPU oracle (a port of the reference's WGSL; the reference itself needs Rust + Vulkan) on
+    a bounded sample of the same workload, all host threads."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    from kmeans_gpu_amd import synth
+    probe = synth.uniform_rgba_numpy(seed, 32768)
+    t = time.perf_counter()
+    O.assign_accumulate_rgba(probe, centroids4)
+    dt = max(time.perf_counter() - t, 1e-4)
+    t = time.perf_counter()
+    O.assign_accumulate_rgba(probe, centroids4)
+    dt = min(dt, max(time.perf_counter() - t, 1e-4))
+    rate = 32768 / dt
+    n = int(min(WIDTH * ROWS_PER_GPU, max(32768, rate * target_seconds)))
+    n -= n % WIDTH if n > WIDTH else 0
+    px = synth.uniform_rgba_numpy(seed, n)
+    t = time.perf_counter()
+    O.assign_accumulate_rgba(px, centroids4)
+    dt = time.perf_counter() - t
+    return {"value": n / dt, "unit": "pixels/s", "cores": O.num_threads(), "kind": "port",
+            "sample": f"first {n} pixels ({n // WIDTH} rows of {WIDTH}) of the same image, k={k}, "
+                      f"one assign+accumulate pass, {dt:.2f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--k", type=int, default=K)
+    ap.add_argument("--rows", type=int, default=ROWS_PER_GPU, help="rows per GPU (default 8192)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import kmeans_gpu_amd as kg
+    from kmeans_gpu_amd import synth
+    from kmeans_gpu_amd.sharded import ShardedLloyd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU path exists)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    k = args.k
+    n_local = WIDTH * args.rows
+    seed = synth.SEED_CFG3
+    proc = kg.ImageProcessor(device=local_rank, shrink_max_dim=0)
+    rgba = synth.uniform_rgba_torch(seed, n_local, first=rank * n_local, device="cuda")
+    labels = torch.empty(n_local, dtype=torch.int32, device="cuda")
+
+    # initial centroids: shader Lab of the pixels at linear index j * floor(N/k) of band 0
+    sel = synth.uniform_rgba_numpy(seed, WIDTH * args.rows)[(np.arange(k) * (n_local // k))]
+    d_sel = torch.from_numpy(sel).cuda()
+    lab = torch.empty((k, 3), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    proc.rgb_to_lab(d_sel.data_ptr(), k, lab.data_ptr(), stream)
+    torch.cuda.synchronize()
+    cent = np.ones((k, 4), np.float32)
+    cent[:, :3] = lab.cpu().numpy()
+
+    lloyd = kg.Lloyd(proc, k)
+    lloyd.set_centroids(cent, stream)
+    sh = ShardedLloyd(lloyd, k, rgba, labels, stream=stream)
+    sh.prime()
+    for _ in range(args.warmup):
+        sh.iterate()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sh.kernel_events = []
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sh.iterate()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = [a.elapsed_time(b) for a, b in sh.kernel_events]
+    sh.kernel_events = None
+
+    if rank == 0:
+        total_pixels = n_local * world
+        ms_per_step = elapsed * 1e3 / args.steps
+        k_ms = sum(kernel_ms) / len(kernel_ms)
+        achieved = ALGORITHMIC_BYTES_PER_PIXEL * n_local / (k_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath) and k == K and args.rows == ROWS_PER_GPU:
+            with open(tpath) as f:
+                traffic = json.load(f).get("k_assign_bytes_per_launch")
+        out = {
+            "metric": "pixels/sec per Lloyd iteration (8192x8192, k=256)",
+            "value": total_pixels * args.steps / elapsed,
+            "unit": "pixels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"synthetic uniform RGBA {WIDTH}x{args.rows * world} (seed 0x5EED0003), "
+                                   f"k={k}, one Lloyd iteration = update + assign + accumulate"
+                                   + (" + RCCL all-reduce of k x 4 int64" if world > 1 else ""),
+                       "width": WIDTH, "height": args.rows * world, "k": k,
+                       "sharding": f"row bands, {args.rows} rows per GPU"},
+            "roofline": {"bound": "hbm", "kernel": "k_assign<true> (fused assign + accumulate)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel_ms": k_ms, "algorithmic_bytes_per_launch": ALGORITHMIC_BYTES_PER_PIXEL * n_local},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(k, cent, seed)
+        print(json.dumps(out), flush=True)
+
+    lloyd.close()
+    proc.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

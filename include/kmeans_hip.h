@@ -127,6 +127,13 @@ KMG_API int kmg_lloyd_init_centroids(kmg_lloyd *s, const uint8_t *d_rgba, uint32
 KMG_API int kmg_lloyd_assign_accumulate(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n_pixels,
                                         uint32_t *d_labels, int64_t *d_acc4, void *stream);
 
+/* The two halves of kmg_lloyd_assign_accumulate, for callers that time or batch them:
+ * _assign_partials runs the fused per-pixel kernel (labels + per-workgroup partial sums kept in
+ * the state), _reduce_partials folds the partial sums of that same launch into d_acc4.        */
+KMG_API int kmg_lloyd_assign_partials(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n_pixels,
+                                      uint32_t *d_labels, void *stream);
+KMG_API int kmg_lloyd_reduce_partials(kmg_lloyd *s, uint64_t n_pixels, int64_t *d_acc4, void *stream);
+
 /* choose_centroid.wgsl:180-206 `pick` for all k at once: centroid <- sum/count, convergence
  * flags.  d_acc4 holds the (all-reduced) accumulators.                                        */
 KMG_API int kmg_lloyd_update(kmg_lloyd *s, const int64_t *d_acc4, void *stream);

@@ -311,6 +311,22 @@ extern "C" int kmg_lloyd_assign_accumulate(kmg_lloyd *s, const uint8_t *d_rgba, 
     return KMG_OK;
 }
 
+extern "C" int kmg_lloyd_assign_partials(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_t *d_labels, void *stream)
+{
+    if (!s || !d_rgba || n == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad assign_partials arguments");
+    HIP_TRY(hipSetDevice(s->p->device));
+    HIP_TRY(launch_assign((const uint32_t *)d_rgba, n, s->d_cent, s->k, s->p->d_lut, d_labels, s->d_partials, S(stream)));
+    return KMG_OK;
+}
+
+extern "C" int kmg_lloyd_reduce_partials(kmg_lloyd *s, uint64_t n, int64_t *d_acc4, void *stream)
+{
+    if (!s || !d_acc4 || n == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad reduce_partials arguments");
+    HIP_TRY(hipSetDevice(s->p->device));
+    HIP_TRY(launch_reduce_partials(s->d_partials, assign_grid(n), s->k, d_acc4, S(stream)));
+    return KMG_OK;
+}
+
 extern "C" int kmg_lloyd_update(kmg_lloyd *s, const int64_t *d_acc4, void *stream)
 {
     if (!s || !d_acc4) return fail(KMG_ERR_INVALID_ARGUMENT, "bad update arguments");

@@ -11,8 +11,8 @@ namespace kmg {
 struct alignas(16) Centroid { float L, a, b, C; };
 
 constexpr int kBlock = 256;          // threads per workgroup (4 waves of 64)
-constexpr int kPixelsPerThread = 4;  // one 16-byte RGBA8 load per thread
-constexpr int kTile = kBlock * kPixelsPerThread;
+
+
 
 // Number of workgroups the assign/accumulate pass uses for n pixels (also the number of rows of
 // the per-workgroup partial-sum slab).

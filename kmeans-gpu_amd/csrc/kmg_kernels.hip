@@ -1,9 +1,9 @@
 // kmg_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the Lloyd hot path.
 //
 // Data layout in HBM
-//   pixels     : RGBA8, 4 B/px, row-major, read with one 16-byte load per thread (4 px)
+//   pixels     : RGBA8, 4 B/px, row-major, read with 16-byte loads (4 px), 8 px per thread
 //   labels     : u32 per pixel (find_centroid.wgsl:43 writes an r32uint texel per pixel)
-//   centroids  : k x (L, a, b, C) f32 -- uniform across a wave, fetched with scalar loads
+//   centroids  : k x (L, a, b, C) f32 -- staged into LDS per workgroup, broadcast to the waves
 //   partials   : [workgroup][k][4] int64 -- per-workgroup exact sums, no float atomics
 //   acc        : [k][4] int64
 // Lab is never materialised: every pass re-derives it from the 4-byte pixel (the sRGB decode is a
@@ -50,12 +50,6 @@ __device__ __forceinline__ void store4(uint32_t *out, uint64_t i0, uint64_t n, b
 
 }  // namespace
 
-uint32_t assign_grid(uint64_t n)
-{
-    uint64_t tiles = (n + kTile - 1) / kTile;
-    if (tiles < 1) tiles = 1;
-    return (uint32_t)(tiles < 2048 ? tiles : 2048);
-}
 
 // ------------------------------------------------------------------------------------------
 // RGBA8 -> Lab  (rgb_to_lab.wgsl:66-80).  Only used by tests / callers that want Lab itself.
@@ -85,71 +79,160 @@ hipError_t launch_rgb_to_lab(const uint32_t *rgba, uint64_t n, const float *lut,
 }
 
 // ------------------------------------------------------------------------------------------
-// assign (+ accumulate): find_centroid.wgsl:15-44 fused with the masked sums of
-// choose_centroid.wgsl:97-104.  One workgroup = 4 waves; each thread owns 4 consecutive pixels
-// and walks the centroid table once (uniform index -> scalar loads, broadcast to the wave).
-// Sums go to per-workgroup int64 bins in LDS (ds_add_u64), flushed once per workgroup.
+// Arg-min scan shared by the assign and the output kernels.
+//
+// The centroid table lives in LDS as (L, a, b, C) float4 entries and is read with ONE
+// ds_read_b128 per centroid per wave (all lanes read the same address -> broadcast), so the
+// centroid operands arrive in VGPRs.  (Scalar loads would be free, but on gfx950 a VALU
+// instruction with an SGPR source issues at half rate -- tools/valu_rate.hip.)
+//
+// CHUNKED: centroids are visited four at a time; only the chunk minimum is compared against the
+// running best (v_min3 + v_min + v_cmp + 2 v_cndmask per 4 pairs instead of 3 per pair) and the
+// winning index inside the chunk is recovered afterwards by re-evaluating that one chunk.
+// Strict '<' between chunk minima keeps the earliest chunk, the recovery takes the first entry
+// that attains the minimum: exactly find_centroid.wgsl's "first minimum wins".
+// The table is padded to a multiple of 4 with entries no pixel can be closest to.
 // ------------------------------------------------------------------------------------------
-template <bool ACCUM>
+constexpr uint32_t kNoChunk = 0xFFFFFFFFu;
+
+__device__ __forceinline__ void stage_centroids(float4 *s_cent, const Centroid *__restrict__ cent,
+                                                uint32_t k, uint32_t kpad)
+{
+    for (uint32_t i = threadIdx.x; i < kpad; i += kBlock) {
+        float4 v;
+        if (i < k) {
+            const Centroid c = cent[i];
+            v = make_float4(c.L, c.a, c.b, c.C);
+        } else {
+            v = make_float4(1.0e18f, 0.0f, 0.0f, 0.0f);   // key ~ 1e36: never below any sentinel
+        }
+        s_cent[i] = v;
+    }
+}
+
+template <int PPT, bool CHUNKED>
+__device__ __forceinline__ void argmin_scan(const PixelTerms (&pt)[PPT], float (&best)[PPT],
+                                            uint32_t (&idx)[PPT], const float4 *s_cent, uint32_t k,
+                                            uint32_t kpad)
+{
+    if (!CHUNKED) {
+#pragma unroll 2
+        for (uint32_t j = 0; j < k; ++j) {
+            const float4 c = s_cent[j];
+#pragma unroll
+            for (int p = 0; p < PPT; ++p) {
+                float d = cie94_key(pt[p], c.x, c.y, c.z, c.w);
+                bool lt = d < best[p];
+                best[p] = lt ? d : best[p];
+                idx[p] = lt ? j : idx[p];
+            }
+        }
+    } else {
+        uint32_t chunk[PPT];
+#pragma unroll
+        for (int p = 0; p < PPT; ++p) chunk[p] = kNoChunk;
+        for (uint32_t j = 0; j < kpad; j += 4) {
+            const float4 c0 = s_cent[j], c1 = s_cent[j + 1], c2 = s_cent[j + 2], c3 = s_cent[j + 3];
+#pragma unroll
+            for (int p = 0; p < PPT; ++p) {
+                float d0 = cie94_key(pt[p], c0.x, c0.y, c0.z, c0.w);
+                float d1 = cie94_key(pt[p], c1.x, c1.y, c1.z, c1.w);
+                float d2 = cie94_key(pt[p], c2.x, c2.y, c2.z, c2.w);
+                float d3 = cie94_key(pt[p], c3.x, c3.y, c3.z, c3.w);
+                float m = fminf(fminf(fminf(d0, d1), d2), d3);
+                bool lt = m < best[p];
+                best[p] = lt ? m : best[p];
+                chunk[p] = lt ? j : chunk[p];
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < PPT; ++p) {
+            if (chunk[p] != kNoChunk) {
+                uint32_t found = chunk[p] + 3;
+#pragma unroll
+                for (int q = 2; q >= 0; --q) {
+                    const float4 c = s_cent[chunk[p] + q];
+                    float d = cie94_key(pt[p], c.x, c.y, c.z, c.w);
+                    found = (d <= best[p]) ? chunk[p] + q : found;
+                }
+                idx[p] = found;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// assign (+ accumulate): find_centroid.wgsl:15-44 fused with the masked sums of
+// choose_centroid.wgsl:97-104.  One workgroup = 4 waves; each thread owns PPT pixels (groups of
+// 4 consecutive pixels = one 16-byte load, the groups of a tile interleaved so every load
+// instruction is fully coalesced).  Sums go to per-workgroup int64 bins in LDS (ds_add_u64),
+// flushed once per workgroup into the partial-sum slab.
+// LDS: [centroids kpad x 16 B][bins k x 32 B (ACCUM)][sRGB table 1 KiB]
+// ------------------------------------------------------------------------------------------
+template <int PPT, bool ACCUM, bool CHUNKED>
 __global__ __launch_bounds__(kBlock) void k_assign(const uint32_t *__restrict__ rgba, uint64_t n,
                                                    const Centroid *__restrict__ cent, uint32_t k,
                                                    const float *__restrict__ lut,
                                                    uint32_t *__restrict__ labels,
                                                    int64_t *__restrict__ partials, int aligned)
 {
-    extern __shared__ unsigned long long smem[];
-    unsigned long long *bins = smem;                                   // [k][4] (ACCUM only)
-    float *s_lut = reinterpret_cast<float *>(smem + (ACCUM ? 4ull * k : 0ull));
+    extern __shared__ float4 smem4[];
+    const uint32_t kpad = (k + 3u) & ~3u;
+    float4 *s_cent = smem4;
+    unsigned long long *bins = reinterpret_cast<unsigned long long *>(smem4 + kpad);
+    float *s_lut = reinterpret_cast<float *>(bins + (ACCUM ? 4ull * k : 0ull));
 
     s_lut[threadIdx.x] = lut[threadIdx.x];
+    stage_centroids(s_cent, cent, k, kpad);
     if (ACCUM)
         for (uint32_t i = threadIdx.x; i < 4 * k; i += kBlock) bins[i] = 0ull;
     __syncthreads();
 
-    const uint64_t tiles = (n + kTile - 1) / kTile;
+    constexpr int GROUPS = PPT / 4;
+    constexpr uint64_t TILE = (uint64_t)kBlock * PPT;
+    const uint64_t tiles = (n + TILE - 1) / TILE;
     for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const uint64_t i0 = tile * kTile + (uint64_t)threadIdx.x * kPixelsPerThread;
-        uint32_t px[4];
-        load4(rgba, i0, n, aligned != 0, px);
-
-        float L[4], A[4], B[4];
-        PixelTerms pt[4];
+        uint64_t i0[GROUPS];
+        float L[PPT], A[PPT], B[PPT];
+        PixelTerms pt[PPT];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            px_to_lab(s_lut, px[p], L[p], A[p], B[p]);
-            pt[p] = pixel_terms(L[p], A[p], B[p]);
+        for (int g = 0; g < GROUPS; ++g) {
+            i0[g] = tile * TILE + (uint64_t)g * (kBlock * 4) + (uint64_t)threadIdx.x * 4;
+            uint32_t px[4];
+            load4(rgba, i0[g], n, aligned != 0, px);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int p = g * 4 + q;
+                px_to_lab(s_lut, px[q], L[p], A[p], B[p]);
+                pt[p] = pixel_terms(L[p], A[p], B[p]);
+            }
         }
 
         // find_centroid.wgsl:29-41: min_distance = 100000.0 (squared here), found_index = 0,
         // strict '<' so the first minimum wins.
-        float best[4];
-        uint32_t idx[4];
+        float best[PPT];
+        uint32_t idx[PPT];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) { best[p] = 1.0e10f; idx[p] = 0u; }
+        for (int p = 0; p < PPT; ++p) { best[p] = 1.0e10f; idx[p] = 0u; }
+        argmin_scan<PPT, CHUNKED>(pt, best, idx, s_cent, k, kpad);
 
-#pragma unroll 2
-        for (uint32_t j = 0; j < k; ++j) {
-            const Centroid c = cent[j];
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                float d = cie94_key(pt[p], c.L, c.a, c.b, c.C);
-                bool lt = d < best[p];
-                best[p] = lt ? d : best[p];
-                idx[p] = lt ? j : idx[p];
+        for (int g = 0; g < GROUPS; ++g) {
+            if (labels) {
+                uint32_t v[4] = {idx[g * 4], idx[g * 4 + 1], idx[g * 4 + 2], idx[g * 4 + 3]};
+                store4(labels, i0[g], n, aligned != 0, v);
             }
-        }
-
-        if (labels) store4(labels, i0, n, aligned != 0, idx);
-
-        if (ACCUM) {
+            if (ACCUM) {
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                if (i0 + p < n) {
-                    unsigned long long *bin = bins + 4ull * idx[p];
-                    atomicAdd(bin + 0, (unsigned long long)(long long)lab_fix(L[p]));
-                    atomicAdd(bin + 1, (unsigned long long)(long long)lab_fix(A[p]));
-                    atomicAdd(bin + 2, (unsigned long long)(long long)lab_fix(B[p]));
-                    atomicAdd(bin + 3, 1ull);
+                for (int q = 0; q < 4; ++q) {
+                    const int p = g * 4 + q;
+                    if (i0[g] + q < n) {
+                        unsigned long long *bin = bins + 4ull * idx[p];
+                        atomicAdd(bin + 0, (unsigned long long)(long long)lab_fix(L[p]));
+                        atomicAdd(bin + 1, (unsigned long long)(long long)lab_fix(A[p]));
+                        atomicAdd(bin + 2, (unsigned long long)(long long)lab_fix(B[p]));
+                        atomicAdd(bin + 3, 1ull);
+                    }
                 }
             }
         }
@@ -163,20 +246,41 @@ __global__ __launch_bounds__(kBlock) void k_assign(const uint32_t *__restrict__ 
     }
 }
 
+constexpr int kAssignPPT = 8;   // pixels per thread of the assign kernel
+
+uint32_t assign_grid(uint64_t n)
+{
+    const uint64_t tile = (uint64_t)kBlock * kAssignPPT;
+    uint64_t tiles = (n + tile - 1) / tile;
+    if (tiles < 1) tiles = 1;
+    return (uint32_t)(tiles < 2048 ? tiles : 2048);
+}
+
 hipError_t launch_assign(const uint32_t *rgba, uint64_t n, const Centroid *cent, uint32_t k,
                          const float *lut, uint32_t *labels, int64_t *partials, hipStream_t st)
 {
     const uint32_t grid = assign_grid(n);
+    const uint32_t kpad = (k + 3u) & ~3u;
     const int aligned = ((reinterpret_cast<uintptr_t>(rgba) & 15u) == 0 &&
                          (labels == nullptr || (reinterpret_cast<uintptr_t>(labels) & 15u) == 0))
                             ? 1 : 0;
+    const bool chunked = k >= 32;   // the recovery step costs ~4 extra pairs per pixel
+    size_t lds = sizeof(float4) * kpad + 256 * sizeof(float);
     if (partials) {
-        size_t lds = sizeof(unsigned long long) * 4ull * k + 256 * sizeof(float);
-        hipLaunchKernelGGL(k_assign<true>, dim3(grid), dim3(kBlock), lds, st, rgba, n, cent, k, lut,
-                           labels, partials, aligned);
+        lds += sizeof(unsigned long long) * 4ull * k;
+        if (chunked)
+            hipLaunchKernelGGL((k_assign<kAssignPPT, true, true>), dim3(grid), dim3(kBlock), lds, st,
+                               rgba, n, cent, k, lut, labels, partials, aligned);
+        else
+            hipLaunchKernelGGL((k_assign<kAssignPPT, true, false>), dim3(grid), dim3(kBlock), lds, st,
+                               rgba, n, cent, k, lut, labels, partials, aligned);
     } else {
-        hipLaunchKernelGGL(k_assign<false>, dim3(grid), dim3(kBlock), 256 * sizeof(float), st, rgba,
-                           n, cent, k, lut, labels, partials, aligned);
+        if (chunked)
+            hipLaunchKernelGGL((k_assign<kAssignPPT, false, true>), dim3(grid), dim3(kBlock), lds, st,
+                               rgba, n, cent, k, lut, labels, partials, aligned);
+        else
+            hipLaunchKernelGGL((k_assign<kAssignPPT, false, false>), dim3(grid), dim3(kBlock), lds, st,
+                               rgba, n, cent, k, lut, labels, partials, aligned);
     }
     return hipGetLastError();
 }
@@ -421,7 +525,7 @@ hipError_t launch_resize(const uint32_t *rgba, uint32_t w, uint32_t h, uint32_t 
 // ------------------------------------------------------------------------------------------
 __constant__ const float c_bayer[16] = {0, 8, 2, 10, 12, 4, 14, 6, 3, 11, 1, 9, 15, 7, 13, 5};
 
-template <bool DITHER>
+template <int PPT, bool DITHER, bool CHUNKED>
 __global__ __launch_bounds__(kBlock) void k_apply(const uint32_t *__restrict__ rgba, uint32_t w,
                                                   uint64_t n, uint32_t row0,
                                                   const Centroid *__restrict__ cent, uint32_t k,
@@ -429,9 +533,14 @@ __global__ __launch_bounds__(kBlock) void k_apply(const uint32_t *__restrict__ r
                                                   const uint32_t *__restrict__ pal, float threshold,
                                                   uint32_t *__restrict__ out, int aligned)
 {
-    __shared__ float s_lut[256];
-    __shared__ float s_off[16];
+    extern __shared__ float4 smem4[];
+    const uint32_t kpad = (k + 3u) & ~3u;
+    float4 *s_cent = smem4;
+    float *s_lut = reinterpret_cast<float *>(smem4 + kpad);
+    float *s_off = s_lut + 256;
+
     s_lut[threadIdx.x] = lut[threadIdx.x];
+    stage_centroids(s_cent, cent, k, kpad);
     if (DITHER && threadIdx.x < 16) {
         // mix_colors.wgsl:21-27,70,72: threshold * (M[x%4 + 4*(y%4)] / 16 - 0.5)
         float iv = c_bayer[threadIdx.x] / 16.0f - 0.5f;
@@ -439,50 +548,50 @@ __global__ __launch_bounds__(kBlock) void k_apply(const uint32_t *__restrict__ r
     }
     __syncthreads();
 
-    const uint64_t tiles = (n + kTile - 1) / kTile;
+    constexpr int GROUPS = PPT / 4;
+    constexpr uint64_t TILE = (uint64_t)kBlock * PPT;
+    const uint64_t tiles = (n + TILE - 1) / TILE;
     for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const uint64_t i0 = tile * kTile + (uint64_t)threadIdx.x * kPixelsPerThread;
-        uint32_t px[4];
-        load4(rgba, i0, n, aligned != 0, px);
-
-        PixelTerms pt[4];
-        float best[4];
-        uint32_t idx[4];
+        uint64_t i0[GROUPS];
+        PixelTerms pt[PPT];
+        float best[PPT];
+        uint32_t idx[PPT];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            float L, a, b;
-            px_to_lab(s_lut, px[p], L, a, b);
-            if (DITHER) {
-                const uint64_t i = i0 + p;
-                const uint32_t x = (uint32_t)(i % w), y = row0 + (uint32_t)(i / w);
-                const float off = s_off[(x & 3u) + ((y & 3u) << 2)];
-                L = L + off; a = a + off; b = b + off;             // :72
-            }
-            pt[p] = pixel_terms(L, a, b);
-            if (DITHER) {
-                // :73 closest = vec3(10000.0): running minimum starts at the sentinel's distance
-                best[p] = cie94_key(pt[p], 10000.0f, 10000.0f, 10000.0f, chroma(10000.0f, 10000.0f));
-                idx[p] = k;
-            } else {
-                best[p] = 1.0e10f;
-                idx[p] = 0u;
-            }
-        }
-#pragma unroll 2
-        for (uint32_t j = 0; j < k; ++j) {
-            const Centroid c = cent[j];
+        for (int g = 0; g < GROUPS; ++g) {
+            i0[g] = tile * TILE + (uint64_t)g * (kBlock * 4) + (uint64_t)threadIdx.x * 4;
+            uint32_t px[4];
+            load4(rgba, i0[g], n, aligned != 0, px);
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                float d = cie94_key(pt[p], c.L, c.a, c.b, c.C);
-                bool lt = d < best[p];
-                best[p] = lt ? d : best[p];
-                idx[p] = lt ? j : idx[p];
+            for (int q = 0; q < 4; ++q) {
+                const int p = g * 4 + q;
+                float L, a, b;
+                px_to_lab(s_lut, px[q], L, a, b);
+                if (DITHER) {
+                    const uint64_t i = i0[g] + q;
+                    const uint32_t x = (uint32_t)(i % w), y = row0 + (uint32_t)(i / w);
+                    const float off = s_off[(x & 3u) + ((y & 3u) << 2)];
+                    L = L + off; a = a + off; b = b + off;         // :72
+                }
+                pt[p] = pixel_terms(L, a, b);
+                if (DITHER) {
+                    // :73 closest = vec3(10000.0): the running minimum starts at the sentinel's
+                    // distance; index k selects the converted sentinel in pal[]
+                    best[p] = cie94_key(pt[p], 10000.0f, 10000.0f, 10000.0f, chroma(10000.0f, 10000.0f));
+                    idx[p] = k;
+                } else {
+                    best[p] = 1.0e10f;                             // find_centroid.wgsl:29-30
+                    idx[p] = 0u;
+                }
             }
         }
-        uint32_t o[4];
+        argmin_scan<PPT, CHUNKED>(pt, best, idx, s_cent, k, kpad);
 #pragma unroll
-        for (int p = 0; p < 4; ++p) o[p] = pal[idx[p]];
-        store4(out, i0, n, aligned != 0, o);
+        for (int g = 0; g < GROUPS; ++g) {
+            uint32_t o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = pal[idx[g * 4 + q]];
+            store4(out, i0[g], n, aligned != 0, o);
+        }
     }
 }
 
@@ -492,14 +601,17 @@ hipError_t launch_apply(const uint32_t *rgba, uint32_t w, uint32_t rows, uint32_
 {
     const uint64_t n = (uint64_t)w * rows;
     const uint32_t grid = assign_grid(n);
+    const uint32_t kpad = (k + 3u) & ~3u;
     const int aligned = ((reinterpret_cast<uintptr_t>(rgba) & 15u) == 0 &&
                          (reinterpret_cast<uintptr_t>(out) & 15u) == 0) ? 1 : 0;
-    if (dither)
-        hipLaunchKernelGGL(k_apply<true>, dim3(grid), dim3(kBlock), 0, st, rgba, w, n, row0, cent, k,
-                           lut, pal, threshold, out, aligned);
-    else
-        hipLaunchKernelGGL(k_apply<false>, dim3(grid), dim3(kBlock), 0, st, rgba, w, n, row0, cent, k,
-                           lut, pal, threshold, out, aligned);
+    const bool chunked = k >= 32;
+    const size_t lds = sizeof(float4) * kpad + (256 + 16) * sizeof(float);
+#define KMG_APPLY(D, C)                                                                            \
+    hipLaunchKernelGGL((k_apply<kAssignPPT, D, C>), dim3(grid), dim3(kBlock), lds, st, rgba, w, n, \
+                       row0, cent, k, lut, pal, threshold, out, aligned)
+    if (dither) { if (chunked) KMG_APPLY(true, true); else KMG_APPLY(true, false); }
+    else        { if (chunked) KMG_APPLY(false, true); else KMG_APPLY(false, false); }
+#undef KMG_APPLY
     return hipGetLastError();
 }
 

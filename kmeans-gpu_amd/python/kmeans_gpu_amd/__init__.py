@@ -65,6 +65,7 @@ SYMBOLS = [
     "kmg_palette_to_centroids", "kmg_centroids_to_palette", "kmg_dev_rgb_to_lab", "kmg_resized_dims",
     "kmg_dev_resize", "kmg_lloyd_create", "kmg_lloyd_destroy", "kmg_lloyd_set_centroids",
     "kmg_lloyd_get_centroids", "kmg_lloyd_init_centroids", "kmg_lloyd_assign_accumulate",
+    "kmg_lloyd_assign_partials", "kmg_lloyd_reduce_partials",
     "kmg_lloyd_update", "kmg_lloyd_converged_count", "kmg_lloyd_run", "kmg_dev_apply",
     "kmg_dither_threshold",
 ]
@@ -79,6 +80,14 @@ def lib():
         raise ImportError(f"{_LIB_PATH} not found: build it with `make -C {_PKG_ROOT}` "
                           "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
                           "There is no fallback implementation.")
+    # When PyTorch shares the process (tests, bench.py, the sharded driver) it must be imported
+    # BEFORE libkmeans_hip.so is loaded: torch bundles its own libamdhip64, and two different HIP
+    # runtimes in one process cannot both own the GPU ("no ROCm-capable device is detected").
+    # With torch's runtime already mapped, our DT_NEEDED libamdhip64 resolves to that same copy.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(_LIB_PATH)
     vp, u8p, u32p, f32p, i64p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
     L.kmg_last_error.restype = C.c_char_p
@@ -105,6 +114,8 @@ def lib():
     L.kmg_lloyd_get_centroids.argtypes = [vp, f32p, vp]
     L.kmg_lloyd_init_centroids.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, vp]
     L.kmg_lloyd_assign_accumulate.argtypes = [vp, u8p, C.c_uint64, u32p, i64p, vp]
+    L.kmg_lloyd_assign_partials.argtypes = [vp, u8p, C.c_uint64, u32p, vp]
+    L.kmg_lloyd_reduce_partials.argtypes = [vp, C.c_uint64, i64p, vp]
     L.kmg_lloyd_update.argtypes = [vp, i64p, vp]
     L.kmg_lloyd_converged_count.argtypes = [vp, C.POINTER(C.c_uint32), vp]
     L.kmg_lloyd_run.argtypes = [vp, u8p, C.c_uint64, u32p, C.POINTER(C.c_uint32), vp]
@@ -279,6 +290,13 @@ class Lloyd:
         _check(lib().kmg_lloyd_assign_accumulate(self._h, C.c_void_p(d_rgba), n_pixels,
                                                  C.c_void_p(d_labels or None), C.c_void_p(d_acc4 or None),
                                                  C.c_void_p(stream)))
+
+    def assign_partials(self, d_rgba, n_pixels, d_labels, stream=0):
+        _check(lib().kmg_lloyd_assign_partials(self._h, C.c_void_p(d_rgba), n_pixels,
+                                               C.c_void_p(d_labels or None), C.c_void_p(stream)))
+
+    def reduce_partials(self, n_pixels, d_acc4, stream=0):
+        _check(lib().kmg_lloyd_reduce_partials(self._h, n_pixels, C.c_void_p(d_acc4), C.c_void_p(stream)))
 
     def update(self, d_acc4, stream=0):
         _check(lib().kmg_lloyd_update(self._h, C.c_void_p(d_acc4), C.c_void_p(stream)))

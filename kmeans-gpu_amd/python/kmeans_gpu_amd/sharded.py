@@ -1,0 +1,89 @@
+"""Row-band data-parallel Lloyd loop: one process per GPU, torch.distributed (RCCL) for the single
+exchange step of the path.
+
+The reference has no multi-device path.  Sharding rule: rank g of G owns the
+image rows [g*H//G, (g+1)*H//G).  Assignment and the per-pixel half of the update are independent
+per pixel; the only coupling is the k x 4 int64 accumulator table (sum qL, sum qa, sum qb, count),
+which is all-reduced (sum) once per iteration.  Because the sums are exact integers the result is
+bit-identical for any G, and every rank then performs the same centroid update locally -- no
+broadcast is needed.  The Bayer index of the dither pass uses image coordinates, so the output
+pass needs no exchange at all (kmg_dev_apply takes the band's first row).
+"""
+import torch
+import torch.distributed as dist
+
+__all__ = ["band_rows", "ShardedLloyd"]
+
+
+def band_rows(height, rank, world):
+    """Rows [r0, r1) owned by `rank`."""
+    return (rank * height) // world, ((rank + 1) * height) // world
+
+
+class ShardedLloyd:
+    """Drives one `Lloyd`-like backend per rank.
+
+    backend  : object with assign_accumulate(d_rgba, n, d_labels, d_acc, stream), update(d_acc, stream),
+               converged_count(stream)  (kmeans_gpu_amd.Lloyd on a GPU)
+    rgba     : this rank's band, uint8 tensor (rows*width, 4) on the backend's device
+    labels   : int32 tensor (rows*width,) or None
+    """
+
+    def __init__(self, backend, k, rgba, labels=None, group=None, stream=0):
+        self.backend = backend
+        self.k = int(k)
+        self.rgba = rgba
+        self.labels = labels
+        self.n_local = int(rgba.shape[0]) if rgba.dim() == 2 else int(rgba.numel() // 4)
+        self.group = group
+        self.stream = stream
+        self.acc = torch.zeros((self.k, 4), dtype=torch.int64, device=rgba.device)
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # optional per-launch timing of the dominant kernel: list of (start, end) events recorded on
+        # the current stream around the fused assign+accumulate launch (bench.py roofline leg)
+        self.kernel_events = None
+
+    def _assign_accumulate(self):
+        lab_ptr = self.labels.data_ptr() if self.labels is not None else 0
+        if self.n_local == 0:
+            self.acc.zero_()
+        elif self.kernel_events is not None:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.backend.assign_partials(self.rgba.data_ptr(), self.n_local, lab_ptr, self.stream)
+            e1.record()
+            self.backend.reduce_partials(self.n_local, self.acc.data_ptr(), self.stream)
+            self.kernel_events.append((e0, e1))
+        else:
+            self.backend.assign_accumulate(self.rgba.data_ptr(), self.n_local, lab_ptr,
+                                           self.acc.data_ptr(), self.stream)
+
+    def exchange(self):
+        """the path's one collective: sum of the k x 4 int64 accumulators over all bands"""
+        if self.world > 1:
+            dist.all_reduce(self.acc, op=dist.ReduceOp.SUM, group=self.group)
+
+    def prime(self):
+        """initial assignment (operations.rs:75-83), fused with the sums of the first update"""
+        self._assign_accumulate()
+        self.exchange()
+
+    def iterate(self):
+        """one Lloyd iteration (modules.rs:769-800): update from the global sums, re-assign"""
+        self.backend.update(self.acc.data_ptr(), self.stream)
+        self._assign_accumulate()
+        self.exchange()
+
+    def run(self, max_iterations=128, check_period=8):
+        """ChooseCentroidModule::compute (modules.rs:763-840) over all bands.  Returns the
+        iteration at which the loop stopped."""
+        self.prime()
+        it = 0
+        for it in range(max_iterations):
+            self.iterate()
+            if it > 0 and it % check_period == 0:
+                # identical on every rank: all ranks updated from the same global sums
+                if self.backend.converged_count(self.stream) >= self.k:
+                    break
+        return it
