@@ -127,6 +127,24 @@ KMG_API int kmg_lloyd_init_centroids(kmg_lloyd *s, const uint8_t *d_rgba, uint32
 KMG_API int kmg_lloyd_assign_accumulate(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n_pixels,
                                         uint32_t *d_labels, int64_t *d_acc4, void *stream);
 
+/* Optional, for large images: build the image's colour table (24-bit colour histogram + per-cell
+ * sums) once.  Subsequent assign passes on the SAME (d_rgba, n_pixels) then iterate over distinct
+ * colours with conservatively pruned candidate sets and materialise labels with one gather pass;
+ * labels, sums and centroids are bit-identical to the per-pixel scan.  kmg_lloyd_run binds by
+ * itself when its cost model says it pays (env KMG_STRATEGY=brute|table overrides).  The caller
+ * must not modify the pixel buffer while it is bound.                                           */
+KMG_API int kmg_lloyd_bind_image(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n_pixels, void *stream);
+KMG_API int kmg_lloyd_unbind_image(kmg_lloyd *s);
+/* One-time preparation of (d_rgba, n_pixels) for repeated assign passes: applies the library's cost
+ * model (want_labels = whether the passes will materialise labels) and binds the image if the colour
+ * table pays.  *strategy (optional) receives 0 = per-pixel scan, 1 = colour table.              */
+KMG_API int kmg_lloyd_prepare(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n_pixels, int want_labels,
+                              int *strategy, void *stream);
+/* Test support: exhaustive check over all 2^24 colours that the colour-table bounds and candidate
+ * masks for the current centroids are conservative.  out[0] = range violations, out[1] = colours
+ * whose true arg-min is missing from its cell's candidate set (both must be 0).                 */
+KMG_API int kmg_debug_check_table(kmg_lloyd *s, uint64_t out[2], void *stream);
+
 /* The two halves of kmg_lloyd_assign_accumulate, for callers that time or batch them:
  * _assign_partials runs the fused per-pixel kernel (labels + per-workgroup partial sums kept in
  * the state), _reduce_partials folds the partial sums of that same launch into d_acc4.        */

@@ -13,11 +13,13 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <new>
 #include <vector>
 
 #include "kmg_color.h"
 #include "kmg_kernels.h"
+#include "kmg_table.h"
 
 using namespace kmg;
 
@@ -71,7 +73,20 @@ extern "C" void kmg_default_options(kmg_options *opt)
 struct kmg_processor {
     int device;
     kmg_options opt;
-    float *d_lut;   // 256 x f32: sRGB decode * 100
+    float *d_lut;            // 256 x f32: sRGB decode * 100
+    std::mutex mu;           // guards the lazily built static tables below
+    CellBounds *d_bounds;    // kCells static cell bounds of the colour-table strategy
+};
+
+// colour table of a bound image (kmg_table.h)
+struct ColourTable {
+    const uint8_t *rgba = nullptr;   // the bound device buffer
+    uint64_t n = 0;
+    uint32_t *d_hist = nullptr;      // 2^24 counts, cell-major colour order
+    int64_t *d_agg = nullptr;        // kCells x 4 per-cell sums of the image
+    uint64_t *d_masks = nullptr;     // kCells x words candidate masks
+    void *d_colour_labels = nullptr; // 2^24 x u8 (k <= 256) or u16
+    uint16_t *d_sub = nullptr;       // kSubCells summaries
 };
 
 struct kmg_lloyd {
@@ -84,6 +99,8 @@ struct kmg_lloyd {
     unsigned long long *d_key;   // 1 (init arg-max)
     float *d_dist;               // init distance map, grown on demand
     uint64_t dist_cap;
+    uint32_t last_rows;          // rows of d_partials written by the last assign pass
+    ColourTable tab;
 };
 
 extern "C" int kmg_processor_create(kmg_processor **out) { return kmg_processor_create_ex(nullptr, out); }
@@ -117,6 +134,7 @@ extern "C" int kmg_processor_create_ex(const kmg_options *opt, kmg_processor **o
     p->device = dev;
     p->opt = o;
     p->d_lut = nullptr;
+    p->d_bounds = nullptr;
     float lut[256];
     build_srgb_lut100(lut);
     hipError_t e1 = hipMalloc((void **)&p->d_lut, sizeof lut);
@@ -135,6 +153,7 @@ extern "C" void kmg_processor_destroy(kmg_processor *p)
     if (!p) return;
     (void)hipSetDevice(p->device);
     if (p->d_lut) (void)hipFree(p->d_lut);
+    if (p->d_bounds) (void)hipFree(p->d_bounds);
     delete p;
 }
 
@@ -205,6 +224,154 @@ extern "C" int kmg_dev_resize(kmg_processor *p, const uint8_t *d_rgba, uint32_t 
     return KMG_OK;
 }
 
+namespace {
+struct DevBuf {
+    void *ptr = nullptr;
+    ~DevBuf() { if (ptr) (void)hipFree(ptr); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&ptr, bytes); }
+};
+
+struct StreamGuard {
+    hipStream_t st = nullptr;
+    ~StreamGuard() { if (st) (void)hipStreamDestroy(st); }
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// colour-table strategy (kmg_table.h): binding an image, strategy choice
+// ---------------------------------------------------------------------------------------------
+static void free_table(ColourTable &t)
+{
+    if (t.d_hist) (void)hipFree(t.d_hist);
+    if (t.d_agg) (void)hipFree(t.d_agg);
+    if (t.d_masks) (void)hipFree(t.d_masks);
+    if (t.d_colour_labels) (void)hipFree(t.d_colour_labels);
+    if (t.d_sub) (void)hipFree(t.d_sub);
+    t = ColourTable();
+}
+
+// Cost model (seconds per iteration, MI355X, measured constants -- DESIGN.md section 4):
+//   brute force : n * (13.3 k + 240) VALU slots / 5.5e13 per second
+//   colour table: ~1e-4 fixed (candidates + cube pass) + n * 1.4e-11 for the label gather when labels
+//                 are materialised + the one-off histogram (n * 5e-11) spread over >= 10 passes
+static bool table_pays(uint64_t n, uint32_t k, bool labels)
+{
+    if (const char *e = getenv("KMG_STRATEGY")) {
+        if (!strcmp(e, "brute")) return false;
+        if (!strcmp(e, "table")) return true;
+    }
+    const double brute = (double)n * (13.3 * k + 240.0) / 5.5e13;
+    const double table = 1.0e-4 + (double)n * ((labels ? 1.4e-11 : 0.0) + 5.0e-12);
+    return table < brute;
+}
+
+static int ensure_bounds(kmg_processor *p, hipStream_t st)
+{
+    std::lock_guard<std::mutex> lock(p->mu);
+    if (p->d_bounds) return KMG_OK;
+    CellBounds *b = nullptr;
+    HIP_TRY(hipMalloc((void **)&b, sizeof(CellBounds) * kCells));
+    hipError_t e = launch_cell_bounds(p->d_lut, b, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { (void)hipFree(b); return fail(KMG_ERR_HIP, "cell bounds failed: %s", hipGetErrorString(e)); }
+    p->d_bounds = b;
+    return KMG_OK;
+}
+
+extern "C" int kmg_lloyd_bind_image(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, void *stream)
+{
+    if (!s || !d_rgba || n == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad bind_image arguments");
+    HIP_TRY(hipSetDevice(s->p->device));
+    int rc;
+    if ((rc = ensure_bounds(s->p, S(stream))) != KMG_OK) return rc;
+    ColourTable &t = s->tab;
+    const uint32_t words = mask_words(s->k);
+    if (!t.d_hist) {
+        hipError_t e = hipMalloc((void **)&t.d_hist, sizeof(uint32_t) << 24);
+        if (e == hipSuccess) e = hipMalloc((void **)&t.d_agg, sizeof(int64_t) * 4ull * kCells);
+        if (e == hipSuccess) e = hipMalloc((void **)&t.d_masks, sizeof(uint64_t) * (size_t)kCells * words);
+        if (e == hipSuccess) e = hipMalloc(&t.d_colour_labels, (size_t)(s->k <= 256 ? 1 : 2) << 24);
+        if (e == hipSuccess) e = hipMalloc((void **)&t.d_sub, sizeof(uint16_t) * kSubCells);
+        if (e != hipSuccess) {
+            free_table(t);
+            return fail(e == hipErrorOutOfMemory ? KMG_ERR_OUT_OF_MEMORY : KMG_ERR_HIP,
+                        "colour table allocation failed: %s", hipGetErrorString(e));
+        }
+    }
+    t.rgba = nullptr;
+    HIP_TRY(hipMemsetAsync(t.d_hist, 0, sizeof(uint32_t) << 24, S(stream)));
+    HIP_TRY(launch_histogram((const uint32_t *)d_rgba, n, t.d_hist, S(stream)));
+    HIP_TRY(launch_cell_aggregates(t.d_hist, s->p->d_lut, t.d_agg, S(stream)));
+    t.rgba = d_rgba;
+    t.n = n;
+    return KMG_OK;
+}
+
+extern "C" int kmg_lloyd_prepare(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, int want_labels, int *strategy, void *stream)
+{
+    if (!s || !d_rgba || n == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad prepare arguments");
+    int chosen = 0;
+    if (table_pays(n, s->k, want_labels != 0)) {
+        int rc = kmg_lloyd_bind_image(s, d_rgba, n, stream);
+        if (rc != KMG_OK) return rc;
+        chosen = 1;
+    } else if (s->tab.rgba == d_rgba) {
+        s->tab.rgba = nullptr;   // the cost model prefers the per-pixel scan for this problem
+    }
+    if (strategy) *strategy = chosen;
+    return KMG_OK;
+}
+
+extern "C" int kmg_lloyd_unbind_image(kmg_lloyd *s)
+{
+    if (!s) return fail(KMG_ERR_INVALID_ARGUMENT, "bad unbind_image arguments");
+    HIP_TRY(hipSetDevice(s->p->device));
+    HIP_TRY(hipDeviceSynchronize());
+    free_table(s->tab);
+    return KMG_OK;
+}
+
+// test support: exhaustive validation of the interval bounds and candidate masks for the current
+// centroid table over all 2^24 colours.  out[0] = range violations, out[1] = mask violations.
+extern "C" int kmg_debug_check_table(kmg_lloyd *s, uint64_t out[2], void *stream)
+{
+    if (!s || !out) return fail(KMG_ERR_INVALID_ARGUMENT, "bad check_table arguments");
+    HIP_TRY(hipSetDevice(s->p->device));
+    int rc;
+    if ((rc = ensure_bounds(s->p, S(stream))) != KMG_OK) return rc;
+    const uint32_t words = mask_words(s->k);
+    DevBuf masks, viol;
+    HIP_TRY(masks.alloc(sizeof(uint64_t) * (size_t)kCells * words));
+    HIP_TRY(viol.alloc(2 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(viol.ptr, 0, 2 * sizeof(unsigned long long), S(stream)));
+    HIP_TRY(launch_cell_candidates(s->p->d_bounds, nullptr, s->d_cent, s->k, (uint64_t *)masks.ptr, S(stream)));
+    HIP_TRY(launch_check_bounds(s->p->d_bounds, s->d_cent, s->k, (const uint64_t *)masks.ptr, s->p->d_lut,
+                                (unsigned long long *)viol.ptr, S(stream)));
+    unsigned long long h[2];
+    HIP_TRY(hipMemcpyAsync(h, viol.ptr, sizeof h, hipMemcpyDeviceToHost, S(stream)));
+    HIP_TRY(hipStreamSynchronize(S(stream)));
+    out[0] = h[0]; out[1] = h[1];
+    return KMG_OK;
+}
+
+static bool table_bound(const kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n)
+{
+    return s->tab.rgba != nullptr && s->tab.rgba == d_rgba && s->tab.n == n;
+}
+
+// labels (optional) + partial sums through the colour table
+static int table_assign(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_t *d_labels, bool sums, hipStream_t st)
+{
+    ColourTable &t = s->tab;
+    (void)sums;
+    HIP_TRY(launch_cell_candidates(s->p->d_bounds, t.d_agg, s->d_cent, s->k, t.d_masks, st));
+    HIP_TRY(launch_cube(t.d_hist, t.d_agg, t.d_masks, s->d_cent, s->k, s->p->d_lut, t.d_colour_labels, t.d_sub,
+                        s->d_partials, st));
+    if (d_labels) HIP_TRY(launch_labels((const uint32_t *)d_rgba, n, t.d_colour_labels, s->k, d_labels, st));
+    return KMG_OK;
+}
+
 extern "C" int kmg_lloyd_create(kmg_processor *p, uint32_t k, kmg_lloyd **out)
 {
     if (!p || !out) return fail(KMG_ERR_INVALID_ARGUMENT, "bad lloyd_create arguments");
@@ -214,9 +381,10 @@ extern "C" int kmg_lloyd_create(kmg_processor *p, uint32_t k, kmg_lloyd **out)
     HIP_TRY(hipSetDevice(p->device));
     kmg_lloyd *s = new (std::nothrow) kmg_lloyd();
     if (!s) return fail(KMG_ERR_OUT_OF_MEMORY, "host allocation failed");
-    memset(s, 0, sizeof *s);
     s->p = p;
     s->k = k;
+    s->d_cent = nullptr; s->d_partials = nullptr; s->d_acc = nullptr; s->d_nconv = nullptr;
+    s->d_key = nullptr; s->d_dist = nullptr; s->dist_cap = 0; s->last_rows = 0;
     hipError_t e = hipMalloc((void **)&s->d_cent, sizeof(Centroid) * k);
     if (e == hipSuccess) e = hipMemset(s->d_cent, 0, sizeof(Centroid) * k);   // structures.rs:501-521
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_partials, sizeof(int64_t) * 4ull * k * 2048ull);
@@ -243,6 +411,7 @@ extern "C" void kmg_lloyd_destroy(kmg_lloyd *s)
     if (s->d_nconv) (void)hipFree(s->d_nconv);
     if (s->d_key) (void)hipFree(s->d_key);
     if (s->d_dist) (void)hipFree(s->d_dist);
+    free_table(s->tab);
     delete s;
 }
 
@@ -299,15 +468,30 @@ extern "C" int kmg_lloyd_init_centroids(kmg_lloyd *s, const uint8_t *d_rgba, uin
     return KMG_OK;
 }
 
+// One pass: labels and/or the partial sums of the current centroid table.  Uses the colour table
+// when this image is bound (kmg_lloyd_bind_image), the per-pixel scan otherwise; both give the
+// same labels and the same integer sums.
+static int assign_pass(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_t *d_labels, bool sums, hipStream_t st)
+{
+    if (table_bound(s, d_rgba, n)) {
+        s->last_rows = kCubeGrid;
+        return table_assign(s, d_rgba, n, d_labels, sums, st);
+    }
+    s->last_rows = assign_grid(n);
+    HIP_TRY(launch_assign((const uint32_t *)d_rgba, n, s->d_cent, s->k, s->p->d_lut, d_labels,
+                          sums ? s->d_partials : nullptr, st));
+    return KMG_OK;
+}
+
 extern "C" int kmg_lloyd_assign_accumulate(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_t *d_labels,
                                            int64_t *d_acc4, void *stream)
 {
     if (!s || !d_rgba || n == 0 || (!d_labels && !d_acc4))
         return fail(KMG_ERR_INVALID_ARGUMENT, "bad assign_accumulate arguments");
     HIP_TRY(hipSetDevice(s->p->device));
-    HIP_TRY(launch_assign((const uint32_t *)d_rgba, n, s->d_cent, s->k, s->p->d_lut, d_labels,
-                          d_acc4 ? s->d_partials : nullptr, S(stream)));
-    if (d_acc4) HIP_TRY(launch_reduce_partials(s->d_partials, assign_grid(n), s->k, d_acc4, S(stream)));
+    int rc;
+    if ((rc = assign_pass(s, d_rgba, n, d_labels, d_acc4 != nullptr, S(stream))) != KMG_OK) return rc;
+    if (d_acc4) HIP_TRY(launch_reduce_partials(s->d_partials, s->last_rows, s->k, d_acc4, S(stream)));
     return KMG_OK;
 }
 
@@ -315,15 +499,15 @@ extern "C" int kmg_lloyd_assign_partials(kmg_lloyd *s, const uint8_t *d_rgba, ui
 {
     if (!s || !d_rgba || n == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad assign_partials arguments");
     HIP_TRY(hipSetDevice(s->p->device));
-    HIP_TRY(launch_assign((const uint32_t *)d_rgba, n, s->d_cent, s->k, s->p->d_lut, d_labels, s->d_partials, S(stream)));
-    return KMG_OK;
+    return assign_pass(s, d_rgba, n, d_labels, true, S(stream));
 }
 
 extern "C" int kmg_lloyd_reduce_partials(kmg_lloyd *s, uint64_t n, int64_t *d_acc4, void *stream)
 {
     if (!s || !d_acc4 || n == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad reduce_partials arguments");
+    if (s->last_rows == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "reduce_partials without a preceding assign_partials");
     HIP_TRY(hipSetDevice(s->p->device));
-    HIP_TRY(launch_reduce_partials(s->d_partials, assign_grid(n), s->k, d_acc4, S(stream)));
+    HIP_TRY(launch_reduce_partials(s->d_partials, s->last_rows, s->k, d_acc4, S(stream)));
     return KMG_OK;
 }
 
@@ -350,6 +534,9 @@ extern "C" int kmg_lloyd_run(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, ui
     if (!s || !d_rgba || n == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad lloyd_run arguments");
     const kmg_options &o = s->p->opt;
     int rc;
+    // large problems iterate over the image's colour table instead of its pixels (same results)
+    if (!table_bound(s, d_rgba, n))
+        if ((rc = kmg_lloyd_prepare(s, d_rgba, n, d_labels != nullptr, nullptr, stream)) != KMG_OK) return rc;
     // operations.rs:75-83 initial assignment (fused with the sums the first update needs)
     if ((rc = kmg_lloyd_assign_accumulate(s, d_rgba, n, d_labels, s->d_acc, stream)) != KMG_OK) return rc;
     uint32_t it = 0;
@@ -421,17 +608,6 @@ extern "C" int kmg_dev_apply(kmg_processor *p, const uint8_t *d_rgba, uint32_t w
 // host-buffer API (ImageProcessor::{palette, find, reduce})
 // ---------------------------------------------------------------------------------------------
 namespace {
-
-struct DevBuf {
-    void *ptr = nullptr;
-    ~DevBuf() { if (ptr) (void)hipFree(ptr); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&ptr, bytes); }
-};
-
-struct StreamGuard {
-    hipStream_t st = nullptr;
-    ~StreamGuard() { if (st) (void)hipStreamDestroy(st); }
-};
 
 struct LloydGuard {
     kmg_lloyd *s = nullptr;

@@ -1,0 +1,80 @@
+// kmg_table.h -- the colour-table strategy of the Lloyd iteration (internal to libkmeans_hip).
+//
+// Labels are a pure function of the 24-bit colour (alpha is ignored, rgb_to_lab.wgsl:78) and the
+// per-cluster sums are exact integers, so for a large image the iteration can run over the
+// image's colour histogram instead of its pixels and still give bit-identical labels, sums and
+// centroids:
+//   bind (once per image)  : hist[2^24] (u32 counts, cell-major colour order) + per-cell sums
+//   per iteration          : 1. k_cell_candidates -- for each 8x8x8 colour cell, a conservative
+//                                superset of the centroids that can be the arg-min of any colour
+//                                in the cell (float-monotone interval bounds, no epsilons)
+//                             2. k_cube -- per cell: one candidate -> the whole cell goes to it
+//                                (precomputed cell sums); otherwise every colour is scanned
+//                                against the candidates only.  Writes label-per-colour (LUT)
+//                                and the per-workgroup partial sums.
+//                             3. k_labels -- labels[i] = LUT[colour(pixel i)]  (4 B in, 4 B out)
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kmg_kernels.h"
+
+namespace kmg {
+
+constexpr uint32_t kCells = 32768;        // 32^3 cells of 8x8x8 colours
+constexpr uint32_t kCellColours = 512;
+constexpr uint32_t kSubCells = kCells * 8;  // 4x4x4 sub-cells (64 colours)
+constexpr uint32_t kCubeGrid = 2048;      // persistent workgroups of k_cube (rows of the partial slab)
+
+// sub-cell table entry (u16): a label, or one of
+constexpr uint16_t kSubEmpty = 0xFFFF;    // no pixel of the image has a colour in this sub-cell
+constexpr uint16_t kSubMixed = 0xFFFE;    // occupied colours of the sub-cell carry different labels
+
+// Range of the per-pixel quantities of kmg_math.h over the 512 colours of a cell (exact float
+// minima / maxima), image independent.
+struct alignas(16) CellBounds {
+    float L0, L1, a0, a1, b0, b1, C0, C1, wC0, wC1, wH0, wH1;
+    float pad[4];
+};
+
+// colour index = [r7..r3 g7..g3 b7..b3][r2 g2 b2][r1 r0 g1 g0 b1 b0]: cell-major, sub-cell-major
+__host__ __device__ inline uint32_t colour_index(uint32_t px)
+{
+    const uint32_t r = px & 255u, g = (px >> 8) & 255u, b = (px >> 16) & 255u;
+    return ((r >> 3) << 19) | ((g >> 3) << 14) | ((b >> 3) << 9) |
+           (((r >> 2) & 1u) << 8) | (((g >> 2) & 1u) << 7) | (((b >> 2) & 1u) << 6) |
+           ((r & 3u) << 4) | ((g & 3u) << 2) | (b & 3u);
+}
+
+__host__ __device__ inline void index_to_rgb(uint32_t idx, uint32_t &r, uint32_t &g, uint32_t &b)
+{
+    r = (((idx >> 19) & 31u) << 3) | (((idx >> 8) & 1u) << 2) | ((idx >> 4) & 3u);
+    g = (((idx >> 14) & 31u) << 3) | (((idx >> 7) & 1u) << 2) | ((idx >> 2) & 3u);
+    b = (((idx >> 9) & 31u) << 3) | (((idx >> 6) & 1u) << 2) | (idx & 3u);
+}
+
+inline uint32_t mask_words(uint32_t k) { return (k + 63u) / 64u; }
+
+// once per processor: bounds[kCells]
+hipError_t launch_cell_bounds(const float *lut, CellBounds *bounds, hipStream_t st);
+// once per image: hist[2^24] must be zero on entry
+hipError_t launch_histogram(const uint32_t *rgba, uint64_t n, uint32_t *hist, hipStream_t st);
+// once per image: agg[kCells][4] = (sum qL, sum qa, sum qb, count) of the image's pixels per cell
+hipError_t launch_cell_aggregates(const uint32_t *hist, const float *lut, int64_t *agg, hipStream_t st);
+// per iteration
+hipError_t launch_cell_candidates(const CellBounds *bounds, const int64_t *agg, const Centroid *cent,
+                                  uint32_t k, uint64_t *masks, hipStream_t st);
+hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const uint64_t *masks,
+                       const Centroid *cent, uint32_t k, const float *lut, void *colour_labels,
+                       uint16_t *sub_table, int64_t *partials, hipStream_t st);
+hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_labels, uint32_t k,
+                         uint32_t *labels, hipStream_t st);
+
+// debug / test support: number of (cell, centroid, colour) triples whose key falls outside the
+// interval bounds, and number of colours whose brute-force arg-min is missing from the cell mask
+hipError_t launch_check_bounds(const CellBounds *bounds, const Centroid *cent, uint32_t k,
+                               const uint64_t *masks, const float *lut, unsigned long long *violations,
+                               hipStream_t st);
+
+}  // namespace kmg

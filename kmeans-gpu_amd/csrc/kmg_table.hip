@@ -1,0 +1,479 @@
+// kmg_table.hip -- gfx950 kernels of the colour-table strategy (see kmg_table.h).
+//
+// Exactness argument (tests/test_gpu_table.py checks every step against the brute-force scan):
+//  * key_range() bounds the FLOAT value cie94_key() returns for any colour of a cell: every
+//    operation of cie94_key is monotone in each operand (IEEE rounding is monotone), so evaluating
+//    the same operations on interval end points gives rigorous bounds without any epsilon.
+//  * a centroid can be the arg-min of some colour of the cell only if its lower bound does not
+//    exceed U = min_j upper_j; the candidate mask keeps exactly those, in index order, so the
+//    strict-'<' first-minimum-wins scan over the candidates returns the brute-force label.
+//  * sums are exact integers: sum over colours of count * q equals the per-pixel sum of q.
+// Compile with -ffp-contract=off.
+
+#include "kmg_table.h"
+#include "kmg_device.h"
+
+namespace kmg {
+
+namespace {
+
+struct KeyRange { float lo, hi; };
+
+__device__ __forceinline__ void abs_range(float x0, float x1, float c, float &m, float &M)
+{
+    const float d0 = x0 - c, d1 = x1 - c;                  // d0 <= d1 (rounding is monotone)
+    M = fmaxf(fabsf(d0), fabsf(d1));
+    m = d0 > 0.0f ? d0 : (d1 < 0.0f ? -d1 : 0.0f);
+}
+
+// [min, max] of cie94_key(pixel, c) over all pixels whose terms lie inside the cell bounds
+__device__ __forceinline__ KeyRange key_range(const CellBounds &cb, float L2, float a2, float b2, float C2)
+{
+    float mL, ML, ma, Ma, mb, Mb, mC, MC;
+    abs_range(cb.L0, cb.L1, L2, mL, ML);
+    abs_range(cb.a0, cb.a1, a2, ma, Ma);
+    abs_range(cb.b0, cb.b1, b2, mb, Mb);
+    abs_range(cb.C0, cb.C1, C2, mC, MC);
+    const float A0 = mL * mL, A1 = ML * ML;                // dL*dL
+    const float D0 = mC * mC, D1 = MC * MC;                // dC2
+    const float t0 = fmaf(mb, mb, ma * ma), t1 = fmaf(Mb, Mb, Ma * Ma);
+    const float h0 = fmaxf(t0 - D1, 0.0f), h1 = fmaxf(t1 - D0, 0.0f);
+    KeyRange r;
+    r.lo = fmaf(h0, cb.wH0, fmaf(D0, cb.wC0, A0));
+    r.hi = fmaf(h1, cb.wH1, fmaf(D1, cb.wC1, A1));
+    return r;
+}
+
+__device__ __forceinline__ void colour_to_lab(const float *s_lut, uint32_t idx, float &L, float &a, float &b)
+{
+    uint32_t r, g, bl;
+    index_to_rgb(idx, r, g, bl);
+    linear100_to_lab(s_lut[r], s_lut[g], s_lut[bl], L, a, b);
+}
+
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v)
+{
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__device__ __forceinline__ long long wave_sum(long long v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// static cell bounds (once per processor): one workgroup per cell, two colours per thread
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_cell_bounds(const float *__restrict__ lut,
+                                                        CellBounds *__restrict__ bounds)
+{
+    __shared__ float s_lut[256];
+    __shared__ float s_min[6][kBlock / 64], s_max[6][kBlock / 64];
+    s_lut[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    float mn[6], mx[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) { mn[q] = 3.0e38f; mx[q] = -3.0e38f; }
+    for (uint32_t c = threadIdx.x; c < kCellColours; c += kBlock) {
+        float L, a, b;
+        colour_to_lab(s_lut, blockIdx.x * kCellColours + c, L, a, b);
+        const PixelTerms p = pixel_terms(L, a, b);
+        const float v[6] = {p.L, p.a, p.b, p.C, p.wC, p.wH};
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { mn[q] = fminf(mn[q], v[q]); mx[q] = fmaxf(mx[q], v[q]); }
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+        for (int off = 32; off > 0; off >>= 1) {
+            mn[q] = fminf(mn[q], __shfl_down(mn[q], off, 64));
+            mx[q] = fmaxf(mx[q], __shfl_down(mx[q], off, 64));
+        }
+    if ((threadIdx.x & 63) == 0)
+        for (int q = 0; q < 6; ++q) { s_min[q][threadIdx.x >> 6] = mn[q]; s_max[q][threadIdx.x >> 6] = mx[q]; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float lo[6], hi[6];
+        for (int q = 0; q < 6; ++q) {
+            lo[q] = s_min[q][0]; hi[q] = s_max[q][0];
+            for (int w = 1; w < kBlock / 64; ++w) { lo[q] = fminf(lo[q], s_min[q][w]); hi[q] = fmaxf(hi[q], s_max[q][w]); }
+        }
+        CellBounds cb;
+        cb.L0 = lo[0]; cb.L1 = hi[0]; cb.a0 = lo[1]; cb.a1 = hi[1]; cb.b0 = lo[2]; cb.b1 = hi[2];
+        cb.C0 = lo[3]; cb.C1 = hi[3]; cb.wC0 = lo[4]; cb.wC1 = hi[4]; cb.wH0 = lo[5]; cb.wH1 = hi[5];
+        cb.pad[0] = cb.pad[1] = cb.pad[2] = cb.pad[3] = 0.0f;
+        bounds[blockIdx.x] = cb;
+    }
+}
+
+hipError_t launch_cell_bounds(const float *lut, CellBounds *bounds, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_cell_bounds, dim3(kCells), dim3(kBlock), 0, st, lut, bounds);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// histogram of the image's colours (once per image), cell-major order
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_histogram(const uint32_t *__restrict__ rgba, uint64_t n,
+                                                      uint32_t *__restrict__ hist, int aligned)
+{
+    constexpr uint64_t TILE = (uint64_t)kBlock * 8;
+    const uint64_t tiles = (n + TILE - 1) / TILE;
+    for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const uint64_t i0 = tile * TILE + (uint64_t)g * (kBlock * 4) + (uint64_t)threadIdx.x * 4;
+            uint32_t px[4];
+            load4(rgba, i0, n, aligned != 0, px);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (i0 + q < n) atomicAdd(hist + colour_index(px[q]), 1u);
+        }
+    }
+}
+
+hipError_t launch_histogram(const uint32_t *rgba, uint64_t n, uint32_t *hist, hipStream_t st)
+{
+    const uint64_t tiles = (n + kBlock * 8 - 1) / (kBlock * 8);
+    const uint32_t grid = (uint32_t)(tiles < 4096 ? (tiles ? tiles : 1) : 4096);
+    const int aligned = (reinterpret_cast<uintptr_t>(rgba) & 15u) == 0 ? 1 : 0;
+    hipLaunchKernelGGL(k_histogram, dim3(grid), dim3(kBlock), 0, st, rgba, n, hist, aligned);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// per-cell sums of the image (once per image): one wave per cell, 8 colours per lane
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_cell_aggregates(const uint32_t *__restrict__ hist,
+                                                            const float *__restrict__ lut,
+                                                            int64_t *__restrict__ agg)
+{
+    __shared__ float s_lut[256];
+    s_lut[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    const uint32_t cell = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t base = cell * kCellColours + lane * 8;
+    const uint4 c0 = *reinterpret_cast<const uint4 *>(hist + base);
+    const uint4 c1 = *reinterpret_cast<const uint4 *>(hist + base + 4);
+    const uint32_t cnt[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    long long s[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        if (cnt[q]) {
+            float L, a, b;
+            colour_to_lab(s_lut, base + q, L, a, b);
+            const long long m = (long long)cnt[q];
+            s[0] += m * (long long)lab_fix(L);
+            s[1] += m * (long long)lab_fix(a);
+            s[2] += m * (long long)lab_fix(b);
+            s[3] += m;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[j] = wave_sum(s[j]);
+    if (lane == 0)
+        for (int j = 0; j < 4; ++j) agg[4ull * cell + j] = s[j];
+}
+
+hipError_t launch_cell_aggregates(const uint32_t *hist, const float *lut, int64_t *agg, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_cell_aggregates, dim3(kCells / (kBlock / 64)), dim3(kBlock), 0, st, hist, lut, agg);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// candidate masks (per iteration): one wave per cell, lanes strided over the centroids
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_cell_candidates(const CellBounds *__restrict__ bounds,
+                                                            const int64_t *__restrict__ agg,
+                                                            const Centroid *__restrict__ cent, uint32_t k,
+                                                            uint64_t *__restrict__ masks)
+{
+    const uint32_t cell = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t words = (k + 63u) / 64u;
+    uint64_t *out = masks + (uint64_t)cell * words;
+    if (agg && agg[4ull * cell + 3] == 0) {                 // no pixel in this cell
+        for (uint32_t w = lane; w < words; w += 64) out[w] = 0ull;
+        return;
+    }
+    const CellBounds cb = bounds[cell];
+    float U = 3.0e38f;
+    for (uint32_t j = lane; j < k; j += 64) {
+        const Centroid c = cent[j];
+        U = fminf(U, key_range(cb, c.L, c.a, c.b, c.C).hi);
+    }
+    for (int off = 32; off > 0; off >>= 1) U = fminf(U, __shfl_xor(U, off, 64));
+    for (uint32_t w = 0; w < words; ++w) {
+        const uint32_t j = w * 64 + lane;
+        bool keep = false;
+        if (j < k) {
+            const Centroid c = cent[j];
+            keep = key_range(cb, c.L, c.a, c.b, c.C).lo <= U;
+        }
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) out[w] = m;
+    }
+}
+
+hipError_t launch_cell_candidates(const CellBounds *bounds, const int64_t *agg, const Centroid *cent,
+                                  uint32_t k, uint64_t *masks, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_cell_candidates, dim3(kCells / (kBlock / 64)), dim3(kBlock), 0, st, bounds, agg,
+                       cent, k, masks);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// cube pass (per iteration): one wave per cell, 8 colours (= 1/8 of a 4x4x4 sub-cell) per lane
+// LDS: [centroids kpad x 16 B][bins k x 32 B][sRGB table 1 KiB]
+// ------------------------------------------------------------------------------------------
+template <typename LabelT>
+__global__ __launch_bounds__(kBlock) void k_cube(const uint32_t *__restrict__ hist,
+                                                 const int64_t *__restrict__ agg,
+                                                 const uint64_t *__restrict__ masks,
+                                                 const Centroid *__restrict__ cent, uint32_t k,
+                                                 const float *__restrict__ lut,
+                                                 LabelT *__restrict__ colour_labels,
+                                                 uint16_t *__restrict__ sub_table,
+                                                 int64_t *__restrict__ partials)
+{
+    extern __shared__ float4 smem4[];
+    const uint32_t kpad = (k + 3u) & ~3u;
+    float4 *s_cent = smem4;
+    unsigned long long *bins = reinterpret_cast<unsigned long long *>(smem4 + kpad);
+    float *s_lut = reinterpret_cast<float *>(bins + 4ull * k);
+
+    s_lut[threadIdx.x] = lut[threadIdx.x];
+    stage_centroids(s_cent, cent, k, kpad);
+    for (uint32_t i = threadIdx.x; i < 4 * k; i += kBlock) bins[i] = 0ull;
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t words = (k + 63u) / 64u;
+    const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * (kBlock / 64);
+
+    for (uint32_t cell = wave; cell < kCells; cell += n_waves) {
+        const long long cell_count = (long long)uniform_u64((unsigned long long)agg[4ull * cell + 3]);
+        uint16_t *sub = sub_table + cell * 8u;
+        if (cell_count == 0) {
+            if (lane < 8) sub[lane] = kSubEmpty;
+            continue;
+        }
+        const uint64_t *mw = masks + (uint64_t)cell * words;
+        uint32_t npop = 0, first = 0;
+        for (uint32_t w = 0; w < words; ++w) {
+            const unsigned long long m = uniform_u64(mw[w]);
+            if (npop == 0 && m) first = w * 64 + (uint32_t)__builtin_ctzll(m);
+            npop += (uint32_t)__builtin_popcountll(m);
+        }
+        const uint32_t base = cell * kCellColours + lane * 8;
+
+        if (npop == 1) {
+            // the whole cell belongs to `first`: labels for its 512 colours, sums from the cell table
+            LabelT v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = (LabelT)first;
+            if (sizeof(LabelT) == 1)
+                *reinterpret_cast<uint2 *>(colour_labels + base) = *reinterpret_cast<uint2 *>(v);
+            else
+                *reinterpret_cast<uint4 *>(colour_labels + base) = *reinterpret_cast<uint4 *>(v);
+            if (lane < 8) sub[lane] = (uint16_t)first;
+            if (lane < 4) atomicAdd(bins + 4ull * first + lane, (unsigned long long)agg[4ull * cell + lane]);
+            continue;
+        }
+
+        const uint4 c0 = *reinterpret_cast<const uint4 *>(hist + base);
+        const uint4 c1 = *reinterpret_cast<const uint4 *>(hist + base + 4);
+        const uint32_t cnt[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        float L[8], A[8], B[8];
+        PixelTerms pt[8];
+        float best[8];
+        uint32_t idx[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            colour_to_lab(s_lut, base + q, L[q], A[q], B[q]);
+            pt[q] = pixel_terms(L[q], A[q], B[q]);
+            best[q] = 1.0e10f;                                   // find_centroid.wgsl:29-30
+            idx[q] = 0u;
+        }
+        for (uint32_t w = 0; w < words; ++w) {
+            unsigned long long m = uniform_u64(mw[w]);
+            while (m) {
+                const uint32_t j = w * 64 + (uint32_t)__builtin_ctzll(m);
+                m &= m - 1;
+                const float4 c = s_cent[j];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float d = cie94_key(pt[q], c.x, c.y, c.z, c.w);
+                    const bool lt = d < best[q];
+                    best[q] = lt ? d : best[q];
+                    idx[q] = lt ? j : idx[q];
+                }
+            }
+        }
+        {
+            LabelT v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = (LabelT)idx[q];
+            if (sizeof(LabelT) == 1)
+                *reinterpret_cast<uint2 *>(colour_labels + base) = *reinterpret_cast<uint2 *>(v);
+            else
+                *reinterpret_cast<uint4 *>(colour_labels + base) = *reinterpret_cast<uint4 *>(v);
+        }
+        // sums: merge runs of equal labels inside the lane before touching LDS
+        uint32_t state = kSubEmpty;                              // label / kSubEmpty / kSubMixed
+        {
+            long long s[4] = {0, 0, 0, 0};
+            uint32_t cur = 0xFFFFFFFFu;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (cnt[q]) {
+                    if (idx[q] != cur) {
+                        if (cur != 0xFFFFFFFFu) {
+                            unsigned long long *bin = bins + 4ull * cur;
+                            for (int j = 0; j < 4; ++j) atomicAdd(bin + j, (unsigned long long)s[j]);
+                        }
+                        cur = idx[q];
+                        s[0] = s[1] = s[2] = s[3] = 0;
+                    }
+                    const long long m = (long long)cnt[q];
+                    s[0] += m * (long long)lab_fix(L[q]);
+                    s[1] += m * (long long)lab_fix(A[q]);
+                    s[2] += m * (long long)lab_fix(B[q]);
+                    s[3] += m;
+                    state = (state == kSubEmpty) ? idx[q] : (state == idx[q] ? state : (uint32_t)kSubMixed);
+                }
+            }
+            if (cur != 0xFFFFFFFFu) {
+                unsigned long long *bin = bins + 4ull * cur;
+                for (int j = 0; j < 4; ++j) atomicAdd(bin + j, (unsigned long long)s[j]);
+            }
+        }
+        // sub-cell summary over the 8 lanes that share a 4x4x4 sub-cell
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) {
+            const uint32_t o = __shfl_xor(state, off, 64);
+            state = (state == kSubEmpty) ? o : ((o == kSubEmpty || o == state) ? state : (uint32_t)kSubMixed);
+        }
+        if ((lane & 7u) == 0) sub[lane >> 3] = (uint16_t)state;
+    }
+
+    __syncthreads();
+    unsigned long long *row = reinterpret_cast<unsigned long long *>(partials) + (uint64_t)blockIdx.x * 4ull * k;
+    for (uint32_t i = threadIdx.x; i < 4 * k; i += kBlock) row[i] = bins[i];
+}
+
+hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const uint64_t *masks, const Centroid *cent,
+                       uint32_t k, const float *lut, void *colour_labels, uint16_t *sub_table,
+                       int64_t *partials, hipStream_t st)
+{
+    const uint32_t kpad = (k + 3u) & ~3u;
+    const size_t lds = sizeof(float4) * kpad + sizeof(unsigned long long) * 4ull * k + 256 * sizeof(float);
+    if (k <= 256)
+        hipLaunchKernelGGL(k_cube<uint8_t>, dim3(kCubeGrid), dim3(kBlock), lds, st, hist, agg, masks, cent, k,
+                           lut, (uint8_t *)colour_labels, sub_table, partials);
+    else
+        hipLaunchKernelGGL(k_cube<uint16_t>, dim3(kCubeGrid), dim3(kBlock), lds, st, hist, agg, masks, cent, k,
+                           lut, (uint16_t *)colour_labels, sub_table, partials);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// labels[i] = colour_labels[colour_index(pixel i)]   (find_centroid.wgsl:43 output)
+// ------------------------------------------------------------------------------------------
+template <typename LabelT>
+__global__ __launch_bounds__(kBlock) void k_labels(const uint32_t *__restrict__ rgba, uint64_t n,
+                                                   const LabelT *__restrict__ colour_labels,
+                                                   uint32_t *__restrict__ labels, int aligned)
+{
+    constexpr uint64_t TILE = (uint64_t)kBlock * 8;
+    const uint64_t tiles = (n + TILE - 1) / TILE;
+    for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        uint32_t ci[8];
+        uint64_t i0[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            i0[g] = tile * TILE + (uint64_t)g * (kBlock * 4) + (uint64_t)threadIdx.x * 4;
+            uint32_t px[4];
+            load4(rgba, i0[g], n, aligned != 0, px);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ci[g * 4 + q] = colour_index(px[q]);
+        }
+        uint32_t lab[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) lab[p] = (uint32_t)colour_labels[ci[p]];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) store4(labels, i0[g], n, aligned != 0, lab + g * 4);
+    }
+}
+
+hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_labels, uint32_t k,
+                         uint32_t *labels, hipStream_t st)
+{
+    const uint64_t tiles = (n + kBlock * 8 - 1) / (kBlock * 8);
+    const uint32_t grid = (uint32_t)(tiles < 8192 ? (tiles ? tiles : 1) : 8192);
+    const int aligned = ((reinterpret_cast<uintptr_t>(rgba) & 15u) == 0 &&
+                         (reinterpret_cast<uintptr_t>(labels) & 15u) == 0) ? 1 : 0;
+    if (k <= 256)
+        hipLaunchKernelGGL(k_labels<uint8_t>, dim3(grid), dim3(kBlock), 0, st, rgba, n,
+                           (const uint8_t *)colour_labels, labels, aligned);
+    else
+        hipLaunchKernelGGL(k_labels<uint16_t>, dim3(grid), dim3(kBlock), 0, st, rgba, n,
+                           (const uint16_t *)colour_labels, labels, aligned);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// test support: exhaustive check of the bounds and of the candidate masks over all 2^24 colours
+// violations[0] += #(colour, centroid) pairs with key outside [lo, hi]
+// violations[1] += #colours whose brute-force arg-min is not in the cell's mask
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_check_bounds(const CellBounds *__restrict__ bounds,
+                                                         const Centroid *__restrict__ cent, uint32_t k,
+                                                         const uint64_t *__restrict__ masks,
+                                                         const float *__restrict__ lut,
+                                                         unsigned long long *__restrict__ violations)
+{
+    __shared__ float s_lut[256];
+    s_lut[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    const uint32_t cell = blockIdx.x;
+    const uint32_t words = (k + 63u) / 64u;
+    const CellBounds cb = bounds[cell];
+    unsigned long long bad_range = 0, bad_mask = 0;
+    for (uint32_t c = threadIdx.x; c < kCellColours; c += kBlock) {
+        float L, a, b;
+        colour_to_lab(s_lut, cell * kCellColours + c, L, a, b);
+        const PixelTerms pt = pixel_terms(L, a, b);
+        float best = 1.0e10f;
+        uint32_t idx = 0;
+        for (uint32_t j = 0; j < k; ++j) {
+            const Centroid ce = cent[j];
+            const float d = cie94_key(pt, ce.L, ce.a, ce.b, ce.C);
+            const KeyRange r = key_range(cb, ce.L, ce.a, ce.b, ce.C);
+            if (!(r.lo <= d && d <= r.hi)) ++bad_range;
+            if (d < best) { best = d; idx = j; }
+        }
+        const unsigned long long m = masks[(uint64_t)cell * words + idx / 64u];
+        if (!((m >> (idx & 63u)) & 1ull)) ++bad_mask;
+    }
+    if (bad_range) atomicAdd(violations, bad_range);
+    if (bad_mask) atomicAdd(violations + 1, bad_mask);
+}
+
+hipError_t launch_check_bounds(const CellBounds *bounds, const Centroid *cent, uint32_t k, const uint64_t *masks,
+                               const float *lut, unsigned long long *violations, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_check_bounds, dim3(kCells), dim3(kBlock), 0, st, bounds, cent, k, masks, lut, violations);
+    return hipGetLastError();
+}
+
+}  // namespace kmg

@@ -65,7 +65,8 @@ SYMBOLS = [
     "kmg_palette_to_centroids", "kmg_centroids_to_palette", "kmg_dev_rgb_to_lab", "kmg_resized_dims",
     "kmg_dev_resize", "kmg_lloyd_create", "kmg_lloyd_destroy", "kmg_lloyd_set_centroids",
     "kmg_lloyd_get_centroids", "kmg_lloyd_init_centroids", "kmg_lloyd_assign_accumulate",
-    "kmg_lloyd_assign_partials", "kmg_lloyd_reduce_partials",
+    "kmg_lloyd_assign_partials", "kmg_lloyd_reduce_partials", "kmg_lloyd_bind_image",
+    "kmg_lloyd_unbind_image", "kmg_lloyd_prepare", "kmg_debug_check_table",
     "kmg_lloyd_update", "kmg_lloyd_converged_count", "kmg_lloyd_run", "kmg_dev_apply",
     "kmg_dither_threshold",
 ]
@@ -116,6 +117,10 @@ def lib():
     L.kmg_lloyd_assign_accumulate.argtypes = [vp, u8p, C.c_uint64, u32p, i64p, vp]
     L.kmg_lloyd_assign_partials.argtypes = [vp, u8p, C.c_uint64, u32p, vp]
     L.kmg_lloyd_reduce_partials.argtypes = [vp, C.c_uint64, i64p, vp]
+    L.kmg_lloyd_bind_image.argtypes = [vp, u8p, C.c_uint64, vp]
+    L.kmg_lloyd_unbind_image.argtypes = [vp]
+    L.kmg_lloyd_prepare.argtypes = [vp, u8p, C.c_uint64, C.c_int, C.POINTER(C.c_int), vp]
+    L.kmg_debug_check_table.argtypes = [vp, C.POINTER(C.c_uint64), vp]
     L.kmg_lloyd_update.argtypes = [vp, i64p, vp]
     L.kmg_lloyd_converged_count.argtypes = [vp, C.POINTER(C.c_uint32), vp]
     L.kmg_lloyd_run.argtypes = [vp, u8p, C.c_uint64, u32p, C.POINTER(C.c_uint32), vp]
@@ -297,6 +302,25 @@ class Lloyd:
 
     def reduce_partials(self, n_pixels, d_acc4, stream=0):
         _check(lib().kmg_lloyd_reduce_partials(self._h, n_pixels, C.c_void_p(d_acc4), C.c_void_p(stream)))
+
+    def bind_image(self, d_rgba, n_pixels, stream=0):
+        """build the colour table of this image once; later passes on it use the table"""
+        _check(lib().kmg_lloyd_bind_image(self._h, C.c_void_p(d_rgba), n_pixels, C.c_void_p(stream)))
+
+    def prepare(self, d_rgba, n_pixels, want_labels=True, stream=0):
+        """one-time per-image preparation; returns the chosen strategy ("scan" or "table")"""
+        st = C.c_int()
+        _check(lib().kmg_lloyd_prepare(self._h, C.c_void_p(d_rgba), n_pixels, int(bool(want_labels)),
+                                       C.byref(st), C.c_void_p(stream)))
+        return "table" if st.value == 1 else "scan"
+
+    def unbind_image(self):
+        _check(lib().kmg_lloyd_unbind_image(self._h))
+
+    def debug_check_table(self, stream=0):
+        out = (C.c_uint64 * 2)()
+        _check(lib().kmg_debug_check_table(self._h, out, C.c_void_p(stream)))
+        return int(out[0]), int(out[1])
 
     def update(self, d_acc4, stream=0):
         _check(lib().kmg_lloyd_update(self._h, C.c_void_p(d_acc4), C.c_void_p(stream)))

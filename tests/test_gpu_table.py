@@ -1,0 +1,148 @@
+"""GPU tests of the colour-table strategy: it must reproduce the per-pixel scan (and therefore the
+oracle) bit-for-bit -- labels, int64 sums, centroids, iteration count -- and its interval bounds /
+candidate masks must be conservative for every one of the 2^24 colours."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _stream(torch):
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _blobs(rng, n, centres, sigma=12.0):
+    c = rng.integers(0, 256, (centres, 3))
+    px = c[rng.integers(0, centres, n)] + rng.normal(0, sigma, (n, 3))
+    out = np.full((n, 4), 255, np.uint8)
+    out[:, :3] = np.clip(np.rint(px), 0, 255).astype(np.uint8)
+    return out
+
+
+def _centroid_sets(oracle, rng):
+    """centroid tables that stress the bounds: random Lab of real colours, clustered, grey axis,
+    duplicates, far outside the gamut"""
+    px = rng.integers(0, 256, (300, 4), dtype=np.uint8)
+    lab = oracle.rgb_to_lab(px)
+    sets = {"random256": lab[:256], "random16": lab[:16], "single": lab[:1], "k300": lab[:300]}
+    grey = np.stack([np.linspace(0, 100, 64), np.zeros(64), np.zeros(64)], 1).astype(np.float32)
+    sets["grey64"] = grey
+    sets["duplicates"] = np.concatenate([lab[:8], lab[:8], lab[3:4]])
+    sets["tight"] = (lab[5] + rng.normal(0, 0.5, (40, 3))).astype(np.float32)
+    sets["outside"] = np.array([[150, 0, 0], [-50, 0, 0], [50, 300, -300], [50, 0.001, -0.001]], np.float32)
+    return {k: oracle.centroids4(v) for k, v in sets.items()}
+
+
+def test_bounds_and_masks_conservative_for_all_colours(torch_cuda, processor, oracle):
+    import kmeans_gpu_amd as kg
+    rng = np.random.default_rng(11)
+    for name, cent in _centroid_sets(oracle, rng).items():
+        s = kg.Lloyd(processor, cent.shape[0])
+        s.set_centroids(cent)
+        bad_range, bad_mask = s.debug_check_table(_stream(torch_cuda))
+        assert (bad_range, bad_mask) == (0, 0), name
+        s.close()
+
+
+@pytest.mark.parametrize("kind,n,k", [("uniform", 300_001, 16), ("uniform", 1_000_003, 256), ("uniform", 65_536, 300),
+                                      ("blobs", 700_000, 64), ("flat", 100_000, 5), ("tokyo", 0, 8), ("tokyo", 0, 46)])
+def test_table_pass_equals_pixel_scan(torch_cuda, processor, oracle, tokyo, kind, n, k):
+    import kmeans_gpu_amd as kg
+    torch = torch_cuda
+    rng = np.random.default_rng(n + k)
+    if kind == "uniform":
+        rgba = oracle.synth_uniform(n * 7 + k, n)
+    elif kind == "blobs":
+        rgba = _blobs(rng, n, 20)
+    elif kind == "flat":
+        rgba = np.tile(np.array([[12, 200, 77, 255], [12, 200, 78, 255], [0, 0, 0, 255]], np.uint8), (n // 3 + 1, 1))[:n]
+    else:
+        rgba = tokyo.reshape(-1, 4)
+    n = rgba.shape[0]
+    lab = oracle.rgb_to_lab(rgba)
+    cent = oracle.centroids4(lab[rng.choice(n, k, replace=False)])
+    d = _dev(torch, rgba)
+    st = _stream(torch)
+
+    def run(bind):
+        s = kg.Lloyd(processor, k)
+        s.set_centroids(cent)
+        if bind:
+            s.bind_image(d.data_ptr(), n, st)
+        labels = torch.zeros(n, dtype=torch.int32, device="cuda")
+        acc = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
+        out = []
+        for _ in range(3):                       # three Lloyd iterations
+            s.assign_accumulate(d.data_ptr(), n, labels.data_ptr(), acc.data_ptr(), st)
+            torch.cuda.synchronize()
+            out.append((labels.cpu().numpy().copy(), acc.cpu().numpy().copy()))
+            s.update(acc.data_ptr(), st)
+        c = s.get_centroids(st)
+        s.close()
+        return out, c
+
+    brute, c_brute = run(False)
+    table, c_table = run(True)
+    for (lb, ab), (lt, at) in zip(brute, table):
+        assert np.array_equal(lb, lt)
+        assert np.array_equal(ab, at)
+    assert np.array_equal(c_brute.view(np.uint32), c_table.view(np.uint32))
+    # and the first pass against the oracle itself
+    wl, wa = oracle.assign_accumulate_rgba(rgba, cent)
+    assert np.array_equal(table[0][0].view(np.uint32), wl) and np.array_equal(table[0][1], wa)
+
+
+def test_table_sums_only_and_labels_only(torch_cuda, processor, oracle):
+    import kmeans_gpu_amd as kg
+    torch = torch_cuda
+    n, k = 400_000, 33
+    rgba = oracle.synth_uniform(99, n)
+    cent = oracle.centroids4(oracle.rgb_to_lab(rgba[:k]))
+    wl, wa = oracle.assign_accumulate_rgba(rgba, cent)
+    d = _dev(torch, rgba)
+    st = _stream(torch)
+    s = kg.Lloyd(processor, k)
+    s.set_centroids(cent)
+    s.bind_image(d.data_ptr(), n, st)
+    acc = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
+    labels = torch.zeros(n, dtype=torch.int32, device="cuda")
+    s.assign_accumulate(d.data_ptr(), n, 0, acc.data_ptr(), st)
+    s.assign_accumulate(d.data_ptr(), n, labels.data_ptr(), 0, st)
+    torch.cuda.synchronize()
+    assert np.array_equal(acc.cpu().numpy(), wa)
+    assert np.array_equal(labels.cpu().numpy().view(np.uint32), wl)
+    # a different buffer (or length) is not the bound image: falls back to the per-pixel scan
+    s.assign_accumulate(d.data_ptr(), n - 5, labels.data_ptr(), acc.data_ptr(), st)
+    torch.cuda.synchronize()
+    wl2, wa2 = oracle.assign_accumulate_rgba(rgba[:n - 5], cent)
+    assert np.array_equal(acc.cpu().numpy(), wa2)
+    s.unbind_image()
+    s.close()
+
+
+def test_lloyd_run_with_table_matches_oracle(torch_cuda, oracle, monkeypatch):
+    """the whole loop (init on device, table strategy forced) == oracle, full-resolution mode"""
+    import kmeans_gpu_amd as kg
+    torch = torch_cuda
+    monkeypatch.setenv("KMG_STRATEGY", "table")
+    w, h, k = 640, 480, 12
+    img = _blobs(np.random.default_rng(3), w * h, 9).reshape(h, w, 4)
+    lab = oracle.rgb_to_lab(img)
+    want_c, want_labels, want_it = oracle.lloyd(lab, oracle.init_centroids(lab, w, h, k))
+    p = kg.ImageProcessor(shrink_max_dim=0)
+    d = _dev(torch, img)
+    labels = torch.zeros(w * h, dtype=torch.int32, device="cuda")
+    s = kg.Lloyd(p, k)
+    st = _stream(torch)
+    s.init_centroids(d.data_ptr(), w, h, st)
+    it = s.run(d.data_ptr(), w * h, labels.data_ptr(), st)
+    got_c = s.get_centroids(st)
+    assert it == want_it
+    assert np.array_equal(got_c.view(np.uint32), want_c.view(np.uint32))
+    assert np.array_equal(labels.cpu().numpy().view(np.uint32), want_labels)
+    s.close()
+    p.close()
