@@ -368,7 +368,7 @@ static int table_assign(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_
     HIP_TRY(launch_cell_candidates(s->p->d_bounds, t.d_agg, s->d_cent, s->k, t.d_masks, st));
     HIP_TRY(launch_cube(t.d_hist, t.d_agg, t.d_masks, s->d_cent, s->k, s->p->d_lut, t.d_colour_labels, t.d_sub,
                         s->d_partials, st));
-    if (d_labels) HIP_TRY(launch_labels((const uint32_t *)d_rgba, n, t.d_colour_labels, s->k, d_labels, st));
+    if (d_labels) HIP_TRY(launch_labels((const uint32_t *)d_rgba, n, t.d_colour_labels, t.d_sub, s->k, d_labels, st));
     return KMG_OK;
 }
 

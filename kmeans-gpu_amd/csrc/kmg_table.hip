@@ -389,9 +389,13 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const uint64_t 
 // ------------------------------------------------------------------------------------------
 // labels[i] = colour_labels[colour_index(pixel i)]   (find_centroid.wgsl:43 output)
 // ------------------------------------------------------------------------------------------
+// Two levels: the 512 KiB sub-cell table (one u16 per 4x4x4 colours: the common label of the
+// sub-cell's occupied colours, or kSubMixed) stays L2 resident and answers most pixels; only pixels
+// of mixed sub-cells touch the 16 MiB per-colour table.  Pixel / label streams are non-temporal.
 template <typename LabelT>
 __global__ __launch_bounds__(kBlock) void k_labels(const uint32_t *__restrict__ rgba, uint64_t n,
                                                    const LabelT *__restrict__ colour_labels,
+                                                   const uint16_t *__restrict__ sub_table,
                                                    uint32_t *__restrict__ labels, int aligned)
 {
     constexpr uint64_t TILE = (uint64_t)kBlock * 8;
@@ -403,20 +407,23 @@ __global__ __launch_bounds__(kBlock) void k_labels(const uint32_t *__restrict__ 
         for (int g = 0; g < 2; ++g) {
             i0[g] = tile * TILE + (uint64_t)g * (kBlock * 4) + (uint64_t)threadIdx.x * 4;
             uint32_t px[4];
-            load4(rgba, i0[g], n, aligned != 0, px);
+            load4_stream(rgba, i0[g], n, aligned != 0, px);
 #pragma unroll
             for (int q = 0; q < 4; ++q) ci[g * 4 + q] = colour_index(px[q]);
         }
         uint32_t lab[8];
 #pragma unroll
-        for (int p = 0; p < 8; ++p) lab[p] = (uint32_t)colour_labels[ci[p]];
+        for (int p = 0; p < 8; ++p) lab[p] = (uint32_t)sub_table[ci[p] >> 6];
 #pragma unroll
-        for (int g = 0; g < 2; ++g) store4(labels, i0[g], n, aligned != 0, lab + g * 4);
+        for (int p = 0; p < 8; ++p)
+            if (lab[p] == kSubMixed) lab[p] = (uint32_t)colour_labels[ci[p]];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) store4_stream(labels, i0[g], n, aligned != 0, lab + g * 4);
     }
 }
 
-hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_labels, uint32_t k,
-                         uint32_t *labels, hipStream_t st)
+hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_labels, const uint16_t *sub_table,
+                         uint32_t k, uint32_t *labels, hipStream_t st)
 {
     const uint64_t tiles = (n + kBlock * 8 - 1) / (kBlock * 8);
     const uint32_t grid = (uint32_t)(tiles < 8192 ? (tiles ? tiles : 1) : 8192);
@@ -424,10 +431,10 @@ hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_la
                          (reinterpret_cast<uintptr_t>(labels) & 15u) == 0) ? 1 : 0;
     if (k <= 256)
         hipLaunchKernelGGL(k_labels<uint8_t>, dim3(grid), dim3(kBlock), 0, st, rgba, n,
-                           (const uint8_t *)colour_labels, labels, aligned);
+                           (const uint8_t *)colour_labels, sub_table, labels, aligned);
     else
         hipLaunchKernelGGL(k_labels<uint16_t>, dim3(grid), dim3(kBlock), 0, st, rgba, n,
-                           (const uint16_t *)colour_labels, labels, aligned);
+                           (const uint16_t *)colour_labels, sub_table, labels, aligned);
     return hipGetLastError();
 }
 
