@@ -3,8 +3,9 @@
 
 Metric (BASELINE.json): pixels/sec per Lloyd iteration at 8192x8192, k = 256, plus the fraction of
 the HBM roofline.  A "step" is ONE Lloyd iteration over the whole (sharded) image: centroid update
-from the global accumulators, per-pixel CIE94 assignment fused with the per-cluster sums, partial
-sum reduction and -- for N > 1 -- the RCCL all-reduce of the k x 4 int64 accumulators.
+from the global accumulators, a label for every pixel (written to HBM, 4 B/px, every iteration --
+like the reference's find_centroid dispatch) and the per-cluster sums of the new assignment, and
+for N > 1 the RCCL all-reduce of the k x 4 int64 accumulators.
 
 N = 1: synthetic 8192x8192 RGBA (splitmix64 seed 0x5EED0003), k = 256.
 N > 1: weak scaling -- the image is 8192 x (8192*N), row-sharded so every rank owns one 8192x8192
@@ -31,6 +32,15 @@ ALGORITHMIC_BYTES_PER_PIXEL = 8          # 4 B RGBA8 read + 4 B u32 label write 
 HBM_PEAK_GBPS = 8000.0                   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 
 
+def algorithmic_bytes(kernel, n_pixels, k):
+    """per-launch algorithmic bytes of each kernel of the path"""
+    if kernel in ("k_assign", "k_labels"):
+        return ALGORITHMIC_BYTES_PER_PIXEL * n_pixels        # pixel in, label out
+    if kernel == "k_cube":
+        return (1 << 24) * (4 + (1 if k <= 256 else 2))      # colour counts in, colour labels out
+    return None
+
+
 def cpu_baseline(k, centroids4, seed, target_seconds=12.0):
     """The CPU oracle (a port of the reference's WGSL; the reference itself needs Rust + Vulkan) on
     a bounded sample of the same workload, all host threads."""
@@ -53,14 +63,14 @@ def cpu_baseline(k, centroids4, seed, target_seconds=12.0):
     dt = time.perf_counter() - t
     return {"value": n / dt, "unit": "pixels/s", "cores": O.num_threads(), "kind": "port",
             "sample": f"first {n} pixels ({n // WIDTH} rows of {WIDTH}) of the same image, k={k}, "
-                      f"one assign+accumulate pass, {dt:.2f} s"}
+                      f"one assign+accumulate pass (per-pixel scan), {dt:.2f} s"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--k", type=int, default=K)
     ap.add_argument("--rows", type=int, default=ROWS_PER_GPU, help="rows per GPU (default 8192)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -92,6 +102,8 @@ def main():
     k = args.k
     n_local = WIDTH * args.rows
     seed = synth.SEED_CFG3
+    if args.strategy != "auto":
+        os.environ["KMG_STRATEGY"] = {"scan": "brute", "table": "table"}[args.strategy]
     proc = kg.ImageProcessor(device=local_rank, shrink_max_dim=0)
     rgba = synth.uniform_rgba_torch(seed, n_local, first=rank * n_local, device="cuda")
     labels = torch.empty(n_local, dtype=torch.int32, device="cuda")
@@ -106,17 +118,16 @@ def main():
     cent = np.ones((k, 4), np.float32)
     cent[:, :3] = lab.cpu().numpy()
 
-    if args.strategy != "auto":
-        os.environ["KMG_STRATEGY"] = {"scan": "brute", "table": "table"}[args.strategy]
     lloyd = kg.Lloyd(proc, k)
     lloyd.set_centroids(cent, stream)
-    # one-time per-image preparation (like the reference's one-time Lab conversion pass,
-    # operations.rs:63-71): outside the per-iteration timing, reported separately
+    # one-time per-image preparation (the counterpart of the reference's one-time Lab conversion
+    # pass, operations.rs:63-71): outside the per-iteration timing, reported separately
     torch.cuda.synchronize()
     t_prep = time.perf_counter()
     strategy = lloyd.prepare(rgba.data_ptr(), n_local, True, stream)
     torch.cuda.synchronize()
     t_prep = time.perf_counter() - t_prep
+
     sh = ShardedLloyd(lloyd, k, rgba, labels, stream=stream)
     sh.prime()
     for _ in range(args.warmup):
@@ -128,30 +139,33 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    sh.kernel_events = []
+    lloyd.profile(True)          # HIP events around every launch, on the launch stream
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         sh.iterate()
     fence()
     elapsed = time.perf_counter() - t0
+    prof = lloyd.profile_read()
+    lloyd.profile(False)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kernel_ms = [a.elapsed_time(b) for a, b in sh.kernel_events]
-    sh.kernel_events = None
 
     if rank == 0:
         total_pixels = n_local * world
         ms_per_step = elapsed * 1e3 / args.steps
-        k_ms = sum(kernel_ms) / len(kernel_ms)
-        achieved = ALGORITHMIC_BYTES_PER_PIXEL * n_local / (k_ms * 1e-3) / 1e9
+        kernels = {name: {"ms_per_launch": ms / cnt, "launches": cnt} for name, (ms, cnt) in prof.items()}
+        dominant = max(prof, key=lambda name: prof[name][0])
+        k_ms = kernels[dominant]["ms_per_launch"]
+        abytes = algorithmic_bytes(dominant, n_local, k)
+        achieved = abytes / (k_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath) and k == K and args.rows == ROWS_PER_GPU:
             with open(tpath) as f:
-                traffic = json.load(f).get("k_assign_bytes_per_launch")
+                traffic = json.load(f).get("bytes_per_launch", {}).get(dominant)
         out = {
             "metric": "pixels/sec per Lloyd iteration (8192x8192, k=256)",
             "value": total_pixels * args.steps / elapsed,
@@ -161,16 +175,17 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"synthetic uniform RGBA {WIDTH}x{args.rows * world} (seed 0x5EED0003), "
-                                   f"k={k}, one Lloyd iteration = update + assign + accumulate"
+                                   f"k={k}, one Lloyd iteration = update + assign (labels written every "
+                                   f"iteration) + accumulate"
                                    + (" + RCCL all-reduce of k x 4 int64" if world > 1 else ""),
                        "width": WIDTH, "height": args.rows * world, "k": k,
                        "sharding": f"row bands, {args.rows} rows per GPU",
                        "strategy": strategy, "prepare_ms": t_prep * 1e3},
-            "roofline": {"bound": "hbm", "kernel": ("k_assign (fused assign + accumulate)" if strategy == "scan" else
-                                    "candidates + cube + label-gather launches of one assign pass"),
+            "roofline": {"bound": "hbm", "kernel": dominant,
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel_ms": k_ms, "algorithmic_bytes_per_launch": ALGORITHMIC_BYTES_PER_PIXEL * n_local},
+                         "kernel_ms": k_ms, "algorithmic_bytes_per_launch": abytes},
+            "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(k, cent, seed)

@@ -152,6 +152,17 @@ KMG_API int kmg_lloyd_assign_partials(kmg_lloyd *s, const uint8_t *d_rgba, uint6
                                       uint32_t *d_labels, void *stream);
 KMG_API int kmg_lloyd_reduce_partials(kmg_lloyd *s, uint64_t n_pixels, int64_t *d_acc4, void *stream);
 
+/* Per-launch timing of the state's kernels with HIP events recorded on the launch stream itself
+ * (bench.py's roofline leg).  _profile(1) starts collecting, _profile_read synchronises the
+ * recorded events, returns the summed duration and launch count per kernel id and resets.       */
+typedef enum kmg_kernel_id {
+    KMG_K_ASSIGN = 0, KMG_K_REDUCE = 1, KMG_K_UPDATE = 2, KMG_K_CANDIDATES = 3, KMG_K_CUBE = 4,
+    KMG_K_LABELS = 5, KMG_K_COUNT = 6
+} kmg_kernel_id;
+KMG_API const char *kmg_kernel_name(int id);
+KMG_API int kmg_lloyd_profile(kmg_lloyd *s, int enable);
+KMG_API int kmg_lloyd_profile_read(kmg_lloyd *s, double total_ms[KMG_K_COUNT], uint32_t launches[KMG_K_COUNT]);
+
 /* choose_centroid.wgsl:180-206 `pick` for all k at once: centroid <- sum/count, convergence
  * flags.  d_acc4 holds the (all-reduced) accumulators.                                        */
 KMG_API int kmg_lloyd_update(kmg_lloyd *s, const int64_t *d_acc4, void *stream);

@@ -47,6 +47,21 @@ static int fail(int code, const char *fmt, ...)
                         "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+// launch wrapper: when profiling is on, bracket the launch with HIP events on its own stream
+#define PROF_LAUNCH(s_, id_, st_, expr)                                                        \
+    do {                                                                                       \
+        if ((s_)->prof) {                                                                      \
+            ProfEvent pe_; pe_.id = (id_);                                                     \
+            HIP_TRY(hipEventCreate(&pe_.e0)); HIP_TRY(hipEventCreate(&pe_.e1));                \
+            HIP_TRY(hipEventRecord(pe_.e0, (st_)));                                            \
+            HIP_TRY(expr);                                                                     \
+            HIP_TRY(hipEventRecord(pe_.e1, (st_)));                                            \
+            (s_)->events.push_back(pe_);                                                       \
+        } else {                                                                               \
+            HIP_TRY(expr);                                                                     \
+        }                                                                                      \
+    } while (0)
+
 static bool log_debug()
 {
     const char *lv = getenv("KMG_LOG");
@@ -78,6 +93,8 @@ struct kmg_processor {
     CellBounds *d_bounds;    // kCells static cell bounds of the colour-table strategy
 };
 
+struct ProfEvent { int id; hipEvent_t e0, e1; };
+
 // colour table of a bound image (kmg_table.h)
 struct ColourTable {
     const uint8_t *rgba = nullptr;   // the bound device buffer
@@ -101,6 +118,8 @@ struct kmg_lloyd {
     uint64_t dist_cap;
     uint32_t last_rows;          // rows of d_partials written by the last assign pass
     ColourTable tab;
+    bool prof;                   // per-launch HIP-event timing (kmg_lloyd_profile)
+    std::vector<ProfEvent> events;
 };
 
 extern "C" int kmg_processor_create(kmg_processor **out) { return kmg_processor_create_ex(nullptr, out); }
@@ -241,6 +260,7 @@ struct StreamGuard {
 // ---------------------------------------------------------------------------------------------
 // colour-table strategy (kmg_table.h): binding an image, strategy choice
 // ---------------------------------------------------------------------------------------------
+static void drop_events(kmg_lloyd *s);
 static void free_table(ColourTable &t)
 {
     if (t.d_hist) (void)hipFree(t.d_hist);
@@ -365,10 +385,11 @@ static int table_assign(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_
 {
     ColourTable &t = s->tab;
     (void)sums;
-    HIP_TRY(launch_cell_candidates(s->p->d_bounds, t.d_agg, s->d_cent, s->k, t.d_masks, st));
-    HIP_TRY(launch_cube(t.d_hist, t.d_agg, t.d_masks, s->d_cent, s->k, s->p->d_lut, t.d_colour_labels, t.d_sub,
-                        s->d_partials, st));
-    if (d_labels) HIP_TRY(launch_labels((const uint32_t *)d_rgba, n, t.d_colour_labels, t.d_sub, s->k, d_labels, st));
+    PROF_LAUNCH(s, KMG_K_CANDIDATES, st, launch_cell_candidates(s->p->d_bounds, t.d_agg, s->d_cent, s->k, t.d_masks, st));
+    PROF_LAUNCH(s, KMG_K_CUBE, st, launch_cube(t.d_hist, t.d_agg, t.d_masks, s->d_cent, s->k, s->p->d_lut,
+                                               t.d_colour_labels, t.d_sub, s->d_partials, st));
+    if (d_labels)
+        PROF_LAUNCH(s, KMG_K_LABELS, st, launch_labels((const uint32_t *)d_rgba, n, t.d_colour_labels, t.d_sub, s->k, d_labels, st));
     return KMG_OK;
 }
 
@@ -384,7 +405,7 @@ extern "C" int kmg_lloyd_create(kmg_processor *p, uint32_t k, kmg_lloyd **out)
     s->p = p;
     s->k = k;
     s->d_cent = nullptr; s->d_partials = nullptr; s->d_acc = nullptr; s->d_nconv = nullptr;
-    s->d_key = nullptr; s->d_dist = nullptr; s->dist_cap = 0; s->last_rows = 0;
+    s->d_key = nullptr; s->d_dist = nullptr; s->dist_cap = 0; s->last_rows = 0; s->prof = false;
     hipError_t e = hipMalloc((void **)&s->d_cent, sizeof(Centroid) * k);
     if (e == hipSuccess) e = hipMemset(s->d_cent, 0, sizeof(Centroid) * k);   // structures.rs:501-521
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_partials, sizeof(int64_t) * 4ull * k * 2048ull);
@@ -412,6 +433,7 @@ extern "C" void kmg_lloyd_destroy(kmg_lloyd *s)
     if (s->d_key) (void)hipFree(s->d_key);
     if (s->d_dist) (void)hipFree(s->d_dist);
     free_table(s->tab);
+    drop_events(s);
     delete s;
 }
 
@@ -478,8 +500,8 @@ static int assign_pass(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_t
         return table_assign(s, d_rgba, n, d_labels, sums, st);
     }
     s->last_rows = assign_grid(n);
-    HIP_TRY(launch_assign((const uint32_t *)d_rgba, n, s->d_cent, s->k, s->p->d_lut, d_labels,
-                          sums ? s->d_partials : nullptr, st));
+    PROF_LAUNCH(s, KMG_K_ASSIGN, st, launch_assign((const uint32_t *)d_rgba, n, s->d_cent, s->k, s->p->d_lut, d_labels,
+                                                  sums ? s->d_partials : nullptr, st));
     return KMG_OK;
 }
 
@@ -491,7 +513,7 @@ extern "C" int kmg_lloyd_assign_accumulate(kmg_lloyd *s, const uint8_t *d_rgba, 
     HIP_TRY(hipSetDevice(s->p->device));
     int rc;
     if ((rc = assign_pass(s, d_rgba, n, d_labels, d_acc4 != nullptr, S(stream))) != KMG_OK) return rc;
-    if (d_acc4) HIP_TRY(launch_reduce_partials(s->d_partials, s->last_rows, s->k, d_acc4, S(stream)));
+    if (d_acc4) PROF_LAUNCH(s, KMG_K_REDUCE, S(stream), launch_reduce_partials(s->d_partials, s->last_rows, s->k, d_acc4, S(stream)));
     return KMG_OK;
 }
 
@@ -507,7 +529,44 @@ extern "C" int kmg_lloyd_reduce_partials(kmg_lloyd *s, uint64_t n, int64_t *d_ac
     if (!s || !d_acc4 || n == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad reduce_partials arguments");
     if (s->last_rows == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "reduce_partials without a preceding assign_partials");
     HIP_TRY(hipSetDevice(s->p->device));
-    HIP_TRY(launch_reduce_partials(s->d_partials, s->last_rows, s->k, d_acc4, S(stream)));
+    PROF_LAUNCH(s, KMG_K_REDUCE, S(stream), launch_reduce_partials(s->d_partials, s->last_rows, s->k, d_acc4, S(stream)));
+    return KMG_OK;
+}
+
+static void drop_events(kmg_lloyd *s)
+{
+    for (ProfEvent &e : s->events) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); }
+    s->events.clear();
+}
+
+extern "C" const char *kmg_kernel_name(int id)
+{
+    static const char *names[KMG_K_COUNT] = {"k_assign", "k_reduce_partials", "k_update", "k_cell_candidates", "k_cube", "k_labels"};
+    return (id >= 0 && id < KMG_K_COUNT) ? names[id] : "?";
+}
+
+extern "C" int kmg_lloyd_profile(kmg_lloyd *s, int enable)
+{
+    if (!s) return fail(KMG_ERR_INVALID_ARGUMENT, "bad profile arguments");
+    HIP_TRY(hipSetDevice(s->p->device));
+    drop_events(s);
+    s->prof = enable != 0;
+    return KMG_OK;
+}
+
+extern "C" int kmg_lloyd_profile_read(kmg_lloyd *s, double total_ms[KMG_K_COUNT], uint32_t launches[KMG_K_COUNT])
+{
+    if (!s || !total_ms || !launches) return fail(KMG_ERR_INVALID_ARGUMENT, "bad profile_read arguments");
+    HIP_TRY(hipSetDevice(s->p->device));
+    for (int i = 0; i < KMG_K_COUNT; ++i) { total_ms[i] = 0.0; launches[i] = 0; }
+    for (ProfEvent &e : s->events) {
+        HIP_TRY(hipEventSynchronize(e.e1));
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, e.e0, e.e1));
+        total_ms[e.id] += ms;
+        launches[e.id] += 1;
+    }
+    drop_events(s);
     return KMG_OK;
 }
 
@@ -515,7 +574,7 @@ extern "C" int kmg_lloyd_update(kmg_lloyd *s, const int64_t *d_acc4, void *strea
 {
     if (!s || !d_acc4) return fail(KMG_ERR_INVALID_ARGUMENT, "bad update arguments");
     HIP_TRY(hipSetDevice(s->p->device));
-    HIP_TRY(launch_update(d_acc4, s->k, s->p->opt.convergence, s->d_cent, s->d_nconv, S(stream)));
+    PROF_LAUNCH(s, KMG_K_UPDATE, S(stream), launch_update(d_acc4, s->k, s->p->opt.convergence, s->d_cent, s->d_nconv, S(stream)));
     return KMG_OK;
 }
 

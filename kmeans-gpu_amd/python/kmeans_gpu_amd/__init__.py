@@ -66,7 +66,8 @@ SYMBOLS = [
     "kmg_dev_resize", "kmg_lloyd_create", "kmg_lloyd_destroy", "kmg_lloyd_set_centroids",
     "kmg_lloyd_get_centroids", "kmg_lloyd_init_centroids", "kmg_lloyd_assign_accumulate",
     "kmg_lloyd_assign_partials", "kmg_lloyd_reduce_partials", "kmg_lloyd_bind_image",
-    "kmg_lloyd_unbind_image", "kmg_lloyd_prepare", "kmg_debug_check_table",
+    "kmg_lloyd_unbind_image", "kmg_lloyd_prepare", "kmg_debug_check_table", "kmg_kernel_name",
+    "kmg_lloyd_profile", "kmg_lloyd_profile_read",
     "kmg_lloyd_update", "kmg_lloyd_converged_count", "kmg_lloyd_run", "kmg_dev_apply",
     "kmg_dither_threshold",
 ]
@@ -118,6 +119,10 @@ def lib():
     L.kmg_lloyd_assign_partials.argtypes = [vp, u8p, C.c_uint64, u32p, vp]
     L.kmg_lloyd_reduce_partials.argtypes = [vp, C.c_uint64, i64p, vp]
     L.kmg_lloyd_bind_image.argtypes = [vp, u8p, C.c_uint64, vp]
+    L.kmg_kernel_name.argtypes = [C.c_int]
+    L.kmg_kernel_name.restype = C.c_char_p
+    L.kmg_lloyd_profile.argtypes = [vp, C.c_int]
+    L.kmg_lloyd_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
     L.kmg_lloyd_unbind_image.argtypes = [vp]
     L.kmg_lloyd_prepare.argtypes = [vp, u8p, C.c_uint64, C.c_int, C.POINTER(C.c_int), vp]
     L.kmg_debug_check_table.argtypes = [vp, C.POINTER(C.c_uint64), vp]
@@ -313,6 +318,18 @@ class Lloyd:
         _check(lib().kmg_lloyd_prepare(self._h, C.c_void_p(d_rgba), n_pixels, int(bool(want_labels)),
                                        C.byref(st), C.c_void_p(stream)))
         return "table" if st.value == 1 else "scan"
+
+    def profile(self, enable=True):
+        """start / stop per-launch HIP-event timing of this state's kernels"""
+        _check(lib().kmg_lloyd_profile(self._h, int(bool(enable))))
+
+    def profile_read(self):
+        """{kernel name: (total ms, launches)} since the last read; synchronises the events"""
+        n = 6
+        ms = (C.c_double * n)()
+        cnt = (C.c_uint32 * n)()
+        _check(lib().kmg_lloyd_profile_read(self._h, ms, cnt))
+        return {lib().kmg_kernel_name(i).decode(): (ms[i], cnt[i]) for i in range(n) if cnt[i]}
 
     def unbind_image(self):
         _check(lib().kmg_lloyd_unbind_image(self._h))

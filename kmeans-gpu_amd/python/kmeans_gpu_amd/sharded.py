@@ -39,22 +39,11 @@ class ShardedLloyd:
         self.stream = stream
         self.acc = torch.zeros((self.k, 4), dtype=torch.int64, device=rgba.device)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        # optional per-launch timing of the dominant kernel: list of (start, end) events recorded on
-        # the current stream around the fused assign+accumulate launch (bench.py roofline leg)
-        self.kernel_events = None
 
     def _assign_accumulate(self):
         lab_ptr = self.labels.data_ptr() if self.labels is not None else 0
         if self.n_local == 0:
             self.acc.zero_()
-        elif self.kernel_events is not None:
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-            self.backend.assign_partials(self.rgba.data_ptr(), self.n_local, lab_ptr, self.stream)
-            e1.record()
-            self.backend.reduce_partials(self.n_local, self.acc.data_ptr(), self.stream)
-            self.kernel_events.append((e0, e1))
         else:
             self.backend.assign_accumulate(self.rgba.data_ptr(), self.n_local, lab_ptr,
                                            self.acc.data_ptr(), self.stream)
