@@ -263,8 +263,10 @@ __global__ __launch_bounds__(kBlock) void k_cube(const uint32_t *__restrict__ hi
     for (uint32_t cell = wave; cell < kCells; cell += n_waves) {
         const long long cell_count = (long long)uniform_u64((unsigned long long)agg[4ull * cell + 3]);
         uint16_t *sub = sub_table + cell * 8u;
+        uint16_t *cell_entry = sub_table + kSubCells + cell;       // 8x8x8 summary, same encoding
         if (cell_count == 0) {
             if (lane < 8) sub[lane] = kSubEmpty;
+            if (lane == 0) *cell_entry = kSubEmpty;
             continue;
         }
         const uint64_t *mw = masks + (uint64_t)cell * words;
@@ -286,6 +288,7 @@ __global__ __launch_bounds__(kBlock) void k_cube(const uint32_t *__restrict__ hi
             else
                 *reinterpret_cast<uint4 *>(colour_labels + base) = *reinterpret_cast<uint4 *>(v);
             if (lane < 8) sub[lane] = (uint16_t)first;
+            if (lane == 0) *cell_entry = (uint16_t)first;
             if (lane < 4) atomicAdd(bins + 4ull * first + lane, (unsigned long long)agg[4ull * cell + lane]);
             continue;
         }
@@ -364,6 +367,13 @@ __global__ __launch_bounds__(kBlock) void k_cube(const uint32_t *__restrict__ hi
             state = (state == kSubEmpty) ? o : ((o == kSubEmpty || o == state) ? state : (uint32_t)kSubMixed);
         }
         if ((lane & 7u) == 0) sub[lane >> 3] = (uint16_t)state;
+        // ... and over the whole 8x8x8 cell
+#pragma unroll
+        for (int off = 8; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_xor(state, off, 64);
+            state = (state == kSubEmpty) ? o : ((o == kSubEmpty || o == state) ? state : (uint32_t)kSubMixed);
+        }
+        if (lane == 0) *cell_entry = (uint16_t)state;
     }
 
     __syncthreads();
@@ -389,23 +399,35 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const uint64_t 
 // ------------------------------------------------------------------------------------------
 // labels[i] = colour_labels[colour_index(pixel i)]   (find_centroid.wgsl:43 output)
 // ------------------------------------------------------------------------------------------
-// Two levels: the 512 KiB sub-cell table (one u16 per 4x4x4 colours: the common label of the
-// sub-cell's occupied colours, or kSubMixed) stays L2 resident and answers most pixels; only pixels
-// of mixed sub-cells touch the 16 MiB per-colour table.  Pixel / label streams are non-temporal.
+// Three levels, coarse to fine; an entry is the common label of the occupied colours below it, or
+// kSubMixed:
+//   8x8x8 cells   (32768 x u16 = 64 KiB)  staged in LDS by every workgroup  -> no memory request
+//   4x4x4 cells   (2^18 x u16 = 512 KiB)  L2 resident
+//   single colour (2^24 x u8/u16)         Infinity Cache / HBM, only for pixels of mixed sub-cells
+// Pixel and label streams are non-temporal so they do not evict the tables from L2.
+constexpr int kLabelBlock = 1024;
+
 template <typename LabelT>
-__global__ __launch_bounds__(kBlock) void k_labels(const uint32_t *__restrict__ rgba, uint64_t n,
-                                                   const LabelT *__restrict__ colour_labels,
-                                                   const uint16_t *__restrict__ sub_table,
-                                                   uint32_t *__restrict__ labels, int aligned)
+__global__ __launch_bounds__(kLabelBlock) void k_labels(const uint32_t *__restrict__ rgba, uint64_t n,
+                                                        const LabelT *__restrict__ colour_labels,
+                                                        const uint16_t *__restrict__ sub_table,
+                                                        uint32_t *__restrict__ labels, int aligned)
 {
-    constexpr uint64_t TILE = (uint64_t)kBlock * 8;
+    __shared__ uint16_t s_cell[kCells];
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(sub_table + kSubCells);
+        uint4 *dst = reinterpret_cast<uint4 *>(s_cell);
+        for (uint32_t i = threadIdx.x; i < kCells / 8; i += kLabelBlock) dst[i] = src[i];
+    }
+    __syncthreads();
+    constexpr uint64_t TILE = (uint64_t)kLabelBlock * 8;
     const uint64_t tiles = (n + TILE - 1) / TILE;
     for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         uint32_t ci[8];
         uint64_t i0[2];
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-            i0[g] = tile * TILE + (uint64_t)g * (kBlock * 4) + (uint64_t)threadIdx.x * 4;
+            i0[g] = tile * TILE + (uint64_t)g * (kLabelBlock * 4) + (uint64_t)threadIdx.x * 4;
             uint32_t px[4];
             load4_stream(rgba, i0[g], n, aligned != 0, px);
 #pragma unroll
@@ -413,7 +435,10 @@ __global__ __launch_bounds__(kBlock) void k_labels(const uint32_t *__restrict__ 
         }
         uint32_t lab[8];
 #pragma unroll
-        for (int p = 0; p < 8; ++p) lab[p] = (uint32_t)sub_table[ci[p] >> 6];
+        for (int p = 0; p < 8; ++p) lab[p] = (uint32_t)s_cell[ci[p] >> 9];
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+            if (lab[p] == kSubMixed) lab[p] = (uint32_t)sub_table[ci[p] >> 6];
 #pragma unroll
         for (int p = 0; p < 8; ++p)
             if (lab[p] == kSubMixed) lab[p] = (uint32_t)colour_labels[ci[p]];
@@ -425,15 +450,15 @@ __global__ __launch_bounds__(kBlock) void k_labels(const uint32_t *__restrict__ 
 hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_labels, const uint16_t *sub_table,
                          uint32_t k, uint32_t *labels, hipStream_t st)
 {
-    const uint64_t tiles = (n + kBlock * 8 - 1) / (kBlock * 8);
-    const uint32_t grid = (uint32_t)(tiles < 8192 ? (tiles ? tiles : 1) : 8192);
+    const uint64_t tiles = (n + kLabelBlock * 8 - 1) / (kLabelBlock * 8);
+    const uint32_t grid = (uint32_t)(tiles < 512 ? (tiles ? tiles : 1) : 512);   // 2 workgroups per CU
     const int aligned = ((reinterpret_cast<uintptr_t>(rgba) & 15u) == 0 &&
                          (reinterpret_cast<uintptr_t>(labels) & 15u) == 0) ? 1 : 0;
     if (k <= 256)
-        hipLaunchKernelGGL(k_labels<uint8_t>, dim3(grid), dim3(kBlock), 0, st, rgba, n,
+        hipLaunchKernelGGL(k_labels<uint8_t>, dim3(grid), dim3(kLabelBlock), 0, st, rgba, n,
                            (const uint8_t *)colour_labels, sub_table, labels, aligned);
     else
-        hipLaunchKernelGGL(k_labels<uint16_t>, dim3(grid), dim3(kBlock), 0, st, rgba, n,
+        hipLaunchKernelGGL(k_labels<uint16_t>, dim3(grid), dim3(kLabelBlock), 0, st, rgba, n,
                            (const uint16_t *)colour_labels, sub_table, labels, aligned);
     return hipGetLastError();
 }
