@@ -593,15 +593,19 @@ extern "C" int kmg_lloyd_run(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, ui
     if (!s || !d_rgba || n == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad lloyd_run arguments");
     const kmg_options &o = s->p->opt;
     int rc;
-    // large problems iterate over the image's colour table instead of its pixels (same results)
+    // large problems iterate over the image's colour table instead of its pixels (same results);
+    // the loop itself only needs the sums, so with the table the per-pixel label map is written
+    // once, after the last iteration (the per-pixel scan writes it in the same pass for free)
     if (!table_bound(s, d_rgba, n))
-        if ((rc = kmg_lloyd_prepare(s, d_rgba, n, d_labels != nullptr, nullptr, stream)) != KMG_OK) return rc;
+        if ((rc = kmg_lloyd_prepare(s, d_rgba, n, 0, nullptr, stream)) != KMG_OK) return rc;
+    const bool table = table_bound(s, d_rgba, n);
+    uint32_t *loop_labels = table ? nullptr : d_labels;
     // operations.rs:75-83 initial assignment (fused with the sums the first update needs)
-    if ((rc = kmg_lloyd_assign_accumulate(s, d_rgba, n, d_labels, s->d_acc, stream)) != KMG_OK) return rc;
+    if ((rc = kmg_lloyd_assign_accumulate(s, d_rgba, n, loop_labels, s->d_acc, stream)) != KMG_OK) return rc;
     uint32_t it = 0;
     for (it = 0; it < o.max_iterations; ++it) {                       // modules.rs:769
         if ((rc = kmg_lloyd_update(s, s->d_acc, stream)) != KMG_OK) return rc;           // :773-788
-        if ((rc = kmg_lloyd_assign_accumulate(s, d_rgba, n, d_labels, s->d_acc, stream)) != KMG_OK) return rc;  // :793-800
+        if ((rc = kmg_lloyd_assign_accumulate(s, d_rgba, n, loop_labels, s->d_acc, stream)) != KMG_OK) return rc;  // :793-800
         if (it > 0 && it % o.check_period == 0) {                    // :802
             uint32_t conv = 0;
             if ((rc = kmg_lloyd_converged_count(s, &conv, stream)) != KMG_OK) return rc;
@@ -611,6 +615,9 @@ extern "C" int kmg_lloyd_run(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, ui
             }
         }
     }
+    if (table && d_labels)   // the label tables of the last pass belong to the final centroids
+        PROF_LAUNCH(s, KMG_K_LABELS, S(stream), launch_labels((const uint32_t *)d_rgba, n, s->tab.d_colour_labels,
+                                                              s->tab.d_sub, s->k, d_labels, S(stream)));
     HIP_TRY(hipStreamSynchronize(S(stream)));
     if (iterations) *iterations = it < o.max_iterations ? it : o.max_iterations - 1;
     return KMG_OK;

@@ -146,3 +146,45 @@ def test_lloyd_run_with_table_matches_oracle(torch_cuda, oracle, monkeypatch):
     assert np.array_equal(labels.cpu().numpy().view(np.uint32), want_labels)
     s.close()
     p.close()
+
+
+def test_full_size_table_equals_scan(torch_cuda, oracle):
+    """BASELINE config 3 size (8192x8192, k=256): colour-table pass == per-pixel scan, every label and
+    every accumulator; plus size-independent properties (counts sum to N, labels < k, idempotence)."""
+    import kmeans_gpu_amd as kg
+    from kmeans_gpu_amd import synth
+    torch = torch_cuda
+    n, k = 8192 * 8192, 256
+    p = kg.ImageProcessor(shrink_max_dim=0)
+    rgba = synth.uniform_rgba_torch(synth.SEED_CFG3, n, device="cuda")
+    st = _stream(torch)
+    cent = oracle.centroids4(oracle.rgb_to_lab(synth.uniform_rgba_numpy(synth.SEED_CFG3, n // 64)[::(n // 64) // k][:k]))
+    res = []
+    for bind in (False, True):
+        s = kg.Lloyd(p, k)
+        s.set_centroids(cent)
+        if bind:
+            s.bind_image(rgba.data_ptr(), n, st)
+        labels = torch.zeros(n, dtype=torch.int32, device="cuda")
+        acc = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
+        s.assign_accumulate(rgba.data_ptr(), n, labels.data_ptr(), acc.data_ptr(), st)
+        s.update(acc.data_ptr(), st)
+        labels2 = torch.zeros(n, dtype=torch.int32, device="cuda")
+        acc2 = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
+        s.assign_accumulate(rgba.data_ptr(), n, labels2.data_ptr(), acc2.data_ptr(), st)
+        torch.cuda.synchronize()
+        res.append((labels, acc, labels2, acc2, s.get_centroids(st)))
+        s.close()
+    (l0, a0, l0b, a0b, c0), (l1, a1, l1b, a1b, c1) = res
+    assert torch.equal(l0, l1) and torch.equal(a0, a1) and torch.equal(l0b, l1b) and torch.equal(a0b, a1b)
+    assert np.array_equal(c0.view(np.uint32), c1.view(np.uint32))
+    assert int(a1[:, 3].sum()) == n and int(a1b[:, 3].sum()) == n
+    assert int(l1.max()) < k and int(l1.min()) >= 0
+    # counts per label equal the accumulator's counts; sums re-derivable from labels (checksum of checksums)
+    cnt = torch.bincount(l1b.to(torch.int64), minlength=k)
+    assert torch.equal(cnt, a1b[:, 3])
+    # oracle spot check on a slice of the image
+    m = 1 << 16
+    wl, _ = oracle.assign_accumulate_rgba(rgba[:m].cpu().numpy(), cent)
+    assert np.array_equal(l1[:m].cpu().numpy().view(np.uint32), wl)
+    p.close()
