@@ -200,3 +200,61 @@ def test_palette_matches_oracle(processor, oracle, tokyo):
     assert np.array_equal(got, want)
     gold = load_rgba("tokyo-palette-c8-kmeans-s40.png")[0, ::40, :]
     assert np.abs(got.astype(int) - gold.astype(int)).max() <= 1
+
+
+def test_concurrent_calls_on_one_processor(processor, oracle, tokyo):
+    """core/examples/parallel.rs:36-50: 14 threads share one ImageProcessor (k = 2..15)"""
+    import threading
+    img = tokyo[::2, ::2].copy()
+    results, errors = {}, []
+
+    def work(k):
+        try:
+            results[k] = processor.reduce(k, img, reduce_mode=k % 2)
+        except Exception as e:      # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2, 16)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors
+    for k in range(2, 16):
+        assert np.array_equal(results[k], oracle.reduce(img, k, k % 2)), k
+
+
+def test_error_behaviour(processor, tokyo):
+    """cli/src/args.rs:160-171 (k >= 1) and the documented status codes"""
+    import kmeans_gpu_amd as kg
+    with pytest.raises(kg.KmgError) as e:
+        processor.reduce(0, tokyo)
+    assert e.value.status == -1 and "higher than 0" in str(e.value)
+    with pytest.raises(kg.KmgError) as e:
+        processor.reduce(4, tokyo, algo=kg.Algorithm.Octree)
+    assert e.value.status == -5
+    with pytest.raises(kg.KmgError) as e:
+        processor.find(tokyo, np.zeros((0, 4), np.uint8))
+    assert e.value.status == -1
+    with pytest.raises(kg.KmgError) as e:
+        processor.palette(5000, tokyo)
+    assert e.value.status == -5          # KMG_MAX_K
+
+
+def test_single_pixel_and_single_row_images(processor, oracle):
+    for shape in [(1, 1), (1, 37), (41, 1), (3, 5)]:
+        img = oracle.synth_uniform(shape[0] * 100 + shape[1], shape[0] * shape[1]).reshape(shape[0], shape[1], 4)
+        for k in (1, 2, 3):
+            for mode in (0, 1):
+                assert np.array_equal(processor.reduce(k, img, reduce_mode=mode), oracle.reduce(img, k, mode)), (shape, k, mode)
+        pal = oracle.synth_uniform(5, 6)
+        for mode in (0, 1):
+            assert np.array_equal(processor.find(img, pal, mode), oracle.find(img, pal, mode))
+
+
+def test_more_clusters_than_pixels(processor, oracle):
+    """empty clusters keep their centroid and block convergence (choose_centroid.wgsl:192-194):
+    the loop runs to MAX_ITERATION"""
+    img = oracle.synth_uniform(8, 12).reshape(3, 4, 4)
+    assert np.array_equal(processor.reduce(20, img), oracle.reduce(img, 20, 0))
+    assert np.array_equal(processor.palette(20, img), oracle.palette(img, 20))
