@@ -178,7 +178,7 @@ KMG_API int kmg_lloyd_run(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n_pixels
 /* find_colors / dither_colors (core/src/operations.rs:99-155,215-271; find_centroid.wgsl,
  * swap.wgsl, mix_colors.wgsl main_dither, lab_to_rgb.wgsl) on a row band: `row0` is the image
  * row of the band's first pixel (the Bayer index uses image coordinates).  centroids4 is a
- * HOST table.  Output RGBA8 in d_out_rgba.                                                    */
+ * HOST table.  Output RGBA8 in d_out_rgba.  mode = replace, dither or meld (mix_colors.wgsl main_meld).  */
 KMG_API int kmg_dev_apply(kmg_processor *p, const uint8_t *d_rgba, uint32_t width, uint32_t rows,
                           uint32_t row0, const float *centroids4, uint32_t k, int mode,
                           uint8_t *d_out_rgba, void *stream);

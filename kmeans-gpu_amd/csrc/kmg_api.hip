@@ -629,8 +629,8 @@ extern "C" int kmg_dev_apply(kmg_processor *p, const uint8_t *d_rgba, uint32_t w
     if (!p || !d_rgba || !d_out || !c4 || !w || !rows || k == 0)
         return fail(KMG_ERR_INVALID_ARGUMENT, "bad apply arguments");
     if (k > KMG_MAX_K) return fail(KMG_ERR_UNSUPPORTED, "k = %u exceeds KMG_MAX_K = %u", k, KMG_MAX_K);
-    if (mode == KMG_MODE_MELD) return fail(KMG_ERR_UNSUPPORTED, "ReduceMode::Meld is not implemented yet");
-    if (mode != KMG_MODE_REPLACE && mode != KMG_MODE_DITHER) return fail(KMG_ERR_INVALID_ARGUMENT, "unknown mode %d", mode);
+    if (mode != KMG_MODE_REPLACE && mode != KMG_MODE_DITHER && mode != KMG_MODE_MELD)
+        return fail(KMG_ERR_INVALID_ARGUMENT, "unknown mode %d", mode);
     HIP_TRY(hipSetDevice(p->device));
 
     // per-centroid work on the host: (L,a,b,C) table, RGBA8 palette (lab_to_rgb.wgsl), threshold
@@ -658,9 +658,13 @@ extern "C" int kmg_dev_apply(kmg_processor *p, const uint8_t *d_rgba, uint32_t w
     hipError_t e = hipMalloc((void **)&d_pal, sizeof(uint32_t) * (k + 1));
     if (e == hipSuccess) e = hipMemcpyAsync(d_cent, hc.data(), sizeof(Centroid) * k, hipMemcpyHostToDevice, S(stream));
     if (e == hipSuccess) e = hipMemcpyAsync(d_pal, pal.data(), sizeof(uint32_t) * (k + 1), hipMemcpyHostToDevice, S(stream));
-    if (e == hipSuccess)
-        e = launch_apply((const uint32_t *)d_rgba, w, rows, row0, d_cent, k, p->d_lut, d_pal, dither, thr,
-                         (uint32_t *)d_out, S(stream));
+    if (e == hipSuccess) {
+        if (mode == KMG_MODE_MELD)
+            e = launch_meld((const uint32_t *)d_rgba, (uint64_t)w * rows, d_cent, k, p->d_lut, (uint32_t *)d_out, S(stream));
+        else
+            e = launch_apply((const uint32_t *)d_rgba, w, rows, row0, d_cent, k, p->d_lut, d_pal, dither, thr,
+                             (uint32_t *)d_out, S(stream));
+    }
     // the staging vectors and the two small device tables die with this call
     hipError_t e2 = hipStreamSynchronize(S(stream));
     (void)hipFree(d_cent);

@@ -567,4 +567,87 @@ hipError_t launch_apply(const uint32_t *rgba, uint32_t w, uint32_t rows, uint32_
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// meld output pass: mix_colors.wgsl:29-48 two_closest_colors, :85-90 meld, :117-135 main_meld,
+// then lab_to_rgb.wgsl per pixel.  Literal CIE94 throughout (the values themselves are used).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float srgb_encode_dev(float c)
+{
+    // lab_to_rgb.wgsl:21-35; pow(c, 1/2.4) correctly rounded via f64
+    return c > 0.0031308f ? 1.055f * (float)pow((double)c, (double)(1.0f / 2.4f)) - 0.055f : 12.92f * c;
+}
+
+__device__ __forceinline__ float lab_finv_dev(float t)
+{
+    const float t3 = t * t * t;                                  // lab_to_rgb.wgsl:45-59
+    return t3 > 0.008856f ? t3 : (t - 16.0f / 116.0f) / 7.787f;
+}
+
+__device__ __forceinline__ uint32_t lab_to_rgba8_dev(float L, float a, float b)
+{
+    float y = (L + 16.0f) / 116.0f;
+    float x = a / 500.0f + y;
+    float z = y - b / 200.0f;
+    const float X = lab_finv_dev(x) * 95.0489f, Y = lab_finv_dev(y) * 100.0f, Z = lab_finv_dev(z) * 108.8840f;
+    x = X / 100.0f; y = Y / 100.0f; z = Z / 100.0f;
+    const float r = fmaf(-0.4985314f, z, fmaf(-1.5371385f, y, 3.2404542f * x));
+    const float g = fmaf(0.0415560f, z, fmaf(1.8760108f, y, -0.9692660f * x));
+    const float bl = fmaf(1.0572252f, z, fmaf(-0.2040259f, y, 0.0556434f * x));
+    return unorm8(srgb_encode_dev(r)) | (unorm8(srgb_encode_dev(g)) << 8) | (unorm8(srgb_encode_dev(bl)) << 16) |
+           0xFF000000u;
+}
+
+__global__ __launch_bounds__(kBlock) void k_meld(const uint32_t *__restrict__ rgba, uint64_t n,
+                                                 const Centroid *__restrict__ cent, uint32_t k,
+                                                 const float *__restrict__ lut, uint32_t *__restrict__ out)
+{
+    extern __shared__ float4 smem4[];
+    const uint32_t kpad = (k + 3u) & ~3u;
+    float4 *s_cent = smem4;
+    float *s_lut = reinterpret_cast<float *>(smem4 + kpad);
+    s_lut[threadIdx.x] = lut[threadIdx.x];
+    stage_centroids(s_cent, cent, k, kpad);
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        float L, a, b;
+        px_to_lab(s_lut, rgba[i], L, a, b);
+        if (k == 1) {                                            // mix_colors.wgsl:127-131
+            const float4 c = s_cent[0];
+            out[i] = lab_to_rgba8_dev(c.x, c.y, c.z);
+            continue;
+        }
+        // :30-31 closest = second_closest = vec4(10000.0)
+        float cL = 10000.0f, ca = 10000.0f, cb = 10000.0f, sL = 10000.0f, sa = 10000.0f, sb = 10000.0f;
+        float d_closest = cie94(L, a, b, cL, ca, cb), d_second = d_closest;
+        for (uint32_t j = 0; j < k; ++j) {
+            const float4 c = s_cent[j];
+            const float d = cie94(L, a, b, c.x, c.y, c.z);
+            if (d < d_closest) {                                 // :36-38
+                sL = cL; sa = ca; sb = cb; d_second = d_closest;
+                cL = c.x; ca = c.y; cb = c.z; d_closest = d;
+            } else if (d < d_second) {                           // :39-41
+                sL = c.x; sa = c.y; sb = c.z; d_second = d;
+            }
+        }
+        // :86-89
+        const float factor = cie94(L, a, b, sL, sa, sb) / cie94(cL, ca, cb, sL, sa, sb);
+        const float oL = factor * cL + (1.0f - factor) * sL;
+        const float oa = factor * ca + (1.0f - factor) * sa;
+        const float ob = factor * cb + (1.0f - factor) * sb;
+        out[i] = lab_to_rgba8_dev(oL, oa, ob);
+    }
+}
+
+hipError_t launch_meld(const uint32_t *rgba, uint64_t n, const Centroid *cent, uint32_t k, const float *lut,
+                       uint32_t *out, hipStream_t st)
+{
+    const uint64_t blocks = (n + kBlock - 1) / kBlock;
+    const uint32_t grid = (uint32_t)(blocks < 8192 ? (blocks ? blocks : 1) : 8192);
+    const uint32_t kpad = (k + 3u) & ~3u;
+    const size_t lds = sizeof(float4) * kpad + 256 * sizeof(float);
+    hipLaunchKernelGGL(k_meld, dim3(grid), dim3(kBlock), lds, st, rgba, n, cent, k, lut, out);
+    return hipGetLastError();
+}
+
 }  // namespace kmg

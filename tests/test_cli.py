@@ -1,0 +1,71 @@
+"""The Python CLI mirrors the reference CLI's argument validation and file naming
+(cli/src/args.rs:237-293 unit tests, cli/src/main.rs:127-219)."""
+import argparse
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_rgba
+
+
+def test_validate_palette():
+    from kmeans_gpu_amd import cli
+    assert cli.validate_palette("#ffffff,#000000").tolist() == [[255, 255, 255, 255], [0, 0, 0, 255]]
+    for bad in ("#ffffff#000000", ""):
+        with pytest.raises(argparse.ArgumentTypeError):
+            cli.validate_palette(bad)
+
+
+def test_validate_k():
+    from kmeans_gpu_amd import cli
+    assert cli.validate_k("1") == 1 and cli.validate_k("150") == 150
+    for bad in ("abs", "0"):
+        with pytest.raises(argparse.ArgumentTypeError):
+            cli.validate_k(bad)
+
+
+def test_validate_filename():
+    from kmeans_gpu_amd import cli
+    assert cli.validate_filename("jog.png") and cli.validate_filename("jog.jpg")
+    for bad in ("jog.pom", ".png"):
+        with pytest.raises(argparse.ArgumentTypeError):
+            cli.validate_filename(bad)
+
+
+def test_parse_palette_file():
+    from kmeans_gpu_amd import cli
+    assert len(cli.parse_palette(os.path.join(GOLDEN, "resurrect_64.png"))) == 64
+    ap = cli.parse_palette(os.path.join(GOLDEN, "apollo-1x.png"))
+    assert len(ap) == 46 and [tuple(c) for c in ap] == sorted(tuple(c) for c in ap)
+
+
+def test_output_names():
+    from kmeans_gpu_amd import cli
+    assert cli.reduce_file_path(8, "kmeans", "replace", None, "gfx/tokyo.png") == "gfx/tokyo-reduce-c8-kmeans-replace.png"
+    assert cli.palette_file_path(8, "gfx/tokyo.png", None, "kmeans", 40) == "gfx/tokyo-palette-c8-kmeans-s40.png"
+    assert cli.find_file_path("dither", None, "gfx/tokyo.png").startswith("gfx/tokyo-find-dither-")
+    assert cli.reduce_file_path(8, "kmeans", "replace", "x.png", "gfx/tokyo.png") == "x.png"
+
+
+@pytest.mark.gpu
+def test_cli_reproduces_samples(tmp_path, capsys):
+    """samples.sh:3-8 through the CLI on the GPU"""
+    from kmeans_gpu_amd import cli
+    src = str(tmp_path / "tokyo.png")
+    shutil.copy(os.path.join(GOLDEN, "tokyo.png"), src)
+    out = str(tmp_path / "o.png")
+    assert cli.main(["find", "-i", src, "-p", "#050505,#ffffff,#ff0000", "-o", out]) == 0
+    assert np.array_equal(load_rgba(out), load_rgba("tokyo-find-replace-dark-white-red.png"))
+    assert cli.main(["find", "-i", src, "-p", os.path.join(GOLDEN, "apollo-1x.png"), "-m", "dither", "-o", out]) == 0
+    assert np.array_equal(load_rgba(out), load_rgba("tokyo-find-dither-apollo.png"))
+    assert cli.main(["reduce", "-i", src, "-c", "8"]) == 0
+    got = load_rgba(str(tmp_path / "tokyo-reduce-c8-kmeans-replace.png"))
+    gold = load_rgba("tokyo-reduce-c8-kmeans-replace.png")
+    c1, c2 = np.unique(got.reshape(-1, 4), axis=0), np.unique(gold.reshape(-1, 4), axis=0)
+    assert c1.shape == c2.shape and np.abs(c1.astype(int) - c2.astype(int)).max() <= 1
+    assert cli.main(["palette", "-i", src, "-c", "8", "-s", "40"]) == 0
+    assert "Palette: #" in capsys.readouterr().out
+    pal = load_rgba(str(tmp_path / "tokyo-palette-c8-kmeans-s40.png"))
+    assert pal.shape == (40, 320, 4)

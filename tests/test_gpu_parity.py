@@ -258,3 +258,28 @@ def test_more_clusters_than_pixels(processor, oracle):
     img = oracle.synth_uniform(8, 12).reshape(3, 4, 4)
     assert np.array_equal(processor.reduce(20, img), oracle.reduce(img, 20, 0))
     assert np.array_equal(processor.palette(20, img), oracle.palette(img, 20))
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 8, 46])
+def test_meld_matches_oracle(processor, oracle, tokyo, k):
+    """ReduceMode::Meld (mix_colors.wgsl main_meld).  Lab -> sRGB8 needs pow(c, 1/2.4) per pixel: the
+    oracle uses glibc's double pow, the device ocml's; both round a < 1 ulp(double) result to float,
+    so bytes may differ only at exact rounding boundaries -- tolerance: <= 1 LSB on <= 1e-5 of channels."""
+    img = tokyo[::3, ::3].copy()
+    if k == 46:
+        pal = sorted_palette("apollo-1x.png")
+    else:
+        pal = np.array(sorted(map(tuple, oracle.synth_uniform(k, k))), np.uint8)
+    got = processor.find(img, pal, 2)
+    want = oracle.find(img, pal, oracle.MODE_MELD)
+    diff = np.abs(got.astype(int) - want.astype(int))
+    assert diff.max() <= 1
+    assert (diff > 0).mean() <= 1e-5
+    assert np.all(got[..., 3] == 255)
+
+
+def test_reduce_meld_end_to_end(processor, oracle, tokyo):
+    got = processor.reduce(6, tokyo, reduce_mode=2)
+    want = oracle.reduce(tokyo, 6, oracle.MODE_MELD)
+    diff = np.abs(got.astype(int) - want.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() <= 1e-5
