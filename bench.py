@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--k", type=int, default=K)
     ap.add_argument("--rows", type=int, default=ROWS_PER_GPU, help="rows per GPU (default 8192)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise RCCL and run the all-reduce even with one rank (sanity check)")
     ap.add_argument("--strategy", choices=["auto", "scan", "table"], default="auto",
                     help="per-pixel scan, colour table, or the library's cost model (default)")
     args = ap.parse_args()
@@ -95,8 +97,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU path exists)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     k = args.k
@@ -129,13 +135,15 @@ def main():
     t_prep = time.perf_counter() - t_prep
 
     sh = ShardedLloyd(lloyd, k, rgba, labels, stream=stream)
+    if args.force_dist:
+        sh.world = 2          # take the collective path even though the group has one rank
     sh.prime()
     for _ in range(args.warmup):
         sh.iterate()
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -189,13 +197,22 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(k, cent, seed)
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
+    else:
+        line = None
 
     lloyd.close()
     proc.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if line is not None:
+        # RCCL writes its version banner to the C stdout buffer; flush it first so that the JSON
+        # line is the last thing on stdout
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
