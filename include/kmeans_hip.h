@@ -144,6 +144,10 @@ KMG_API int kmg_lloyd_prepare(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n_pi
  * masks for the current centroids are conservative.  out[0] = range violations, out[1] = colours
  * whose true arg-min is missing from its cell's candidate set (both must be 0).                 */
 KMG_API int kmg_debug_check_table(kmg_lloyd *s, uint64_t out[2], void *stream);
+/* Tuning support: statistics of the last colour-table pass over the bound image (synchronises).
+ * out = {occupied cells, sum of candidate counts, cells with one candidate, max candidates,
+ *        cells with one label, occupied sub-cells, sub-cells with one label, distinct colours}.  */
+KMG_API int kmg_debug_table_stats(kmg_lloyd *s, uint64_t out[8], void *stream);
 
 /* The two halves of kmg_lloyd_assign_accumulate, for callers that time or batch them:
  * _assign_partials runs the fused per-pixel kernel (labels + per-workgroup partial sums kept in

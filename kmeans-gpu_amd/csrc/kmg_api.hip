@@ -375,6 +375,42 @@ extern "C" int kmg_debug_check_table(kmg_lloyd *s, uint64_t out[2], void *stream
     return KMG_OK;
 }
 
+// test / tuning support: statistics of the last colour-table pass of the bound image.
+// out[0] occupied cells, [1] sum of candidate counts over occupied cells, [2] occupied cells with one
+// candidate, [3] largest candidate count, [4] cells whose occupied colours share one label,
+// [5] occupied sub-cells, [6] sub-cells whose occupied colours share one label, [7] distinct colours
+extern "C" int kmg_debug_table_stats(kmg_lloyd *s, uint64_t out[8], void *stream)
+{
+    if (!s || !out) return fail(KMG_ERR_INVALID_ARGUMENT, "bad table_stats arguments");
+    if (!s->tab.rgba) return fail(KMG_ERR_INVALID_ARGUMENT, "no image is bound");
+    HIP_TRY(hipSetDevice(s->p->device));
+    HIP_TRY(hipStreamSynchronize(S(stream)));
+    const uint32_t words = mask_words(s->k);
+    std::vector<uint64_t> masks((size_t)kCells * words);
+    std::vector<int64_t> agg(4ull * kCells);
+    std::vector<uint16_t> sub(kSubCells + kCells);
+    std::vector<uint32_t> hist(1u << 24);
+    HIP_TRY(hipMemcpy(masks.data(), s->tab.d_masks, masks.size() * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(agg.data(), s->tab.d_agg, agg.size() * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(sub.data(), s->tab.d_sub, sub.size() * 2, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hist.data(), s->tab.d_hist, hist.size() * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    for (uint32_t c = 0; c < kCells; ++c) {
+        if (agg[4ull * c + 3] == 0) continue;
+        uint64_t pop = 0;
+        for (uint32_t w = 0; w < words; ++w) pop += (uint64_t)__builtin_popcountll(masks[(size_t)c * words + w]);
+        out[0] += 1; out[1] += pop; out[2] += pop == 1; out[3] = std::max<uint64_t>(out[3], pop);
+        out[4] += sub[kSubCells + c] < kSubMixed;
+        for (uint32_t q = 0; q < 8; ++q) {
+            const uint16_t e = sub[c * 8 + q];
+            out[5] += e != kSubEmpty;
+            out[6] += e < kSubMixed;
+        }
+    }
+    for (uint32_t v : hist) out[7] += v != 0;
+    return KMG_OK;
+}
+
 static bool table_bound(const kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n)
 {
     return s->tab.rgba != nullptr && s->tab.rgba == d_rgba && s->tab.n == n;
