@@ -91,6 +91,7 @@ struct kmg_processor {
     float *d_lut;            // 256 x f32: sRGB decode * 100
     std::mutex mu;           // guards the lazily built static tables below
     CellBounds *d_bounds;    // kCells static cell bounds of the colour-table strategy
+    float4 *d_lab_table;     // 2^24 x (L, a, b, C): Lab of every colour (256 MiB, built with d_bounds)
 };
 
 struct ProfEvent { int id; hipEvent_t e0, e1; };
@@ -154,6 +155,7 @@ extern "C" int kmg_processor_create_ex(const kmg_options *opt, kmg_processor **o
     p->opt = o;
     p->d_lut = nullptr;
     p->d_bounds = nullptr;
+    p->d_lab_table = nullptr;
     float lut[256];
     build_srgb_lut100(lut);
     hipError_t e1 = hipMalloc((void **)&p->d_lut, sizeof lut);
@@ -173,6 +175,7 @@ extern "C" void kmg_processor_destroy(kmg_processor *p)
     (void)hipSetDevice(p->device);
     if (p->d_lut) (void)hipFree(p->d_lut);
     if (p->d_bounds) (void)hipFree(p->d_bounds);
+    if (p->d_lab_table) (void)hipFree(p->d_lab_table);
     delete p;
 }
 
@@ -291,10 +294,17 @@ static int ensure_bounds(kmg_processor *p, hipStream_t st)
     std::lock_guard<std::mutex> lock(p->mu);
     if (p->d_bounds) return KMG_OK;
     CellBounds *b = nullptr;
+    float4 *lab = nullptr;
     HIP_TRY(hipMalloc((void **)&b, sizeof(CellBounds) * kCells));
-    hipError_t e = launch_cell_bounds(p->d_lut, b, st);
+    hipError_t e = hipMalloc((void **)&lab, sizeof(float4) << 24);
+    if (e == hipSuccess) e = launch_cell_bounds(p->d_lut, b, lab, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { (void)hipFree(b); return fail(KMG_ERR_HIP, "cell bounds failed: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) {
+        (void)hipFree(b);
+        if (lab) (void)hipFree(lab);
+        return fail(e == hipErrorOutOfMemory ? KMG_ERR_OUT_OF_MEMORY : KMG_ERR_HIP, "colour tables failed: %s", hipGetErrorString(e));
+    }
+    p->d_lab_table = lab;
     p->d_bounds = b;
     return KMG_OK;
 }
@@ -322,7 +332,7 @@ extern "C" int kmg_lloyd_bind_image(kmg_lloyd *s, const uint8_t *d_rgba, uint64_
     t.rgba = nullptr;
     HIP_TRY(hipMemsetAsync(t.d_hist, 0, sizeof(uint32_t) << 24, S(stream)));
     HIP_TRY(launch_histogram((const uint32_t *)d_rgba, n, t.d_hist, S(stream)));
-    HIP_TRY(launch_cell_aggregates(t.d_hist, s->p->d_lut, t.d_agg, S(stream)));
+    HIP_TRY(launch_cell_aggregates(t.d_hist, s->p->d_lab_table, t.d_agg, S(stream)));
     t.rgba = d_rgba;
     t.n = n;
     return KMG_OK;
@@ -422,7 +432,7 @@ static int table_assign(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_
     ColourTable &t = s->tab;
     (void)sums;
     PROF_LAUNCH(s, KMG_K_CANDIDATES, st, launch_cell_candidates(s->p->d_bounds, t.d_agg, s->d_cent, s->k, t.d_masks, st));
-    PROF_LAUNCH(s, KMG_K_CUBE, st, launch_cube(t.d_hist, t.d_agg, t.d_masks, s->d_cent, s->k, s->p->d_lut,
+    PROF_LAUNCH(s, KMG_K_CUBE, st, launch_cube(t.d_hist, t.d_agg, t.d_masks, s->d_cent, s->k, s->p->d_lab_table,
                                                t.d_colour_labels, t.d_sub, s->d_partials, st));
     if (d_labels)
         PROF_LAUNCH(s, KMG_K_LABELS, st, launch_labels((const uint32_t *)d_rgba, n, t.d_colour_labels, t.d_sub, s->k, d_labels, st));

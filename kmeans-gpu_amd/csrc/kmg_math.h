@@ -90,11 +90,12 @@ KMG_HD float cie94(float L1, float a1, float b1, float L2, float a2, float b2)
 // Per-pixel terms of the arg-min key (hoisted out of the centroid loop).
 struct PixelTerms { float L, a, b, C, wC, wH; };
 
-KMG_HD PixelTerms pixel_terms(float L, float a, float b)
+// (C = chroma(a, b) supplied by the caller, e.g. from the per-colour Lab table)
+KMG_HD PixelTerms pixel_terms_c(float L, float a, float b, float C)
 {
     PixelTerms p;
     p.L = L; p.a = a; p.b = b;
-    p.C = chroma(a, b);
+    p.C = C;
     float SC = 1.0f + 0.045f * p.C;
     float SH = 1.0f + 0.015f * p.C;
     float iSC = 1.0f / SC, iSH = 1.0f / SH;
@@ -102,6 +103,8 @@ KMG_HD PixelTerms pixel_terms(float L, float a, float b)
     p.wH = iSH * iSH;
     return p;
 }
+
+KMG_HD PixelTerms pixel_terms(float L, float a, float b) { return pixel_terms_c(L, a, b, chroma(a, b)); }
 
 // Squared CIE94 used only for ordering: dL^2 + dC^2 wC + max(da^2 + db^2 - dC^2, 0) wH.
 KMG_HD float cie94_key(const PixelTerms &p, float L2, float a2, float b2, float C2)

@@ -56,17 +56,18 @@ __host__ __device__ inline void index_to_rgb(uint32_t idx, uint32_t &r, uint32_t
 
 inline uint32_t mask_words(uint32_t k) { return (k + 63u) / 64u; }
 
-// once per processor: bounds[kCells]
-hipError_t launch_cell_bounds(const float *lut, CellBounds *bounds, hipStream_t st);
+// once per processor: bounds[kCells] and lab_table[2^24] = (L, a, b, C) of every colour (256 MiB,
+// image independent) so that the per-iteration cube pass loads Lab instead of recomputing it
+hipError_t launch_cell_bounds(const float *lut, CellBounds *bounds, float4 *lab_table, hipStream_t st);
 // once per image: hist[2^24] must be zero on entry
 hipError_t launch_histogram(const uint32_t *rgba, uint64_t n, uint32_t *hist, hipStream_t st);
 // once per image: agg[kCells][4] = (sum qL, sum qa, sum qb, count) of the image's pixels per cell
-hipError_t launch_cell_aggregates(const uint32_t *hist, const float *lut, int64_t *agg, hipStream_t st);
+hipError_t launch_cell_aggregates(const uint32_t *hist, const float4 *lab_table, int64_t *agg, hipStream_t st);
 // per iteration
 hipError_t launch_cell_candidates(const CellBounds *bounds, const int64_t *agg, const Centroid *cent,
                                   uint32_t k, uint64_t *masks, hipStream_t st);
 hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const uint64_t *masks,
-                       const Centroid *cent, uint32_t k, const float *lut, void *colour_labels,
+                       const Centroid *cent, uint32_t k, const float4 *lab_table, void *colour_labels,
                        uint16_t *sub_table, int64_t *partials, hipStream_t st);
 hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_labels,
                          const uint16_t *sub_table, uint32_t k, uint32_t *labels, hipStream_t st);

@@ -70,7 +70,8 @@ __device__ __forceinline__ long long wave_sum(long long v)
 // static cell bounds (once per processor): one workgroup per cell, two colours per thread
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_cell_bounds(const float *__restrict__ lut,
-                                                        CellBounds *__restrict__ bounds)
+                                                        CellBounds *__restrict__ bounds,
+                                                        float4 *__restrict__ lab_table)
 {
     __shared__ float s_lut[256];
     __shared__ float s_min[6][kBlock / 64], s_max[6][kBlock / 64];
@@ -83,6 +84,7 @@ __global__ __launch_bounds__(kBlock) void k_cell_bounds(const float *__restrict_
         float L, a, b;
         colour_to_lab(s_lut, blockIdx.x * kCellColours + c, L, a, b);
         const PixelTerms p = pixel_terms(L, a, b);
+        lab_table[blockIdx.x * kCellColours + c] = make_float4(p.L, p.a, p.b, p.C);
         const float v[6] = {p.L, p.a, p.b, p.C, p.wC, p.wH};
 #pragma unroll
         for (int q = 0; q < 6; ++q) { mn[q] = fminf(mn[q], v[q]); mx[q] = fmaxf(mx[q], v[q]); }
@@ -110,9 +112,9 @@ __global__ __launch_bounds__(kBlock) void k_cell_bounds(const float *__restrict_
     }
 }
 
-hipError_t launch_cell_bounds(const float *lut, CellBounds *bounds, hipStream_t st)
+hipError_t launch_cell_bounds(const float *lut, CellBounds *bounds, float4 *lab_table, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_cell_bounds, dim3(kCells), dim3(kBlock), 0, st, lut, bounds);
+    hipLaunchKernelGGL(k_cell_bounds, dim3(kCells), dim3(kBlock), 0, st, lut, bounds, lab_table);
     return hipGetLastError();
 }
 
@@ -150,12 +152,9 @@ hipError_t launch_histogram(const uint32_t *rgba, uint64_t n, uint32_t *hist, hi
 // per-cell sums of the image (once per image): one wave per cell, 8 colours per lane
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_cell_aggregates(const uint32_t *__restrict__ hist,
-                                                            const float *__restrict__ lut,
+                                                            const float4 *__restrict__ lab_table,
                                                             int64_t *__restrict__ agg)
 {
-    __shared__ float s_lut[256];
-    s_lut[threadIdx.x] = lut[threadIdx.x];
-    __syncthreads();
     const uint32_t cell = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t base = cell * kCellColours + lane * 8;
@@ -166,12 +165,11 @@ __global__ __launch_bounds__(kBlock) void k_cell_aggregates(const uint32_t *__re
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         if (cnt[q]) {
-            float L, a, b;
-            colour_to_lab(s_lut, base + q, L, a, b);
+            const float4 v = lab_table[base + q];
             const long long m = (long long)cnt[q];
-            s[0] += m * (long long)lab_fix(L);
-            s[1] += m * (long long)lab_fix(a);
-            s[2] += m * (long long)lab_fix(b);
+            s[0] += m * (long long)lab_fix(v.x);
+            s[1] += m * (long long)lab_fix(v.y);
+            s[2] += m * (long long)lab_fix(v.z);
             s[3] += m;
         }
     }
@@ -181,9 +179,9 @@ __global__ __launch_bounds__(kBlock) void k_cell_aggregates(const uint32_t *__re
         for (int j = 0; j < 4; ++j) agg[4ull * cell + j] = s[j];
 }
 
-hipError_t launch_cell_aggregates(const uint32_t *hist, const float *lut, int64_t *agg, hipStream_t st)
+hipError_t launch_cell_aggregates(const uint32_t *hist, const float4 *lab_table, int64_t *agg, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_cell_aggregates, dim3(kCells / (kBlock / 64)), dim3(kBlock), 0, st, hist, lut, agg);
+    hipLaunchKernelGGL(k_cell_aggregates, dim3(kCells / (kBlock / 64)), dim3(kBlock), 0, st, hist, lab_table, agg);
     return hipGetLastError();
 }
 
@@ -232,14 +230,15 @@ hipError_t launch_cell_candidates(const CellBounds *bounds, const int64_t *agg, 
 
 // ------------------------------------------------------------------------------------------
 // cube pass (per iteration): one wave per cell, 8 colours (= 1/8 of a 4x4x4 sub-cell) per lane
-// LDS: [centroids kpad x 16 B][bins k x 32 B][sRGB table 1 KiB]
+// LDS: [centroids kpad x 16 B][bins k x 32 B].  Lab of a colour comes from the static per-colour
+// table (16 B load instead of ~200 VALU slots of sRGB->Lab).
 // ------------------------------------------------------------------------------------------
 template <typename LabelT>
 __global__ __launch_bounds__(kBlock) void k_cube(const uint32_t *__restrict__ hist,
                                                  const int64_t *__restrict__ agg,
                                                  const uint64_t *__restrict__ masks,
                                                  const Centroid *__restrict__ cent, uint32_t k,
-                                                 const float *__restrict__ lut,
+                                                 const float4 *__restrict__ lab_table,
                                                  LabelT *__restrict__ colour_labels,
                                                  uint16_t *__restrict__ sub_table,
                                                  int64_t *__restrict__ partials)
@@ -248,9 +247,7 @@ __global__ __launch_bounds__(kBlock) void k_cube(const uint32_t *__restrict__ hi
     const uint32_t kpad = (k + 3u) & ~3u;
     float4 *s_cent = smem4;
     unsigned long long *bins = reinterpret_cast<unsigned long long *>(smem4 + kpad);
-    float *s_lut = reinterpret_cast<float *>(bins + 4ull * k);
 
-    s_lut[threadIdx.x] = lut[threadIdx.x];
     stage_centroids(s_cent, cent, k, kpad);
     for (uint32_t i = threadIdx.x; i < 4 * k; i += kBlock) bins[i] = 0ull;
     __syncthreads();
@@ -302,8 +299,9 @@ __global__ __launch_bounds__(kBlock) void k_cube(const uint32_t *__restrict__ hi
         uint32_t idx[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            colour_to_lab(s_lut, base + q, L[q], A[q], B[q]);
-            pt[q] = pixel_terms(L[q], A[q], B[q]);
+            const float4 v = lab_table[base + q];              // (L, a, b, C) of this colour
+            L[q] = v.x; A[q] = v.y; B[q] = v.z;
+            pt[q] = pixel_terms_c(v.x, v.y, v.z, v.w);
             best[q] = 1.0e10f;                                   // find_centroid.wgsl:29-30
             idx[q] = 0u;
         }
@@ -382,17 +380,17 @@ __global__ __launch_bounds__(kBlock) void k_cube(const uint32_t *__restrict__ hi
 }
 
 hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const uint64_t *masks, const Centroid *cent,
-                       uint32_t k, const float *lut, void *colour_labels, uint16_t *sub_table,
+                       uint32_t k, const float4 *lab_table, void *colour_labels, uint16_t *sub_table,
                        int64_t *partials, hipStream_t st)
 {
     const uint32_t kpad = (k + 3u) & ~3u;
-    const size_t lds = sizeof(float4) * kpad + sizeof(unsigned long long) * 4ull * k + 256 * sizeof(float);
+    const size_t lds = sizeof(float4) * kpad + sizeof(unsigned long long) * 4ull * k;
     if (k <= 256)
         hipLaunchKernelGGL(k_cube<uint8_t>, dim3(kCubeGrid), dim3(kBlock), lds, st, hist, agg, masks, cent, k,
-                           lut, (uint8_t *)colour_labels, sub_table, partials);
+                           lab_table, (uint8_t *)colour_labels, sub_table, partials);
     else
         hipLaunchKernelGGL(k_cube<uint16_t>, dim3(kCubeGrid), dim3(kBlock), lds, st, hist, agg, masks, cent, k,
-                           lut, (uint16_t *)colour_labels, sub_table, partials);
+                           lab_table, (uint16_t *)colour_labels, sub_table, partials);
     return hipGetLastError();
 }
 
