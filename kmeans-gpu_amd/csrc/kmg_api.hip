@@ -104,7 +104,7 @@ struct ColourTable {
     int64_t *d_agg = nullptr;        // kCells x 4 per-cell sums of the image
     uint64_t *d_masks = nullptr;     // kCells x words candidate masks
     void *d_colour_labels = nullptr; // 2^24 x u8 (k <= 256) or u16
-    uint16_t *d_sub = nullptr;       // kSubCells 4x4x4 summaries followed by kCells 8x8x8 summaries
+    uint16_t *d_sub = nullptr;       // kSubCells 4x4x4 summaries (u16), kCells 8x8x8 summaries (u16), kCells pair entries (u32)
 };
 
 struct kmg_lloyd {
@@ -322,7 +322,7 @@ extern "C" int kmg_lloyd_bind_image(kmg_lloyd *s, const uint8_t *d_rgba, uint64_
         if (e == hipSuccess) e = hipMalloc((void **)&t.d_agg, sizeof(int64_t) * 4ull * kCells);
         if (e == hipSuccess) e = hipMalloc((void **)&t.d_masks, sizeof(uint64_t) * (size_t)kCells * words);
         if (e == hipSuccess) e = hipMalloc(&t.d_colour_labels, (size_t)(s->k <= 256 ? 1 : 2) << 24);
-        if (e == hipSuccess) e = hipMalloc((void **)&t.d_sub, sizeof(uint16_t) * (kSubCells + kCells));
+        if (e == hipSuccess) e = hipMalloc((void **)&t.d_sub, sizeof(uint16_t) * (kSubCells + kCells) + sizeof(uint32_t) * kCells);
         if (e != hipSuccess) {
             free_table(t);
             return fail(e == hipErrorOutOfMemory ? KMG_ERR_OUT_OF_MEMORY : KMG_ERR_HIP,

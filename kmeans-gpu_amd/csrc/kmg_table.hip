@@ -261,9 +261,12 @@ __global__ __launch_bounds__(kBlock) void k_cube(const uint32_t *__restrict__ hi
         const long long cell_count = (long long)uniform_u64((unsigned long long)agg[4ull * cell + 3]);
         uint16_t *sub = sub_table + cell * 8u;
         uint16_t *cell_entry = sub_table + kSubCells + cell;       // 8x8x8 summary, same encoding
+        // pair entry (k <= 256): [label A:8][label B:8][mask A:8][mask B:8]; bit s of a mask = every
+        // occupied colour of sub-cell s carries that label
+        uint32_t *pair_entry = reinterpret_cast<uint32_t *>(sub_table + kSubCells + kCells) + cell;
         if (cell_count == 0) {
             if (lane < 8) sub[lane] = kSubEmpty;
-            if (lane == 0) *cell_entry = kSubEmpty;
+            if (lane == 0) { *cell_entry = kSubEmpty; *pair_entry = 0u; }
             continue;
         }
         const uint64_t *mw = masks + (uint64_t)cell * words;
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(kBlock) void k_cube(const uint32_t *__restrict__ hi
             else
                 *reinterpret_cast<uint4 *>(colour_labels + base) = *reinterpret_cast<uint4 *>(v);
             if (lane < 8) sub[lane] = (uint16_t)first;
-            if (lane == 0) *cell_entry = (uint16_t)first;
+            if (lane == 0) { *cell_entry = (uint16_t)first; *pair_entry = (first & 0xFFu) | 0x00FF0000u; }
             if (lane < 4) atomicAdd(bins + 4ull * first + lane, (unsigned long long)agg[4ull * cell + lane]);
             continue;
         }
@@ -365,6 +368,28 @@ __global__ __launch_bounds__(kBlock) void k_cube(const uint32_t *__restrict__ hi
             state = (state == kSubEmpty) ? o : ((o == kSubEmpty || o == state) ? state : (uint32_t)kSubMixed);
         }
         if ((lane & 7u) == 0) sub[lane >> 3] = (uint16_t)state;
+        {
+            // the two first uniform labels of the cell and which sub-cells they cover
+            uint32_t st8[8];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) st8[g] = __shfl(state, g * 8, 64);
+            uint32_t A = 0xFFFFFFFFu, B = 0xFFFFFFFFu, mA = 0, mB = 0;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const uint32_t v = st8[g];
+                if (v < kSubMixed) {
+                    if (A == 0xFFFFFFFFu) A = v;
+                    else if (v != A && B == 0xFFFFFFFFu) B = v;
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const uint32_t v = st8[g];
+                if (v == kSubEmpty || v == A) mA |= 1u << g;
+                else if (v == B) mB |= 1u << g;
+            }
+            if (lane == 0) *pair_entry = (A & 0xFFu) | ((B & 0xFFu) << 8) | (mA << 16) | (mB << 24);
+        }
         // ... and over the whole 8x8x8 cell
 #pragma unroll
         for (int off = 8; off < 64; off <<= 1) {
@@ -445,9 +470,67 @@ __global__ __launch_bounds__(kLabelBlock) void k_labels(const uint32_t *__restri
     }
 }
 
+// k <= 256: the whole first two levels live in LDS.  One u32 per 8x8x8 cell (128 KiB, one workgroup
+// of 1024 threads per CU): two labels and, for each, the mask of 4x4x4 sub-cells all of whose occupied
+// colours carry it.  Pixels of other sub-cells (mixed, or a third label) go to the per-colour table.
+// Divergent global gathers retire at ~1 per 2 clocks per CU whether they hit L2 or not
+// (tools/gather_rate.hip), so resolving ~2/3 of the pixels from LDS is what pays.
+__global__ __launch_bounds__(kLabelBlock) void k_labels_pairs(const uint32_t *__restrict__ rgba, uint64_t n,
+                                                              const uint8_t *__restrict__ colour_labels,
+                                                              const uint32_t *__restrict__ pair_table,
+                                                              uint32_t *__restrict__ labels, int aligned)
+{
+    __shared__ uint32_t s_pair[kCells];
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(pair_table);
+        uint4 *dst = reinterpret_cast<uint4 *>(s_pair);
+        for (uint32_t i = threadIdx.x; i < kCells / 4; i += kLabelBlock) dst[i] = src[i];
+    }
+    __syncthreads();
+    constexpr uint64_t TILE = (uint64_t)kLabelBlock * 8;
+    const uint64_t tiles = (n + TILE - 1) / TILE;
+    for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        uint32_t ci[8];
+        uint64_t i0[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            i0[g] = tile * TILE + (uint64_t)g * (kLabelBlock * 4) + (uint64_t)threadIdx.x * 4;
+            uint32_t px[4];
+            load4_stream(rgba, i0[g], n, aligned != 0, px);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ci[g * 4 + q] = colour_index(px[q]);
+        }
+        uint32_t lab[8];
+        bool fine[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const uint32_t e = s_pair[ci[p] >> 9];
+            const uint32_t sub = (ci[p] >> 6) & 7u;
+            const bool inA = (e >> (16 + sub)) & 1u, inB = (e >> (24 + sub)) & 1u;
+            lab[p] = inA ? (e & 0xFFu) : ((e >> 8) & 0xFFu);
+            fine[p] = !(inA || inB);
+        }
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+            if (fine[p]) lab[p] = (uint32_t)colour_labels[ci[p]];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) store4_stream(labels, i0[g], n, aligned != 0, lab + g * 4);
+    }
+}
+
 hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_labels, const uint16_t *sub_table,
                          uint32_t k, uint32_t *labels, hipStream_t st)
 {
+    if (k <= 256) {
+        const uint64_t tiles = (n + kLabelBlock * 8 - 1) / (kLabelBlock * 8);
+        const uint32_t grid = (uint32_t)(tiles < 256 ? (tiles ? tiles : 1) : 256);   // 1 workgroup per CU
+        const int aligned = ((reinterpret_cast<uintptr_t>(rgba) & 15u) == 0 &&
+                             (reinterpret_cast<uintptr_t>(labels) & 15u) == 0) ? 1 : 0;
+        hipLaunchKernelGGL(k_labels_pairs, dim3(grid), dim3(kLabelBlock), 0, st, rgba, n,
+                           (const uint8_t *)colour_labels,
+                           reinterpret_cast<const uint32_t *>(sub_table + kSubCells + kCells), labels, aligned);
+        return hipGetLastError();
+    }
     const uint64_t tiles = (n + kLabelBlock * 8 - 1) / (kLabelBlock * 8);
     const uint32_t grid = (uint32_t)(tiles < 512 ? (tiles ? tiles : 1) : 512);   // 2 workgroups per CU
     const int aligned = ((reinterpret_cast<uintptr_t>(rgba) & 15u) == 0 &&
