@@ -165,7 +165,8 @@ def main():
         total_pixels = n_local * world
         ms_per_step = elapsed * 1e3 / args.steps
         kernels = {name: {"ms_per_launch": ms / cnt, "launches": cnt} for name, (ms, cnt) in prof.items()}
-        dominant = max(prof, key=lambda name: prof[name][0])
+        dominant = max((nm for nm in prof if algorithmic_bytes(nm, n_local, k) is not None),
+                       key=lambda name: prof[name][0])
         k_ms = kernels[dominant]["ms_per_launch"]
         abytes = algorithmic_bytes(dominant, n_local, k)
         achieved = abytes / (k_ms * 1e-3) / 1e9

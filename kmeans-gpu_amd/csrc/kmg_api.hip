@@ -103,6 +103,7 @@ struct ColourTable {
     uint32_t *d_hist = nullptr;      // 2^24 counts, cell-major colour order
     int64_t *d_agg = nullptr;        // kCells x 4 per-cell sums of the image
     uint64_t *d_masks = nullptr;     // kCells x words candidate masks
+    uint32_t *d_work = nullptr;      // 1 + kCells: dense list of the occupied cells
     void *d_colour_labels = nullptr; // 2^24 x u8 (k <= 256) or u16
     uint16_t *d_sub = nullptr;       // kSubCells 4x4x4 summaries (u16), kCells 8x8x8 summaries (u16), kCells pair entries (u32)
 };
@@ -269,6 +270,7 @@ static void free_table(ColourTable &t)
     if (t.d_hist) (void)hipFree(t.d_hist);
     if (t.d_agg) (void)hipFree(t.d_agg);
     if (t.d_masks) (void)hipFree(t.d_masks);
+    if (t.d_work) (void)hipFree(t.d_work);
     if (t.d_colour_labels) (void)hipFree(t.d_colour_labels);
     if (t.d_sub) (void)hipFree(t.d_sub);
     t = ColourTable();
@@ -321,6 +323,7 @@ extern "C" int kmg_lloyd_bind_image(kmg_lloyd *s, const uint8_t *d_rgba, uint64_
         hipError_t e = hipMalloc((void **)&t.d_hist, sizeof(uint32_t) << 24);
         if (e == hipSuccess) e = hipMalloc((void **)&t.d_agg, sizeof(int64_t) * 4ull * kCells);
         if (e == hipSuccess) e = hipMalloc((void **)&t.d_masks, sizeof(uint64_t) * (size_t)kCells * words);
+        if (e == hipSuccess) e = hipMalloc((void **)&t.d_work, sizeof(uint32_t) * (kCells + 1));
         if (e == hipSuccess) e = hipMalloc(&t.d_colour_labels, (size_t)(s->k <= 256 ? 1 : 2) << 24);
         if (e == hipSuccess) e = hipMalloc((void **)&t.d_sub, sizeof(uint16_t) * (kSubCells + kCells) + sizeof(uint32_t) * kCells);
         if (e != hipSuccess) {
@@ -330,9 +333,24 @@ extern "C" int kmg_lloyd_bind_image(kmg_lloyd *s, const uint8_t *d_rgba, uint64_
         }
     }
     t.rgba = nullptr;
+    // entries of cells no pixel falls into are never read by the label pass; 0xFF.. = "empty"
+    HIP_TRY(hipMemsetAsync(t.d_sub, 0xFF, sizeof(uint16_t) * (kSubCells + kCells) + sizeof(uint32_t) * kCells, S(stream)));
     HIP_TRY(hipMemsetAsync(t.d_hist, 0, sizeof(uint32_t) << 24, S(stream)));
     HIP_TRY(launch_histogram((const uint32_t *)d_rgba, n, t.d_hist, S(stream)));
     HIP_TRY(launch_cell_aggregates(t.d_hist, s->p->d_lab_table, t.d_agg, S(stream)));
+    {
+        // dense list of the occupied cells (static for this image)
+        std::vector<int64_t> agg(4ull * kCells);
+        HIP_TRY(hipMemcpyAsync(agg.data(), t.d_agg, sizeof(int64_t) * agg.size(), hipMemcpyDeviceToHost, S(stream)));
+        HIP_TRY(hipStreamSynchronize(S(stream)));
+        std::vector<uint32_t> work(1, 0u);
+        work.reserve(kCells + 1);
+        for (uint32_t c = 0; c < kCells; ++c)
+            if (agg[4ull * c + 3] != 0) work.push_back(c);
+        work[0] = (uint32_t)work.size() - 1;
+        HIP_TRY(hipMemcpyAsync(t.d_work, work.data(), sizeof(uint32_t) * work.size(), hipMemcpyHostToDevice, S(stream)));
+        HIP_TRY(hipStreamSynchronize(S(stream)));
+    }
     t.rgba = d_rgba;
     t.n = n;
     return KMG_OK;
@@ -432,7 +450,7 @@ static int table_assign(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_
     ColourTable &t = s->tab;
     (void)sums;
     PROF_LAUNCH(s, KMG_K_CANDIDATES, st, launch_cell_candidates(s->p->d_bounds, t.d_agg, s->d_cent, s->k, t.d_masks, st));
-    PROF_LAUNCH(s, KMG_K_CUBE, st, launch_cube(t.d_hist, t.d_agg, t.d_masks, s->d_cent, s->k, s->p->d_lab_table,
+    PROF_LAUNCH(s, KMG_K_CUBE, st, launch_cube(t.d_hist, t.d_agg, t.d_masks, t.d_work, s->d_cent, s->k, s->p->d_lab_table,
                                                t.d_colour_labels, t.d_sub, s->d_partials, st));
     if (d_labels)
         PROF_LAUNCH(s, KMG_K_LABELS, st, launch_labels((const uint32_t *)d_rgba, n, t.d_colour_labels, t.d_sub, s->k, d_labels, st));

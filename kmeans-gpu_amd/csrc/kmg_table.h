@@ -66,7 +66,9 @@ hipError_t launch_cell_aggregates(const uint32_t *hist, const float4 *lab_table,
 // per iteration
 hipError_t launch_cell_candidates(const CellBounds *bounds, const int64_t *agg, const Centroid *cent,
                                   uint32_t k, uint64_t *masks, hipStream_t st);
-hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const uint64_t *masks,
+// work: [0] = number of occupied cells of the bound image, [1..] = their indices (built at bind time):
+// the cube pass walks a dense list and issues all loads of a cell at once
+hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const uint64_t *masks, const uint32_t *work,
                        const Centroid *cent, uint32_t k, const float4 *lab_table, void *colour_labels,
                        uint16_t *sub_table, int64_t *partials, hipStream_t st);
 hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_labels,

@@ -237,6 +237,7 @@ template <typename LabelT>
 __global__ __launch_bounds__(kBlock) void k_cube(const uint32_t *__restrict__ hist,
                                                  const int64_t *__restrict__ agg,
                                                  const uint64_t *__restrict__ masks,
+                                                 const uint32_t *__restrict__ work,
                                                  const Centroid *__restrict__ cent, uint32_t k,
                                                  const float4 *__restrict__ lab_table,
                                                  LabelT *__restrict__ colour_labels,
@@ -257,18 +258,21 @@ __global__ __launch_bounds__(kBlock) void k_cube(const uint32_t *__restrict__ hi
     const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (kBlock / 64);
 
-    for (uint32_t cell = wave; cell < kCells; cell += n_waves) {
-        const long long cell_count = (long long)uniform_u64((unsigned long long)agg[4ull * cell + 3]);
+    const uint32_t n_work = __builtin_amdgcn_readfirstlane(work[0]);
+    for (uint32_t wi = wave; wi < n_work; wi += n_waves) {
+        const uint32_t cell = __builtin_amdgcn_readfirstlane(work[1u + wi]);
         uint16_t *sub = sub_table + cell * 8u;
         uint16_t *cell_entry = sub_table + kSubCells + cell;       // 8x8x8 summary, same encoding
         // pair entry (k <= 256): [label A:8][label B:8][mask A:8][mask B:8]; bit s of a mask = every
         // occupied colour of sub-cell s carries that label
         uint32_t *pair_entry = reinterpret_cast<uint32_t *>(sub_table + kSubCells + kCells) + cell;
-        if (cell_count == 0) {
-            if (lane < 8) sub[lane] = kSubEmpty;
-            if (lane == 0) { *cell_entry = kSubEmpty; *pair_entry = 0u; }
-            continue;
-        }
+        const uint32_t base = cell * kCellColours + lane * 8;
+        // every load of this cell is issued before anything depends on one of them
+        const uint4 c0 = *reinterpret_cast<const uint4 *>(hist + base);
+        const uint4 c1 = *reinterpret_cast<const uint4 *>(hist + base + 4);
+        float4 lab8[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) lab8[q] = lab_table[base + q];   // (L, a, b, C) of this colour
         const uint64_t *mw = masks + (uint64_t)cell * words;
         uint32_t npop = 0, first = 0;
         for (uint32_t w = 0; w < words; ++w) {
@@ -276,7 +280,6 @@ __global__ __launch_bounds__(kBlock) void k_cube(const uint32_t *__restrict__ hi
             if (npop == 0 && m) first = w * 64 + (uint32_t)__builtin_ctzll(m);
             npop += (uint32_t)__builtin_popcountll(m);
         }
-        const uint32_t base = cell * kCellColours + lane * 8;
 
         if (npop == 1) {
             // the whole cell belongs to `first`: labels for its 512 colours, sums from the cell table
@@ -293,8 +296,6 @@ __global__ __launch_bounds__(kBlock) void k_cube(const uint32_t *__restrict__ hi
             continue;
         }
 
-        const uint4 c0 = *reinterpret_cast<const uint4 *>(hist + base);
-        const uint4 c1 = *reinterpret_cast<const uint4 *>(hist + base + 4);
         const uint32_t cnt[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
         float L[8], A[8], B[8];
         PixelTerms pt[8];
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(kBlock) void k_cube(const uint32_t *__restrict__ hi
         uint32_t idx[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const float4 v = lab_table[base + q];              // (L, a, b, C) of this colour
+            const float4 v = lab8[q];
             L[q] = v.x; A[q] = v.y; B[q] = v.z;
             pt[q] = pixel_terms_c(v.x, v.y, v.z, v.w);
             best[q] = 1.0e10f;                                   // find_centroid.wgsl:29-30
@@ -404,17 +405,17 @@ __global__ __launch_bounds__(kBlock) void k_cube(const uint32_t *__restrict__ hi
     for (uint32_t i = threadIdx.x; i < 4 * k; i += kBlock) row[i] = bins[i];
 }
 
-hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const uint64_t *masks, const Centroid *cent,
-                       uint32_t k, const float4 *lab_table, void *colour_labels, uint16_t *sub_table,
+hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const uint64_t *masks, const uint32_t *work,
+                       const Centroid *cent, uint32_t k, const float4 *lab_table, void *colour_labels, uint16_t *sub_table,
                        int64_t *partials, hipStream_t st)
 {
     const uint32_t kpad = (k + 3u) & ~3u;
     const size_t lds = sizeof(float4) * kpad + sizeof(unsigned long long) * 4ull * k;
     if (k <= 256)
-        hipLaunchKernelGGL(k_cube<uint8_t>, dim3(kCubeGrid), dim3(kBlock), lds, st, hist, agg, masks, cent, k,
+        hipLaunchKernelGGL(k_cube<uint8_t>, dim3(kCubeGrid), dim3(kBlock), lds, st, hist, agg, masks, work, cent, k,
                            lab_table, (uint8_t *)colour_labels, sub_table, partials);
     else
-        hipLaunchKernelGGL(k_cube<uint16_t>, dim3(kCubeGrid), dim3(kBlock), lds, st, hist, agg, masks, cent, k,
+        hipLaunchKernelGGL(k_cube<uint16_t>, dim3(kCubeGrid), dim3(kBlock), lds, st, hist, agg, masks, work, cent, k,
                            lab_table, (uint16_t *)colour_labels, sub_table, partials);
     return hipGetLastError();
 }
