@@ -149,6 +149,11 @@ KMG_API int kmg_debug_check_table(kmg_lloyd *s, uint64_t out[2], void *stream);
  *        cells with one label, occupied sub-cells, sub-cells with one label, distinct colours}.  */
 KMG_API int kmg_debug_table_stats(kmg_lloyd *s, uint64_t out[8], void *stream);
 
+/* Labels only, for the CURRENT centroid table: find_centroid.wgsl:15-44 without the sums.  With a
+ * bound image whose label tables are current (an assign pass ran since the last centroid change) this
+ * is just the label-gather pass.                                                                 */
+KMG_API int kmg_lloyd_labels(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n_pixels, uint32_t *d_labels, void *stream);
+
 /* The two halves of kmg_lloyd_assign_accumulate, for callers that time or batch them:
  * _assign_partials runs the fused per-pixel kernel (labels + per-workgroup partial sums kept in
  * the state), _reduce_partials folds the partial sums of that same launch into d_acc4.        */
@@ -157,8 +162,10 @@ KMG_API int kmg_lloyd_assign_partials(kmg_lloyd *s, const uint8_t *d_rgba, uint6
 KMG_API int kmg_lloyd_reduce_partials(kmg_lloyd *s, uint64_t n_pixels, int64_t *d_acc4, void *stream);
 
 /* Per-launch timing of the state's kernels with HIP events recorded on the launch stream itself
- * (bench.py's roofline leg).  _profile(1) starts collecting, _profile_read synchronises the
- * recorded events, returns the summed duration and launch count per kernel id and resets.       */
+ * (bench.py's roofline leg).  _profile(mask) starts collecting for the kernel ids whose bit is set
+ * (-1 = all, 0 = stop); _profile_read synchronises the recorded events, returns the summed duration
+ * and launch count per kernel id and resets.  Every timed launch adds two event records to the
+ * stream, so time only what is needed inside a throughput measurement.                            */
 typedef enum kmg_kernel_id {
     KMG_K_ASSIGN = 0, KMG_K_REDUCE = 1, KMG_K_UPDATE = 2, KMG_K_CANDIDATES = 3, KMG_K_CUBE = 4,
     KMG_K_LABELS = 5, KMG_K_COUNT = 6

@@ -48,11 +48,17 @@ static int fail(int code, const char *fmt, ...)
     } while (0)
 
 // launch wrapper: when profiling is on, bracket the launch with HIP events on its own stream
+// (events come from a pool that kmg_lloyd_profile_read recycles: no create/destroy in the hot loop)
 #define PROF_LAUNCH(s_, id_, st_, expr)                                                        \
     do {                                                                                       \
-        if ((s_)->prof) {                                                                      \
+        if ((s_)->prof & (1u << (id_))) {                                                      \
             ProfEvent pe_; pe_.id = (id_);                                                     \
-            HIP_TRY(hipEventCreate(&pe_.e0)); HIP_TRY(hipEventCreate(&pe_.e1));                \
+            if ((s_)->pool.size() >= 2) {                                                      \
+                pe_.e0 = (s_)->pool.back(); (s_)->pool.pop_back();                             \
+                pe_.e1 = (s_)->pool.back(); (s_)->pool.pop_back();                             \
+            } else {                                                                           \
+                HIP_TRY(hipEventCreate(&pe_.e0)); HIP_TRY(hipEventCreate(&pe_.e1));            \
+            }                                                                                  \
             HIP_TRY(hipEventRecord(pe_.e0, (st_)));                                            \
             HIP_TRY(expr);                                                                     \
             HIP_TRY(hipEventRecord(pe_.e1, (st_)));                                            \
@@ -104,6 +110,7 @@ struct ColourTable {
     int64_t *d_agg = nullptr;        // kCells x 4 per-cell sums of the image
     uint64_t *d_masks = nullptr;     // kCells x words candidate masks
     uint32_t *d_work = nullptr;      // 1 + kCells: dense list of the occupied cells
+    bool tables_valid = false;       // label tables describe the CURRENT centroid table
     void *d_colour_labels = nullptr; // 2^24 x u8 (k <= 256) or u16
     uint16_t *d_sub = nullptr;       // kSubCells 4x4x4 summaries (u16), kCells 8x8x8 summaries (u16), kCells pair entries (u32)
 };
@@ -120,8 +127,9 @@ struct kmg_lloyd {
     uint64_t dist_cap;
     uint32_t last_rows;          // rows of d_partials written by the last assign pass
     ColourTable tab;
-    bool prof;                   // per-launch HIP-event timing (kmg_lloyd_profile)
+    uint32_t prof;               // per-launch HIP-event timing: bit i = time kernel id i (kmg_lloyd_profile)
     std::vector<ProfEvent> events;
+    std::vector<hipEvent_t> pool; // recycled timing events
 };
 
 extern "C" int kmg_processor_create(kmg_processor **out) { return kmg_processor_create_ex(nullptr, out); }
@@ -265,6 +273,7 @@ struct StreamGuard {
 // colour-table strategy (kmg_table.h): binding an image, strategy choice
 // ---------------------------------------------------------------------------------------------
 static void drop_events(kmg_lloyd *s);
+static void destroy_events(kmg_lloyd *s);
 static void free_table(ColourTable &t)
 {
     if (t.d_hist) (void)hipFree(t.d_hist);
@@ -333,6 +342,7 @@ extern "C" int kmg_lloyd_bind_image(kmg_lloyd *s, const uint8_t *d_rgba, uint64_
         }
     }
     t.rgba = nullptr;
+    t.tables_valid = false;
     // entries of cells no pixel falls into are never read by the label pass; 0xFF.. = "empty"
     HIP_TRY(hipMemsetAsync(t.d_sub, 0xFF, sizeof(uint16_t) * (kSubCells + kCells) + sizeof(uint32_t) * kCells, S(stream)));
     HIP_TRY(hipMemsetAsync(t.d_hist, 0, sizeof(uint32_t) << 24, S(stream)));
@@ -452,6 +462,7 @@ static int table_assign(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_
     PROF_LAUNCH(s, KMG_K_CANDIDATES, st, launch_cell_candidates(s->p->d_bounds, t.d_agg, s->d_cent, s->k, t.d_masks, st));
     PROF_LAUNCH(s, KMG_K_CUBE, st, launch_cube(t.d_hist, t.d_agg, t.d_masks, t.d_work, s->d_cent, s->k, s->p->d_lab_table,
                                                t.d_colour_labels, t.d_sub, s->d_partials, st));
+    t.tables_valid = true;
     if (d_labels)
         PROF_LAUNCH(s, KMG_K_LABELS, st, launch_labels((const uint32_t *)d_rgba, n, t.d_colour_labels, t.d_sub, s->k, d_labels, st));
     return KMG_OK;
@@ -469,7 +480,7 @@ extern "C" int kmg_lloyd_create(kmg_processor *p, uint32_t k, kmg_lloyd **out)
     s->p = p;
     s->k = k;
     s->d_cent = nullptr; s->d_partials = nullptr; s->d_acc = nullptr; s->d_nconv = nullptr;
-    s->d_key = nullptr; s->d_dist = nullptr; s->dist_cap = 0; s->last_rows = 0; s->prof = false;
+    s->d_key = nullptr; s->d_dist = nullptr; s->dist_cap = 0; s->last_rows = 0; s->prof = 0;
     hipError_t e = hipMalloc((void **)&s->d_cent, sizeof(Centroid) * k);
     if (e == hipSuccess) e = hipMemset(s->d_cent, 0, sizeof(Centroid) * k);   // structures.rs:501-521
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_partials, sizeof(int64_t) * 4ull * k * 2048ull);
@@ -497,7 +508,7 @@ extern "C" void kmg_lloyd_destroy(kmg_lloyd *s)
     if (s->d_key) (void)hipFree(s->d_key);
     if (s->d_dist) (void)hipFree(s->d_dist);
     free_table(s->tab);
-    drop_events(s);
+    destroy_events(s);
     delete s;
 }
 
@@ -510,6 +521,7 @@ extern "C" int kmg_lloyd_set_centroids(kmg_lloyd *s, const float *c4, void *stre
         h[i].L = c4[4 * i]; h[i].a = c4[4 * i + 1]; h[i].b = c4[4 * i + 2];
         h[i].C = chroma(h[i].a, h[i].b);
     }
+    s->tab.tables_valid = false;
     HIP_TRY(hipMemcpyAsync(s->d_cent, h.data(), sizeof(Centroid) * s->k, hipMemcpyHostToDevice, S(stream)));
     HIP_TRY(hipStreamSynchronize(S(stream)));
     return KMG_OK;
@@ -534,6 +546,7 @@ extern "C" int kmg_lloyd_init_centroids(kmg_lloyd *s, const uint8_t *d_rgba, uin
     HIP_TRY(hipSetDevice(s->p->device));
     const uint64_t n = (uint64_t)w * h;
     if (n > 0xFFFFFFFFull) return fail(KMG_ERR_UNSUPPORTED, "image has more than 2^32-1 pixels");
+    s->tab.tables_valid = false;
     // plus_plus_init.wgsl:161-168: rand(42) = 0.5625, rand(12) = 0.93359375 in IEEE binary32
     const int32_t x0 = (int32_t)((float)w * 0.5625f);
     const int32_t y0 = (int32_t)((float)h * 0.93359375f);
@@ -588,6 +601,20 @@ extern "C" int kmg_lloyd_assign_partials(kmg_lloyd *s, const uint8_t *d_rgba, ui
     return assign_pass(s, d_rgba, n, d_labels, true, S(stream));
 }
 
+extern "C" int kmg_lloyd_labels(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_t *d_labels, void *stream)
+{
+    if (!s || !d_rgba || !d_labels || n == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad labels arguments");
+    HIP_TRY(hipSetDevice(s->p->device));
+    if (table_bound(s, d_rgba, n) && s->tab.tables_valid) {
+        PROF_LAUNCH(s, KMG_K_LABELS, S(stream), launch_labels((const uint32_t *)d_rgba, n, s->tab.d_colour_labels,
+                                                              s->tab.d_sub, s->k, d_labels, S(stream)));
+        return KMG_OK;
+    }
+    PROF_LAUNCH(s, KMG_K_ASSIGN, S(stream), launch_assign((const uint32_t *)d_rgba, n, s->d_cent, s->k, s->p->d_lut,
+                                                          d_labels, nullptr, S(stream)));
+    return KMG_OK;
+}
+
 extern "C" int kmg_lloyd_reduce_partials(kmg_lloyd *s, uint64_t n, int64_t *d_acc4, void *stream)
 {
     if (!s || !d_acc4 || n == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad reduce_partials arguments");
@@ -599,8 +626,15 @@ extern "C" int kmg_lloyd_reduce_partials(kmg_lloyd *s, uint64_t n, int64_t *d_ac
 
 static void drop_events(kmg_lloyd *s)
 {
-    for (ProfEvent &e : s->events) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); }
+    for (ProfEvent &e : s->events) { s->pool.push_back(e.e0); s->pool.push_back(e.e1); }
     s->events.clear();
+}
+
+static void destroy_events(kmg_lloyd *s)
+{
+    drop_events(s);
+    for (hipEvent_t e : s->pool) (void)hipEventDestroy(e);
+    s->pool.clear();
 }
 
 extern "C" const char *kmg_kernel_name(int id)
@@ -614,7 +648,13 @@ extern "C" int kmg_lloyd_profile(kmg_lloyd *s, int enable)
     if (!s) return fail(KMG_ERR_INVALID_ARGUMENT, "bad profile arguments");
     HIP_TRY(hipSetDevice(s->p->device));
     drop_events(s);
-    s->prof = enable != 0;
+    s->prof = enable < 0 ? 0xFFFFFFFFu : (uint32_t)enable;
+    if (s->prof)   // pre-create a pool so the timed region does not pay for event creation
+        while (s->pool.size() < 512) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            s->pool.push_back(e);
+        }
     return KMG_OK;
 }
 
@@ -638,6 +678,7 @@ extern "C" int kmg_lloyd_update(kmg_lloyd *s, const int64_t *d_acc4, void *strea
 {
     if (!s || !d_acc4) return fail(KMG_ERR_INVALID_ARGUMENT, "bad update arguments");
     HIP_TRY(hipSetDevice(s->p->device));
+    s->tab.tables_valid = false;
     PROF_LAUNCH(s, KMG_K_UPDATE, S(stream), launch_update(d_acc4, s->k, s->p->opt.convergence, s->d_cent, s->d_nconv, S(stream)));
     return KMG_OK;
 }

@@ -65,7 +65,7 @@ SYMBOLS = [
     "kmg_palette_to_centroids", "kmg_centroids_to_palette", "kmg_dev_rgb_to_lab", "kmg_resized_dims",
     "kmg_dev_resize", "kmg_lloyd_create", "kmg_lloyd_destroy", "kmg_lloyd_set_centroids",
     "kmg_lloyd_get_centroids", "kmg_lloyd_init_centroids", "kmg_lloyd_assign_accumulate",
-    "kmg_lloyd_assign_partials", "kmg_lloyd_reduce_partials", "kmg_lloyd_bind_image",
+    "kmg_lloyd_assign_partials", "kmg_lloyd_reduce_partials", "kmg_lloyd_labels", "kmg_lloyd_bind_image",
     "kmg_lloyd_unbind_image", "kmg_lloyd_prepare", "kmg_debug_check_table", "kmg_debug_table_stats", "kmg_kernel_name",
     "kmg_lloyd_profile", "kmg_lloyd_profile_read",
     "kmg_lloyd_update", "kmg_lloyd_converged_count", "kmg_lloyd_run", "kmg_dev_apply",
@@ -118,6 +118,7 @@ def lib():
     L.kmg_lloyd_assign_accumulate.argtypes = [vp, u8p, C.c_uint64, u32p, i64p, vp]
     L.kmg_lloyd_assign_partials.argtypes = [vp, u8p, C.c_uint64, u32p, vp]
     L.kmg_lloyd_reduce_partials.argtypes = [vp, C.c_uint64, i64p, vp]
+    L.kmg_lloyd_labels.argtypes = [vp, u8p, C.c_uint64, u32p, vp]
     L.kmg_lloyd_bind_image.argtypes = [vp, u8p, C.c_uint64, vp]
     L.kmg_debug_table_stats.argtypes = [vp, C.POINTER(C.c_uint64), vp]
     L.kmg_kernel_name.argtypes = [C.c_int]
@@ -306,6 +307,10 @@ class Lloyd:
         _check(lib().kmg_lloyd_assign_partials(self._h, C.c_void_p(d_rgba), n_pixels,
                                                C.c_void_p(d_labels or None), C.c_void_p(stream)))
 
+    def labels(self, d_rgba, n_pixels, d_labels, stream=0):
+        """labels only, for the current centroid table"""
+        _check(lib().kmg_lloyd_labels(self._h, C.c_void_p(d_rgba), n_pixels, C.c_void_p(d_labels), C.c_void_p(stream)))
+
     def reduce_partials(self, n_pixels, d_acc4, stream=0):
         _check(lib().kmg_lloyd_reduce_partials(self._h, n_pixels, C.c_void_p(d_acc4), C.c_void_p(stream)))
 
@@ -320,9 +325,21 @@ class Lloyd:
                                        C.byref(st), C.c_void_p(stream)))
         return "table" if st.value == 1 else "scan"
 
+    KERNEL_IDS = {"k_assign": 0, "k_reduce_partials": 1, "k_update": 2, "k_cell_candidates": 3, "k_cube": 4,
+                  "k_labels": 5}
+
     def profile(self, enable=True):
-        """start / stop per-launch HIP-event timing of this state's kernels"""
-        _check(lib().kmg_lloyd_profile(self._h, int(bool(enable))))
+        """start / stop per-launch HIP-event timing: True = every kernel, False = stop, or an iterable
+        of kernel names (KERNEL_IDS) to time only those"""
+        if enable is True:
+            mask = -1
+        elif not enable:
+            mask = 0
+        else:
+            mask = 0
+            for name in enable:
+                mask |= 1 << self.KERNEL_IDS[name]
+        _check(lib().kmg_lloyd_profile(self._h, mask))
 
     def profile_read(self):
         """{kernel name: (total ms, launches)} since the last read; synchronises the events"""
