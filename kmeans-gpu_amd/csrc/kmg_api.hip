@@ -285,18 +285,21 @@ static void free_table(ColourTable &t)
     t = ColourTable();
 }
 
-// Cost model (seconds per iteration, MI355X, measured constants -- DESIGN.md section 4):
-//   brute force : n * (13.3 k + 240) VALU slots / 5.5e13 per second
-//   colour table: ~1e-4 fixed (candidates + cube pass) + n * 1.4e-11 for the label gather when labels
-//                 are materialised + the one-off histogram (n * 5e-11) spread over >= 10 passes
+// Cost model (seconds per iteration on MI355X; constants fitted to tools/strategy_sweep.py, round 1):
+//   per-pixel scan : n * (8.1e-12 + 2.2e-13 k)
+//   colour table   : 1.03e-4 + 2.3e-7 k                      candidates + cube pass (independent of n)
+//                    + n * (1.7e-12 + 6e-15 k)                label pass, k <= 256 (6.6e-12 for u16 labels)
+//                    + (2.5e-4 + n * 4.1e-11) / 16            one-off histogram, spread over ~16 passes
 static bool table_pays(uint64_t n, uint32_t k, bool labels)
 {
     if (const char *e = getenv("KMG_STRATEGY")) {
         if (!strcmp(e, "brute")) return false;
         if (!strcmp(e, "table")) return true;
     }
-    const double brute = (double)n * (13.3 * k + 240.0) / 5.5e13;
-    const double table = 1.0e-4 + (double)n * ((labels ? 1.4e-11 : 0.0) + 5.0e-12);
+    const double N = (double)n;
+    const double brute = N * (8.1e-12 + 2.2e-13 * k);
+    const double label_pass = labels ? N * (k <= 256 ? 1.7e-12 + 6.0e-15 * k : 6.6e-12) : 0.0;
+    const double table = 1.03e-4 + 2.3e-7 * k + label_pass + (2.5e-4 + N * 4.1e-11) / 16.0;
     return table < brute;
 }
 
