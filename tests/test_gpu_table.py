@@ -188,3 +188,77 @@ def test_full_size_table_equals_scan(torch_cuda, oracle):
     wl, _ = oracle.assign_accumulate_rgba(rgba[:m].cpu().numpy(), cent)
     assert np.array_equal(l1[:m].cpu().numpy().view(np.uint32), wl)
     p.close()
+
+
+@pytest.mark.parametrize("strategy", ["brute", "table"])
+def test_two_bands_on_one_gpu_equal_unsharded(torch_cuda, oracle, monkeypatch, strategy):
+    """The multi-GPU data flow with the real kernels: two row bands (two Lloyd states), their int64
+    accumulators summed (what the RCCL all-reduce does), both updated from the sum -- must equal the
+    unsharded run and the oracle bit-for-bit, for either strategy."""
+    import kmeans_gpu_amd as kg
+    from kmeans_gpu_amd.sharded import band_rows
+    torch = torch_cuda
+    monkeypatch.setenv("KMG_STRATEGY", strategy)
+    w, h, k = 512, 301, 24
+    img = _blobs(np.random.default_rng(17), w * h, 30).reshape(h, w, 4)
+    lab = oracle.rgb_to_lab(img)
+    init = oracle.init_centroids(lab, w, h, k)
+    want_c, want_labels, want_it = oracle.lloyd(lab, init)
+    p = kg.ImageProcessor(shrink_max_dim=0)
+    st = _stream(torch)
+    d = _dev(torch, img.reshape(-1, 4))
+    bands = []
+    for r in range(2):
+        r0, r1 = band_rows(h, r, 2)
+        s = kg.Lloyd(p, k)
+        s.set_centroids(init, st)
+        n = (r1 - r0) * w
+        ptr = d.data_ptr() + r0 * w * 4
+        s.prepare(ptr, n, True, st)
+        bands.append((s, ptr, n, torch.zeros(n, dtype=torch.int32, device="cuda"),
+                      torch.zeros((k, 4), dtype=torch.int64, device="cuda"), r0))
+
+    def assign_all():
+        for s, ptr, n, labels, acc, _ in bands:
+            s.assign_accumulate(ptr, n, labels.data_ptr(), acc.data_ptr(), st)
+        total = bands[0][4] + bands[1][4]                      # the all-reduce
+        for b in bands:
+            b[4].copy_(total)
+
+    assign_all()
+    it = 0
+    for it in range(128):
+        for s, _, _, _, acc, _ in bands:
+            s.update(acc.data_ptr(), st)
+        assign_all()
+        if it > 0 and it % 8 == 0 and bands[0][0].converged_count(st) >= k:
+            break
+    assert it == want_it
+    for s, _, n, labels, _, r0 in bands:
+        assert np.array_equal(s.get_centroids(st).view(np.uint32), want_c.view(np.uint32))
+        assert np.array_equal(labels.cpu().numpy().view(np.uint32), want_labels[r0 * w:r0 * w + n])
+        s.close()
+    p.close()
+
+
+def test_table_on_unaligned_band(torch_cuda, processor, oracle):
+    """a band whose first pixel is not 16-byte aligned (odd width x odd first row) through the table"""
+    import kmeans_gpu_amd as kg
+    torch = torch_cuda
+    n, k = 200_003, 9
+    rgba = oracle.synth_uniform(31, n + 3)
+    cent = oracle.centroids4(oracle.rgb_to_lab(rgba[:k]))
+    d = _dev(torch, rgba)
+    st = _stream(torch)
+    for off in (1, 3):
+        s = kg.Lloyd(processor, k)
+        s.set_centroids(cent, st)
+        labels = torch.zeros(n + 3, dtype=torch.int32, device="cuda")
+        acc = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
+        s.bind_image(d.data_ptr() + 4 * off, n, st)
+        s.assign_accumulate(d.data_ptr() + 4 * off, n, labels.data_ptr() + 4 * off, acc.data_ptr(), st)
+        torch.cuda.synchronize()
+        wl, wa = oracle.assign_accumulate_rgba(rgba[off:off + n], cent)
+        assert np.array_equal(labels.cpu().numpy().view(np.uint32)[off:off + n], wl)
+        assert np.array_equal(acc.cpu().numpy(), wa)
+        s.close()
