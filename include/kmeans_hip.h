@@ -40,7 +40,7 @@ typedef enum kmg_status {
     KMG_ERR_NO_DEVICE = -2,        /* no HIP device / device init failed                    */
     KMG_ERR_HIP = -3,              /* a HIP runtime call failed (message has the detail)    */
     KMG_ERR_OUT_OF_MEMORY = -4,
-    KMG_ERR_UNSUPPORTED = -5       /* e.g. Algorithm::Octree (CPU algorithm, out of scope)  */
+    KMG_ERR_UNSUPPORTED = -5       /* e.g. k > KMG_MAX_K, more than 2^32-1 pixels            */
 } kmg_status;
 
 /* core/src/lib.rs:215-219 `enum Algorithm` */
@@ -92,6 +92,11 @@ KMG_API int kmg_reduce(kmg_processor *p, const uint8_t *rgba, uint32_t width, ui
 KMG_API int kmg_palette_to_centroids(const uint8_t *palette_rgba, uint32_t n_colors, float *centroids4);
 /* CentroidsBuffer::pull_values (core/src/structures.rs:581-617): Lab -> sRGB8 (alpha 255)    */
 KMG_API int kmg_centroids_to_palette(const float *centroids4, uint32_t k, uint8_t *out_rgba);
+/* ColorTree::{add_color, reduce} (core/src/octree.rs:28-115, core/src/operations.rs:90-97): the
+ * reference's CPU octree quantiser on n_pixels RGBA8 pixels.  out_rgba: capacity 4 * min(color_count,
+ * n_pixels) bytes; *out_count <= color_count colours, sorted (r, g, b, a), deduplicated.  Host only.  */
+KMG_API int kmg_octree_palette(const uint8_t *rgba, uint64_t n_pixels, uint32_t color_count,
+                               uint8_t *out_rgba, uint32_t *out_count);
 
 /* ======================= device-pointer API (hot path building blocks) ================== */
 /* `stream` is a hipStream_t (NULL = the default stream).  Calls only enqueue work unless the

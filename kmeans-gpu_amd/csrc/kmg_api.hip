@@ -19,6 +19,7 @@
 
 #include "kmg_color.h"
 #include "kmg_kernels.h"
+#include "kmg_octree.h"
 #include "kmg_table.h"
 
 using namespace kmg;
@@ -860,7 +861,53 @@ int apply_and_download(kmg_processor *p, const uint8_t *d_rgba, uint32_t w, uint
     return KMG_OK;
 }
 
+// octree_palette (lib.rs:288-331) on a device-resident image: shrink to <= 128 on the device, pull
+// the <= 128x128 image, run the reference's CPU octree on it, sort ascending by palette-crate Lab L
+int octree_palette_of(kmg_processor *p, const uint8_t *d_rgba, uint32_t w, uint32_t h, uint32_t color_count,
+                      hipStream_t st, std::vector<std::array<uint8_t, 4>> &colors)
+{
+    const uint32_t MAX_SIZE = 128;                                     // lib.rs:293
+    int rc;
+    uint32_t sw = w, sh = h;
+    const uint8_t *src = d_rgba;
+    DevBuf small;
+    if (w > MAX_SIZE || h > MAX_SIZE) {
+        kmg_resized_dims(w, h, MAX_SIZE, &sw, &sh);
+        HIP_TRY(small.alloc((size_t)sw * sh * 4));
+        if ((rc = kmg_dev_resize(p, d_rgba, w, h, sw, sh, (uint8_t *)small.ptr, st)) != KMG_OK) return rc;
+        src = (const uint8_t *)small.ptr;
+    }
+    std::vector<uint8_t> host((size_t)sw * sh * 4);
+    HIP_TRY(hipMemcpyAsync(host.data(), src, host.size(), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    colors = octree_palette(host.data(), (uint64_t)sw * sh, color_count);   // operations.rs:90-97
+    std::vector<float> L(colors.size());
+    for (size_t i = 0; i < colors.size(); ++i) {
+        float lab[3];
+        crate_srgb8_to_lab(colors[i].data(), lab);
+        L[i] = lab[0];
+    }
+    std::vector<size_t> order(colors.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return L[a] < L[b]; });   // lib.rs:320-328
+    std::vector<std::array<uint8_t, 4>> sorted(colors.size());
+    for (size_t i = 0; i < order.size(); ++i) sorted[i] = colors[order[i]];
+    colors.swap(sorted);
+    return KMG_OK;
+}
+
 }  // namespace
+
+// ColorTree::{add_color, reduce} (core/src/octree.rs): host helper, needs no device
+extern "C" int kmg_octree_palette(const uint8_t *rgba, uint64_t n_pixels, uint32_t color_count, uint8_t *out_rgba,
+                                  uint32_t *out_count)
+{
+    if (!rgba || !out_rgba || !out_count || n_pixels == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad octree arguments");
+    const std::vector<std::array<uint8_t, 4>> c = octree_palette(rgba, n_pixels, color_count);
+    for (size_t i = 0; i < c.size(); ++i) memcpy(out_rgba + 4 * i, c[i].data(), 4);
+    *out_count = (uint32_t)c.size();
+    return KMG_OK;
+}
 
 extern "C" int kmg_find(kmg_processor *p, const uint8_t *rgba, uint32_t w, uint32_t h, const uint8_t *palette_rgba,
                         uint32_t n_colors, int mode, uint8_t *out_rgba)
@@ -886,14 +933,22 @@ extern "C" int kmg_reduce(kmg_processor *p, const uint8_t *rgba, uint32_t w, uin
     if ((rc = check_image(p, rgba, w, h)) != KMG_OK) return rc;
     if (color_count == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "k must be an integer higher than 0");
     if (!out_rgba) return fail(KMG_ERR_INVALID_ARGUMENT, "output pointer is NULL");
-    if (algo == KMG_ALGO_OCTREE) return fail(KMG_ERR_UNSUPPORTED, "Algorithm::Octree is a CPU algorithm outside the accelerated path");
-    if (algo != KMG_ALGO_KMEANS) return fail(KMG_ERR_INVALID_ARGUMENT, "unknown algorithm %d", algo);
+    if (algo != KMG_ALGO_KMEANS && algo != KMG_ALGO_OCTREE) return fail(KMG_ERR_INVALID_ARGUMENT, "unknown algorithm %d", algo);
     if (mode < KMG_MODE_REPLACE || mode > KMG_MODE_MELD) return fail(KMG_ERR_INVALID_ARGUMENT, "unknown mode %d", mode);
+    if (algo == KMG_ALGO_KMEANS && color_count > KMG_MAX_K)
+        return fail(KMG_ERR_UNSUPPORTED, "k = %u exceeds KMG_MAX_K = %u", color_count, KMG_MAX_K);
     HIP_TRY(hipSetDevice(p->device));
     StreamGuard sg;
     HIP_TRY(hipStreamCreateWithFlags(&sg.st, hipStreamNonBlocking));
     DevBuf img;
     if ((rc = upload_image(rgba, w, h, sg.st, img)) != KMG_OK) return rc;
+    if (algo == KMG_ALGO_OCTREE) {                                     // lib.rs:133-136
+        std::vector<std::array<uint8_t, 4>> colors;
+        if ((rc = octree_palette_of(p, (const uint8_t *)img.ptr, w, h, color_count, sg.st, colors)) != KMG_OK) return rc;
+        std::vector<float> oc4(4 * colors.size());
+        if ((rc = kmg_palette_to_centroids(colors[0].data(), (uint32_t)colors.size(), oc4.data())) != KMG_OK) return rc;
+        return apply_and_download(p, (const uint8_t *)img.ptr, w, h, oc4.data(), (uint32_t)colors.size(), mode, sg.st, out_rgba);
+    }
     std::vector<float> c4(4 * (size_t)color_count);
     if ((rc = extract_palette_kmeans(p, (const uint8_t *)img.ptr, w, h, color_count, sg.st, c4.data())) != KMG_OK) return rc;
     return apply_and_download(p, (const uint8_t *)img.ptr, w, h, c4.data(), color_count, mode, sg.st, out_rgba);
@@ -906,13 +961,21 @@ extern "C" int kmg_palette(kmg_processor *p, const uint8_t *rgba, uint32_t w, ui
     if ((rc = check_image(p, rgba, w, h)) != KMG_OK) return rc;
     if (color_count == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "k must be an integer higher than 0");
     if (!out_rgba || !out_count) return fail(KMG_ERR_INVALID_ARGUMENT, "output pointer is NULL");
-    if (algo == KMG_ALGO_OCTREE) return fail(KMG_ERR_UNSUPPORTED, "Algorithm::Octree is a CPU algorithm outside the accelerated path");
-    if (algo != KMG_ALGO_KMEANS) return fail(KMG_ERR_INVALID_ARGUMENT, "unknown algorithm %d", algo);
+    if (algo != KMG_ALGO_KMEANS && algo != KMG_ALGO_OCTREE) return fail(KMG_ERR_INVALID_ARGUMENT, "unknown algorithm %d", algo);
+    if (algo == KMG_ALGO_KMEANS && color_count > KMG_MAX_K)
+        return fail(KMG_ERR_UNSUPPORTED, "k = %u exceeds KMG_MAX_K = %u", color_count, KMG_MAX_K);
     HIP_TRY(hipSetDevice(p->device));
     StreamGuard sg;
     HIP_TRY(hipStreamCreateWithFlags(&sg.st, hipStreamNonBlocking));
     DevBuf img;
     if ((rc = upload_image(rgba, w, h, sg.st, img)) != KMG_OK) return rc;
+    if (algo == KMG_ALGO_OCTREE) {                                     // lib.rs:288-331
+        std::vector<std::array<uint8_t, 4>> colors;
+        if ((rc = octree_palette_of(p, (const uint8_t *)img.ptr, w, h, color_count, sg.st, colors)) != KMG_OK) return rc;
+        for (size_t i = 0; i < colors.size(); ++i) memcpy(out_rgba + 4 * i, colors[i].data(), 4);
+        *out_count = (uint32_t)colors.size();
+        return KMG_OK;
+    }
     std::vector<float> c4(4 * (size_t)color_count);
     if ((rc = extract_palette_kmeans(p, (const uint8_t *)img.ptr, w, h, color_count, sg.st, c4.data())) != KMG_OK) return rc;
     // lib.rs:255-286: pull_values (palette-crate Lab -> sRGB8) then sort ascending by Lab L

@@ -62,7 +62,8 @@ _lib = None
 SYMBOLS = [
     "kmg_last_error", "kmg_version", "kmg_default_options", "kmg_processor_create",
     "kmg_processor_create_ex", "kmg_processor_destroy", "kmg_palette", "kmg_find", "kmg_reduce",
-    "kmg_palette_to_centroids", "kmg_centroids_to_palette", "kmg_dev_rgb_to_lab", "kmg_resized_dims",
+    "kmg_palette_to_centroids", "kmg_centroids_to_palette", "kmg_octree_palette", "kmg_dev_rgb_to_lab",
+    "kmg_resized_dims",
     "kmg_dev_resize", "kmg_lloyd_create", "kmg_lloyd_destroy", "kmg_lloyd_set_centroids",
     "kmg_lloyd_get_centroids", "kmg_lloyd_init_centroids", "kmg_lloyd_assign_accumulate",
     "kmg_lloyd_assign_partials", "kmg_lloyd_reduce_partials", "kmg_lloyd_labels", "kmg_lloyd_bind_image",
@@ -105,6 +106,7 @@ def lib():
     L.kmg_reduce.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, u8p]
     L.kmg_palette_to_centroids.argtypes = [u8p, C.c_uint32, f32p]
     L.kmg_centroids_to_palette.argtypes = [f32p, C.c_uint32, u8p]
+    L.kmg_octree_palette.argtypes = [u8p, C.c_uint64, C.c_uint32, u8p, C.POINTER(C.c_uint32)]
     L.kmg_dev_rgb_to_lab.argtypes = [vp, u8p, C.c_uint64, f32p, vp]
     L.kmg_resized_dims.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.kmg_resized_dims.restype = None
@@ -175,6 +177,15 @@ def centroids_to_palette(centroids4):
     return out
 
 
+def octree_palette(pixels, color_count):
+    """ColorTree::{add_color, reduce} (core/src/octree.rs): the reference's CPU octree quantiser."""
+    px = np.ascontiguousarray(pixels, np.uint8).reshape(-1, 4)
+    out = np.empty((max(min(int(color_count), px.shape[0]), 1), 4), np.uint8)
+    cnt = C.c_uint32()
+    _check(lib().kmg_octree_palette(_np_ptr(px), px.shape[0], int(color_count), _np_ptr(out), C.byref(cnt)))
+    return out[:cnt.value].copy()
+
+
 def dither_threshold(centroids4):
     c = np.ascontiguousarray(centroids4, np.float32).reshape(-1, 4)
     t = C.c_float()
@@ -229,7 +240,7 @@ class ImageProcessor:
     def palette(self, color_count, image, algo=Algorithm.Kmeans):
         img = _image(image)
         h, w = img.shape[:2]
-        out = np.empty((max(int(color_count), 1), 4), np.uint8)
+        out = np.empty((max(int(color_count), 1), 4), np.uint8)     # octree returns <= color_count colours
         cnt = C.c_uint32()
         _check(lib().kmg_palette(self._h, _np_ptr(img), w, h, int(color_count), int(algo), _np_ptr(out), C.byref(cnt)))
         return out[:cnt.value].copy()

@@ -685,6 +685,130 @@ void orc_palette(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t k, uint8_
 }
 
 /* ------------------------------------------------------------------------------------ */
+/* Algorithm::Octree         core/src/octree.rs, core/src/lib.rs:288-331                 */
+/* ------------------------------------------------------------------------------------ */
+
+typedef struct {
+    uint32_t level; int32_t parent; uint32_t color_index; int32_t children[8]; uint32_t child_count;
+    uint64_t count, r, g, b; int in_leaves;
+} orc_node;
+
+/* Node::partial_cmp (octree.rs:214-233): returns <0, 0, >0 */
+static int node_cmp(const orc_node *nodes, int32_t a, int32_t b)
+{
+    if (a == b) return 0;
+    if (nodes[a].child_count != nodes[b].child_count) return nodes[a].child_count < nodes[b].child_count ? -1 : 1;
+    uint64_t ac = nodes[a].count >> nodes[a].level, bc = nodes[b].count >> nodes[b].level;
+    if (ac != bc) return ac < bc ? -1 : 1;
+    return a < b ? -1 : 1;
+}
+
+uint32_t orc_octree_palette(const uint8_t *rgba, uint64_t n, uint32_t color_count, uint8_t *out_rgba)
+{
+    if (color_count == 0) return 0;                                   /* octree.rs:67-69 */
+    uint64_t cap = 1 + 8 * n;
+    orc_node *nodes = (orc_node *)calloc(cap, sizeof(orc_node));
+    uint64_t n_nodes = 1;
+    nodes[0].parent = -1;
+    for (int i = 0; i < 8; ++i) nodes[0].children[i] = -1;
+    for (uint64_t i = 0; i < n; ++i) {                                /* add_color, :41-64 */
+        const uint8_t *px = rgba + 4 * i;
+        int32_t cur = 0;
+        for (uint32_t level = 0; level < 8; ++level) {
+            uint8_t mask = (uint8_t)(0x80u >> level);
+            uint32_t ci = 0;
+            if (px[0] & mask) ci |= 4u;
+            if (px[1] & mask) ci |= 2u;
+            if (px[2] & mask) ci |= 1u;
+            if (nodes[cur].children[ci] < 0) {
+                orc_node *nd = &nodes[n_nodes];
+                nd->level = level; nd->parent = cur; nd->color_index = ci;
+                for (int q = 0; q < 8; ++q) nd->children[q] = -1;
+                nodes[cur].children[ci] = (int32_t)n_nodes;
+                nodes[cur].child_count += 1;
+                n_nodes += 1;
+            }
+            cur = nodes[cur].children[ci];
+        }
+        nodes[cur].r += px[0]; nodes[cur].g += px[1]; nodes[cur].b += px[2]; nodes[cur].count += 1;
+    }
+    uint64_t n_leaves = 0;
+    for (uint64_t i = 0; i < n_nodes; ++i)
+        if (nodes[i].count > 0) { nodes[i].in_leaves = 1; n_leaves += 1; }   /* :71-78 */
+    while (n_leaves > color_count) {                                  /* :80-103: smallest leaf merges into its parent */
+        int32_t m = -1;
+        for (uint64_t i = 0; i < n_nodes; ++i)
+            if (nodes[i].in_leaves && (m < 0 || node_cmp(nodes, (int32_t)i, m) < 0)) m = (int32_t)i;
+        nodes[m].in_leaves = 0; n_leaves -= 1;
+        int32_t pid = nodes[m].parent;
+        if (pid >= 0) {
+            if (nodes[pid].in_leaves) { nodes[pid].in_leaves = 0; n_leaves -= 1; }
+            nodes[pid].r += nodes[m].r; nodes[pid].g += nodes[m].g; nodes[pid].b += nodes[m].b;
+            nodes[pid].count += nodes[m].count;
+            nodes[pid].child_count -= 1;
+            nodes[pid].children[nodes[m].color_index] = -1;
+            nodes[m].parent = -1;
+            nodes[pid].in_leaves = 1; n_leaves += 1;
+        }
+    }
+    uint32_t cnt = 0;
+    for (uint64_t i = 0; i < n_nodes; ++i)
+        if (nodes[i].in_leaves) {                                     /* :106-109 output_color */
+            out_rgba[4 * cnt + 0] = (uint8_t)(nodes[i].r / nodes[i].count);
+            out_rgba[4 * cnt + 1] = (uint8_t)(nodes[i].g / nodes[i].count);
+            out_rgba[4 * cnt + 2] = (uint8_t)(nodes[i].b / nodes[i].count);
+            out_rgba[4 * cnt + 3] = 255;
+            cnt += 1;
+        }
+    free(nodes);
+    /* :110-111 sort (RGBA8 derives Ord: r, g, b, a) and dedup */
+    for (uint32_t i = 1; i < cnt; ++i) {
+        uint8_t px[4]; memcpy(px, out_rgba + 4 * i, 4);
+        int64_t j = (int64_t)i - 1;
+        while (j >= 0 && memcmp(out_rgba + 4 * j, px, 4) > 0) { memcpy(out_rgba + 4 * (j + 1), out_rgba + 4 * j, 4); --j; }
+        memcpy(out_rgba + 4 * (j + 1), px, 4);
+    }
+    uint32_t u = 0;
+    for (uint32_t i = 0; i < cnt; ++i)
+        if (u == 0 || memcmp(out_rgba + 4 * (u - 1), out_rgba + 4 * i, 4) != 0) { memmove(out_rgba + 4 * u, out_rgba + 4 * i, 4); u += 1; }
+    return u;
+}
+
+/* octree_palette (lib.rs:288-331): shrink to <= 128, octree, sort ascending by palette-crate Lab L */
+uint32_t orc_palette_octree(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t k, uint8_t *out_rgba)
+{
+    const uint8_t *src = rgba; uint8_t *small = NULL;
+    uint32_t sw = w, sh = h;
+    if (w > 128 || h > 128) {                                         /* lib.rs:293-308 */
+        orc_resized_dims(w, h, 128, &sw, &sh);
+        small = (uint8_t *)malloc((uint64_t)sw * sh * 4);
+        orc_resize(rgba, w, h, sw, sh, small);
+        src = small;
+    }
+    uint32_t cnt = orc_octree_palette(src, (uint64_t)sw * sh, k, out_rgba);
+    free(small);
+    float *keyL = (float *)malloc(sizeof(float) * (cnt ? cnt : 1));
+    for (uint32_t j = 0; j < cnt; ++j) { float lab[3]; orc_palette_srgb8_to_lab(out_rgba + 4 * j, lab); keyL[j] = lab[0]; }
+    for (uint32_t i = 1; i < cnt; ++i) {                              /* lib.rs:320-328 (stable here) */
+        float kl = keyL[i]; uint8_t px[4]; memcpy(px, out_rgba + 4 * i, 4);
+        int64_t j = (int64_t)i - 1;
+        while (j >= 0 && keyL[j] > kl) { keyL[j + 1] = keyL[j]; memcpy(out_rgba + 4 * (j + 1), out_rgba + 4 * j, 4); --j; }
+        keyL[j + 1] = kl; memcpy(out_rgba + 4 * (j + 1), px, 4);
+    }
+    free(keyL);
+    return cnt;
+}
+
+/* ImageProcessor::reduce with Algorithm::Octree (lib.rs:133-136) */
+void orc_reduce_octree(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t k, int mode, uint8_t *out_rgba)
+{
+    uint8_t *pal = (uint8_t *)malloc(4 * (size_t)(k ? k : 1));
+    uint32_t cnt = orc_palette_octree(rgba, w, h, k, pal);
+    orc_find(rgba, w, h, pal, cnt, mode, out_rgba);
+    free(pal);
+}
+
+/* ------------------------------------------------------------------------------------ */
 /* synthetic inputs and the CPU-baseline kernel                                          */
 /* ------------------------------------------------------------------------------------ */
 

@@ -125,6 +125,12 @@ void orc_reduce(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t k, int mod
 /* ImageProcessor::palette with Algorithm::Kmeans: k RGBA8 colours sorted by Lab L */
 void orc_palette(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t k, uint8_t *out_rgba);
 
+/* ---- Algorithm::Octree (core/src/octree.rs, core/src/lib.rs:288-331).  out_rgba: capacity 4*k bytes
+ * (the pixel count when k is larger); returns the number of colours (<= k).                       */
+uint32_t orc_octree_palette(const uint8_t *rgba, uint64_t n, uint32_t color_count, uint8_t *out_rgba);
+uint32_t orc_palette_octree(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t k, uint8_t *out_rgba);
+void     orc_reduce_octree(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t k, int mode, uint8_t *out_rgba);
+
 /* ---- synthetic inputs: splitmix64, R=r&255, G=(r>>8)&255, B=(r>>16)&255 */
 void orc_synth_uniform(uint64_t seed, uint64_t n, uint8_t *rgba);
 

@@ -277,3 +277,35 @@ def num_threads():
 
 def set_num_threads(n):
     lib().orc_set_num_threads(int(n))
+
+
+# ---- Algorithm::Octree --------------------------------------------------------------------
+def _declare_octree(L):
+    u8p = C.POINTER(C.c_uint8)
+    L.orc_octree_palette.argtypes = [u8p, C.c_uint64, C.c_uint32, u8p]; L.orc_octree_palette.restype = C.c_uint32
+    L.orc_palette_octree.argtypes = [u8p, C.c_uint32, C.c_uint32, C.c_uint32, u8p]; L.orc_palette_octree.restype = C.c_uint32
+    L.orc_reduce_octree.argtypes = [u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, u8p]
+
+
+def octree_palette(pixels, color_count):
+    _declare_octree(lib())
+    px = _rgba(pixels).reshape(-1, 4)
+    out = np.empty((max(min(int(color_count), px.shape[0]), 1), 4), np.uint8)
+    n = lib().orc_octree_palette(_p(px, C.c_uint8), px.shape[0], int(color_count), _p(out, C.c_uint8))
+    return out[:n].copy()
+
+
+def palette_octree(rgba, k):
+    _declare_octree(lib())
+    rgba = _rgba(rgba); h, w = rgba.shape[:2]
+    out = np.empty((max(int(k), 1), 4), np.uint8)
+    n = lib().orc_palette_octree(_p(rgba, C.c_uint8), w, h, int(k), _p(out, C.c_uint8))
+    return out[:n].copy()
+
+
+def reduce_octree(rgba, k, mode):
+    _declare_octree(lib())
+    rgba = _rgba(rgba); h, w = rgba.shape[:2]
+    out = np.empty_like(rgba)
+    lib().orc_reduce_octree(_p(rgba, C.c_uint8), w, h, int(k), int(mode), _p(out, C.c_uint8))
+    return out

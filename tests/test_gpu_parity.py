@@ -231,8 +231,8 @@ def test_error_behaviour(processor, tokyo):
         processor.reduce(0, tokyo)
     assert e.value.status == -1 and "higher than 0" in str(e.value)
     with pytest.raises(kg.KmgError) as e:
-        processor.reduce(4, tokyo, algo=kg.Algorithm.Octree)
-    assert e.value.status == -5
+        processor.reduce(4, tokyo, algo=7)
+    assert e.value.status == -1
     with pytest.raises(kg.KmgError) as e:
         processor.find(tokyo, np.zeros((0, 4), np.uint8))
     assert e.value.status == -1
