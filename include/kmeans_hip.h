@@ -49,7 +49,8 @@ typedef enum kmg_algorithm { KMG_ALGO_KMEANS = 0, KMG_ALGO_OCTREE = 1 } kmg_algo
 typedef enum kmg_reduce_mode { KMG_MODE_REPLACE = 0, KMG_MODE_DITHER = 1, KMG_MODE_MELD = 2 } kmg_reduce_mode;
 
 #define KMG_FIX_SHIFT 20
-#define KMG_MAX_K 4096u
+/* largest k: the kernels keep 48 bytes of LDS per cluster (centroid + int64 sums), 160 KiB per CU */
+#define KMG_MAX_K 3072u
 
 /* Compile-time constants of the reference exposed as options (defaults = reference values). */
 typedef struct kmg_options {

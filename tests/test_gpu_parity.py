@@ -237,7 +237,7 @@ def test_error_behaviour(processor, tokyo):
         processor.find(tokyo, np.zeros((0, 4), np.uint8))
     assert e.value.status == -1
     with pytest.raises(kg.KmgError) as e:
-        processor.palette(5000, tokyo)
+        processor.palette(5000, tokyo)   # > KMG_MAX_K = 3072
     assert e.value.status == -5          # KMG_MAX_K
 
 
