@@ -41,6 +41,35 @@ def algorithmic_bytes(kernel, n_pixels, k):
     return None
 
 
+def output_pass_timing(proc, rgba, n_pixels, stream):
+    """Not part of `value`: the other kernel family of the path, BASELINE config 5 -- find + ordered
+    dither with the 64-entry resurrect_64 palette on the same 8192x8192 pixels (8 B/px algorithmic:
+    4 B in, 4 B RGBA8 out), and the iteration without the per-pixel label map."""
+    import numpy as np
+    import torch
+    import kmeans_gpu_amd as kg
+    extra = {}
+    try:
+        from PIL import Image
+        px = np.array(Image.open(os.path.join(ROOT, "tests", "golden", "resurrect_64.png")).convert("RGBA")).reshape(-1, 4)
+        pal = np.array(sorted(set(map(tuple, px))), np.uint8)
+        cent = kg.palette_to_centroids(pal)
+        out = torch.empty((n_pixels, 4), dtype=torch.uint8, device="cuda")
+        for mode, name in ((kg.ReduceMode.Dither, "find_dither"), (kg.ReduceMode.Replace, "find_replace")):
+            proc.apply(rgba.data_ptr(), WIDTH, n_pixels // WIDTH, 0, cent, mode, out.data_ptr(), stream)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(3):
+                proc.apply(rgba.data_ptr(), WIDTH, n_pixels // WIDTH, 0, cent, mode, out.data_ptr(), stream)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t) / 3 * 1e3
+            extra[f"{name}_k{len(pal)}_ms"] = ms
+            extra[f"{name}_k{len(pal)}_hbm_frac"] = ALGORITHMIC_BYTES_PER_PIXEL * n_pixels / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
+    except Exception as e:      # the extras must never break the benchmark line
+        extra["error"] = repr(e)
+    return extra
+
+
 def cpu_baseline(k, centroids4, seed, target_seconds=12.0):
     """The CPU oracle (a port of the reference's WGSL; the reference itself needs Rust + Vulkan) on
     a bounded sample of the same workload, all host threads."""
@@ -198,6 +227,8 @@ def main():
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": abytes},
             "kernels": kernels,
         }
+        if world == 1 and args.rows == ROWS_PER_GPU:
+            out["extra"] = output_pass_timing(proc, rgba, n_local, stream)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(k, cent, seed)
         line = json.dumps(out)
