@@ -304,6 +304,20 @@ static bool table_pays(uint64_t n, uint32_t k, bool labels)
     return table < brute;
 }
 
+// Same model for the replace-mode output pass (no histogram: every cell is labelled; the three
+// scratch buffers are allocated per call, ~0.25 ms).
+static bool replace_table_pays(uint64_t n, uint32_t k)
+{
+    if (const char *e = getenv("KMG_STRATEGY")) {
+        if (!strcmp(e, "brute")) return false;
+        if (!strcmp(e, "table")) return true;
+    }
+    const double N = (double)n;
+    const double brute = N * (8.1e-12 + 2.2e-13 * k);
+    const double table = 3.8e-4 + 2.3e-7 * k + N * (k <= 256 ? 1.7e-12 + 6.0e-15 * k : 6.6e-12);
+    return table < brute;
+}
+
 static int ensure_bounds(kmg_processor *p, hipStream_t st)
 {
     std::lock_guard<std::mutex> lock(p->mu);
@@ -468,7 +482,7 @@ static int table_assign(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_
                                                t.d_colour_labels, t.d_sub, s->d_partials, st));
     t.tables_valid = true;
     if (d_labels)
-        PROF_LAUNCH(s, KMG_K_LABELS, st, launch_labels((const uint32_t *)d_rgba, n, t.d_colour_labels, t.d_sub, s->k, d_labels, st));
+        PROF_LAUNCH(s, KMG_K_LABELS, st, launch_labels((const uint32_t *)d_rgba, n, t.d_colour_labels, t.d_sub, s->k, nullptr, d_labels, st));
     return KMG_OK;
 }
 
@@ -611,7 +625,7 @@ extern "C" int kmg_lloyd_labels(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n,
     HIP_TRY(hipSetDevice(s->p->device));
     if (table_bound(s, d_rgba, n) && s->tab.tables_valid) {
         PROF_LAUNCH(s, KMG_K_LABELS, S(stream), launch_labels((const uint32_t *)d_rgba, n, s->tab.d_colour_labels,
-                                                              s->tab.d_sub, s->k, d_labels, S(stream)));
+                                                              s->tab.d_sub, s->k, nullptr, d_labels, S(stream)));
         return KMG_OK;
     }
     PROF_LAUNCH(s, KMG_K_ASSIGN, S(stream), launch_assign((const uint32_t *)d_rgba, n, s->d_cent, s->k, s->p->d_lut,
@@ -726,7 +740,7 @@ extern "C" int kmg_lloyd_run(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, ui
     }
     if (table && d_labels)   // the label tables of the last pass belong to the final centroids
         PROF_LAUNCH(s, KMG_K_LABELS, S(stream), launch_labels((const uint32_t *)d_rgba, n, s->tab.d_colour_labels,
-                                                              s->tab.d_sub, s->k, d_labels, S(stream)));
+                                                              s->tab.d_sub, s->k, nullptr, d_labels, S(stream)));
     HIP_TRY(hipStreamSynchronize(S(stream)));
     if (iterations) *iterations = it < o.max_iterations ? it : o.max_iterations - 1;
     return KMG_OK;
@@ -767,6 +781,34 @@ extern "C" int kmg_dev_apply(kmg_processor *p, const uint8_t *d_rgba, uint32_t w
     hipError_t e = hipMalloc((void **)&d_pal, sizeof(uint32_t) * (k + 1));
     if (e == hipSuccess) e = hipMemcpyAsync(d_cent, hc.data(), sizeof(Centroid) * k, hipMemcpyHostToDevice, S(stream));
     if (e == hipSuccess) e = hipMemcpyAsync(d_pal, pal.data(), sizeof(uint32_t) * (k + 1), hipMemcpyHostToDevice, S(stream));
+    const uint64_t n_px = (uint64_t)w * rows;
+    if (e == hipSuccess && mode != KMG_MODE_MELD && !dither && replace_table_pays(n_px, k)) {
+        // replace mode on a large image: the label of a pixel depends on its colour only, so label the
+        // colour cube once (candidate masks + cube pass without sums) and emit pal[label] through the
+        // hierarchical label tables -- the same bit-exact machinery as the Lloyd label pass
+        int rc = ensure_bounds(p, S(stream));
+        DevBuf masks, colour_labels, sub;
+        if (rc == KMG_OK) {
+            const size_t sub_bytes = sizeof(uint16_t) * (kSubCells + kCells) + sizeof(uint32_t) * kCells;
+            e = masks.alloc(sizeof(uint64_t) * (size_t)kCells * mask_words(k));
+            if (e == hipSuccess) e = colour_labels.alloc((size_t)(k <= 256 ? 1 : 2) << 24);
+            if (e == hipSuccess) e = sub.alloc(sub_bytes);
+            if (e == hipSuccess) e = launch_cell_candidates(p->d_bounds, nullptr, d_cent, k, (uint64_t *)masks.ptr, S(stream));
+            if (e == hipSuccess)
+                e = launch_cube(nullptr, nullptr, (const uint64_t *)masks.ptr, nullptr, d_cent, k, p->d_lab_table,
+                                colour_labels.ptr, (uint16_t *)sub.ptr, nullptr, S(stream));
+            if (e == hipSuccess)
+                e = launch_labels((const uint32_t *)d_rgba, n_px, colour_labels.ptr, (const uint16_t *)sub.ptr, k, d_pal,
+                                  (uint32_t *)d_out, S(stream));
+        }
+        hipError_t e2 = hipStreamSynchronize(S(stream));
+        (void)hipFree(d_cent);
+        (void)hipFree(d_pal);
+        if (rc != KMG_OK) return rc;
+        if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? KMG_ERR_OUT_OF_MEMORY : KMG_ERR_HIP, "apply failed: %s", hipGetErrorString(e));
+        if (e2 != hipSuccess) return fail(KMG_ERR_HIP, "apply failed: %s", hipGetErrorString(e2));
+        return KMG_OK;
+    }
     if (e == hipSuccess) {
         if (mode == KMG_MODE_MELD)
             e = launch_meld((const uint32_t *)d_rgba, (uint64_t)w * rows, d_cent, k, p->d_lut, (uint32_t *)d_out, S(stream));

@@ -71,8 +71,11 @@ hipError_t launch_cell_candidates(const CellBounds *bounds, const int64_t *agg, 
 hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const uint64_t *masks, const uint32_t *work,
                        const Centroid *cent, uint32_t k, const float4 *lab_table, void *colour_labels,
                        uint16_t *sub_table, int64_t *partials, hipStream_t st);
+// pal == NULL: labels[i] = label; pal != NULL: labels[i] = pal[label] (RGBA8 output of replace mode).
+// launch_cube with hist == NULL labels every colour of every cell and accumulates nothing.
 hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_labels,
-                         const uint16_t *sub_table, uint32_t k, uint32_t *labels, hipStream_t st);
+                         const uint16_t *sub_table, uint32_t k, const uint32_t *pal, uint32_t *labels,
+                         hipStream_t st);
 
 // debug / test support: number of (cell, centroid, colour) triples whose key falls outside the
 // interval bounds, and number of colours whose brute-force arg-min is missing from the cell mask

@@ -233,7 +233,9 @@ hipError_t launch_cell_candidates(const CellBounds *bounds, const int64_t *agg, 
 // LDS: [centroids kpad x 16 B][bins k x 32 B].  Lab of a colour comes from the static per-colour
 // table (16 B load instead of ~200 VALU slots of sRGB->Lab).
 // ------------------------------------------------------------------------------------------
-template <typename LabelT>
+// SUMS = false (output pass of find/reduce in replace mode): no image histogram -- every colour of
+// every cell is labelled, nothing is accumulated; hist, agg, work and partials are unused.
+template <typename LabelT, bool SUMS>
 __global__ __launch_bounds__(kBlock) void k_cube(const uint32_t *__restrict__ hist,
                                                  const int64_t *__restrict__ agg,
                                                  const uint64_t *__restrict__ masks,
@@ -250,7 +252,8 @@ __global__ __launch_bounds__(kBlock) void k_cube(const uint32_t *__restrict__ hi
     unsigned long long *bins = reinterpret_cast<unsigned long long *>(smem4 + kpad);
 
     stage_centroids(s_cent, cent, k, kpad);
-    for (uint32_t i = threadIdx.x; i < 4 * k; i += kBlock) bins[i] = 0ull;
+    if (SUMS)
+        for (uint32_t i = threadIdx.x; i < 4 * k; i += kBlock) bins[i] = 0ull;
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63;
@@ -258,9 +261,9 @@ __global__ __launch_bounds__(kBlock) void k_cube(const uint32_t *__restrict__ hi
     const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (kBlock / 64);
 
-    const uint32_t n_work = __builtin_amdgcn_readfirstlane(work[0]);
+    const uint32_t n_work = SUMS ? __builtin_amdgcn_readfirstlane(work[0]) : kCells;
     for (uint32_t wi = wave; wi < n_work; wi += n_waves) {
-        const uint32_t cell = __builtin_amdgcn_readfirstlane(work[1u + wi]);
+        const uint32_t cell = SUMS ? __builtin_amdgcn_readfirstlane(work[1u + wi]) : wi;
         uint16_t *sub = sub_table + cell * 8u;
         uint16_t *cell_entry = sub_table + kSubCells + cell;       // 8x8x8 summary, same encoding
         // pair entry (k <= 256): [label A:8][label B:8][mask A:8][mask B:8]; bit s of a mask = every
@@ -268,8 +271,9 @@ __global__ __launch_bounds__(kBlock) void k_cube(const uint32_t *__restrict__ hi
         uint32_t *pair_entry = reinterpret_cast<uint32_t *>(sub_table + kSubCells + kCells) + cell;
         const uint32_t base = cell * kCellColours + lane * 8;
         // every load of this cell is issued before anything depends on one of them
-        const uint4 c0 = *reinterpret_cast<const uint4 *>(hist + base);
-        const uint4 c1 = *reinterpret_cast<const uint4 *>(hist + base + 4);
+        const uint4 one4 = make_uint4(1u, 1u, 1u, 1u);
+        const uint4 c0 = SUMS ? *reinterpret_cast<const uint4 *>(hist + base) : one4;
+        const uint4 c1 = SUMS ? *reinterpret_cast<const uint4 *>(hist + base + 4) : one4;
         float4 lab8[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) lab8[q] = lab_table[base + q];   // (L, a, b, C) of this colour
@@ -292,7 +296,7 @@ __global__ __launch_bounds__(kBlock) void k_cube(const uint32_t *__restrict__ hi
                 *reinterpret_cast<uint4 *>(colour_labels + base) = *reinterpret_cast<uint4 *>(v);
             if (lane < 8) sub[lane] = (uint16_t)first;
             if (lane == 0) { *cell_entry = (uint16_t)first; *pair_entry = (first & 0xFFu) | 0x00FF0000u; }
-            if (lane < 4) atomicAdd(bins + 4ull * first + lane, (unsigned long long)agg[4ull * cell + lane]);
+            if (SUMS && lane < 4) atomicAdd(bins + 4ull * first + lane, (unsigned long long)agg[4ull * cell + lane]);
             continue;
         }
 
@@ -341,23 +345,25 @@ __global__ __launch_bounds__(kBlock) void k_cube(const uint32_t *__restrict__ hi
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 if (cnt[q]) {
-                    if (idx[q] != cur) {
-                        if (cur != 0xFFFFFFFFu) {
-                            unsigned long long *bin = bins + 4ull * cur;
-                            for (int j = 0; j < 4; ++j) atomicAdd(bin + j, (unsigned long long)s[j]);
+                    if (SUMS) {
+                        if (idx[q] != cur) {
+                            if (cur != 0xFFFFFFFFu) {
+                                unsigned long long *bin = bins + 4ull * cur;
+                                for (int j = 0; j < 4; ++j) atomicAdd(bin + j, (unsigned long long)s[j]);
+                            }
+                            cur = idx[q];
+                            s[0] = s[1] = s[2] = s[3] = 0;
                         }
-                        cur = idx[q];
-                        s[0] = s[1] = s[2] = s[3] = 0;
+                        const long long m = (long long)cnt[q];
+                        s[0] += m * (long long)lab_fix(L[q]);
+                        s[1] += m * (long long)lab_fix(A[q]);
+                        s[2] += m * (long long)lab_fix(B[q]);
+                        s[3] += m;
                     }
-                    const long long m = (long long)cnt[q];
-                    s[0] += m * (long long)lab_fix(L[q]);
-                    s[1] += m * (long long)lab_fix(A[q]);
-                    s[2] += m * (long long)lab_fix(B[q]);
-                    s[3] += m;
                     state = (state == kSubEmpty) ? idx[q] : (state == idx[q] ? state : (uint32_t)kSubMixed);
                 }
             }
-            if (cur != 0xFFFFFFFFu) {
+            if (SUMS && cur != 0xFFFFFFFFu) {
                 unsigned long long *bin = bins + 4ull * cur;
                 for (int j = 0; j < 4; ++j) atomicAdd(bin + j, (unsigned long long)s[j]);
             }
@@ -400,9 +406,11 @@ __global__ __launch_bounds__(kBlock) void k_cube(const uint32_t *__restrict__ hi
         if (lane == 0) *cell_entry = (uint16_t)state;
     }
 
-    __syncthreads();
-    unsigned long long *row = reinterpret_cast<unsigned long long *>(partials) + (uint64_t)blockIdx.x * 4ull * k;
-    for (uint32_t i = threadIdx.x; i < 4 * k; i += kBlock) row[i] = bins[i];
+    if (SUMS) {
+        __syncthreads();
+        unsigned long long *row = reinterpret_cast<unsigned long long *>(partials) + (uint64_t)blockIdx.x * 4ull * k;
+        for (uint32_t i = threadIdx.x; i < 4 * k; i += kBlock) row[i] = bins[i];
+    }
 }
 
 hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const uint64_t *masks, const uint32_t *work,
@@ -410,13 +418,14 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const uint64_t 
                        int64_t *partials, hipStream_t st)
 {
     const uint32_t kpad = (k + 3u) & ~3u;
-    const size_t lds = sizeof(float4) * kpad + sizeof(unsigned long long) * 4ull * k;
-    if (k <= 256)
-        hipLaunchKernelGGL(k_cube<uint8_t>, dim3(kCubeGrid), dim3(kBlock), lds, st, hist, agg, masks, work, cent, k,
-                           lab_table, (uint8_t *)colour_labels, sub_table, partials);
-    else
-        hipLaunchKernelGGL(k_cube<uint16_t>, dim3(kCubeGrid), dim3(kBlock), lds, st, hist, agg, masks, work, cent, k,
-                           lab_table, (uint16_t *)colour_labels, sub_table, partials);
+    const bool sums = hist != nullptr;
+    const size_t lds = sizeof(float4) * kpad + (sums ? sizeof(unsigned long long) * 4ull * k : 0);
+#define KMG_CUBE(T, S)                                                                                   \
+    hipLaunchKernelGGL((k_cube<T, S>), dim3(kCubeGrid), dim3(kBlock), lds, st, hist, agg, masks, work, cent, k, \
+                       lab_table, (T *)colour_labels, sub_table, partials)
+    if (k <= 256) { if (sums) KMG_CUBE(uint8_t, true); else KMG_CUBE(uint8_t, false); }
+    else          { if (sums) KMG_CUBE(uint16_t, true); else KMG_CUBE(uint16_t, false); }
+#undef KMG_CUBE
     return hipGetLastError();
 }
 
@@ -435,9 +444,13 @@ template <typename LabelT>
 __global__ __launch_bounds__(kLabelBlock) void k_labels(const uint32_t *__restrict__ rgba, uint64_t n,
                                                         const LabelT *__restrict__ colour_labels,
                                                         const uint16_t *__restrict__ sub_table,
+                                                        const uint32_t *__restrict__ pal, uint32_t k,
                                                         uint32_t *__restrict__ labels, int aligned)
 {
     __shared__ uint16_t s_cell[kCells];
+    __shared__ uint32_t s_pal[3072];                       // KMG_MAX_K output colours (pal != NULL)
+    if (pal)
+        for (uint32_t i = threadIdx.x; i < k; i += kLabelBlock) s_pal[i] = pal[i];
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(sub_table + kSubCells);
         uint4 *dst = reinterpret_cast<uint4 *>(s_cell);
@@ -466,6 +479,10 @@ __global__ __launch_bounds__(kLabelBlock) void k_labels(const uint32_t *__restri
 #pragma unroll
         for (int p = 0; p < 8; ++p)
             if (lab[p] == kSubMixed) lab[p] = (uint32_t)colour_labels[ci[p]];
+        if (pal) {                                           // swap.wgsl + lab_to_rgb: colour of the label
+#pragma unroll
+            for (int p = 0; p < 8; ++p) lab[p] = s_pal[lab[p]];
+        }
 #pragma unroll
         for (int g = 0; g < 2; ++g) store4_stream(labels, i0[g], n, aligned != 0, lab + g * 4);
     }
@@ -479,9 +496,12 @@ __global__ __launch_bounds__(kLabelBlock) void k_labels(const uint32_t *__restri
 __global__ __launch_bounds__(kLabelBlock) void k_labels_pairs(const uint32_t *__restrict__ rgba, uint64_t n,
                                                               const uint8_t *__restrict__ colour_labels,
                                                               const uint32_t *__restrict__ pair_table,
+                                                              const uint32_t *__restrict__ pal, uint32_t k,
                                                               uint32_t *__restrict__ labels, int aligned)
 {
     __shared__ uint32_t s_pair[kCells];
+    __shared__ uint32_t s_pal[256];
+    if (pal && threadIdx.x < k) s_pal[threadIdx.x] = pal[threadIdx.x];
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(pair_table);
         uint4 *dst = reinterpret_cast<uint4 *>(s_pair);
@@ -514,13 +534,17 @@ __global__ __launch_bounds__(kLabelBlock) void k_labels_pairs(const uint32_t *__
 #pragma unroll
         for (int p = 0; p < 8; ++p)
             if (fine[p]) lab[p] = (uint32_t)colour_labels[ci[p]];
+        if (pal) {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) lab[p] = s_pal[lab[p]];
+        }
 #pragma unroll
         for (int g = 0; g < 2; ++g) store4_stream(labels, i0[g], n, aligned != 0, lab + g * 4);
     }
 }
 
 hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_labels, const uint16_t *sub_table,
-                         uint32_t k, uint32_t *labels, hipStream_t st)
+                         uint32_t k, const uint32_t *pal, uint32_t *labels, hipStream_t st)
 {
     if (k <= 256) {
         const uint64_t tiles = (n + kLabelBlock * 8 - 1) / (kLabelBlock * 8);
@@ -529,7 +553,7 @@ hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_la
                              (reinterpret_cast<uintptr_t>(labels) & 15u) == 0) ? 1 : 0;
         hipLaunchKernelGGL(k_labels_pairs, dim3(grid), dim3(kLabelBlock), 0, st, rgba, n,
                            (const uint8_t *)colour_labels,
-                           reinterpret_cast<const uint32_t *>(sub_table + kSubCells + kCells), labels, aligned);
+                           reinterpret_cast<const uint32_t *>(sub_table + kSubCells + kCells), pal, k, labels, aligned);
         return hipGetLastError();
     }
     const uint64_t tiles = (n + kLabelBlock * 8 - 1) / (kLabelBlock * 8);
@@ -538,10 +562,10 @@ hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_la
                          (reinterpret_cast<uintptr_t>(labels) & 15u) == 0) ? 1 : 0;
     if (k <= 256)
         hipLaunchKernelGGL(k_labels<uint8_t>, dim3(grid), dim3(kLabelBlock), 0, st, rgba, n,
-                           (const uint8_t *)colour_labels, sub_table, labels, aligned);
+                           (const uint8_t *)colour_labels, sub_table, pal, k, labels, aligned);
     else
         hipLaunchKernelGGL(k_labels<uint16_t>, dim3(grid), dim3(kLabelBlock), 0, st, rgba, n,
-                           (const uint16_t *)colour_labels, sub_table, labels, aligned);
+                           (const uint16_t *)colour_labels, sub_table, pal, k, labels, aligned);
     return hipGetLastError();
 }
 

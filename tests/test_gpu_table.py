@@ -305,3 +305,27 @@ def test_cfg3_full_lloyd_both_strategies(torch_cuda, oracle, monkeypatch):
     m = 1 << 15
     wl, _ = oracle.assign_accumulate_rgba(rgba[:m].cpu().numpy(), c1)
     assert np.array_equal(l1[:m].cpu().numpy().view(np.uint32), wl)
+
+
+@pytest.mark.parametrize("k", [1, 3, 46, 64, 300])
+def test_replace_output_pass_table_equals_scan(torch_cuda, oracle, monkeypatch, k):
+    """find / reduce in replace mode through the colour table (forced) == per-pixel scan == oracle"""
+    import kmeans_gpu_amd as kg
+    torch = torch_cuda
+    w, h = 1000, 777
+    img = _blobs(np.random.default_rng(k), w * h, 25, sigma=20.0).reshape(h, w, 4)
+    pal = np.array(sorted(set(map(tuple, oracle.synth_uniform(k + 5, k)))), np.uint8)
+    cent = kg.palette_to_centroids(pal)
+    d = _dev(torch, img.reshape(-1, 4))
+    st = _stream(torch)
+    outs = {}
+    for strategy in ("brute", "table"):
+        monkeypatch.setenv("KMG_STRATEGY", strategy)
+        p = kg.ImageProcessor()
+        out = torch.zeros((w * h, 4), dtype=torch.uint8, device="cuda")
+        p.apply(d.data_ptr(), w, h, 0, cent, kg.ReduceMode.Replace, out.data_ptr(), st)
+        torch.cuda.synchronize()
+        outs[strategy] = out.cpu().numpy().reshape(h, w, 4)
+        p.close()
+    assert np.array_equal(outs["brute"], outs["table"])
+    assert np.array_equal(outs["table"], oracle.find(img, pal, oracle.MODE_REPLACE))
