@@ -144,7 +144,7 @@ def main():
     labels = torch.empty(n_local, dtype=torch.int32, device="cuda")
 
     # initial centroids: shader Lab of the pixels at linear index j * floor(N/k) of band 0
-    sel = synth.uniform_rgba_numpy(seed, WIDTH * args.rows)[(np.arange(k) * (n_local // k))]
+    sel = synth.uniform_rgba_at(seed, np.arange(k, dtype=np.uint64) * np.uint64(n_local // k))
     d_sel = torch.from_numpy(sel).cuda()
     lab = torch.empty((k, 3), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream

@@ -52,3 +52,19 @@ def uniform_rgba_torch(seed, n, first=0, device="cuda", chunk=1 << 24):
         o[:, 2] = ((z >> 16) & 255).to(torch.uint8)
         o[:, 3] = 255
     return out
+
+
+def uniform_rgba_at(seed, indices):
+    """(len(indices), 4) uint8: the pixels at the given linear indices of stream `seed` (random access)"""
+    with np.errstate(over="ignore"):
+        i = np.asarray(indices, dtype=np.uint64) + np.uint64(1)
+        z = np.uint64(seed) + i * np.uint64(GAMMA)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(M1)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(M2)
+        z = z ^ (z >> np.uint64(31))
+    out = np.empty((len(i), 4), np.uint8)
+    out[:, 0] = (z & np.uint64(255)).astype(np.uint8)
+    out[:, 1] = ((z >> np.uint64(8)) & np.uint64(255)).astype(np.uint8)
+    out[:, 2] = ((z >> np.uint64(16)) & np.uint64(255)).astype(np.uint8)
+    out[:, 3] = 255
+    return out
