@@ -164,6 +164,7 @@ def main():
     t_prep = time.perf_counter() - t_prep
 
     sh = ShardedLloyd(lloyd, k, rgba, labels, stream=stream)
+    sh.split_labels = strategy == "table"     # the all-reduce overlaps the label-gather pass
     if args.force_dist:
         sh.world = 2          # take the collective path even though the group has one rank
     sh.prime()

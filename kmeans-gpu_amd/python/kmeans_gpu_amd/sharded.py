@@ -39,30 +39,46 @@ class ShardedLloyd:
         self.stream = stream
         self.acc = torch.zeros((self.k, 4), dtype=torch.int64, device=rgba.device)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # True when the backend produces labels with a separate pass (kmeans_gpu_amd.Lloyd after
+        # prepare() chose the colour table): lets the collective overlap that pass
+        self.split_labels = False
 
-    def _assign_accumulate(self):
+    def _pass(self):
+        """labels + sums of the current centroids, and the exchange of the sums.
+
+        With the colour-table strategy (`split_labels`) the sums come from the cube pass and the
+        label map from a separate gather pass that does not feed the collective: the all-reduce is
+        issued asynchronously right after the sums and overlaps the label pass."""
         lab_ptr = self.labels.data_ptr() if self.labels is not None else 0
         if self.n_local == 0:
             self.acc.zero_()
+            self.exchange()
+            return
+        if self.split_labels and lab_ptr:
+            self.backend.assign_accumulate(self.rgba.data_ptr(), self.n_local, 0, self.acc.data_ptr(), self.stream)
+            work = self.exchange(async_op=True)
+            self.backend.labels(self.rgba.data_ptr(), self.n_local, lab_ptr, self.stream)
+            if work is not None:
+                work.wait()           # the compute stream waits for the collective, not the host
         else:
             self.backend.assign_accumulate(self.rgba.data_ptr(), self.n_local, lab_ptr,
                                            self.acc.data_ptr(), self.stream)
+            self.exchange()
 
-    def exchange(self):
+    def exchange(self, async_op=False):
         """the path's one collective: sum of the k x 4 int64 accumulators over all bands"""
         if self.world > 1:
-            dist.all_reduce(self.acc, op=dist.ReduceOp.SUM, group=self.group)
+            return dist.all_reduce(self.acc, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        return None
 
     def prime(self):
         """initial assignment (operations.rs:75-83), fused with the sums of the first update"""
-        self._assign_accumulate()
-        self.exchange()
+        self._pass()
 
     def iterate(self):
         """one Lloyd iteration (modules.rs:769-800): update from the global sums, re-assign"""
         self.backend.update(self.acc.data_ptr(), self.stream)
-        self._assign_accumulate()
-        self.exchange()
+        self._pass()
 
     def run(self, max_iterations=128, check_period=8):
         """ChooseCentroidModule::compute (modules.rs:763-840) over all bands.  Returns the

@@ -35,6 +35,10 @@ class OracleBackend:
             self._view(d_labels, (n,), np.uint32)[:] = labels
         self._view(d_acc, (self.k, 4), np.int64)[:] = acc
 
+    def labels(self, d_rgba, n, d_labels, stream=0):
+        px = self._view(d_rgba, (n, 4), np.uint8)
+        self._view(d_labels, (n,), np.uint32)[:] = self.O.assign(self.O.rgb_to_lab(px), self.cent)
+
     def update(self, d_acc, stream=0):
         acc = self._view(d_acc, (self.k, 4), np.int64)
         self.cent, self.nconv = self.O.finalize(acc, self.cent, 1.0)
@@ -43,7 +47,7 @@ class OracleBackend:
         return self.nconv
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, split=False):
     import sys
     sys.path.insert(0, os.path.join(ROOT, "kmeans-gpu_amd", "python"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -63,6 +67,7 @@ def _worker(rank, world, port, q):
         labels = torch.zeros((r1 - r0) * w, dtype=torch.int32)
         be = OracleBackend(O, k, init)
         sh = ShardedLloyd(be, k, band, labels)
+        sh.split_labels = split          # sums first, async all-reduce, labels from a separate pass
         it = sh.run(128, 8)
         q.put((rank, it, be.cent.copy(), labels.numpy().view(np.uint32).copy(), (r0, r1)))
     finally:
@@ -77,12 +82,12 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_lloyd_equals_unsharded(oracle, world):
+@pytest.mark.parametrize("world,split", [(2, False), (3, False), (2, True)])
+def test_sharded_lloyd_equals_unsharded(oracle, world, split):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, split)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=180) for _ in range(world)), key=lambda t: t[0])
