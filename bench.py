@@ -41,7 +41,7 @@ def algorithmic_bytes(kernel, n_pixels, k):
     return None
 
 
-def output_pass_timing(proc, rgba, n_pixels, stream):
+def output_pass_timing(proc, rgba, n_pixels, stream, sh=None):
     """Not part of `value`: the other kernel family of the path, BASELINE config 5 -- find + ordered
     dither with the 64-entry resurrect_64 palette on the same 8192x8192 pixels (8 B/px algorithmic:
     4 B in, 4 B RGBA8 out), and the iteration without the per-pixel label map."""
@@ -65,6 +65,18 @@ def output_pass_timing(proc, rgba, n_pixels, stream):
             ms = (time.perf_counter() - t) / 3 * 1e3
             extra[f"{name}_k{len(pal)}_ms"] = ms
             extra[f"{name}_k{len(pal)}_hbm_frac"] = ALGORITHMIC_BYTES_PER_PIXEL * n_pixels / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
+        if sh is not None:
+            # what kmg_lloyd_run executes per iteration: sums only, the label map is written once at the end
+            def sums_only(iters):
+                for _ in range(iters):
+                    sh.backend.update(sh.acc.data_ptr(), stream)
+                    sh.backend.assign_accumulate(rgba.data_ptr(), n_pixels, 0, sh.acc.data_ptr(), stream)
+            sums_only(2)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            sums_only(10)
+            torch.cuda.synchronize()
+            extra["iteration_without_label_map_ms"] = (time.perf_counter() - t) / 10 * 1e3
     except Exception as e:      # the extras must never break the benchmark line
         extra["error"] = repr(e)
     return extra
@@ -229,7 +241,7 @@ def main():
             "kernels": kernels,
         }
         if world == 1 and args.rows == ROWS_PER_GPU:
-            out["extra"] = output_pass_timing(proc, rgba, n_local, stream)
+            out["extra"] = output_pass_timing(proc, rgba, n_local, stream, sh)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(k, cent, seed)
         line = json.dumps(out)
