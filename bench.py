@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--k", type=int, default=K)
     ap.add_argument("--rows", type=int, default=ROWS_PER_GPU, help="rows per GPU (default 8192)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the untimed extra measurements (use under rocprofv3 to keep kernel averages clean)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the all-reduce even with one rank (sanity check)")
     ap.add_argument("--strategy", choices=["auto", "scan", "table"], default="auto",
@@ -240,7 +242,7 @@ def main():
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": abytes},
             "kernels": kernels,
         }
-        if world == 1 and args.rows == ROWS_PER_GPU:
+        if world == 1 and args.rows == ROWS_PER_GPU and not args.no_extras:
             out["extra"] = output_pass_timing(proc, rgba, n_local, stream, sh)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(k, cent, seed)
