@@ -513,16 +513,24 @@ __global__ __launch_bounds__(kBlock) void k_apply(const uint32_t *__restrict__ r
             i0[g] = tile * TILE + (uint64_t)g * (kBlock * 4) + (uint64_t)threadIdx.x * 4;
             uint32_t px[4];
             load4(rgba, i0[g], n, aligned != 0, px);
+            // image coordinates of the group's first pixel (n < 2^32): one 32-bit divide per 4 pixels
+            uint32_t gx = 0, gy = 0;
+            if (DITHER) {
+                const uint32_t i32 = (uint32_t)i0[g];
+                gy = i32 / w;
+                gx = i32 - gy * w;
+                gy += row0;
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int p = g * 4 + q;
                 float L, a, b;
                 px_to_lab(s_lut, px[q], L, a, b);
                 if (DITHER) {
-                    const uint64_t i = i0[g] + q;
-                    const uint32_t x = (uint32_t)(i % w), y = row0 + (uint32_t)(i / w);
-                    const float off = s_off[(x & 3u) + ((y & 3u) << 2)];
+                    const float off = s_off[(gx & 3u) + ((gy & 3u) << 2)];
                     L = L + off; a = a + off; b = b + off;         // :72
+                    gx += 1;
+                    if (gx == w) { gx = 0; gy += 1; }
                 }
                 pt[p] = pixel_terms(L, a, b);
                 if (DITHER) {
