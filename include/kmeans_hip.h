@@ -188,7 +188,9 @@ KMG_API int kmg_lloyd_converged_count(kmg_lloyd *s, uint32_t *count, void *strea
 
 /* ChooseCentroidModule::compute (core/src/modules.rs:763-840): the whole loop on one device.
  * Expects the centroid table initialised.  Synchronises.  *iterations = the reference's
- * `current_iteration` when the loop stopped.                                                  */
+ * `current_iteration` when the loop stopped.  d_labels (optional) receives the final assignment;
+ * the loop applies kmg_lloyd_prepare's cost model itself and, with the colour table, iterates on the
+ * sums only and writes the label map once after the last iteration (same result).               */
 KMG_API int kmg_lloyd_run(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n_pixels,
                           uint32_t *d_labels, uint32_t *iterations, void *stream);
 
