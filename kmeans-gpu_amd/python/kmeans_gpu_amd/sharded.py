@@ -12,7 +12,7 @@ pass needs no exchange at all (kmg_dev_apply takes the band's first row).
 import torch
 import torch.distributed as dist
 
-__all__ = ["band_rows", "ShardedLloyd"]
+__all__ = ["band_rows", "ShardedLloyd", "ShardedBatch"]
 
 
 def band_rows(height, rank, world):
@@ -92,3 +92,61 @@ class ShardedLloyd:
                 if self.backend.converged_count(self.stream) >= self.k:
                     break
         return it
+
+
+class ShardedBatch:
+    """A batch of images, each tiled over all ranks (BASELINE config 4: 16 images over 8 GPUs).
+
+    Every image is an independent k-means problem (its own backend per rank, same k); the
+    accumulators of the whole batch live in ONE (images, k, 4) int64 tensor, so an iteration costs a
+    single all-reduce of images*k*32 bytes instead of one per image.  An image that has converged (at
+    one of its every-`check_period` checks, exactly like the single-image loop) stops being updated.
+
+    backends : list of Lloyd-like objects, one per image (centroids already set)
+    bands    : list of uint8 tensors, this rank's band of each image
+    labels   : list of int32 tensors (or None entries)
+    """
+
+    def __init__(self, backends, k, bands, labels=None, group=None, stream=0):
+        assert len(backends) == len(bands)
+        self.backends = list(backends)
+        self.k = int(k)
+        self.bands = list(bands)
+        self.labels = list(labels) if labels is not None else [None] * len(bands)
+        self.group = group
+        self.stream = stream
+        self.n_local = [int(b.shape[0]) if b.dim() == 2 else int(b.numel() // 4) for b in self.bands]
+        self.acc = torch.zeros((len(bands), self.k, 4), dtype=torch.int64, device=self.bands[0].device)
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = [True] * len(bands)
+        self.iterations = [0] * len(bands)
+
+    def _pass(self):
+        for i, be in enumerate(self.backends):
+            if not self.active[i]:
+                continue
+            lab = self.labels[i].data_ptr() if self.labels[i] is not None else 0
+            if self.n_local[i]:
+                be.assign_accumulate(self.bands[i].data_ptr(), self.n_local[i], lab, self.acc[i].data_ptr(), self.stream)
+            else:
+                self.acc[i].zero_()
+        if self.world > 1:
+            # converged images keep their (stale, unused) rows: shapes stay fixed for the collective
+            dist.all_reduce(self.acc, op=dist.ReduceOp.SUM, group=self.group)
+
+    def run(self, max_iterations=128, check_period=8):
+        self._pass()
+        for it in range(max_iterations):
+            if not any(self.active):
+                break
+            for i, be in enumerate(self.backends):
+                if self.active[i]:
+                    be.update(self.acc[i].data_ptr(), self.stream)
+                    self.iterations[i] = it
+            self._pass()
+            if it > 0 and it % check_period == 0:
+                for i, be in enumerate(self.backends):
+                    if self.active[i] and be.converged_count(self.stream) >= self.k:
+                        self.active[i] = False
+                        self.acc[i].zero_()      # its rows stay in the collective but carry nothing
+        return list(self.iterations)

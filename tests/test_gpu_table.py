@@ -329,3 +329,32 @@ def test_replace_output_pass_table_equals_scan(torch_cuda, oracle, monkeypatch, 
         p.close()
     assert np.array_equal(outs["brute"], outs["table"])
     assert np.array_equal(outs["table"], oracle.find(img, pal, oracle.MODE_REPLACE))
+
+
+def test_batch_of_images_on_one_gpu(torch_cuda, processor, oracle):
+    """ShardedBatch with the real kernels (one rank): three images, one accumulator tensor"""
+    import kmeans_gpu_amd as kg
+    from kmeans_gpu_amd.sharded import ShardedBatch
+    torch = torch_cuda
+    st = _stream(torch)
+    k, shapes = 6, [(200, 150), (333, 77), (64, 64)]
+    p = kg.ImageProcessor(shrink_max_dim=0)
+    backends, bands, labels, wants = [], [], [], []
+    for j, (w, h) in enumerate(shapes):
+        img = _blobs(np.random.default_rng(50 + j), w * h, 10).reshape(h, w, 4)
+        lab = oracle.rgb_to_lab(img)
+        init = oracle.init_centroids(lab, w, h, k)
+        wants.append(oracle.lloyd(lab, init))
+        s = kg.Lloyd(p, k)
+        s.set_centroids(init, st)
+        backends.append(s)
+        bands.append(_dev(torch, img.reshape(-1, 4)))
+        labels.append(torch.zeros(w * h, dtype=torch.int32, device="cuda"))
+    its = ShardedBatch(backends, k, bands, labels, stream=st).run(128, 8)
+    torch.cuda.synchronize()
+    for j, (want_c, want_labels, want_it) in enumerate(wants):
+        assert its[j] == want_it
+        assert np.array_equal(backends[j].get_centroids(st).view(np.uint32), want_c.view(np.uint32))
+        assert np.array_equal(labels[j].cpu().numpy().view(np.uint32), want_labels)
+        backends[j].close()
+    p.close()

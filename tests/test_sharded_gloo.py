@@ -112,3 +112,56 @@ def test_band_rows_partition():
             rows = [band_rows(h, r, g) for r in range(g)]
             assert rows[0][0] == 0 and rows[-1][1] == h
             assert all(rows[i][1] == rows[i + 1][0] for i in range(g - 1))
+
+
+def _batch_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "kmeans-gpu_amd", "python"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    from kmeans_gpu_amd.sharded import ShardedBatch, band_rows
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        O.set_num_threads(2)
+        k, shapes = 5, [(64, 40), (33, 57), (80, 21)]
+        backends, bands, labels = [], [], []
+        for j, (w, h) in enumerate(shapes):
+            img = O.synth_uniform(900 + j, w * h).reshape(h, w, 4)
+            lab = O.rgb_to_lab(img)
+            r0, r1 = band_rows(h, rank, world)
+            backends.append(OracleBackend(O, k, O.init_centroids(lab, w, h, k)))
+            bands.append(torch.from_numpy(np.ascontiguousarray(img[r0:r1]).reshape(-1, 4)))
+            labels.append(torch.zeros((r1 - r0) * w, dtype=torch.int32))
+        sb = ShardedBatch(backends, k, bands, labels)
+        its = sb.run(128, 8)
+        q.put((rank, its, [b.cent.copy() for b in backends], [l.numpy().view(np.uint32).copy() for l in labels]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_batch_equals_per_image_oracle(oracle):
+    """BASELINE config 4 in miniature: 3 images tiled over 2 ranks, one all-reduce per iteration"""
+    from kmeans_gpu_amd.sharded import band_rows
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_batch_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    k, shapes = 5, [(64, 40), (33, 57), (80, 21)]
+    for j, (w, h) in enumerate(shapes):
+        img = oracle.synth_uniform(900 + j, w * h).reshape(h, w, 4)
+        lab = oracle.rgb_to_lab(img)
+        want_c, want_labels, want_it = oracle.lloyd(lab, oracle.init_centroids(lab, w, h, k))
+        for rank, its, cents, labs in res:
+            r0, r1 = band_rows(h, rank, world)
+            assert its[j] == want_it
+            assert np.array_equal(cents[j].view(np.uint32), want_c.view(np.uint32))
+            assert np.array_equal(labs[j], want_labels[r0 * w:r1 * w])
