@@ -126,6 +126,23 @@ KMG_API int kmg_lloyd_get_centroids(kmg_lloyd *s, float *centroids4, void *strea
 KMG_API int kmg_lloyd_init_centroids(kmg_lloyd *s, const uint8_t *d_rgba, uint32_t width,
                                      uint32_t height, void *stream);
 
+/* The same initialisation for an image sharded in row bands (one kmg_lloyd per band / GPU).  Step j:
+ *   kmg_lloyd_init_step      band-local pass for centroid j-1; *d_key (device u64) = arg-max key of
+ *                            this band over IMAGE-wide pixel indices (first_index = index of the band's
+ *                            first pixel).  The caller all-reduces the key with MAX (compare as signed
+ *                            or unsigned 64-bit: the top bit is never set).
+ *   kmg_lloyd_init_pick_band d_colour2[0..1] = {RGBA8 of the pixel the reduced key names, 1} on the band
+ *                            that owns that pixel, {0, 0} elsewhere.  The caller all-reduces with SUM.
+ *   kmg_lloyd_set_centroid_rgba   centroid j <- shader Lab of d_colour[0].
+ * Centroid 0 uses the same two calls with kmg_init_first_key(width, height) as the key.  Everything
+ * is enqueued on `stream`; nothing synchronises.                                                     */
+KMG_API int kmg_lloyd_init_step(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n_local, uint64_t first_index,
+                                uint32_t j, uint64_t *d_key, void *stream);
+KMG_API int kmg_lloyd_init_pick_band(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n_local, uint64_t first_index,
+                                     const uint64_t *d_key, uint32_t *d_colour2, void *stream);
+KMG_API int kmg_lloyd_set_centroid_rgba(kmg_lloyd *s, uint32_t j, const uint32_t *d_colour, void *stream);
+KMG_API uint64_t kmg_init_first_key(uint32_t width, uint32_t height);
+
 /* FindCentroidModule::dispatch (find_centroid.wgsl:15-44) fused with the masked sums of
  * choose_centroid.wgsl:75-178: labels for every pixel AND the k x 4 int64 accumulators of this
  * pixel range, one pass over the RGBA8 data.  d_acc4 may be NULL (assignment only);

@@ -578,11 +578,65 @@ extern "C" int kmg_lloyd_init_centroids(kmg_lloyd *s, const uint8_t *d_rgba, uin
             s->dist_cap = n;
         }
         for (uint32_t j = 1; j < s->k; ++j) {   // modules.rs:1211-1246
-            HIP_TRY(launch_init_pass(rgba, n, s->p->d_lut, s->d_cent, j, s->d_dist, s->d_key, S(stream)));
+            HIP_TRY(launch_init_pass(rgba, n, s->p->d_lut, s->d_cent, j, s->d_dist, s->d_key, 0, S(stream)));
             HIP_TRY(launch_init_pick(rgba, s->p->d_lut, s->d_key, s->d_cent, j, S(stream)));
         }
     }
     return KMG_OK;
+}
+
+// ---- the same initialisation for an image sharded in row bands (last row) ----
+// One step = local pass (running min-distance map of this band, arg-max key over IMAGE-wide pixel
+// indices) -> caller all-reduces the key (max) -> kmg_lloyd_init_pick_band publishes the winning
+// pixel's colour from the band that owns it -> caller all-reduces {colour, 1} (sum) ->
+// kmg_lloyd_set_centroid_rgba.  No host synchronisation is involved.
+extern "C" int kmg_lloyd_init_step(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n_local, uint64_t first_index,
+                                   uint32_t j, uint64_t *d_key, void *stream)
+{
+    if (!s || !d_key || j == 0 || j >= s->k || (n_local && !d_rgba))
+        return fail(KMG_ERR_INVALID_ARGUMENT, "bad init_step arguments");
+    if (first_index + n_local > 0xFFFFFFFFull) return fail(KMG_ERR_UNSUPPORTED, "image has more than 2^32-1 pixels");
+    HIP_TRY(hipSetDevice(s->p->device));
+    s->tab.tables_valid = false;
+    HIP_TRY(hipMemsetAsync(d_key, 0, sizeof(uint64_t), S(stream)));
+    if (n_local == 0) return KMG_OK;
+    if (s->dist_cap < n_local) {
+        if (j != 1) return fail(KMG_ERR_INVALID_ARGUMENT, "init_step: the distance map of this band was never started (j = 1)");
+        if (s->d_dist) { HIP_TRY(hipStreamSynchronize(S(stream))); HIP_TRY(hipFree(s->d_dist)); s->d_dist = nullptr; s->dist_cap = 0; }
+        HIP_TRY(hipMalloc((void **)&s->d_dist, sizeof(float) * n_local));
+        s->dist_cap = n_local;
+    }
+    HIP_TRY(launch_init_pass((const uint32_t *)d_rgba, n_local, s->p->d_lut, s->d_cent, j, s->d_dist,
+                             (unsigned long long *)d_key, first_index, S(stream)));
+    return KMG_OK;
+}
+
+extern "C" int kmg_lloyd_init_pick_band(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n_local, uint64_t first_index,
+                                        const uint64_t *d_key, uint32_t *d_colour2, void *stream)
+{
+    if (!s || !d_key || !d_colour2 || (n_local && !d_rgba)) return fail(KMG_ERR_INVALID_ARGUMENT, "bad init_pick_band arguments");
+    HIP_TRY(hipSetDevice(s->p->device));
+    HIP_TRY(launch_init_pick_band((const uint32_t *)d_rgba, n_local, first_index, (const unsigned long long *)d_key,
+                                  d_colour2, S(stream)));
+    return KMG_OK;
+}
+
+extern "C" int kmg_lloyd_set_centroid_rgba(kmg_lloyd *s, uint32_t j, const uint32_t *d_colour, void *stream)
+{
+    if (!s || !d_colour || j >= s->k) return fail(KMG_ERR_INVALID_ARGUMENT, "bad set_centroid_rgba arguments");
+    HIP_TRY(hipSetDevice(s->p->device));
+    s->tab.tables_valid = false;
+    HIP_TRY(launch_set_centroid_rgba(d_colour, s->p->d_lut, s->d_cent, j, S(stream)));
+    return KMG_OK;
+}
+
+extern "C" uint64_t kmg_init_first_key(uint32_t width, uint32_t height)
+{
+    // plus_plus_init.wgsl:161-168 `initial`: the key that names pixel (floor(w rand(42)), floor(h rand(12)))
+    const int32_t x0 = (int32_t)((float)width * 0.5625f);
+    const int32_t y0 = (int32_t)((float)height * 0.93359375f);
+    const uint64_t i0 = (uint64_t)y0 * width + (uint64_t)x0;
+    return (1ull << 32) | (uint64_t)((((uint32_t)(i0 >> 4)) << 4) | (15u - (uint32_t)(i0 & 15u)));
 }
 
 // One pass: labels and/or the partial sums of the current centroid table.  Uses the colour table

@@ -38,9 +38,14 @@ hipError_t launch_init_first(const uint32_t *rgba, uint64_t index, const float *
                              Centroid *cent, unsigned long long *key, hipStream_t st);
 hipError_t launch_init_pass(const uint32_t *rgba, uint64_t n, const float *lut,
                             const Centroid *cent, uint32_t j, float *dist,
-                            unsigned long long *key, hipStream_t st);
+                            unsigned long long *key, uint64_t first_index, hipStream_t st);
 hipError_t launch_init_pick(const uint32_t *rgba, const float *lut, unsigned long long *key,
                             Centroid *cent, uint32_t j, hipStream_t st);
+// sharded init (row bands): publish the colour of the pixel named by an all-reduced key; set one centroid
+hipError_t launch_init_pick_band(const uint32_t *rgba, uint64_t n, uint64_t first_index,
+                                 const unsigned long long *key, uint32_t *colour2, hipStream_t st);
+hipError_t launch_set_centroid_rgba(const uint32_t *colour, const float *lut, Centroid *cent, uint32_t j,
+                                    hipStream_t st);
 
 hipError_t launch_resize(const uint32_t *rgba, uint32_t w, uint32_t h, uint32_t nw, uint32_t nh,
                          uint32_t *out, hipStream_t st);

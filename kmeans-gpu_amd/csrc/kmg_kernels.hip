@@ -346,8 +346,11 @@ __global__ __launch_bounds__(kBlock) void k_init_pass(const uint32_t *__restrict
                                                       const float *__restrict__ lut,
                                                       const Centroid *__restrict__ cent, uint32_t j,
                                                       float *__restrict__ dist,
-                                                      unsigned long long *__restrict__ key)
+                                                      unsigned long long *__restrict__ key,
+                                                      uint64_t first_index)
 {
+    // first_index: image-wide linear index of this band's first pixel (0 for a whole image), so the
+    // tie rule of the key is the image's, not the band's
     __shared__ float s_lut[256];
     __shared__ unsigned long long s_key[kBlock / 64];
     s_lut[threadIdx.x] = lut[threadIdx.x];
@@ -362,8 +365,9 @@ __global__ __launch_bounds__(kBlock) void k_init_pass(const uint32_t *__restrict
         float d = cie94(L, a, b, c.L, c.a, c.b);
         float m = fminf(j == 1 ? 1000000.0f : dist[i], d);
         dist[i] = m;
+        const uint64_t gi = first_index + i;
         unsigned long long kk = ((unsigned long long)float_to_bits(m) << 32) |
-                                (unsigned long long)(((uint32_t)(i >> 4) << 4) | (15u - (uint32_t)(i & 15u)));
+                                (unsigned long long)(((uint32_t)(gi >> 4) << 4) | (15u - (uint32_t)(gi & 15u)));
         best = kk > best ? kk : best;
     }
     for (int off = 32; off > 0; off >>= 1) {
@@ -379,11 +383,56 @@ __global__ __launch_bounds__(kBlock) void k_init_pass(const uint32_t *__restrict
 }
 
 hipError_t launch_init_pass(const uint32_t *rgba, uint64_t n, const float *lut, const Centroid *cent,
-                            uint32_t j, float *dist, unsigned long long *key, hipStream_t st)
+                            uint32_t j, float *dist, unsigned long long *key, uint64_t first_index, hipStream_t st)
 {
     uint64_t blocks = (n + kBlock - 1) / kBlock;
     uint32_t grid = (uint32_t)(blocks < 2048 ? (blocks ? blocks : 1) : 2048);
-    hipLaunchKernelGGL(k_init_pass, dim3(grid), dim3(kBlock), 0, st, rgba, n, lut, cent, j, dist, key);
+    hipLaunchKernelGGL(k_init_pass, dim3(grid), dim3(kBlock), 0, st, rgba, n, lut, cent, j, dist, key, first_index);
+    return hipGetLastError();
+}
+
+// Sharded init: the (all-reduced, max) key names one pixel of the whole image; the band that owns it
+// publishes its colour as {rgba, 1}, every other band {0, 0}, so a sum all-reduce delivers it everywhere.
+__global__ void k_init_pick_band(const uint32_t *__restrict__ rgba, uint64_t n, uint64_t first_index,
+                                 const unsigned long long *__restrict__ key, uint32_t *__restrict__ colour2)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const unsigned long long kk = *key;
+        uint64_t index = 0;                                   // Candidate(0, 0.0) when every distance is 0
+        if ((kk >> 32) != 0ull) {
+            const uint32_t low = (uint32_t)kk;
+            index = (low & ~15u) | (15u - (low & 15u));
+        }
+        const bool mine = index >= first_index && index < first_index + n;
+        colour2[0] = mine ? rgba[index - first_index] : 0u;
+        colour2[1] = mine ? 1u : 0u;
+    }
+}
+
+hipError_t launch_init_pick_band(const uint32_t *rgba, uint64_t n, uint64_t first_index,
+                                 const unsigned long long *key, uint32_t *colour2, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_init_pick_band, dim3(1), dim3(64), 0, st, rgba, n, first_index, key, colour2);
+    return hipGetLastError();
+}
+
+// centroid j <- shader Lab of one RGBA8 colour held in device memory
+__global__ void k_set_centroid_rgba(const uint32_t *__restrict__ colour, const float *__restrict__ lut,
+                                    Centroid *__restrict__ cent, uint32_t j)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const uint32_t px = colour[0];
+        float L, a, b;
+        linear100_to_lab(lut[px & 255u], lut[(px >> 8) & 255u], lut[(px >> 16) & 255u], L, a, b);
+        Centroid c; c.L = L; c.a = a; c.b = b; c.C = chroma(a, b);
+        cent[j] = c;
+    }
+}
+
+hipError_t launch_set_centroid_rgba(const uint32_t *colour, const float *lut, Centroid *cent, uint32_t j,
+                                    hipStream_t st)
+{
+    hipLaunchKernelGGL(k_set_centroid_rgba, dim3(1), dim3(64), 0, st, colour, lut, cent, j);
     return hipGetLastError();
 }
 

@@ -65,7 +65,8 @@ SYMBOLS = [
     "kmg_palette_to_centroids", "kmg_centroids_to_palette", "kmg_octree_palette", "kmg_dev_rgb_to_lab",
     "kmg_resized_dims",
     "kmg_dev_resize", "kmg_lloyd_create", "kmg_lloyd_destroy", "kmg_lloyd_set_centroids",
-    "kmg_lloyd_get_centroids", "kmg_lloyd_init_centroids", "kmg_lloyd_assign_accumulate",
+    "kmg_lloyd_get_centroids", "kmg_lloyd_init_centroids", "kmg_lloyd_init_step", "kmg_lloyd_init_pick_band",
+    "kmg_lloyd_set_centroid_rgba", "kmg_init_first_key", "kmg_lloyd_assign_accumulate",
     "kmg_lloyd_assign_partials", "kmg_lloyd_reduce_partials", "kmg_lloyd_labels", "kmg_lloyd_bind_image",
     "kmg_lloyd_unbind_image", "kmg_lloyd_prepare", "kmg_debug_check_table", "kmg_debug_table_stats", "kmg_kernel_name",
     "kmg_lloyd_profile", "kmg_lloyd_profile_read",
@@ -117,6 +118,11 @@ def lib():
     L.kmg_lloyd_set_centroids.argtypes = [vp, f32p, vp]
     L.kmg_lloyd_get_centroids.argtypes = [vp, f32p, vp]
     L.kmg_lloyd_init_centroids.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, vp]
+    L.kmg_lloyd_init_step.argtypes = [vp, u8p, C.c_uint64, C.c_uint64, C.c_uint32, vp, vp]
+    L.kmg_lloyd_init_pick_band.argtypes = [vp, u8p, C.c_uint64, C.c_uint64, vp, vp, vp]
+    L.kmg_lloyd_set_centroid_rgba.argtypes = [vp, C.c_uint32, vp, vp]
+    L.kmg_init_first_key.argtypes = [C.c_uint32, C.c_uint32]
+    L.kmg_init_first_key.restype = C.c_uint64
     L.kmg_lloyd_assign_accumulate.argtypes = [vp, u8p, C.c_uint64, u32p, i64p, vp]
     L.kmg_lloyd_assign_partials.argtypes = [vp, u8p, C.c_uint64, u32p, vp]
     L.kmg_lloyd_reduce_partials.argtypes = [vp, C.c_uint64, i64p, vp]
@@ -308,6 +314,22 @@ class Lloyd:
 
     def init_centroids(self, d_rgba, width, height, stream=0):
         _check(lib().kmg_lloyd_init_centroids(self._h, C.c_void_p(d_rgba), width, height, C.c_void_p(stream)))
+
+    # sharded (row band) initialisation steps -- see kmeans_gpu_amd.sharded.sharded_init
+    def init_step(self, d_rgba, n_local, first_index, j, d_key, stream=0):
+        _check(lib().kmg_lloyd_init_step(self._h, C.c_void_p(d_rgba or None), n_local, first_index, j,
+                                         C.c_void_p(d_key), C.c_void_p(stream)))
+
+    def init_pick_band(self, d_rgba, n_local, first_index, d_key, d_colour2, stream=0):
+        _check(lib().kmg_lloyd_init_pick_band(self._h, C.c_void_p(d_rgba or None), n_local, first_index,
+                                              C.c_void_p(d_key), C.c_void_p(d_colour2), C.c_void_p(stream)))
+
+    def set_centroid_rgba(self, j, d_colour, stream=0):
+        _check(lib().kmg_lloyd_set_centroid_rgba(self._h, j, C.c_void_p(d_colour), C.c_void_p(stream)))
+
+    @staticmethod
+    def init_first_key(width, height):
+        return int(lib().kmg_init_first_key(width, height))
 
     def assign_accumulate(self, d_rgba, n_pixels, d_labels, d_acc4, stream=0):
         _check(lib().kmg_lloyd_assign_accumulate(self._h, C.c_void_p(d_rgba), n_pixels,

@@ -12,12 +12,45 @@ pass needs no exchange at all (kmg_dev_apply takes the band's first row).
 import torch
 import torch.distributed as dist
 
-__all__ = ["band_rows", "ShardedLloyd", "ShardedBatch"]
+__all__ = ["band_rows", "sharded_init", "ShardedLloyd", "ShardedBatch"]
 
 
 def band_rows(height, rank, world):
     """Rows [r0, r1) owned by `rank`."""
     return (rank * height) // world, ((rank + 1) * height) // world
+
+
+def sharded_init(backend, k, band, width, height, row0, group=None, stream=0):
+    """PlusPlusInitModule::compute (modules.rs:946-1246) for an image sharded in row bands.
+
+    Every rank runs the local pass of its band; the arg-max is found with a MAX all-reduce of a 64-bit
+    key (distance bits | image-wide pixel position under the reference's tie rule), the winning pixel's
+    colour reaches all ranks with a SUM all-reduce of {colour, 1}, and every rank sets the same centroid.
+    2 tiny collectives per centroid, no host synchronisation.  Identical to the unsharded init.
+
+    backend : object with init_step / init_pick_band / set_centroid_rgba / init_first_key (kmeans_gpu_amd.Lloyd)
+    band    : this rank's rows, uint8 tensor (rows*width, 4); row0 = image row of its first pixel
+    """
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    n_local = int(band.shape[0]) if band.dim() == 2 else int(band.numel() // 4)
+    first = int(row0) * int(width)
+    ptr = band.data_ptr() if n_local else 0
+    key = torch.zeros(1, dtype=torch.int64, device=band.device)
+    colour = torch.zeros(2, dtype=torch.int32, device=band.device)
+
+    def publish(j):
+        backend.init_pick_band(ptr, n_local, first, key.data_ptr(), colour.data_ptr(), stream)
+        if world > 1:
+            dist.all_reduce(colour, op=dist.ReduceOp.SUM, group=group)
+        backend.set_centroid_rgba(j, colour.data_ptr(), stream)
+
+    key.fill_(backend.init_first_key(width, height))          # plus_plus_init.wgsl:161-168 `initial`
+    publish(0)
+    for j in range(1, int(k)):
+        backend.init_step(ptr, n_local, first, j, key.data_ptr(), stream)
+        if world > 1:
+            dist.all_reduce(key, op=dist.ReduceOp.MAX, group=group)
+        publish(j)
 
 
 class ShardedLloyd:

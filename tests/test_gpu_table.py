@@ -358,3 +358,47 @@ def test_batch_of_images_on_one_gpu(torch_cuda, processor, oracle):
         assert np.array_equal(labels[j].cpu().numpy().view(np.uint32), want_labels)
         backends[j].close()
     p.close()
+
+
+@pytest.mark.parametrize("w,h,k,bands", [(256, 171, 8, 2), (67, 41, 6, 3), (300, 200, 33, 4)])
+def test_sharded_init_steps_equal_unsharded_init(torch_cuda, processor, oracle, tokyo, w, h, k, bands):
+    """the band-wise init (local pass + MAX of keys + SUM of {colour, 1}) with the real kernels, the two
+    collectives emulated on one GPU, equals the unsharded device init and the oracle"""
+    import kmeans_gpu_amd as kg
+    from kmeans_gpu_amd.sharded import band_rows
+    torch = torch_cuda
+    st = _stream(torch)
+    if (w, h) == (256, 171):
+        img = oracle.resize(tokyo, w, h)
+    else:
+        rng = np.random.default_rng(w)
+        pal = rng.integers(0, 256, (5, 4), dtype=np.uint8); pal[:, 3] = 255
+        img = pal[rng.integers(0, 5, (h, w))]                   # few colours: many exact ties
+    want = oracle.init_centroids(oracle.rgb_to_lab(img), w, h, k)
+    d = _dev(torch, img.reshape(-1, 4))
+    states = []
+    for r in range(bands):
+        r0, r1 = band_rows(h, r, bands)
+        states.append((kg.Lloyd(processor, k), d.data_ptr() + r0 * w * 4, (r1 - r0) * w, r0 * w,
+                       torch.zeros(1, dtype=torch.int64, device="cuda"), torch.zeros(2, dtype=torch.int32, device="cuda")))
+
+    def publish(j, key_value):
+        total = torch.zeros(2, dtype=torch.int32, device="cuda")
+        for s, ptr, n, first, key, colour in states:
+            key.copy_(key_value)
+            s.init_pick_band(ptr, n, first, key.data_ptr(), colour.data_ptr(), st)
+            total += colour                                      # SUM all-reduce
+        assert int(total[1]) == 1                                # exactly one band owns the pixel
+        for s, *_ in states:
+            s.set_centroid_rgba(j, total.data_ptr(), st)
+
+    publish(0, torch.tensor([kg.Lloyd.init_first_key(w, h)], dtype=torch.int64, device="cuda"))
+    for j in range(1, k):
+        best = None
+        for s, ptr, n, first, key, _ in states:
+            s.init_step(ptr, n, first, j, key.data_ptr(), st)
+            best = key.clone() if best is None else torch.maximum(best, key)   # MAX all-reduce
+        publish(j, best)
+    for s, *_ in states:
+        assert np.array_equal(s.get_centroids(st).view(np.uint32), want.view(np.uint32))
+        s.close()

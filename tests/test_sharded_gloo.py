@@ -165,3 +165,95 @@ def test_sharded_batch_equals_per_image_oracle(oracle):
             assert its[j] == want_it
             assert np.array_equal(cents[j].view(np.uint32), want_c.view(np.uint32))
             assert np.array_equal(labs[j], want_labels[r0 * w:r1 * w])
+
+
+class OracleInitBackend(OracleBackend):
+    """adds the sharded-init steps (kmg_lloyd_init_step / _init_pick_band / _set_centroid_rgba)"""
+
+    @staticmethod
+    def _pack(g):
+        return ((g >> 4) << 4) | (15 - (g & 15))
+
+    @staticmethod
+    def init_first_key(width, height):
+        x0 = int(np.float32(width) * np.float32(0.5625)); y0 = int(np.float32(height) * np.float32(0.93359375))
+        return (1 << 32) | OracleInitBackend._pack(y0 * width + x0)
+
+    def init_step(self, d_rgba, n, first, j, d_key, stream=0):
+        key = self._view(d_key, (1,), np.int64)
+        key[0] = 0
+        if n == 0:
+            return
+        px = self._view(d_rgba, (n, 4), np.uint8)
+        lab = self.O.rgb_to_lab(px)
+        d = np.array([self.O.cie94(lab[i], self.cent[j - 1, :3]) for i in range(n)], np.float32)
+        self.dist = np.minimum(np.float32(1000000.0) if j == 1 else self.dist, d)
+        bits = self.dist.view(np.uint32).astype(np.int64)
+        g = first + np.arange(n, dtype=np.int64)
+        key[0] = int(((bits << 32) | (((g >> 4) << 4) | (15 - (g & 15)))).max())
+
+    def init_pick_band(self, d_rgba, n, first, d_key, d_colour2, stream=0):
+        kk = int(self._view(d_key, (1,), np.int64)[0])
+        idx = 0
+        if kk >> 32:
+            low = kk & 0xFFFFFFFF
+            idx = (low & ~15) | (15 - (low & 15))
+        out = self._view(d_colour2, (2,), np.uint32)
+        if first <= idx < first + n:
+            out[0] = self._view(d_rgba, (n,), np.uint32)[idx - first]; out[1] = 1
+        else:
+            out[:] = 0
+
+    def set_centroid_rgba(self, j, d_colour, stream=0):
+        px = self._view(d_colour, (1,), np.uint32).view(np.uint8).reshape(1, 4)
+        self.cent[j, :3] = self.O.rgb_to_lab(px)[0]
+        self.cent[j, 3] = 1.0
+
+
+def _init_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "kmeans-gpu_amd", "python"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    from kmeans_gpu_amd.sharded import ShardedLloyd, band_rows, sharded_init
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        O.set_num_threads(2)
+        w, h, k = 40, 33, 6
+        img = O.synth_uniform(77, w * h).reshape(h, w, 4)
+        img[5:9] = img[20:24]                      # duplicated rows: exact ties across the bands
+        r0, r1 = band_rows(h, rank, world)
+        band = torch.from_numpy(np.ascontiguousarray(img[r0:r1]).reshape(-1, 4))
+        be = OracleInitBackend(O, k, np.zeros((k, 4), np.float32))
+        sharded_init(be, k, band, w, h, r0)
+        init = be.cent.copy()
+        labels = torch.zeros((r1 - r0) * w, dtype=torch.int32)
+        it = ShardedLloyd(be, k, band, labels).run(128, 8)
+        q.put((rank, init, it, be.cent.copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_init_then_lloyd_equals_oracle(oracle):
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_init_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    w, h, k = 40, 33, 6
+    img = oracle.synth_uniform(77, w * h).reshape(h, w, 4)
+    img[5:9] = img[20:24]
+    lab = oracle.rgb_to_lab(img)
+    want_init = oracle.init_centroids(lab, w, h, k)
+    want_c, _, want_it = oracle.lloyd(lab, want_init)
+    for rank, init, it, cent in res:
+        assert np.array_equal(init.view(np.uint32), want_init.view(np.uint32))
+        assert it == want_it and np.array_equal(cent.view(np.uint32), want_c.view(np.uint32))
