@@ -175,16 +175,31 @@ __global__ __launch_bounds__(kBlock) void k_assign(const uint32_t *__restrict__ 
                 store4(labels, i0[g], n, aligned != 0, v);
             }
             if (ACCUM) {
+                // the 4 consecutive pixels of a group often share a label (always, in flat regions of a
+                // real image): merge such runs in registers and touch the LDS bins once per run
+                long long rs[4] = {0, 0, 0, 0};
+                uint32_t cur = 0xFFFFFFFFu;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int p = g * 4 + q;
                     if (i0[g] + q < n) {
-                        unsigned long long *bin = bins + 4ull * idx[p];
-                        atomicAdd(bin + 0, (unsigned long long)(long long)lab_fix(L[p]));
-                        atomicAdd(bin + 1, (unsigned long long)(long long)lab_fix(A[p]));
-                        atomicAdd(bin + 2, (unsigned long long)(long long)lab_fix(B[p]));
-                        atomicAdd(bin + 3, 1ull);
+                        if (idx[p] != cur) {
+                            if (cur != 0xFFFFFFFFu) {
+                                unsigned long long *bin = bins + 4ull * cur;
+                                for (int c = 0; c < 4; ++c) atomicAdd(bin + c, (unsigned long long)rs[c]);
+                            }
+                            cur = idx[p];
+                            rs[0] = rs[1] = rs[2] = rs[3] = 0;
+                        }
+                        rs[0] += (long long)lab_fix(L[p]);
+                        rs[1] += (long long)lab_fix(A[p]);
+                        rs[2] += (long long)lab_fix(B[p]);
+                        rs[3] += 1;
                     }
+                }
+                if (cur != 0xFFFFFFFFu) {
+                    unsigned long long *bin = bins + 4ull * cur;
+                    for (int c = 0; c < 4; ++c) atomicAdd(bin + c, (unsigned long long)rs[c]);
                 }
             }
         }
