@@ -402,3 +402,31 @@ def test_sharded_init_steps_equal_unsharded_init(torch_cuda, processor, oracle, 
     for s, *_ in states:
         assert np.array_equal(s.get_centroids(st).view(np.uint32), want.view(np.uint32))
         s.close()
+
+
+@pytest.mark.parametrize("n,k", [(1, 1), (1, 4), (7, 3), (1000, 16), (4097, 256)])
+def test_table_tiny_and_flat_images(torch_cuda, processor, oracle, n, k):
+    """degenerate inputs through the forced colour table: a handful of pixels, a single colour"""
+    import kmeans_gpu_amd as kg
+    torch = torch_cuda
+    st = _stream(torch)
+    for flat in (False, True):
+        rgba = oracle.synth_uniform(n + k, n)
+        if flat:
+            rgba[:] = rgba[0]
+        cent = oracle.centroids4(oracle.rgb_to_lab(oracle.synth_uniform(k * 3 + 1, k)))
+        wl, wa = oracle.assign_accumulate_rgba(rgba, cent)
+        d = _dev(torch, rgba)
+        s = kg.Lloyd(processor, k)
+        s.set_centroids(cent, st)
+        s.bind_image(d.data_ptr(), n, st)
+        labels = torch.zeros(n, dtype=torch.int32, device="cuda")
+        acc = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
+        s.assign_accumulate(d.data_ptr(), n, labels.data_ptr(), acc.data_ptr(), st)
+        torch.cuda.synchronize()
+        assert np.array_equal(labels.cpu().numpy().view(np.uint32), wl)
+        assert np.array_equal(acc.cpu().numpy(), wa)
+        s.update(acc.data_ptr(), st)
+        want_c, _ = oracle.finalize(wa, cent)
+        assert np.array_equal(s.get_centroids(st).view(np.uint32), want_c.view(np.uint32))
+        s.close()
