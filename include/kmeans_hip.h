@@ -171,6 +171,10 @@ KMG_API int kmg_debug_check_table(kmg_lloyd *s, uint64_t out[2], void *stream);
  * out = {occupied cells, sum of candidate counts, cells with one candidate, max candidates,
  *        cells with one label, occupied sub-cells, sub-cells with one label, distinct colours}.  */
 KMG_API int kmg_debug_table_stats(kmg_lloyd *s, uint64_t out[8], void *stream);
+/* Test support (k <= 256): checks the per-cell pair entries the label pass keeps in LDS against the
+ * per-colour label table of the last colour-table pass (synchronises).  out[0] = occupied colours
+ * whose entry disagrees (must be 0), out[1] = pixels resolved by the entries alone, out[2] = pixels. */
+KMG_API int kmg_debug_check_pairs(kmg_lloyd *s, uint64_t out[3], void *stream);
 
 /* Labels only, for the CURRENT centroid table: find_centroid.wgsl:15-44 without the sums.  With a
  * bound image whose label tables are current (an assign pass ran since the last centroid change) this

@@ -444,26 +444,76 @@ extern "C" int kmg_debug_table_stats(kmg_lloyd *s, uint64_t out[8], void *stream
     const uint32_t words = mask_words(s->k);
     std::vector<uint64_t> masks((size_t)kCells * words);
     std::vector<int64_t> agg(4ull * kCells);
-    std::vector<uint16_t> sub(kSubCells + kCells);
     std::vector<uint32_t> hist(1u << 24);
+    std::vector<uint16_t> labels(1u << 24);
     HIP_TRY(hipMemcpy(masks.data(), s->tab.d_masks, masks.size() * 8, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(agg.data(), s->tab.d_agg, agg.size() * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(sub.data(), s->tab.d_sub, sub.size() * 2, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(hist.data(), s->tab.d_hist, hist.size() * 4, hipMemcpyDeviceToHost));
+    if (s->k <= 256) {
+        std::vector<uint8_t> l8(1u << 24);
+        HIP_TRY(hipMemcpy(l8.data(), s->tab.d_colour_labels, l8.size(), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < l8.size(); ++i) labels[i] = l8[i];
+    } else {
+        HIP_TRY(hipMemcpy(labels.data(), s->tab.d_colour_labels, labels.size() * 2, hipMemcpyDeviceToHost));
+    }
     for (int i = 0; i < 8; ++i) out[i] = 0;
     for (uint32_t c = 0; c < kCells; ++c) {
         if (agg[4ull * c + 3] == 0) continue;
         uint64_t pop = 0;
         for (uint32_t w = 0; w < words; ++w) pop += (uint64_t)__builtin_popcountll(masks[(size_t)c * words + w]);
         out[0] += 1; out[1] += pop; out[2] += pop == 1; out[3] = std::max<uint64_t>(out[3], pop);
-        out[4] += sub[kSubCells + c] < kSubMixed;
+        int cell_first = -1;
+        bool cell_one = true;
         for (uint32_t q = 0; q < 8; ++q) {
-            const uint16_t e = sub[c * 8 + q];
-            out[5] += e != kSubEmpty;
-            out[6] += e < kSubMixed;
+            int first = -1;
+            bool one = true;
+            for (uint32_t i = 0; i < 64; ++i) {
+                const uint32_t col = c * kCellColours + q * 64 + i;
+                if (!hist[col]) continue;
+                if (first < 0) first = labels[col];
+                one = one && first == (int)labels[col];
+                if (cell_first < 0) cell_first = labels[col];
+                cell_one = cell_one && cell_first == (int)labels[col];
+            }
+            out[5] += first >= 0;
+            out[6] += first >= 0 && one;
         }
+        out[4] += cell_one;
     }
     for (uint32_t v : hist) out[7] += v != 0;
+    return KMG_OK;
+}
+
+// test / tuning support (k <= 256): validates the pair entries of the last colour-table pass against
+// the per-colour labels.  out[0] = occupied colours whose pair entry gives a label different from the
+// per-colour table (must be 0), out[1] = pixels the label pass resolves from the pair entry alone,
+// out[2] = pixels of the bound image.
+extern "C" int kmg_debug_check_pairs(kmg_lloyd *s, uint64_t out[3], void *stream)
+{
+    if (!s || !out) return fail(KMG_ERR_INVALID_ARGUMENT, "bad check_pairs arguments");
+    if (!s->tab.rgba || !s->tab.tables_valid) return fail(KMG_ERR_INVALID_ARGUMENT, "no current colour table");
+    if (s->k > 256) return fail(KMG_ERR_INVALID_ARGUMENT, "pair entries exist for k <= 256 only");
+    HIP_TRY(hipSetDevice(s->p->device));
+    HIP_TRY(hipStreamSynchronize(S(stream)));
+    std::vector<uint32_t> hist(1u << 24), pairs(kCells);
+    std::vector<uint8_t> labels(1u << 24);
+    HIP_TRY(hipMemcpy(hist.data(), s->tab.d_hist, hist.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(labels.data(), s->tab.d_colour_labels, labels.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pairs.data(), reinterpret_cast<const uint32_t *>(s->tab.d_sub + kSubCells + kCells),
+                      pairs.size() * 4, hipMemcpyDeviceToHost));
+    out[0] = out[1] = out[2] = 0;
+    for (uint32_t c = 0; c < (1u << 24); ++c) {
+        if (!hist[c]) continue;
+        uint32_t r, g, b;
+        index_to_rgb(c, r, g, b);
+        const uint32_t e = pairs[c >> 9];
+        const uint32_t px = r | (g << 8) | (b << 16);
+        const uint32_t got = pair_decode(e, pair_project(pair_dir_word((e >> 16) & 127u), px));
+        out[2] += hist[c];
+        if (got == kPairFine) continue;
+        out[1] += hist[c];
+        out[0] += got != labels[c];
+    }
     return KMG_OK;
 }
 

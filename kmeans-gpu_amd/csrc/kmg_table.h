@@ -56,6 +56,55 @@ __host__ __device__ inline void index_to_rgb(uint32_t idx, uint32_t &r, uint32_t
 
 inline uint32_t mask_words(uint32_t k) { return (k + 63u) / 64u; }
 
+// ---- pair entries (k <= 256): one u32 per 8x8x8 cell, all 32768 of them live in LDS during the
+// label pass.  [label A:8][label B:8][direction:7][tlo:6][w:3]
+//   p = n . (r & 7, g & 7, b & 7) - min over the cell of the same (so 0 <= p <= 42), n = one of the
+//   125 integer directions with components in -2..2;
+//   p < tlo      -> label A
+//   p >= tlo + w -> label B           (w = 7: no B side)
+//   otherwise    -> the per-colour table decides (kPairFine)
+// The cube pass picks n so that the plane separates the cell's most frequent label from the rest
+// and computes tlo / w exactly from the labels of the occupied colours, so the entry is always
+// right and only the colours in a thin slab around the boundary need the per-colour gather.
+constexpr uint32_t kPairDirs = 125;
+constexpr uint32_t kPairFine = 0xFFFFFFFFu;
+
+__host__ __device__ inline uint32_t pair_dir_code(int nx, int ny, int nz)
+{
+    return (uint32_t)((nx + 2) * 25 + (ny + 2) * 5 + (nz + 2));
+}
+
+// bytes (nx, ny, nz, -min p) as i8: one v_dot4_i32_i8 against (r & 7, g & 7, b & 7, 1) gives p
+__host__ __device__ inline uint32_t pair_dir_word(uint32_t code)
+{
+    const int nx = (int)(code / 25u) - 2, ny = (int)((code / 5u) % 5u) - 2, nz = (int)(code % 5u) - 2;
+    const int bias = 7 * ((nx < 0 ? -nx : 0) + (ny < 0 ? -ny : 0) + (nz < 0 ? -nz : 0));
+    return ((uint32_t)nx & 255u) | (((uint32_t)ny & 255u) << 8) | (((uint32_t)nz & 255u) << 16) | ((uint32_t)bias << 24);
+}
+
+__host__ __device__ inline uint32_t pair_entry(uint32_t A, uint32_t B, uint32_t code, uint32_t tlo, uint32_t w)
+{
+    return (A & 255u) | ((B & 255u) << 8) | (code << 16) | (tlo << 23) | (w << 29);
+}
+
+// p of a pixel (portable form of the dot4 used by the label kernel)
+__host__ __device__ inline int pair_project(uint32_t dir_word, uint32_t px)
+{
+    return (int)(int8_t)(dir_word & 255u) * (int)(px & 7u) + (int)(int8_t)((dir_word >> 8) & 255u) * (int)((px >> 8) & 7u) +
+           (int)(int8_t)((dir_word >> 16) & 255u) * (int)((px >> 16) & 7u) + (int)(dir_word >> 24);
+}
+
+// label of a pixel from its cell's entry and p, or kPairFine
+__host__ __device__ inline uint32_t pair_decode(uint32_t e, int p)
+{
+    const int tlo = (int)((e >> 23) & 63u);
+    const int w = (int)(e >> 29);
+    const int thr = tlo + w + (w == 7 ? 64 : 0);
+    if (p < tlo) return e & 255u;
+    if (p >= thr) return (e >> 8) & 255u;
+    return kPairFine;
+}
+
 // once per processor: bounds[kCells] and lab_table[2^24] = (L, a, b, C) of every colour (256 MiB,
 // image independent) so that the per-iteration cube pass loads Lab instead of recomputing it
 hipError_t launch_cell_bounds(const float *lut, CellBounds *bounds, float4 *lab_table, hipStream_t st);

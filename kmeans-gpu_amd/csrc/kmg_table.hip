@@ -229,6 +229,132 @@ hipError_t launch_cell_candidates(const CellBounds *bounds, const int64_t *agg, 
 }
 
 // ------------------------------------------------------------------------------------------
+// pair entry of one cell (kmg_table.h), computed by the wave that has just labelled its colours:
+// lane l holds the colours [8l, 8l+8) of the cell, idx[q] their labels, bit q of occ = colour occupied
+// ------------------------------------------------------------------------------------------
+struct Ballot4 { unsigned long long b[4]; };
+
+__device__ __forceinline__ Ballot4 ballot4(uint32_t v)          // v < 16 per lane
+{
+    Ballot4 r;
+    r.b[0] = __ballot((v & 1u) != 0u); r.b[1] = __ballot((v & 2u) != 0u);
+    r.b[2] = __ballot((v & 4u) != 0u); r.b[3] = __ballot((v & 8u) != 0u);
+    return r;
+}
+
+__device__ __forceinline__ uint32_t count4(const Ballot4 &x, unsigned long long lanes)   // sum of v over `lanes`
+{
+    return (uint32_t)__builtin_popcountll(x.b[0] & lanes) + 2u * (uint32_t)__builtin_popcountll(x.b[1] & lanes) +
+           4u * (uint32_t)__builtin_popcountll(x.b[2] & lanes) + 8u * (uint32_t)__builtin_popcountll(x.b[3] & lanes);
+}
+
+__device__ __forceinline__ uint32_t sel3(uint32_t i, uint32_t x0, uint32_t x1, uint32_t x2)
+{
+    return i == 0u ? x0 : (i == 1u ? x1 : x2);
+}
+
+__device__ __forceinline__ int round_dir(int g, int m)           // rint(2 g / m), |g| <= m, m > 0
+{
+    const int a = g < 0 ? -g : g;
+    const int r = (4 * a >= 3 * m ? 1 : 0) + (4 * a >= m ? 1 : 0);
+    return g < 0 ? -r : r;
+}
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t cell_pair_entry(const uint32_t idx[8], uint32_t occ, uint32_t lane)
+{
+    // the (up to) three first distinct labels among the occupied colours, their colours and counts
+    uint32_t rem = occ;
+    uint32_t lab0 = 0, lab1 = 0, lab2 = 0, cnt0 = 0, cnt1 = 0, cnt2 = 0, msk0 = 0, msk1 = 0, msk2 = 0;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const unsigned long long any = __ballot(rem != 0u);
+        if (any) {
+            uint32_t mine = 0;
+#pragma unroll
+            for (int q = 7; q >= 0; --q) mine = ((rem >> q) & 1u) ? idx[q] : mine;
+            const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)__builtin_ctzll(any));
+            uint32_t mm = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) mm |= (idx[q] == v ? 1u : 0u) << q;
+            mm &= rem;
+            rem &= ~mm;
+            const uint32_t c = count4(ballot4((uint32_t)__builtin_popcount(mm)), ~0ull);
+            if (t == 0) { lab0 = v; msk0 = mm; cnt0 = c; }
+            if (t == 1) { lab1 = v; msk1 = mm; cnt1 = c; }
+            if (t == 2) { lab2 = v; msk2 = mm; cnt2 = c; }
+        }
+    }
+    // A = the most frequent of them, B = the runner-up
+    uint32_t a = 0;
+    if (cnt1 > cnt0) a = 1;
+    if (cnt2 > sel3(a, cnt0, cnt1, cnt2)) a = 2;
+    uint32_t b = a == 0u ? 1u : 0u;
+    if (a != 1u && b != 1u && cnt1 > sel3(b, cnt0, cnt1, cnt2)) b = 1;
+    if (a != 2u && cnt2 > sel3(b, cnt0, cnt1, cnt2)) b = 2;
+    const uint32_t labA = sel3(a, lab0, lab1, lab2), labB = sel3(b, lab0, lab1, lab2);
+    const uint32_t mA = sel3(a, msk0, msk1, msk2), mB = sel3(b, msk0, msk1, msk2);
+    const uint32_t rest = occ & ~mA;                              // occupied colours with another label
+    const Ballot4 bA = ballot4((uint32_t)__builtin_popcount(mA));
+    const Ballot4 bR = ballot4((uint32_t)__builtin_popcount(rest));
+    const uint32_t nA = count4(bA, ~0ull), nR = count4(bR, ~0ull);
+    if (nR == 0u) return pair_entry(labA, labA, 0u, 0u, 0u);
+
+    // direction: from the centre of mass of A towards the one of the rest, at half-cell resolution
+    // (lane bits 5, 4, 3 = r2, g2, b2), rounded to components in -2..2.  Any direction is valid
+    // (tlo and w below are exact for it); a good one only makes the slab thin.
+    constexpr unsigned long long HX = 0xFFFFFFFF00000000ull, HY = 0xFFFF0000FFFF0000ull, HZ = 0xFF00FF00FF00FF00ull;
+    const int gx = (int)(count4(bR, HX) * nA) - (int)(count4(bA, HX) * nR);
+    const int gy = (int)(count4(bR, HY) * nA) - (int)(count4(bA, HY) * nR);
+    const int gz = (int)(count4(bR, HZ) * nA) - (int)(count4(bA, HZ) * nR);
+    const int ax = gx < 0 ? -gx : gx, ay = gy < 0 ? -gy : gy, az = gz < 0 ? -gz : gz;
+    const int m = ax > ay ? (ax > az ? ax : az) : (ay > az ? ay : az);
+    int nx = 2, ny = 0, nz = 0;
+    if (m > 0) { nx = round_dir(gx, m); ny = round_dir(gy, m); nz = round_dir(gz, m); }
+
+    // p of this lane's colours: x = r & 7 and the high bits of y, z are lane constants
+    const int xl = (int)(((lane >> 5) & 1u) * 4u + ((lane >> 1) & 3u));
+    const int yl = (int)(((lane >> 4) & 1u) * 4u + (lane & 1u) * 2u);
+    const int zl = (int)(((lane >> 3) & 1u) * 4u);
+    const int bias = 7 * ((nx < 0 ? -nx : 0) + (ny < 0 ? -ny : 0) + (nz < 0 ? -nz : 0));
+    const int p0 = nx * xl + ny * yl + nz * zl + bias;
+    int p[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) p[q] = p0 + ny * (q >> 2) + nz * (q & 3);
+    // tlo = lowest p of a colour that is not A, thi = highest p of a colour that is not B
+    const uint32_t notB = occ & ~mB;
+    uint32_t tl = 63u, hi = 64u;                                  // hi = 63 - thi
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        if ((rest >> q) & 1u) tl = min(tl, (uint32_t)p[q]);
+        if ((notB >> q) & 1u) hi = min(hi, (uint32_t)(63 - p[q]));
+    }
+    uint32_t packed = tl | (hi << 16);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_xor(packed, off, 64);
+        const u16x2 r = __builtin_elementwise_min(__builtin_bit_cast(u16x2, packed), __builtin_bit_cast(u16x2, o));
+        packed = __builtin_bit_cast(uint32_t, r);
+    }
+    const int tlo = (int)(packed & 0xFFFFu), thi = 63 - (int)(packed >> 16);
+    const int w = thi + 1 > tlo ? thi + 1 - tlo : 0;
+    const uint32_t code = pair_dir_code(nx, ny, nz);
+    if (w <= 6) return pair_entry(labA, labB, code, (uint32_t)tlo, (uint32_t)w);
+    // the slab is too wide to encode (a third label, or a strongly curved boundary): keep the
+    // side that resolves more colours, the other one goes through the per-colour table
+    uint32_t low = 0, high = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        if ((occ >> q) & 1u) { low += p[q] < tlo ? 1u : 0u; high += p[q] > thi ? 1u : 0u; }
+    }
+    const uint32_t cl = count4(ballot4(low), ~0ull), ch = count4(ballot4(high), ~0ull);
+    if (cl >= ch) return pair_entry(labA, labB, code, (uint32_t)tlo, 7u);
+    const int range = 7 * ((nx < 0 ? -nx : nx) + (ny < 0 ? -ny : ny) + (nz < 0 ? -nz : nz));
+    return pair_entry(labB, labA, pair_dir_code(-nx, -ny, -nz), (uint32_t)(range - thi), 7u);
+}
+
+// ------------------------------------------------------------------------------------------
 // cube pass (per iteration): one wave per cell, 8 colours (= 1/8 of a 4x4x4 sub-cell) per lane
 // LDS: [centroids kpad x 16 B][bins k x 32 B].  Lab of a colour comes from the static per-colour
 // table (16 B load instead of ~200 VALU slots of sRGB->Lab).
@@ -266,9 +392,7 @@ __global__ __launch_bounds__(kBlock) void k_cube(const uint32_t *__restrict__ hi
         const uint32_t cell = SUMS ? __builtin_amdgcn_readfirstlane(work[1u + wi]) : wi;
         uint16_t *sub = sub_table + cell * 8u;
         uint16_t *cell_entry = sub_table + kSubCells + cell;       // 8x8x8 summary, same encoding
-        // pair entry (k <= 256): [label A:8][label B:8][mask A:8][mask B:8]; bit s of a mask = every
-        // occupied colour of sub-cell s carries that label
-        uint32_t *pair_entry = reinterpret_cast<uint32_t *>(sub_table + kSubCells + kCells) + cell;
+        uint32_t *pair_entry_ptr = reinterpret_cast<uint32_t *>(sub_table + kSubCells + kCells) + cell;   // k <= 256
         const uint32_t base = cell * kCellColours + lane * 8;
         // every load of this cell is issued before anything depends on one of them
         const uint4 one4 = make_uint4(1u, 1u, 1u, 1u);
@@ -294,8 +418,12 @@ __global__ __launch_bounds__(kBlock) void k_cube(const uint32_t *__restrict__ hi
                 *reinterpret_cast<uint2 *>(colour_labels + base) = *reinterpret_cast<uint2 *>(v);
             else
                 *reinterpret_cast<uint4 *>(colour_labels + base) = *reinterpret_cast<uint4 *>(v);
-            if (lane < 8) sub[lane] = (uint16_t)first;
-            if (lane == 0) { *cell_entry = (uint16_t)first; *pair_entry = (first & 0xFFu) | 0x00FF0000u; }
+            if (sizeof(LabelT) == 1) {
+                if (lane == 0) *pair_entry_ptr = pair_entry(first, first, 0u, 0u, 0u);
+            } else {
+                if (lane < 8) sub[lane] = (uint16_t)first;
+                if (lane == 0) *cell_entry = (uint16_t)first;
+            }
             if (SUMS && lane < 4) atomicAdd(bins + 4ull * first + lane, (unsigned long long)agg[4ull * cell + lane]);
             continue;
         }
@@ -368,42 +496,29 @@ __global__ __launch_bounds__(kBlock) void k_cube(const uint32_t *__restrict__ hi
                 for (int j = 0; j < 4; ++j) atomicAdd(bin + j, (unsigned long long)s[j]);
             }
         }
-        // sub-cell summary over the 8 lanes that share a 4x4x4 sub-cell
+        if (sizeof(LabelT) == 1) {
+            // k <= 256: the label pass works from the pair entries
+            uint32_t occ = 0;
 #pragma unroll
-        for (int off = 1; off < 8; off <<= 1) {
-            const uint32_t o = __shfl_xor(state, off, 64);
-            state = (state == kSubEmpty) ? o : ((o == kSubEmpty || o == state) ? state : (uint32_t)kSubMixed);
-        }
-        if ((lane & 7u) == 0) sub[lane >> 3] = (uint16_t)state;
-        {
-            // the two first uniform labels of the cell and which sub-cells they cover
-            uint32_t st8[8];
+            for (int q = 0; q < 8; ++q) occ |= (cnt[q] ? 1u : 0u) << q;
+            const uint32_t e = cell_pair_entry(idx, occ, lane);
+            if (lane == 0) *pair_entry_ptr = e;
+        } else {
+            // k > 256: sub-cell summary over the 8 lanes that share a 4x4x4 sub-cell ...
 #pragma unroll
-            for (int g = 0; g < 8; ++g) st8[g] = __shfl(state, g * 8, 64);
-            uint32_t A = 0xFFFFFFFFu, B = 0xFFFFFFFFu, mA = 0, mB = 0;
-#pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                const uint32_t v = st8[g];
-                if (v < kSubMixed) {
-                    if (A == 0xFFFFFFFFu) A = v;
-                    else if (v != A && B == 0xFFFFFFFFu) B = v;
-                }
+            for (int off = 1; off < 8; off <<= 1) {
+                const uint32_t o = __shfl_xor(state, off, 64);
+                state = (state == kSubEmpty) ? o : ((o == kSubEmpty || o == state) ? state : (uint32_t)kSubMixed);
             }
+            if ((lane & 7u) == 0) sub[lane >> 3] = (uint16_t)state;
+            // ... and over the whole 8x8x8 cell
 #pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                const uint32_t v = st8[g];
-                if (v == kSubEmpty || v == A) mA |= 1u << g;
-                else if (v == B) mB |= 1u << g;
+            for (int off = 8; off < 64; off <<= 1) {
+                const uint32_t o = __shfl_xor(state, off, 64);
+                state = (state == kSubEmpty) ? o : ((o == kSubEmpty || o == state) ? state : (uint32_t)kSubMixed);
             }
-            if (lane == 0) *pair_entry = (A & 0xFFu) | ((B & 0xFFu) << 8) | (mA << 16) | (mB << 24);
+            if (lane == 0) *cell_entry = (uint16_t)state;
         }
-        // ... and over the whole 8x8x8 cell
-#pragma unroll
-        for (int off = 8; off < 64; off <<= 1) {
-            const uint32_t o = __shfl_xor(state, off, 64);
-            state = (state == kSubEmpty) ? o : ((o == kSubEmpty || o == state) ? state : (uint32_t)kSubMixed);
-        }
-        if (lane == 0) *cell_entry = (uint16_t)state;
     }
 
     if (SUMS) {
@@ -501,7 +616,9 @@ __global__ __launch_bounds__(kLabelBlock) void k_labels_pairs(const uint32_t *__
 {
     __shared__ uint32_t s_pair[kCells];
     __shared__ uint32_t s_pal[256];
+    __shared__ uint32_t s_dir[128];
     if (pal && threadIdx.x < k) s_pal[threadIdx.x] = pal[threadIdx.x];
+    if (threadIdx.x < kPairDirs) s_dir[threadIdx.x] = pair_dir_word(threadIdx.x);
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(pair_table);
         uint4 *dst = reinterpret_cast<uint4 *>(s_pair);
@@ -511,7 +628,7 @@ __global__ __launch_bounds__(kLabelBlock) void k_labels_pairs(const uint32_t *__
     constexpr uint64_t TILE = (uint64_t)kLabelBlock * 8;
     const uint64_t tiles = (n + TILE - 1) / TILE;
     for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        uint32_t ci[8];
+        uint32_t ci[8], xyz[8];
         uint64_t i0[2];
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
@@ -519,15 +636,19 @@ __global__ __launch_bounds__(kLabelBlock) void k_labels_pairs(const uint32_t *__
             uint32_t px[4];
             load4_stream(rgba, i0[g], n, aligned != 0, px);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) ci[g * 4 + q] = colour_index(px[q]);
+            for (int q = 0; q < 4; ++q) {
+                ci[g * 4 + q] = colour_index(px[q]);
+                xyz[g * 4 + q] = (px[q] & 0x00070707u) | 0x01000000u;   // (r & 7, g & 7, b & 7, 1)
+            }
         }
         uint32_t lab[8];
         bool fine[8];
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             const uint32_t e = s_pair[ci[p] >> 9];
-            const uint32_t sub = (ci[p] >> 6) & 7u;
-            const bool inA = (e >> (16 + sub)) & 1u, inB = (e >> (24 + sub)) & 1u;
+            const int proj = __builtin_amdgcn_sdot4((int)xyz[p], (int)s_dir[(e >> 16) & 127u], 0, false);
+            const int tlo = (int)((e >> 23) & 63u), w = (int)(e >> 29);
+            const bool inA = proj < tlo, inB = proj >= tlo + w + (w == 7 ? 64 : 0);
             lab[p] = inA ? (e & 0xFFu) : ((e >> 8) & 0xFFu);
             fine[p] = !(inA || inB);
         }
@@ -560,12 +681,8 @@ hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_la
     const uint32_t grid = (uint32_t)(tiles < 512 ? (tiles ? tiles : 1) : 512);   // 2 workgroups per CU
     const int aligned = ((reinterpret_cast<uintptr_t>(rgba) & 15u) == 0 &&
                          (reinterpret_cast<uintptr_t>(labels) & 15u) == 0) ? 1 : 0;
-    if (k <= 256)
-        hipLaunchKernelGGL(k_labels<uint8_t>, dim3(grid), dim3(kLabelBlock), 0, st, rgba, n,
-                           (const uint8_t *)colour_labels, sub_table, pal, k, labels, aligned);
-    else
-        hipLaunchKernelGGL(k_labels<uint16_t>, dim3(grid), dim3(kLabelBlock), 0, st, rgba, n,
-                           (const uint16_t *)colour_labels, sub_table, pal, k, labels, aligned);
+    hipLaunchKernelGGL(k_labels<uint16_t>, dim3(grid), dim3(kLabelBlock), 0, st, rgba, n,
+                       (const uint16_t *)colour_labels, sub_table, pal, k, labels, aligned);
     return hipGetLastError();
 }
 

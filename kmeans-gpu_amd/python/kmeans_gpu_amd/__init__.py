@@ -68,7 +68,7 @@ SYMBOLS = [
     "kmg_lloyd_get_centroids", "kmg_lloyd_init_centroids", "kmg_lloyd_init_step", "kmg_lloyd_init_pick_band",
     "kmg_lloyd_set_centroid_rgba", "kmg_init_first_key", "kmg_lloyd_assign_accumulate",
     "kmg_lloyd_assign_partials", "kmg_lloyd_reduce_partials", "kmg_lloyd_labels", "kmg_lloyd_bind_image",
-    "kmg_lloyd_unbind_image", "kmg_lloyd_prepare", "kmg_debug_check_table", "kmg_debug_table_stats", "kmg_kernel_name",
+    "kmg_lloyd_unbind_image", "kmg_lloyd_prepare", "kmg_debug_check_table", "kmg_debug_table_stats", "kmg_debug_check_pairs", "kmg_kernel_name",
     "kmg_lloyd_profile", "kmg_lloyd_profile_read",
     "kmg_lloyd_update", "kmg_lloyd_converged_count", "kmg_lloyd_run", "kmg_dev_apply",
     "kmg_dither_threshold",
@@ -129,6 +129,7 @@ def lib():
     L.kmg_lloyd_labels.argtypes = [vp, u8p, C.c_uint64, u32p, vp]
     L.kmg_lloyd_bind_image.argtypes = [vp, u8p, C.c_uint64, vp]
     L.kmg_debug_table_stats.argtypes = [vp, C.POINTER(C.c_uint64), vp]
+    L.kmg_debug_check_pairs.argtypes = [vp, C.POINTER(C.c_uint64), vp]
     L.kmg_kernel_name.argtypes = [C.c_int]
     L.kmg_kernel_name.restype = C.c_char_p
     L.kmg_lloyd_profile.argtypes = [vp, C.c_int]
@@ -396,6 +397,12 @@ class Lloyd:
         names = ["occupied_cells", "candidates_total", "cells_one_candidate", "max_candidates",
                  "cells_one_label", "occupied_sub_cells", "sub_cells_one_label", "distinct_colours"]
         return dict(zip(names, (int(v) for v in out)))
+
+    def debug_check_pairs(self, stream=0):
+        """(mismatching colours, pixels resolved by the LDS pair entries, pixels) of the last table pass"""
+        out = (C.c_uint64 * 3)()
+        _check(lib().kmg_debug_check_pairs(self._h, out, C.c_void_p(stream)))
+        return int(out[0]), int(out[1]), int(out[2])
 
     def update(self, d_acc4, stream=0):
         _check(lib().kmg_lloyd_update(self._h, C.c_void_p(d_acc4), C.c_void_p(stream)))

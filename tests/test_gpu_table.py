@@ -80,6 +80,9 @@ def test_table_pass_equals_pixel_scan(torch_cuda, processor, oracle, tokyo, kind
             s.assign_accumulate(d.data_ptr(), n, labels.data_ptr(), acc.data_ptr(), st)
             torch.cuda.synchronize()
             out.append((labels.cpu().numpy().copy(), acc.cpu().numpy().copy()))
+            if bind and k <= 256:                # the LDS pair entries agree with the per-colour labels
+                bad, resolved, total = s.debug_check_pairs(st)
+                assert bad == 0 and total == n and resolved <= total
             s.update(acc.data_ptr(), st)
         c = s.get_centroids(st)
         s.close()
