@@ -203,6 +203,28 @@ __global__ __launch_bounds__(kBlock) void k_cell_candidates(const CellBounds *__
     }
     const CellBounds cb = bounds[cell];
     float U = 3.0e38f;
+    if (words <= 4u) {
+        // k <= 256: one evaluation per centroid, the lower bounds wait in registers for U
+        float lo[4];
+#pragma unroll
+        for (uint32_t w = 0; w < 4u; ++w) {
+            const uint32_t j = w * 64 + lane;
+            lo[w] = 0.0f;
+            if (j < k) {
+                const Centroid c = cent[j];
+                const KeyRange r = key_range(cb, c.L, c.a, c.b, c.C);
+                lo[w] = r.lo;
+                U = fminf(U, r.hi);
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) U = fminf(U, __shfl_xor(U, off, 64));
+#pragma unroll
+        for (uint32_t w = 0; w < 4u; ++w) {
+            const unsigned long long m = __ballot(w * 64 + lane < k && lo[w] <= U);
+            if (w < words && lane == 0) out[w] = m;
+        }
+        return;
+    }
     for (uint32_t j = lane; j < k; j += 64) {
         const Centroid c = cent[j];
         U = fminf(U, key_range(cb, c.L, c.a, c.b, c.C).hi);
