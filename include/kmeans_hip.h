@@ -175,6 +175,11 @@ KMG_API int kmg_debug_table_stats(kmg_lloyd *s, uint64_t out[8], void *stream);
  * per-colour label table of the last colour-table pass (synchronises).  out[0] = occupied colours
  * whose entry disagrees (must be 0), out[1] = pixels resolved by the entries alone, out[2] = pixels. */
 KMG_API int kmg_debug_check_pairs(kmg_lloyd *s, uint64_t out[3], void *stream);
+/* Test support: exhaustive check (2^24 colours x 16 Bayer offsets) that the candidate masks of the
+ * pruned dither pass for this centroid table (k >= 2, (L, a, b, pad) per entry) contain every pixel's
+ * true arg-min of mix_colors.wgsl:73-80.  *violations must come back 0.                            */
+KMG_API int kmg_debug_check_dither_masks(kmg_processor *p, const float *centroids4, uint32_t k, uint64_t *violations,
+                                         void *stream);
 
 /* Labels only, for the CURRENT centroid table: find_centroid.wgsl:15-44 without the sums.  With a
  * bound image whose label tables are current (an assign pass ran since the last centroid change) this

@@ -263,6 +263,15 @@ struct DevBuf {
     hipError_t alloc(size_t bytes) { return hipMalloc(&ptr, bytes); }
 };
 
+// scratch that lives for one call on one stream: stream-ordered allocation from the device's memory
+// pool (a reused block after the first call instead of a ~0.1 ms hipMalloc + hipFree pair)
+struct StreamBuf {
+    void *ptr = nullptr;
+    hipStream_t st = nullptr;
+    ~StreamBuf() { if (ptr) (void)hipFreeAsync(ptr, st); }
+    hipError_t alloc(size_t bytes, hipStream_t stream) { st = stream; return hipMallocAsync(&ptr, bytes, stream); }
+};
+
 struct StreamGuard {
     hipStream_t st = nullptr;
     ~StreamGuard() { if (st) (void)hipStreamDestroy(st); }
@@ -316,6 +325,19 @@ static bool replace_table_pays(uint64_t n, uint32_t k)
     const double brute = N * (8.1e-12 + 2.2e-13 * k);
     const double table = 3.8e-4 + 2.3e-7 * k + N * (k <= 256 ? 1.7e-12 + 6.0e-15 * k : 6.6e-12);
     return table < brute;
+}
+
+// Dither output pass: per-pixel scan of all k centroids, or of the candidates of the pixel's
+// (colour cell, Bayer index) only.  Measured on MI355X (tools/dither_probe.py): building the 2^19
+// masks costs 0.11 ms per 64 centroids, the pruned pass then saves 13 ps (k = 64) .. 28 ps (k = 256)
+// per pixel of a noise image (more on photographs); below k = 32 the scan of all centroids wins.
+static bool dither_pruning_pays(uint64_t n, uint32_t k)
+{
+    if (const char *e = getenv("KMG_STRATEGY")) {
+        if (!strcmp(e, "brute")) return false;
+        if (!strcmp(e, "table")) return true;
+    }
+    return k >= 32 && n >= 12000000ull;
 }
 
 static int ensure_bounds(kmg_processor *p, hipStream_t st)
@@ -428,6 +450,37 @@ extern "C" int kmg_debug_check_table(kmg_lloyd *s, uint64_t out[2], void *stream
     HIP_TRY(hipMemcpyAsync(h, viol.ptr, sizeof h, hipMemcpyDeviceToHost, S(stream)));
     HIP_TRY(hipStreamSynchronize(S(stream)));
     out[0] = h[0]; out[1] = h[1];
+    return KMG_OK;
+}
+
+// test support: exhaustive validation of the dither candidate masks (kmg_table.hip) for a centroid
+// table: over all 2^24 colours x 16 Bayer offsets, the arg-min over the candidates must equal the
+// brute-force arg-min.  *violations must come back 0.
+extern "C" int kmg_debug_check_dither_masks(kmg_processor *p, const float *c4, uint32_t k, uint64_t *violations, void *stream)
+{
+    if (!p || !c4 || !violations || k < 2 || k > KMG_MAX_K) return fail(KMG_ERR_INVALID_ARGUMENT, "bad check_dither_masks arguments");
+    HIP_TRY(hipSetDevice(p->device));
+    int rc;
+    if ((rc = ensure_bounds(p, S(stream))) != KMG_OK) return rc;
+    std::vector<Centroid> hc(k);
+    for (uint32_t i = 0; i < k; ++i) {
+        hc[i].L = c4[4 * i]; hc[i].a = c4[4 * i + 1]; hc[i].b = c4[4 * i + 2];
+        hc[i].C = chroma(hc[i].a, hc[i].b);
+    }
+    const float thr = dither_threshold(c4, k);
+    DevBuf cent, masks, viol;
+    HIP_TRY(cent.alloc(sizeof(Centroid) * k));
+    HIP_TRY(masks.alloc(sizeof(uint64_t) * (size_t)kCells * 16u * mask_words(k)));
+    HIP_TRY(viol.alloc(sizeof(unsigned long long)));
+    HIP_TRY(hipMemcpyAsync(cent.ptr, hc.data(), sizeof(Centroid) * k, hipMemcpyHostToDevice, S(stream)));
+    HIP_TRY(hipMemsetAsync(viol.ptr, 0, sizeof(unsigned long long), S(stream)));
+    HIP_TRY(launch_offset_candidates(p->d_bounds, (const Centroid *)cent.ptr, k, thr, (uint64_t *)masks.ptr, S(stream)));
+    HIP_TRY(launch_check_offset_masks((const Centroid *)cent.ptr, k, (const uint64_t *)masks.ptr, p->d_lut, thr,
+                                      (unsigned long long *)viol.ptr, S(stream)));
+    unsigned long long h = 0;
+    HIP_TRY(hipMemcpyAsync(&h, viol.ptr, sizeof h, hipMemcpyDeviceToHost, S(stream)));
+    HIP_TRY(hipStreamSynchronize(S(stream)));
+    *violations = h;
     return KMG_OK;
 }
 
@@ -879,24 +932,29 @@ extern "C" int kmg_dev_apply(kmg_processor *p, const uint8_t *d_rgba, uint32_t w
     bool dither = (mode == KMG_MODE_DITHER) && k > 1;                 // mix_colors.wgsl:104-108
     float thr = dither ? dither_threshold(c4, k) : 0.0f;
 
-    Centroid *d_cent = nullptr;
-    uint32_t *d_pal = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_cent, sizeof(Centroid) * k));
-    hipError_t e = hipMalloc((void **)&d_pal, sizeof(uint32_t) * (k + 1));
+    // every scratch buffer of the call is stream-ordered and dies with it (the call synchronises)
+    StreamBuf cent_buf, pal_buf, masks, colour_labels, sub;
+    hipError_t e = cent_buf.alloc(sizeof(Centroid) * k, S(stream));
+    if (e == hipSuccess) e = pal_buf.alloc(sizeof(uint32_t) * (k + 1), S(stream));
+    Centroid *d_cent = (Centroid *)cent_buf.ptr;
+    uint32_t *d_pal = (uint32_t *)pal_buf.ptr;
     if (e == hipSuccess) e = hipMemcpyAsync(d_cent, hc.data(), sizeof(Centroid) * k, hipMemcpyHostToDevice, S(stream));
     if (e == hipSuccess) e = hipMemcpyAsync(d_pal, pal.data(), sizeof(uint32_t) * (k + 1), hipMemcpyHostToDevice, S(stream));
     const uint64_t n_px = (uint64_t)w * rows;
-    if (e == hipSuccess && mode != KMG_MODE_MELD && !dither && replace_table_pays(n_px, k)) {
+    int rc = KMG_OK;
+    if (e != hipSuccess) {
+        // fall through to the error report
+    } else if (mode == KMG_MODE_MELD) {
+        e = launch_meld((const uint32_t *)d_rgba, n_px, d_cent, k, p->d_lut, (uint32_t *)d_out, S(stream));
+    } else if (!dither && replace_table_pays(n_px, k)) {
         // replace mode on a large image: the label of a pixel depends on its colour only, so label the
         // colour cube once (candidate masks + cube pass without sums) and emit pal[label] through the
-        // hierarchical label tables -- the same bit-exact machinery as the Lloyd label pass
-        int rc = ensure_bounds(p, S(stream));
-        DevBuf masks, colour_labels, sub;
-        if (rc == KMG_OK) {
+        // label tables -- the same bit-exact machinery as the Lloyd label pass
+        if ((rc = ensure_bounds(p, S(stream))) == KMG_OK) {
             const size_t sub_bytes = sizeof(uint16_t) * (kSubCells + kCells) + sizeof(uint32_t) * kCells;
-            e = masks.alloc(sizeof(uint64_t) * (size_t)kCells * mask_words(k));
-            if (e == hipSuccess) e = colour_labels.alloc((size_t)(k <= 256 ? 1 : 2) << 24);
-            if (e == hipSuccess) e = sub.alloc(sub_bytes);
+            e = masks.alloc(sizeof(uint64_t) * (size_t)kCells * mask_words(k), S(stream));
+            if (e == hipSuccess) e = colour_labels.alloc((size_t)(k <= 256 ? 1 : 2) << 24, S(stream));
+            if (e == hipSuccess) e = sub.alloc(sub_bytes, S(stream));
             if (e == hipSuccess) e = launch_cell_candidates(p->d_bounds, nullptr, d_cent, k, (uint64_t *)masks.ptr, S(stream));
             if (e == hipSuccess)
                 e = launch_cube(nullptr, nullptr, (const uint64_t *)masks.ptr, nullptr, d_cent, k, p->d_lab_table,
@@ -905,26 +963,23 @@ extern "C" int kmg_dev_apply(kmg_processor *p, const uint8_t *d_rgba, uint32_t w
                 e = launch_labels((const uint32_t *)d_rgba, n_px, colour_labels.ptr, (const uint16_t *)sub.ptr, k, d_pal,
                                   (uint32_t *)d_out, S(stream));
         }
-        hipError_t e2 = hipStreamSynchronize(S(stream));
-        (void)hipFree(d_cent);
-        (void)hipFree(d_pal);
-        if (rc != KMG_OK) return rc;
-        if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? KMG_ERR_OUT_OF_MEMORY : KMG_ERR_HIP, "apply failed: %s", hipGetErrorString(e));
-        if (e2 != hipSuccess) return fail(KMG_ERR_HIP, "apply failed: %s", hipGetErrorString(e2));
-        return KMG_OK;
+    } else if (dither && dither_pruning_pays(n_px, k)) {
+        // dither on a large image: candidate masks per (colour cell, Bayer index), then a scan of the
+        // pixel's candidates only
+        if ((rc = ensure_bounds(p, S(stream))) == KMG_OK) {
+            e = masks.alloc(sizeof(uint64_t) * (size_t)kCells * 16u * mask_words(k), S(stream));
+            if (e == hipSuccess) e = launch_offset_candidates(p->d_bounds, d_cent, k, thr, (uint64_t *)masks.ptr, S(stream));
+            if (e == hipSuccess)
+                e = launch_dither_pruned((const uint32_t *)d_rgba, w, rows, row0, d_cent, k, p->d_lut, d_pal, thr,
+                                         (const uint64_t *)masks.ptr, (uint32_t *)d_out, S(stream));
+        }
+    } else {
+        e = launch_apply((const uint32_t *)d_rgba, w, rows, row0, d_cent, k, p->d_lut, d_pal, dither, thr,
+                         (uint32_t *)d_out, S(stream));
     }
-    if (e == hipSuccess) {
-        if (mode == KMG_MODE_MELD)
-            e = launch_meld((const uint32_t *)d_rgba, (uint64_t)w * rows, d_cent, k, p->d_lut, (uint32_t *)d_out, S(stream));
-        else
-            e = launch_apply((const uint32_t *)d_rgba, w, rows, row0, d_cent, k, p->d_lut, d_pal, dither, thr,
-                             (uint32_t *)d_out, S(stream));
-    }
-    // the staging vectors and the two small device tables die with this call
-    hipError_t e2 = hipStreamSynchronize(S(stream));
-    (void)hipFree(d_cent);
-    if (d_pal) (void)hipFree(d_pal);
-    if (e != hipSuccess) return fail(KMG_ERR_HIP, "apply failed: %s", hipGetErrorString(e));
+    const hipError_t e2 = hipStreamSynchronize(S(stream));
+    if (rc != KMG_OK) return rc;
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? KMG_ERR_OUT_OF_MEMORY : KMG_ERR_HIP, "apply failed: %s", hipGetErrorString(e));
     if (e2 != hipSuccess) return fail(KMG_ERR_HIP, "apply failed: %s", hipGetErrorString(e2));
     return KMG_OK;
 }

@@ -126,6 +126,19 @@ hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_la
                          const uint16_t *sub_table, uint32_t k, const uint32_t *pal, uint32_t *labels,
                          hipStream_t st);
 
+// ordered-dither output pass with candidate pruning: masks[(cell * 16 + Bayer index) * words + w] are the
+// centroids that can be the arg-min of Lab(colour) + threshold * (M[Bayer index] / 16 - 0.5) for any
+// colour of the cell; the pass scans only those (pal: k + 1 RGBA8 words, entry k = the sentinel)
+hipError_t launch_offset_candidates(const CellBounds *bounds, const Centroid *cent, uint32_t k, float threshold,
+                                    uint64_t *masks, hipStream_t st);
+hipError_t launch_dither_pruned(const uint32_t *rgba, uint32_t w, uint32_t rows, uint32_t row0, const Centroid *cent,
+                                uint32_t k, const float *lut, const uint32_t *pal, float threshold,
+                                const uint64_t *masks, uint32_t *out, hipStream_t st);
+// test support: number of (colour, Bayer index) pairs whose arg-min over the candidates differs from
+// the brute-force dither arg-min
+hipError_t launch_check_offset_masks(const Centroid *cent, uint32_t k, const uint64_t *masks, const float *lut,
+                                     float threshold, unsigned long long *violations, hipStream_t st);
+
 // debug / test support: number of (cell, centroid, colour) triples whose key falls outside the
 // interval bounds, and number of colours whose brute-force arg-min is missing from the cell mask
 hipError_t launch_check_bounds(const CellBounds *bounds, const Centroid *cent, uint32_t k,

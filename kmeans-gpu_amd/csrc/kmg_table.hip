@@ -709,6 +709,251 @@ hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_la
 }
 
 // ------------------------------------------------------------------------------------------
+// ordered-dither output pass with candidate pruning (mix_colors.wgsl:50-83)
+//
+// The dithered colour of a pixel is Lab(colour) + off, off = one of the 16 Bayer offsets of the
+// pass, so its nearest centroid depends on (colour, Bayer index) only.  For every (cell, Bayer
+// index) k_offset_candidates builds the same kind of conservative candidate mask as
+// k_cell_candidates, from the static cell bounds shifted by the offset; the output pass then
+// scans, per pixel, only the candidates of its (cell, Bayer index) instead of all k centroids.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bayer16(uint32_t i)            // mix_colors.wgsl:13-16
+{
+    constexpr uint64_t M = 0x5D7F91B36E4CA280ull;               // 0 8 2 10 12 4 14 6 3 11 1 9 15 7 13 5, 4 bits each
+    return (float)((M >> (4u * i)) & 15ull);
+}
+
+// bounds of the per-pixel terms after adding `off` to L, a and b of every colour of the cell
+__device__ __forceinline__ CellBounds shifted_bounds(const CellBounds &cb, float off)
+{
+    CellBounds s;
+    s.L0 = cb.L0 + off; s.L1 = cb.L1 + off;                     // rounding is monotone: still bounds
+    s.a0 = cb.a0 + off; s.a1 = cb.a1 + off;
+    s.b0 = cb.b0 + off; s.b1 = cb.b1 + off;
+    float ma, Ma, mb, Mb;
+    abs_range(s.a0, s.a1, 0.0f, ma, Ma);
+    abs_range(s.b0, s.b1, 0.0f, mb, Mb);
+    s.C0 = chroma(ma, mb);                                      // sqrtf(a*a + b*b) is monotone in |a|, |b|
+    s.C1 = chroma(Ma, Mb);
+    const PixelTerms lo = pixel_terms_c(0.0f, 0.0f, 0.0f, s.C0), hi = pixel_terms_c(0.0f, 0.0f, 0.0f, s.C1);
+    s.wC0 = hi.wC; s.wC1 = lo.wC;                               // the weights decrease with C
+    s.wH0 = hi.wH; s.wH1 = lo.wH;
+    s.pad[0] = s.pad[1] = s.pad[2] = s.pad[3] = 0.0f;
+    return s;
+}
+
+// masks[(cell * 16 + bayer) * words + w]; one wave per cell, lanes strided over the centroids.
+// Lane i < 16 derives the shifted bounds of Bayer index i once; they reach the wave through readlane.
+__device__ __forceinline__ float lane_value(float v, uint32_t src)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int)src));
+}
+
+__global__ __launch_bounds__(kBlock) void k_offset_candidates(const CellBounds *__restrict__ bounds,
+                                                              const Centroid *__restrict__ cent, uint32_t k,
+                                                              float threshold, uint64_t *__restrict__ masks)
+{
+    const uint32_t cell = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t words = (k + 63u) / 64u;
+    const CellBounds cb = bounds[cell];
+    const float my_off = threshold * (bayer16(lane & 15u) / 16.0f - 0.5f);   // as k_apply computes it
+    const CellBounds mine = shifted_bounds(cb, my_off);
+    Centroid c[4];
+#pragma unroll
+    for (uint32_t w = 0; w < 4u; ++w) {
+        const uint32_t j = w * 64 + lane;
+        c[w] = cent[j < k ? j : 0u];
+    }
+    for (uint32_t bi = 0; bi < 16u; ++bi) {
+        CellBounds sb;
+        sb.L0 = lane_value(mine.L0, bi); sb.L1 = lane_value(mine.L1, bi);
+        sb.a0 = lane_value(mine.a0, bi); sb.a1 = lane_value(mine.a1, bi);
+        sb.b0 = lane_value(mine.b0, bi); sb.b1 = lane_value(mine.b1, bi);
+        sb.C0 = lane_value(mine.C0, bi); sb.C1 = lane_value(mine.C1, bi);
+        sb.wC0 = lane_value(mine.wC0, bi); sb.wC1 = lane_value(mine.wC1, bi);
+        sb.wH0 = lane_value(mine.wH0, bi); sb.wH1 = lane_value(mine.wH1, bi);
+        uint64_t *out = masks + ((uint64_t)cell * 16u + bi) * words;
+        float U = 3.0e38f;
+        if (words <= 4u) {
+            // k <= 256: one evaluation per centroid, the lower bounds wait in registers for U
+            float lo[4];
+#pragma unroll
+            for (uint32_t w = 0; w < 4u; ++w) {
+                lo[w] = 0.0f;
+                if (w < words) {
+                    const KeyRange r = key_range(sb, c[w].L, c[w].a, c[w].b, c[w].C);
+                    lo[w] = r.lo;
+                    if (w * 64 + lane < k) U = fminf(U, r.hi);
+                }
+            }
+            for (int o = 32; o > 0; o >>= 1) U = fminf(U, __shfl_xor(U, o, 64));
+#pragma unroll
+            for (uint32_t w = 0; w < 4u; ++w) {
+                const unsigned long long m = __ballot(w * 64 + lane < k && lo[w] <= U);
+                if (w < words && lane == 0) out[w] = m;
+            }
+            continue;
+        }
+        for (uint32_t j = lane; j < k; j += 64) {
+            const Centroid ce = cent[j];
+            U = fminf(U, key_range(sb, ce.L, ce.a, ce.b, ce.C).hi);
+        }
+        for (int o = 32; o > 0; o >>= 1) U = fminf(U, __shfl_xor(U, o, 64));
+        for (uint32_t w = 0; w < words; ++w) {
+            const uint32_t j = w * 64 + lane;
+            bool keep = false;
+            if (j < k) {
+                const Centroid ce = cent[j];
+                keep = key_range(sb, ce.L, ce.a, ce.b, ce.C).lo <= U;
+            }
+            const unsigned long long m = __ballot(keep);
+            if (lane == 0) out[w] = m;
+        }
+    }
+}
+
+hipError_t launch_offset_candidates(const CellBounds *bounds, const Centroid *cent, uint32_t k, float threshold,
+                                    uint64_t *masks, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_offset_candidates, dim3(kCells / (kBlock / 64)), dim3(kBlock), 0, st, bounds, cent, k,
+                       threshold, masks);
+    return hipGetLastError();
+}
+
+// out[i] = pal[arg-min over the candidates of (cell, Bayer index) of the key of Lab(pixel) + off];
+// the running minimum starts at the sentinel's distance with index k (mix_colors.wgsl:73-80)
+template <bool ONE_WORD>
+__global__ __launch_bounds__(kBlock) void k_dither_pruned(const uint32_t *__restrict__ rgba, uint32_t w, uint64_t n,
+                                                          uint32_t row0, const Centroid *__restrict__ cent, uint32_t k,
+                                                          const float *__restrict__ lut, const uint32_t *__restrict__ pal,
+                                                          float threshold, const uint64_t *__restrict__ masks,
+                                                          uint32_t *__restrict__ out, int aligned)
+{
+    extern __shared__ float4 smem4[];
+    const uint32_t kpad = (k + 3u) & ~3u;
+    float4 *s_cent = smem4;
+    float *s_lut = reinterpret_cast<float *>(smem4 + kpad);
+    float *s_off = s_lut + 256;
+    s_lut[threadIdx.x] = lut[threadIdx.x];
+    stage_centroids(s_cent, cent, k, kpad);
+    if (threadIdx.x < 16) s_off[threadIdx.x] = threshold * (bayer16(threadIdx.x) / 16.0f - 0.5f);
+    __syncthreads();
+    const uint32_t words = (k + 63u) / 64u;
+    const float sentinel_C = chroma(10000.0f, 10000.0f);
+
+    constexpr uint64_t TILE = (uint64_t)kBlock * 4;
+    const uint64_t tiles = (n + TILE - 1) / TILE;
+    for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const uint64_t i0 = tile * TILE + (uint64_t)threadIdx.x * 4;
+        uint32_t px[4];
+        load4_stream(rgba, i0, n, aligned != 0, px);
+        const uint32_t i32 = (uint32_t)i0;                          // n < 2^32
+        uint32_t gy = i32 / w, gx = i32 - gy * w;
+        gy += row0;
+        uint32_t slot[4];
+        unsigned long long m0[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t bi = (gx & 3u) + ((gy & 3u) << 2);
+            const uint32_t cell = (((px[q] >> 3) & 31u) << 10) | (((px[q] >> 11) & 31u) << 5) | ((px[q] >> 19) & 31u);
+            slot[q] = cell * 16u + bi;
+            m0[q] = masks[(uint64_t)slot[q] * words];              // gathers in flight during the Lab conversion
+            gx += 1;
+            if (gx == w) { gx = 0; gy += 1; }
+        }
+        uint32_t res[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float L, a, b;
+            px_to_lab(s_lut, px[q], L, a, b);
+            const float off = s_off[slot[q] & 15u];
+            L = L + off; a = a + off; b = b + off;                   // mix_colors.wgsl:72
+            const PixelTerms pt = pixel_terms(L, a, b);
+            float best = cie94_key(pt, 10000.0f, 10000.0f, 10000.0f, sentinel_C);
+            uint32_t idx = k;
+            unsigned long long m = m0[q];
+            for (uint32_t wd = 0;;) {
+                while (m) {
+                    const uint32_t j = wd * 64 + (uint32_t)__builtin_ctzll(m);
+                    m &= m - 1;
+                    const float4 c = s_cent[j];
+                    const float d = cie94_key(pt, c.x, c.y, c.z, c.w);
+                    if (d < best) { best = d; idx = j; }
+                }
+                if (ONE_WORD || ++wd >= words) break;
+                m = masks[(uint64_t)slot[q] * words + wd];
+            }
+            res[q] = pal[idx];
+        }
+        store4_stream(out, i0, n, aligned != 0, res);
+    }
+}
+
+hipError_t launch_dither_pruned(const uint32_t *rgba, uint32_t w, uint32_t rows, uint32_t row0, const Centroid *cent,
+                                uint32_t k, const float *lut, const uint32_t *pal, float threshold,
+                                const uint64_t *masks, uint32_t *out, hipStream_t st)
+{
+    const uint64_t n = (uint64_t)w * rows;
+    const uint64_t tiles = (n + kBlock * 4 - 1) / (kBlock * 4);
+    const uint32_t grid = (uint32_t)(tiles < 8192 ? (tiles ? tiles : 1) : 8192);
+    const uint32_t kpad = (k + 3u) & ~3u;
+    const size_t lds = sizeof(float4) * kpad + (256 + 16) * sizeof(float);
+    const int aligned = ((reinterpret_cast<uintptr_t>(rgba) & 15u) == 0 &&
+                         (reinterpret_cast<uintptr_t>(out) & 15u) == 0) ? 1 : 0;
+    if (k <= 64)
+        hipLaunchKernelGGL(k_dither_pruned<true>, dim3(grid), dim3(kBlock), lds, st, rgba, w, n, row0, cent, k, lut,
+                           pal, threshold, masks, out, aligned);
+    else
+        hipLaunchKernelGGL(k_dither_pruned<false>, dim3(grid), dim3(kBlock), lds, st, rgba, w, n, row0, cent, k, lut,
+                           pal, threshold, masks, out, aligned);
+    return hipGetLastError();
+}
+
+// test support: violations += #(colour, Bayer index) whose brute-force dither arg-min (sentinel
+// included) differs from the arg-min over the candidates of its (cell, Bayer index)
+__global__ __launch_bounds__(kBlock) void k_check_offset_masks(const Centroid *__restrict__ cent, uint32_t k,
+                                                               const uint64_t *__restrict__ masks,
+                                                               const float *__restrict__ lut, float threshold,
+                                                               unsigned long long *__restrict__ violations)
+{
+    __shared__ float s_lut[256];
+    s_lut[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    const uint32_t cell = blockIdx.x;
+    const uint32_t words = (k + 63u) / 64u;
+    const float sentinel_C = chroma(10000.0f, 10000.0f);
+    unsigned long long bad = 0;
+    for (uint32_t c = threadIdx.x; c < kCellColours; c += kBlock) {
+        float L0, a0, b0;
+        colour_to_lab(s_lut, cell * kCellColours + c, L0, a0, b0);
+        for (uint32_t bi = 0; bi < 16u; ++bi) {
+            const float off = threshold * (bayer16(bi) / 16.0f - 0.5f);
+            const PixelTerms pt = pixel_terms(L0 + off, a0 + off, b0 + off);
+            const float start = cie94_key(pt, 10000.0f, 10000.0f, 10000.0f, sentinel_C);
+            float best = start, bestp = start;
+            uint32_t idx = k, idxp = k;
+            for (uint32_t j = 0; j < k; ++j) {
+                const Centroid ce = cent[j];
+                const float d = cie94_key(pt, ce.L, ce.a, ce.b, ce.C);
+                if (d < best) { best = d; idx = j; }
+                const unsigned long long m = masks[((uint64_t)cell * 16u + bi) * words + j / 64u];
+                if (((m >> (j & 63u)) & 1ull) && d < bestp) { bestp = d; idxp = j; }
+            }
+            bad += idx != idxp;
+        }
+    }
+    if (bad) atomicAdd(violations, bad);
+}
+
+hipError_t launch_check_offset_masks(const Centroid *cent, uint32_t k, const uint64_t *masks, const float *lut,
+                                     float threshold, unsigned long long *violations, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_check_offset_masks, dim3(kCells), dim3(kBlock), 0, st, cent, k, masks, lut, threshold, violations);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // test support: exhaustive check of the bounds and of the candidate masks over all 2^24 colours
 // violations[0] += #(colour, centroid) pairs with key outside [lo, hi]
 // violations[1] += #colours whose brute-force arg-min is not in the cell's mask

@@ -433,3 +433,40 @@ def test_table_tiny_and_flat_images(torch_cuda, processor, oracle, n, k):
         want_c, _ = oracle.finalize(wa, cent)
         assert np.array_equal(s.get_centroids(st).view(np.uint32), want_c.view(np.uint32))
         s.close()
+
+
+def test_dither_masks_conservative_for_all_colours(torch_cuda, processor, oracle):
+    """pruned dither pass: over all 2^24 colours x 16 Bayer offsets the arg-min over the candidates of the
+    pixel's (cell, Bayer index) equals the brute-force arg-min (sentinel start included)"""
+    rng = np.random.default_rng(12)
+    for name, cent in _centroid_sets(oracle, rng).items():
+        if cent.shape[0] < 2:
+            continue
+        assert processor.debug_check_dither_masks(cent, _stream(torch_cuda)) == 0, name
+
+
+@pytest.mark.parametrize("k", [2, 3, 46, 64, 65, 300])
+def test_dither_output_pass_pruned_equals_scan(torch_cuda, oracle, monkeypatch, k):
+    """find / reduce in dither mode: candidate-pruned pass (forced) == scan of all centroids == oracle,
+    for a whole image and for a row band that starts at an odd image row"""
+    import kmeans_gpu_amd as kg
+    torch = torch_cuda
+    w, h = 1001, 700
+    img = _blobs(np.random.default_rng(100 + k), w * h, 25, sigma=25.0).reshape(h, w, 4)
+    pal = np.array(sorted(set(map(tuple, oracle.synth_uniform(k + 9, k)))), np.uint8)
+    cent = kg.palette_to_centroids(pal)
+    d = _dev(torch, img.reshape(-1, 4))
+    st = _stream(torch)
+    want = oracle.find(img, pal, oracle.MODE_DITHER)
+    r0, r1 = 333, 512
+    for strategy in ("brute", "table"):
+        monkeypatch.setenv("KMG_STRATEGY", strategy)
+        p = kg.ImageProcessor()
+        out = torch.zeros((w * h, 4), dtype=torch.uint8, device="cuda")
+        p.apply(d.data_ptr(), w, h, 0, cent, kg.ReduceMode.Dither, out.data_ptr(), st)
+        band = torch.zeros(((r1 - r0) * w, 4), dtype=torch.uint8, device="cuda")
+        p.apply(d.data_ptr() + 4 * r0 * w, w, r1 - r0, r0, cent, kg.ReduceMode.Dither, band.data_ptr(), st)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().reshape(h, w, 4), want), strategy
+        assert np.array_equal(band.cpu().numpy().reshape(r1 - r0, w, 4), want[r0:r1]), strategy
+        p.close()
