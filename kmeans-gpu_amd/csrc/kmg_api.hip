@@ -114,6 +114,12 @@ struct ColourTable {
     bool tables_valid = false;       // label tables describe the CURRENT centroid table
     void *d_colour_labels = nullptr; // 2^24 x u8 (k <= 256) or u16
     uint16_t *d_sub = nullptr;       // kSubCells 4x4x4 summaries (u16), kCells 8x8x8 summaries (u16), kCells pair entries (u32)
+    // farthest-point init over the colours (built on demand by the init entry points)
+    uint32_t *d_tie = nullptr;       // 2^24: 1 + largest low half of the init key per colour, 0 = unoccupied
+    float *d_cdist = nullptr;        // 2^24 running min-distance per colour
+    unsigned long long *d_cell_key = nullptr;   // kCells: largest init key of each cell's colours
+    bool tie_valid = false;          // d_tie describes (rgba, n, tie_first)
+    uint64_t tie_first = 0;
 };
 
 struct kmg_lloyd {
@@ -127,6 +133,7 @@ struct kmg_lloyd {
     float *d_dist;               // init distance map, grown on demand
     uint64_t dist_cap;
     uint32_t last_rows;          // rows of d_partials written by the last assign pass
+    bool init_colours;           // the running sharded init (kmg_lloyd_init_step) walks colours, not pixels
     ColourTable tab;
     uint32_t prof;               // per-launch HIP-event timing: bit i = time kernel id i (kmg_lloyd_profile)
     std::vector<ProfEvent> events;
@@ -292,6 +299,9 @@ static void free_table(ColourTable &t)
     if (t.d_work) (void)hipFree(t.d_work);
     if (t.d_colour_labels) (void)hipFree(t.d_colour_labels);
     if (t.d_sub) (void)hipFree(t.d_sub);
+    if (t.d_tie) (void)hipFree(t.d_tie);
+    if (t.d_cdist) (void)hipFree(t.d_cdist);
+    if (t.d_cell_key) (void)hipFree(t.d_cell_key);
     t = ColourTable();
 }
 
@@ -383,6 +393,7 @@ extern "C" int kmg_lloyd_bind_image(kmg_lloyd *s, const uint8_t *d_rgba, uint64_
     }
     t.rgba = nullptr;
     t.tables_valid = false;
+    t.tie_valid = false;
     // entries of cells no pixel falls into are never read by the label pass; 0xFF.. = "empty"
     HIP_TRY(hipMemsetAsync(t.d_sub, 0xFF, sizeof(uint16_t) * (kSubCells + kCells) + sizeof(uint32_t) * kCells, S(stream)));
     HIP_TRY(hipMemsetAsync(t.d_hist, 0, sizeof(uint32_t) << 24, S(stream)));
@@ -601,7 +612,7 @@ extern "C" int kmg_lloyd_create(kmg_processor *p, uint32_t k, kmg_lloyd **out)
     s->p = p;
     s->k = k;
     s->d_cent = nullptr; s->d_partials = nullptr; s->d_acc = nullptr; s->d_nconv = nullptr;
-    s->d_key = nullptr; s->d_dist = nullptr; s->dist_cap = 0; s->last_rows = 0; s->prof = 0;
+    s->d_key = nullptr; s->d_dist = nullptr; s->dist_cap = 0; s->last_rows = 0; s->prof = 0; s->init_colours = false;
     hipError_t e = hipMalloc((void **)&s->d_cent, sizeof(Centroid) * k);
     if (e == hipSuccess) e = hipMemset(s->d_cent, 0, sizeof(Centroid) * k);   // structures.rs:501-521
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_partials, sizeof(int64_t) * 4ull * k * 2048ull);
@@ -661,6 +672,53 @@ extern "C" int kmg_lloyd_get_centroids(kmg_lloyd *s, float *c4, void *stream)
     return KMG_OK;
 }
 
+// Farthest-point init: k - 1 passes over the pixels (n * 7.0e-12 s each: sRGB->Lab + literal CIE94 per
+// pixel) or over the image's colours (1.1e-4 s for a pass that reaches every cell -- the first ~20 --
+// falling to ~4e-5 s once most cells are skipped; one-off 2.5e-4 + n * 3.7e-11 s for the tie keys, and
+// 2.5e-4 + n * 4.1e-11 s for the histogram if the image is not bound yet); MI355X, tools/cfg3_probe.py.
+static bool init_table_pays(uint64_t n, uint32_t k, bool bound)
+{
+    if (const char *e = getenv("KMG_STRATEGY")) {
+        if (!strcmp(e, "brute")) return false;
+        if (!strcmp(e, "table")) return true;
+    }
+    const double N = (double)n, passes = (double)(k - 1);
+    const double pixels = passes * N * 7.0e-12;
+    const double colours = passes * 4.5e-5 + (passes < 20.0 ? passes : 20.0) * 7.0e-5 + 2.5e-4 + N * 3.7e-11 +
+                           (bound ? 0.0 : 2.5e-4 + N * 4.1e-11);
+    return colours < pixels;
+}
+
+// decides the init strategy for (d_rgba, n, first_index) and, for the colour strategy, makes sure the
+// image is bound and its tie keys and per-colour distance map exist
+static int init_over_colours(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint64_t first_index, bool *colours,
+                             void *stream)
+{
+    *colours = false;
+    const bool bound = s->tab.rgba != nullptr && s->tab.rgba == d_rgba && s->tab.n == n;
+    if (first_index + n > 0xFFFFFFF0ull || !init_table_pays(n, s->k, bound)) return KMG_OK;
+    int rc;
+    if (!bound && (rc = kmg_lloyd_bind_image(s, d_rgba, n, stream)) != KMG_OK) return rc;
+    ColourTable &t = s->tab;
+    if (!t.d_tie) {
+        hipError_t e = hipMalloc((void **)&t.d_tie, sizeof(uint32_t) << 24);
+        if (e == hipSuccess) e = hipMalloc((void **)&t.d_cdist, sizeof(float) << 24);
+        if (e == hipSuccess) e = hipMalloc((void **)&t.d_cell_key, sizeof(unsigned long long) * kCells);
+        if (e != hipSuccess)
+            return fail(e == hipErrorOutOfMemory ? KMG_ERR_OUT_OF_MEMORY : KMG_ERR_HIP, "init tables allocation failed: %s", hipGetErrorString(e));
+        t.tie_valid = false;
+    }
+    if (!t.tie_valid || t.tie_first != first_index) {
+        HIP_TRY(hipMemsetAsync(t.d_tie, 0, sizeof(uint32_t) << 24, S(stream)));
+        HIP_TRY(hipMemsetAsync(t.d_cell_key, 0, sizeof(unsigned long long) * kCells, S(stream)));
+        HIP_TRY(launch_tie_keys((const uint32_t *)d_rgba, n, first_index, t.d_tie, S(stream)));
+        t.tie_valid = true;
+        t.tie_first = first_index;
+    }
+    *colours = true;
+    return KMG_OK;
+}
+
 extern "C" int kmg_lloyd_init_centroids(kmg_lloyd *s, const uint8_t *d_rgba, uint32_t w, uint32_t h, void *stream)
 {
     if (!s || !d_rgba || !w || !h) return fail(KMG_ERR_INVALID_ARGUMENT, "bad init_centroids arguments");
@@ -675,14 +733,22 @@ extern "C" int kmg_lloyd_init_centroids(kmg_lloyd *s, const uint8_t *d_rgba, uin
     const uint32_t *rgba = (const uint32_t *)d_rgba;
     HIP_TRY(launch_init_first(rgba, i0, s->p->d_lut, s->d_cent, s->d_key, S(stream)));
     if (s->k > 1) {
-        if (s->dist_cap < n) {
+        int rc;
+        bool colours = false;
+        if ((rc = init_over_colours(s, d_rgba, n, 0, &colours, stream)) != KMG_OK) return rc;
+        if (!colours && s->dist_cap < n) {
             if (s->d_dist) { HIP_TRY(hipStreamSynchronize(S(stream))); HIP_TRY(hipFree(s->d_dist)); s->d_dist = nullptr; s->dist_cap = 0; }
             HIP_TRY(hipMalloc((void **)&s->d_dist, sizeof(float) * n));
             s->dist_cap = n;
         }
         for (uint32_t j = 1; j < s->k; ++j) {   // modules.rs:1211-1246
-            HIP_TRY(launch_init_pass(rgba, n, s->p->d_lut, s->d_cent, j, s->d_dist, s->d_key, 0, S(stream)));
-            HIP_TRY(launch_init_pick(rgba, s->p->d_lut, s->d_key, s->d_cent, j, S(stream)));
+            if (colours) {
+                HIP_TRY(launch_init_pass_cells(s->tab.d_work, s->tab.d_tie, s->p->d_lab_table, s->p->d_bounds, s->d_cent, j,
+                                               s->tab.d_cdist, s->tab.d_cell_key, s->d_key, rgba, s->p->d_lut, S(stream)));
+            } else {
+                HIP_TRY(launch_init_pass(rgba, n, s->p->d_lut, s->d_cent, j, s->d_dist, s->d_key, 0, S(stream)));
+                HIP_TRY(launch_init_pick(rgba, s->p->d_lut, s->d_key, s->d_cent, j, S(stream)));
+            }
         }
     }
     return KMG_OK;
@@ -703,6 +769,18 @@ extern "C" int kmg_lloyd_init_step(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t
     s->tab.tables_valid = false;
     HIP_TRY(hipMemsetAsync(d_key, 0, sizeof(uint64_t), S(stream)));
     if (n_local == 0) return KMG_OK;
+    if (j == 1) {
+        int rc;
+        if ((rc = init_over_colours(s, d_rgba, n_local, first_index, &s->init_colours, stream)) != KMG_OK) return rc;
+    }
+    if (s->init_colours) {
+        const ColourTable &t = s->tab;
+        if (t.rgba != d_rgba || t.n != n_local || !t.tie_valid || t.tie_first != first_index)
+            return fail(KMG_ERR_INVALID_ARGUMENT, "init_step: the band changed since step j = 1");
+        HIP_TRY(launch_init_pass_cells(t.d_work, t.d_tie, s->p->d_lab_table, s->p->d_bounds, s->d_cent, j, t.d_cdist, t.d_cell_key,
+                                       (unsigned long long *)d_key, nullptr, nullptr, S(stream)));
+        return KMG_OK;
+    }
     if (s->dist_cap < n_local) {
         if (j != 1) return fail(KMG_ERR_INVALID_ARGUMENT, "init_step: the distance map of this band was never started (j = 1)");
         if (s->d_dist) { HIP_TRY(hipStreamSynchronize(S(stream))); HIP_TRY(hipFree(s->d_dist)); s->d_dist = nullptr; s->dist_cap = 0; }

@@ -112,6 +112,17 @@ hipError_t launch_cell_bounds(const float *lut, CellBounds *bounds, float4 *lab_
 hipError_t launch_histogram(const uint32_t *rgba, uint64_t n, uint32_t *hist, hipStream_t st);
 // once per image: agg[kCells][4] = (sum qL, sum qa, sum qb, count) of the image's pixels per cell
 hipError_t launch_cell_aggregates(const uint32_t *hist, const float4 *lab_table, int64_t *agg, hipStream_t st);
+// farthest-point initialisation over the colours of a large image: tie[2^24] (zero on entry) = 1 + the
+// largest low half of the init key among the pixels of each colour (first_index = image-wide index of
+// rgba[0], first_index + n <= 0xFFFFFFF0).  One pass = running min-distance per colour for the cells the
+// new centroid can reach (work: the bound image's occupied cells; cell_key[kCells], zero before the first
+// pass, caches each cell's largest key) + key = the largest cell key; with pick_rgba != NULL centroid j is
+// set to the Lab of the pixel the key names (plus_plus_init.wgsl:172-181) in the same launch.
+hipError_t launch_tie_keys(const uint32_t *rgba, uint64_t n, uint64_t first_index, uint32_t *tie, hipStream_t st);
+hipError_t launch_init_pass_cells(const uint32_t *work, const uint32_t *tie, const float4 *lab_table,
+                                  const CellBounds *bounds, Centroid *cent, uint32_t j, float *dist,
+                                  unsigned long long *cell_key, unsigned long long *key,
+                                  const uint32_t *pick_rgba, const float *lut, hipStream_t st);
 // per iteration
 hipError_t launch_cell_candidates(const CellBounds *bounds, const int64_t *agg, const Centroid *cent,
                                   uint32_t k, uint64_t *masks, hipStream_t st);

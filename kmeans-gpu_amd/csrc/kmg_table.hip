@@ -149,6 +149,176 @@ hipError_t launch_histogram(const uint32_t *rgba, uint64_t n, uint32_t *hist, hi
 }
 
 // ------------------------------------------------------------------------------------------
+// Farthest-point initialisation over the image's colours (plus_plus_init.wgsl, kmeans++_calc_diff.wgsl)
+//
+// All pixels of one colour share their distance to the chosen centroids, so the arg-max key of
+// kmg_kernels.hip -- [distance bits:32][index / 16:28][15 - index % 16:4] -- is maximised per
+// colour by the pixel with the largest low half.  tie[colour] = 1 + that largest low half (0 = no
+// pixel has this colour), built once per image; a pass then walks the 2^24 colours (28 B each:
+// tie, running distance, Lab from the static table) instead of the pixels (sRGB->Lab + 12 B each).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_tie_keys(const uint32_t *__restrict__ rgba, uint64_t n,
+                                                     uint64_t first_index, uint32_t *__restrict__ tie, int aligned)
+{
+    constexpr uint64_t TILE = (uint64_t)kBlock * 8;
+    const uint64_t tiles = (n + TILE - 1) / TILE;
+    for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const uint64_t i0 = tile * TILE + (uint64_t)g * (kBlock * 4) + (uint64_t)threadIdx.x * 4;
+            uint32_t px[4];
+            load4(rgba, i0, n, aligned != 0, px);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (i0 + q < n) {
+                    const uint64_t gi = first_index + i0 + q;
+                    const uint32_t low = ((uint32_t)(gi >> 4) << 4) | (15u - (uint32_t)(gi & 15u));
+                    atomicMax(tie + colour_index(px[q]), low + 1u);
+                }
+            }
+        }
+    }
+}
+
+hipError_t launch_tie_keys(const uint32_t *rgba, uint64_t n, uint64_t first_index, uint32_t *tie, hipStream_t st)
+{
+    const uint64_t tiles = (n + kBlock * 8 - 1) / (kBlock * 8);
+    const uint32_t grid = (uint32_t)(tiles < 4096 ? (tiles ? tiles : 1) : 4096);
+    const int aligned = (reinterpret_cast<uintptr_t>(rgba) & 15u) == 0 ? 1 : 0;
+    hipLaunchKernelGGL(k_tie_keys, dim3(grid), dim3(kBlock), 0, st, rgba, n, first_index, tie, aligned);
+    return hipGetLastError();
+}
+
+// A float lower bound of cie94(pixel, centroid) (kmg_math.h, literal form, weights from the pixel) over
+// every colour of a cell: the same operations on the interval end points that minimise each term
+// (every operation is monotone, so no colour of the cell can come out lower).
+__device__ __forceinline__ float cie94_lower_bound(const CellBounds &cb, float L2, float a2, float b2, float C2)
+{
+    float mL, ML, ma, Ma, mb, Mb, mC, MC;
+    abs_range(cb.L0, cb.L1, L2, mL, ML);
+    abs_range(cb.a0, cb.a1, a2, ma, Ma);
+    abs_range(cb.b0, cb.b1, b2, mb, Mb);
+    abs_range(cb.C0, cb.C1, C2, mC, MC);
+    const float SC = 1.0f + 0.045f * cb.C1, SH = 1.0f + 0.015f * cb.C1;      // the largest divisors
+    const float dH = sqrtf(fmaxf((ma * ma) + (mb * mb) - (MC * MC), 0.0f));
+    const float tL = mL / 1.0f, tC = mC / SC, tH = dH / SH;
+    return sqrtf(tL * tL + tC * tC + tH * tH);
+}
+
+// One init pass, one wave per occupied cell.  cell_key[cell] caches the largest key of the cell's
+// colours; a new centroid can only lower the running distances, and it cannot lower any distance of a
+// cell whose lower bound to it is not below the cell's largest running distance -- such a cell (most of
+// them once a few dozen centroids exist) is skipped and its cached key stays valid.  A wave owns up to
+// four cells per round and tests them together (lanes 0..3) before it works on the ones it must visit.
+__global__ __launch_bounds__(kBlock) void k_init_pass_cells(const uint32_t *__restrict__ work,
+                                                            const uint32_t *__restrict__ tie,
+                                                            const float4 *__restrict__ lab_table,
+                                                            const CellBounds *__restrict__ bounds,
+                                                            const Centroid *__restrict__ cent, uint32_t j,
+                                                            float *__restrict__ dist,
+                                                            unsigned long long *__restrict__ cell_key)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * (kBlock / 64);
+    const Centroid c = cent[j - 1];
+    const uint32_t n_work = __builtin_amdgcn_readfirstlane(work[0]);
+    for (uint32_t w0 = wave; w0 < n_work; w0 += 4u * n_waves) {
+        const uint32_t wi = w0 + (lane & 3u) * n_waves;
+        uint32_t my_cell = 0;
+        bool reached = false;
+        if (lane < 4u && wi < n_work) {
+            my_cell = work[1u + wi];
+            reached = true;
+            if (j != 1) {
+                const float cell_max = __uint_as_float((uint32_t)(cell_key[my_cell] >> 32));
+                reached = cie94_lower_bound(bounds[my_cell], c.L, c.a, c.b, c.C) < cell_max;
+            }
+        }
+        unsigned long long todo = __ballot(reached);
+        while (todo) {
+            const uint32_t src = (uint32_t)__builtin_ctzll(todo);
+            todo &= todo - 1;
+            const uint32_t cell = (uint32_t)__builtin_amdgcn_readlane((int)my_cell, (int)src);
+            const uint32_t base = cell * kCellColours + lane * 8;
+            const uint4 t0 = *reinterpret_cast<const uint4 *>(tie + base), t1 = *reinterpret_cast<const uint4 *>(tie + base + 4);
+            float4 d0 = make_float4(1000000.0f, 1000000.0f, 1000000.0f, 1000000.0f), d1 = d0;   // kmeans++_calc_diff.wgsl:26-30
+            if (j != 1) {
+                d0 = *reinterpret_cast<const float4 *>(dist + base);
+                d1 = *reinterpret_cast<const float4 *>(dist + base + 4);
+            }
+            const uint32_t t[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+            float m[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+            unsigned long long best = 0ull;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (t[q]) {
+                    const float4 v = lab_table[base + q];
+                    m[q] = fminf(m[q], cie94(v.x, v.y, v.z, c.L, c.a, c.b));
+                    const unsigned long long kk = ((unsigned long long)float_to_bits(m[q]) << 32) | (unsigned long long)(t[q] - 1u);
+                    best = kk > best ? kk : best;
+                }
+            }
+            *reinterpret_cast<float4 *>(dist + base) = make_float4(m[0], m[1], m[2], m[3]);
+            *reinterpret_cast<float4 *>(dist + base + 4) = make_float4(m[4], m[5], m[6], m[7]);
+            for (int off = 32; off > 0; off >>= 1) {
+                const unsigned long long o = __shfl_xor(best, off, 64);
+                best = o > best ? o : best;
+            }
+            if (lane == 0) cell_key[cell] = best;
+        }
+    }
+}
+
+// key = max over the cells' cached keys (one workgroup); with rgba != NULL also plus_plus_init.wgsl:172-181
+// `pick`: centroid j = Lab of the pixel the key names
+__global__ __launch_bounds__(1024) void k_init_reduce_cells(const unsigned long long *__restrict__ cell_key,
+                                                            unsigned long long *__restrict__ key,
+                                                            const uint32_t *__restrict__ rgba,
+                                                            const float *__restrict__ lut,
+                                                            Centroid *__restrict__ cent, uint32_t j)
+{
+    __shared__ unsigned long long s_key[16];
+    unsigned long long best = 0ull;
+    for (uint32_t i = threadIdx.x; i < kCells; i += 1024) {
+        const unsigned long long v = cell_key[i];
+        best = v > best ? v : best;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(best, off, 64);
+        best = o > best ? o : best;
+    }
+    if ((threadIdx.x & 63) == 0) s_key[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) best = s_key[w] > best ? s_key[w] : best;
+        *key = best;
+        if (rgba) {
+            uint32_t index = 0;                                   // Candidate(0, 0.0) when every distance is 0
+            if ((best >> 32) != 0ull) {
+                const uint32_t low = (uint32_t)best;
+                index = (low & ~15u) | (15u - (low & 15u));
+            }
+            const uint32_t px = rgba[index];
+            float L, a, b;
+            linear100_to_lab(lut[px & 255u], lut[(px >> 8) & 255u], lut[(px >> 16) & 255u], L, a, b);
+            Centroid c; c.L = L; c.a = a; c.b = b; c.C = chroma(a, b);
+            cent[j] = c;
+        }
+    }
+}
+
+hipError_t launch_init_pass_cells(const uint32_t *work, const uint32_t *tie, const float4 *lab_table,
+                                  const CellBounds *bounds, Centroid *cent, uint32_t j, float *dist,
+                                  unsigned long long *cell_key, unsigned long long *key,
+                                  const uint32_t *pick_rgba, const float *lut, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_init_pass_cells, dim3(2048), dim3(kBlock), 0, st, work, tie, lab_table, bounds, cent, j, dist, cell_key);
+    hipLaunchKernelGGL(k_init_reduce_cells, dim3(1), dim3(1024), 0, st, cell_key, key, pick_rgba, lut, cent, j);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // per-cell sums of the image (once per image): one wave per cell, 8 colours per lane
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_cell_aggregates(const uint32_t *__restrict__ hist,

@@ -363,14 +363,17 @@ def test_batch_of_images_on_one_gpu(torch_cuda, processor, oracle):
     p.close()
 
 
+@pytest.mark.parametrize("strategy", ["brute", "table"])
 @pytest.mark.parametrize("w,h,k,bands", [(256, 171, 8, 2), (67, 41, 6, 3), (300, 200, 33, 4)])
-def test_sharded_init_steps_equal_unsharded_init(torch_cuda, processor, oracle, tokyo, w, h, k, bands):
+def test_sharded_init_steps_equal_unsharded_init(torch_cuda, processor, oracle, tokyo, monkeypatch, w, h, k, bands, strategy):
     """the band-wise init (local pass + MAX of keys + SUM of {colour, 1}) with the real kernels, the two
-    collectives emulated on one GPU, equals the unsharded device init and the oracle"""
+    collectives emulated on one GPU, equals the unsharded device init and the oracle -- with the passes
+    over the band's pixels ("brute") and over its colours ("table")"""
     import kmeans_gpu_amd as kg
     from kmeans_gpu_amd.sharded import band_rows
     torch = torch_cuda
     st = _stream(torch)
+    monkeypatch.setenv("KMG_STRATEGY", strategy)
     if (w, h) == (256, 171):
         img = oracle.resize(tokyo, w, h)
     else:
@@ -469,4 +472,39 @@ def test_dither_output_pass_pruned_equals_scan(torch_cuda, oracle, monkeypatch, 
         torch.cuda.synchronize()
         assert np.array_equal(out.cpu().numpy().reshape(h, w, 4), want), strategy
         assert np.array_equal(band.cpu().numpy().reshape(r1 - r0, w, 4), want[r0:r1]), strategy
+        p.close()
+
+
+@pytest.mark.parametrize("kind,w,h,k", [("tokyo", 256, 171, 2), ("tokyo", 256, 171, 33), ("few", 67, 41, 6),
+                                        ("noise", 300, 200, 17), ("noise", 1, 1, 3), ("few", 16, 1, 4)])
+def test_init_over_colours_equals_init_over_pixels(torch_cuda, oracle, tokyo, monkeypatch, kind, w, h, k):
+    """farthest-point init walking the image's colours (forced) == walking its pixels == oracle,
+    including the arg-max tie rule on images with few colours"""
+    import kmeans_gpu_amd as kg
+    torch = torch_cuda
+    st = _stream(torch)
+    rng = np.random.default_rng(w * 7 + k)
+    if kind == "tokyo":
+        img = oracle.resize(tokyo, w, h)
+    elif kind == "few":
+        pal = rng.integers(0, 256, (5, 4), dtype=np.uint8); pal[:, 3] = 255
+        img = pal[rng.integers(0, 5, (h, w))]
+    else:
+        img = oracle.synth_uniform(w * h + k, w * h).reshape(h, w, 4)
+    want = oracle.init_centroids(oracle.rgb_to_lab(img), w, h, k)
+    d = _dev(torch, img.reshape(-1, 4))
+    for strategy in ("brute", "table"):
+        monkeypatch.setenv("KMG_STRATEGY", strategy)
+        p = kg.ImageProcessor(shrink_max_dim=0)
+        s = kg.Lloyd(p, k)
+        s.init_centroids(d.data_ptr(), w, h, st)
+        got = s.get_centroids(st)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), strategy
+        # and the Lloyd loop that follows works from the same bound image
+        labels = torch.zeros(w * h, dtype=torch.int32, device="cuda")
+        s.run(d.data_ptr(), w * h, labels.data_ptr(), st)
+        want_c, want_l, _ = oracle.lloyd(oracle.rgb_to_lab(img), want)
+        assert np.array_equal(s.get_centroids(st).view(np.uint32), want_c.view(np.uint32)), strategy
+        assert np.array_equal(labels.cpu().numpy().view(np.uint32), want_l), strategy
+        s.close()
         p.close()
