@@ -155,7 +155,9 @@ KMG_API int kmg_lloyd_assign_accumulate(kmg_lloyd *s, const uint8_t *d_rgba, uin
  * colours with conservatively pruned candidate sets and materialise labels with one gather pass;
  * labels, sums and centroids are bit-identical to the per-pixel scan.  kmg_lloyd_run binds by
  * itself when its cost model says it pays (env KMG_STRATEGY=brute|table overrides).  The caller
- * must not modify the pixel buffer while it is bound.                                           */
+ * must not modify the pixel buffer while it is bound.  kmg_lloyd_init_centroids / _init_step (j = 1)
+ * start a new problem: they drop any earlier binding of the buffer (and bind it afresh when the
+ * initialisation itself runs over the colour table).                                             */
 KMG_API int kmg_lloyd_bind_image(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n_pixels, void *stream);
 KMG_API int kmg_lloyd_unbind_image(kmg_lloyd *s);
 /* One-time preparation of (d_rgba, n_pixels) for repeated assign passes: applies the library's cost

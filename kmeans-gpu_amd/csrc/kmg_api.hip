@@ -695,10 +695,14 @@ static int init_over_colours(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, ui
                              void *stream)
 {
     *colours = false;
-    const bool bound = s->tab.rgba != nullptr && s->tab.rgba == d_rgba && s->tab.n == n;
-    if (first_index + n > 0xFFFFFFF0ull || !init_table_pays(n, s->k, bound)) return KMG_OK;
+    // an initialisation starts a new problem: the image is (re)bound from the buffer's current contents,
+    // so the loop that follows never works from the histogram of an earlier image in the same buffer
+    if (first_index + n > 0xFFFFFFF0ull || !init_table_pays(n, s->k, false)) {
+        if (s->tab.rgba == d_rgba) s->tab.rgba = nullptr;
+        return KMG_OK;
+    }
     int rc;
-    if (!bound && (rc = kmg_lloyd_bind_image(s, d_rgba, n, stream)) != KMG_OK) return rc;
+    if ((rc = kmg_lloyd_bind_image(s, d_rgba, n, stream)) != KMG_OK) return rc;
     ColourTable &t = s->tab;
     if (!t.d_tie) {
         hipError_t e = hipMalloc((void **)&t.d_tie, sizeof(uint32_t) << 24);

@@ -508,3 +508,28 @@ def test_init_over_colours_equals_init_over_pixels(torch_cuda, oracle, tokyo, mo
         assert np.array_equal(labels.cpu().numpy().view(np.uint32), want_l), strategy
         s.close()
         p.close()
+
+
+def test_buffer_reused_for_a_second_image(torch_cuda, oracle, monkeypatch):
+    """one Lloyd object, one device buffer, two different images in turn (colour table forced): the
+    initialisation re-binds, so the second problem never sees the first image's histogram"""
+    import kmeans_gpu_amd as kg
+    torch = torch_cuda
+    st = _stream(torch)
+    monkeypatch.setenv("KMG_STRATEGY", "table")
+    w, h, k = 160, 90, 7
+    p = kg.ImageProcessor(shrink_max_dim=0)
+    s = kg.Lloyd(p, k)
+    d = torch.zeros((w * h, 4), dtype=torch.uint8, device="cuda")
+    labels = torch.zeros(w * h, dtype=torch.int32, device="cuda")
+    for seed in (1, 2):
+        img = _blobs(np.random.default_rng(seed), w * h, 6, sigma=15.0).reshape(h, w, 4)
+        d.copy_(torch.from_numpy(img.reshape(-1, 4)))
+        s.init_centroids(d.data_ptr(), w, h, st)
+        s.run(d.data_ptr(), w * h, labels.data_ptr(), st)
+        lab = oracle.rgb_to_lab(img)
+        want_c, want_l, _ = oracle.lloyd(lab, oracle.init_centroids(lab, w, h, k))
+        assert np.array_equal(s.get_centroids(st).view(np.uint32), want_c.view(np.uint32)), seed
+        assert np.array_equal(labels.cpu().numpy().view(np.uint32), want_l), seed
+    s.close()
+    p.close()
