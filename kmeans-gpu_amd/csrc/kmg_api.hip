@@ -306,9 +306,9 @@ static void free_table(ColourTable &t)
 }
 
 // Cost model (seconds per iteration on MI355X; constants fitted to tools/strategy_sweep.py, round 1):
-//   per-pixel scan : n * (8.1e-12 + 2.2e-13 k)
-//   colour table   : 1.03e-4 + 2.3e-7 k                      candidates + cube pass (independent of n)
-//                    + n * (1.7e-12 + 6e-15 k)                label pass, k <= 256 (6.6e-12 for u16 labels)
+//   per-pixel scan : 1.4e-5 + n * (7.0e-12 + 2.25e-13 k)
+//   colour table   : 9.0e-5 + 2.7e-7 k                       candidates + cube pass (independent of n)
+//                    + n * (1.7e-12 + 2.3e-15 k)              label pass, k <= 256 (6.7e-12 for u16 labels)
 //                    + (2.5e-4 + n * 4.1e-11) / 16            one-off histogram, spread over ~16 passes
 static bool table_pays(uint64_t n, uint32_t k, bool labels)
 {
@@ -317,9 +317,9 @@ static bool table_pays(uint64_t n, uint32_t k, bool labels)
         if (!strcmp(e, "table")) return true;
     }
     const double N = (double)n;
-    const double brute = N * (8.1e-12 + 2.2e-13 * k);
-    const double label_pass = labels ? N * (k <= 256 ? 1.7e-12 + 6.0e-15 * k : 6.6e-12) : 0.0;
-    const double table = 1.03e-4 + 2.3e-7 * k + label_pass + (2.5e-4 + N * 4.1e-11) / 16.0;
+    const double brute = 1.4e-5 + N * (7.0e-12 + 2.25e-13 * k);
+    const double label_pass = labels ? N * (k <= 256 ? 1.7e-12 + 2.3e-15 * k : 6.7e-12) : 0.0;
+    const double table = 9.0e-5 + 2.7e-7 * k + label_pass + (2.5e-4 + N * 4.1e-11) / 16.0;
     return table < brute;
 }
 
