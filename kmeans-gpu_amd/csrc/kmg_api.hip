@@ -99,6 +99,7 @@ struct kmg_processor {
     std::mutex mu;           // guards the lazily built static tables below
     CellBounds *d_bounds;    // kCells static cell bounds of the colour-table strategy
     float4 *d_lab_table;     // 2^24 x (L, a, b, C): Lab of every colour (256 MiB, built with d_bounds)
+    std::vector<hipStream_t> idle_streams;   // streams of finished host-buffer calls, reused by the next ones (mu)
 };
 
 struct ProfEvent { int id; hipEvent_t e0, e1; };
@@ -134,6 +135,8 @@ struct kmg_lloyd {
     uint64_t dist_cap;
     uint32_t last_rows;          // rows of d_partials written by the last assign pass
     bool init_colours;           // the running sharded init (kmg_lloyd_init_step) walks colours, not pixels
+    bool pooled;                 // workspace came from the stream-ordered pool of `pool_stream` (internal per-call objects)
+    hipStream_t pool_stream;
     ColourTable tab;
     uint32_t prof;               // per-launch HIP-event timing: bit i = time kernel id i (kmg_lloyd_profile)
     std::vector<ProfEvent> events;
@@ -193,6 +196,7 @@ extern "C" void kmg_processor_destroy(kmg_processor *p)
     if (p->d_lut) (void)hipFree(p->d_lut);
     if (p->d_bounds) (void)hipFree(p->d_bounds);
     if (p->d_lab_table) (void)hipFree(p->d_lab_table);
+    for (hipStream_t st : p->idle_streams) (void)hipStreamDestroy(st);
     delete p;
 }
 
@@ -279,9 +283,26 @@ struct StreamBuf {
     hipError_t alloc(size_t bytes, hipStream_t stream) { st = stream; return hipMallocAsync(&ptr, bytes, stream); }
 };
 
+// the private stream of one host-buffer call (every call has its own, so calls on one processor run
+// concurrently, examples/parallel.rs); taken from / returned to the processor's idle list
 struct StreamGuard {
+    kmg_processor *p = nullptr;
     hipStream_t st = nullptr;
-    ~StreamGuard() { if (st) (void)hipStreamDestroy(st); }
+    hipError_t acquire(kmg_processor *proc)
+    {
+        p = proc;
+        {
+            std::lock_guard<std::mutex> lock(p->mu);
+            if (!p->idle_streams.empty()) { st = p->idle_streams.back(); p->idle_streams.pop_back(); return hipSuccess; }
+        }
+        return hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    }
+    ~StreamGuard()
+    {
+        if (!st) return;
+        std::lock_guard<std::mutex> lock(p->mu);
+        p->idle_streams.push_back(st);
+    }
 };
 
 }  // namespace
@@ -600,7 +621,9 @@ static int table_assign(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_
     return KMG_OK;
 }
 
-extern "C" int kmg_lloyd_create(kmg_processor *p, uint32_t k, kmg_lloyd **out)
+// pool_stream != NULL: the small workspace buffers are stream-ordered allocations on that stream (the
+// per-call objects of the host-buffer API, which would otherwise pay ~6 hipMalloc + hipFree per call)
+static int lloyd_create_impl(kmg_processor *p, uint32_t k, kmg_lloyd **out, hipStream_t pool_stream)
 {
     if (!p || !out) return fail(KMG_ERR_INVALID_ARGUMENT, "bad lloyd_create arguments");
     *out = nullptr;
@@ -613,13 +636,21 @@ extern "C" int kmg_lloyd_create(kmg_processor *p, uint32_t k, kmg_lloyd **out)
     s->k = k;
     s->d_cent = nullptr; s->d_partials = nullptr; s->d_acc = nullptr; s->d_nconv = nullptr;
     s->d_key = nullptr; s->d_dist = nullptr; s->dist_cap = 0; s->last_rows = 0; s->prof = 0; s->init_colours = false;
-    hipError_t e = hipMalloc((void **)&s->d_cent, sizeof(Centroid) * k);
-    if (e == hipSuccess) e = hipMemset(s->d_cent, 0, sizeof(Centroid) * k);   // structures.rs:501-521
-    if (e == hipSuccess) e = hipMalloc((void **)&s->d_partials, sizeof(int64_t) * 4ull * k * 2048ull);
-    if (e == hipSuccess) e = hipMalloc((void **)&s->d_acc, sizeof(int64_t) * 4ull * k);
-    if (e == hipSuccess) e = hipMalloc((void **)&s->d_nconv, sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemset(s->d_nconv, 0, sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc((void **)&s->d_key, sizeof(unsigned long long));
+    s->pooled = pool_stream != nullptr;
+    s->pool_stream = pool_stream;
+    auto alloc = [&](void **ptr, size_t bytes) {
+        return s->pooled ? hipMallocAsync(ptr, bytes, pool_stream) : hipMalloc(ptr, bytes);
+    };
+    auto zero = [&](void *ptr, size_t bytes) {
+        return s->pooled ? hipMemsetAsync(ptr, 0, bytes, pool_stream) : hipMemset(ptr, 0, bytes);
+    };
+    hipError_t e = alloc((void **)&s->d_cent, sizeof(Centroid) * k);
+    if (e == hipSuccess) e = zero(s->d_cent, sizeof(Centroid) * k);   // structures.rs:501-521
+    if (e == hipSuccess) e = alloc((void **)&s->d_partials, sizeof(int64_t) * 4ull * k * 2048ull);
+    if (e == hipSuccess) e = alloc((void **)&s->d_acc, sizeof(int64_t) * 4ull * k);
+    if (e == hipSuccess) e = alloc((void **)&s->d_nconv, sizeof(uint32_t));
+    if (e == hipSuccess) e = zero(s->d_nconv, sizeof(uint32_t));
+    if (e == hipSuccess) e = alloc((void **)&s->d_key, sizeof(unsigned long long));
     if (e != hipSuccess) {
         kmg_lloyd_destroy(s);
         return fail(e == hipErrorOutOfMemory ? KMG_ERR_OUT_OF_MEMORY : KMG_ERR_HIP,
@@ -629,16 +660,25 @@ extern "C" int kmg_lloyd_create(kmg_processor *p, uint32_t k, kmg_lloyd **out)
     return KMG_OK;
 }
 
+extern "C" int kmg_lloyd_create(kmg_processor *p, uint32_t k, kmg_lloyd **out)
+{
+    return lloyd_create_impl(p, k, out, nullptr);
+}
+
 extern "C" void kmg_lloyd_destroy(kmg_lloyd *s)
 {
     if (!s) return;
     (void)hipSetDevice(s->p->device);
-    if (s->d_cent) (void)hipFree(s->d_cent);
-    if (s->d_partials) (void)hipFree(s->d_partials);
-    if (s->d_acc) (void)hipFree(s->d_acc);
-    if (s->d_nconv) (void)hipFree(s->d_nconv);
-    if (s->d_key) (void)hipFree(s->d_key);
-    if (s->d_dist) (void)hipFree(s->d_dist);
+    auto release = [&](void *ptr) {
+        if (!ptr) return;
+        if (s->pooled) (void)hipFreeAsync(ptr, s->pool_stream); else (void)hipFree(ptr);
+    };
+    release(s->d_cent);
+    release(s->d_partials);
+    release(s->d_acc);
+    release(s->d_nconv);
+    release(s->d_key);
+    release(s->d_dist);
     free_table(s->tab);
     destroy_events(s);
     delete s;
@@ -741,8 +781,13 @@ extern "C" int kmg_lloyd_init_centroids(kmg_lloyd *s, const uint8_t *d_rgba, uin
         bool colours = false;
         if ((rc = init_over_colours(s, d_rgba, n, 0, &colours, stream)) != KMG_OK) return rc;
         if (!colours && s->dist_cap < n) {
-            if (s->d_dist) { HIP_TRY(hipStreamSynchronize(S(stream))); HIP_TRY(hipFree(s->d_dist)); s->d_dist = nullptr; s->dist_cap = 0; }
-            HIP_TRY(hipMalloc((void **)&s->d_dist, sizeof(float) * n));
+            if (s->d_dist) {
+                HIP_TRY(hipStreamSynchronize(S(stream)));
+                HIP_TRY(s->pooled ? hipFreeAsync(s->d_dist, s->pool_stream) : hipFree(s->d_dist));
+                s->d_dist = nullptr; s->dist_cap = 0;
+            }
+            HIP_TRY(s->pooled ? hipMallocAsync((void **)&s->d_dist, sizeof(float) * n, s->pool_stream)
+                              : hipMalloc((void **)&s->d_dist, sizeof(float) * n));
             s->dist_cap = n;
         }
         for (uint32_t j = 1; j < s->k; ++j) {   // modules.rs:1211-1246
@@ -787,8 +832,13 @@ extern "C" int kmg_lloyd_init_step(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t
     }
     if (s->dist_cap < n_local) {
         if (j != 1) return fail(KMG_ERR_INVALID_ARGUMENT, "init_step: the distance map of this band was never started (j = 1)");
-        if (s->d_dist) { HIP_TRY(hipStreamSynchronize(S(stream))); HIP_TRY(hipFree(s->d_dist)); s->d_dist = nullptr; s->dist_cap = 0; }
-        HIP_TRY(hipMalloc((void **)&s->d_dist, sizeof(float) * n_local));
+        if (s->d_dist) {
+            HIP_TRY(hipStreamSynchronize(S(stream)));
+            HIP_TRY(s->pooled ? hipFreeAsync(s->d_dist, s->pool_stream) : hipFree(s->d_dist));
+            s->d_dist = nullptr; s->dist_cap = 0;
+        }
+        HIP_TRY(s->pooled ? hipMallocAsync((void **)&s->d_dist, sizeof(float) * n_local, s->pool_stream)
+                          : hipMalloc((void **)&s->d_dist, sizeof(float) * n_local));
         s->dist_cap = n_local;
     }
     HIP_TRY(launch_init_pass((const uint32_t *)d_rgba, n_local, s->p->d_lut, s->d_cent, j, s->d_dist,
@@ -1092,16 +1142,16 @@ int extract_palette_kmeans(kmg_processor *p, const uint8_t *d_rgba, uint32_t w, 
     int rc;
     const uint8_t *src = d_rgba;
     uint32_t sw = w, sh = h;
-    DevBuf small;
+    StreamBuf small;
     const uint32_t m = p->opt.shrink_max_dim;
     if (m && (w > m || h > m)) {                                       // structures.rs:67-74
         kmg_resized_dims(w, h, m, &sw, &sh);
-        HIP_TRY(small.alloc((size_t)sw * sh * 4));
+        HIP_TRY(small.alloc((size_t)sw * sh * 4, st));
         if ((rc = kmg_dev_resize(p, d_rgba, w, h, sw, sh, (uint8_t *)small.ptr, st)) != KMG_OK) return rc;
         src = (const uint8_t *)small.ptr;
     }
     LloydGuard g;
-    if ((rc = kmg_lloyd_create(p, k, &g.s)) != KMG_OK) return rc;
+    if ((rc = lloyd_create_impl(p, k, &g.s, st)) != KMG_OK) return rc;
     if ((rc = kmg_lloyd_init_centroids(g.s, src, sw, sh, st)) != KMG_OK) return rc;   // operations.rs:73
     if (log_debug()) {
         std::vector<float> c(4 * k);
@@ -1122,10 +1172,10 @@ int extract_palette_kmeans(kmg_processor *p, const uint8_t *d_rgba, uint32_t w, 
     return KMG_OK;
 }
 
-int upload_image(const uint8_t *rgba, uint32_t w, uint32_t h, hipStream_t st, DevBuf &buf)
+int upload_image(const uint8_t *rgba, uint32_t w, uint32_t h, hipStream_t st, StreamBuf &buf)
 {
     const size_t bytes = (size_t)w * h * 4;
-    HIP_TRY(buf.alloc(bytes));
+    HIP_TRY(buf.alloc(bytes, st));
     HIP_TRY(hipMemcpyAsync(buf.ptr, rgba, bytes, hipMemcpyHostToDevice, st));   // structures.rs:31-65
     return KMG_OK;
 }
@@ -1135,9 +1185,9 @@ int apply_and_download(kmg_processor *p, const uint8_t *d_rgba, uint32_t w, uint
                        uint32_t k, int mode, hipStream_t st, uint8_t *out_rgba)
 {
     int rc;
-    DevBuf out;
+    StreamBuf out;
     const size_t bytes = (size_t)w * h * 4;
-    HIP_TRY(out.alloc(bytes));
+    HIP_TRY(out.alloc(bytes, st));
     if ((rc = kmg_dev_apply(p, d_rgba, w, h, 0, c4, k, mode, (uint8_t *)out.ptr, st)) != KMG_OK) return rc;
     HIP_TRY(hipMemcpyAsync(out_rgba, out.ptr, bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -1153,10 +1203,10 @@ int octree_palette_of(kmg_processor *p, const uint8_t *d_rgba, uint32_t w, uint3
     int rc;
     uint32_t sw = w, sh = h;
     const uint8_t *src = d_rgba;
-    DevBuf small;
+    StreamBuf small;
     if (w > MAX_SIZE || h > MAX_SIZE) {
         kmg_resized_dims(w, h, MAX_SIZE, &sw, &sh);
-        HIP_TRY(small.alloc((size_t)sw * sh * 4));
+        HIP_TRY(small.alloc((size_t)sw * sh * 4, st));
         if ((rc = kmg_dev_resize(p, d_rgba, w, h, sw, sh, (uint8_t *)small.ptr, st)) != KMG_OK) return rc;
         src = (const uint8_t *)small.ptr;
     }
@@ -1201,10 +1251,10 @@ extern "C" int kmg_find(kmg_processor *p, const uint8_t *rgba, uint32_t w, uint3
     if (!out_rgba) return fail(KMG_ERR_INVALID_ARGUMENT, "output pointer is NULL");
     HIP_TRY(hipSetDevice(p->device));
     StreamGuard sg;
-    HIP_TRY(hipStreamCreateWithFlags(&sg.st, hipStreamNonBlocking));
+    HIP_TRY(sg.acquire(p));
     std::vector<float> c4(4 * (size_t)n_colors);
     if ((rc = kmg_palette_to_centroids(palette_rgba, n_colors, c4.data())) != KMG_OK) return rc;  // lib.rs:86-87
-    DevBuf img;
+    StreamBuf img;
     if ((rc = upload_image(rgba, w, h, sg.st, img)) != KMG_OK) return rc;
     return apply_and_download(p, (const uint8_t *)img.ptr, w, h, c4.data(), n_colors, mode, sg.st, out_rgba);
 }
@@ -1222,8 +1272,8 @@ extern "C" int kmg_reduce(kmg_processor *p, const uint8_t *rgba, uint32_t w, uin
         return fail(KMG_ERR_UNSUPPORTED, "k = %u exceeds KMG_MAX_K = %u", color_count, KMG_MAX_K);
     HIP_TRY(hipSetDevice(p->device));
     StreamGuard sg;
-    HIP_TRY(hipStreamCreateWithFlags(&sg.st, hipStreamNonBlocking));
-    DevBuf img;
+    HIP_TRY(sg.acquire(p));
+    StreamBuf img;
     if ((rc = upload_image(rgba, w, h, sg.st, img)) != KMG_OK) return rc;
     if (algo == KMG_ALGO_OCTREE) {                                     // lib.rs:133-136
         std::vector<std::array<uint8_t, 4>> colors;
@@ -1249,8 +1299,8 @@ extern "C" int kmg_palette(kmg_processor *p, const uint8_t *rgba, uint32_t w, ui
         return fail(KMG_ERR_UNSUPPORTED, "k = %u exceeds KMG_MAX_K = %u", color_count, KMG_MAX_K);
     HIP_TRY(hipSetDevice(p->device));
     StreamGuard sg;
-    HIP_TRY(hipStreamCreateWithFlags(&sg.st, hipStreamNonBlocking));
-    DevBuf img;
+    HIP_TRY(sg.acquire(p));
+    StreamBuf img;
     if ((rc = upload_image(rgba, w, h, sg.st, img)) != KMG_OK) return rc;
     if (algo == KMG_ALGO_OCTREE) {                                     // lib.rs:288-331
         std::vector<std::array<uint8_t, 4>> colors;
