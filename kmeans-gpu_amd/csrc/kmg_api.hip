@@ -391,7 +391,9 @@ static int ensure_bounds(kmg_processor *p, hipStream_t st)
     return KMG_OK;
 }
 
-extern "C" int kmg_lloyd_bind_image(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, void *stream)
+// want_tie: also build the init tie keys (ColourTable::d_tie, allocated by the caller) for an image whose
+// first pixel has the image-wide index first_index
+static int bind_image_impl(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, void *stream, bool want_tie, uint64_t first_index)
 {
     if (!s || !d_rgba || n == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad bind_image arguments");
     HIP_TRY(hipSetDevice(s->p->device));
@@ -417,8 +419,30 @@ extern "C" int kmg_lloyd_bind_image(kmg_lloyd *s, const uint8_t *d_rgba, uint64_
     t.tie_valid = false;
     // entries of cells no pixel falls into are never read by the label pass; 0xFF.. = "empty"
     HIP_TRY(hipMemsetAsync(t.d_sub, 0xFF, sizeof(uint16_t) * (kSubCells + kCells) + sizeof(uint32_t) * kCells, S(stream)));
-    HIP_TRY(hipMemsetAsync(t.d_hist, 0, sizeof(uint32_t) << 24, S(stream)));
-    HIP_TRY(launch_histogram((const uint32_t *)d_rgba, n, t.d_hist, S(stream)));
+    if (n >= (1ull << 21)) {
+        // partition + per-partition LDS histograms: no global atomic per pixel (kmg_table.hip)
+        StreamBuf small, elems, keys;
+        hipError_t e = small.alloc(sizeof(uint32_t) * (4 * 1024 + 1), S(stream));
+        if (e == hipSuccess) e = elems.alloc(sizeof(uint16_t) * n, S(stream));
+        if (e == hipSuccess && want_tie) e = keys.alloc(sizeof(uint32_t) * n, S(stream));
+        if (e == hipSuccess)
+            e = launch_partitioned_histogram((const uint32_t *)d_rgba, n, first_index, (uint32_t *)small.ptr, (uint16_t *)elems.ptr,
+                                             (uint32_t *)keys.ptr, t.d_hist, t.d_tie, S(stream));
+        if (e != hipSuccess)
+            return fail(e == hipErrorOutOfMemory ? KMG_ERR_OUT_OF_MEMORY : KMG_ERR_HIP, "histogram failed: %s", hipGetErrorString(e));
+    } else {
+        HIP_TRY(hipMemsetAsync(t.d_hist, 0, sizeof(uint32_t) << 24, S(stream)));
+        HIP_TRY(launch_histogram((const uint32_t *)d_rgba, n, t.d_hist, S(stream)));
+        if (want_tie) {
+            HIP_TRY(hipMemsetAsync(t.d_tie, 0, sizeof(uint32_t) << 24, S(stream)));
+            HIP_TRY(launch_tie_keys((const uint32_t *)d_rgba, n, first_index, t.d_tie, S(stream)));
+        }
+    }
+    if (want_tie) {
+        HIP_TRY(hipMemsetAsync(t.d_cell_key, 0, sizeof(unsigned long long) * kCells, S(stream)));
+        t.tie_valid = true;
+        t.tie_first = first_index;
+    }
     HIP_TRY(launch_cell_aggregates(t.d_hist, s->p->d_lab_table, t.d_agg, S(stream)));
     {
         // dense list of the occupied cells (static for this image)
@@ -436,6 +460,11 @@ extern "C" int kmg_lloyd_bind_image(kmg_lloyd *s, const uint8_t *d_rgba, uint64_
     t.rgba = d_rgba;
     t.n = n;
     return KMG_OK;
+}
+
+extern "C" int kmg_lloyd_bind_image(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, void *stream)
+{
+    return bind_image_impl(s, d_rgba, n, stream, false, 0);
 }
 
 extern "C" int kmg_lloyd_prepare(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, int want_labels, int *strategy, void *stream)
@@ -741,8 +770,6 @@ static int init_over_colours(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, ui
         if (s->tab.rgba == d_rgba) s->tab.rgba = nullptr;
         return KMG_OK;
     }
-    int rc;
-    if ((rc = kmg_lloyd_bind_image(s, d_rgba, n, stream)) != KMG_OK) return rc;
     ColourTable &t = s->tab;
     if (!t.d_tie) {
         hipError_t e = hipMalloc((void **)&t.d_tie, sizeof(uint32_t) << 24);
@@ -750,15 +777,9 @@ static int init_over_colours(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, ui
         if (e == hipSuccess) e = hipMalloc((void **)&t.d_cell_key, sizeof(unsigned long long) * kCells);
         if (e != hipSuccess)
             return fail(e == hipErrorOutOfMemory ? KMG_ERR_OUT_OF_MEMORY : KMG_ERR_HIP, "init tables allocation failed: %s", hipGetErrorString(e));
-        t.tie_valid = false;
     }
-    if (!t.tie_valid || t.tie_first != first_index) {
-        HIP_TRY(hipMemsetAsync(t.d_tie, 0, sizeof(uint32_t) << 24, S(stream)));
-        HIP_TRY(hipMemsetAsync(t.d_cell_key, 0, sizeof(unsigned long long) * kCells, S(stream)));
-        HIP_TRY(launch_tie_keys((const uint32_t *)d_rgba, n, first_index, t.d_tie, S(stream)));
-        t.tie_valid = true;
-        t.tie_first = first_index;
-    }
+    int rc;
+    if ((rc = bind_image_impl(s, d_rgba, n, stream, true, first_index)) != KMG_OK) return rc;
     *colours = true;
     return KMG_OK;
 }

@@ -110,6 +110,11 @@ __host__ __device__ inline uint32_t pair_decode(uint32_t e, int p)
 hipError_t launch_cell_bounds(const float *lut, CellBounds *bounds, float4 *lab_table, hipStream_t st);
 // once per image: hist[2^24] must be zero on entry
 hipError_t launch_histogram(const uint32_t *rgba, uint64_t n, uint32_t *hist, hipStream_t st);
+// the same histogram for large images without a global atomic per pixel (partition by the top 10 colour
+// bits, then one LDS histogram per partition chunk); with keys != NULL also tie[2^24] of the init below.
+// small: 4 * 1024 + 1 u32 of scratch, elems: n u16, keys: n u32 or NULL.  hist / tie are cleared here.
+hipError_t launch_partitioned_histogram(const uint32_t *rgba, uint64_t n, uint64_t first_index, uint32_t *small,
+                                        uint16_t *elems, uint32_t *keys, uint32_t *hist, uint32_t *tie, hipStream_t st);
 // once per image: agg[kCells][4] = (sum qL, sum qa, sum qb, count) of the image's pixels per cell
 hipError_t launch_cell_aggregates(const uint32_t *hist, const float4 *lab_table, int64_t *agg, hipStream_t st);
 // farthest-point initialisation over the colours of a large image: tie[2^24] (zero on entry) = 1 + the

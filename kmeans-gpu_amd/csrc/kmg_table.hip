@@ -149,6 +149,219 @@ hipError_t launch_histogram(const uint32_t *rgba, uint64_t n, uint32_t *hist, hi
 }
 
 // ------------------------------------------------------------------------------------------
+// Histogram (and init tie keys) of a large image without a global atomic per pixel.
+//
+// 67 M random increments into a 64 MiB table cost 2.5 ms as global atomics (every one is an L2 miss).
+// Instead the pixels are first partitioned by the top 10 bits of their colour index (1024 partitions
+// of 16384 colours): k_part_count totals the partitions, k_part_prefix turns the totals into segment
+// starts, k_part_scatter writes each pixel's low 14 colour bits (u16) -- and, for the init, the low
+// half of its arg-max key -- into its partition's segment (ranks from LDS atomics, one global atomic
+// per partition per 16384-pixel tile), and k_part_histogram counts one segment chunk per workgroup
+// entirely in LDS (64 KiB of counters + 64 KiB of tie keys) and stores the result coalesced.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kPartBits = 14;
+constexpr uint32_t kParts = 1u << (24 - kPartBits);               // 1024
+constexpr uint32_t kPartColours = 1u << kPartBits;                // 16384
+constexpr uint32_t kPartChunk = 1u << 20;                         // elements per k_part_histogram workgroup
+constexpr int kPartBlock = 1024;
+
+__global__ __launch_bounds__(kPartBlock) void k_part_count(const uint32_t *__restrict__ rgba, uint64_t n,
+                                                           uint32_t *__restrict__ totals, int aligned)
+{
+    __shared__ uint32_t s_cnt[kParts];
+    s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    constexpr uint64_t TILE = (uint64_t)kPartBlock * 8;
+    const uint64_t tiles = (n + TILE - 1) / TILE;
+    for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const uint64_t i0 = tile * TILE + (uint64_t)g * (kPartBlock * 4) + (uint64_t)threadIdx.x * 4;
+            uint32_t px[4];
+            load4(rgba, i0, n, aligned != 0, px);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (i0 + q < n) atomicAdd(&s_cnt[colour_index(px[q]) >> kPartBits], 1u);
+        }
+    }
+    __syncthreads();
+    if (s_cnt[threadIdx.x]) atomicAdd(totals + threadIdx.x, s_cnt[threadIdx.x]);
+}
+
+// start[p] = first element of partition p; cursor[p] = start[p]; chunk_first[p] = first k_part_histogram
+// workgroup of partition p (every partition has at least one), chunk_first[kParts] = their number
+__global__ __launch_bounds__(kPartBlock) void k_part_prefix(const uint32_t *__restrict__ totals,
+                                                            uint32_t *__restrict__ start, uint32_t *__restrict__ cursor,
+                                                            uint32_t *__restrict__ chunk_first)
+{
+    __shared__ uint32_t s_a[kParts], s_b[kParts];
+    const uint32_t t = threadIdx.x;
+    const uint32_t mine = totals[t];
+    const uint32_t chunks = mine ? (mine + kPartChunk - 1) / kPartChunk : 1u;
+    s_a[t] = mine; s_b[t] = chunks;
+    __syncthreads();
+    for (uint32_t off = 1; off < kParts; off <<= 1) {           // Hillis-Steele inclusive scan of both arrays
+        const uint32_t a = t >= off ? s_a[t - off] : 0u, b = t >= off ? s_b[t - off] : 0u;
+        __syncthreads();
+        s_a[t] += a; s_b[t] += b;
+        __syncthreads();
+    }
+    start[t] = s_a[t] - mine;
+    cursor[t] = s_a[t] - mine;
+    chunk_first[t] = s_b[t] - chunks;
+    if (t == kParts - 1) chunk_first[kParts] = s_b[t];
+}
+
+// A tile of 16384 pixels is counting-sorted by partition inside LDS (ranks from LDS atomics, a scan of
+// the 1024 tile counts), one global atomic per non-empty partition reserves its run in the segment, and
+// the sorted tile is written out: consecutive lanes write consecutive elements of a few runs instead of
+// 64 unrelated addresses.
+__global__ __launch_bounds__(kPartBlock) void k_part_scatter(const uint32_t *__restrict__ rgba, uint64_t n,
+                                                             uint64_t first_index, uint32_t *__restrict__ cursor,
+                                                             uint16_t *__restrict__ elems, uint32_t *__restrict__ keys,
+                                                             int aligned)
+{
+    constexpr int G = 4;                                            // 16 pixels per thread and tile
+    constexpr uint32_t TILE = (uint32_t)kPartBlock * 4 * G;
+    __shared__ uint32_t s_cnt[kParts], s_pre[kParts], s_base[kParts];
+    extern __shared__ uint32_t s_dyn[];                             // [keys TILE u32 (if keys)][low colour bits TILE u16][partition TILE u16]
+    uint32_t *s_key = s_dyn;
+    uint16_t *s_el = reinterpret_cast<uint16_t *>(s_dyn + (keys ? TILE : 0u));
+    uint16_t *s_pt = s_el + TILE;
+    const uint64_t tiles = (n + TILE - 1) / TILE;
+    for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const uint64_t tile0 = tile * TILE;
+        const uint32_t tile_n = (uint32_t)(n - tile0 < TILE ? n - tile0 : TILE);
+        s_cnt[threadIdx.x] = 0u;
+        __syncthreads();
+        uint32_t where[4 * G];                                      // [partition:10][rank within the tile:15]
+        uint16_t low[4 * G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const uint64_t i0 = tile0 + (uint64_t)g * (kPartBlock * 4) + (uint64_t)threadIdx.x * 4;
+            uint32_t px[4];
+            load4(rgba, i0, n, aligned != 0, px);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t ci = colour_index(px[q]);
+                const uint32_t part = ci >> kPartBits;
+                uint32_t rank = 0;
+                if (i0 + q < n) rank = atomicAdd(&s_cnt[part], 1u);
+                where[g * 4 + q] = (part << 15) | rank;
+                low[g * 4 + q] = (uint16_t)(ci & (kPartColours - 1u));
+            }
+        }
+        __syncthreads();
+        const uint32_t mine = s_cnt[threadIdx.x];
+        s_base[threadIdx.x] = mine ? atomicAdd(cursor + threadIdx.x, mine) : 0u;
+        s_pre[threadIdx.x] = mine;
+        __syncthreads();
+        for (uint32_t off = 1; off < kParts; off <<= 1) {          // inclusive scan of the tile counts
+            const uint32_t a = threadIdx.x >= off ? s_pre[threadIdx.x - off] : 0u;
+            __syncthreads();
+            s_pre[threadIdx.x] += a;
+            __syncthreads();
+        }
+        s_pre[threadIdx.x] -= mine;                                 // exclusive: first sorted position of the partition
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const uint64_t i0 = tile0 + (uint64_t)g * (kPartBlock * 4) + (uint64_t)threadIdx.x * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (i0 + q < n) {
+                    const uint32_t wq = where[g * 4 + q], part = wq >> 15;
+                    const uint32_t j = s_pre[part] + (wq & 32767u);
+                    s_el[j] = low[g * 4 + q];
+                    s_pt[j] = (uint16_t)part;
+                    if (keys) {
+                        const uint64_t gi = first_index + i0 + q;
+                        s_key[j] = ((uint32_t)(gi >> 4) << 4) | (15u - (uint32_t)(gi & 15u));
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < tile_n; j += kPartBlock) {
+            const uint32_t part = s_pt[j];
+            const uint64_t dst = (uint64_t)s_base[part] + (j - s_pre[part]);
+            elems[dst] = s_el[j];
+            if (keys) keys[dst] = s_key[j];
+        }
+        __syncthreads();
+    }
+}
+
+// one workgroup per (partition, chunk of <= 2^20 elements); hist / tie are zero on entry
+__global__ __launch_bounds__(kPartBlock) void k_part_histogram(const uint16_t *__restrict__ elems,
+                                                               const uint32_t *__restrict__ keys,
+                                                               const uint32_t *__restrict__ start,
+                                                               const uint32_t *__restrict__ totals,
+                                                               const uint32_t *__restrict__ chunk_first,
+                                                               uint32_t *__restrict__ hist, uint32_t *__restrict__ tie)
+{
+    extern __shared__ uint32_t s_tab[];                             // [counts 16384][tie keys 16384 (if keys)]
+    uint32_t *s_cnt = s_tab, *s_tie = s_tab + kPartColours;
+    if (blockIdx.x >= chunk_first[kParts]) return;
+    uint32_t lo = 0, hi = kParts - 1;                               // last partition whose first workgroup is <= blockIdx.x
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (chunk_first[mid] <= blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const uint32_t part = lo;
+    const uint32_t chunk = blockIdx.x - chunk_first[part];
+    const uint32_t n_chunks = chunk_first[part + 1] - chunk_first[part];
+    const uint64_t total = totals[part];
+    const uint64_t b = (uint64_t)chunk * kPartChunk, e = b + kPartChunk < total ? b + kPartChunk : total;
+    if (b >= e) return;                                             // empty partition: hist / tie stay zero
+    for (uint32_t i = threadIdx.x; i < kPartColours; i += kPartBlock) { s_cnt[i] = 0u; if (keys) s_tie[i] = 0u; }
+    __syncthreads();
+    const uint64_t seg = start[part];
+    for (uint64_t i = b + threadIdx.x; i < e; i += kPartBlock) {
+        const uint32_t c = elems[seg + i];
+        atomicAdd(&s_cnt[c], 1u);
+        if (keys) atomicMax(&s_tie[c], keys[seg + i] + 1u);
+    }
+    __syncthreads();
+    const uint32_t out = part * kPartColours;
+    for (uint32_t i = threadIdx.x; i < kPartColours; i += kPartBlock) {
+        const uint32_t c = s_cnt[i];
+        if (n_chunks == 1u) {
+            hist[out + i] = c;
+            if (keys) tie[out + i] = s_tie[i];
+        } else if (c) {
+            atomicAdd(hist + out + i, c);
+            if (keys) atomicMax(tie + out + i, s_tie[i]);
+        }
+    }
+}
+
+// scratch: 3 * kParts + 1 u32 (totals, start, cursor, chunk_first) zeroed by the caller is NOT needed:
+// this function clears what it uses.  elems: n u16; keys: n u32 or NULL (then tie is not touched).
+hipError_t launch_partitioned_histogram(const uint32_t *rgba, uint64_t n, uint64_t first_index, uint32_t *small,
+                                        uint16_t *elems, uint32_t *keys, uint32_t *hist, uint32_t *tie, hipStream_t st)
+{
+    uint32_t *totals = small, *start = small + kParts, *cursor = small + 2 * kParts, *chunk_first = small + 3 * kParts;
+    const int aligned = (reinterpret_cast<uintptr_t>(rgba) & 15u) == 0 ? 1 : 0;
+    hipError_t e = hipMemsetAsync(totals, 0, sizeof(uint32_t) * kParts, st);
+    if (e != hipSuccess) return e;
+    if ((e = hipMemsetAsync(hist, 0, sizeof(uint32_t) << 24, st)) != hipSuccess) return e;
+    if (keys && (e = hipMemsetAsync(tie, 0, sizeof(uint32_t) << 24, st)) != hipSuccess) return e;
+    const uint64_t tiles8 = (n + kPartBlock * 8 - 1) / (kPartBlock * 8);
+    const uint32_t grid_count = (uint32_t)(tiles8 < 512 ? (tiles8 ? tiles8 : 1) : 512);
+    hipLaunchKernelGGL(k_part_count, dim3(grid_count), dim3(kPartBlock), 0, st, rgba, n, totals, aligned);
+    hipLaunchKernelGGL(k_part_prefix, dim3(1), dim3(kPartBlock), 0, st, totals, start, cursor, chunk_first);
+    const uint64_t tiles16 = (n + kPartBlock * 16 - 1) / (kPartBlock * 16);
+    const uint32_t grid_scatter = (uint32_t)(tiles16 < 256 ? (tiles16 ? tiles16 : 1) : 256);   // one workgroup per CU (LDS)
+    const size_t lds_scatter = (size_t)kPartBlock * 16 * (keys ? 8 : 4);
+    hipLaunchKernelGGL(k_part_scatter, dim3(grid_scatter), dim3(kPartBlock), lds_scatter, st, rgba, n, first_index, cursor, elems, keys, aligned);
+    const uint32_t grid_hist = kParts + (uint32_t)(n / kPartChunk) + 1u;      // >= the number of chunks
+    const size_t lds = sizeof(uint32_t) * kPartColours * (keys ? 2 : 1);
+    hipLaunchKernelGGL(k_part_histogram, dim3(grid_hist), dim3(kPartBlock), lds, st, elems, keys, start, totals, chunk_first, hist, tie);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // Farthest-point initialisation over the image's colours (plus_plus_init.wgsl, kmeans++_calc_diff.wgsl)
 //
 // All pixels of one colour share their distance to the chosen centroids, so the arg-max key of
