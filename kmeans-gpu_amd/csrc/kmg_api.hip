@@ -330,7 +330,14 @@ static void free_table(ColourTable &t)
 //   per-pixel scan : 1.4e-5 + n * (7.0e-12 + 2.25e-13 k)
 //   colour table   : 9.0e-5 + 2.7e-7 k                       candidates + cube pass (independent of n)
 //                    + n * (1.7e-12 + 2.3e-15 k)              label pass, k <= 256 (6.7e-12 for u16 labels)
-//                    + (2.5e-4 + n * 4.1e-11) / 16            one-off histogram, spread over ~16 passes
+//                    + bind_seconds(n) / 16                   one-off histogram + cell sums, spread over ~16 passes
+// one-off cost of binding an image: partitioned histogram (n >= 2^21) or one global atomic per pixel, + cell sums
+static double bind_seconds(uint64_t n)
+{
+    const double N = (double)n;
+    return n >= (1ull << 21) ? 6.0e-4 + N * 1.0e-11 : 3.5e-4 + N * 4.1e-11;
+}
+
 static bool table_pays(uint64_t n, uint32_t k, bool labels)
 {
     if (const char *e = getenv("KMG_STRATEGY")) {
@@ -340,7 +347,7 @@ static bool table_pays(uint64_t n, uint32_t k, bool labels)
     const double N = (double)n;
     const double brute = 1.4e-5 + N * (7.0e-12 + 2.25e-13 * k);
     const double label_pass = labels ? N * (k <= 256 ? 1.7e-12 + 2.3e-15 * k : 6.7e-12) : 0.0;
-    const double table = 9.0e-5 + 2.7e-7 * k + label_pass + (2.5e-4 + N * 4.1e-11) / 16.0;
+    const double table = 9.0e-5 + 2.7e-7 * k + label_pass + bind_seconds(n) / 16.0;
     return table < brute;
 }
 
@@ -743,9 +750,10 @@ extern "C" int kmg_lloyd_get_centroids(kmg_lloyd *s, float *c4, void *stream)
 
 // Farthest-point init: k - 1 passes over the pixels (n * 7.0e-12 s each: sRGB->Lab + literal CIE94 per
 // pixel) or over the image's colours (1.1e-4 s for a pass that reaches every cell -- the first ~20 --
-// falling to ~4e-5 s once most cells are skipped; one-off 2.5e-4 + n * 3.7e-11 s for the tie keys, and
-// 2.5e-4 + n * 4.1e-11 s for the histogram if the image is not bound yet); MI355X, tools/cfg3_probe.py.
-static bool init_table_pays(uint64_t n, uint32_t k, bool bound)
+// falling to ~4e-5 s once most cells are skipped) after binding the image (bind_seconds; the tie keys
+// come with the partitioned histogram, or cost another atomic per pixel on small images); MI355X,
+// tools/cfg3_probe.py.
+static bool init_table_pays(uint64_t n, uint32_t k)
 {
     if (const char *e = getenv("KMG_STRATEGY")) {
         if (!strcmp(e, "brute")) return false;
@@ -753,8 +761,8 @@ static bool init_table_pays(uint64_t n, uint32_t k, bool bound)
     }
     const double N = (double)n, passes = (double)(k - 1);
     const double pixels = passes * N * 7.0e-12;
-    const double colours = passes * 4.5e-5 + (passes < 20.0 ? passes : 20.0) * 7.0e-5 + 2.5e-4 + N * 3.7e-11 +
-                           (bound ? 0.0 : 2.5e-4 + N * 4.1e-11);
+    const double colours = passes * 4.5e-5 + (passes < 20.0 ? passes : 20.0) * 7.0e-5 + bind_seconds(n) +
+                           (n >= (1ull << 21) ? 0.0 : 1.0e-4 + N * 3.7e-11);
     return colours < pixels;
 }
 
@@ -766,7 +774,7 @@ static int init_over_colours(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, ui
     *colours = false;
     // an initialisation starts a new problem: the image is (re)bound from the buffer's current contents,
     // so the loop that follows never works from the histogram of an earlier image in the same buffer
-    if (first_index + n > 0xFFFFFFF0ull || !init_table_pays(n, s->k, false)) {
+    if (first_index + n > 0xFFFFFFF0ull || !init_table_pays(n, s->k)) {
         if (s->tab.rgba == d_rgba) s->tab.rgba = nullptr;
         return KMG_OK;
     }
