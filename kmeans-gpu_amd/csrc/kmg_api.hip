@@ -335,7 +335,7 @@ static void free_table(ColourTable &t)
 static double bind_seconds(uint64_t n)
 {
     const double N = (double)n;
-    return n >= (1ull << 21) ? 6.0e-4 + N * 1.0e-11 : 3.5e-4 + N * 4.1e-11;
+    return n >= (1ull << 21) ? 4.0e-4 + N * 9.0e-12 : 3.5e-4 + N * 4.1e-11;
 }
 
 static bool table_pays(uint64_t n, uint32_t k, bool labels)
@@ -451,19 +451,7 @@ static int bind_image_impl(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, void
         t.tie_first = first_index;
     }
     HIP_TRY(launch_cell_aggregates(t.d_hist, s->p->d_lab_table, t.d_agg, S(stream)));
-    {
-        // dense list of the occupied cells (static for this image)
-        std::vector<int64_t> agg(4ull * kCells);
-        HIP_TRY(hipMemcpyAsync(agg.data(), t.d_agg, sizeof(int64_t) * agg.size(), hipMemcpyDeviceToHost, S(stream)));
-        HIP_TRY(hipStreamSynchronize(S(stream)));
-        std::vector<uint32_t> work(1, 0u);
-        work.reserve(kCells + 1);
-        for (uint32_t c = 0; c < kCells; ++c)
-            if (agg[4ull * c + 3] != 0) work.push_back(c);
-        work[0] = (uint32_t)work.size() - 1;
-        HIP_TRY(hipMemcpyAsync(t.d_work, work.data(), sizeof(uint32_t) * work.size(), hipMemcpyHostToDevice, S(stream)));
-        HIP_TRY(hipStreamSynchronize(S(stream)));
-    }
+    HIP_TRY(launch_work_list(t.d_agg, t.d_work, S(stream)));       // dense list of the occupied cells (static for this image)
     t.rgba = d_rgba;
     t.n = n;
     return KMG_OK;

@@ -117,6 +117,8 @@ hipError_t launch_partitioned_histogram(const uint32_t *rgba, uint64_t n, uint64
                                         uint16_t *elems, uint32_t *keys, uint32_t *hist, uint32_t *tie, hipStream_t st);
 // once per image: agg[kCells][4] = (sum qL, sum qa, sum qb, count) of the image's pixels per cell
 hipError_t launch_cell_aggregates(const uint32_t *hist, const float4 *lab_table, int64_t *agg, hipStream_t st);
+// once per image: work[0] = number of occupied cells, work[1..] = their indices in ascending order
+hipError_t launch_work_list(const int64_t *agg, uint32_t *work, hipStream_t st);
 // farthest-point initialisation over the colours of a large image: tie[2^24] (zero on entry) = 1 + the
 // largest low half of the init key among the pixels of each colour (first_index = image-wide index of
 // rgba[0], first_index + n <= 0xFFFFFFF0).  One pass = running min-distance per colour for the cells the

@@ -568,6 +568,35 @@ hipError_t launch_cell_aggregates(const uint32_t *hist, const float4 *lab_table,
     return hipGetLastError();
 }
 
+// dense list of the occupied cells in ascending order (once per image): work[0] = count, work[1..] = cells
+__global__ __launch_bounds__(1024) void k_work_list(const int64_t *__restrict__ agg, uint32_t *__restrict__ work)
+{
+    __shared__ uint32_t s_n[1024];
+    constexpr uint32_t PER = kCells / 1024;                        // 32 consecutive cells per thread
+    const uint32_t c0 = threadIdx.x * PER;
+    uint32_t occupied = 0;                                         // bit i = cell c0 + i has pixels
+    for (uint32_t i = 0; i < PER; ++i) occupied |= (agg[4ull * (c0 + i) + 3] != 0 ? 1u : 0u) << i;
+    const uint32_t mine = (uint32_t)__builtin_popcount(occupied);
+    s_n[threadIdx.x] = mine;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        const uint32_t a = threadIdx.x >= off ? s_n[threadIdx.x - off] : 0u;
+        __syncthreads();
+        s_n[threadIdx.x] += a;
+        __syncthreads();
+    }
+    uint32_t at = 1u + s_n[threadIdx.x] - mine;
+    for (uint32_t i = 0; i < PER; ++i)
+        if ((occupied >> i) & 1u) work[at++] = c0 + i;
+    if (threadIdx.x == 1023) work[0] = s_n[1023];
+}
+
+hipError_t launch_work_list(const int64_t *agg, uint32_t *work, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_work_list, dim3(1), dim3(1024), 0, st, agg, work);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------
 // candidate masks (per iteration): one wave per cell, lanes strided over the centroids
 // ------------------------------------------------------------------------------------------
