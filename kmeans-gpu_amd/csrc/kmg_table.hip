@@ -317,10 +317,21 @@ __global__ __launch_bounds__(kPartBlock) void k_part_histogram(const uint16_t *_
     for (uint32_t i = threadIdx.x; i < kPartColours; i += kPartBlock) { s_cnt[i] = 0u; if (keys) s_tie[i] = 0u; }
     __syncthreads();
     const uint64_t seg = start[part];
-    for (uint64_t i = b + threadIdx.x; i < e; i += kPartBlock) {
-        const uint32_t c = elems[seg + i];
-        atomicAdd(&s_cnt[c], 1u);
-        if (keys) atomicMax(&s_tie[c], keys[seg + i] + 1u);
+    for (uint64_t i0 = b + threadIdx.x; i0 < e; i0 += 8ull * kPartBlock) {      // 8 loads in flight per thread
+        uint32_t c[8], kk[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint64_t i = i0 + (uint64_t)u * kPartBlock;
+            c[u] = i < e ? (uint32_t)elems[seg + i] : 0xFFFFFFFFu;
+            kk[u] = (keys && i < e) ? keys[seg + i] + 1u : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (c[u] != 0xFFFFFFFFu) {
+                atomicAdd(&s_cnt[c[u]], 1u);
+                if (keys) atomicMax(&s_tie[c[u]], kk[u]);
+            }
+        }
     }
     __syncthreads();
     const uint32_t out = part * kPartColours;
@@ -543,12 +554,15 @@ __global__ __launch_bounds__(kBlock) void k_cell_aggregates(const uint32_t *__re
     const uint32_t base = cell * kCellColours + lane * 8;
     const uint4 c0 = *reinterpret_cast<const uint4 *>(hist + base);
     const uint4 c1 = *reinterpret_cast<const uint4 *>(hist + base + 4);
+    float4 lab8[8];                                                // all loads in flight together (one latency)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) lab8[q] = lab_table[base + q];
     const uint32_t cnt[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
     long long s[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         if (cnt[q]) {
-            const float4 v = lab_table[base + q];
+            const float4 v = lab8[q];
             const long long m = (long long)cnt[q];
             s[0] += m * (long long)lab_fix(v.x);
             s[1] += m * (long long)lab_fix(v.y);
