@@ -182,6 +182,10 @@ KMG_API int kmg_debug_check_pairs(kmg_lloyd *s, uint64_t out[3], void *stream);
  * true arg-min of mix_colors.wgsl:73-80.  *violations must come back 0.                            */
 KMG_API int kmg_debug_check_dither_masks(kmg_processor *p, const float *centroids4, uint32_t k, uint64_t *violations,
                                          void *stream);
+/* Test support: the same exhaustive check (2^24 colours) for the pruned meld pass: the two closest
+ * centroids of mix_colors.wgsl:29-48 found among a cell's candidates must be those of the full scan.  */
+KMG_API int kmg_debug_check_meld_masks(kmg_processor *p, const float *centroids4, uint32_t k, uint64_t *violations,
+                                       void *stream);
 
 /* Labels only, for the CURRENT centroid table: find_centroid.wgsl:15-44 without the sums.  With a
  * bound image whose label tables are current (an assign pass ran since the last centroid change) this

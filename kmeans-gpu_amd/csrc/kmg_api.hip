@@ -378,6 +378,17 @@ static bool dither_pruning_pays(uint64_t n, uint32_t k)
     return k >= 32 && n >= 12000000ull;
 }
 
+// Meld output pass: ordered scan of all k centroids per pixel, or of the candidates of the pixel's colour
+// cell only (k_meld_candidates: ~0.03 ms per 64 centroids; tools/dither_probe.py).
+static bool meld_pruning_pays(uint64_t n, uint32_t k)
+{
+    if (const char *e = getenv("KMG_STRATEGY")) {
+        if (!strcmp(e, "brute")) return false;
+        if (!strcmp(e, "table")) return true;
+    }
+    return k >= 16 && n >= (1ull << 20);
+}
+
 static int ensure_bounds(kmg_processor *p, hipStream_t st)
 {
     std::lock_guard<std::mutex> lock(p->mu);
@@ -533,6 +544,35 @@ extern "C" int kmg_debug_check_dither_masks(kmg_processor *p, const float *c4, u
     HIP_TRY(launch_offset_candidates(p->d_bounds, (const Centroid *)cent.ptr, k, thr, (uint64_t *)masks.ptr, S(stream)));
     HIP_TRY(launch_check_offset_masks((const Centroid *)cent.ptr, k, (const uint64_t *)masks.ptr, p->d_lut, thr,
                                       (unsigned long long *)viol.ptr, S(stream)));
+    unsigned long long h = 0;
+    HIP_TRY(hipMemcpyAsync(&h, viol.ptr, sizeof h, hipMemcpyDeviceToHost, S(stream)));
+    HIP_TRY(hipStreamSynchronize(S(stream)));
+    *violations = h;
+    return KMG_OK;
+}
+
+// test support: exhaustive validation of the meld candidate masks for a centroid table (k >= 2): over all
+// 2^24 colours the two closest centroids found among the cell's candidates must be those of the full scan.
+extern "C" int kmg_debug_check_meld_masks(kmg_processor *p, const float *c4, uint32_t k, uint64_t *violations, void *stream)
+{
+    if (!p || !c4 || !violations || k < 2 || k > KMG_MAX_K) return fail(KMG_ERR_INVALID_ARGUMENT, "bad check_meld_masks arguments");
+    HIP_TRY(hipSetDevice(p->device));
+    int rc;
+    if ((rc = ensure_bounds(p, S(stream))) != KMG_OK) return rc;
+    std::vector<Centroid> hc(k);
+    for (uint32_t i = 0; i < k; ++i) {
+        hc[i].L = c4[4 * i]; hc[i].a = c4[4 * i + 1]; hc[i].b = c4[4 * i + 2];
+        hc[i].C = chroma(hc[i].a, hc[i].b);
+    }
+    DevBuf cent, masks, viol;
+    HIP_TRY(cent.alloc(sizeof(Centroid) * k));
+    HIP_TRY(masks.alloc(sizeof(uint64_t) * (size_t)kCells * mask_words(k)));
+    HIP_TRY(viol.alloc(sizeof(unsigned long long)));
+    HIP_TRY(hipMemcpyAsync(cent.ptr, hc.data(), sizeof(Centroid) * k, hipMemcpyHostToDevice, S(stream)));
+    HIP_TRY(hipMemsetAsync(viol.ptr, 0, sizeof(unsigned long long), S(stream)));
+    HIP_TRY(launch_meld_candidates(p->d_bounds, (const Centroid *)cent.ptr, k, (uint64_t *)masks.ptr, S(stream)));
+    HIP_TRY(launch_check_meld_masks((const Centroid *)cent.ptr, k, (const uint64_t *)masks.ptr, p->d_lut,
+                                    (unsigned long long *)viol.ptr, S(stream)));
     unsigned long long h = 0;
     HIP_TRY(hipMemcpyAsync(&h, viol.ptr, sizeof h, hipMemcpyDeviceToHost, S(stream)));
     HIP_TRY(hipStreamSynchronize(S(stream)));
@@ -1094,7 +1134,17 @@ extern "C" int kmg_dev_apply(kmg_processor *p, const uint8_t *d_rgba, uint32_t w
     if (e != hipSuccess) {
         // fall through to the error report
     } else if (mode == KMG_MODE_MELD) {
-        e = launch_meld((const uint32_t *)d_rgba, n_px, d_cent, k, p->d_lut, (uint32_t *)d_out, S(stream));
+        const uint64_t *meld_masks = nullptr;
+        if (k >= 2 && meld_pruning_pays(n_px, k)) {
+            // large image: per colour cell, the centroids that can be one of a pixel's two closest
+            if ((rc = ensure_bounds(p, S(stream))) == KMG_OK) {
+                e = masks.alloc(sizeof(uint64_t) * (size_t)kCells * mask_words(k), S(stream));
+                if (e == hipSuccess) e = launch_meld_candidates(p->d_bounds, d_cent, k, (uint64_t *)masks.ptr, S(stream));
+                meld_masks = (const uint64_t *)masks.ptr;
+            }
+        }
+        if (rc == KMG_OK && e == hipSuccess)
+            e = launch_meld((const uint32_t *)d_rgba, n_px, d_cent, k, p->d_lut, meld_masks, (uint32_t *)d_out, S(stream));
     } else if (!dither && replace_table_pays(n_px, k)) {
         // replace mode on a large image: the label of a pixel depends on its colour only, so label the
         // colour cube once (candidate masks + cube pass without sums) and emit pal[label] through the

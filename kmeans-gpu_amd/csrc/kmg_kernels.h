@@ -56,7 +56,8 @@ hipError_t launch_apply(const uint32_t *rgba, uint32_t w, uint32_t rows, uint32_
                         bool dither, float threshold, uint32_t *out, hipStream_t st);
 
 // meld output pass (mix_colors.wgsl main_meld + lab_to_rgb.wgsl)
+// masks: NULL, or per colour cell the candidate centroids of kmg_table.h's launch_meld_candidates
 hipError_t launch_meld(const uint32_t *rgba, uint64_t n, const Centroid *cent, uint32_t k, const float *lut,
-                       uint32_t *out, hipStream_t st);
+                       const uint64_t *masks, uint32_t *out, hipStream_t st);
 
 }  // namespace kmg

@@ -669,9 +669,12 @@ __device__ __forceinline__ uint32_t lab_to_rgba8_dev(float L, float a, float b)
            0xFF000000u;
 }
 
+// masks != NULL: per colour cell, the centroids that can be among the pixel's two closest (kmg_table.hip,
+// k_meld_candidates); the ordered scan then visits only those -- same two slots, same output
 __global__ __launch_bounds__(kBlock) void k_meld(const uint32_t *__restrict__ rgba, uint64_t n,
                                                  const Centroid *__restrict__ cent, uint32_t k,
-                                                 const float *__restrict__ lut, uint32_t *__restrict__ out)
+                                                 const float *__restrict__ lut, const uint64_t *__restrict__ masks,
+                                                 uint32_t *__restrict__ out)
 {
     extern __shared__ float4 smem4[];
     const uint32_t kpad = (k + 3u) & ~3u;
@@ -680,10 +683,12 @@ __global__ __launch_bounds__(kBlock) void k_meld(const uint32_t *__restrict__ rg
     s_lut[threadIdx.x] = lut[threadIdx.x];
     stage_centroids(s_cent, cent, k, kpad);
     __syncthreads();
+    const uint32_t words = (k + 63u) / 64u;
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const uint32_t px = rgba[i];
         float L, a, b;
-        px_to_lab(s_lut, rgba[i], L, a, b);
+        px_to_lab(s_lut, px, L, a, b);
         if (k == 1) {                                            // mix_colors.wgsl:127-131
             const float4 c = s_cent[0];
             out[i] = lab_to_rgba8_dev(c.x, c.y, c.z);
@@ -692,7 +697,7 @@ __global__ __launch_bounds__(kBlock) void k_meld(const uint32_t *__restrict__ rg
         // :30-31 closest = second_closest = vec4(10000.0)
         float cL = 10000.0f, ca = 10000.0f, cb = 10000.0f, sL = 10000.0f, sa = 10000.0f, sb = 10000.0f;
         float d_closest = cie94(L, a, b, cL, ca, cb), d_second = d_closest;
-        for (uint32_t j = 0; j < k; ++j) {
+        auto visit = [&](uint32_t j) {
             const float4 c = s_cent[j];
             const float d = cie94(L, a, b, c.x, c.y, c.z);
             if (d < d_closest) {                                 // :36-38
@@ -701,6 +706,18 @@ __global__ __launch_bounds__(kBlock) void k_meld(const uint32_t *__restrict__ rg
             } else if (d < d_second) {                           // :39-41
                 sL = c.x; sa = c.y; sb = c.z; d_second = d;
             }
+        };
+        if (masks) {
+            const uint32_t cell = (((px >> 3) & 31u) << 10) | (((px >> 11) & 31u) << 5) | ((px >> 19) & 31u);
+            for (uint32_t w = 0; w < words; ++w) {
+                unsigned long long m = masks[(uint64_t)cell * words + w];
+                while (m) {
+                    visit(w * 64 + (uint32_t)__builtin_ctzll(m));
+                    m &= m - 1;
+                }
+            }
+        } else {
+            for (uint32_t j = 0; j < k; ++j) visit(j);
         }
         // :86-89
         const float factor = cie94(L, a, b, sL, sa, sb) / cie94(cL, ca, cb, sL, sa, sb);
@@ -712,13 +729,13 @@ __global__ __launch_bounds__(kBlock) void k_meld(const uint32_t *__restrict__ rg
 }
 
 hipError_t launch_meld(const uint32_t *rgba, uint64_t n, const Centroid *cent, uint32_t k, const float *lut,
-                       uint32_t *out, hipStream_t st)
+                       const uint64_t *masks, uint32_t *out, hipStream_t st)
 {
     const uint64_t blocks = (n + kBlock - 1) / kBlock;
     const uint32_t grid = (uint32_t)(blocks < 8192 ? (blocks ? blocks : 1) : 8192);
     const uint32_t kpad = (k + 3u) & ~3u;
     const size_t lds = sizeof(float4) * kpad + 256 * sizeof(float);
-    hipLaunchKernelGGL(k_meld, dim3(grid), dim3(kBlock), lds, st, rgba, n, cent, k, lut, out);
+    hipLaunchKernelGGL(k_meld, dim3(grid), dim3(kBlock), lds, st, rgba, n, cent, k, lut, masks, out);
     return hipGetLastError();
 }
 

@@ -157,6 +157,13 @@ hipError_t launch_dither_pruned(const uint32_t *rgba, uint32_t w, uint32_t rows,
 hipError_t launch_check_offset_masks(const Centroid *cent, uint32_t k, const uint64_t *masks, const float *lut,
                                      float threshold, unsigned long long *violations, hipStream_t st);
 
+// meld output pass with candidate pruning: masks[cell * words + w] = the centroids that can be one of the two
+// closest (literal CIE94) of any colour of the cell, k >= 2; launch_meld (kmg_kernels.h) scans only those
+hipError_t launch_meld_candidates(const CellBounds *bounds, const Centroid *cent, uint32_t k, uint64_t *masks, hipStream_t st);
+// test support: number of colours whose two closest centroids differ between the full and the pruned scan
+hipError_t launch_check_meld_masks(const Centroid *cent, uint32_t k, const uint64_t *masks, const float *lut,
+                                   unsigned long long *violations, hipStream_t st);
+
 // debug / test support: number of (cell, centroid, colour) triples whose key falls outside the
 // interval bounds, and number of colours whose brute-force arg-min is missing from the cell mask
 hipError_t launch_check_bounds(const CellBounds *bounds, const Centroid *cent, uint32_t k,

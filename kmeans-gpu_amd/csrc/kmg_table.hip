@@ -1336,6 +1336,114 @@ hipError_t launch_dither_pruned(const uint32_t *rgba, uint32_t w, uint32_t rows,
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// meld output pass with candidate pruning (mix_colors.wgsl:29-48 two_closest_colors, :85-90 meld)
+//
+// The pass needs the two closest centroids of a pixel under the literal CIE94, found by one ordered
+// scan with `<` comparisons.  Removing from that scan any centroid whose distance exceeds the second
+// smallest one changes neither slot of the result (such a centroid can only sit in a slot until
+// something smaller arrives, and never displaces an equal value), so it is enough to scan, in index
+// order, a superset of the centroids within the second smallest distance: per cell, those whose
+// lower bound is not above the second smallest upper bound.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float cie94_upper_bound(const CellBounds &cb, float L2, float a2, float b2, float C2)
+{
+    float mL, ML, ma, Ma, mb, Mb, mC, MC;
+    abs_range(cb.L0, cb.L1, L2, mL, ML);
+    abs_range(cb.a0, cb.a1, a2, ma, Ma);
+    abs_range(cb.b0, cb.b1, b2, mb, Mb);
+    abs_range(cb.C0, cb.C1, C2, mC, MC);
+    const float SC = 1.0f + 0.045f * cb.C0, SH = 1.0f + 0.015f * cb.C0;      // the smallest divisors
+    const float dH = sqrtf(fmaxf((Ma * Ma) + (Mb * Mb) - (mC * mC), 0.0f));
+    const float tL = ML / 1.0f, tC = MC / SC, tH = dH / SH;
+    return sqrtf(tL * tL + tC * tC + tH * tH);
+}
+
+// (m1 <= m2) <- the two smallest of {m1, m2, o1, o2}, o1 <= o2
+__device__ __forceinline__ void merge_two_smallest(float &m1, float &m2, float o1, float o2)
+{
+    const float lo = fminf(m1, o1), hi = fmaxf(m1, o1);
+    m2 = fminf(hi, fminf(m2, o2));
+    m1 = lo;
+}
+
+// masks[cell * words + w]: one wave per cell, lanes strided over the centroids (k >= 2)
+__global__ __launch_bounds__(kBlock) void k_meld_candidates(const CellBounds *__restrict__ bounds,
+                                                            const Centroid *__restrict__ cent, uint32_t k,
+                                                            uint64_t *__restrict__ masks)
+{
+    const uint32_t cell = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t words = (k + 63u) / 64u;
+    const CellBounds cb = bounds[cell];
+    float u1 = 3.0e38f, u2 = 3.0e38f;                              // the two smallest upper bounds
+    for (uint32_t j = lane; j < k; j += 64) {
+        const Centroid c = cent[j];
+        merge_two_smallest(u1, u2, cie94_upper_bound(cb, c.L, c.a, c.b, c.C), 3.0e38f);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const float o1 = __shfl_xor(u1, off, 64), o2 = __shfl_xor(u2, off, 64);
+        merge_two_smallest(u1, u2, o1, o2);
+    }
+    uint64_t *out = masks + (uint64_t)cell * words;
+    for (uint32_t w = 0; w < words; ++w) {
+        const uint32_t j = w * 64 + lane;
+        bool keep = false;
+        if (j < k) {
+            const Centroid c = cent[j];
+            keep = cie94_lower_bound(cb, c.L, c.a, c.b, c.C) <= u2;
+        }
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) out[w] = m;
+    }
+}
+
+hipError_t launch_meld_candidates(const CellBounds *bounds, const Centroid *cent, uint32_t k, uint64_t *masks, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_meld_candidates, dim3(kCells / (kBlock / 64)), dim3(kBlock), 0, st, bounds, cent, k, masks);
+    return hipGetLastError();
+}
+
+// test support: violations += #colours whose two closest centroids (mix_colors.wgsl:29-48) differ between
+// the scan of all centroids and the scan of the cell's candidates
+__global__ __launch_bounds__(kBlock) void k_check_meld_masks(const Centroid *__restrict__ cent, uint32_t k,
+                                                             const uint64_t *__restrict__ masks,
+                                                             const float *__restrict__ lut,
+                                                             unsigned long long *__restrict__ violations)
+{
+    __shared__ float s_lut[256];
+    s_lut[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    const uint32_t cell = blockIdx.x;
+    const uint32_t words = (k + 63u) / 64u;
+    unsigned long long bad = 0;
+    for (uint32_t c = threadIdx.x; c < kCellColours; c += kBlock) {
+        float L, a, b;
+        colour_to_lab(s_lut, cell * kCellColours + c, L, a, b);
+        const float d0 = cie94(L, a, b, 10000.0f, 10000.0f, 10000.0f);
+        float dc = d0, ds = d0, pc = d0, ps = d0;
+        uint32_t ic = k, is = k, jc = k, js = k;
+        for (uint32_t j = 0; j < k; ++j) {
+            const Centroid ce = cent[j];
+            const float d = cie94(L, a, b, ce.L, ce.a, ce.b);
+            if (d < dc) { ds = dc; is = ic; dc = d; ic = j; } else if (d < ds) { ds = d; is = j; }
+            const unsigned long long m = masks[(uint64_t)cell * words + j / 64u];
+            if ((m >> (j & 63u)) & 1ull) {
+                if (d < pc) { ps = pc; js = jc; pc = d; jc = j; } else if (d < ps) { ps = d; js = j; }
+            }
+        }
+        bad += (ic != jc) || (is != js);
+    }
+    if (bad) atomicAdd(violations, bad);
+}
+
+hipError_t launch_check_meld_masks(const Centroid *cent, uint32_t k, const uint64_t *masks, const float *lut,
+                                   unsigned long long *violations, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_check_meld_masks, dim3(kCells), dim3(kBlock), 0, st, cent, k, masks, lut, violations);
+    return hipGetLastError();
+}
+
 // test support: violations += #(colour, Bayer index) whose brute-force dither arg-min (sentinel
 // included) differs from the arg-min over the candidates of its (cell, Bayer index)
 __global__ __launch_bounds__(kBlock) void k_check_offset_masks(const Centroid *__restrict__ cent, uint32_t k,

@@ -68,7 +68,7 @@ SYMBOLS = [
     "kmg_lloyd_get_centroids", "kmg_lloyd_init_centroids", "kmg_lloyd_init_step", "kmg_lloyd_init_pick_band",
     "kmg_lloyd_set_centroid_rgba", "kmg_init_first_key", "kmg_lloyd_assign_accumulate",
     "kmg_lloyd_assign_partials", "kmg_lloyd_reduce_partials", "kmg_lloyd_labels", "kmg_lloyd_bind_image",
-    "kmg_lloyd_unbind_image", "kmg_lloyd_prepare", "kmg_debug_check_table", "kmg_debug_table_stats", "kmg_debug_check_pairs", "kmg_debug_check_dither_masks", "kmg_kernel_name",
+    "kmg_lloyd_unbind_image", "kmg_lloyd_prepare", "kmg_debug_check_table", "kmg_debug_table_stats", "kmg_debug_check_pairs", "kmg_debug_check_dither_masks", "kmg_debug_check_meld_masks", "kmg_kernel_name",
     "kmg_lloyd_profile", "kmg_lloyd_profile_read",
     "kmg_lloyd_update", "kmg_lloyd_converged_count", "kmg_lloyd_run", "kmg_dev_apply",
     "kmg_dither_threshold",
@@ -131,6 +131,7 @@ def lib():
     L.kmg_debug_table_stats.argtypes = [vp, C.POINTER(C.c_uint64), vp]
     L.kmg_debug_check_pairs.argtypes = [vp, C.POINTER(C.c_uint64), vp]
     L.kmg_debug_check_dither_masks.argtypes = [vp, f32p, C.c_uint32, C.POINTER(C.c_uint64), vp]
+    L.kmg_debug_check_meld_masks.argtypes = [vp, f32p, C.c_uint32, C.POINTER(C.c_uint64), vp]
     L.kmg_kernel_name.argtypes = [C.c_int]
     L.kmg_kernel_name.restype = C.c_char_p
     L.kmg_lloyd_profile.argtypes = [vp, C.c_int]
@@ -288,6 +289,13 @@ class ImageProcessor:
         c = np.ascontiguousarray(centroids4, np.float32).reshape(-1, 4)
         v = C.c_uint64()
         _check(lib().kmg_debug_check_dither_masks(self._h, _np_ptr(c), c.shape[0], C.byref(v), C.c_void_p(stream)))
+        return int(v.value)
+
+    def debug_check_meld_masks(self, centroids4, stream=0):
+        """exhaustive check of the pruned meld pass's candidate masks; returns the violation count"""
+        c = np.ascontiguousarray(centroids4, np.float32).reshape(-1, 4)
+        v = C.c_uint64()
+        _check(lib().kmg_debug_check_meld_masks(self._h, _np_ptr(c), c.shape[0], C.byref(v), C.c_void_p(stream)))
         return int(v.value)
 
 

@@ -533,3 +533,37 @@ def test_buffer_reused_for_a_second_image(torch_cuda, oracle, monkeypatch):
         assert np.array_equal(labels.cpu().numpy().view(np.uint32), want_l), seed
     s.close()
     p.close()
+
+
+def test_meld_masks_conservative_for_all_colours(torch_cuda, processor, oracle):
+    """pruned meld pass: over all 2^24 colours the two closest centroids found among the cell's candidates
+    are the two closest of the full ordered scan"""
+    rng = np.random.default_rng(13)
+    for name, cent in _centroid_sets(oracle, rng).items():
+        if cent.shape[0] < 2:
+            continue
+        assert processor.debug_check_meld_masks(cent, _stream(torch_cuda)) == 0, name
+
+
+@pytest.mark.parametrize("k", [2, 5, 46, 64, 65, 300])
+def test_meld_output_pass_pruned_equals_scan(torch_cuda, oracle, monkeypatch, k):
+    """find / reduce in meld mode: candidate-pruned pass (forced) is byte-identical to the scan of all
+    centroids (the oracle comparison of the scan itself is tests/test_gpu_parity.py::test_meld_matches_oracle)"""
+    import kmeans_gpu_amd as kg
+    torch = torch_cuda
+    w, h = 801, 600
+    img = _blobs(np.random.default_rng(200 + k), w * h, 25, sigma=25.0).reshape(h, w, 4)
+    pal = np.array(sorted(set(map(tuple, oracle.synth_uniform(k + 11, k)))), np.uint8)
+    cent = kg.palette_to_centroids(pal)
+    d = _dev(torch, img.reshape(-1, 4))
+    st = _stream(torch)
+    outs = {}
+    for strategy in ("brute", "table"):
+        monkeypatch.setenv("KMG_STRATEGY", strategy)
+        p = kg.ImageProcessor()
+        out = torch.zeros((w * h, 4), dtype=torch.uint8, device="cuda")
+        p.apply(d.data_ptr(), w, h, 0, cent, kg.ReduceMode.Meld, out.data_ptr(), st)
+        torch.cuda.synchronize()
+        outs[strategy] = out.cpu().numpy()
+        p.close()
+    assert np.array_equal(outs["brute"], outs["table"])

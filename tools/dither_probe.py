@@ -42,3 +42,15 @@ for name, pal in (("resurrect64", pal64), ("random16", rng.integers(0, 256, (16,
             proc.close()
         same = bool(torch.equal(res["brute"][1], res["table"][1]))
         print(f"{name} {iname} {w}x{h}: scan {res['brute'][0]:.3f} ms, pruned {res['table'][0]:.3f} ms, identical {same}")
+        if (w, h) in ((W, W), (2048, 2048)):
+            meld = {}
+            for strat in ("brute", "table"):
+                os.environ["KMG_STRATEGY"] = strat
+                proc = kg.ImageProcessor(shrink_max_dim=0)
+                proc.apply(img.data_ptr(), w, h, 0, cent, kg.ReduceMode.Meld, out.data_ptr(), st)
+                torch.cuda.synchronize(); t = time.perf_counter()
+                proc.apply(img.data_ptr(), w, h, 0, cent, kg.ReduceMode.Meld, out.data_ptr(), st)
+                torch.cuda.synchronize()
+                meld[strat] = ((time.perf_counter() - t) * 1e3, out[: w * h].clone())
+                proc.close()
+            print(f"   meld {w}x{h}: scan {meld['brute'][0]:.3f} ms, pruned {meld['table'][0]:.3f} ms, identical {bool(torch.equal(meld['brute'][1], meld['table'][1]))}")
