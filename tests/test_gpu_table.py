@@ -567,3 +567,30 @@ def test_meld_output_pass_pruned_equals_scan(torch_cuda, oracle, monkeypatch, k)
         outs[strategy] = out.cpu().numpy()
         p.close()
     assert np.array_equal(outs["brute"], outs["table"])
+
+
+def test_partitioned_histogram_with_crowded_partitions(torch_cuda, oracle, monkeypatch):
+    """> 2^21 pixels in very few colours: colour partitions larger than one histogram chunk (the multi-chunk,
+    atomic-merge path of the partitioned build), many exact ties in the colour-based init"""
+    import kmeans_gpu_amd as kg
+    torch = torch_cuda
+    st = _stream(torch)
+    monkeypatch.setenv("KMG_STRATEGY", "table")
+    w, h, k = 2048, 1537, 4
+    rng = np.random.default_rng(77)
+    pal = np.array([[10, 20, 30, 255], [10, 20, 31, 255], [200, 100, 50, 255], [0, 0, 0, 255], [255, 255, 255, 255]], np.uint8)
+    img = pal[rng.choice(5, size=(h, w), p=[0.5, 0.3, 0.1, 0.05, 0.05])]
+    lab = oracle.rgb_to_lab(img)
+    want_init = oracle.init_centroids(lab, w, h, k)
+    want_c, want_l, _ = oracle.lloyd(lab, want_init)
+    d = _dev(torch, img.reshape(-1, 4))
+    p = kg.ImageProcessor(shrink_max_dim=0)
+    s = kg.Lloyd(p, k)
+    s.init_centroids(d.data_ptr(), w, h, st)
+    assert np.array_equal(s.get_centroids(st).view(np.uint32), want_init.view(np.uint32))
+    labels = torch.zeros(w * h, dtype=torch.int32, device="cuda")
+    s.run(d.data_ptr(), w * h, labels.data_ptr(), st)
+    assert np.array_equal(s.get_centroids(st).view(np.uint32), want_c.view(np.uint32))
+    assert np.array_equal(labels.cpu().numpy().view(np.uint32), want_l)
+    s.close()
+    p.close()
