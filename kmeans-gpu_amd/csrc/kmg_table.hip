@@ -23,7 +23,7 @@ __device__ __forceinline__ void abs_range(float x0, float x1, float c, float &m,
 {
     const float d0 = x0 - c, d1 = x1 - c;                  // d0 <= d1 (rounding is monotone)
     M = fmaxf(fabsf(d0), fabsf(d1));
-    m = d0 > 0.0f ? d0 : (d1 < 0.0f ? -d1 : 0.0f);
+    m = fmaxf(fmaxf(d0, -d1), 0.0f);                       // d0 if the interval is above c, -d1 if below, 0 if it straddles c (one v_max3)
 }
 
 // [min, max] of cie94_key(pixel, c) over all pixels whose terms lie inside the cell bounds
