@@ -589,7 +589,11 @@ __global__ __launch_bounds__(1024) void k_work_list(const int64_t *__restrict__ 
     constexpr uint32_t PER = kCells / 1024;                        // 32 consecutive cells per thread
     const uint32_t c0 = threadIdx.x * PER;
     uint32_t occupied = 0;                                         // bit i = cell c0 + i has pixels
-    for (uint32_t i = 0; i < PER; ++i) occupied |= (agg[4ull * (c0 + i) + 3] != 0 ? 1u : 0u) << i;
+    long long cnt[PER];
+#pragma unroll
+    for (uint32_t i = 0; i < PER; ++i) cnt[i] = agg[4ull * (c0 + i) + 3];      // all 32 loads in flight
+#pragma unroll
+    for (uint32_t i = 0; i < PER; ++i) occupied |= (cnt[i] != 0 ? 1u : 0u) << i;
     const uint32_t mine = (uint32_t)__builtin_popcount(occupied);
     s_n[threadIdx.x] = mine;
     __syncthreads();
