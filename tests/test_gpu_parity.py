@@ -283,3 +283,27 @@ def test_reduce_meld_end_to_end(processor, oracle, tokyo):
     want = oracle.reduce(tokyo, 6, oracle.MODE_MELD)
     diff = np.abs(got.astype(int) - want.astype(int))
     assert diff.max() <= 1 and (diff > 0).mean() <= 1e-5
+
+
+@pytest.mark.parametrize("w,h", [(16385, 3), (5, 9001)])
+def test_images_beyond_the_reference_texture_limit(processor, oracle, w, h):
+    """the reference stops at 8192 px per side (README.md:9-11, wgpu texture limit); this library has no
+    such limit: reduce / find of a 16385-wide and a 9001-tall image equal the oracle"""
+    import kmeans_gpu_amd as kg
+    rng = np.random.default_rng(w)
+    img = _gradient_noise(rng, w, h)
+    for mode, omode in ((kg.ReduceMode.Replace, oracle.MODE_REPLACE), (kg.ReduceMode.Dither, oracle.MODE_DITHER)):
+        got = processor.reduce(5, img, kg.Algorithm.Kmeans, mode)
+        assert np.array_equal(got, oracle.reduce(img, 5, omode))
+    pal = np.array([[0, 0, 0, 255], [255, 255, 255, 255], [128, 64, 32, 255]], np.uint8)
+    assert np.array_equal(processor.find(img, pal, kg.ReduceMode.Dither), oracle.find(img, pal, oracle.MODE_DITHER))
+
+
+def _gradient_noise(rng, w, h):
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.zeros((h, w, 4), np.uint8)
+    img[..., 0] = (xx * 255 // max(w - 1, 1)).astype(np.uint8)
+    img[..., 1] = (yy * 255 // max(h - 1, 1)).astype(np.uint8)
+    img[..., 2] = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    img[..., 3] = 255
+    return img
