@@ -594,3 +594,82 @@ def test_partitioned_histogram_with_crowded_partitions(torch_cuda, oracle, monke
     assert np.array_equal(labels.cpu().numpy().view(np.uint32), want_l)
     s.close()
     p.close()
+
+
+def test_cfg2_full_size_assign_update(torch_cuda, oracle, monkeypatch):
+    """BASELINE config 2: synthetic 4096x4096, k=16, assign + update only -- four iterations with each
+    strategy: identical labels / sums / centroids, the size-independent properties, a prefix vs the oracle"""
+    import kmeans_gpu_amd as kg
+    from kmeans_gpu_amd import synth
+    torch = torch_cuda
+    st = _stream(torch)
+    w = h = 4096
+    n, k = w * h, 16
+    rgba = synth.uniform_rgba_torch(synth.SEED_CFG2, n, device="cuda")
+    sel = synth.uniform_rgba_at(synth.SEED_CFG2, np.arange(k, dtype=np.uint64) * np.uint64(n // k))
+    cent0 = oracle.centroids4(oracle.rgb_to_lab(sel))
+    res = {}
+    for strategy in ("brute", "table"):
+        monkeypatch.setenv("KMG_STRATEGY", strategy)
+        p = kg.ImageProcessor(shrink_max_dim=0)
+        s = kg.Lloyd(p, k)
+        s.set_centroids(cent0, st)
+        assert s.prepare(rgba.data_ptr(), n, True, st) == ("table" if strategy == "table" else "scan")
+        labels = torch.zeros(n, dtype=torch.int32, device="cuda")
+        acc = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
+        for _ in range(4):
+            s.assign_accumulate(rgba.data_ptr(), n, labels.data_ptr(), acc.data_ptr(), st)
+            s.update(acc.data_ptr(), st)
+        torch.cuda.synchronize()
+        res[strategy] = (labels, acc.clone(), s.get_centroids(st))
+        s.close()
+        p.close()
+    (l0, a0, c0), (l1, a1, c1) = res["brute"], res["table"]
+    assert torch.equal(l0, l1) and torch.equal(a0, a1) and np.array_equal(c0.view(np.uint32), c1.view(np.uint32))
+    assert int(a1[:, 3].sum()) == n and int(l1.max()) < k
+    assert int(torch.bincount(l1.to(torch.int64), minlength=k).sum()) == n
+    # the whole run on the oracle (16.7 M pixels x 16 centroids x 4 passes: seconds with OpenMP)
+    host = rgba.cpu().numpy()
+    cent = cent0
+    for _ in range(4):
+        want_l, want_a = oracle.assign_accumulate_rgba(host, cent)
+        cent, _ = oracle.finalize(want_a, cent)
+    assert np.array_equal(l1.cpu().numpy().view(np.uint32), want_l)
+    assert np.array_equal(a1.cpu().numpy(), want_a)
+    assert np.array_equal(c1.view(np.uint32), cent.view(np.uint32))
+
+
+def test_cfg5_full_size_find_dither(torch_cuda, oracle, monkeypatch):
+    """BASELINE config 5: find + ordered dither with the 64-entry resurrect_64 palette on synthetic
+    8192x8192: pruned pass == scan of all centroids, every output pixel is a palette colour, the first
+    rows equal the oracle"""
+    import kmeans_gpu_amd as kg
+    from kmeans_gpu_amd import synth
+    from PIL import Image
+    import os
+    torch = torch_cuda
+    st = _stream(torch)
+    w = h = 8192
+    n = w * h
+    px = np.array(Image.open(os.path.join(os.path.dirname(__file__), "golden", "resurrect_64.png")).convert("RGBA")).reshape(-1, 4)
+    pal = np.array(sorted(set(map(tuple, px))), np.uint8)
+    assert pal.shape[0] == 64
+    cent = kg.palette_to_centroids(pal)
+    rgba = synth.uniform_rgba_torch(synth.SEED_CFG5, n, device="cuda")
+    outs = {}
+    for strategy in ("brute", "table"):
+        monkeypatch.setenv("KMG_STRATEGY", strategy)
+        p = kg.ImageProcessor()
+        out = torch.zeros((n, 4), dtype=torch.uint8, device="cuda")
+        p.apply(rgba.data_ptr(), w, h, 0, cent, kg.ReduceMode.Dither, out.data_ptr(), st)
+        torch.cuda.synchronize()
+        outs[strategy] = out
+        p.close()
+    assert torch.equal(outs["brute"], outs["table"])
+    used = torch.unique(outs["table"].view(torch.int32)).cpu().numpy().view(np.uint32)
+    # dither emits lab_to_rgb(centroid): at most 64 distinct colours
+    assert used.size <= 64
+    rows = 4
+    head = rgba[: rows * w].cpu().numpy().reshape(rows, w, 4)
+    want = oracle.find(head, pal, oracle.MODE_DITHER)
+    assert np.array_equal(outs["table"][: rows * w].cpu().numpy().reshape(rows, w, 4), want)
