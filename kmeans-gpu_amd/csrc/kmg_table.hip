@@ -503,11 +503,12 @@ __global__ __launch_bounds__(1024) void k_init_reduce_cells(const unsigned long 
                                                             Centroid *__restrict__ cent, uint32_t j)
 {
     __shared__ unsigned long long s_key[16];
+    unsigned long long v[kCells / 1024];
+#pragma unroll
+    for (uint32_t i = 0; i < kCells / 1024; ++i) v[i] = cell_key[i * 1024 + threadIdx.x];   // 32 loads in flight
     unsigned long long best = 0ull;
-    for (uint32_t i = threadIdx.x; i < kCells; i += 1024) {
-        const unsigned long long v = cell_key[i];
-        best = v > best ? v : best;
-    }
+#pragma unroll
+    for (uint32_t i = 0; i < kCells / 1024; ++i) best = v[i] > best ? v[i] : best;
     for (int off = 32; off > 0; off >>= 1) {
         const unsigned long long o = __shfl_xor(best, off, 64);
         best = o > best ? o : best;
