@@ -12,7 +12,12 @@
 //                                (precomputed cell sums); otherwise every colour is scanned
 //                                against the candidates only.  Writes label-per-colour (LUT)
 //                                and the per-workgroup partial sums.
-//                             3. k_labels -- labels[i] = LUT[colour(pixel i)]  (4 B in, 4 B out)
+//                             3. k_labels -- labels[i] = LUT[colour(pixel i)]  (4 B in, 4 B out); for
+//                                k <= 256 most pixels are resolved from a per-cell plane + slab entry
+//                                held in LDS (pair entries below), the rest gathers from the LUT
+// The same machinery (static cell bounds, monotone interval evaluation) also serves, on large images,
+// the farthest-point initialisation over the image's colours and the candidate-pruned dither and meld
+// output passes; all of them are bit-identical to the per-pixel kernels of kmg_kernels.hip.
 #pragma once
 
 #include <hip/hip_runtime.h>
