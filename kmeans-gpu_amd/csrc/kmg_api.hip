@@ -510,7 +510,7 @@ extern "C" int kmg_debug_check_table(kmg_lloyd *s, uint64_t out[2], void *stream
     HIP_TRY(masks.alloc(sizeof(uint64_t) * (size_t)kCells * words));
     HIP_TRY(viol.alloc(2 * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(viol.ptr, 0, 2 * sizeof(unsigned long long), S(stream)));
-    HIP_TRY(launch_cell_candidates(s->p->d_bounds, nullptr, s->d_cent, s->k, (uint64_t *)masks.ptr, S(stream)));
+    HIP_TRY(launch_cell_candidates(s->p->d_bounds, nullptr, s->d_cent, s->k, (uint64_t *)masks.ptr, nullptr, S(stream)));
     HIP_TRY(launch_check_bounds(s->p->d_bounds, s->d_cent, s->k, (const uint64_t *)masks.ptr, s->p->d_lut,
                                 (unsigned long long *)viol.ptr, S(stream)));
     unsigned long long h[2];
@@ -676,7 +676,7 @@ static int table_assign(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_
 {
     ColourTable &t = s->tab;
     (void)sums;
-    PROF_LAUNCH(s, KMG_K_CANDIDATES, st, launch_cell_candidates(s->p->d_bounds, t.d_agg, s->d_cent, s->k, t.d_masks, st));
+    PROF_LAUNCH(s, KMG_K_CANDIDATES, st, launch_cell_candidates(s->p->d_bounds, t.d_agg, s->d_cent, s->k, t.d_masks, s->d_partials, st));
     PROF_LAUNCH(s, KMG_K_CUBE, st, launch_cube(t.d_hist, t.d_agg, t.d_masks, t.d_work, s->d_cent, s->k, s->p->d_lab_table,
                                                t.d_colour_labels, t.d_sub, s->d_partials, st));
     t.tables_valid = true;
@@ -937,7 +937,7 @@ extern "C" uint64_t kmg_init_first_key(uint32_t width, uint32_t height)
 static int assign_pass(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_t *d_labels, bool sums, hipStream_t st)
 {
     if (table_bound(s, d_rgba, n)) {
-        s->last_rows = kCubeGrid;
+        s->last_rows = kMergeRows;
         return table_assign(s, d_rgba, n, d_labels, sums, st);
     }
     s->last_rows = assign_grid(n);
@@ -1154,7 +1154,7 @@ extern "C" int kmg_dev_apply(kmg_processor *p, const uint8_t *d_rgba, uint32_t w
             e = masks.alloc(sizeof(uint64_t) * (size_t)kCells * mask_words(k), S(stream));
             if (e == hipSuccess) e = colour_labels.alloc((size_t)(k <= 256 ? 1 : 2) << 24, S(stream));
             if (e == hipSuccess) e = sub.alloc(sub_bytes, S(stream));
-            if (e == hipSuccess) e = launch_cell_candidates(p->d_bounds, nullptr, d_cent, k, (uint64_t *)masks.ptr, S(stream));
+            if (e == hipSuccess) e = launch_cell_candidates(p->d_bounds, nullptr, d_cent, k, (uint64_t *)masks.ptr, nullptr, S(stream));
             if (e == hipSuccess)
                 e = launch_cube(nullptr, nullptr, (const uint64_t *)masks.ptr, nullptr, d_cent, k, p->d_lab_table,
                                 colour_labels.ptr, (uint16_t *)sub.ptr, nullptr, S(stream));

@@ -30,7 +30,8 @@ namespace kmg {
 constexpr uint32_t kCells = 32768;        // 32^3 cells of 8x8x8 colours
 constexpr uint32_t kCellColours = 512;
 constexpr uint32_t kSubCells = kCells * 8;  // 4x4x4 sub-cells (64 colours)
-constexpr uint32_t kCubeGrid = 2048;      // persistent workgroups of k_cube (rows of the partial slab)
+constexpr uint32_t kCubeGrid = 2048;      // persistent workgroups of k_cube
+constexpr uint32_t kMergeRows = 64;       // rows of the partial slab the cube workgroups add their sums into
 
 // sub-cell table entry (u16): a label, or one of
 constexpr uint16_t kSubEmpty = 0xFFFF;    // no pixel of the image has a colour in this sub-cell
@@ -136,8 +137,9 @@ hipError_t launch_init_pass_cells(const uint32_t *work, const uint32_t *tie, con
                                   unsigned long long *cell_key, unsigned long long *key,
                                   const uint32_t *pick_rgba, const float *lut, hipStream_t st);
 // per iteration
+// merge_rows (optional): the kMergeRows x k x 4 int64 accumulators of the cube pass that follows, cleared here
 hipError_t launch_cell_candidates(const CellBounds *bounds, const int64_t *agg, const Centroid *cent,
-                                  uint32_t k, uint64_t *masks, hipStream_t st);
+                                  uint32_t k, uint64_t *masks, int64_t *merge_rows, hipStream_t st);
 // work: [0] = number of occupied cells of the bound image, [1..] = their indices (built at bind time):
 // the cube pass walks a dense list and issues all loads of a cell at once
 hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const uint64_t *masks, const uint32_t *work,

@@ -622,8 +622,14 @@ hipError_t launch_work_list(const int64_t *agg, uint32_t *work, hipStream_t st)
 __global__ __launch_bounds__(kBlock) void k_cell_candidates(const CellBounds *__restrict__ bounds,
                                                             const int64_t *__restrict__ agg,
                                                             const Centroid *__restrict__ cent, uint32_t k,
-                                                            uint64_t *__restrict__ masks)
+                                                            uint64_t *__restrict__ masks,
+                                                            unsigned long long *__restrict__ merge_rows)
 {
+    // the cube pass that follows adds its per-workgroup sums into kMergeRows x k x 4 accumulators: clear them
+    if (merge_rows) {
+        const uint32_t total = kMergeRows * 4u * k;
+        for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) merge_rows[i] = 0ull;
+    }
     const uint32_t cell = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t words = (k + 63u) / 64u;
@@ -674,10 +680,10 @@ __global__ __launch_bounds__(kBlock) void k_cell_candidates(const CellBounds *__
 }
 
 hipError_t launch_cell_candidates(const CellBounds *bounds, const int64_t *agg, const Centroid *cent,
-                                  uint32_t k, uint64_t *masks, hipStream_t st)
+                                  uint32_t k, uint64_t *masks, int64_t *merge_rows, hipStream_t st)
 {
     hipLaunchKernelGGL(k_cell_candidates, dim3(kCells / (kBlock / 64)), dim3(kBlock), 0, st, bounds, agg,
-                       cent, k, masks);
+                       cent, k, masks, reinterpret_cast<unsigned long long *>(merge_rows));
     return hipGetLastError();
 }
 
@@ -976,8 +982,13 @@ __global__ __launch_bounds__(kBlock) void k_cube(const uint32_t *__restrict__ hi
 
     if (SUMS) {
         __syncthreads();
-        unsigned long long *row = reinterpret_cast<unsigned long long *>(partials) + (uint64_t)blockIdx.x * 4ull * k;
-        for (uint32_t i = threadIdx.x; i < 4 * k; i += kBlock) row[i] = bins[i];
+        // only the clusters this workgroup met are non-zero: add them into one of kMergeRows shared rows
+        // (cleared by k_cell_candidates) instead of writing, and later re-reading, a full row per workgroup
+        unsigned long long *row = reinterpret_cast<unsigned long long *>(partials) + (uint64_t)(blockIdx.x % kMergeRows) * 4ull * k;
+        for (uint32_t i = threadIdx.x; i < 4 * k; i += kBlock) {
+            const unsigned long long v = bins[i];
+            if (v) atomicAdd(row + i, v);
+        }
     }
 }
 
