@@ -510,7 +510,7 @@ extern "C" int kmg_debug_check_table(kmg_lloyd *s, uint64_t out[2], void *stream
     HIP_TRY(masks.alloc(sizeof(uint64_t) * (size_t)kCells * words));
     HIP_TRY(viol.alloc(2 * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(viol.ptr, 0, 2 * sizeof(unsigned long long), S(stream)));
-    HIP_TRY(launch_cell_candidates(s->p->d_bounds, nullptr, s->d_cent, s->k, (uint64_t *)masks.ptr, nullptr, S(stream)));
+    HIP_TRY(launch_cell_candidates(s->p->d_bounds, nullptr, s->d_cent, s->k, (uint64_t *)masks.ptr, nullptr, 0, S(stream)));
     HIP_TRY(launch_check_bounds(s->p->d_bounds, s->d_cent, s->k, (const uint64_t *)masks.ptr, s->p->d_lut,
                                 (unsigned long long *)viol.ptr, S(stream)));
     unsigned long long h[2];
@@ -671,14 +671,16 @@ static bool table_bound(const kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n)
     return s->tab.rgba != nullptr && s->tab.rgba == d_rgba && s->tab.n == n;
 }
 
-// labels (optional) + partial sums through the colour table
-static int table_assign(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_t *d_labels, bool sums, hipStream_t st)
+// labels (optional) + sums through the colour table.  The cube workgroups add their sums into `rows` shared
+// rows of `d_sums` (k x 4 int64 each): the caller's accumulators directly (rows = 1, no reduction pass), or
+// the partial slab for the two-step entry points.
+static int table_assign(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_t *d_labels, int64_t *d_sums,
+                        uint32_t rows, hipStream_t st)
 {
     ColourTable &t = s->tab;
-    (void)sums;
-    PROF_LAUNCH(s, KMG_K_CANDIDATES, st, launch_cell_candidates(s->p->d_bounds, t.d_agg, s->d_cent, s->k, t.d_masks, s->d_partials, st));
+    PROF_LAUNCH(s, KMG_K_CANDIDATES, st, launch_cell_candidates(s->p->d_bounds, t.d_agg, s->d_cent, s->k, t.d_masks, d_sums, rows, st));
     PROF_LAUNCH(s, KMG_K_CUBE, st, launch_cube(t.d_hist, t.d_agg, t.d_masks, t.d_work, s->d_cent, s->k, s->p->d_lab_table,
-                                               t.d_colour_labels, t.d_sub, s->d_partials, st));
+                                               t.d_colour_labels, t.d_sub, d_sums, rows, st));
     t.tables_valid = true;
     if (d_labels)
         PROF_LAUNCH(s, KMG_K_LABELS, st, launch_labels((const uint32_t *)d_rgba, n, t.d_colour_labels, t.d_sub, s->k, nullptr, d_labels, st));
@@ -938,7 +940,7 @@ static int assign_pass(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_t
 {
     if (table_bound(s, d_rgba, n)) {
         s->last_rows = kMergeRows;
-        return table_assign(s, d_rgba, n, d_labels, sums, st);
+        return table_assign(s, d_rgba, n, d_labels, s->d_partials, kMergeRows, st);
     }
     s->last_rows = assign_grid(n);
     PROF_LAUNCH(s, KMG_K_ASSIGN, st, launch_assign((const uint32_t *)d_rgba, n, s->d_cent, s->k, s->p->d_lut, d_labels,
@@ -952,6 +954,8 @@ extern "C" int kmg_lloyd_assign_accumulate(kmg_lloyd *s, const uint8_t *d_rgba, 
     if (!s || !d_rgba || n == 0 || (!d_labels && !d_acc4))
         return fail(KMG_ERR_INVALID_ARGUMENT, "bad assign_accumulate arguments");
     HIP_TRY(hipSetDevice(s->p->device));
+    if (d_acc4 && table_bound(s, d_rgba, n))        // the cube pass adds straight into d_acc4: no reduction pass
+        return table_assign(s, d_rgba, n, d_labels, d_acc4, 1u, S(stream));
     int rc;
     if ((rc = assign_pass(s, d_rgba, n, d_labels, d_acc4 != nullptr, S(stream))) != KMG_OK) return rc;
     if (d_acc4) PROF_LAUNCH(s, KMG_K_REDUCE, S(stream), launch_reduce_partials(s->d_partials, s->last_rows, s->k, d_acc4, S(stream)));
@@ -1154,10 +1158,10 @@ extern "C" int kmg_dev_apply(kmg_processor *p, const uint8_t *d_rgba, uint32_t w
             e = masks.alloc(sizeof(uint64_t) * (size_t)kCells * mask_words(k), S(stream));
             if (e == hipSuccess) e = colour_labels.alloc((size_t)(k <= 256 ? 1 : 2) << 24, S(stream));
             if (e == hipSuccess) e = sub.alloc(sub_bytes, S(stream));
-            if (e == hipSuccess) e = launch_cell_candidates(p->d_bounds, nullptr, d_cent, k, (uint64_t *)masks.ptr, nullptr, S(stream));
+            if (e == hipSuccess) e = launch_cell_candidates(p->d_bounds, nullptr, d_cent, k, (uint64_t *)masks.ptr, nullptr, 0, S(stream));
             if (e == hipSuccess)
                 e = launch_cube(nullptr, nullptr, (const uint64_t *)masks.ptr, nullptr, d_cent, k, p->d_lab_table,
-                                colour_labels.ptr, (uint16_t *)sub.ptr, nullptr, S(stream));
+                                colour_labels.ptr, (uint16_t *)sub.ptr, nullptr, 0, S(stream));
             if (e == hipSuccess)
                 e = launch_labels((const uint32_t *)d_rgba, n_px, colour_labels.ptr, (const uint16_t *)sub.ptr, k, d_pal,
                                   (uint32_t *)d_out, S(stream));

@@ -137,14 +137,15 @@ hipError_t launch_init_pass_cells(const uint32_t *work, const uint32_t *tie, con
                                   unsigned long long *cell_key, unsigned long long *key,
                                   const uint32_t *pick_rgba, const float *lut, hipStream_t st);
 // per iteration
-// merge_rows (optional): the kMergeRows x k x 4 int64 accumulators of the cube pass that follows, cleared here
+// merge_rows (optional): the n_merge_rows x k x 4 int64 accumulators of the cube pass that follows, cleared here
 hipError_t launch_cell_candidates(const CellBounds *bounds, const int64_t *agg, const Centroid *cent,
-                                  uint32_t k, uint64_t *masks, int64_t *merge_rows, hipStream_t st);
+                                  uint32_t k, uint64_t *masks, int64_t *merge_rows, uint32_t n_merge_rows, hipStream_t st);
 // work: [0] = number of occupied cells of the bound image, [1..] = their indices (built at bind time):
-// the cube pass walks a dense list and issues all loads of a cell at once
+// the cube pass walks a dense list and issues all loads of a cell at once.  Every workgroup adds the sums of
+// the clusters it met into row (workgroup % n_merge_rows) of `partials` (n_merge_rows = 1: the final sums)
 hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const uint64_t *masks, const uint32_t *work,
                        const Centroid *cent, uint32_t k, const float4 *lab_table, void *colour_labels,
-                       uint16_t *sub_table, int64_t *partials, hipStream_t st);
+                       uint16_t *sub_table, int64_t *partials, uint32_t n_merge_rows, hipStream_t st);
 // pal == NULL: labels[i] = label; pal != NULL: labels[i] = pal[label] (RGBA8 output of replace mode).
 // launch_cube with hist == NULL labels every colour of every cell and accumulates nothing.
 hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_labels,

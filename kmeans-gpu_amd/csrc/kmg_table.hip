@@ -623,11 +623,11 @@ __global__ __launch_bounds__(kBlock) void k_cell_candidates(const CellBounds *__
                                                             const int64_t *__restrict__ agg,
                                                             const Centroid *__restrict__ cent, uint32_t k,
                                                             uint64_t *__restrict__ masks,
-                                                            unsigned long long *__restrict__ merge_rows)
+                                                            unsigned long long *__restrict__ merge_rows, uint32_t n_merge_rows)
 {
-    // the cube pass that follows adds its per-workgroup sums into kMergeRows x k x 4 accumulators: clear them
+    // the cube pass that follows adds its per-workgroup sums into n_merge_rows x k x 4 accumulators: clear them
     if (merge_rows) {
-        const uint32_t total = kMergeRows * 4u * k;
+        const uint32_t total = n_merge_rows * 4u * k;
         for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) merge_rows[i] = 0ull;
     }
     const uint32_t cell = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -680,10 +680,10 @@ __global__ __launch_bounds__(kBlock) void k_cell_candidates(const CellBounds *__
 }
 
 hipError_t launch_cell_candidates(const CellBounds *bounds, const int64_t *agg, const Centroid *cent,
-                                  uint32_t k, uint64_t *masks, int64_t *merge_rows, hipStream_t st)
+                                  uint32_t k, uint64_t *masks, int64_t *merge_rows, uint32_t n_merge_rows, hipStream_t st)
 {
     hipLaunchKernelGGL(k_cell_candidates, dim3(kCells / (kBlock / 64)), dim3(kBlock), 0, st, bounds, agg,
-                       cent, k, masks, reinterpret_cast<unsigned long long *>(merge_rows));
+                       cent, k, masks, reinterpret_cast<unsigned long long *>(merge_rows), n_merge_rows);
     return hipGetLastError();
 }
 
@@ -829,7 +829,7 @@ __global__ __launch_bounds__(kBlock) void k_cube(const uint32_t *__restrict__ hi
                                                  const float4 *__restrict__ lab_table,
                                                  LabelT *__restrict__ colour_labels,
                                                  uint16_t *__restrict__ sub_table,
-                                                 int64_t *__restrict__ partials)
+                                                 int64_t *__restrict__ partials, uint32_t n_merge_rows)
 {
     extern __shared__ float4 smem4[];
     const uint32_t kpad = (k + 3u) & ~3u;
@@ -982,9 +982,10 @@ __global__ __launch_bounds__(kBlock) void k_cube(const uint32_t *__restrict__ hi
 
     if (SUMS) {
         __syncthreads();
-        // only the clusters this workgroup met are non-zero: add them into one of kMergeRows shared rows
-        // (cleared by k_cell_candidates) instead of writing, and later re-reading, a full row per workgroup
-        unsigned long long *row = reinterpret_cast<unsigned long long *>(partials) + (uint64_t)(blockIdx.x % kMergeRows) * 4ull * k;
+        // only the clusters this workgroup met are non-zero: add them into one of n_merge_rows shared rows
+        // (cleared by k_cell_candidates) instead of writing, and later re-reading, a full row per workgroup;
+        // with one row the sums land directly in the caller's accumulators
+        unsigned long long *row = reinterpret_cast<unsigned long long *>(partials) + (uint64_t)(blockIdx.x % n_merge_rows) * 4ull * k;
         for (uint32_t i = threadIdx.x; i < 4 * k; i += kBlock) {
             const unsigned long long v = bins[i];
             if (v) atomicAdd(row + i, v);
@@ -994,14 +995,14 @@ __global__ __launch_bounds__(kBlock) void k_cube(const uint32_t *__restrict__ hi
 
 hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const uint64_t *masks, const uint32_t *work,
                        const Centroid *cent, uint32_t k, const float4 *lab_table, void *colour_labels, uint16_t *sub_table,
-                       int64_t *partials, hipStream_t st)
+                       int64_t *partials, uint32_t n_merge_rows, hipStream_t st)
 {
     const uint32_t kpad = (k + 3u) & ~3u;
     const bool sums = hist != nullptr;
     const size_t lds = sizeof(float4) * kpad + (sums ? sizeof(unsigned long long) * 4ull * k : 0);
 #define KMG_CUBE(T, S)                                                                                   \
     hipLaunchKernelGGL((k_cube<T, S>), dim3(kCubeGrid), dim3(kBlock), lds, st, hist, agg, masks, work, cent, k, \
-                       lab_table, (T *)colour_labels, sub_table, partials)
+                       lab_table, (T *)colour_labels, sub_table, partials, n_merge_rows ? n_merge_rows : 1u)
     if (k <= 256) { if (sums) KMG_CUBE(uint8_t, true); else KMG_CUBE(uint8_t, false); }
     else          { if (sums) KMG_CUBE(uint16_t, true); else KMG_CUBE(uint16_t, false); }
 #undef KMG_CUBE
