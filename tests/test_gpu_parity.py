@@ -307,3 +307,27 @@ def _gradient_noise(rng, w, h):
     img[..., 2] = rng.integers(0, 256, (h, w), dtype=np.uint8)
     img[..., 3] = 255
     return img
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_images_reduce_find_palette_match_oracle(processor, oracle, seed):
+    """random small images of awkward shapes through the host-buffer API against the oracle, byte for byte"""
+    import kmeans_gpu_amd as kg
+    rng = np.random.default_rng(1000 + seed)
+    w, h = int(rng.integers(1, 400)), int(rng.integers(1, 400))
+    kind = seed % 3
+    if kind == 0:
+        img = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    elif kind == 1:
+        pal = rng.integers(0, 256, (int(rng.integers(1, 7)), 4), dtype=np.uint8)
+        img = pal[rng.integers(0, pal.shape[0], (h, w))]
+    else:
+        img = _gradient_noise(rng, w, h)
+    img[..., 3] = 255
+    k = int(rng.choice([1, 2, 3, 6, 12, 40]))
+    for mode, omode in ((kg.ReduceMode.Replace, oracle.MODE_REPLACE), (kg.ReduceMode.Dither, oracle.MODE_DITHER)):
+        assert np.array_equal(processor.reduce(k, img, kg.Algorithm.Kmeans, mode), oracle.reduce(img, k, omode)), (w, h, k, mode)
+    assert np.array_equal(processor.palette(k, img, kg.Algorithm.Kmeans), oracle.palette(img, k))
+    colors = rng.integers(0, 256, (int(rng.integers(1, 20)), 4), dtype=np.uint8); colors[:, 3] = 255
+    for mode, omode in ((kg.ReduceMode.Replace, oracle.MODE_REPLACE), (kg.ReduceMode.Dither, oracle.MODE_DITHER)):
+        assert np.array_equal(processor.find(img, colors, mode), oracle.find(img, colors, omode)), (w, h, mode)
