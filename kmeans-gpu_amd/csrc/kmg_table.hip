@@ -58,6 +58,11 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v)
     return ((unsigned long long)hi << 32) | lo;
 }
 
+__device__ __forceinline__ float lane_value(float v, uint32_t src)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int)src));
+}
+
 __device__ __forceinline__ long long wave_sum(long long v)
 {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -630,59 +635,91 @@ __global__ __launch_bounds__(kBlock) void k_cell_candidates(const CellBounds *__
         const uint32_t total = n_merge_rows * 4u * k;
         for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) merge_rows[i] = 0ull;
     }
-    const uint32_t cell = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t words = (k + 63u) / 64u;
-    uint64_t *out = masks + (uint64_t)cell * words;
-    if (agg && agg[4ull * cell + 3] == 0) {                 // no pixel in this cell
-        for (uint32_t w = lane; w < words; w += 64) out[w] = 0ull;
-        return;
-    }
-    const CellBounds cb = bounds[cell];
-    float U = 3.0e38f;
+    const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * (kBlock / 64);
     if (words <= 4u) {
-        // k <= 256: one evaluation per centroid, the lower bounds wait in registers for U
-        float lo[4];
+        // k <= 256: a lane keeps its (up to) four centroids in registers for all the cells of the wave; one
+        // evaluation per (cell, centroid), the lower bounds wait in registers for U.  Lane i < 16 fetches float i
+        // of the NEXT cell's bounds while the current cell is evaluated.
+        Centroid c[4];
 #pragma unroll
         for (uint32_t w = 0; w < 4u; ++w) {
             const uint32_t j = w * 64 + lane;
-            lo[w] = 0.0f;
-            if (j < k) {
-                const Centroid c = cent[j];
-                const KeyRange r = key_range(cb, c.L, c.a, c.b, c.C);
-                lo[w] = r.lo;
-                U = fminf(U, r.hi);
-            }
+            c[w] = cent[j < k ? j : 0u];
         }
-        for (int off = 32; off > 0; off >>= 1) U = fminf(U, __shfl_xor(U, off, 64));
+        const float *bf = reinterpret_cast<const float *>(bounds);
+        float nb = wave < kCells ? bf[(uint64_t)wave * 16u + (lane & 15u)] : 0.0f;
+        long long ncount = (agg && wave < kCells) ? agg[4ull * wave + 3] : 1;
+        for (uint32_t cell = wave; cell < kCells; cell += n_waves) {
+            const float mine = nb;
+            const long long count = ncount;
+            const uint32_t next = cell + n_waves;
+            if (next < kCells) {
+                nb = bf[(uint64_t)next * 16u + (lane & 15u)];
+                if (agg) ncount = agg[4ull * next + 3];
+            }
+            uint64_t *out = masks + (uint64_t)cell * words;
+            if (count == 0) {                                   // no pixel in this cell
+                if (lane < words) out[lane] = 0ull;
+                continue;
+            }
+            CellBounds cb;
+            cb.L0 = lane_value(mine, 0); cb.L1 = lane_value(mine, 1); cb.a0 = lane_value(mine, 2); cb.a1 = lane_value(mine, 3);
+            cb.b0 = lane_value(mine, 4); cb.b1 = lane_value(mine, 5); cb.C0 = lane_value(mine, 6); cb.C1 = lane_value(mine, 7);
+            cb.wC0 = lane_value(mine, 8); cb.wC1 = lane_value(mine, 9); cb.wH0 = lane_value(mine, 10); cb.wH1 = lane_value(mine, 11);
+            float U = 3.0e38f, lo[4];
 #pragma unroll
-        for (uint32_t w = 0; w < 4u; ++w) {
-            const unsigned long long m = __ballot(w * 64 + lane < k && lo[w] <= U);
-            if (w < words && lane == 0) out[w] = m;
+            for (uint32_t w = 0; w < 4u; ++w) {
+                lo[w] = 0.0f;
+                if (w < words) {
+                    const KeyRange r = key_range(cb, c[w].L, c[w].a, c[w].b, c[w].C);
+                    lo[w] = r.lo;
+                    if (w * 64 + lane < k) U = fminf(U, r.hi);
+                }
+            }
+            for (int off = 32; off > 0; off >>= 1) U = fminf(U, __shfl_xor(U, off, 64));
+#pragma unroll
+            for (uint32_t w = 0; w < 4u; ++w) {
+                const unsigned long long m = __ballot(w * 64 + lane < k && lo[w] <= U);
+                if (w < words && lane == 0) out[w] = m;
+            }
         }
         return;
     }
-    for (uint32_t j = lane; j < k; j += 64) {
-        const Centroid c = cent[j];
-        U = fminf(U, key_range(cb, c.L, c.a, c.b, c.C).hi);
-    }
-    for (int off = 32; off > 0; off >>= 1) U = fminf(U, __shfl_xor(U, off, 64));
-    for (uint32_t w = 0; w < words; ++w) {
-        const uint32_t j = w * 64 + lane;
-        bool keep = false;
-        if (j < k) {
-            const Centroid c = cent[j];
-            keep = key_range(cb, c.L, c.a, c.b, c.C).lo <= U;
+    for (uint32_t cell = wave; cell < kCells; cell += n_waves) {
+        uint64_t *out = masks + (uint64_t)cell * words;
+        if (agg && agg[4ull * cell + 3] == 0) {
+            for (uint32_t w = lane; w < words; w += 64) out[w] = 0ull;
+            continue;
         }
-        const unsigned long long m = __ballot(keep);
-        if (lane == 0) out[w] = m;
+        const CellBounds cb = bounds[cell];
+        float U = 3.0e38f;
+        for (uint32_t j = lane; j < k; j += 64) {
+            const Centroid ce = cent[j];
+            U = fminf(U, key_range(cb, ce.L, ce.a, ce.b, ce.C).hi);
+        }
+        for (int off = 32; off > 0; off >>= 1) U = fminf(U, __shfl_xor(U, off, 64));
+        for (uint32_t w = 0; w < words; ++w) {
+            const uint32_t j = w * 64 + lane;
+            bool keep = false;
+            if (j < k) {
+                const Centroid ce = cent[j];
+                keep = key_range(cb, ce.L, ce.a, ce.b, ce.C).lo <= U;
+            }
+            const unsigned long long m = __ballot(keep);
+            if (lane == 0) out[w] = m;
+        }
     }
 }
 
 hipError_t launch_cell_candidates(const CellBounds *bounds, const int64_t *agg, const Centroid *cent,
                                   uint32_t k, uint64_t *masks, int64_t *merge_rows, uint32_t n_merge_rows, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_cell_candidates, dim3(kCells / (kBlock / 64)), dim3(kBlock), 0, st, bounds, agg,
+    // k <= 256: persistent waves (4 cells each) with the next cell's bounds prefetched; larger k: one cell per wave
+    const uint32_t grid = k <= 256 ? 2048u : kCells / (kBlock / 64);
+    hipLaunchKernelGGL(k_cell_candidates, dim3(grid), dim3(kBlock), 0, st, bounds, agg,
                        cent, k, masks, reinterpret_cast<unsigned long long *>(merge_rows), n_merge_rows);
     return hipGetLastError();
 }
@@ -1187,10 +1224,6 @@ __device__ __forceinline__ CellBounds shifted_bounds(const CellBounds &cb, float
 
 // masks[(cell * 16 + bayer) * words + w]; one wave per cell, lanes strided over the centroids.
 // Lane i < 16 derives the shifted bounds of Bayer index i once; they reach the wave through readlane.
-__device__ __forceinline__ float lane_value(float v, uint32_t src)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int)src));
-}
 
 __global__ __launch_bounds__(kBlock) void k_offset_candidates(const CellBounds *__restrict__ bounds,
                                                               const Centroid *__restrict__ cent, uint32_t k,
