@@ -709,8 +709,20 @@ __global__ __launch_bounds__(kBlock) void k_meld(const uint32_t *__restrict__ rg
         };
         if (masks) {
             const uint32_t cell = (((px >> 3) & 31u) << 10) | (((px >> 11) & 31u) << 5) | ((px >> 19) & 31u);
-            for (uint32_t w = 0; w < words; ++w) {
-                unsigned long long m = masks[(uint64_t)cell * words + w];
+            const uint64_t *mw = masks + (uint64_t)cell * words;
+            unsigned long long first4[4];                        // k <= 256: every word requested at once
+#pragma unroll
+            for (uint32_t w = 0; w < 4u; ++w) first4[w] = w < words ? mw[w] : 0ull;
+#pragma unroll
+            for (uint32_t w = 0; w < 4u; ++w) {
+                unsigned long long m = first4[w];
+                while (m) {
+                    visit(w * 64 + (uint32_t)__builtin_ctzll(m));
+                    m &= m - 1;
+                }
+            }
+            for (uint32_t w = 4; w < words; ++w) {
+                unsigned long long m = mw[w];
                 while (m) {
                     visit(w * 64 + (uint32_t)__builtin_ctzll(m));
                     m &= m - 1;

@@ -1299,7 +1299,9 @@ hipError_t launch_offset_candidates(const CellBounds *bounds, const Centroid *ce
 
 // out[i] = pal[arg-min over the candidates of (cell, Bayer index) of the key of Lab(pixel) + off];
 // the running minimum starts at the sentinel's distance with index k (mix_colors.wgsl:73-80)
-template <bool ONE_WORD>
+// WORDS = number of 64-bit mask words when it is 1, 2 or 4 (k <= 64, 128, 256: all words of the four pixels are
+// requested up front), 0 = any k (first word up front, the others on demand)
+template <int WORDS>
 __global__ __launch_bounds__(kBlock) void k_dither_pruned(const uint32_t *__restrict__ rgba, uint32_t w, uint64_t n,
                                                           uint32_t row0, const Centroid *__restrict__ cent, uint32_t k,
                                                           const float *__restrict__ lut, const uint32_t *__restrict__ pal,
@@ -1327,14 +1329,16 @@ __global__ __launch_bounds__(kBlock) void k_dither_pruned(const uint32_t *__rest
         const uint32_t i32 = (uint32_t)i0;                          // n < 2^32
         uint32_t gy = i32 / w, gx = i32 - gy * w;
         gy += row0;
+        constexpr int UP = WORDS > 0 ? WORDS : 1;
         uint32_t slot[4];
-        unsigned long long m0[4];
+        unsigned long long m0[4][UP];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const uint32_t bi = (gx & 3u) + ((gy & 3u) << 2);
             const uint32_t cell = (((px[q] >> 3) & 31u) << 10) | (((px[q] >> 11) & 31u) << 5) | ((px[q] >> 19) & 31u);
             slot[q] = cell * 16u + bi;
-            m0[q] = masks[(uint64_t)slot[q] * words];              // gathers in flight during the Lab conversion
+#pragma unroll
+            for (int u = 0; u < UP; ++u) m0[q][u] = masks[(uint64_t)slot[q] * words + u];   // gathers in flight during the Lab conversion
             gx += 1;
             if (gx == w) { gx = 0; gy += 1; }
         }
@@ -1348,8 +1352,7 @@ __global__ __launch_bounds__(kBlock) void k_dither_pruned(const uint32_t *__rest
             const PixelTerms pt = pixel_terms(L, a, b);
             float best = cie94_key(pt, 10000.0f, 10000.0f, 10000.0f, sentinel_C);
             uint32_t idx = k;
-            unsigned long long m = m0[q];
-            for (uint32_t wd = 0;;) {
+            auto scan_word = [&](unsigned long long m, uint32_t wd) {
                 while (m) {
                     const uint32_t j = wd * 64 + (uint32_t)__builtin_ctzll(m);
                     m &= m - 1;
@@ -1357,9 +1360,11 @@ __global__ __launch_bounds__(kBlock) void k_dither_pruned(const uint32_t *__rest
                     const float d = cie94_key(pt, c.x, c.y, c.z, c.w);
                     if (d < best) { best = d; idx = j; }
                 }
-                if (ONE_WORD || ++wd >= words) break;
-                m = masks[(uint64_t)slot[q] * words + wd];
-            }
+            };
+#pragma unroll
+            for (int u = 0; u < UP; ++u) scan_word(m0[q][u], (uint32_t)u);
+            if (WORDS == 0)
+                for (uint32_t wd = 1; wd < words; ++wd) scan_word(masks[(uint64_t)slot[q] * words + wd], wd);
             res[q] = pal[idx];
         }
         store4_stream(out, i0, n, aligned != 0, res);
@@ -1377,12 +1382,11 @@ hipError_t launch_dither_pruned(const uint32_t *rgba, uint32_t w, uint32_t rows,
     const size_t lds = sizeof(float4) * kpad + (256 + 16) * sizeof(float);
     const int aligned = ((reinterpret_cast<uintptr_t>(rgba) & 15u) == 0 &&
                          (reinterpret_cast<uintptr_t>(out) & 15u) == 0) ? 1 : 0;
-    if (k <= 64)
-        hipLaunchKernelGGL(k_dither_pruned<true>, dim3(grid), dim3(kBlock), lds, st, rgba, w, n, row0, cent, k, lut,
-                           pal, threshold, masks, out, aligned);
-    else
-        hipLaunchKernelGGL(k_dither_pruned<false>, dim3(grid), dim3(kBlock), lds, st, rgba, w, n, row0, cent, k, lut,
-                           pal, threshold, masks, out, aligned);
+#define KMG_DP(W) hipLaunchKernelGGL(k_dither_pruned<W>, dim3(grid), dim3(kBlock), lds, st, rgba, w, n, row0, cent, k, lut, \
+                                     pal, threshold, masks, out, aligned)
+    const uint32_t n_words = (k + 63u) / 64u;
+    if (n_words == 1) KMG_DP(1); else if (n_words == 2) KMG_DP(2); else if (n_words == 4) KMG_DP(4); else KMG_DP(0);
+#undef KMG_DP
     return hipGetLastError();
 }
 
