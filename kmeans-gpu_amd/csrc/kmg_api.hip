@@ -375,7 +375,7 @@ static bool dither_pruning_pays(uint64_t n, uint32_t k)
         if (!strcmp(e, "brute")) return false;
         if (!strcmp(e, "table")) return true;
     }
-    return k >= 32 && n >= 12000000ull;
+    return k >= 32 && n >= (k >= 128 ? 6000000ull : 12000000ull);   // per-pixel saving grows with k, 43 ps at k = 256
 }
 
 // Meld output pass: ordered scan of all k centroids per pixel, or of the candidates of the pixel's colour
