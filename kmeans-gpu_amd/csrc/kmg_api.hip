@@ -1126,13 +1126,15 @@ extern "C" int kmg_dev_apply(kmg_processor *p, const uint8_t *d_rgba, uint32_t w
     float thr = dither ? dither_threshold(c4, k) : 0.0f;
 
     // every scratch buffer of the call is stream-ordered and dies with it (the call synchronises)
-    StreamBuf cent_buf, pal_buf, masks, colour_labels, sub;
-    hipError_t e = cent_buf.alloc(sizeof(Centroid) * k, S(stream));
-    if (e == hipSuccess) e = pal_buf.alloc(sizeof(uint32_t) * (k + 1), S(stream));
-    Centroid *d_cent = (Centroid *)cent_buf.ptr;
-    uint32_t *d_pal = (uint32_t *)pal_buf.ptr;
-    if (e == hipSuccess) e = hipMemcpyAsync(d_cent, hc.data(), sizeof(Centroid) * k, hipMemcpyHostToDevice, S(stream));
-    if (e == hipSuccess) e = hipMemcpyAsync(d_pal, pal.data(), sizeof(uint32_t) * (k + 1), hipMemcpyHostToDevice, S(stream));
+    StreamBuf tables, masks, colour_labels, sub;
+    // centroid table and palette travel in one block (one allocation, one copy)
+    std::vector<uint8_t> staged(sizeof(Centroid) * k + sizeof(uint32_t) * (k + 1));
+    memcpy(staged.data(), hc.data(), sizeof(Centroid) * k);
+    memcpy(staged.data() + sizeof(Centroid) * k, pal.data(), sizeof(uint32_t) * (k + 1));
+    hipError_t e = tables.alloc(staged.size(), S(stream));
+    Centroid *d_cent = (Centroid *)tables.ptr;
+    uint32_t *d_pal = (uint32_t *)((uint8_t *)tables.ptr + sizeof(Centroid) * k);
+    if (e == hipSuccess) e = hipMemcpyAsync(tables.ptr, staged.data(), staged.size(), hipMemcpyHostToDevice, S(stream));
     const uint64_t n_px = (uint64_t)w * rows;
     int rc = KMG_OK;
     if (e != hipSuccess) {
