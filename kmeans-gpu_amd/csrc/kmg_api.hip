@@ -120,6 +120,7 @@ struct ColourTable {
     float *d_cdist = nullptr;        // 2^24 running min-distance per colour
     unsigned long long *d_cell_key = nullptr;   // kCells: largest init key of each cell's colours
     bool tie_valid = false;          // d_tie describes (rgba, n, tie_first)
+    bool bound_by_init = false;      // the binding was made by the initialisation of the current problem
     uint64_t tie_first = 0;
 };
 
@@ -435,6 +436,7 @@ static int bind_image_impl(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, void
     t.rgba = nullptr;
     t.tables_valid = false;
     t.tie_valid = false;
+    t.bound_by_init = false;
     // entries of cells no pixel falls into are never read by the label pass; 0xFF.. = "empty"
     HIP_TRY(hipMemsetAsync(t.d_sub, 0xFF, sizeof(uint16_t) * (kSubCells + kCells) + sizeof(uint32_t) * kCells, S(stream)));
     if (n >= (1ull << 21)) {
@@ -478,8 +480,13 @@ extern "C" int kmg_lloyd_prepare(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n
     if (!s || !d_rgba || n == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad prepare arguments");
     int chosen = 0;
     if (table_pays(n, s->k, want_labels != 0)) {
-        int rc = kmg_lloyd_bind_image(s, d_rgba, n, stream);
-        if (rc != KMG_OK) return rc;
+        // the initialisation of this problem may have bound the image a moment ago: keep that binding
+        const bool fresh = s->tab.rgba == d_rgba && s->tab.n == n && s->tab.bound_by_init;
+        s->tab.bound_by_init = false;
+        if (!fresh) {
+            int rc = kmg_lloyd_bind_image(s, d_rgba, n, stream);
+            if (rc != KMG_OK) return rc;
+        }
         chosen = 1;
     } else if (s->tab.rgba == d_rgba) {
         s->tab.rgba = nullptr;   // the cost model prefers the per-pixel scan for this problem
@@ -678,6 +685,7 @@ static int table_assign(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_
                         uint32_t rows, hipStream_t st)
 {
     ColourTable &t = s->tab;
+    t.bound_by_init = false;      // only a prepare() that directly follows the initialisation may reuse its binding
     PROF_LAUNCH(s, KMG_K_CANDIDATES, st, launch_cell_candidates(s->p->d_bounds, t.d_agg, s->d_cent, s->k, t.d_masks, d_sums, rows, st));
     PROF_LAUNCH(s, KMG_K_CUBE, st, launch_cube(t.d_hist, t.d_agg, t.d_masks, t.d_work, s->d_cent, s->k, s->p->d_lab_table,
                                                t.d_colour_labels, t.d_sub, d_sums, rows, st));
@@ -818,6 +826,7 @@ static int init_over_colours(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, ui
     }
     int rc;
     if ((rc = bind_image_impl(s, d_rgba, n, stream, true, first_index)) != KMG_OK) return rc;
+    t.bound_by_init = true;
     *colours = true;
     return KMG_OK;
 }
