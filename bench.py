@@ -137,6 +137,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the untimed extra measurements (use under rocprofv3 to keep kernel averages clean)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="run the label pass of an iteration before the next iteration's cube pass instead of beside it")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the all-reduce even with one rank (sanity check)")
     ap.add_argument("--strategy", choices=["auto", "scan", "table"], default="auto",
@@ -199,6 +201,7 @@ def main():
 
     sh = ShardedLloyd(lloyd, k, rgba, labels, stream=stream)
     sh.split_labels = strategy == "table"     # the all-reduce overlaps the label-gather pass
+    sh.pipeline = not args.no_overlap
     if args.force_dist:
         sh.world = 2          # take the collective path even though the group has one rank
     sh.prime()

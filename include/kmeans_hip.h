@@ -165,14 +165,17 @@ KMG_API int kmg_lloyd_unbind_image(kmg_lloyd *s);
  * table pays.  *strategy (optional) receives 0 = per-pixel scan, 1 = colour table.              */
 KMG_API int kmg_lloyd_prepare(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n_pixels, int want_labels,
                               int *strategy, void *stream);
-/* Test support: exhaustive check over all 2^24 colours that the colour-table bounds and candidate
- * masks for the current centroids are conservative.  out[0] = range violations, out[1] = colours
- * whose true arg-min is missing from its cell's candidate set (both must be 0).                 */
-KMG_API int kmg_debug_check_table(kmg_lloyd *s, uint64_t out[2], void *stream);
+/* Test support: exhaustive check over all 2^24 colours of the colour-table pass for the current
+ * centroids.  out[0] = (colour, centroid) pairs whose key lies outside the interval bounds of the colour's
+ * cell or sub-cell, out[1] = colours whose true arg-min is missing from its cell's candidate set,
+ * out[2] = colours whose label in the per-colour table is not the true arg-min (all must be 0). */
+KMG_API int kmg_debug_check_table(kmg_lloyd *s, uint64_t out[3], void *stream);
 /* Tuning support: statistics of the last colour-table pass over the bound image (synchronises).
  * out = {occupied cells, sum of candidate counts, cells with one candidate, max candidates,
- *        cells with one label, occupied sub-cells, sub-cells with one label, distinct colours}.  */
-KMG_API int kmg_debug_table_stats(kmg_lloyd *s, uint64_t out[8], void *stream);
+ *        cells with one label, occupied sub-cells, sub-cells with one label, distinct colours,
+ *        sub-cells decided from their bounds, sub-cells scanned, candidates over the scanned sub-cells,
+ *        cells with too many candidates for the sub-cell stage}.                                 */
+KMG_API int kmg_debug_table_stats(kmg_lloyd *s, uint64_t out[12], void *stream);
 /* Test support (k <= 256): checks the per-cell pair entries the label pass keeps in LDS against the
  * per-colour label table of the last colour-table pass (synchronises).  out[0] = occupied colours
  * whose entry disagrees (must be 0), out[1] = pixels resolved by the entries alone, out[2] = pixels. */
@@ -217,6 +220,19 @@ KMG_API int kmg_lloyd_profile_read(kmg_lloyd *s, double total_ms[KMG_K_COUNT], u
 KMG_API int kmg_lloyd_update(kmg_lloyd *s, const int64_t *d_acc4, void *stream);
 /* convergence[K] of choose_centroid.wgsl:196-202 after the last update (synchronises).       */
 KMG_API int kmg_lloyd_converged_count(kmg_lloyd *s, uint32_t *count, void *stream);
+
+/* One iteration of the loop of ChooseCentroidModule::compute (modules.rs:769-800) as ONE asynchronous call:
+ * update_first != 0: centroids <- kmg_lloyd_update(d_acc4); then labels (optional) + sums of the new
+ * assignment into d_acc4 (cleared first).  With a bound image (colour table) and d_labels != NULL the label
+ * pass runs on an internal high-priority stream beside the NEXT iteration's update + cube pass -- it feeds
+ * nothing in the loop; `stream` is ordered after everything that produces d_acc4 and the centroids, but NOT
+ * after the label map: call kmg_lloyd_flush (or synchronise the device) before reading d_labels.
+ * Between two calls the caller may all-reduce d_acc4 on `stream` (sharded images).  Without a bound image it
+ * is kmg_lloyd_update + kmg_lloyd_assign_accumulate.                                                  */
+KMG_API int kmg_lloyd_iterate(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n_pixels, uint32_t *d_labels,
+                              int64_t *d_acc4, int update_first, void *stream);
+/* `stream` waits (on the device, no host synchronisation) for the label passes kmg_lloyd_iterate started. */
+KMG_API int kmg_lloyd_flush(kmg_lloyd *s, void *stream);
 
 /* ChooseCentroidModule::compute (core/src/modules.rs:763-840): the whole loop on one device.
  * Expects the centroid table initialised.  Synchronises.  *iterations = the reference's

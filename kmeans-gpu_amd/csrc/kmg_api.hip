@@ -98,6 +98,7 @@ struct kmg_processor {
     float *d_lut;            // 256 x f32: sRGB decode * 100
     std::mutex mu;           // guards the lazily built static tables below
     CellBounds *d_bounds;    // kCells static cell bounds of the colour-table strategy
+    CellBounds *d_sub_bounds;   // kSubCells static bounds of the 4x4x4 sub-cells
     float4 *d_lab_table;     // 2^24 x (L, a, b, C): Lab of every colour (256 MiB, built with d_bounds)
     std::vector<hipStream_t> idle_streams;   // streams of finished host-buffer calls, reused by the next ones (mu)
 };
@@ -110,17 +111,25 @@ struct ColourTable {
     uint64_t n = 0;
     uint32_t *d_hist = nullptr;      // 2^24 counts, cell-major colour order
     int64_t *d_agg = nullptr;        // kCells x 4 per-cell sums of the image
+    int64_t *d_sub_agg = nullptr;    // kSubCells x 4 per-sub-cell sums of the image
+    uint8_t *d_occ = nullptr;        // 2^24 bits: colours the image has pixels of
+    void *d_cell_work = nullptr;     // cube_work_bytes(): records the cube pass's stage kernel leaves for its scan kernel
     uint64_t *d_masks = nullptr;     // kCells x words candidate masks
     uint32_t *d_work = nullptr;      // 1 + kCells: dense list of the occupied cells
     bool tables_valid = false;       // label tables describe the CURRENT centroid table
     void *d_colour_labels = nullptr; // 2^24 x u8 (k <= 256) or u16
     uint16_t *d_sub = nullptr;       // kSubCells 4x4x4 summaries (u16), kCells 8x8x8 summaries (u16), kCells pair entries (u32)
+    // second set of label tables (kmg_lloyd_iterate): the cube pass of iteration t + 1 writes one set while the
+    // label pass of iteration t still reads the other; d_colour_labels / d_sub are always the set written last
+    void *d_colour_labels_alt = nullptr;
+    uint16_t *d_sub_alt = nullptr;
     // farthest-point init over the colours (built on demand by the init entry points)
     uint32_t *d_tie = nullptr;       // 2^24: 1 + largest low half of the init key per colour, 0 = unoccupied
     float *d_cdist = nullptr;        // 2^24 running min-distance per colour
     unsigned long long *d_cell_key = nullptr;   // kCells: largest init key of each cell's colours
     bool tie_valid = false;          // d_tie describes (rgba, n, tie_first)
     bool bound_by_init = false;      // the binding was made by the initialisation of the current problem
+    bool bound_by_caller = false;    // kmg_lloyd_bind_image / kmg_lloyd_prepare: the caller vouches for the buffer's contents
     uint64_t tie_first = 0;
 };
 
@@ -139,6 +148,12 @@ struct kmg_lloyd {
     bool pooled;                 // workspace came from the stream-ordered pool of `pool_stream` (internal per-call objects)
     hipStream_t pool_stream;
     ColourTable tab;
+    // kmg_lloyd_iterate: label passes run on a stream of their own, beside the next iteration's cube pass
+    hipStream_t side;            // high-priority stream of the label passes (created on first use)
+    hipEvent_t ev_cube;          // cube pass of the current iteration done (main stream -> side stream)
+    hipEvent_t ev_lab[2];        // label pass reading table set i done (side stream -> main stream)
+    bool lab_pending[2];
+    int set;                     // event slot of the table set written last
     uint32_t prof;               // per-launch HIP-event timing: bit i = time kernel id i (kmg_lloyd_profile)
     std::vector<ProfEvent> events;
     std::vector<hipEvent_t> pool; // recycled timing events
@@ -176,6 +191,7 @@ extern "C" int kmg_processor_create_ex(const kmg_options *opt, kmg_processor **o
     p->opt = o;
     p->d_lut = nullptr;
     p->d_bounds = nullptr;
+    p->d_sub_bounds = nullptr;
     p->d_lab_table = nullptr;
     float lut[256];
     build_srgb_lut100(lut);
@@ -196,6 +212,7 @@ extern "C" void kmg_processor_destroy(kmg_processor *p)
     (void)hipSetDevice(p->device);
     if (p->d_lut) (void)hipFree(p->d_lut);
     if (p->d_bounds) (void)hipFree(p->d_bounds);
+    if (p->d_sub_bounds) (void)hipFree(p->d_sub_bounds);
     if (p->d_lab_table) (void)hipFree(p->d_lab_table);
     for (hipStream_t st : p->idle_streams) (void)hipStreamDestroy(st);
     delete p;
@@ -313,14 +330,21 @@ struct StreamGuard {
 // ---------------------------------------------------------------------------------------------
 static void drop_events(kmg_lloyd *s);
 static void destroy_events(kmg_lloyd *s);
+static int debug_refresh(kmg_lloyd *s, hipStream_t st, unsigned long long stage[6]);
+static int side_flush(kmg_lloyd *s, hipStream_t st);
 static void free_table(ColourTable &t)
 {
     if (t.d_hist) (void)hipFree(t.d_hist);
     if (t.d_agg) (void)hipFree(t.d_agg);
+    if (t.d_sub_agg) (void)hipFree(t.d_sub_agg);
+    if (t.d_occ) (void)hipFree(t.d_occ);
+    if (t.d_cell_work) (void)hipFree(t.d_cell_work);
     if (t.d_masks) (void)hipFree(t.d_masks);
     if (t.d_work) (void)hipFree(t.d_work);
     if (t.d_colour_labels) (void)hipFree(t.d_colour_labels);
     if (t.d_sub) (void)hipFree(t.d_sub);
+    if (t.d_colour_labels_alt) (void)hipFree(t.d_colour_labels_alt);
+    if (t.d_sub_alt) (void)hipFree(t.d_sub_alt);
     if (t.d_tie) (void)hipFree(t.d_tie);
     if (t.d_cdist) (void)hipFree(t.d_cdist);
     if (t.d_cell_key) (void)hipFree(t.d_cell_key);
@@ -394,18 +418,21 @@ static int ensure_bounds(kmg_processor *p, hipStream_t st)
 {
     std::lock_guard<std::mutex> lock(p->mu);
     if (p->d_bounds) return KMG_OK;
-    CellBounds *b = nullptr;
+    CellBounds *b = nullptr, *sb = nullptr;
     float4 *lab = nullptr;
     HIP_TRY(hipMalloc((void **)&b, sizeof(CellBounds) * kCells));
-    hipError_t e = hipMalloc((void **)&lab, sizeof(float4) << 24);
-    if (e == hipSuccess) e = launch_cell_bounds(p->d_lut, b, lab, st);
+    hipError_t e = hipMalloc((void **)&sb, sizeof(CellBounds) * kSubCells);
+    if (e == hipSuccess) e = hipMalloc((void **)&lab, sizeof(float4) << 24);
+    if (e == hipSuccess) e = launch_cell_bounds(p->d_lut, b, sb, lab, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) {
         (void)hipFree(b);
+        if (sb) (void)hipFree(sb);
         if (lab) (void)hipFree(lab);
         return fail(e == hipErrorOutOfMemory ? KMG_ERR_OUT_OF_MEMORY : KMG_ERR_HIP, "colour tables failed: %s", hipGetErrorString(e));
     }
     p->d_lab_table = lab;
+    p->d_sub_bounds = sb;
     p->d_bounds = b;
     return KMG_OK;
 }
@@ -415,6 +442,10 @@ static int ensure_bounds(kmg_processor *p, hipStream_t st)
 static int bind_image_impl(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, void *stream, bool want_tie, uint64_t first_index)
 {
     if (!s || !d_rgba || n == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad bind_image arguments");
+    if (s->side) HIP_TRY(hipStreamSynchronize(s->side));             // label passes of the previous binding
+    s->lab_pending[0] = s->lab_pending[1] = false;
+    // the histogram counts, partition totals and prefix sums are u32 (kmg_table.hip)
+    if (n > 0xFFFFFFFFull) return fail(KMG_ERR_UNSUPPORTED, "image has more than 2^32-1 pixels");
     HIP_TRY(hipSetDevice(s->p->device));
     int rc;
     if ((rc = ensure_bounds(s->p, S(stream))) != KMG_OK) return rc;
@@ -423,6 +454,9 @@ static int bind_image_impl(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, void
     if (!t.d_hist) {
         hipError_t e = hipMalloc((void **)&t.d_hist, sizeof(uint32_t) << 24);
         if (e == hipSuccess) e = hipMalloc((void **)&t.d_agg, sizeof(int64_t) * 4ull * kCells);
+        if (e == hipSuccess) e = hipMalloc((void **)&t.d_sub_agg, sizeof(int64_t) * 4ull * kSubCells);
+        if (e == hipSuccess) e = hipMalloc((void **)&t.d_occ, (size_t)1 << 21);
+        if (e == hipSuccess) e = hipMalloc(&t.d_cell_work, cube_work_bytes());
         if (e == hipSuccess) e = hipMalloc((void **)&t.d_masks, sizeof(uint64_t) * (size_t)kCells * words);
         if (e == hipSuccess) e = hipMalloc((void **)&t.d_work, sizeof(uint32_t) * (kCells + 1));
         if (e == hipSuccess) e = hipMalloc(&t.d_colour_labels, (size_t)(s->k <= 256 ? 1 : 2) << 24);
@@ -437,6 +471,7 @@ static int bind_image_impl(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, void
     t.tables_valid = false;
     t.tie_valid = false;
     t.bound_by_init = false;
+    t.bound_by_caller = false;
     // entries of cells no pixel falls into are never read by the label pass; 0xFF.. = "empty"
     HIP_TRY(hipMemsetAsync(t.d_sub, 0xFF, sizeof(uint16_t) * (kSubCells + kCells) + sizeof(uint32_t) * kCells, S(stream)));
     if (n >= (1ull << 21)) {
@@ -463,7 +498,7 @@ static int bind_image_impl(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, void
         t.tie_valid = true;
         t.tie_first = first_index;
     }
-    HIP_TRY(launch_cell_aggregates(t.d_hist, s->p->d_lab_table, t.d_agg, S(stream)));
+    HIP_TRY(launch_cell_aggregates(t.d_hist, s->p->d_lab_table, t.d_agg, t.d_sub_agg, t.d_occ, S(stream)));
     HIP_TRY(launch_work_list(t.d_agg, t.d_work, S(stream)));       // dense list of the occupied cells (static for this image)
     t.rgba = d_rgba;
     t.n = n;
@@ -472,27 +507,37 @@ static int bind_image_impl(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, void
 
 extern "C" int kmg_lloyd_bind_image(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, void *stream)
 {
-    return bind_image_impl(s, d_rgba, n, stream, false, 0);
+    const int rc = bind_image_impl(s, d_rgba, n, stream, false, 0);
+    if (rc == KMG_OK) s->tab.bound_by_caller = true;
+    return rc;
 }
 
-extern "C" int kmg_lloyd_prepare(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, int want_labels, int *strategy, void *stream)
+// caller = true: the public entry point (the binding then lasts until the caller unbinds or binds again);
+// false: made on behalf of one kmg_lloyd_run, which drops it before it returns
+static int prepare_impl(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, int want_labels, int *strategy, void *stream, bool caller)
 {
     if (!s || !d_rgba || n == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad prepare arguments");
     int chosen = 0;
-    if (table_pays(n, s->k, want_labels != 0)) {
+    if (n <= 0xFFFFFFFFull && table_pays(n, s->k, want_labels != 0)) {
         // the initialisation of this problem may have bound the image a moment ago: keep that binding
         const bool fresh = s->tab.rgba == d_rgba && s->tab.n == n && s->tab.bound_by_init;
         s->tab.bound_by_init = false;
         if (!fresh) {
-            int rc = kmg_lloyd_bind_image(s, d_rgba, n, stream);
+            int rc = bind_image_impl(s, d_rgba, n, stream, false, 0);
             if (rc != KMG_OK) return rc;
         }
+        s->tab.bound_by_caller = caller;
         chosen = 1;
     } else if (s->tab.rgba == d_rgba) {
         s->tab.rgba = nullptr;   // the cost model prefers the per-pixel scan for this problem
     }
     if (strategy) *strategy = chosen;
     return KMG_OK;
+}
+
+extern "C" int kmg_lloyd_prepare(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, int want_labels, int *strategy, void *stream)
+{
+    return prepare_impl(s, d_rgba, n, want_labels, strategy, stream, true);
 }
 
 extern "C" int kmg_lloyd_unbind_image(kmg_lloyd *s)
@@ -504,26 +549,34 @@ extern "C" int kmg_lloyd_unbind_image(kmg_lloyd *s)
     return KMG_OK;
 }
 
-// test support: exhaustive validation of the interval bounds and candidate masks for the current
-// centroid table over all 2^24 colours.  out[0] = range violations, out[1] = mask violations.
-extern "C" int kmg_debug_check_table(kmg_lloyd *s, uint64_t out[2], void *stream)
+// test support: exhaustive validation, over all 2^24 colours, of the cube pass for the current centroid
+// table (run without an image: every colour counts).  out[0] = (colour, centroid) pairs whose key lies outside
+// the cell's or the sub-cell's interval bounds, out[1] = colours whose brute-force arg-min is missing from the
+// cell's candidate mask, out[2] = colours whose label in the per-colour table differs from the brute-force
+// arg-min (this covers the sub-cell stage and the near-tie repair).
+extern "C" int kmg_debug_check_table(kmg_lloyd *s, uint64_t out[3], void *stream)
 {
     if (!s || !out) return fail(KMG_ERR_INVALID_ARGUMENT, "bad check_table arguments");
     HIP_TRY(hipSetDevice(s->p->device));
     int rc;
     if ((rc = ensure_bounds(s->p, S(stream))) != KMG_OK) return rc;
     const uint32_t words = mask_words(s->k);
-    DevBuf masks, viol;
+    DevBuf masks, viol, labels, sub, cwork;
     HIP_TRY(masks.alloc(sizeof(uint64_t) * (size_t)kCells * words));
-    HIP_TRY(viol.alloc(2 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemsetAsync(viol.ptr, 0, 2 * sizeof(unsigned long long), S(stream)));
-    HIP_TRY(launch_cell_candidates(s->p->d_bounds, nullptr, s->d_cent, s->k, (uint64_t *)masks.ptr, nullptr, 0, S(stream)));
-    HIP_TRY(launch_check_bounds(s->p->d_bounds, s->d_cent, s->k, (const uint64_t *)masks.ptr, s->p->d_lut,
-                                (unsigned long long *)viol.ptr, S(stream)));
-    unsigned long long h[2];
+    HIP_TRY(cwork.alloc(cube_work_bytes()));
+    HIP_TRY(viol.alloc(3 * sizeof(unsigned long long)));
+    HIP_TRY(labels.alloc((size_t)(s->k <= 256 ? 1 : 2) << 24));
+    HIP_TRY(sub.alloc(sizeof(uint16_t) * (kSubCells + kCells) + sizeof(uint32_t) * kCells));
+    HIP_TRY(hipMemsetAsync(viol.ptr, 0, 3 * sizeof(unsigned long long), S(stream)));
+    HIP_TRY(launch_cube(nullptr, nullptr, nullptr, nullptr, nullptr, s->p->d_bounds, s->p->d_sub_bounds, s->d_cent, s->k,
+                        s->p->d_lab_table, (uint64_t *)masks.ptr, cwork.ptr, labels.ptr, (uint16_t *)sub.ptr, nullptr, 0, 1u, nullptr,
+                        S(stream)));
+    HIP_TRY(launch_check_bounds(s->p->d_bounds, s->p->d_sub_bounds, s->d_cent, s->k, (const uint64_t *)masks.ptr, labels.ptr,
+                                s->p->d_lut, (unsigned long long *)viol.ptr, S(stream)));
+    unsigned long long h[3];
     HIP_TRY(hipMemcpyAsync(h, viol.ptr, sizeof h, hipMemcpyDeviceToHost, S(stream)));
     HIP_TRY(hipStreamSynchronize(S(stream)));
-    out[0] = h[0]; out[1] = h[1];
+    out[0] = h[0]; out[1] = h[1]; out[2] = h[2];
     return KMG_OK;
 }
 
@@ -590,13 +643,18 @@ extern "C" int kmg_debug_check_meld_masks(kmg_processor *p, const float *c4, uin
 // test / tuning support: statistics of the last colour-table pass of the bound image.
 // out[0] occupied cells, [1] sum of candidate counts over occupied cells, [2] occupied cells with one
 // candidate, [3] largest candidate count, [4] cells whose occupied colours share one label,
-// [5] occupied sub-cells, [6] sub-cells whose occupied colours share one label, [7] distinct colours
-extern "C" int kmg_debug_table_stats(kmg_lloyd *s, uint64_t out[8], void *stream)
+// [5] occupied sub-cells, [6] sub-cells whose occupied colours share one label, [7] distinct colours,
+// [8] sub-cells the cube pass decided from their bounds, [9] sub-cells whose colours it scanned,
+// [10] candidates summed over the scanned sub-cells, [11] cells with too many candidates for the sub-cell stage
+extern "C" int kmg_debug_table_stats(kmg_lloyd *s, uint64_t out[12], void *stream)
 {
     if (!s || !out) return fail(KMG_ERR_INVALID_ARGUMENT, "bad table_stats arguments");
-    if (!s->tab.rgba) return fail(KMG_ERR_INVALID_ARGUMENT, "no image is bound");
+    if (!s->tab.rgba || !s->tab.tables_valid) return fail(KMG_ERR_INVALID_ARGUMENT, "no current colour table");
     HIP_TRY(hipSetDevice(s->p->device));
     HIP_TRY(hipStreamSynchronize(S(stream)));
+    int rc_;
+    unsigned long long stage[6] = {0, 0, 0, 0, 0, 0};
+    if ((rc_ = debug_refresh(s, S(stream), stage)) != KMG_OK) return rc_;
     const uint32_t words = mask_words(s->k);
     std::vector<uint64_t> masks((size_t)kCells * words);
     std::vector<int64_t> agg(4ull * kCells);
@@ -613,6 +671,7 @@ extern "C" int kmg_debug_table_stats(kmg_lloyd *s, uint64_t out[8], void *stream
         HIP_TRY(hipMemcpy(labels.data(), s->tab.d_colour_labels, labels.size() * 2, hipMemcpyDeviceToHost));
     }
     for (int i = 0; i < 8; ++i) out[i] = 0;
+    out[8] = stage[2]; out[9] = stage[3]; out[10] = stage[4]; out[11] = stage[5];
     for (uint32_t c = 0; c < kCells; ++c) {
         if (agg[4ull * c + 3] == 0) continue;
         uint64_t pop = 0;
@@ -651,6 +710,8 @@ extern "C" int kmg_debug_check_pairs(kmg_lloyd *s, uint64_t out[3], void *stream
     if (s->k > 256) return fail(KMG_ERR_INVALID_ARGUMENT, "pair entries exist for k <= 256 only");
     HIP_TRY(hipSetDevice(s->p->device));
     HIP_TRY(hipStreamSynchronize(S(stream)));
+    int rc_;
+    if ((rc_ = debug_refresh(s, S(stream), nullptr)) != KMG_OK) return rc_;
     std::vector<uint32_t> hist(1u << 24), pairs(kCells);
     std::vector<uint8_t> labels(1u << 24);
     HIP_TRY(hipMemcpy(hist.data(), s->tab.d_hist, hist.size() * 4, hipMemcpyDeviceToHost));
@@ -673,6 +734,34 @@ extern "C" int kmg_debug_check_pairs(kmg_lloyd *s, uint64_t out[3], void *stream
     return KMG_OK;
 }
 
+// statistics / checks read the cell masks and the per-colour labels of EVERY cell, which the normal pass does
+// not store: repeat the cube pass of the bound image for the current centroids with both switched on
+static int debug_refresh(kmg_lloyd *s, hipStream_t st, unsigned long long stage[6] = nullptr)
+{
+    ColourTable &t = s->tab;
+    int rc_;
+    if ((rc_ = side_flush(s, st)) != KMG_OK) return rc_;
+    // d_partials is scratch here: the sums of this repeat pass and, behind them, the stage counters
+    unsigned long long *d_stage = reinterpret_cast<unsigned long long *>(s->d_partials) + 4ull * s->k;
+    HIP_TRY(hipMemsetAsync(s->d_partials, 0, sizeof(int64_t) * (4ull * s->k + 6ull), st));
+    HIP_TRY(launch_cube(t.d_hist, t.d_agg, t.d_sub_agg, t.d_occ, t.d_work, s->p->d_bounds, s->p->d_sub_bounds, s->d_cent, s->k,
+                        s->p->d_lab_table, t.d_masks, t.d_cell_work, t.d_colour_labels, t.d_sub, s->d_partials, 1u, 1u, d_stage, st));
+    if (stage) HIP_TRY(hipMemcpyAsync(stage, d_stage, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return KMG_OK;
+}
+
+// label passes that kmg_lloyd_iterate left running on the side stream: `st` waits for them (no host sync)
+static int side_flush(kmg_lloyd *s, hipStream_t st)
+{
+    for (int i = 0; i < 2; ++i)
+        if (s->lab_pending[i]) {
+            HIP_TRY(hipStreamWaitEvent(st, s->ev_lab[i], 0));
+            s->lab_pending[i] = false;
+        }
+    return KMG_OK;
+}
+
 static bool table_bound(const kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n)
 {
     return s->tab.rgba != nullptr && s->tab.rgba == d_rgba && s->tab.n == n;
@@ -686,9 +775,12 @@ static int table_assign(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_
 {
     ColourTable &t = s->tab;
     t.bound_by_init = false;      // only a prepare() that directly follows the initialisation may reuse its binding
-    PROF_LAUNCH(s, KMG_K_CANDIDATES, st, launch_cell_candidates(s->p->d_bounds, t.d_agg, s->d_cent, s->k, t.d_masks, d_sums, rows, st));
-    PROF_LAUNCH(s, KMG_K_CUBE, st, launch_cube(t.d_hist, t.d_agg, t.d_masks, t.d_work, s->d_cent, s->k, s->p->d_lab_table,
-                                               t.d_colour_labels, t.d_sub, d_sums, rows, st));
+    int rc_;
+    if ((rc_ = side_flush(s, st)) != KMG_OK) return rc_;
+    HIP_TRY(hipMemsetAsync(d_sums, 0, sizeof(int64_t) * 4ull * s->k * rows, st));
+    PROF_LAUNCH(s, KMG_K_CUBE, st, launch_cube(t.d_hist, t.d_agg, t.d_sub_agg, t.d_occ, t.d_work, s->p->d_bounds, s->p->d_sub_bounds,
+                                               s->d_cent, s->k, s->p->d_lab_table, t.d_masks, t.d_cell_work, t.d_colour_labels, t.d_sub,
+                                               d_sums, rows, 0u, nullptr, st));
     t.tables_valid = true;
     if (d_labels)
         PROF_LAUNCH(s, KMG_K_LABELS, st, launch_labels((const uint32_t *)d_rgba, n, t.d_colour_labels, t.d_sub, s->k, nullptr, d_labels, st));
@@ -710,6 +802,8 @@ static int lloyd_create_impl(kmg_processor *p, uint32_t k, kmg_lloyd **out, hipS
     s->k = k;
     s->d_cent = nullptr; s->d_partials = nullptr; s->d_acc = nullptr; s->d_nconv = nullptr;
     s->d_key = nullptr; s->d_dist = nullptr; s->dist_cap = 0; s->last_rows = 0; s->prof = 0; s->init_colours = false;
+    s->side = nullptr; s->ev_cube = nullptr; s->ev_lab[0] = s->ev_lab[1] = nullptr;
+    s->lab_pending[0] = s->lab_pending[1] = false; s->set = 0;
     s->pooled = pool_stream != nullptr;
     s->pool_stream = pool_stream;
     auto alloc = [&](void **ptr, size_t bytes) {
@@ -747,6 +841,11 @@ extern "C" void kmg_lloyd_destroy(kmg_lloyd *s)
         if (!ptr) return;
         if (s->pooled) (void)hipFreeAsync(ptr, s->pool_stream); else (void)hipFree(ptr);
     };
+    if (s->side) {
+        (void)hipStreamSynchronize(s->side);
+        (void)hipStreamDestroy(s->side);
+        (void)hipEventDestroy(s->ev_cube); (void)hipEventDestroy(s->ev_lab[0]); (void)hipEventDestroy(s->ev_lab[1]);
+    }
     release(s->d_cent);
     release(s->d_partials);
     release(s->d_acc);
@@ -983,6 +1082,8 @@ extern "C" int kmg_lloyd_labels(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n,
     if (!s || !d_rgba || !d_labels || n == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad labels arguments");
     HIP_TRY(hipSetDevice(s->p->device));
     if (table_bound(s, d_rgba, n) && s->tab.tables_valid) {
+        int rc_;
+        if ((rc_ = side_flush(s, S(stream))) != KMG_OK) return rc_;
         PROF_LAUNCH(s, KMG_K_LABELS, S(stream), launch_labels((const uint32_t *)d_rgba, n, s->tab.d_colour_labels,
                                                               s->tab.d_sub, s->k, nullptr, d_labels, S(stream)));
         return KMG_OK;
@@ -1060,6 +1161,71 @@ extern "C" int kmg_lloyd_update(kmg_lloyd *s, const int64_t *d_acc4, void *strea
     return KMG_OK;
 }
 
+// One Lloyd iteration with the label pass taken off the critical path (modules.rs:769-800: update, then
+// re-assign).  The loop only depends on the sums; with the colour table they come from the cube pass, and the
+// label pass that turns the cube pass's tables into the per-pixel label map feeds nothing.  So the label pass
+// of iteration t runs on a stream of its own while the main stream already updates the centroids and runs the
+// cube pass of iteration t + 1 -- a memory-bound kernel beside an issue-bound one.  Two sets of label tables
+// alternate; the cube pass that is about to overwrite a set first waits for the label pass that read it.
+extern "C" int kmg_lloyd_iterate(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_t *d_labels, int64_t *d_acc4,
+                                 int update_first, void *stream)
+{
+    if (!s || !d_rgba || n == 0 || !d_acc4) return fail(KMG_ERR_INVALID_ARGUMENT, "bad iterate arguments");
+    HIP_TRY(hipSetDevice(s->p->device));
+    int rc;
+    if (!table_bound(s, d_rgba, n) || !d_labels) {
+        // per-pixel scan (labels and sums come out of one kernel) or no label map wanted: nothing to overlap
+        if (update_first && (rc = kmg_lloyd_update(s, d_acc4, stream)) != KMG_OK) return rc;
+        return kmg_lloyd_assign_accumulate(s, d_rgba, n, d_labels, d_acc4, stream);
+    }
+    hipStream_t st = S(stream);
+    ColourTable &t = s->tab;
+    if (!s->side) {
+        int least = 0, greatest = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_TRY(hipStreamCreateWithPriority(&s->side, hipStreamNonBlocking, greatest));
+        HIP_TRY(hipEventCreateWithFlags(&s->ev_cube, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&s->ev_lab[0], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&s->ev_lab[1], hipEventDisableTiming));
+    }
+    const size_t sub_bytes = sizeof(uint16_t) * (kSubCells + kCells) + sizeof(uint32_t) * kCells;
+    if (!t.d_colour_labels_alt) {
+        HIP_TRY(hipMalloc(&t.d_colour_labels_alt, (size_t)(s->k <= 256 ? 1 : 2) << 24));
+        HIP_TRY(hipMalloc((void **)&t.d_sub_alt, sub_bytes));
+        HIP_TRY(hipMemsetAsync(t.d_sub_alt, 0xFF, sub_bytes, st));     // as bind_image_impl does for the first set
+    }
+    // write the other set; its last reader (the label pass of two iterations ago) must be through
+    std::swap(t.d_colour_labels, t.d_colour_labels_alt);
+    std::swap(t.d_sub, t.d_sub_alt);
+    s->set ^= 1;
+    if (s->lab_pending[s->set]) {
+        HIP_TRY(hipStreamWaitEvent(st, s->ev_lab[s->set], 0));
+        s->lab_pending[s->set] = false;
+    }
+    t.bound_by_init = false;
+    if (update_first)
+        PROF_LAUNCH(s, KMG_K_UPDATE, st, launch_update(d_acc4, s->k, s->p->opt.convergence, s->d_cent, s->d_nconv, st));
+    HIP_TRY(hipMemsetAsync(d_acc4, 0, sizeof(int64_t) * 4ull * s->k, st));
+    PROF_LAUNCH(s, KMG_K_CUBE, st, launch_cube(t.d_hist, t.d_agg, t.d_sub_agg, t.d_occ, t.d_work, s->p->d_bounds, s->p->d_sub_bounds,
+                                               s->d_cent, s->k, s->p->d_lab_table, t.d_masks, t.d_cell_work, t.d_colour_labels, t.d_sub,
+                                               d_acc4, 1u, 0u, nullptr, st));
+    t.tables_valid = true;
+    HIP_TRY(hipEventRecord(s->ev_cube, st));
+    HIP_TRY(hipStreamWaitEvent(s->side, s->ev_cube, 0));
+    PROF_LAUNCH(s, KMG_K_LABELS, s->side, launch_labels((const uint32_t *)d_rgba, n, t.d_colour_labels, t.d_sub, s->k, nullptr,
+                                                        d_labels, s->side));
+    HIP_TRY(hipEventRecord(s->ev_lab[s->set], s->side));
+    s->lab_pending[s->set] = true;
+    return KMG_OK;
+}
+
+extern "C" int kmg_lloyd_flush(kmg_lloyd *s, void *stream)
+{
+    if (!s) return fail(KMG_ERR_INVALID_ARGUMENT, "bad flush arguments");
+    HIP_TRY(hipSetDevice(s->p->device));
+    return side_flush(s, S(stream));
+}
+
 extern "C" int kmg_lloyd_converged_count(kmg_lloyd *s, uint32_t *count, void *stream)
 {
     if (!s || !count) return fail(KMG_ERR_INVALID_ARGUMENT, "bad converged_count arguments");
@@ -1078,8 +1244,13 @@ extern "C" int kmg_lloyd_run(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, ui
     // large problems iterate over the image's colour table instead of its pixels (same results);
     // the loop itself only needs the sums, so with the table the per-pixel label map is written
     // once, after the last iteration (the per-pixel scan writes it in the same pass for free)
-    if (!table_bound(s, d_rgba, n))
-        if ((rc = kmg_lloyd_prepare(s, d_rgba, n, 0, nullptr, stream)) != KMG_OK) return rc;
+    // A binding made by the caller (kmg_lloyd_bind_image / _prepare) is trusted.  Any other one is (re)made
+    // here from the buffer's CURRENT contents -- only the initialisation of this very problem may hand its
+    // binding over (prepare keeps it) -- and dropped before returning: a later run on the same buffer with
+    // new pixels must not meet the histogram of the old ones.
+    const bool callers = table_bound(s, d_rgba, n) && s->tab.bound_by_caller;
+    if (!callers)
+        if ((rc = prepare_impl(s, d_rgba, n, 0, nullptr, stream, false)) != KMG_OK) return rc;
     const bool table = table_bound(s, d_rgba, n);
     uint32_t *loop_labels = table ? nullptr : d_labels;
     // operations.rs:75-83 initial assignment (fused with the sums the first update needs)
@@ -1101,6 +1272,7 @@ extern "C" int kmg_lloyd_run(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, ui
         PROF_LAUNCH(s, KMG_K_LABELS, S(stream), launch_labels((const uint32_t *)d_rgba, n, s->tab.d_colour_labels,
                                                               s->tab.d_sub, s->k, nullptr, d_labels, S(stream)));
     HIP_TRY(hipStreamSynchronize(S(stream)));
+    if (table && !callers) { s->tab.rgba = nullptr; s->tab.tables_valid = false; }
     if (iterations) *iterations = it < o.max_iterations ? it : o.max_iterations - 1;
     return KMG_OK;
 }
@@ -1113,6 +1285,8 @@ extern "C" int kmg_dev_apply(kmg_processor *p, const uint8_t *d_rgba, uint32_t w
     if (k > KMG_MAX_K) return fail(KMG_ERR_UNSUPPORTED, "k = %u exceeds KMG_MAX_K = %u", k, KMG_MAX_K);
     if (mode != KMG_MODE_REPLACE && mode != KMG_MODE_DITHER && mode != KMG_MODE_MELD)
         return fail(KMG_ERR_INVALID_ARGUMENT, "unknown mode %d", mode);
+    // the output kernels keep the pixel index (and from it the Bayer coordinates) in 32 bits
+    if ((uint64_t)w * rows > 0xFFFFFFFFull) return fail(KMG_ERR_UNSUPPORTED, "band has more than 2^32-1 pixels");
     HIP_TRY(hipSetDevice(p->device));
 
     // per-centroid work on the host: (L,a,b,C) table, RGBA8 palette (lab_to_rgb.wgsl), threshold
@@ -1166,13 +1340,15 @@ extern "C" int kmg_dev_apply(kmg_processor *p, const uint8_t *d_rgba, uint32_t w
         // label tables -- the same bit-exact machinery as the Lloyd label pass
         if ((rc = ensure_bounds(p, S(stream))) == KMG_OK) {
             const size_t sub_bytes = sizeof(uint16_t) * (kSubCells + kCells) + sizeof(uint32_t) * kCells;
-            e = masks.alloc(sizeof(uint64_t) * (size_t)kCells * mask_words(k), S(stream));
-            if (e == hipSuccess) e = colour_labels.alloc((size_t)(k <= 256 ? 1 : 2) << 24, S(stream));
+            StreamBuf cwork;
+            e = colour_labels.alloc((size_t)(k <= 256 ? 1 : 2) << 24, S(stream));
             if (e == hipSuccess) e = sub.alloc(sub_bytes, S(stream));
-            if (e == hipSuccess) e = launch_cell_candidates(p->d_bounds, nullptr, d_cent, k, (uint64_t *)masks.ptr, nullptr, 0, S(stream));
+            if (e == hipSuccess) e = masks.alloc(sizeof(uint64_t) * (size_t)kCells * mask_words(k), S(stream));
+            if (e == hipSuccess) e = cwork.alloc(cube_work_bytes(), S(stream));
             if (e == hipSuccess)
-                e = launch_cube(nullptr, nullptr, (const uint64_t *)masks.ptr, nullptr, d_cent, k, p->d_lab_table,
-                                colour_labels.ptr, (uint16_t *)sub.ptr, nullptr, 0, S(stream));
+                e = launch_cube(nullptr, nullptr, nullptr, nullptr, nullptr, p->d_bounds, p->d_sub_bounds, d_cent, k, p->d_lab_table,
+                                (uint64_t *)masks.ptr, cwork.ptr, colour_labels.ptr, (uint16_t *)sub.ptr, nullptr, 0, 0u, nullptr,
+                                S(stream));
             if (e == hipSuccess)
                 e = launch_labels((const uint32_t *)d_rgba, n_px, colour_labels.ptr, (const uint16_t *)sub.ptr, k, d_pal,
                                   (uint32_t *)d_out, S(stream));

@@ -1,0 +1,743 @@
+// kmg_cube.hip -- the per-iteration pass of the colour-table strategy over the colour cube (kmg_table.h), in
+// three launches of one wave per 8x8x8 colour cell each.  Every one of them is a chain of dependent steps per
+// wave, so what they need is many resident waves: split this way each keeps few registers.
+//
+//   k_cube_stage  1. cell candidates -- lanes strided over the centroids: interval bounds [lo_j, hi_j] of the key
+//                    over the cell (static bounds, kmg_table_dev.h key_range), U = min_j hi_j, keep
+//                    lo_j <= U (1 + slack).  One candidate -> the whole cell belongs to it: sums from the
+//                    per-cell table of the image, one pair entry, NO per-colour traffic at all.
+//                 2. sub-cell stage -- the (<= 32) candidates are listed; lane (s, c) bounds candidate c over the
+//                    4x4x4 sub-cell s with the sub-cell's own static bounds; per sub-cell the same U / lo test.
+//                    One candidate -> the sub-cell belongs to it: sums from the per-sub-cell table, 64 labels.
+//                    What is left goes into the cell's work record (candidate list, per-sub-cell sets).
+//   k_cube_scan   3. undecided sub-cells, two per step, ONE colour of each per lane: (L, a, b, C) and the count
+//                    are fully coalesced 1 KiB + 256 B loads per sub-cell; the colour scans the candidates of the
+//                    two sub-cells in index order (a centroid outside a sub-cell's own set is provably neither its
+//                    arg-min nor a near-tie, so visiting it changes nothing).
+//   k_cube_pairs  4. (k <= 256) the pair entry of every cell with more than one candidate, from its 512
+//                    per-colour labels and the image's occupancy bits; (k > 256) the cell summary.
+// Exactness: bounds are float-monotone interval evaluations of the very operations of cie94_key, so the
+// arg-min of every colour (and everything within the near-tie threshold of it) survives both prunings; sums are
+// integers.  tests/test_gpu_table.py compares every label / sum with the per-pixel scan and the oracle.
+// Compile with -ffp-contract=off.
+
+#include "kmg_table_dev.h"
+
+#include <stdlib.h>
+
+namespace kmg {
+
+namespace {
+
+constexpr uint32_t kMaxListed = 32;       // candidates per cell the sub-cell stage handles (4 rounds of 8 lanes)
+
+__device__ __forceinline__ uint32_t sel3(uint32_t i, uint32_t x0, uint32_t x1, uint32_t x2)
+{
+    return i == 0u ? x0 : (i == 1u ? x1 : x2);
+}
+
+__device__ __forceinline__ int round_dir(int g, int m)           // rint(2 g / m), |g| <= m, m > 0
+{
+    const int a = g < 0 ? -g : g;
+    const int r = (4 * a >= 3 * m ? 1 : 0) + (4 * a >= m ? 1 : 0);
+    return g < 0 ? -r : r;
+}
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+
+// ------------------------------------------------------------------------------------------
+// pair entry of one cell (kmg_table.h).  Lane l holds the colours 8 l .. 8 l + 7 of the cell
+// (l = [r2 g2 b2 r1 r0 g1], q = [g0 b1 b0]); idx[q] their labels, bit q of occ = the colour is occupied.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t cell_pair_entry(const uint32_t idx[8], uint32_t occ, uint32_t lane)
+{
+    // the (up to) three first distinct labels among the occupied colours, their colours and counts (per-lane
+    // counts are <= 8, wave totals <= 512: three 10-bit counters share one DPP reduction)
+    uint32_t rem = occ;
+    uint32_t lab0 = 0, lab1 = 0, lab2 = 0, cnt0 = 0, cnt1 = 0, cnt2 = 0, msk0 = 0, msk1 = 0, msk2 = 0, n_occ = 0;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const unsigned long long any = __ballot(rem != 0u);
+        if (any) {
+            uint32_t mine = 0;
+#pragma unroll
+            for (int q = 7; q >= 0; --q) mine = ((rem >> q) & 1u) ? idx[q] : mine;
+            const uint32_t v = lane_value(mine, (uint32_t)__builtin_ctzll(any));
+            uint32_t mm = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) mm |= (idx[q] == v ? 1u : 0u) << q;
+            mm &= rem;
+            rem &= ~mm;
+            const uint32_t packed = wave_add_u32((uint32_t)__builtin_popcount(mm) | (t == 0 ? (uint32_t)__builtin_popcount(occ) << 10 : 0u));
+            const uint32_t c = packed & 1023u;
+            if (t == 0) { lab0 = v; msk0 = mm; cnt0 = c; n_occ = packed >> 10; }
+            if (t == 1) { lab1 = v; msk1 = mm; cnt1 = c; }
+            if (t == 2) { lab2 = v; msk2 = mm; cnt2 = c; }
+        }
+    }
+    // A = the most frequent of them, B = the runner-up
+    uint32_t a = 0;
+    if (cnt1 > cnt0) a = 1;
+    if (cnt2 > sel3(a, cnt0, cnt1, cnt2)) a = 2;
+    uint32_t b = a == 0u ? 1u : 0u;
+    if (a != 1u && b != 1u && cnt1 > sel3(b, cnt0, cnt1, cnt2)) b = 1;
+    if (a != 2u && cnt2 > sel3(b, cnt0, cnt1, cnt2)) b = 2;
+    const uint32_t labA = sel3(a, lab0, lab1, lab2), labB = sel3(b, lab0, lab1, lab2);
+    const uint32_t mA = sel3(a, msk0, msk1, msk2), mB = sel3(b, msk0, msk1, msk2);
+    const uint32_t rest = occ & ~mA;                              // occupied colours with another label
+    const uint32_t nA = sel3(a, cnt0, cnt1, cnt2), nR = n_occ - nA;
+    if (nR == 0u) return pair_entry(labA, labA, 0u, 0u, 0u);
+
+    // direction: from the centre of mass of A towards the one of the rest, at half-cell resolution
+    // (lane bits 5, 4, 3 = r2, g2, b2), rounded to components in -2..2.  Any direction is valid
+    // (tlo and w below are exact for it); a good one only makes the slab thin.
+    const uint32_t half = ((lane >> 5) & 1u) | (((lane >> 4) & 1u) << 10) | (((lane >> 3) & 1u) << 20);   // r2, g2, b2 of this lane
+    const uint32_t hR = wave_add_u32((uint32_t)__builtin_popcount(rest) * half);
+    const uint32_t hA = wave_add_u32((uint32_t)__builtin_popcount(mA) * half);
+    const int gx = (int)((hR & 1023u) * nA) - (int)((hA & 1023u) * nR);
+    const int gy = (int)(((hR >> 10) & 1023u) * nA) - (int)(((hA >> 10) & 1023u) * nR);
+    const int gz = (int)((hR >> 20) * nA) - (int)((hA >> 20) * nR);
+    const int ax = gx < 0 ? -gx : gx, ay = gy < 0 ? -gy : gy, az = gz < 0 ? -gz : gz;
+    const int m = ax > ay ? (ax > az ? ax : az) : (ay > az ? ay : az);
+    int nx = 2, ny = 0, nz = 0;
+    if (m > 0) { nx = round_dir(gx, m); ny = round_dir(gy, m); nz = round_dir(gz, m); }
+
+    // p of this lane's colours: x = r & 7 and the high bits of y, z are lane constants
+    const int xl = (int)(((lane >> 5) & 1u) * 4u + ((lane >> 1) & 3u));
+    const int yl = (int)(((lane >> 4) & 1u) * 4u + (lane & 1u) * 2u);
+    const int zl = (int)(((lane >> 3) & 1u) * 4u);
+    const int bias = 7 * ((nx < 0 ? -nx : 0) + (ny < 0 ? -ny : 0) + (nz < 0 ? -nz : 0));
+    const int p0 = nx * xl + ny * yl + nz * zl + bias;
+    int p[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) p[q] = p0 + ny * (q >> 2) + nz * (q & 3);
+    // tlo = lowest p of a colour that is not A, thi = highest p of a colour that is not B
+    const uint32_t notB = occ & ~mB;
+    uint32_t tl = 63u, hi = 64u;                                  // hi = 63 - thi
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        if ((rest >> q) & 1u) tl = min(tl, (uint32_t)p[q]);
+        if ((notB >> q) & 1u) hi = min(hi, (uint32_t)(63 - p[q]));
+    }
+    u16x2 packed = __builtin_bit_cast(u16x2, tl | (hi << 16));
+    packed = __builtin_elementwise_min(packed, __builtin_bit_cast(u16x2, dpp_u32<kDppXor1>(__builtin_bit_cast(uint32_t, packed))));
+    packed = __builtin_elementwise_min(packed, __builtin_bit_cast(u16x2, dpp_u32<kDppXor2>(__builtin_bit_cast(uint32_t, packed))));
+    packed = __builtin_elementwise_min(packed, __builtin_bit_cast(u16x2, dpp_u32<kDppHalfMirror>(__builtin_bit_cast(uint32_t, packed))));
+    packed = __builtin_elementwise_min(packed, __builtin_bit_cast(u16x2, dpp_u32<kDppMirror>(__builtin_bit_cast(uint32_t, packed))));
+    const uint32_t pk = __builtin_bit_cast(uint32_t, packed);
+    const uint32_t r0 = lane_value(pk, 0), r1 = lane_value(pk, 16), r2 = lane_value(pk, 32), r3 = lane_value(pk, 48);
+    const int tlo = (int)min(min(r0 & 0xFFFFu, r1 & 0xFFFFu), min(r2 & 0xFFFFu, r3 & 0xFFFFu));
+    const int thi = 63 - (int)min(min(r0 >> 16, r1 >> 16), min(r2 >> 16, r3 >> 16));
+    const int w = thi + 1 > tlo ? thi + 1 - tlo : 0;
+    const uint32_t code = pair_dir_code(nx, ny, nz);
+    if (w <= 6) return pair_entry(labA, labB, code, (uint32_t)tlo, (uint32_t)w);
+    // the slab is too wide to encode (a third label, or a strongly curved boundary): keep the
+    // side that resolves more colours, the other one goes through the per-colour table
+    uint32_t low = 0, high = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        if ((occ >> q) & 1u) { low += p[q] < tlo ? 1u : 0u; high += p[q] > thi ? 1u : 0u; }
+    }
+    const uint32_t lh = wave_add_u32(low | (high << 10));
+    if ((lh & 1023u) >= (lh >> 10)) return pair_entry(labA, labB, code, (uint32_t)tlo, 7u);
+    const int range = 7 * ((nx < 0 ? -nx : nx) + (ny < 0 ? -ny : ny) + (nz < 0 ? -nz : nz));
+    return pair_entry(labB, labA, pair_dir_code(-nx, -ny, -nz), (uint32_t)(range - thi), 7u);
+}
+
+__device__ __forceinline__ uint32_t merge_state(uint32_t a, uint32_t b)       // label / kSubEmpty / kSubMixed
+{
+    return (a == kSubEmpty) ? b : ((b == kSubEmpty || b == a) ? a : (uint32_t)kSubMixed);
+}
+
+// 64 consecutive labels of a sub-cell, lane l holding label l: four (u8) / two (u16) neighbouring lanes
+// combine theirs into one dword through DPP, so a sub-cell is 16 (32) dword stores instead of 64 byte stores
+template <typename LabelT>
+__device__ __forceinline__ void store_labels64(LabelT *dst64, uint32_t label, uint32_t lane)
+{
+    if (sizeof(LabelT) == 1) {
+        const uint32_t t = label | (dpp_u32<kDppXor1>(label) << 8);          // even lane: own | next << 8
+        const uint32_t u = t | (dpp_u32<kDppXor2>(t) << 16);                  // lane % 4 == 0: four labels in order
+        if ((lane & 3u) == 0u) reinterpret_cast<uint32_t *>(dst64)[lane >> 2] = u;
+    } else {
+        const uint32_t t = label | (dpp_u32<kDppXor1>(label) << 16);
+        if ((lane & 1u) == 0u) reinterpret_cast<uint32_t *>(dst64)[lane >> 1] = t;
+    }
+}
+
+
+// What k_cube_stage leaves for k_cube_scan, one record per cell (128 B)
+struct alignas(16) CellWork {
+    uint16_t list[kMaxListed];     // the cell's candidates in index order (listed cells)
+    unsigned long long br[4];      // round r: bit 8 s + c = sub-cell s keeps candidate 8 r + c of the list
+    uint32_t npop;                 // number of candidates of the cell
+    uint32_t scan_set;             // bits 0..7: sub-cells whose colours are scanned; bit 8: the cell is listed
+    uint32_t pad[6];
+};
+static_assert(sizeof(CellWork) == 128, "CellWork layout");
+
+constexpr uint32_t kPairPending = 0xFFFFFFFEu;   // pair entry of a cell k_cube_pairs still has to derive
+
+// LDS bins: repl copies of k x 4 u64, consecutive copies 32 B further along the bank row
+__device__ __forceinline__ void flush_bins(const unsigned long long *bins, uint32_t k, uint32_t repl, uint32_t bin_stride,
+                                           int64_t *sums, uint32_t n_rows)
+{
+    __syncthreads();
+    // only the clusters this workgroup met are non-zero
+    unsigned long long *row = reinterpret_cast<unsigned long long *>(sums) + (uint64_t)(blockIdx.x % n_rows) * 4ull * k;
+    for (uint32_t i = threadIdx.x; i < 4u * k; i += kBlock) {
+        unsigned long long v = 0ull;
+        for (uint32_t r = 0; r < repl; ++r) v += bins[(uint64_t)r * bin_stride + i];
+        if (v) atomicAdd(row + i, v);
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// k_cube_stage.  LDS: [centroids kpad x 16 B, kpad = k rounded up to 64][bins k x 32 B (SUMS)]
+//                     [candidate list 4 waves x 32 u32][cell masks 4 waves x words u64]
+// SUMS = false (output pass of find / reduce in replace mode): no image -- every colour of every cell counts
+// once, nothing is accumulated; agg, sub_agg, work and sums are unused.
+// flags bit 0: also write the 512 per-colour labels of single-candidate cells (debug / statistics).
+// flags bits 8..: knock-outs for tools/cube_knockout.py (results are then WRONG; never set by the library):
+//   9 no sums, 10 no colour scan, 11 every cell handled as a single-candidate cell, 12 no sub-cell stage
+// stats (optional, u64[6]): single-candidate cells, other cells, sub-cells decided by their bounds, sub-cells
+// scanned, candidates summed over the scanned sub-cells, cells with more than kMaxListed candidates
+// ------------------------------------------------------------------------------------------
+template <typename LabelT, bool SUMS>
+__global__ __launch_bounds__(kBlock) void k_cube_stage(const int64_t *__restrict__ agg,
+                                                       const int64_t *__restrict__ sub_agg,
+                                                       const uint32_t *__restrict__ work,
+                                                       const CellBounds *__restrict__ bounds,
+                                                       const CellBounds *__restrict__ sub_bounds,
+                                                       const Centroid *__restrict__ cent, uint32_t k,
+                                                       uint64_t *__restrict__ masks_out,
+                                                       CellWork *__restrict__ cell_work,
+                                                       LabelT *__restrict__ colour_labels,
+                                                       uint16_t *__restrict__ sub_table,
+                                                       int64_t *__restrict__ sums, uint32_t n_rows,
+                                                       uint32_t flags, unsigned long long *__restrict__ stats)
+{
+    extern __shared__ float4 smem4[];
+    const uint32_t kpad = (k + 63u) & ~63u;
+    const uint32_t words = kpad / 64u;
+    float4 *s_cent = smem4;
+    unsigned long long *bins = reinterpret_cast<unsigned long long *>(smem4 + kpad);
+    const uint32_t n_bins = SUMS ? 4u * k : 0u;
+    uint32_t *s_list_all = reinterpret_cast<uint32_t *>(bins + n_bins);
+    unsigned long long *s_masks_all = reinterpret_cast<unsigned long long *>(s_list_all + (kBlock / 64) * kMaxListed);
+
+    for (uint32_t i = threadIdx.x; i < kpad; i += kBlock) {
+        float4 v = make_float4(1.0e18f, 0.0f, 0.0f, 0.0f);       // key ~ 1e36: never a candidate
+        if (i < k) { const Centroid c = cent[i]; v = make_float4(c.L, c.a, c.b, c.C); }
+        s_cent[i] = v;
+    }
+    for (uint32_t i = threadIdx.x; i < n_bins; i += kBlock) bins[i] = 0ull;
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wv = threadIdx.x >> 6;
+    uint32_t *s_list = s_list_all + wv * kMaxListed;
+    unsigned long long *s_masks = s_masks_all + wv * words;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / 64) + wv);
+    const uint32_t n_waves = gridDim.x * (kBlock / 64);
+    const uint32_t sub_of_lane = lane >> 3, cand_of_lane = lane & 7u;
+    const float *bf = reinterpret_cast<const float *>(bounds);
+    unsigned long long st_single = 0, st_multi = 0, st_decided = 0, st_scanned = 0, st_cands = 0, st_unlisted = 0;
+
+    const uint32_t n_work = SUMS ? __builtin_amdgcn_readfirstlane(work[0]) : kCells;
+    // the small per-cell data of the NEXT cell are requested while the current one is worked on
+    uint32_t cell_n = 0;
+    float bv_n = 0.0f;
+    long long sagg_n = 0, cagg_n = 0;
+#define KMG_REQUEST_CELL(wi_)                                                                                    \
+    do {                                                                                                         \
+        if ((wi_) < n_work) {                                                                                    \
+            cell_n = SUMS ? __builtin_amdgcn_readfirstlane(work[1u + (wi_)]) : (wi_);                            \
+            bv_n = bf[(uint64_t)cell_n * 16u + (lane & 15u)];                                                    \
+            if (SUMS) {                                                                                          \
+                sagg_n = sub_agg[(uint64_t)cell_n * 32u + (lane & 31u)];    /* lane 4 s + j: sum j of sub-cell s */ \
+                cagg_n = agg[4ull * cell_n + (lane & 3u)];                                                       \
+            }                                                                                                    \
+        }                                                                                                        \
+    } while (0)
+    KMG_REQUEST_CELL(wave);
+    for (uint32_t wi = wave; wi < n_work; wi += n_waves) {
+        const uint32_t cell = cell_n;
+        const float bv = bv_n;
+        const long long sagg = sagg_n, cagg = cagg_n;
+        KMG_REQUEST_CELL(wi + n_waves);
+        // the sub-cell bounds of THIS cell: requested now, needed after the cell's candidates are known
+        const float4 *sbp = reinterpret_cast<const float4 *>(sub_bounds + (uint64_t)cell * 8u + sub_of_lane);
+        const float4 sb0 = sbp[0], sb1 = sbp[1], sb2 = sbp[2];
+
+        uint16_t *sub = sub_table + cell * 8u;
+        uint16_t *cell_entry = sub_table + kSubCells + cell;       // 8x8x8 summary, same encoding
+        uint32_t *pair_entry_ptr = reinterpret_cast<uint32_t *>(sub_table + kSubCells + kCells) + cell;   // k <= 256
+        LabelT *cell_labels = colour_labels + (uint64_t)cell * kCellColours;
+        CellWork *cw = cell_work + cell;
+
+        // ---- 1. candidates of the cell ----
+        CellBounds cb;
+        cb.L0 = lane_value(bv, 0); cb.L1 = lane_value(bv, 1); cb.a0 = lane_value(bv, 2); cb.a1 = lane_value(bv, 3);
+        cb.b0 = lane_value(bv, 4); cb.b1 = lane_value(bv, 5); cb.C0 = lane_value(bv, 6); cb.C1 = lane_value(bv, 7);
+        cb.wC0 = lane_value(bv, 8); cb.wC1 = lane_value(bv, 9); cb.wH0 = lane_value(bv, 10); cb.wH1 = lane_value(bv, 11);
+        unsigned long long mw[4] = {0ull, 0ull, 0ull, 0ull};      // the mask itself when words <= 4 (k <= 256)
+        uint32_t npop = 0, first = 0;
+        if (words <= 4u) {
+            float U = 3.0e38f, lo[4];
+#pragma unroll
+            for (uint32_t w = 0; w < 4u; ++w) {
+                lo[w] = 3.0e38f;
+                if (w < words) {
+                    const float4 c = s_cent[w * 64u + lane];
+                    const KeyRange r = key_range(cb, c.x, c.y, c.z, c.w);
+                    lo[w] = r.lo;
+                    U = fminf(U, r.hi);                            // padding entries: hi ~ 1e36
+                }
+            }
+            const float Us = mask_threshold(wave_min(U));
+#pragma unroll
+            for (uint32_t w = 0; w < 4u; ++w) {
+                if (w < words) {
+                    mw[w] = __ballot(w * 64u + lane < k && lo[w] <= Us);
+                    if (npop == 0u && mw[w]) first = w * 64u + (uint32_t)__builtin_ctzll(mw[w]);
+                    npop += (uint32_t)__builtin_popcountll(mw[w]);
+                }
+            }
+        } else {
+            float U = 3.0e38f;
+            for (uint32_t j = lane; j < k; j += 64u) {
+                const float4 c = s_cent[j];
+                U = fminf(U, key_range(cb, c.x, c.y, c.z, c.w).hi);
+            }
+            const float Us = mask_threshold(wave_min(U));
+            for (uint32_t w = 0; w < words; ++w) {
+                const uint32_t j = w * 64u + lane;
+                const float4 c = s_cent[j];
+                const unsigned long long m = __ballot(j < k && key_range(cb, c.x, c.y, c.z, c.w).lo <= Us);
+                if (lane == 0u) s_masks[w] = m;
+                if (npop == 0u && m) first = j - lane + (uint32_t)__builtin_ctzll(m);
+                npop += (uint32_t)__builtin_popcountll(m);
+            }
+        }
+        {
+            uint64_t *out = masks_out + (uint64_t)cell * ((k + 63u) / 64u);
+            if (words <= 4u) {
+#pragma unroll
+                for (uint32_t w = 0; w < 4u; ++w)
+                    if (w < words && lane == 0u) out[w] = mw[w];
+            } else {
+                for (uint32_t w = lane; w < words; w += 64u) out[w] = s_masks[w];
+            }
+        }
+
+        if (npop == 1u || (flags & 0x800u)) {
+            // the whole cell belongs to `first`: sums from the cell table, no per-colour traffic
+            if (sizeof(LabelT) == 1) {
+                if (lane == 0u) *pair_entry_ptr = pair_entry(first, first, 0u, 0u, 0u);
+            } else {
+                if (lane < 8u) sub[lane] = (uint16_t)first;
+                if (lane == 0u) *cell_entry = (uint16_t)first;
+            }
+            if (lane == 0u) { cw->npop = 1u; cw->scan_set = 0u; }
+            if (SUMS && lane < 4u) atomicAdd(bins + 4ull * first + lane, (unsigned long long)cagg);
+            if (flags & 1u) {
+#pragma unroll
+                for (uint32_t s = 0; s < 8u; ++s) store_labels64(cell_labels + s * 64u, first, lane);
+            }
+            st_single += 1;
+            continue;
+        }
+        st_multi += 1;
+
+        // ---- 2. sub-cell stage: list the candidates, bound each over each sub-cell ----
+        const bool listed = npop <= kMaxListed && !(flags & 0x1000u);
+        uint32_t my_cand = 0;                                       // lane p < npop: the p-th candidate
+        unsigned long long br[4] = {0ull, 0ull, 0ull, 0ull};       // round r: bit 8 s + c = sub-cell s keeps candidate 8 r + c
+        if (listed) {
+            uint32_t base = 0;
+            if (words <= 4u) {
+#pragma unroll
+                for (uint32_t w = 0; w < 4u; ++w) {
+                    if (w < words) {
+                        if ((mw[w] >> lane) & 1ull) s_list[base + bits_below_lane(mw[w])] = w * 64u + lane;
+                        base += (uint32_t)__builtin_popcountll(mw[w]);
+                    }
+                }
+            } else {
+                for (uint32_t w = 0; w < words; ++w) {
+                    const unsigned long long m = uniform_u64(s_masks[w]);
+                    if ((m >> lane) & 1ull) s_list[base + bits_below_lane(m)] = w * 64u + lane;
+                    base += (uint32_t)__builtin_popcountll(m);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            my_cand = s_list[lane & (kMaxListed - 1u)];
+            __builtin_amdgcn_wave_barrier();
+            if (lane < kMaxListed) cw->list[lane] = (uint16_t)(lane < npop ? my_cand : 0u);
+
+            CellBounds sb;
+            sb.L0 = sb0.x; sb.L1 = sb0.y; sb.a0 = sb0.z; sb.a1 = sb0.w;
+            sb.b0 = sb1.x; sb.b1 = sb1.y; sb.C0 = sb1.z; sb.C1 = sb1.w;
+            sb.wC0 = sb2.x; sb.wC1 = sb2.y; sb.wH0 = sb2.z; sb.wH1 = sb2.w;
+            const uint32_t rounds = (npop + 7u) >> 3;
+            float Usub = 3.0e38f, lo[4];
+#pragma unroll
+            for (uint32_t r = 0; r < 4u; ++r) {
+                lo[r] = 3.0e38f;
+                if (r < rounds) {
+                    const uint32_t pos = r * 8u + cand_of_lane;    // < 32: lanes pos and pos + 32 hold the same candidate
+                    const uint32_t j = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(pos << 2), (int)my_cand);
+                    if (pos < npop) {
+                        const float4 c = s_cent[j];
+                        const KeyRange kr = key_range(sb, c.x, c.y, c.z, c.w);
+                        lo[r] = kr.lo;
+                        Usub = fminf(Usub, kr.hi);
+                    }
+                }
+            }
+            const float Us = mask_threshold(group8_min(Usub));
+#pragma unroll
+            for (uint32_t r = 0; r < 4u; ++r)
+                if (r < rounds) br[r] = __ballot(lo[r] <= Us);
+            if (lane < 4u) cw->br[lane] = lane == 0u ? br[0] : (lane == 1u ? br[1] : (lane == 2u ? br[2] : br[3]));
+        } else {
+            st_unlisted += 1;
+        }
+
+        // what each sub-cell needs: empty / decided as a whole (one candidate) / scan its colours
+        uint32_t scan_set = 0u;
+        uint32_t cell_state = kSubEmpty;
+#pragma unroll
+        for (uint32_t s = 0; s < 8u; ++s) {
+            const bool occupied = SUMS ? (lane_value64(sagg, 4u * s + 3u) != 0) : true;
+            if (!occupied) {
+                if (sizeof(LabelT) != 1 && lane == 0u) sub[s] = kSubEmpty;
+                continue;
+            }
+            uint32_t sm = 0u;
+#pragma unroll
+            for (uint32_t r = 0; r < 4u; ++r) sm |= ((uint32_t)(br[r] >> (8u * s)) & 0xFFu) << (8u * r);
+            if (listed && __builtin_popcount(sm) == 1) {
+                const uint32_t X = lane_value(my_cand, (uint32_t)__builtin_ctz(sm));
+                store_labels64(cell_labels + s * 64u, X, lane);
+                if (SUMS && !(flags & 0x200u) && (lane >> 2) == s) atomicAdd(bins + 4ull * X + (lane & 3u), (unsigned long long)sagg);
+                if (sizeof(LabelT) != 1) {
+                    if (lane == 0u) sub[s] = (uint16_t)X;
+                    cell_state = merge_state(cell_state, X);
+                }
+                st_decided += 1;
+            } else if (!(flags & 0x400u)) {
+                scan_set |= 1u << s;
+                st_scanned += 1;
+                st_cands += listed ? (uint32_t)__builtin_popcount(sm) : npop;
+            }
+        }
+        if (lane == 0u) {
+            cw->npop = npop;
+            cw->scan_set = scan_set | (listed ? 0x100u : 0u);
+            if (sizeof(LabelT) == 1) *pair_entry_ptr = kPairPending;
+            else *cell_entry = (uint16_t)cell_state;               // k_cube_pairs merges the scanned sub-cells in
+        }
+    }
+#undef KMG_REQUEST_CELL
+
+    if (stats && lane == 0u) {
+        atomicAdd(stats + 0, st_single); atomicAdd(stats + 1, st_multi); atomicAdd(stats + 2, st_decided);
+        atomicAdd(stats + 3, st_scanned); atomicAdd(stats + 4, st_cands); atomicAdd(stats + 5, st_unlisted);
+    }
+    if (SUMS) flush_bins(bins, k, 1u, 4u * k, sums, n_rows);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_cube_scan.  LDS: [centroids kpad x 16 B][bins repl x (k x 32 + 32) B (SUMS)]
+// flags bits: 9 no sums, 13 no label stores
+// ------------------------------------------------------------------------------------------
+template <typename LabelT, bool SUMS>
+__global__ __launch_bounds__(kBlock) void k_cube_scan(const uint32_t *__restrict__ hist,
+                                                      const int64_t *__restrict__ sub_agg,
+                                                      const uint32_t *__restrict__ work,
+                                                      const Centroid *__restrict__ cent, uint32_t k,
+                                                      const float4 *__restrict__ lab_table,
+                                                      const uint64_t *__restrict__ masks,
+                                                      const CellWork *__restrict__ cell_work,
+                                                      LabelT *__restrict__ colour_labels,
+                                                      uint16_t *__restrict__ sub_table,
+                                                      int64_t *__restrict__ sums, uint32_t n_rows, uint32_t repl,
+                                                      uint32_t flags)
+{
+    extern __shared__ float4 smem4[];
+    const uint32_t kpad = (k + 63u) & ~63u;
+    const uint32_t words = kpad / 64u;
+    float4 *s_cent = smem4;
+    unsigned long long *bins = reinterpret_cast<unsigned long long *>(smem4 + kpad);
+    const uint32_t bin_stride = 4u * k + 4u;                      // u64 per copy (+ 32 B: next copy, other banks)
+    const uint32_t n_bins = SUMS ? repl * bin_stride : 0u;
+    for (uint32_t i = threadIdx.x; i < kpad; i += kBlock) {
+        float4 v = make_float4(1.0e18f, 0.0f, 0.0f, 0.0f);
+        if (i < k) { const Centroid c = cent[i]; v = make_float4(c.L, c.a, c.b, c.C); }
+        s_cent[i] = v;
+    }
+    for (uint32_t i = threadIdx.x; i < n_bins; i += kBlock) bins[i] = 0ull;
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wv = threadIdx.x >> 6;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / 64) + wv);
+    const uint32_t n_waves = gridDim.x * (kBlock / 64);
+    unsigned long long *my_bins = bins + (uint64_t)(lane & (repl - 1u)) * bin_stride;
+
+    const uint32_t n_work = SUMS ? __builtin_amdgcn_readfirstlane(work[0]) : kCells;
+    for (uint32_t wi = wave; wi < n_work; wi += n_waves) {
+        const uint32_t cell = SUMS ? __builtin_amdgcn_readfirstlane(work[1u + wi]) : wi;
+        const CellWork *cw = cell_work + cell;
+        uint32_t scan_set = __builtin_amdgcn_readfirstlane(cw->scan_set);
+        if ((scan_set & 0xFFu) == 0u) continue;                     // one candidate, or every sub-cell decided
+        const bool listed = (scan_set & 0x100u) != 0u;
+        scan_set &= 0xFFu;
+        const uint32_t npop = __builtin_amdgcn_readfirstlane(cw->npop);
+        const uint32_t my_cand = listed ? (uint32_t)cw->list[lane & (kMaxListed - 1u)] : 0u;   // lane p: the p-th candidate ...
+        const unsigned long long br0 = listed ? uniform_u64(cw->br[0]) : 0ull, br1 = listed ? uniform_u64(cw->br[1]) : 0ull;
+        const unsigned long long br2 = listed ? uniform_u64(cw->br[2]) : 0ull, br3 = listed ? uniform_u64(cw->br[3]) : 0ull;
+        const long long sagg = SUMS ? sub_agg[(uint64_t)cell * 32u + (lane & 31u)] : 0;      // lane 4 s + j: sum j of sub-cell s
+        const uint64_t *cmask = masks + (uint64_t)cell * ((k + 63u) / 64u);
+        uint16_t *sub = sub_table + cell * 8u;
+        LabelT *cell_labels = colour_labels + (uint64_t)cell * kCellColours;
+        auto submask_of = [&](uint32_t s) {                        // bit p = the sub-cell keeps candidate p of the list
+            return (((uint32_t)(br0 >> (8u * s)) & 0xFFu)) | (((uint32_t)(br1 >> (8u * s)) & 0xFFu) << 8) |
+                   (((uint32_t)(br2 >> (8u * s)) & 0xFFu) << 16) | (((uint32_t)(br3 >> (8u * s)) & 0xFFu) << 24);
+        };
+
+        // TWO sub-cells per step (two independent dependency chains per lane); the next pair's loads are in
+        // flight while the current one is scanned.  Two register sets A / B alternate, and the loop body exists
+        // once per set: with one loop-carried set the compiler moves components of the freshly loaded (L, a, b, C)
+        // right behind the load, i.e. waits for it, and the prefetch is gone.
+        float4 A_v0, A_v1, B_v0, B_v1;
+        uint32_t A_c0 = 1u, A_c1 = 1u, B_c0 = 1u, B_c1 = 1u, A_s0 = 0u, A_s1 = 8u, B_s0 = 0u, B_s1 = 8u;
+#define KMG_REQUEST_COLOURS(X)                                                                                   \
+        do {                                                                                                     \
+            /* unconditional (an exhausted set re-requests sub-cell 0, unused): a conditional request makes the  \
+               compiler shuffle -- and therefore wait for -- the registers it has just requested */               \
+            X##_s0 = scan_set ? (uint32_t)__builtin_ctz(scan_set) : 8u;                                          \
+            scan_set &= scan_set - 1u;                                                                           \
+            X##_s1 = scan_set ? (uint32_t)__builtin_ctz(scan_set) : 8u;                                          \
+            scan_set &= scan_set - 1u;                                                                           \
+            const uint32_t c0_ = cell * kCellColours + (X##_s0 & 7u) * 64u + lane;                               \
+            const uint32_t c1_ = cell * kCellColours + (X##_s1 & 7u) * 64u + lane;                               \
+            X##_v0 = lab_table[c0_];                                                                             \
+            X##_v1 = lab_table[c1_];                                /* s1 == 8: sub-cell 0 again, unused */      \
+            if (SUMS) { X##_c0 = hist[c0_]; X##_c1 = hist[c1_]; }                                                \
+        } while (0)
+        KMG_REQUEST_COLOURS(A);
+        const float4 my_c = (listed && (lane & (kMaxListed - 1u)) < npop) ? s_cent[my_cand] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // ... and its (L, a, b, C)
+        uint32_t idx[8], label_set = 0u;
+#pragma unroll
+        for (uint32_t q = 0; q < 8u; ++q) idx[q] = 0u;
+        auto scan_pair = [&](const uint32_t s0, const uint32_t s1, const float4 v0, const float4 v1, const uint32_t cnt0,
+                             const uint32_t cnt1) {
+            const uint32_t sm = submask_of(s0) | (s1 < 8u ? submask_of(s1) : 0u);
+
+            const PixelTerms pt0 = pixel_terms_c(v0.x, v0.y, v0.z, v0.w), pt1 = pixel_terms_c(v1.x, v1.y, v1.z, v1.w);
+            float best0 = 1.0e10f, second0 = 1.0e10f, best1 = 1.0e10f, second1 = 1.0e10f;   // find_centroid.wgsl:29-30
+            uint32_t ix0 = 0u, ix1 = 0u;
+            auto visit = [&](uint32_t j, float cL, float ca, float cbb, float cC) {
+                const float d0 = cie94_key(pt0, cL, ca, cbb, cC), d1 = cie94_key(pt1, cL, ca, cbb, cC);
+                const bool lt0 = d0 < best0, lt1 = d1 < best1;
+                if (kLiteralArgmin) {                              // best <= second: the two smallest keys so far
+                    second0 = __builtin_amdgcn_fmed3f(d0, best0, second0);
+                    second1 = __builtin_amdgcn_fmed3f(d1, best1, second1);
+                }
+                best0 = lt0 ? d0 : best0; ix0 = lt0 ? j : ix0;
+                best1 = lt1 ? d1 : best1; ix1 = lt1 ? j : ix1;
+            };
+            auto for_candidates = [&](auto &&f) {
+                if (listed) {
+                    uint32_t m = sm;
+                    while (m) {
+                        const uint32_t pos = (uint32_t)__builtin_ctz(m);
+                        m &= m - 1u;
+                        f(lane_value(my_cand, pos), lane_value(my_c.x, pos), lane_value(my_c.y, pos), lane_value(my_c.z, pos),
+                          lane_value(my_c.w, pos));
+                    }
+                } else {
+                    for (uint32_t w = 0; w < (k + 63u) / 64u; ++w) {
+                        unsigned long long m = uniform_u64(cmask[w]);
+                        while (m) {
+                            const uint32_t j = w * 64u + (uint32_t)__builtin_ctzll(m);
+                            m &= m - 1ull;
+                            const float4 c = s_cent[j];
+                            f(j, c.x, c.y, c.z, c.w);
+                        }
+                    }
+                }
+            };
+            for_candidates(visit);
+            if (kLiteralArgmin) {
+                // near-tie repair (kmg_math.h): rare; decided by the literal distance, first minimum wins
+                const float thr0 = tie_threshold(best0), thr1 = tie_threshold(best1);
+                const bool near0 = second0 <= thr0, near1 = second1 <= thr1;
+                if (__ballot(near0 || near1)) {
+                    float lb0 = 100000.0f, lb1 = 100000.0f;       // find_centroid.wgsl:29-30
+                    uint32_t li0 = 0u, li1 = 0u;
+                    auto revisit = [&](uint32_t j, float cL, float ca, float cbb, float cC) {
+                        if (near0 && cie94_key(pt0, cL, ca, cbb, cC) <= thr0) {
+                            const float d = cie94_c(v0.x, v0.y, v0.z, v0.w, cL, ca, cbb, cC);
+                            if (d < lb0) { lb0 = d; li0 = j; }
+                        }
+                        if (near1 && cie94_key(pt1, cL, ca, cbb, cC) <= thr1) {
+                            const float d = cie94_c(v1.x, v1.y, v1.z, v1.w, cL, ca, cbb, cC);
+                            if (d < lb1) { lb1 = d; li1 = j; }
+                        }
+                    };
+                    for_candidates(revisit);
+                    ix0 = near0 ? li0 : ix0;
+                    ix1 = near1 ? li1 : ix1;
+                }
+            }
+            // what a scanned sub-cell leaves behind: labels (registers, stored at the end of the cell), sums, summary
+            auto finish = [&](uint32_t s, uint32_t ix, uint32_t cnt, float vL, float va, float vb) {
+#pragma unroll
+                for (uint32_t q = 0; q < 8u; ++q) idx[q] = (s == q) ? ix : idx[q];
+                label_set |= 1u << s;
+                const bool counts = cnt != 0u;
+                // sums: the sub-cell's total (sub-cell table) goes to a reference label R; a colour with another
+                // label moves its own contribution from R to that label.  Half of the scanned sub-cells turn out
+                // uniform: no per-colour arithmetic and four LDS adds instead of 256.
+                const unsigned long long occm = __ballot(counts);
+                uint32_t st = kSubEmpty;
+                if (occm) {
+                    const uint32_t X0 = lane_value(ix, (uint32_t)__builtin_ctzll(occm));
+                    const unsigned long long other = __ballot(counts && ix != X0);
+                    uint32_t R = X0;
+                    if (other) {
+                        const uint32_t X1 = lane_value(ix, (uint32_t)__builtin_ctzll(other));
+                        if (__builtin_popcountll(__ballot(counts && ix == X1)) > __builtin_popcountll(occm & ~other)) R = X1;
+                    }
+                    st = other ? (uint32_t)kSubMixed : X0;
+                    if (SUMS && !(flags & 0x200u)) {
+                        if ((lane >> 2) == s) atomicAdd(bins + 4ull * R + (lane & 3u), (unsigned long long)sagg);
+                        if (other && counts && ix != R) {
+                            const long long m = (long long)cnt;
+                            const long long c0 = m * (long long)lab_fix(vL), c1 = m * (long long)lab_fix(va), c2 = m * (long long)lab_fix(vb);
+                            unsigned long long *to = my_bins + 4ull * ix, *from = my_bins + 4ull * R;
+                            atomicAdd(to + 0, (unsigned long long)c0); atomicAdd(from + 0, (unsigned long long)(-c0));
+                            atomicAdd(to + 1, (unsigned long long)c1); atomicAdd(from + 1, (unsigned long long)(-c1));
+                            atomicAdd(to + 2, (unsigned long long)c2); atomicAdd(from + 2, (unsigned long long)(-c2));
+                            atomicAdd(to + 3, (unsigned long long)m);  atomicAdd(from + 3, (unsigned long long)(-m));
+                        }
+                    }
+                }
+                if (sizeof(LabelT) != 1 && lane == 0u) sub[s] = (uint16_t)st;
+            };
+            finish(s0, ix0, cnt0, v0.x, v0.y, v0.z);
+            if (s1 < 8u) finish(s1, ix1, cnt1, v1.x, v1.y, v1.z);
+        };
+        for (;;) {
+            KMG_REQUEST_COLOURS(B);
+            scan_pair(A_s0, A_s1, A_v0, A_v1, A_c0, A_c1);
+            if (B_s0 >= 8u) break;
+            KMG_REQUEST_COLOURS(A);
+            scan_pair(B_s0, B_s1, B_v0, B_v1, B_c0, B_c1);
+            if (A_s0 >= 8u) break;
+        }
+#undef KMG_REQUEST_COLOURS
+        if (!(flags & 0x2000u)) {
+#pragma unroll
+            for (uint32_t s = 0; s < 8u; ++s)
+                if ((label_set >> s) & 1u) store_labels64(cell_labels + s * 64u, idx[s], lane);
+        }
+    }
+    if (SUMS) flush_bins(bins, k, repl, bin_stride, sums, n_rows);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_cube_pairs: pair entries (k <= 256) / cell summaries (k > 256) of the cells k_cube_stage left pending.
+// occ_bits: one bit per colour of the bound image (NULL: every colour counts).
+// ------------------------------------------------------------------------------------------
+template <typename LabelT>
+__global__ __launch_bounds__(kBlock) void k_cube_pairs(const uint32_t *__restrict__ work, int with_work,
+                                                       const uint8_t *__restrict__ occ_bits,
+                                                       const LabelT *__restrict__ colour_labels,
+                                                       uint16_t *__restrict__ sub_table, uint32_t flags)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
+    const uint32_t n_waves = gridDim.x * (kBlock / 64);
+    const uint32_t n_work = with_work ? __builtin_amdgcn_readfirstlane(work[0]) : kCells;
+    for (uint32_t wi = wave; wi < n_work; wi += n_waves) {
+        const uint32_t cell = with_work ? __builtin_amdgcn_readfirstlane(work[1u + wi]) : wi;
+        if (sizeof(LabelT) == 1) {
+            uint32_t *pair_entry_ptr = reinterpret_cast<uint32_t *>(sub_table + kSubCells + kCells) + cell;
+            if (__builtin_amdgcn_readfirstlane(*pair_entry_ptr) != kPairPending) continue;
+            const uint2 lv = *reinterpret_cast<const uint2 *>(colour_labels + (uint64_t)cell * kCellColours + lane * 8u);
+            const uint32_t occ = occ_bits ? (uint32_t)occ_bits[(uint64_t)cell * 64u + lane] : 0xFFu;
+            uint32_t idx[8];
+#pragma unroll
+            for (uint32_t q = 0; q < 4u; ++q) { idx[q] = (lv.x >> (8u * q)) & 0xFFu; idx[4u + q] = (lv.y >> (8u * q)) & 0xFFu; }
+            const uint32_t e = (flags & 0x100u) ? pair_entry(idx[0], idx[0], 0u, 0u, 0u) : cell_pair_entry(idx, occ, lane);
+            if (lane == 0u) *pair_entry_ptr = e;
+        } else {
+            // cell summary = merge of the eight sub-cell summaries (k_cube_stage wrote the decided / empty ones,
+            // k_cube_scan the scanned ones)
+            uint32_t st = lane < 8u ? (uint32_t)sub_table[cell * 8u + lane] : (uint32_t)kSubEmpty;
+#pragma unroll
+            for (int off = 1; off < 8; off <<= 1) st = merge_state(st, (uint32_t)__shfl_xor(st, off, 64));
+            if (lane == 0u) sub_table[kSubCells + cell] = (uint16_t)st;
+        }
+    }
+}
+
+static uint32_t env_grid(const char *name, uint32_t dflt)
+{
+    if (const char *e = getenv(name)) { const int v = atoi(e); if (v >= 1 && v <= 65536) return (uint32_t)v; }
+    return dflt;
+}
+
+uint32_t cube_replicas(uint32_t k)
+{
+    // copies of the scan kernel's LDS bins (lanes spread their atomic adds over them); one by default: two
+    // workgroups then fit into the LDS a label-pass workgroup leaves free on its CU
+    uint32_t r = 1;
+    if (const char *e = getenv("KMG_CUBE_REPL")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) r = (uint32_t)v; }
+    while (r > 1u && (uint64_t)r * (k * 32ull + 32ull) > 33024ull) r >>= 1;
+    return r;
+}
+
+size_t cube_work_bytes() { return sizeof(CellWork) * (size_t)kCells; }
+
+hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *sub_agg, const uint8_t *occ_bits,
+                       const uint32_t *work, const CellBounds *bounds, const CellBounds *sub_bounds, const Centroid *cent,
+                       uint32_t k, const float4 *lab_table, uint64_t *masks, void *cell_work, void *colour_labels,
+                       uint16_t *sub_table, int64_t *sums, uint32_t n_rows, uint32_t flags, unsigned long long *stats,
+                       hipStream_t st)
+{
+    const uint32_t kpad = (k + 63u) & ~63u;
+    const bool with_sums = hist != nullptr;
+    const uint32_t repl = with_sums ? cube_replicas(k) : 1u;
+    if (const char *e = getenv("KMG_CUBE_FLAGS")) flags |= (uint32_t)strtoul(e, nullptr, 0) & 0xFF00u;
+    const size_t lds_stage = sizeof(float4) * kpad + (with_sums ? sizeof(unsigned long long) * 4ull * k : 0) +
+                             sizeof(uint32_t) * (kBlock / 64) * kMaxListed + sizeof(unsigned long long) * (kBlock / 64) * (kpad / 64u);
+    const size_t lds_scan = sizeof(float4) * kpad + (with_sums ? sizeof(unsigned long long) * (4ull * k + 4ull) * repl : 0);
+    static const uint32_t g_stage = env_grid("KMG_CUBE_GRID", kCubeGrid), g_scan = env_grid("KMG_SCAN_GRID", kCubeGrid),
+                          g_pairs = env_grid("KMG_PAIRS_GRID", kCubeGrid);
+    CellWork *cw = (CellWork *)cell_work;
+    if (!n_rows) n_rows = 1u;
+#define KMG_CUBE(T, S)                                                                                                      \
+    do {                                                                                                                    \
+        hipLaunchKernelGGL((k_cube_stage<T, S>), dim3(g_stage), dim3(kBlock), lds_stage, st, agg, sub_agg, work, bounds,    \
+                           sub_bounds, cent, k, masks, cw, (T *)colour_labels, sub_table, sums, n_rows, flags, stats);      \
+        if (!(flags & 0xC00u))                                                                                              \
+            hipLaunchKernelGGL((k_cube_scan<T, S>), dim3(g_scan), dim3(kBlock), lds_scan, st, hist, sub_agg, work, cent, k, \
+                               lab_table, masks, cw, (T *)colour_labels, sub_table, sums, n_rows, repl, flags);             \
+        hipLaunchKernelGGL((k_cube_pairs<T>), dim3(g_pairs), dim3(kBlock), 0, st, work, S ? 1 : 0, occ_bits,               \
+                           (const T *)colour_labels, sub_table, flags);                                                     \
+    } while (0)
+    if (k <= 256) { if (with_sums) KMG_CUBE(uint8_t, true); else KMG_CUBE(uint8_t, false); }
+    else          { if (with_sums) KMG_CUBE(uint16_t, true); else KMG_CUBE(uint16_t, false); }
+#undef KMG_CUBE
+    return hipGetLastError();
+}
+
+}  // namespace kmg

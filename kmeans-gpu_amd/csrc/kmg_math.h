@@ -116,6 +116,46 @@ KMG_HD float cie94_key(const PixelTerms &p, float L2, float a2, float b2, float 
     return fmaf(h, p.wH, fmaf(dC2, p.wC, dL * dL));
 }
 
+// delta_e.wgsl:1-22 with the two chroma values supplied (C1 = chroma(a1, b1), C2 = chroma(a2, b2)): the
+// same operations as cie94() above, hence the same float.
+KMG_HD float cie94_c(float L1, float a1, float b1, float C1, float L2, float a2, float b2, float C2)
+{
+    float dL = L1 - L2, da = a1 - a2, db = b1 - b2;
+    float dC = C1 - C2;
+    float dH = sqrtf(fmaxf((da * da) + (db * db) - (dC * dC), 0.0f));
+    float SC = 1.0f + 0.045f * C1;
+    float SH = 1.0f + 0.015f * C1;
+    float tL = dL / 1.0f, tC = dC / SC, tH = dH / SH;
+    return sqrtf(tL * tL + tC * tC + tH * tH);
+}
+
+// ---- near-tie repair: the arg-min is that of the LITERAL distance -------------------------------------
+// find_centroid.wgsl:32-41 takes the first index that minimises the literal distance_cie94 under strict
+// '<'.  The kernels order by cie94_key (no sqrt, no divide per pair); key and literal^2 are two float
+// evaluations of the same real quantity T = dL^2 + dC^2/SC^2 + max(da^2 + db^2 - dC^2, 0)/SH^2 from the same
+// float inputs (dL, da, db, dC, SC, SH).  With u = 2^-24 per rounding:
+//   * every product / quotient / sum of non-negative terms carries at most 9 roundings in the literal form
+//     and 6 in the key, i.e. relative errors <= 9u and <= 6u on each term;
+//   * the hue term subtracts: h = (da^2 + db^2) - dC^2 is computed with absolute error <= 3u (G + Q)
+//     (G = da^2 + db^2, Q = dC^2) in either form, and G <= Q + h(1 + small), so the error it adds to T is
+//     <= 3u (h + 2Q) / SH^2 <= 3u (h/SH^2 + 18 Q/SC^2) <= 57u T     ((SC/SH)^2 < 9 for every chroma);
+//   hence |key - T| <= 63u T and |literal^2 - T| <= 66u T, and a centroid j can have
+//   literal_j <= literal_best only if key_j <= key_best (1 + 66u)(1 + 63u) / ((1 - 66u)(1 - 63u))
+//   < key_best (1 + 260u) = key_best (1 + 1.6e-5).
+// The kernels use kTieSlack = 2^-13 = 1.2e-4 (8x that): while scanning they keep the second smallest key; a
+// pixel whose second smallest key is <= best (1 + kTieSlack) is re-decided with the literal distance among
+// the centroids whose key is within that threshold, in index order with strict '<' -- exactly the
+// reference's result, because everything outside the threshold is strictly farther in the literal
+// distance.  Candidate sets built from interval bounds keep lo_j <= U (1 + kMaskSlack), kMaskSlack = 2^-12.
+#define KMG_TIE_SLACK 0.0001220703125f     // 2^-13
+constexpr float kTieSlack = KMG_TIE_SLACK;
+constexpr float kMaskSlack = 0.000244140625f;   // 2^-12
+
+// false: the arg-min is that of the key alone (round-1 definition, kept as a switch for A/B timing)
+constexpr bool kLiteralArgmin = false;
+
+KMG_HD float tie_threshold(float best) { return fmaf(best, kTieSlack, best); }
+
 // Lab -> fixed point for the exact integer accumulators.
 KMG_HD int32_t lab_fix(float x) { return (int32_t)rintf(x * KMG_FIX_SCALE); }
 

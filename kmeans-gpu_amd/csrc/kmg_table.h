@@ -5,14 +5,15 @@
 // image's colour histogram instead of its pixels and still give bit-identical labels, sums and
 // centroids:
 //   bind (once per image)  : hist[2^24] (u32 counts, cell-major colour order) + per-cell sums
-//   per iteration          : 1. k_cell_candidates -- for each 8x8x8 colour cell, a conservative
-//                                superset of the centroids that can be the arg-min of any colour
-//                                in the cell (float-monotone interval bounds, no epsilons)
-//                             2. k_cube -- per cell: one candidate -> the whole cell goes to it
-//                                (precomputed cell sums); otherwise every colour is scanned
-//                                against the candidates only.  Writes label-per-colour (LUT)
-//                                and the per-workgroup partial sums.
-//                             3. k_labels -- labels[i] = LUT[colour(pixel i)]  (4 B in, 4 B out); for
+//   per iteration          : 1. k_cube (kmg_cube.hip) -- one wave per 8x8x8 colour cell: a conservative
+//                                superset of the centroids that can be the arg-min of any colour in
+//                                the cell (float-monotone interval bounds, no epsilons); one candidate
+//                                -> the whole cell goes to it (precomputed cell sums).  Otherwise the
+//                                same test per 4x4x4 sub-cell with its own bounds (precomputed sub-cell
+//                                sums), and only the colours of still undecided sub-cells are scanned,
+//                                against their sub-cell's candidates.  Writes label-per-colour (LUT),
+//                                the LDS tables of the label pass and the k x 4 sums.
+//                             2. k_labels -- labels[i] = LUT[colour(pixel i)]  (4 B in, 4 B out); for
 //                                k <= 256 most pixels are resolved from a per-cell plane + slab entry
 //                                held in LDS (pair entries below), the rest gathers from the LUT
 // The same machinery (static cell bounds, monotone interval evaluation) also serves, on large images,
@@ -30,7 +31,7 @@ namespace kmg {
 constexpr uint32_t kCells = 32768;        // 32^3 cells of 8x8x8 colours
 constexpr uint32_t kCellColours = 512;
 constexpr uint32_t kSubCells = kCells * 8;  // 4x4x4 sub-cells (64 colours)
-constexpr uint32_t kCubeGrid = 2048;      // persistent workgroups of k_cube
+constexpr uint32_t kCubeGrid = 2048;      // workgroups of k_cube (4 waves each, a wave walks cells wave, wave + n_waves, ...)
 constexpr uint32_t kMergeRows = 64;       // rows of the partial slab the cube workgroups add their sums into
 
 // sub-cell table entry (u16): a label, or one of
@@ -111,9 +112,10 @@ __host__ __device__ inline uint32_t pair_decode(uint32_t e, int p)
     return kPairFine;
 }
 
-// once per processor: bounds[kCells] and lab_table[2^24] = (L, a, b, C) of every colour (256 MiB,
+// once per processor: bounds[kCells], sub_bounds[kSubCells] (same quantities over a 4x4x4 sub-cell, index
+// cell * 8 + [r2 g2 b2] = colour index >> 6) and lab_table[2^24] = (L, a, b, C) of every colour (256 MiB,
 // image independent) so that the per-iteration cube pass loads Lab instead of recomputing it
-hipError_t launch_cell_bounds(const float *lut, CellBounds *bounds, float4 *lab_table, hipStream_t st);
+hipError_t launch_cell_bounds(const float *lut, CellBounds *bounds, CellBounds *sub_bounds, float4 *lab_table, hipStream_t st);
 // once per image: hist[2^24] must be zero on entry
 hipError_t launch_histogram(const uint32_t *rgba, uint64_t n, uint32_t *hist, hipStream_t st);
 // the same histogram for large images without a global atomic per pixel (partition by the top 10 colour
@@ -121,8 +123,11 @@ hipError_t launch_histogram(const uint32_t *rgba, uint64_t n, uint32_t *hist, hi
 // small: 4 * 1024 + 1 u32 of scratch, elems: n u16, keys: n u32 or NULL.  hist / tie are cleared here.
 hipError_t launch_partitioned_histogram(const uint32_t *rgba, uint64_t n, uint64_t first_index, uint32_t *small,
                                         uint16_t *elems, uint32_t *keys, uint32_t *hist, uint32_t *tie, hipStream_t st);
-// once per image: agg[kCells][4] = (sum qL, sum qa, sum qb, count) of the image's pixels per cell
-hipError_t launch_cell_aggregates(const uint32_t *hist, const float4 *lab_table, int64_t *agg, hipStream_t st);
+// once per image: agg[kCells][4] = (sum qL, sum qa, sum qb, count) of the image's pixels per cell,
+// sub_agg[kSubCells][4] the same per 4x4x4 sub-cell, occ_bits[2^24 / 8]: bit (colour & 7) of byte (colour >> 3) = the
+// image has pixels of this colour
+hipError_t launch_cell_aggregates(const uint32_t *hist, const float4 *lab_table, int64_t *agg, int64_t *sub_agg, uint8_t *occ_bits,
+                                  hipStream_t st);
 // once per image: work[0] = number of occupied cells, work[1..] = their indices in ascending order
 hipError_t launch_work_list(const int64_t *agg, uint32_t *work, hipStream_t st);
 // farthest-point initialisation over the colours of a large image: tie[2^24] (zero on entry) = 1 + the
@@ -136,18 +141,23 @@ hipError_t launch_init_pass_cells(const uint32_t *work, const uint32_t *tie, con
                                   const CellBounds *bounds, Centroid *cent, uint32_t j, float *dist,
                                   unsigned long long *cell_key, unsigned long long *key,
                                   const uint32_t *pick_rgba, const float *lut, hipStream_t st);
-// per iteration
-// merge_rows (optional): the n_merge_rows x k x 4 int64 accumulators of the cube pass that follows, cleared here
-hipError_t launch_cell_candidates(const CellBounds *bounds, const int64_t *agg, const Centroid *cent,
-                                  uint32_t k, uint64_t *masks, int64_t *merge_rows, uint32_t n_merge_rows, hipStream_t st);
-// work: [0] = number of occupied cells of the bound image, [1..] = their indices (built at bind time):
-// the cube pass walks a dense list and issues all loads of a cell at once.  Every workgroup adds the sums of
-// the clusters it met into row (workgroup % n_merge_rows) of `partials` (n_merge_rows = 1: the final sums)
-hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const uint64_t *masks, const uint32_t *work,
-                       const Centroid *cent, uint32_t k, const float4 *lab_table, void *colour_labels,
-                       uint16_t *sub_table, int64_t *partials, uint32_t n_merge_rows, hipStream_t st);
+// per iteration (kmg_cube.hip): candidates + sub-cell stage, colour scan, pair entries -- three launches.
+// work: [0] = number of occupied cells of the bound image, [1..] = their indices (built at bind time).
+// masks: the cell candidate masks, mask_words(k) u64 per cell; cell_work: cube_work_bytes() of scratch (the
+// stage kernel's records for the scan kernel).
+// Every workgroup adds the sums of the clusters it met into row (workgroup % n_rows) of `sums` (k x 4 int64
+// per row, zero on entry; n_rows = 1: the final sums).  hist == NULL: output pass of replace mode -- every
+// colour of every cell is labelled, nothing is accumulated (agg, sub_agg, occ_bits, work, sums unused).
+// flags bit 0: also write the per-colour labels of single-candidate cells (the label passes never read them).
+// stats (optional, 6 x u64, zero on entry): single-candidate cells, other cells, sub-cells decided by their
+// bounds, sub-cells scanned, candidates summed over the scanned sub-cells, cells beyond the listing limit.
+size_t cube_work_bytes();
+hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *sub_agg, const uint8_t *occ_bits,
+                       const uint32_t *work, const CellBounds *bounds, const CellBounds *sub_bounds, const Centroid *cent,
+                       uint32_t k, const float4 *lab_table, uint64_t *masks, void *cell_work, void *colour_labels,
+                       uint16_t *sub_table, int64_t *sums, uint32_t n_rows, uint32_t flags, unsigned long long *stats,
+                       hipStream_t st);
 // pal == NULL: labels[i] = label; pal != NULL: labels[i] = pal[label] (RGBA8 output of replace mode).
-// launch_cube with hist == NULL labels every colour of every cell and accumulates nothing.
 hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_labels,
                          const uint16_t *sub_table, uint32_t k, const uint32_t *pal, uint32_t *labels,
                          hipStream_t st);
@@ -172,10 +182,10 @@ hipError_t launch_meld_candidates(const CellBounds *bounds, const Centroid *cent
 hipError_t launch_check_meld_masks(const Centroid *cent, uint32_t k, const uint64_t *masks, const float *lut,
                                    unsigned long long *violations, hipStream_t st);
 
-// debug / test support: number of (cell, centroid, colour) triples whose key falls outside the
-// interval bounds, and number of colours whose brute-force arg-min is missing from the cell mask
-hipError_t launch_check_bounds(const CellBounds *bounds, const Centroid *cent, uint32_t k,
-                               const uint64_t *masks, const float *lut, unsigned long long *violations,
-                               hipStream_t st);
+// debug / test support (see k_check_bounds): bound violations, arg-mins missing from the cell masks, per-colour
+// labels that are not the arg-min, over all 2^24 colours
+hipError_t launch_check_bounds(const CellBounds *bounds, const CellBounds *sub_bounds, const Centroid *cent, uint32_t k,
+                               const uint64_t *masks, const void *colour_labels, const float *lut,
+                               unsigned long long *violations, hipStream_t st);
 
 }  // namespace kmg

@@ -10,104 +10,55 @@
 //  * sums are exact integers: sum over colours of count * q equals the per-pixel sum of q.
 // Compile with -ffp-contract=off.
 
-#include "kmg_table.h"
-#include "kmg_device.h"
+#include "kmg_table_dev.h"
 
 namespace kmg {
 
-namespace {
-
-struct KeyRange { float lo, hi; };
-
-__device__ __forceinline__ void abs_range(float x0, float x1, float c, float &m, float &M)
-{
-    const float d0 = x0 - c, d1 = x1 - c;                  // d0 <= d1 (rounding is monotone)
-    M = fmaxf(fabsf(d0), fabsf(d1));
-    m = fmaxf(fmaxf(d0, -d1), 0.0f);                       // d0 if the interval is above c, -d1 if below, 0 if it straddles c (one v_max3)
-}
-
-// [min, max] of cie94_key(pixel, c) over all pixels whose terms lie inside the cell bounds
-__device__ __forceinline__ KeyRange key_range(const CellBounds &cb, float L2, float a2, float b2, float C2)
-{
-    float mL, ML, ma, Ma, mb, Mb, mC, MC;
-    abs_range(cb.L0, cb.L1, L2, mL, ML);
-    abs_range(cb.a0, cb.a1, a2, ma, Ma);
-    abs_range(cb.b0, cb.b1, b2, mb, Mb);
-    abs_range(cb.C0, cb.C1, C2, mC, MC);
-    const float A0 = mL * mL, A1 = ML * ML;                // dL*dL
-    const float D0 = mC * mC, D1 = MC * MC;                // dC2
-    const float t0 = fmaf(mb, mb, ma * ma), t1 = fmaf(Mb, Mb, Ma * Ma);
-    const float h0 = fmaxf(t0 - D1, 0.0f), h1 = fmaxf(t1 - D0, 0.0f);
-    KeyRange r;
-    r.lo = fmaf(h0, cb.wH0, fmaf(D0, cb.wC0, A0));
-    r.hi = fmaf(h1, cb.wH1, fmaf(D1, cb.wC1, A1));
-    return r;
-}
-
-__device__ __forceinline__ void colour_to_lab(const float *s_lut, uint32_t idx, float &L, float &a, float &b)
-{
-    uint32_t r, g, bl;
-    index_to_rgb(idx, r, g, bl);
-    linear100_to_lab(s_lut[r], s_lut[g], s_lut[bl], L, a, b);
-}
-
-__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v)
-{
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
-    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-    return ((unsigned long long)hi << 32) | lo;
-}
-
-__device__ __forceinline__ float lane_value(float v, uint32_t src)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int)src));
-}
-
-__device__ __forceinline__ long long wave_sum(long long v)
-{
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-
-}  // namespace
-
 // ------------------------------------------------------------------------------------------
-// static cell bounds (once per processor): one workgroup per cell, two colours per thread
+// static bounds (once per processor): one workgroup per cell, two colours per thread.  Wave w meets the
+// colours of sub-cell w in its first pass and of sub-cell 4 + w in its second, so its two wave reductions
+// are those sub-cells' bounds; the cell's bounds are their union.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_cell_bounds(const float *__restrict__ lut,
                                                         CellBounds *__restrict__ bounds,
+                                                        CellBounds *__restrict__ sub_bounds,
                                                         float4 *__restrict__ lab_table)
 {
     __shared__ float s_lut[256];
-    __shared__ float s_min[6][kBlock / 64], s_max[6][kBlock / 64];
+    __shared__ float s_min[6][8], s_max[6][8];
     s_lut[threadIdx.x] = lut[threadIdx.x];
     __syncthreads();
-    float mn[6], mx[6];
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
-    for (int q = 0; q < 6; ++q) { mn[q] = 3.0e38f; mx[q] = -3.0e38f; }
-    for (uint32_t c = threadIdx.x; c < kCellColours; c += kBlock) {
+    for (uint32_t pass = 0; pass < 2u; ++pass) {
+        const uint32_t c = pass * kBlock + threadIdx.x;
         float L, a, b;
         colour_to_lab(s_lut, blockIdx.x * kCellColours + c, L, a, b);
         const PixelTerms p = pixel_terms(L, a, b);
         lab_table[blockIdx.x * kCellColours + c] = make_float4(p.L, p.a, p.b, p.C);
-        const float v[6] = {p.L, p.a, p.b, p.C, p.wC, p.wH};
+        float mn[6] = {p.L, p.a, p.b, p.C, p.wC, p.wH}, mx[6] = {p.L, p.a, p.b, p.C, p.wC, p.wH};
 #pragma unroll
-        for (int q = 0; q < 6; ++q) { mn[q] = fminf(mn[q], v[q]); mx[q] = fmaxf(mx[q], v[q]); }
-    }
-#pragma unroll
-    for (int q = 0; q < 6; ++q)
-        for (int off = 32; off > 0; off >>= 1) {
-            mn[q] = fminf(mn[q], __shfl_down(mn[q], off, 64));
-            mx[q] = fmaxf(mx[q], __shfl_down(mx[q], off, 64));
+        for (int q = 0; q < 6; ++q)
+            for (int off = 32; off > 0; off >>= 1) {
+                mn[q] = fminf(mn[q], __shfl_xor(mn[q], off, 64));
+                mx[q] = fmaxf(mx[q], __shfl_xor(mx[q], off, 64));
+            }
+        const uint32_t sc = pass * 4u + wv;                          // colour >> 6
+        if (lane == 0) {
+            CellBounds sb;
+            sb.L0 = mn[0]; sb.L1 = mx[0]; sb.a0 = mn[1]; sb.a1 = mx[1]; sb.b0 = mn[2]; sb.b1 = mx[2];
+            sb.C0 = mn[3]; sb.C1 = mx[3]; sb.wC0 = mn[4]; sb.wC1 = mx[4]; sb.wH0 = mn[5]; sb.wH1 = mx[5];
+            sb.pad[0] = sb.pad[1] = sb.pad[2] = sb.pad[3] = 0.0f;
+            sub_bounds[(uint64_t)blockIdx.x * 8u + sc] = sb;
+            for (int q = 0; q < 6; ++q) { s_min[q][sc] = mn[q]; s_max[q][sc] = mx[q]; }
         }
-    if ((threadIdx.x & 63) == 0)
-        for (int q = 0; q < 6; ++q) { s_min[q][threadIdx.x >> 6] = mn[q]; s_max[q][threadIdx.x >> 6] = mx[q]; }
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         float lo[6], hi[6];
         for (int q = 0; q < 6; ++q) {
             lo[q] = s_min[q][0]; hi[q] = s_max[q][0];
-            for (int w = 1; w < kBlock / 64; ++w) { lo[q] = fminf(lo[q], s_min[q][w]); hi[q] = fmaxf(hi[q], s_max[q][w]); }
+            for (int w = 1; w < 8; ++w) { lo[q] = fminf(lo[q], s_min[q][w]); hi[q] = fmaxf(hi[q], s_max[q][w]); }
         }
         CellBounds cb;
         cb.L0 = lo[0]; cb.L1 = hi[0]; cb.a0 = lo[1]; cb.a1 = hi[1]; cb.b0 = lo[2]; cb.b1 = hi[2];
@@ -117,9 +68,9 @@ __global__ __launch_bounds__(kBlock) void k_cell_bounds(const float *__restrict_
     }
 }
 
-hipError_t launch_cell_bounds(const float *lut, CellBounds *bounds, float4 *lab_table, hipStream_t st)
+hipError_t launch_cell_bounds(const float *lut, CellBounds *bounds, CellBounds *sub_bounds, float4 *lab_table, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_cell_bounds, dim3(kCells), dim3(kBlock), 0, st, lut, bounds, lab_table);
+    hipLaunchKernelGGL(k_cell_bounds, dim3(kCells), dim3(kBlock), 0, st, lut, bounds, sub_bounds, lab_table);
     return hipGetLastError();
 }
 
@@ -549,11 +500,13 @@ hipError_t launch_init_pass_cells(const uint32_t *work, const uint32_t *tie, con
 }
 
 // ------------------------------------------------------------------------------------------
-// per-cell sums of the image (once per image): one wave per cell, 8 colours per lane
+// per-cell and per-sub-cell sums of the image (once per image): one wave per cell, 8 colours per lane
+// (lane l holds colours 8 l .. 8 l + 7, i.e. an eighth of sub-cell l >> 3)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_cell_aggregates(const uint32_t *__restrict__ hist,
                                                             const float4 *__restrict__ lab_table,
-                                                            int64_t *__restrict__ agg)
+                                                            int64_t *__restrict__ agg, int64_t *__restrict__ sub_agg,
+                                                            uint8_t *__restrict__ occ_bits)
 {
     const uint32_t cell = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
@@ -565,6 +518,7 @@ __global__ __launch_bounds__(kBlock) void k_cell_aggregates(const uint32_t *__re
     for (int q = 0; q < 8; ++q) lab8[q] = lab_table[base + q];
     const uint32_t cnt[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
     long long s[4] = {0, 0, 0, 0};
+    uint32_t occ = 0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         if (cnt[q]) {
@@ -574,17 +528,26 @@ __global__ __launch_bounds__(kBlock) void k_cell_aggregates(const uint32_t *__re
             s[1] += m * (long long)lab_fix(v.y);
             s[2] += m * (long long)lab_fix(v.z);
             s[3] += m;
+            occ |= 1u << q;
         }
     }
+    occ_bits[(uint64_t)cell * 64u + lane] = (uint8_t)occ;          // bit q of byte (colour >> 3) = colour occupied
 #pragma unroll
-    for (int j = 0; j < 4; ++j) s[j] = wave_sum(s[j]);
+    for (int j = 0; j < 4; ++j)
+        for (int off = 1; off < 8; off <<= 1) s[j] += __shfl_xor(s[j], off, 64);     // the sub-cell's 8 lanes
+    if ((lane & 7u) == 0)
+        for (int j = 0; j < 4; ++j) sub_agg[4ull * (cell * 8u + (lane >> 3)) + j] = s[j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        for (int off = 8; off < 64; off <<= 1) s[j] += __shfl_xor(s[j], off, 64);
     if (lane == 0)
         for (int j = 0; j < 4; ++j) agg[4ull * cell + j] = s[j];
 }
 
-hipError_t launch_cell_aggregates(const uint32_t *hist, const float4 *lab_table, int64_t *agg, hipStream_t st)
+hipError_t launch_cell_aggregates(const uint32_t *hist, const float4 *lab_table, int64_t *agg, int64_t *sub_agg, uint8_t *occ_bits,
+                                  hipStream_t st)
 {
-    hipLaunchKernelGGL(k_cell_aggregates, dim3(kCells / (kBlock / 64)), dim3(kBlock), 0, st, hist, lab_table, agg);
+    hipLaunchKernelGGL(k_cell_aggregates, dim3(kCells / (kBlock / 64)), dim3(kBlock), 0, st, hist, lab_table, agg, sub_agg, occ_bits);
     return hipGetLastError();
 }
 
@@ -618,431 +581,6 @@ __global__ __launch_bounds__(1024) void k_work_list(const int64_t *__restrict__ 
 hipError_t launch_work_list(const int64_t *agg, uint32_t *work, hipStream_t st)
 {
     hipLaunchKernelGGL(k_work_list, dim3(1), dim3(1024), 0, st, agg, work);
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------
-// candidate masks (per iteration): one wave per cell, lanes strided over the centroids
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_cell_candidates(const CellBounds *__restrict__ bounds,
-                                                            const int64_t *__restrict__ agg,
-                                                            const Centroid *__restrict__ cent, uint32_t k,
-                                                            uint64_t *__restrict__ masks,
-                                                            unsigned long long *__restrict__ merge_rows, uint32_t n_merge_rows)
-{
-    // the cube pass that follows adds its per-workgroup sums into n_merge_rows x k x 4 accumulators: clear them
-    if (merge_rows) {
-        const uint32_t total = n_merge_rows * 4u * k;
-        for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) merge_rows[i] = 0ull;
-    }
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t words = (k + 63u) / 64u;
-    const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    const uint32_t n_waves = gridDim.x * (kBlock / 64);
-    if (words <= 4u) {
-        // k <= 256: a lane keeps its (up to) four centroids in registers for all the cells of the wave; one
-        // evaluation per (cell, centroid), the lower bounds wait in registers for U.  Lane i < 16 fetches float i
-        // of the NEXT cell's bounds while the current cell is evaluated.
-        Centroid c[4];
-#pragma unroll
-        for (uint32_t w = 0; w < 4u; ++w) {
-            const uint32_t j = w * 64 + lane;
-            c[w] = cent[j < k ? j : 0u];
-        }
-        const float *bf = reinterpret_cast<const float *>(bounds);
-        float nb = wave < kCells ? bf[(uint64_t)wave * 16u + (lane & 15u)] : 0.0f;
-        long long ncount = (agg && wave < kCells) ? agg[4ull * wave + 3] : 1;
-        for (uint32_t cell = wave; cell < kCells; cell += n_waves) {
-            const float mine = nb;
-            const long long count = ncount;
-            const uint32_t next = cell + n_waves;
-            if (next < kCells) {
-                nb = bf[(uint64_t)next * 16u + (lane & 15u)];
-                if (agg) ncount = agg[4ull * next + 3];
-            }
-            uint64_t *out = masks + (uint64_t)cell * words;
-            if (count == 0) {                                   // no pixel in this cell
-                if (lane < words) out[lane] = 0ull;
-                continue;
-            }
-            CellBounds cb;
-            cb.L0 = lane_value(mine, 0); cb.L1 = lane_value(mine, 1); cb.a0 = lane_value(mine, 2); cb.a1 = lane_value(mine, 3);
-            cb.b0 = lane_value(mine, 4); cb.b1 = lane_value(mine, 5); cb.C0 = lane_value(mine, 6); cb.C1 = lane_value(mine, 7);
-            cb.wC0 = lane_value(mine, 8); cb.wC1 = lane_value(mine, 9); cb.wH0 = lane_value(mine, 10); cb.wH1 = lane_value(mine, 11);
-            float U = 3.0e38f, lo[4];
-#pragma unroll
-            for (uint32_t w = 0; w < 4u; ++w) {
-                lo[w] = 0.0f;
-                if (w < words) {
-                    const KeyRange r = key_range(cb, c[w].L, c[w].a, c[w].b, c[w].C);
-                    lo[w] = r.lo;
-                    if (w * 64 + lane < k) U = fminf(U, r.hi);
-                }
-            }
-            for (int off = 32; off > 0; off >>= 1) U = fminf(U, __shfl_xor(U, off, 64));
-#pragma unroll
-            for (uint32_t w = 0; w < 4u; ++w) {
-                const unsigned long long m = __ballot(w * 64 + lane < k && lo[w] <= U);
-                if (w < words && lane == 0) out[w] = m;
-            }
-        }
-        return;
-    }
-    for (uint32_t cell = wave; cell < kCells; cell += n_waves) {
-        uint64_t *out = masks + (uint64_t)cell * words;
-        if (agg && agg[4ull * cell + 3] == 0) {
-            for (uint32_t w = lane; w < words; w += 64) out[w] = 0ull;
-            continue;
-        }
-        const CellBounds cb = bounds[cell];
-        float U = 3.0e38f;
-        for (uint32_t j = lane; j < k; j += 64) {
-            const Centroid ce = cent[j];
-            U = fminf(U, key_range(cb, ce.L, ce.a, ce.b, ce.C).hi);
-        }
-        for (int off = 32; off > 0; off >>= 1) U = fminf(U, __shfl_xor(U, off, 64));
-        for (uint32_t w = 0; w < words; ++w) {
-            const uint32_t j = w * 64 + lane;
-            bool keep = false;
-            if (j < k) {
-                const Centroid ce = cent[j];
-                keep = key_range(cb, ce.L, ce.a, ce.b, ce.C).lo <= U;
-            }
-            const unsigned long long m = __ballot(keep);
-            if (lane == 0) out[w] = m;
-        }
-    }
-}
-
-hipError_t launch_cell_candidates(const CellBounds *bounds, const int64_t *agg, const Centroid *cent,
-                                  uint32_t k, uint64_t *masks, int64_t *merge_rows, uint32_t n_merge_rows, hipStream_t st)
-{
-    // k <= 256: persistent waves (4 cells each) with the next cell's bounds prefetched; larger k: one cell per wave
-    const uint32_t grid = k <= 256 ? 2048u : kCells / (kBlock / 64);
-    hipLaunchKernelGGL(k_cell_candidates, dim3(grid), dim3(kBlock), 0, st, bounds, agg,
-                       cent, k, masks, reinterpret_cast<unsigned long long *>(merge_rows), n_merge_rows);
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------
-// pair entry of one cell (kmg_table.h), computed by the wave that has just labelled its colours:
-// lane l holds the colours [8l, 8l+8) of the cell, idx[q] their labels, bit q of occ = colour occupied
-// ------------------------------------------------------------------------------------------
-struct Ballot4 { unsigned long long b[4]; };
-
-__device__ __forceinline__ Ballot4 ballot4(uint32_t v)          // v < 16 per lane
-{
-    Ballot4 r;
-    r.b[0] = __ballot((v & 1u) != 0u); r.b[1] = __ballot((v & 2u) != 0u);
-    r.b[2] = __ballot((v & 4u) != 0u); r.b[3] = __ballot((v & 8u) != 0u);
-    return r;
-}
-
-__device__ __forceinline__ uint32_t count4(const Ballot4 &x, unsigned long long lanes)   // sum of v over `lanes`
-{
-    return (uint32_t)__builtin_popcountll(x.b[0] & lanes) + 2u * (uint32_t)__builtin_popcountll(x.b[1] & lanes) +
-           4u * (uint32_t)__builtin_popcountll(x.b[2] & lanes) + 8u * (uint32_t)__builtin_popcountll(x.b[3] & lanes);
-}
-
-__device__ __forceinline__ uint32_t sel3(uint32_t i, uint32_t x0, uint32_t x1, uint32_t x2)
-{
-    return i == 0u ? x0 : (i == 1u ? x1 : x2);
-}
-
-__device__ __forceinline__ int round_dir(int g, int m)           // rint(2 g / m), |g| <= m, m > 0
-{
-    const int a = g < 0 ? -g : g;
-    const int r = (4 * a >= 3 * m ? 1 : 0) + (4 * a >= m ? 1 : 0);
-    return g < 0 ? -r : r;
-}
-
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ uint32_t cell_pair_entry(const uint32_t idx[8], uint32_t occ, uint32_t lane)
-{
-    // the (up to) three first distinct labels among the occupied colours, their colours and counts
-    uint32_t rem = occ;
-    uint32_t lab0 = 0, lab1 = 0, lab2 = 0, cnt0 = 0, cnt1 = 0, cnt2 = 0, msk0 = 0, msk1 = 0, msk2 = 0;
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        const unsigned long long any = __ballot(rem != 0u);
-        if (any) {
-            uint32_t mine = 0;
-#pragma unroll
-            for (int q = 7; q >= 0; --q) mine = ((rem >> q) & 1u) ? idx[q] : mine;
-            const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)__builtin_ctzll(any));
-            uint32_t mm = 0;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) mm |= (idx[q] == v ? 1u : 0u) << q;
-            mm &= rem;
-            rem &= ~mm;
-            const uint32_t c = count4(ballot4((uint32_t)__builtin_popcount(mm)), ~0ull);
-            if (t == 0) { lab0 = v; msk0 = mm; cnt0 = c; }
-            if (t == 1) { lab1 = v; msk1 = mm; cnt1 = c; }
-            if (t == 2) { lab2 = v; msk2 = mm; cnt2 = c; }
-        }
-    }
-    // A = the most frequent of them, B = the runner-up
-    uint32_t a = 0;
-    if (cnt1 > cnt0) a = 1;
-    if (cnt2 > sel3(a, cnt0, cnt1, cnt2)) a = 2;
-    uint32_t b = a == 0u ? 1u : 0u;
-    if (a != 1u && b != 1u && cnt1 > sel3(b, cnt0, cnt1, cnt2)) b = 1;
-    if (a != 2u && cnt2 > sel3(b, cnt0, cnt1, cnt2)) b = 2;
-    const uint32_t labA = sel3(a, lab0, lab1, lab2), labB = sel3(b, lab0, lab1, lab2);
-    const uint32_t mA = sel3(a, msk0, msk1, msk2), mB = sel3(b, msk0, msk1, msk2);
-    const uint32_t rest = occ & ~mA;                              // occupied colours with another label
-    const Ballot4 bA = ballot4((uint32_t)__builtin_popcount(mA));
-    const Ballot4 bR = ballot4((uint32_t)__builtin_popcount(rest));
-    const uint32_t nA = count4(bA, ~0ull), nR = count4(bR, ~0ull);
-    if (nR == 0u) return pair_entry(labA, labA, 0u, 0u, 0u);
-
-    // direction: from the centre of mass of A towards the one of the rest, at half-cell resolution
-    // (lane bits 5, 4, 3 = r2, g2, b2), rounded to components in -2..2.  Any direction is valid
-    // (tlo and w below are exact for it); a good one only makes the slab thin.
-    constexpr unsigned long long HX = 0xFFFFFFFF00000000ull, HY = 0xFFFF0000FFFF0000ull, HZ = 0xFF00FF00FF00FF00ull;
-    const int gx = (int)(count4(bR, HX) * nA) - (int)(count4(bA, HX) * nR);
-    const int gy = (int)(count4(bR, HY) * nA) - (int)(count4(bA, HY) * nR);
-    const int gz = (int)(count4(bR, HZ) * nA) - (int)(count4(bA, HZ) * nR);
-    const int ax = gx < 0 ? -gx : gx, ay = gy < 0 ? -gy : gy, az = gz < 0 ? -gz : gz;
-    const int m = ax > ay ? (ax > az ? ax : az) : (ay > az ? ay : az);
-    int nx = 2, ny = 0, nz = 0;
-    if (m > 0) { nx = round_dir(gx, m); ny = round_dir(gy, m); nz = round_dir(gz, m); }
-
-    // p of this lane's colours: x = r & 7 and the high bits of y, z are lane constants
-    const int xl = (int)(((lane >> 5) & 1u) * 4u + ((lane >> 1) & 3u));
-    const int yl = (int)(((lane >> 4) & 1u) * 4u + (lane & 1u) * 2u);
-    const int zl = (int)(((lane >> 3) & 1u) * 4u);
-    const int bias = 7 * ((nx < 0 ? -nx : 0) + (ny < 0 ? -ny : 0) + (nz < 0 ? -nz : 0));
-    const int p0 = nx * xl + ny * yl + nz * zl + bias;
-    int p[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) p[q] = p0 + ny * (q >> 2) + nz * (q & 3);
-    // tlo = lowest p of a colour that is not A, thi = highest p of a colour that is not B
-    const uint32_t notB = occ & ~mB;
-    uint32_t tl = 63u, hi = 64u;                                  // hi = 63 - thi
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        if ((rest >> q) & 1u) tl = min(tl, (uint32_t)p[q]);
-        if ((notB >> q) & 1u) hi = min(hi, (uint32_t)(63 - p[q]));
-    }
-    uint32_t packed = tl | (hi << 16);
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = __shfl_xor(packed, off, 64);
-        const u16x2 r = __builtin_elementwise_min(__builtin_bit_cast(u16x2, packed), __builtin_bit_cast(u16x2, o));
-        packed = __builtin_bit_cast(uint32_t, r);
-    }
-    const int tlo = (int)(packed & 0xFFFFu), thi = 63 - (int)(packed >> 16);
-    const int w = thi + 1 > tlo ? thi + 1 - tlo : 0;
-    const uint32_t code = pair_dir_code(nx, ny, nz);
-    if (w <= 6) return pair_entry(labA, labB, code, (uint32_t)tlo, (uint32_t)w);
-    // the slab is too wide to encode (a third label, or a strongly curved boundary): keep the
-    // side that resolves more colours, the other one goes through the per-colour table
-    uint32_t low = 0, high = 0;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        if ((occ >> q) & 1u) { low += p[q] < tlo ? 1u : 0u; high += p[q] > thi ? 1u : 0u; }
-    }
-    const uint32_t cl = count4(ballot4(low), ~0ull), ch = count4(ballot4(high), ~0ull);
-    if (cl >= ch) return pair_entry(labA, labB, code, (uint32_t)tlo, 7u);
-    const int range = 7 * ((nx < 0 ? -nx : nx) + (ny < 0 ? -ny : ny) + (nz < 0 ? -nz : nz));
-    return pair_entry(labB, labA, pair_dir_code(-nx, -ny, -nz), (uint32_t)(range - thi), 7u);
-}
-
-// ------------------------------------------------------------------------------------------
-// cube pass (per iteration): one wave per cell, 8 colours (= 1/8 of a 4x4x4 sub-cell) per lane
-// LDS: [centroids kpad x 16 B][bins k x 32 B].  Lab of a colour comes from the static per-colour
-// table (16 B load instead of ~200 VALU slots of sRGB->Lab).
-// ------------------------------------------------------------------------------------------
-// SUMS = false (output pass of find/reduce in replace mode): no image histogram -- every colour of
-// every cell is labelled, nothing is accumulated; hist, agg, work and partials are unused.
-template <typename LabelT, bool SUMS>
-__global__ __launch_bounds__(kBlock) void k_cube(const uint32_t *__restrict__ hist,
-                                                 const int64_t *__restrict__ agg,
-                                                 const uint64_t *__restrict__ masks,
-                                                 const uint32_t *__restrict__ work,
-                                                 const Centroid *__restrict__ cent, uint32_t k,
-                                                 const float4 *__restrict__ lab_table,
-                                                 LabelT *__restrict__ colour_labels,
-                                                 uint16_t *__restrict__ sub_table,
-                                                 int64_t *__restrict__ partials, uint32_t n_merge_rows)
-{
-    extern __shared__ float4 smem4[];
-    const uint32_t kpad = (k + 3u) & ~3u;
-    float4 *s_cent = smem4;
-    unsigned long long *bins = reinterpret_cast<unsigned long long *>(smem4 + kpad);
-
-    stage_centroids(s_cent, cent, k, kpad);
-    if (SUMS)
-        for (uint32_t i = threadIdx.x; i < 4 * k; i += kBlock) bins[i] = 0ull;
-    __syncthreads();
-
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t words = (k + 63u) / 64u;
-    const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    const uint32_t n_waves = gridDim.x * (kBlock / 64);
-
-    const uint32_t n_work = SUMS ? __builtin_amdgcn_readfirstlane(work[0]) : kCells;
-    for (uint32_t wi = wave; wi < n_work; wi += n_waves) {
-        const uint32_t cell = SUMS ? __builtin_amdgcn_readfirstlane(work[1u + wi]) : wi;
-        uint16_t *sub = sub_table + cell * 8u;
-        uint16_t *cell_entry = sub_table + kSubCells + cell;       // 8x8x8 summary, same encoding
-        uint32_t *pair_entry_ptr = reinterpret_cast<uint32_t *>(sub_table + kSubCells + kCells) + cell;   // k <= 256
-        const uint32_t base = cell * kCellColours + lane * 8;
-        // every load of this cell is issued before anything depends on one of them
-        const uint4 one4 = make_uint4(1u, 1u, 1u, 1u);
-        const uint4 c0 = SUMS ? *reinterpret_cast<const uint4 *>(hist + base) : one4;
-        const uint4 c1 = SUMS ? *reinterpret_cast<const uint4 *>(hist + base + 4) : one4;
-        float4 lab8[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) lab8[q] = lab_table[base + q];   // (L, a, b, C) of this colour
-        const uint64_t *mw = masks + (uint64_t)cell * words;
-        uint32_t npop = 0, first = 0;
-        for (uint32_t w = 0; w < words; ++w) {
-            const unsigned long long m = uniform_u64(mw[w]);
-            if (npop == 0 && m) first = w * 64 + (uint32_t)__builtin_ctzll(m);
-            npop += (uint32_t)__builtin_popcountll(m);
-        }
-
-        if (npop == 1) {
-            // the whole cell belongs to `first`: labels for its 512 colours, sums from the cell table
-            LabelT v[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = (LabelT)first;
-            if (sizeof(LabelT) == 1)
-                *reinterpret_cast<uint2 *>(colour_labels + base) = *reinterpret_cast<uint2 *>(v);
-            else
-                *reinterpret_cast<uint4 *>(colour_labels + base) = *reinterpret_cast<uint4 *>(v);
-            if (sizeof(LabelT) == 1) {
-                if (lane == 0) *pair_entry_ptr = pair_entry(first, first, 0u, 0u, 0u);
-            } else {
-                if (lane < 8) sub[lane] = (uint16_t)first;
-                if (lane == 0) *cell_entry = (uint16_t)first;
-            }
-            if (SUMS && lane < 4) atomicAdd(bins + 4ull * first + lane, (unsigned long long)agg[4ull * cell + lane]);
-            continue;
-        }
-
-        const uint32_t cnt[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-        float L[8], A[8], B[8];
-        PixelTerms pt[8];
-        float best[8];
-        uint32_t idx[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float4 v = lab8[q];
-            L[q] = v.x; A[q] = v.y; B[q] = v.z;
-            pt[q] = pixel_terms_c(v.x, v.y, v.z, v.w);
-            best[q] = 1.0e10f;                                   // find_centroid.wgsl:29-30
-            idx[q] = 0u;
-        }
-        for (uint32_t w = 0; w < words; ++w) {
-            unsigned long long m = uniform_u64(mw[w]);
-            while (m) {
-                const uint32_t j = w * 64 + (uint32_t)__builtin_ctzll(m);
-                m &= m - 1;
-                const float4 c = s_cent[j];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const float d = cie94_key(pt[q], c.x, c.y, c.z, c.w);
-                    const bool lt = d < best[q];
-                    best[q] = lt ? d : best[q];
-                    idx[q] = lt ? j : idx[q];
-                }
-            }
-        }
-        {
-            LabelT v[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = (LabelT)idx[q];
-            if (sizeof(LabelT) == 1)
-                *reinterpret_cast<uint2 *>(colour_labels + base) = *reinterpret_cast<uint2 *>(v);
-            else
-                *reinterpret_cast<uint4 *>(colour_labels + base) = *reinterpret_cast<uint4 *>(v);
-        }
-        // sums: merge runs of equal labels inside the lane before touching LDS
-        uint32_t state = kSubEmpty;                              // label / kSubEmpty / kSubMixed
-        {
-            long long s[4] = {0, 0, 0, 0};
-            uint32_t cur = 0xFFFFFFFFu;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                if (cnt[q]) {
-                    if (SUMS) {
-                        if (idx[q] != cur) {
-                            if (cur != 0xFFFFFFFFu) {
-                                unsigned long long *bin = bins + 4ull * cur;
-                                for (int j = 0; j < 4; ++j) atomicAdd(bin + j, (unsigned long long)s[j]);
-                            }
-                            cur = idx[q];
-                            s[0] = s[1] = s[2] = s[3] = 0;
-                        }
-                        const long long m = (long long)cnt[q];
-                        s[0] += m * (long long)lab_fix(L[q]);
-                        s[1] += m * (long long)lab_fix(A[q]);
-                        s[2] += m * (long long)lab_fix(B[q]);
-                        s[3] += m;
-                    }
-                    state = (state == kSubEmpty) ? idx[q] : (state == idx[q] ? state : (uint32_t)kSubMixed);
-                }
-            }
-            if (SUMS && cur != 0xFFFFFFFFu) {
-                unsigned long long *bin = bins + 4ull * cur;
-                for (int j = 0; j < 4; ++j) atomicAdd(bin + j, (unsigned long long)s[j]);
-            }
-        }
-        if (sizeof(LabelT) == 1) {
-            // k <= 256: the label pass works from the pair entries
-            uint32_t occ = 0;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) occ |= (cnt[q] ? 1u : 0u) << q;
-            const uint32_t e = cell_pair_entry(idx, occ, lane);
-            if (lane == 0) *pair_entry_ptr = e;
-        } else {
-            // k > 256: sub-cell summary over the 8 lanes that share a 4x4x4 sub-cell ...
-#pragma unroll
-            for (int off = 1; off < 8; off <<= 1) {
-                const uint32_t o = __shfl_xor(state, off, 64);
-                state = (state == kSubEmpty) ? o : ((o == kSubEmpty || o == state) ? state : (uint32_t)kSubMixed);
-            }
-            if ((lane & 7u) == 0) sub[lane >> 3] = (uint16_t)state;
-            // ... and over the whole 8x8x8 cell
-#pragma unroll
-            for (int off = 8; off < 64; off <<= 1) {
-                const uint32_t o = __shfl_xor(state, off, 64);
-                state = (state == kSubEmpty) ? o : ((o == kSubEmpty || o == state) ? state : (uint32_t)kSubMixed);
-            }
-            if (lane == 0) *cell_entry = (uint16_t)state;
-        }
-    }
-
-    if (SUMS) {
-        __syncthreads();
-        // only the clusters this workgroup met are non-zero: add them into one of n_merge_rows shared rows
-        // (cleared by k_cell_candidates) instead of writing, and later re-reading, a full row per workgroup;
-        // with one row the sums land directly in the caller's accumulators
-        unsigned long long *row = reinterpret_cast<unsigned long long *>(partials) + (uint64_t)(blockIdx.x % n_merge_rows) * 4ull * k;
-        for (uint32_t i = threadIdx.x; i < 4 * k; i += kBlock) {
-            const unsigned long long v = bins[i];
-            if (v) atomicAdd(row + i, v);
-        }
-    }
-}
-
-hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const uint64_t *masks, const uint32_t *work,
-                       const Centroid *cent, uint32_t k, const float4 *lab_table, void *colour_labels, uint16_t *sub_table,
-                       int64_t *partials, uint32_t n_merge_rows, hipStream_t st)
-{
-    const uint32_t kpad = (k + 3u) & ~3u;
-    const bool sums = hist != nullptr;
-    const size_t lds = sizeof(float4) * kpad + (sums ? sizeof(unsigned long long) * 4ull * k : 0);
-#define KMG_CUBE(T, S)                                                                                   \
-    hipLaunchKernelGGL((k_cube<T, S>), dim3(kCubeGrid), dim3(kBlock), lds, st, hist, agg, masks, work, cent, k, \
-                       lab_table, (T *)colour_labels, sub_table, partials, n_merge_rows ? n_merge_rows : 1u)
-    if (k <= 256) { if (sums) KMG_CUBE(uint8_t, true); else KMG_CUBE(uint8_t, false); }
-    else          { if (sums) KMG_CUBE(uint16_t, true); else KMG_CUBE(uint16_t, false); }
-#undef KMG_CUBE
     return hipGetLastError();
 }
 
@@ -1542,13 +1080,20 @@ hipError_t launch_check_offset_masks(const Centroid *cent, uint32_t k, const uin
 }
 
 // ------------------------------------------------------------------------------------------
-// test support: exhaustive check of the bounds and of the candidate masks over all 2^24 colours
-// violations[0] += #(colour, centroid) pairs with key outside [lo, hi]
-// violations[1] += #colours whose brute-force arg-min is not in the cell's mask
+// test support: exhaustive check of the cube pass over all 2^24 colours (run without an image, per-colour
+// labels of every cell stored)
+// violations[0] += #(colour, centroid) pairs with key outside [lo, hi] of the colour's cell or sub-cell
+// violations[1] += #colours whose arg-min is not in the cell's mask
+// violations[2] += #colours whose per-colour label is not the arg-min
+// The arg-min is the reference's: first index of the smallest LITERAL distance (kLiteralArgmin), or of the
+// smallest key.
 // ------------------------------------------------------------------------------------------
+template <typename LabelT>
 __global__ __launch_bounds__(kBlock) void k_check_bounds(const CellBounds *__restrict__ bounds,
+                                                         const CellBounds *__restrict__ sub_bounds,
                                                          const Centroid *__restrict__ cent, uint32_t k,
                                                          const uint64_t *__restrict__ masks,
+                                                         const LabelT *__restrict__ colour_labels,
                                                          const float *__restrict__ lut,
                                                          unsigned long long *__restrict__ violations)
 {
@@ -1558,31 +1103,43 @@ __global__ __launch_bounds__(kBlock) void k_check_bounds(const CellBounds *__res
     const uint32_t cell = blockIdx.x;
     const uint32_t words = (k + 63u) / 64u;
     const CellBounds cb = bounds[cell];
-    unsigned long long bad_range = 0, bad_mask = 0;
+    unsigned long long bad_range = 0, bad_mask = 0, bad_label = 0;
     for (uint32_t c = threadIdx.x; c < kCellColours; c += kBlock) {
         float L, a, b;
         colour_to_lab(s_lut, cell * kCellColours + c, L, a, b);
         const PixelTerms pt = pixel_terms(L, a, b);
-        float best = 1.0e10f;
+        const CellBounds sb = sub_bounds[cell * 8u + (c >> 6)];
+        float best = kLiteralArgmin ? 100000.0f : 1.0e10f;       // find_centroid.wgsl:29-30
         uint32_t idx = 0;
         for (uint32_t j = 0; j < k; ++j) {
             const Centroid ce = cent[j];
             const float d = cie94_key(pt, ce.L, ce.a, ce.b, ce.C);
             const KeyRange r = key_range(cb, ce.L, ce.a, ce.b, ce.C);
+            const KeyRange q = key_range(sb, ce.L, ce.a, ce.b, ce.C);
             if (!(r.lo <= d && d <= r.hi)) ++bad_range;
-            if (d < best) { best = d; idx = j; }
+            if (!(q.lo <= d && d <= q.hi)) ++bad_range;
+            const float v = kLiteralArgmin ? cie94_c(pt.L, pt.a, pt.b, pt.C, ce.L, ce.a, ce.b, ce.C) : d;
+            if (v < best) { best = v; idx = j; }
         }
         const unsigned long long m = masks[(uint64_t)cell * words + idx / 64u];
         if (!((m >> (idx & 63u)) & 1ull)) ++bad_mask;
+        if ((uint32_t)colour_labels[cell * kCellColours + c] != idx) ++bad_label;
     }
     if (bad_range) atomicAdd(violations, bad_range);
     if (bad_mask) atomicAdd(violations + 1, bad_mask);
+    if (bad_label) atomicAdd(violations + 2, bad_label);
 }
 
-hipError_t launch_check_bounds(const CellBounds *bounds, const Centroid *cent, uint32_t k, const uint64_t *masks,
-                               const float *lut, unsigned long long *violations, hipStream_t st)
+hipError_t launch_check_bounds(const CellBounds *bounds, const CellBounds *sub_bounds, const Centroid *cent, uint32_t k,
+                               const uint64_t *masks, const void *colour_labels, const float *lut,
+                               unsigned long long *violations, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_check_bounds, dim3(kCells), dim3(kBlock), 0, st, bounds, cent, k, masks, lut, violations);
+    if (k <= 256)
+        hipLaunchKernelGGL(k_check_bounds<uint8_t>, dim3(kCells), dim3(kBlock), 0, st, bounds, sub_bounds, cent, k, masks,
+                           (const uint8_t *)colour_labels, lut, violations);
+    else
+        hipLaunchKernelGGL(k_check_bounds<uint16_t>, dim3(kCells), dim3(kBlock), 0, st, bounds, sub_bounds, cent, k, masks,
+                           (const uint16_t *)colour_labels, lut, violations);
     return hipGetLastError();
 }
 

@@ -1,0 +1,133 @@
+// kmg_table_dev.h -- device helpers shared by the colour-table translation units (kmg_table.hip,
+// kmg_cube.hip).  Compile with -ffp-contract=off.
+#pragma once
+
+#include "kmg_table.h"
+#include "kmg_device.h"
+
+namespace kmg {
+
+struct KeyRange { float lo, hi; };
+
+__device__ __forceinline__ void abs_range(float x0, float x1, float c, float &m, float &M)
+{
+    const float d0 = x0 - c, d1 = x1 - c;                  // d0 <= d1 (rounding is monotone)
+    M = fmaxf(fabsf(d0), fabsf(d1));
+    m = fmaxf(fmaxf(d0, -d1), 0.0f);                       // d0 if the interval is above c, -d1 if below, 0 if it straddles c (one v_max3)
+}
+
+// [min, max] of cie94_key(pixel, c) over all pixels whose terms lie inside the bounds: every operation of
+// cie94_key is monotone in each operand (IEEE rounding is monotone), so the same operations on the interval
+// end points bound the FLOAT key of every colour rigorously -- no epsilons
+__device__ __forceinline__ KeyRange key_range(const CellBounds &cb, float L2, float a2, float b2, float C2)
+{
+    float mL, ML, ma, Ma, mb, Mb, mC, MC;
+    abs_range(cb.L0, cb.L1, L2, mL, ML);
+    abs_range(cb.a0, cb.a1, a2, ma, Ma);
+    abs_range(cb.b0, cb.b1, b2, mb, Mb);
+    abs_range(cb.C0, cb.C1, C2, mC, MC);
+    const float A0 = mL * mL, A1 = ML * ML;                // dL*dL
+    const float D0 = mC * mC, D1 = MC * MC;                // dC2
+    const float t0 = fmaf(mb, mb, ma * ma), t1 = fmaf(Mb, Mb, Ma * Ma);
+    const float h0 = fmaxf(t0 - D1, 0.0f), h1 = fmaxf(t1 - D0, 0.0f);
+    KeyRange r;
+    r.lo = fmaf(h0, cb.wH0, fmaf(D0, cb.wC0, A0));
+    r.hi = fmaf(h1, cb.wH1, fmaf(D1, cb.wC1, A1));
+    return r;
+}
+
+// The arg-min of the reference is over the LITERAL distance (find_centroid.wgsl:32-41); the kernels order by
+// the cheaper key and repair near-ties with the literal form (kmg_math.h, "near-tie repair").  A centroid
+// can win or tie under the literal distance only if its key is within kTieSlack of the smallest key, so the
+// candidate sets keep everything whose lower bound is not above U * (1 + kMaskSlack), kMaskSlack > kTieSlack.
+__device__ __forceinline__ float mask_threshold(float U) { return fmaf(U, kMaskSlack, U); }
+
+__device__ __forceinline__ void colour_to_lab(const float *s_lut, uint32_t idx, float &L, float &a, float &b)
+{
+    uint32_t r, g, bl;
+    index_to_rgb(idx, r, g, bl);
+    linear100_to_lab(s_lut[r], s_lut[g], s_lut[bl], L, a, b);
+}
+
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v)
+{
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__device__ __forceinline__ float lane_value(float v, uint32_t src)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int)src));
+}
+
+__device__ __forceinline__ uint32_t lane_value(uint32_t v, uint32_t src)
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src);
+}
+
+__device__ __forceinline__ long long lane_value64(long long v, uint32_t src)
+{
+    const uint32_t lo = lane_value((uint32_t)v, src), hi = lane_value((uint32_t)((unsigned long long)v >> 32), src);
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
+__device__ __forceinline__ long long wave_sum(long long v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// DPP cross-lane moves (no LDS traffic): src of lane i = lane perm(i) within its row of 16
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v),
+                                                                 CTRL, 0xF, 0xF, false));
+}
+constexpr int kDppXor1 = 0xB1;          // quad_perm [1,0,3,2]
+constexpr int kDppXor2 = 0x4E;          // quad_perm [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141;   // row_half_mirror: i <-> 7 - i inside each group of 8
+constexpr int kDppMirror = 0x140;       // row_mirror: i <-> 15 - i inside each row of 16
+
+// min over the 8 lanes that share lane >> 3 (all of them receive it)
+__device__ __forceinline__ float group8_min(float v)
+{
+    v = fminf(v, dpp_f32<kDppXor1>(v));
+    v = fminf(v, dpp_f32<kDppXor2>(v));
+    v = fminf(v, dpp_f32<kDppHalfMirror>(v));
+    return v;
+}
+
+// min over the wave (uniform result)
+__device__ __forceinline__ float wave_min(float v)
+{
+    v = group8_min(v);
+    v = fminf(v, dpp_f32<kDppMirror>(v));
+    return fminf(fminf(lane_value(v, 0), lane_value(v, 16)), fminf(lane_value(v, 32), lane_value(v, 48)));
+}
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+
+// sum over the wave of a per-lane u32 whose wave total cannot overflow (e.g. three packed 10-bit counters of
+// values <= 8); uniform result
+__device__ __forceinline__ uint32_t wave_add_u32(uint32_t v)
+{
+    v += dpp_u32<kDppXor1>(v);
+    v += dpp_u32<kDppXor2>(v);
+    v += dpp_u32<kDppHalfMirror>(v);
+    v += dpp_u32<kDppMirror>(v);
+    return lane_value(v, 0) + lane_value(v, 16) + lane_value(v, 32) + lane_value(v, 48);
+}
+
+// number of set bits of m below this lane's bit
+__device__ __forceinline__ uint32_t bits_below_lane(unsigned long long m)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+}  // namespace kmg

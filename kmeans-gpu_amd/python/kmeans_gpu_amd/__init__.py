@@ -70,7 +70,7 @@ SYMBOLS = [
     "kmg_lloyd_assign_partials", "kmg_lloyd_reduce_partials", "kmg_lloyd_labels", "kmg_lloyd_bind_image",
     "kmg_lloyd_unbind_image", "kmg_lloyd_prepare", "kmg_debug_check_table", "kmg_debug_table_stats", "kmg_debug_check_pairs", "kmg_debug_check_dither_masks", "kmg_debug_check_meld_masks", "kmg_kernel_name",
     "kmg_lloyd_profile", "kmg_lloyd_profile_read",
-    "kmg_lloyd_update", "kmg_lloyd_converged_count", "kmg_lloyd_run", "kmg_dev_apply",
+    "kmg_lloyd_update", "kmg_lloyd_converged_count", "kmg_lloyd_iterate", "kmg_lloyd_flush", "kmg_lloyd_run", "kmg_dev_apply",
     "kmg_dither_threshold",
 ]
 
@@ -141,6 +141,8 @@ def lib():
     L.kmg_debug_check_table.argtypes = [vp, C.POINTER(C.c_uint64), vp]
     L.kmg_lloyd_update.argtypes = [vp, i64p, vp]
     L.kmg_lloyd_converged_count.argtypes = [vp, C.POINTER(C.c_uint32), vp]
+    L.kmg_lloyd_iterate.argtypes = [vp, u8p, C.c_uint64, u32p, i64p, C.c_int, vp]
+    L.kmg_lloyd_flush.argtypes = [vp, vp]
     L.kmg_lloyd_run.argtypes = [vp, u8p, C.c_uint64, u32p, C.POINTER(C.c_uint32), vp]
     L.kmg_dev_apply.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, C.c_uint32, f32p, C.c_uint32, C.c_int, u8p, vp]
     L.kmg_dither_threshold.argtypes = [f32p, C.c_uint32, C.POINTER(C.c_float)]
@@ -403,15 +405,18 @@ class Lloyd:
         _check(lib().kmg_lloyd_unbind_image(self._h))
 
     def debug_check_table(self, stream=0):
-        out = (C.c_uint64 * 2)()
+        """exhaustive check over all 2^24 colours: (bound violations, arg-mins missing from the cell masks,
+        per-colour labels that differ from the brute-force arg-min)"""
+        out = (C.c_uint64 * 3)()
         _check(lib().kmg_debug_check_table(self._h, out, C.c_void_p(stream)))
-        return int(out[0]), int(out[1])
+        return int(out[0]), int(out[1]), int(out[2])
 
     def debug_table_stats(self, stream=0):
-        out = (C.c_uint64 * 8)()
+        out = (C.c_uint64 * 12)()
         _check(lib().kmg_debug_table_stats(self._h, out, C.c_void_p(stream)))
         names = ["occupied_cells", "candidates_total", "cells_one_candidate", "max_candidates",
-                 "cells_one_label", "occupied_sub_cells", "sub_cells_one_label", "distinct_colours"]
+                 "cells_one_label", "occupied_sub_cells", "sub_cells_one_label", "distinct_colours",
+                 "sub_cells_decided", "sub_cells_scanned", "scan_candidates", "cells_unlisted"]
         return dict(zip(names, (int(v) for v in out)))
 
     def debug_check_pairs(self, stream=0):
@@ -422,6 +427,15 @@ class Lloyd:
 
     def update(self, d_acc4, stream=0):
         _check(lib().kmg_lloyd_update(self._h, C.c_void_p(d_acc4), C.c_void_p(stream)))
+
+    def iterate(self, d_rgba, n_pixels, d_labels, d_acc4, update_first=True, stream=0):
+        """one Lloyd iteration, asynchronous; the label map is complete after flush() (or a device sync)"""
+        _check(lib().kmg_lloyd_iterate(self._h, C.c_void_p(d_rgba), n_pixels, C.c_void_p(d_labels or None),
+                                       C.c_void_p(d_acc4), int(bool(update_first)), C.c_void_p(stream)))
+
+    def flush(self, stream=0):
+        """make `stream` wait for the label passes that iterate() left running on the library's side stream"""
+        _check(lib().kmg_lloyd_flush(self._h, C.c_void_p(stream)))
 
     def converged_count(self, stream=0):
         n = C.c_uint32()

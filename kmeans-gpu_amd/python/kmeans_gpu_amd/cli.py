@@ -93,6 +93,16 @@ def find_file_path(mode, output, inp):                   # main.rs:184-219
     return os.path.join(os.path.dirname(inp), f"{stem}-find-{mode}-{millis}{ext}")
 
 
+def validate_size(s):                                       # args.rs:36-38 value_parser!(u32).range(1..=60)
+    try:
+        v = int(s)
+    except ValueError:
+        raise argparse.ArgumentTypeError(f"invalid value '{s}': not an integer")
+    if not 1 <= v <= 60:
+        raise argparse.ArgumentTypeError(f"{v} is not in 1..=60")
+    return v
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="kmeans-hip", description="k-means colour quantisation on MI355X")
     sub = ap.add_subparsers(dest="command", required=True)
@@ -101,7 +111,7 @@ def main(argv=None):
     p.add_argument("-i", "--input", type=validate_filename, required=True)
     p.add_argument("-o", "--output", type=validate_filename)
     p.add_argument("-a", "--algo", choices=list(_ALGOS), default="kmeans")
-    p.add_argument("-s", "--size", type=int, default=40)
+    p.add_argument("-s", "--size", type=validate_size, default=40)
     f = sub.add_parser("find", help="Replace the colors of the input with the closest ones of a palette")
     f.add_argument("-i", "--input", type=validate_filename, required=True)
     f.add_argument("-o", "--output", type=validate_filename)

@@ -15,6 +15,19 @@ import torch.distributed as dist
 __all__ = ["band_rows", "sharded_init", "ShardedLloyd", "ShardedBatch"]
 
 
+def _require_current_stream(tensor, stream):
+    """The library kernels run on the raw `stream`; the torch ops of this module (fill_, zero_, all_reduce,
+    Work.wait) order against torch's CURRENT stream of the tensor's device.  The two must be the same
+    stream, otherwise the collective races with the kernels that produce / consume the accumulators
+    (torch side streams are non-blocking: the null stream does not order against them either)."""
+    if not tensor.is_cuda:
+        return
+    current = torch.cuda.current_stream(tensor.device).cuda_stream
+    if int(stream or 0) != int(current):
+        raise ValueError(f"stream {int(stream or 0):#x} is not torch's current stream {int(current):#x} of {tensor.device}: "
+                         "pass stream=torch.cuda.current_stream().cuda_stream (or enter torch.cuda.stream(...) first)")
+
+
 def band_rows(height, rank, world):
     """Rows [r0, r1) owned by `rank`."""
     return (rank * height) // world, ((rank + 1) * height) // world
@@ -32,6 +45,7 @@ def sharded_init(backend, k, band, width, height, row0, group=None, stream=0):
     band    : this rank's rows, uint8 tensor (rows*width, 4); row0 = image row of its first pixel
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
+    _require_current_stream(band, stream)
     n_local = int(band.shape[0]) if band.dim() == 2 else int(band.numel() // 4)
     first = int(row0) * int(width)
     ptr = band.data_ptr() if n_local else 0
@@ -62,7 +76,7 @@ class ShardedLloyd:
     labels   : int32 tensor (rows*width,) or None
     """
 
-    def __init__(self, backend, k, rgba, labels=None, group=None, stream=0):
+    def __init__(self, backend, k, rgba, labels=None, group=None, stream=0, collective=None):
         self.backend = backend
         self.k = int(k)
         self.rgba = rgba
@@ -72,9 +86,15 @@ class ShardedLloyd:
         self.stream = stream
         self.acc = torch.zeros((self.k, 4), dtype=torch.int64, device=rgba.device)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # collective(acc) -> None replaces the SUM all-reduce (tests: the other ranks' share computed locally)
+        self.collective = collective
+        if collective is not None:
+            self.world = max(self.world, 2)
         # True when the backend produces labels with a separate pass (kmeans_gpu_amd.Lloyd after
         # prepare() chose the colour table): lets the collective overlap that pass
         self.split_labels = False
+        # label pass of iteration t beside the cube pass of iteration t + 1 (Lloyd.iterate); False: step by step
+        self.pipeline = True
 
     def _pass(self):
         """labels + sums of the current centroids, and the exchange of the sums.
@@ -83,6 +103,7 @@ class ShardedLloyd:
         label map from a separate gather pass that does not feed the collective: the all-reduce is
         issued asynchronously right after the sums and overlaps the label pass."""
         lab_ptr = self.labels.data_ptr() if self.labels is not None else 0
+        _require_current_stream(self.acc, self.stream)
         if self.n_local == 0:
             self.acc.zero_()
             self.exchange()
@@ -100,18 +121,42 @@ class ShardedLloyd:
 
     def exchange(self, async_op=False):
         """the path's one collective: sum of the k x 4 int64 accumulators over all bands"""
+        if self.collective is not None:
+            self.collective(self.acc)
+            return None
         if self.world > 1:
             return dist.all_reduce(self.acc, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
         return None
 
+    def _pipelined(self):
+        """kmeans_gpu_amd.Lloyd.iterate: the label pass of iteration t runs beside the update + cube pass of
+        iteration t + 1 on the library's own stream (colour-table strategy with a label map)"""
+        return (self.pipeline and self.split_labels and self.labels is not None and self.n_local > 0
+                and hasattr(self.backend, "iterate"))
+
     def prime(self):
         """initial assignment (operations.rs:75-83), fused with the sums of the first update"""
-        self._pass()
+        if self._pipelined():
+            _require_current_stream(self.acc, self.stream)
+            self.backend.iterate(self.rgba.data_ptr(), self.n_local, self.labels.data_ptr(), self.acc.data_ptr(), False, self.stream)
+            self.exchange()
+        else:
+            self._pass()
 
     def iterate(self):
         """one Lloyd iteration (modules.rs:769-800): update from the global sums, re-assign"""
-        self.backend.update(self.acc.data_ptr(), self.stream)
-        self._pass()
+        if self._pipelined():
+            _require_current_stream(self.acc, self.stream)
+            self.backend.iterate(self.rgba.data_ptr(), self.n_local, self.labels.data_ptr(), self.acc.data_ptr(), True, self.stream)
+            self.exchange()
+        else:
+            self.backend.update(self.acc.data_ptr(), self.stream)
+            self._pass()
+
+    def flush(self):
+        """the label map of the last iteration is complete once the stream has passed this point"""
+        if hasattr(self.backend, "flush"):
+            self.backend.flush(self.stream)
 
     def run(self, max_iterations=128, check_period=8):
         """ChooseCentroidModule::compute (modules.rs:763-840) over all bands.  Returns the
@@ -124,6 +169,7 @@ class ShardedLloyd:
                 # identical on every rank: all ranks updated from the same global sums
                 if self.backend.converged_count(self.stream) >= self.k:
                     break
+        self.flush()
         return it
 
 
@@ -140,8 +186,10 @@ class ShardedBatch:
     labels   : list of int32 tensors (or None entries)
     """
 
-    def __init__(self, backends, k, bands, labels=None, group=None, stream=0):
+    def __init__(self, backends, k, bands, labels=None, group=None, stream=0, collective=None):
         assert len(backends) == len(bands)
+        # collective(acc, active) -> None replaces the SUM all-reduce (tests: the other ranks' share computed locally)
+        self.collective = collective
         self.backends = list(backends)
         self.k = int(k)
         self.bands = list(bands)
@@ -155,6 +203,7 @@ class ShardedBatch:
         self.iterations = [0] * len(bands)
 
     def _pass(self):
+        _require_current_stream(self.acc, self.stream)
         for i, be in enumerate(self.backends):
             if not self.active[i]:
                 continue
@@ -163,7 +212,9 @@ class ShardedBatch:
                 be.assign_accumulate(self.bands[i].data_ptr(), self.n_local[i], lab, self.acc[i].data_ptr(), self.stream)
             else:
                 self.acc[i].zero_()
-        if self.world > 1:
+        if self.collective is not None:
+            self.collective(self.acc, list(self.active))
+        elif self.world > 1:
             # converged images keep their (stale, unused) rows: shapes stay fixed for the collective
             dist.all_reduce(self.acc, op=dist.ReduceOp.SUM, group=self.group)
 

@@ -1,0 +1,190 @@
+"""Oracle parity at BASELINE.json's full sizes (-m gpu): every label and every accumulator of one cfg3
+pass, the literal CIE94 arg-min of the reference (find_centroid.wgsl:32-41) on every pixel, >= 1024 rows
+of the cfg5 dither pass, and one rank's share of cfg4 (16 x 8192x8192 tiled over 8 GPUs)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _stream(torch):
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _cfg3_centroids(oracle, synth, n, k):
+    """bench.py's initial centroids: shader Lab of the pixels at linear index j * floor(N / k)"""
+    sel = synth.uniform_rgba_at(synth.SEED_CFG3, np.arange(k, dtype=np.uint64) * np.uint64(n // k))
+    return oracle.centroids4(oracle.rgb_to_lab(sel))
+
+
+def test_cfg3_full_pass_every_label_and_sum_vs_oracle(torch_cuda, oracle, monkeypatch):
+    """BASELINE config 3 (8192x8192, k=256), colour-table strategy: ALL 67 M labels and all k x 4 int64
+    accumulators of an assign+accumulate pass equal the oracle's, for the initial centroids and again
+    after one centroid update (oracle update from the oracle's own sums)."""
+    import kmeans_gpu_amd as kg
+    from kmeans_gpu_amd import synth
+    torch = torch_cuda
+    monkeypatch.setenv("KMG_STRATEGY", "table")
+    n, k = 8192 * 8192, 256
+    st = _stream(torch)
+    rgba = synth.uniform_rgba_torch(synth.SEED_CFG3, n, device="cuda")
+    host = rgba.cpu().numpy()
+    cent = _cfg3_centroids(oracle, synth, n, k)
+    p = kg.ImageProcessor(shrink_max_dim=0)
+    s = kg.Lloyd(p, k)
+    s.set_centroids(cent, st)
+    assert s.prepare(rgba.data_ptr(), n, True, st) == "table"
+    labels = torch.zeros(n, dtype=torch.int32, device="cuda")
+    acc = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
+    for step in range(2):
+        s.assign_accumulate(rgba.data_ptr(), n, labels.data_ptr(), acc.data_ptr(), st)
+        torch.cuda.synchronize()
+        want_l, want_a = oracle.assign_accumulate_rgba(host, cent)
+        got_l = labels.cpu().numpy().view(np.uint32)
+        assert np.array_equal(got_l, want_l), f"pass {step}: {int((got_l != want_l).sum())} labels differ"
+        assert np.array_equal(acc.cpu().numpy(), want_a), f"pass {step}: accumulators differ"
+        s.update(acc.data_ptr(), st)
+        cent, _ = oracle.finalize(want_a, cent)
+        assert np.array_equal(s.get_centroids(st).view(np.uint32), cent.view(np.uint32))
+    s.close()
+    p.close()
+
+
+def test_cfg3_labels_equal_the_literal_cie94_argmin_on_every_pixel(torch_cuda, oracle, monkeypatch):
+    """The reference's arg-min is over the literal distance_cie94 with strict '<' (find_centroid.wgsl:32-41,
+    delta_e.wgsl:1-22).  A label is a function of the 24-bit colour, so the literal arg-min of all 2^24
+    colours (oracle, literal=1) is a complete table of the reference labels: every pixel of the cfg3 image
+    must carry it -- for the initial centroids and for the centroids after four Lloyd iterations."""
+    import kmeans_gpu_amd as kg
+    from kmeans_gpu_amd import synth
+    torch = torch_cuda
+    monkeypatch.setenv("KMG_STRATEGY", "table")
+    n, k = 8192 * 8192, 256
+    st = _stream(torch)
+    rgba = synth.uniform_rgba_torch(synth.SEED_CFG3, n, device="cuda")
+    idx = np.arange(1 << 24, dtype=np.uint32)
+    cube = np.empty((1 << 24, 4), np.uint8)
+    cube[:, 0] = idx & 255; cube[:, 1] = (idx >> 8) & 255; cube[:, 2] = (idx >> 16) & 255; cube[:, 3] = 255
+    cube_lab = oracle.rgb_to_lab(cube)
+    v = rgba.view(torch.int32).reshape(-1)
+    colour = (v & 0xFFFFFF).to(torch.int64)                        # r | g << 8 | b << 16
+    p = kg.ImageProcessor(shrink_max_dim=0)
+    s = kg.Lloyd(p, k)
+    s.set_centroids(_cfg3_centroids(oracle, synth, n, k), st)
+    s.prepare(rgba.data_ptr(), n, True, st)
+    labels = torch.zeros(n, dtype=torch.int32, device="cuda")
+    acc = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
+    for round_ in range(2):
+        cent = s.get_centroids(st)
+        s.assign_accumulate(rgba.data_ptr(), n, labels.data_ptr(), acc.data_ptr(), st)
+        lut = torch.from_numpy(oracle.assign(cube_lab, cent, literal=True).astype(np.int32)).cuda()
+        want = lut[colour]
+        bad = int((want != labels).sum())
+        assert bad == 0, f"round {round_}: {bad} of {n} pixels differ from the literal CIE94 arg-min"
+        for _ in range(4):
+            s.update(acc.data_ptr(), st)
+            s.assign_accumulate(rgba.data_ptr(), n, 0, acc.data_ptr(), st)
+    s.close()
+    p.close()
+
+
+@pytest.mark.parametrize("palette", ["resurrect_64.png", "apollo-1x.png"])
+def test_cfg5_find_dither_1024_rows_and_tail_vs_oracle(torch_cuda, oracle, palette):
+    """BASELINE config 5 (find -m dither, fixed palette, 8192x8192): the first 1024 rows, 1028 rows that
+    start inside the image (Bayer rows 3..2 across many periods) and the last 1028 rows equal the oracle."""
+    import kmeans_gpu_amd as kg
+    from kmeans_gpu_amd import synth
+    from PIL import Image
+    torch = torch_cuda
+    st = _stream(torch)
+    w = h = 8192
+    n = w * h
+    px = np.array(Image.open(os.path.join(os.path.dirname(__file__), "golden", palette)).convert("RGBA")).reshape(-1, 4)
+    pal = np.array(sorted(set(map(tuple, px))), np.uint8)
+    cent = kg.palette_to_centroids(pal)
+    rgba = synth.uniform_rgba_torch(synth.SEED_CFG5, n, device="cuda")
+    p = kg.ImageProcessor()
+    out = torch.zeros((n, 4), dtype=torch.uint8, device="cuda")
+    p.apply(rgba.data_ptr(), w, h, 0, cent, kg.ReduceMode.Dither, out.data_ptr(), st)
+    torch.cuda.synchronize()
+    for r0, rows in ((0, 1024), (4000, 1028), (h - 1028, 1028)):     # r0 % 4 == 0: the oracle's Bayer rows line up
+        src = rgba[r0 * w:(r0 + rows) * w].cpu().numpy().reshape(rows, w, 4)
+        want = oracle.find(src, pal, oracle.MODE_DITHER)
+        got = out[r0 * w:(r0 + rows) * w].cpu().numpy().reshape(rows, w, 4)
+        assert np.array_equal(got, want), f"rows {r0}..{r0 + rows}: {int((got != want).any(-1).sum())} pixels differ"
+    p.close()
+
+
+def test_cfg4_one_ranks_share_of_the_batch(torch_cuda, oracle):
+    """BASELINE config 4: 16 images of 8192x8192 (seeds 0x5EED0400 + i), k=256, each tiled over 8 GPUs in row
+    bands; this is rank 3's share -- 16 bands of 8192x1024 through ShardedBatch (one accumulator tensor, one
+    exchange per iteration).  The exchange is emulated on the same GPU: the other seven ranks' contribution
+    = the sums of the complementary 7168 rows under the rank's current centroids.  After three iterations the
+    centroids and the band's labels equal the unsharded run on the whole image, and image 0 equals the oracle."""
+    import kmeans_gpu_amd as kg
+    from kmeans_gpu_amd import synth
+    from kmeans_gpu_amd.sharded import ShardedBatch, band_rows
+    torch = torch_cuda
+    st = _stream(torch)
+    w = h = 8192
+    k, images, world, rank, iters = 256, 16, 8, 3, 3
+    r0, r1 = band_rows(h, rank, world)
+    n_band, n = (r1 - r0) * w, w * h
+    p = kg.ImageProcessor(shrink_max_dim=0, max_iterations=iters, check_period=8)
+    cent0 = []
+    for i in range(images):
+        sel = synth.uniform_rgba_at(synth.SEED_CFG4 + i, np.arange(k, dtype=np.uint64) * np.uint64(n // k))
+        cent0.append(oracle.centroids4(oracle.rgb_to_lab(sel)))
+
+    # unsharded runs, one image at a time (centroids + the band's labels kept)
+    want = []
+    for i in range(images):
+        img = synth.uniform_rgba_torch(synth.SEED_CFG4 + i, n, device="cuda")
+        s = kg.Lloyd(p, k)
+        s.set_centroids(cent0[i], st)
+        labels = torch.zeros(n, dtype=torch.int32, device="cuda")
+        s.run(img.data_ptr(), n, labels.data_ptr(), st)
+        want.append((s.get_centroids(st), labels[r0 * w:r1 * w].clone()))
+        if i == 0:                                                  # the oracle on image 0's band, final centroids' predecessor
+            host_band = img[r0 * w:r1 * w].cpu().numpy()
+        s.close()
+        del img, labels
+    torch.cuda.empty_cache()
+
+    # the rank's share: its band of every image + a helper over the complementary rows (the other 7 ranks)
+    bands, others, backends, helpers, labels = [], [], [], [], []
+    for i in range(images):
+        band = synth.uniform_rgba_torch(synth.SEED_CFG4 + i, n_band, first=r0 * w, device="cuda")
+        top = synth.uniform_rgba_torch(synth.SEED_CFG4 + i, r0 * w, first=0, device="cuda")
+        bottom = synth.uniform_rgba_torch(synth.SEED_CFG4 + i, n - r1 * w, first=r1 * w, device="cuda")
+        other = torch.cat([top, bottom])
+        s = kg.Lloyd(p, k)
+        s.set_centroids(cent0[i], st)
+        s.prepare(band.data_ptr(), n_band, True, st)
+        hlp = kg.Lloyd(p, k)
+        hlp.bind_image(other.data_ptr(), n - n_band, st)
+        bands.append(band); others.append(other); backends.append(s); helpers.append(hlp)
+        labels.append(torch.zeros(n_band, dtype=torch.int32, device="cuda"))
+    rest = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
+
+    def other_ranks(acc, active):
+        for i in range(images):
+            if not active[i]:
+                continue
+            helpers[i].set_centroids(backends[i].get_centroids(st), st)
+            helpers[i].assign_accumulate(others[i].data_ptr(), n - n_band, 0, rest.data_ptr(), st)
+            acc[i] += rest
+
+    batch = ShardedBatch(backends, k, bands, labels, stream=st, collective=other_ranks)
+    batch.run(iters, 8)
+    torch.cuda.synchronize()
+    for i in range(images):
+        assert np.array_equal(backends[i].get_centroids(st).view(np.uint32), want[i][0].view(np.uint32)), f"image {i}"
+        assert torch.equal(labels[i], want[i][1]), f"image {i}"
+    wl, _ = oracle.assign_accumulate_rgba(host_band, backends[0].get_centroids(st))
+    assert np.array_equal(labels[0].cpu().numpy().view(np.uint32), wl)
+    for s in backends + helpers:
+        s.close()
+    p.close()

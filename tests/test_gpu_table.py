@@ -43,8 +43,7 @@ def test_bounds_and_masks_conservative_for_all_colours(torch_cuda, processor, or
     for name, cent in _centroid_sets(oracle, rng).items():
         s = kg.Lloyd(processor, cent.shape[0])
         s.set_centroids(cent)
-        bad_range, bad_mask = s.debug_check_table(_stream(torch_cuda))
-        assert (bad_range, bad_mask) == (0, 0), name
+        assert s.debug_check_table(_stream(torch_cuda)) == (0, 0, 0), name
         s.close()
 
 
@@ -533,6 +532,92 @@ def test_buffer_reused_for_a_second_image(torch_cuda, oracle, monkeypatch):
         assert np.array_equal(labels.cpu().numpy().view(np.uint32), want_l), seed
     s.close()
     p.close()
+
+
+def test_run_twice_on_one_buffer_with_set_centroids(torch_cuda, oracle, monkeypatch):
+    """kmg_lloyd_run binds the image on its own behalf and must not leave that binding behind: a second
+    run on the same device buffer with new pixels and set_centroids (no initialisation in between, e.g. a
+    frame loop or a buffer recycled by the caching allocator) works from the NEW image's histogram.  A
+    binding the caller made explicitly (prepare) survives the run."""
+    import kmeans_gpu_amd as kg
+    torch = torch_cuda
+    st = _stream(torch)
+    monkeypatch.setenv("KMG_STRATEGY", "table")
+    w, h, k = 200, 120, 9
+    p = kg.ImageProcessor(shrink_max_dim=0)
+    s = kg.Lloyd(p, k)
+    d = torch.zeros((w * h, 4), dtype=torch.uint8, device="cuda")
+    labels = torch.zeros(w * h, dtype=torch.int32, device="cuda")
+    for seed in (3, 4, 5):
+        img = _blobs(np.random.default_rng(seed), w * h, 7, sigma=18.0).reshape(h, w, 4)
+        d.copy_(torch.from_numpy(img.reshape(-1, 4)))
+        lab = oracle.rgb_to_lab(img)
+        init = oracle.init_centroids(lab, w, h, k)
+        s.set_centroids(init, st)
+        s.run(d.data_ptr(), w * h, labels.data_ptr(), st)
+        want_c, want_l, _ = oracle.lloyd(lab, init)
+        assert np.array_equal(s.get_centroids(st).view(np.uint32), want_c.view(np.uint32)), seed
+        assert np.array_equal(labels.cpu().numpy().view(np.uint32), want_l), seed
+    # explicit binding: kept across run() (the caller vouches for the contents)
+    assert s.prepare(d.data_ptr(), w * h, True, st) == "table"
+    s.set_centroids(init, st)
+    s.run(d.data_ptr(), w * h, labels.data_ptr(), st)
+    acc = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
+    s.assign_accumulate(d.data_ptr(), w * h, 0, acc.data_ptr(), st)       # table pass: works only while bound
+    torch.cuda.synchronize()
+    assert s.debug_table_stats(st)["distinct_colours"] > 0
+    assert np.array_equal(labels.cpu().numpy().view(np.uint32), want_l)
+    s.close()
+    p.close()
+
+
+@pytest.mark.parametrize("k", [24, 300])
+def test_pipelined_iterate_equals_step_by_step(torch_cuda, oracle, monkeypatch, k):
+    """kmg_lloyd_iterate (label pass of iteration t on the side stream beside the cube pass of t + 1, two
+    alternating sets of label tables) gives the same centroids, sums and -- after every iteration -- the same
+    label map as update + assign_accumulate step by step, and as the oracle."""
+    import kmeans_gpu_amd as kg
+    torch = torch_cuda
+    st = _stream(torch)
+    monkeypatch.setenv("KMG_STRATEGY", "table")
+    w, h = 700, 500
+    n = w * h
+    img = _blobs(np.random.default_rng(k), n, 40, sigma=25.0)
+    lab = oracle.rgb_to_lab(img)
+    init = oracle.centroids4(lab[np.random.default_rng(1).choice(n, k, replace=False)])
+    d = _dev(torch, img)
+    p = kg.ImageProcessor(shrink_max_dim=0)
+    a, b = kg.Lloyd(p, k), kg.Lloyd(p, k)
+    for s in (a, b):
+        s.set_centroids(init, st)
+        assert s.prepare(d.data_ptr(), n, True, st) == "table"
+    la, lb = (torch.zeros(n, dtype=torch.int32, device="cuda") for _ in range(2))
+    acc_a, acc_b = (torch.zeros((k, 4), dtype=torch.int64, device="cuda") for _ in range(2))
+    cent = init
+    for it in range(6):
+        if it:
+            a.update(acc_a.data_ptr(), st)
+        a.assign_accumulate(d.data_ptr(), n, la.data_ptr(), acc_a.data_ptr(), st)
+        b.iterate(d.data_ptr(), n, lb.data_ptr(), acc_b.data_ptr(), it > 0, st)
+        if it in (0, 3, 5):                      # look at the label map of this very iteration
+            b.flush(st)
+            torch.cuda.synchronize()
+            assert torch.equal(la, lb), it
+            assert torch.equal(acc_a, acc_b), it
+            wl, wa = oracle.assign_accumulate_rgba(img, cent)
+            assert np.array_equal(lb.cpu().numpy().view(np.uint32), wl) and np.array_equal(acc_b.cpu().numpy(), wa), it
+        cent, _ = oracle.finalize(oracle.assign_accumulate_rgba(img, cent)[1], cent)
+    b.flush(st)
+    torch.cuda.synchronize()
+    assert torch.equal(la, lb) and torch.equal(acc_a, acc_b)
+    assert np.array_equal(a.get_centroids(st).view(np.uint32), b.get_centroids(st).view(np.uint32))
+    # mixing in a synchronous pass afterwards still sees consistent tables
+    b.update(acc_b.data_ptr(), st); a.update(acc_a.data_ptr(), st)
+    a.assign_accumulate(d.data_ptr(), n, la.data_ptr(), acc_a.data_ptr(), st)
+    b.assign_accumulate(d.data_ptr(), n, lb.data_ptr(), acc_b.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert torch.equal(la, lb) and torch.equal(acc_a, acc_b)
+    a.close(); b.close(); p.close()
 
 
 def test_meld_masks_conservative_for_all_colours(torch_cuda, processor, oracle):

@@ -23,6 +23,8 @@ for k in (16, 64, 256):
             d = s.debug_table_stats(st)
             print(f"k={k} it={it}: mean candidates/cell {d['candidates_total']/d['occupied_cells']:.2f} max {d['max_candidates']} "
                   f"one-candidate cells {d['cells_one_candidate']/d['occupied_cells']:.3f} one-label cells {d['cells_one_label']/d['occupied_cells']:.3f} "
-                  f"one-label sub-cells {d['sub_cells_one_label']/d['occupied_sub_cells']:.3f} colours {d['distinct_colours']}")
+                  f"one-label sub-cells {d['sub_cells_one_label']/d['occupied_sub_cells']:.3f} colours {d['distinct_colours']} | "
+                  f"sub-cells decided by bounds {d['sub_cells_decided']} scanned {d['sub_cells_scanned']} "
+                  f"candidates/scanned sub-cell {d['scan_candidates']/max(d['sub_cells_scanned'],1):.2f} unlisted cells {d['cells_unlisted']}")
         s.update(acc.data_ptr(), st)
     s.close()
