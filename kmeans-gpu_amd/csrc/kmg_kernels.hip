@@ -62,11 +62,18 @@ hipError_t launch_rgb_to_lab(const uint32_t *rgba, uint64_t n, const float *lut,
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kNoChunk = 0xFFFFFFFFu;
 
-template <int PPT, bool CHUNKED>
+// Near-tie repair (kmg_math.h): the scan orders by the key and remembers the second smallest key; a pixel whose
+// second smallest key is within the tie threshold of the smallest is decided again by the LITERAL distance among
+// the centroids inside the threshold, first minimum winning -- find_centroid.wgsl:32-41 / mix_colors.wgsl:73-80
+// exactly.  SENTINEL (dither): the running minimum starts at the distance to vec3(10000.0), index k.
+template <int PPT, bool CHUNKED, bool SENTINEL>
 __device__ __forceinline__ void argmin_scan(const PixelTerms (&pt)[PPT], float (&best)[PPT],
                                             uint32_t (&idx)[PPT], const float4 *s_cent, uint32_t k,
                                             uint32_t kpad)
 {
+    float second[PPT];                                   // best <= second: the two smallest keys met so far
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) second[p] = 3.0e38f;
     if (!CHUNKED) {
 #pragma unroll 2
         for (uint32_t j = 0; j < k; ++j) {
@@ -75,6 +82,7 @@ __device__ __forceinline__ void argmin_scan(const PixelTerms (&pt)[PPT], float (
             for (int p = 0; p < PPT; ++p) {
                 float d = cie94_key(pt[p], c.x, c.y, c.z, c.w);
                 bool lt = d < best[p];
+                if (kLiteralArgmin) second[p] = __builtin_amdgcn_fmed3f(d, best[p], second[p]);
                 best[p] = lt ? d : best[p];
                 idx[p] = lt ? j : idx[p];
             }
@@ -93,6 +101,8 @@ __device__ __forceinline__ void argmin_scan(const PixelTerms (&pt)[PPT], float (
                 float d3 = cie94_key(pt[p], c3.x, c3.y, c3.z, c3.w);
                 float m = fminf(fminf(fminf(d0, d1), d2), d3);
                 bool lt = m < best[p];
+                // second smallest chunk minimum; the other keys of the winning chunk are looked at below
+                if (kLiteralArgmin) second[p] = __builtin_amdgcn_fmed3f(m, best[p], second[p]);
                 best[p] = lt ? m : best[p];
                 chunk[p] = lt ? j : chunk[p];
             }
@@ -101,14 +111,50 @@ __device__ __forceinline__ void argmin_scan(const PixelTerms (&pt)[PPT], float (
         for (int p = 0; p < PPT; ++p) {
             if (chunk[p] != kNoChunk) {
                 uint32_t found = chunk[p] + 3;
+                float d4[4];
 #pragma unroll
-                for (int q = 2; q >= 0; --q) {
+                for (int q = 3; q >= 0; --q) {
                     const float4 c = s_cent[chunk[p] + q];
-                    float d = cie94_key(pt[p], c.x, c.y, c.z, c.w);
-                    found = (d <= best[p]) ? chunk[p] + q : found;
+                    d4[q] = cie94_key(pt[p], c.x, c.y, c.z, c.w);
+                    if (q < 3) found = (d4[q] <= best[p]) ? chunk[p] + q : found;
                 }
                 idx[p] = found;
+                if (kLiteralArgmin) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        second[p] = fminf(second[p], chunk[p] + q == found ? 3.0e38f : d4[q]);
+                }
             }
+        }
+    }
+    if (kLiteralArgmin) {
+        float thr[PPT];
+        bool near_any = false;
+#pragma unroll
+        for (int p = 0; p < PPT; ++p) {
+            thr[p] = tie_threshold(best[p]);
+            near_any = near_any || second[p] <= thr[p];
+        }
+        if (__ballot(near_any)) {
+            float lb[PPT];
+            uint32_t li[PPT];
+#pragma unroll
+            for (int p = 0; p < PPT; ++p) {
+                lb[p] = SENTINEL ? cie94_c(pt[p].L, pt[p].a, pt[p].b, pt[p].C, 10000.0f, 10000.0f, 10000.0f, chroma(10000.0f, 10000.0f)) : 100000.0f;
+                li[p] = SENTINEL ? k : 0u;
+            }
+            for (uint32_t j = 0; j < k; ++j) {
+                const float4 c = s_cent[j];
+#pragma unroll
+                for (int p = 0; p < PPT; ++p) {
+                    if (second[p] <= thr[p] && cie94_key(pt[p], c.x, c.y, c.z, c.w) <= thr[p]) {
+                        const float d = cie94_c(pt[p].L, pt[p].a, pt[p].b, pt[p].C, c.x, c.y, c.z, c.w);
+                        if (d < lb[p]) { lb[p] = d; li[p] = j; }
+                    }
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < PPT; ++p) idx[p] = second[p] <= thr[p] ? li[p] : idx[p];
         }
     }
 }
@@ -166,7 +212,7 @@ __global__ __launch_bounds__(kBlock) void k_assign(const uint32_t *__restrict__ 
         uint32_t idx[PPT];
 #pragma unroll
         for (int p = 0; p < PPT; ++p) { best[p] = 1.0e10f; idx[p] = 0u; }
-        argmin_scan<PPT, CHUNKED>(pt, best, idx, s_cent, k, kpad);
+        argmin_scan<PPT, CHUNKED, false>(pt, best, idx, s_cent, k, kpad);
 
 #pragma unroll
         for (int g = 0; g < GROUPS; ++g) {
@@ -608,7 +654,7 @@ __global__ __launch_bounds__(kBlock) void k_apply(const uint32_t *__restrict__ r
                 }
             }
         }
-        argmin_scan<PPT, CHUNKED>(pt, best, idx, s_cent, k, kpad);
+        argmin_scan<PPT, CHUNKED, DITHER>(pt, best, idx, s_cent, k, kpad);
 #pragma unroll
         for (int g = 0; g < GROUPS; ++g) {
             uint32_t o[4];

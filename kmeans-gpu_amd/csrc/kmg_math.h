@@ -152,7 +152,7 @@ constexpr float kTieSlack = KMG_TIE_SLACK;
 constexpr float kMaskSlack = 0.000244140625f;   // 2^-12
 
 // false: the arg-min is that of the key alone (round-1 definition, kept as a switch for A/B timing)
-constexpr bool kLiteralArgmin = false;
+constexpr bool kLiteralArgmin = true;
 
 KMG_HD float tie_threshold(float best) { return fmaf(best, kTieSlack, best); }
 

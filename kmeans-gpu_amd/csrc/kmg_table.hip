@@ -802,6 +802,7 @@ __global__ __launch_bounds__(kBlock) void k_offset_candidates(const CellBounds *
                 }
             }
             for (int o = 32; o > 0; o >>= 1) U = fminf(U, __shfl_xor(U, o, 64));
+            U = mask_threshold(U);                               // keep what can still be a near-tie (kmg_math.h)
 #pragma unroll
             for (uint32_t w = 0; w < 4u; ++w) {
                 const unsigned long long m = __ballot(w * 64 + lane < k && lo[w] <= U);
@@ -814,6 +815,7 @@ __global__ __launch_bounds__(kBlock) void k_offset_candidates(const CellBounds *
             U = fminf(U, key_range(sb, ce.L, ce.a, ce.b, ce.C).hi);
         }
         for (int o = 32; o > 0; o >>= 1) U = fminf(U, __shfl_xor(U, o, 64));
+        U = mask_threshold(U);
         for (uint32_t w = 0; w < words; ++w) {
             const uint32_t j = w * 64 + lane;
             bool keep = false;
@@ -888,7 +890,7 @@ __global__ __launch_bounds__(kBlock) void k_dither_pruned(const uint32_t *__rest
             const float off = s_off[slot[q] & 15u];
             L = L + off; a = a + off; b = b + off;                   // mix_colors.wgsl:72
             const PixelTerms pt = pixel_terms(L, a, b);
-            float best = cie94_key(pt, 10000.0f, 10000.0f, 10000.0f, sentinel_C);
+            float best = cie94_key(pt, 10000.0f, 10000.0f, 10000.0f, sentinel_C), second = 3.0e38f;
             uint32_t idx = k;
             auto scan_word = [&](unsigned long long m, uint32_t wd) {
                 while (m) {
@@ -896,6 +898,7 @@ __global__ __launch_bounds__(kBlock) void k_dither_pruned(const uint32_t *__rest
                     m &= m - 1;
                     const float4 c = s_cent[j];
                     const float d = cie94_key(pt, c.x, c.y, c.z, c.w);
+                    if (kLiteralArgmin) second = __builtin_amdgcn_fmed3f(d, best, second);
                     if (d < best) { best = d; idx = j; }
                 }
             };
@@ -903,6 +906,28 @@ __global__ __launch_bounds__(kBlock) void k_dither_pruned(const uint32_t *__rest
             for (int u = 0; u < UP; ++u) scan_word(m0[q][u], (uint32_t)u);
             if (WORDS == 0)
                 for (uint32_t wd = 1; wd < words; ++wd) scan_word(masks[(uint64_t)slot[q] * words + wd], wd);
+            if (kLiteralArgmin && second <= tie_threshold(best)) {
+                // near-tie (kmg_math.h): mix_colors.wgsl:73-80 with the literal distance, the sentinel first
+                const float thr = tie_threshold(best);
+                float lb = cie94_c(pt.L, pt.a, pt.b, pt.C, 10000.0f, 10000.0f, 10000.0f, sentinel_C);
+                uint32_t li = k;
+                auto rescan_word = [&](unsigned long long m, uint32_t wd) {
+                    while (m) {
+                        const uint32_t j = wd * 64 + (uint32_t)__builtin_ctzll(m);
+                        m &= m - 1;
+                        const float4 c = s_cent[j];
+                        if (cie94_key(pt, c.x, c.y, c.z, c.w) <= thr) {
+                            const float d = cie94_c(pt.L, pt.a, pt.b, pt.C, c.x, c.y, c.z, c.w);
+                            if (d < lb) { lb = d; li = j; }
+                        }
+                    }
+                };
+#pragma unroll
+                for (int u = 0; u < UP; ++u) rescan_word(m0[q][u], (uint32_t)u);
+                if (WORDS == 0)
+                    for (uint32_t wd = 1; wd < words; ++wd) rescan_word(masks[(uint64_t)slot[q] * words + wd], wd);
+                idx = li;
+            }
             res[q] = pal[idx];
         }
         store4_stream(out, i0, n, aligned != 0, res);
@@ -1056,12 +1081,15 @@ __global__ __launch_bounds__(kBlock) void k_check_offset_masks(const Centroid *_
         for (uint32_t bi = 0; bi < 16u; ++bi) {
             const float off = threshold * (bayer16(bi) / 16.0f - 0.5f);
             const PixelTerms pt = pixel_terms(L0 + off, a0 + off, b0 + off);
-            const float start = cie94_key(pt, 10000.0f, 10000.0f, 10000.0f, sentinel_C);
+            // the arg-min of mix_colors.wgsl:73-80: literal distance (kLiteralArgmin), the sentinel first
+            const float start = kLiteralArgmin ? cie94_c(pt.L, pt.a, pt.b, pt.C, 10000.0f, 10000.0f, 10000.0f, sentinel_C)
+                                               : cie94_key(pt, 10000.0f, 10000.0f, 10000.0f, sentinel_C);
             float best = start, bestp = start;
             uint32_t idx = k, idxp = k;
             for (uint32_t j = 0; j < k; ++j) {
                 const Centroid ce = cent[j];
-                const float d = cie94_key(pt, ce.L, ce.a, ce.b, ce.C);
+                const float d = kLiteralArgmin ? cie94_c(pt.L, pt.a, pt.b, pt.C, ce.L, ce.a, ce.b, ce.C)
+                                               : cie94_key(pt, ce.L, ce.a, ce.b, ce.C);
                 if (d < best) { best = d; idx = j; }
                 const unsigned long long m = masks[((uint64_t)cell * 16u + bi) * words + j / 64u];
                 if (((m >> (j & 63u)) & 1ull) && d < bestp) { bestp = d; idxp = j; }

@@ -39,7 +39,7 @@ void orc_srgb_lut(float lut100[256])
 
 /* rgb_to_lab.wgsl:45,50,55: pow(t, 1.0/3.0).  Fixed as the correctly rounded f32 cube
  * root (double cbrt rounded once; exhaustively equal to the x87 long-double result on
- * [1e-3, 2], tests/test_oracle_units.py).                                              */
+ * [1e-3, 2], tests/native/check_math.cpp via tests/test_host_math.py).                                              */
 float orc_cbrt(float x) { return (float)cbrt((double)x); }
 
 static inline float lab_f(float t)
@@ -112,10 +112,15 @@ float orc_cie94(const float one[3], const float second[3])
     return sqrtf(tL * tL + tC * tC + tH * tH);
 }
 
-/* Arg-min key: the same quantity squared, with the per-`one` factors hoisted:
- *   key = dL^2 + dC^2 * (1/SC)^2 + max(da^2 + db^2 - dC^2, 0) * (1/SH)^2
- * Monotone in the literal distance up to rounding; tests assert label equality with the
- * literal form on every fixture.                                         */
+/* The arg-min of the reference is over the LITERAL distance above (find_centroid.wgsl:32-41,
+ * mix_colors.wgsl:73-80).  lit_terms() is that distance with what depends on `one` only (C1, SC, SH)
+ * and C2 hoisted out of the centroid loop: the same operations on the same operands, hence the same
+ * float as orc_cie94() -- orc_assign(literal = 1) runs the un-hoisted form and the tests compare.
+ *
+ * key_terms() is the squared form the GPU kernels ORDER by before they settle near-ties with the
+ * literal distance:  key = dL^2 + dC^2 * (1/SC)^2 + max(da^2 + db^2 - dC^2, 0) * (1/SH)^2.
+ * It is kept here (orc_assign(literal = 2), orc_cie94_key) only so that tests can show where ordering
+ * by the key alone would differ from the reference.                                             */
 typedef struct { float L, a, b, C, wC, wH; } orc_px;
 
 static inline orc_px px_terms(const float lab[3])
@@ -129,6 +134,17 @@ static inline orc_px px_terms(const float lab[3])
     p.wC = iSC * iSC;
     p.wH = iSH * iSH;
     return p;
+}
+
+static inline float lit_terms(const orc_px *p, float L2, float a2, float b2, float C2)
+{
+    /* delta_e.wgsl:4-21 with C1 = p->C and C2 supplied */
+    float dL = p->L - L2, da = p->a - a2, db = p->b - b2, dC = p->C - C2;
+    float dH = sqrtf(fmaxf((da * da) + (db * db) - (dC * dC), 0.0f));
+    float SC = 1.0f + 0.045f * p->C;
+    float SH = 1.0f + 0.015f * p->C;
+    float tL = dL / 1.0f, tC = dC / SC, tH = dH / SH;
+    return sqrtf(tL * tL + tC * tC + tH * tH);
 }
 
 static inline float key_terms(const orc_px *p, float L2, float a2, float b2, float C2)
@@ -150,10 +166,21 @@ float orc_cie94_key(const float one[3], const float second[3])
 /* S2  assign                core/shaders/find_centroid.wgsl:15-44                       */
 /* ------------------------------------------------------------------------------------ */
 
+static inline uint32_t argmin_lit(const orc_px *p, const float *cent5, uint32_t k)
+{
+    /* find_centroid.wgsl:29-41: min_distance = 100000.0, found_index = 0, strict '<' */
+    float best = 100000.0f;
+    uint32_t idx = 0;
+    for (uint32_t j = 0; j < k; ++j) {
+        float d = lit_terms(p, cent5[5 * j], cent5[5 * j + 1], cent5[5 * j + 2], cent5[5 * j + 3]);
+        if (d < best) { best = d; idx = j; }
+    }
+    return idx;
+}
+
 static inline uint32_t argmin_key(const orc_px *p, const float *cent5, uint32_t k)
 {
-    /* find_centroid.wgsl:29-41: min_distance = 100000.0, found_index = 0, strict '<'.
-     * The key is a squared distance, so the sentinel is squared as well (1e10).         */
+    /* ordering by the squared key alone (NOT the reference's definition; see above) */
     float best = 100000.0f * 100000.0f;
     uint32_t idx = 0;
     for (uint32_t j = 0; j < k; ++j) {
@@ -179,7 +206,7 @@ static float *make_cent5(const float *centroids4, uint32_t k)
 void orc_assign(const float *lab3, uint64_t n, const float *centroids4, uint32_t k,
                 int literal, uint32_t *labels)
 {
-    if (literal) {
+    if (literal == 1) {
 #pragma omp parallel for schedule(static)
         for (int64_t i = 0; i < (int64_t)n; ++i) {
             float best = 100000.0f;
@@ -196,7 +223,7 @@ void orc_assign(const float *lab3, uint64_t n, const float *centroids4, uint32_t
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < (int64_t)n; ++i) {
         orc_px p = px_terms(lab3 + 3 * i);
-        labels[i] = argmin_key(&p, c5, k);
+        labels[i] = literal == 2 ? argmin_key(&p, c5, k) : argmin_lit(&p, c5, k);
     }
     free(c5);
 }
@@ -441,10 +468,10 @@ void orc_dither(const float *lab3, uint32_t w, uint32_t h, const float *centroid
             float adj[3] = {lab3[3 * i] + off, lab3[3 * i + 1] + off, lab3[3 * i + 2] + off};
             orc_px p = px_terms(adj);
             /* :73-80 running minimum starting from the distance to the sentinel */
-            float best = key_terms(&p, sentinel[0], sentinel[1], sentinel[2], sC);
+            float best = lit_terms(&p, sentinel[0], sentinel[1], sentinel[2], sC);
             uint32_t idx = k;
             for (uint32_t j = 0; j < k; ++j) {
-                float d = key_terms(&p, c5[5 * j], c5[5 * j + 1], c5[5 * j + 2], c5[5 * j + 3]);
+                float d = lit_terms(&p, c5[5 * j], c5[5 * j + 1], c5[5 * j + 2], c5[5 * j + 3]);
                 if (d < best) { best = d; idx = j; }
             }
             out_index[i] = idx;
@@ -842,7 +869,7 @@ void orc_assign_accumulate_rgba(const uint8_t *rgba, uint64_t n, const float *ce
             float lab[3];
             pixel_to_lab(lut, rgba + 4 * i, lab);
             orc_px p = px_terms(lab);
-            uint32_t c = argmin_key(&p, c5, k);
+            uint32_t c = argmin_lit(&p, c5, k);
             labels[i] = c;
             loc[4 * c + 0] += fix(lab[0]);
             loc[4 * c + 1] += fix(lab[1]);

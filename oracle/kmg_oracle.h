@@ -27,8 +27,11 @@
  *   - pow(t, 1/3): correctly rounded f32 cube root
  *   - per-cluster sums: exact integers of round-to-nearest-even(Lab * 2^20) per pixel
  *     (order independent, hence identical for any tiling / GPU count)
- *   - arg-min key: the squared CIE94 form (no sqrt / no divide per pair); the literal
- *     form is kept too and tests assert both give the same labels on every fixture.
+ *   - arg-min: over the LITERAL distance_cie94 with strict '<' (first minimum wins), exactly as
+ *     find_centroid.wgsl:32-41 and mix_colors.wgsl:73-80 do.  (The squared, divide-free key the GPU
+ *     kernels order by before settling near-ties with the literal distance is kept as
+ *     orc_assign(literal = 2) / orc_cie94_key for tests; ordered by it alone, about one colour
+ *     in 10^7 per 64 centroids would get another label -- tests/test_oracle_golden.py.)
  */
 #ifndef KMG_ORACLE_H
 #define KMG_ORACLE_H
@@ -56,7 +59,9 @@ float orc_cie94_key(const float one[3], const float second[3]);      /* squared 
 
 /* ---- S2: assign (core/shaders/find_centroid.wgsl:15-44) ----
  * centroids: k x 4 floats (L,a,b,pad) like the reference's vec4 array
- * (core/src/structures.rs:501-521).  literal != 0 uses orc_cie94, else the key. */
+ * (core/src/structures.rs:501-521).  literal: 0 = the literal distance with the per-pixel / per-centroid
+ * terms hoisted (same floats, fast), 1 = orc_cie94 per pair (the un-hoisted restatement), 2 = ordered
+ * by the squared key alone (NOT the reference's arg-min; for tests). */
 void orc_assign(const float *lab3, uint64_t n, const float *centroids4, uint32_t k,
                 int literal, uint32_t *labels);
 

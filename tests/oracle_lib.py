@@ -125,6 +125,7 @@ def centroids4(lab):
 
 
 def assign(lab3, cent4, literal=False):
+    """literal: False / 0 = literal distance, hoisted terms (fast); True / 1 = orc_cie94 per pair; 2 = squared key only"""
     lab3 = _f32(lab3).reshape(-1, 3); cent4 = centroids4(cent4)
     out = np.empty(lab3.shape[0], np.uint32)
     lib().orc_assign(_p(lab3, C.c_float), lab3.shape[0], _p(cent4, C.c_float), cent4.shape[0],

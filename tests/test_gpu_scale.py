@@ -90,6 +90,88 @@ def test_cfg3_labels_equal_the_literal_cie94_argmin_on_every_pixel(torch_cuda, o
     p.close()
 
 
+def _colour_cube():
+    idx = np.arange(1 << 24, dtype=np.uint32)
+    cube = np.empty((1 << 24, 4), np.uint8)
+    cube[:, 0] = idx & 255; cube[:, 1] = (idx >> 8) & 255; cube[:, 2] = (idx >> 16) & 255; cube[:, 3] = 255
+    return cube
+
+
+def _tie_prone_centroids(oracle):
+    """centroid tables on which ordering by the squared key alone is KNOWN to differ from the literal arg-min
+    for some colours (tests/test_oracle_golden.py): the near-tie repair branch of every kernel is taken"""
+    rng = np.random.default_rng(5)
+    grey = np.repeat(np.arange(0, 256, 4, dtype=np.uint8)[:, None], 4, 1)
+    grey16 = np.repeat(np.arange(0, 256, 16, dtype=np.uint8)[:, None], 4, 1)
+    rnd = rng.integers(0, 256, (300, 4), dtype=np.uint8)
+    lab = oracle.rgb_to_lab(rnd)
+    return {"grey64": oracle.centroids4(oracle.rgb_to_lab(grey)),           # chunked scan, k <= 256 tables
+            "grey16": oracle.centroids4(oracle.rgb_to_lab(grey16)),         # plain scan
+            "random300": oracle.centroids4(lab),                            # u16 labels
+            "duplicates": oracle.centroids4(np.concatenate([lab[:20], lab[:20], lab[7:8]]))}   # exact ties: lowest index
+
+
+@pytest.mark.parametrize("strategy", ["brute", "table"])
+def test_every_colour_gets_the_literal_argmin(torch_cuda, oracle, monkeypatch, strategy):
+    """All 2^24 colours as one image, centroid tables with literal-distance ties and key near-ties: labels and
+    sums of both strategies equal the oracle's literal arg-min (find_centroid.wgsl:32-41) -- including the
+    colours where the key alone would decide differently."""
+    import kmeans_gpu_amd as kg
+    torch = torch_cuda
+    monkeypatch.setenv("KMG_STRATEGY", strategy)
+    st = _stream(torch)
+    cube = _colour_cube()
+    lab = oracle.rgb_to_lab(cube)
+    d = torch.from_numpy(cube).cuda()
+    n = cube.shape[0]
+    p = kg.ImageProcessor(shrink_max_dim=0)
+    flipped = 0
+    for name, cent in _tie_prone_centroids(oracle).items():
+        k = cent.shape[0]
+        want = oracle.assign(lab, cent, literal=1)
+        flipped += int((want != oracle.assign(lab, cent, literal=2)).sum())
+        s = kg.Lloyd(p, k)
+        s.set_centroids(cent, st)
+        assert s.prepare(d.data_ptr(), n, True, st) == ("table" if strategy == "table" else "scan")
+        labels = torch.zeros(n, dtype=torch.int32, device="cuda")
+        acc = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
+        s.assign_accumulate(d.data_ptr(), n, labels.data_ptr(), acc.data_ptr(), st)
+        torch.cuda.synchronize()
+        got = labels.cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, want), f"{name}: {int((got != want).sum())} colours differ from the literal arg-min"
+        assert np.array_equal(acc.cpu().numpy(), oracle.accumulate(lab, want, k)), name
+        if strategy == "table":
+            assert s.debug_check_table(st) == (0, 0, 0), name
+        s.close()
+    assert flipped > 0            # the inputs really contain colours the key alone gets wrong
+    p.close()
+
+
+def test_dither_of_every_colour_takes_the_literal_argmin(torch_cuda, oracle, monkeypatch):
+    """ordered dither (mix_colors.wgsl:50-83) of a 4096x1024 image holding 2^22 colours of the cube, grey palette:
+    the per-pixel scan and the pruned pass both equal the oracle's literal arg-min"""
+    import kmeans_gpu_amd as kg
+    torch = torch_cuda
+    st = _stream(torch)
+    w, h = 4096, 1024
+    img = _colour_cube()[::4].reshape(h, w, 4).copy()
+    pal = np.repeat(np.arange(0, 256, 4, dtype=np.uint8)[:, None], 4, 1); pal[:, 3] = 255
+    cent = kg.palette_to_centroids(pal)
+    want = oracle.find(img, pal, oracle.MODE_DITHER)
+    d = torch.from_numpy(img.reshape(-1, 4)).cuda()
+    for strategy in ("brute", "table"):
+        monkeypatch.setenv("KMG_STRATEGY", strategy)
+        p = kg.ImageProcessor()
+        out = torch.zeros((w * h, 4), dtype=torch.uint8, device="cuda")
+        p.apply(d.data_ptr(), w, h, 0, cent, kg.ReduceMode.Dither, out.data_ptr(), st)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().reshape(h, w, 4)
+        assert np.array_equal(got, want), f"{strategy}: {int((got != want).any(-1).sum())} pixels differ"
+        if strategy == "table":
+            assert p.debug_check_dither_masks(cent, st) == 0
+        p.close()
+
+
 @pytest.mark.parametrize("palette", ["resurrect_64.png", "apollo-1x.png"])
 def test_cfg5_find_dither_1024_rows_and_tail_vs_oracle(torch_cuda, oracle, palette):
     """BASELINE config 5 (find -m dither, fixed palette, 8192x8192): the first 1024 rows, 1028 rows that
