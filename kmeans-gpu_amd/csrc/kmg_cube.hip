@@ -452,7 +452,8 @@ __global__ __launch_bounds__(kBlock) void k_cube_stage(const int64_t *__restrict
 }
 
 // ------------------------------------------------------------------------------------------
-// k_cube_scan.  LDS: [centroids kpad x 16 B][bins repl x (k x 32 + 32) B (SUMS)]
+// k_cube_scan.  LDS: [centroids kpad x 16 B][bins repl x (k x 32 + 32) B (SUMS)][candidates 4 waves x 32 x 16 B]
+//                    [labels 4 waves x 512]
 // flags bits: 9 no sums, 13 no label stores
 // ------------------------------------------------------------------------------------------
 template <typename LabelT, bool SUMS>
@@ -475,6 +476,8 @@ __global__ __launch_bounds__(kBlock) void k_cube_scan(const uint32_t *__restrict
     unsigned long long *bins = reinterpret_cast<unsigned long long *>(smem4 + kpad);
     const uint32_t bin_stride = 4u * k + 4u;                      // u64 per copy (+ 32 B: next copy, other banks)
     const uint32_t n_bins = SUMS ? repl * bin_stride : 0u;
+    float4 *s_cc_all = reinterpret_cast<float4 *>(bins + n_bins);              // [4 waves][kMaxListed]: listed candidates by position
+    LabelT *s_lbl_all = reinterpret_cast<LabelT *>(s_cc_all + (kBlock / 64) * kMaxListed);   // [4 waves][512]: labels of the cell
     for (uint32_t i = threadIdx.x; i < kpad; i += kBlock) {
         float4 v = make_float4(1.0e18f, 0.0f, 0.0f, 0.0f);
         if (i < k) { const Centroid c = cent[i]; v = make_float4(c.L, c.a, c.b, c.C); }
@@ -488,6 +491,8 @@ __global__ __launch_bounds__(kBlock) void k_cube_scan(const uint32_t *__restrict
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / 64) + wv);
     const uint32_t n_waves = gridDim.x * (kBlock / 64);
     unsigned long long *my_bins = bins + (uint64_t)(lane & (repl - 1u)) * bin_stride;
+    float4 *s_cc = s_cc_all + wv * kMaxListed;
+    LabelT *s_lbl = s_lbl_all + wv * kCellColours;
 
     const uint32_t n_work = SUMS ? __builtin_amdgcn_readfirstlane(work[0]) : kCells;
     for (uint32_t wi = wave; wi < n_work; wi += n_waves) {
@@ -531,75 +536,96 @@ __global__ __launch_bounds__(kBlock) void k_cube_scan(const uint32_t *__restrict
             if (SUMS) { X##_c0 = hist[c0_]; X##_c1 = hist[c1_]; }                                                \
         } while (0)
         KMG_REQUEST_COLOURS(A);
-        const float4 my_c = (listed && (lane & (kMaxListed - 1u)) < npop) ? s_cent[my_cand] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // ... and its (L, a, b, C)
-        uint32_t idx[8], label_set = 0u;
-#pragma unroll
-        for (uint32_t q = 0; q < 8u; ++q) idx[q] = 0u;
+        // the listed candidates' (L, a, b, C) by list position, in LDS: one broadcast read per candidate visit
+        if (listed && (lane & (kMaxListed - 1u)) < npop) s_cc[lane & (kMaxListed - 1u)] = s_cent[my_cand];
+        uint32_t label_set = 0u;
+        __builtin_amdgcn_wave_barrier();
+
+        // Measured on gfx950 (tools/issue_rate.hip, cycles per wave-instruction per SIMD): plain VALU 2.6,
+        // v_readlane 8, v_cmp + v_cndmask chains 4.5, SALU 4.35, an IEEE divide ~47.  Hence: no readlane and no
+        // compare / select per visit -- the key carries the candidate's list position in its 5 low mantissa
+        // bits, so arg-min and runner-up are one integer min / med3 (keys are non-negative floats: their bit
+        // patterns order like the values; equal keys order by position = centroid index) -- and hardware
+        // reciprocals for the per-colour weights.  Both only perturb the ORDERING key (kmg_math.h).
         auto scan_pair = [&](const uint32_t s0, const uint32_t s1, const float4 v0, const float4 v1, const uint32_t cnt0,
                              const uint32_t cnt1) {
-            const uint32_t sm = submask_of(s0) | (s1 < 8u ? submask_of(s1) : 0u);
-
-            const PixelTerms pt0 = pixel_terms_c(v0.x, v0.y, v0.z, v0.w), pt1 = pixel_terms_c(v1.x, v1.y, v1.z, v1.w);
-            float best0 = 1.0e10f, second0 = 1.0e10f, best1 = 1.0e10f, second1 = 1.0e10f;   // find_centroid.wgsl:29-30
+            const PixelTerms pt0 = pixel_terms_fast(v0.x, v0.y, v0.z, v0.w), pt1 = pixel_terms_fast(v1.x, v1.y, v1.z, v1.w);
             uint32_t ix0 = 0u, ix1 = 0u;
-            auto visit = [&](uint32_t j, float cL, float ca, float cbb, float cC) {
-                const float d0 = cie94_key(pt0, cL, ca, cbb, cC), d1 = cie94_key(pt1, cL, ca, cbb, cC);
-                const bool lt0 = d0 < best0, lt1 = d1 < best1;
-                if (kLiteralArgmin) {                              // best <= second: the two smallest keys so far
-                    second0 = __builtin_amdgcn_fmed3f(d0, best0, second0);
-                    second1 = __builtin_amdgcn_fmed3f(d1, best1, second1);
+            if (listed) {
+                uint32_t b0 = 0x7F7FFFFFu, r0 = 0x7F7FFFFFu, b1 = 0x7F7FFFFFu, r1 = 0x7F7FFFFFu;   // smallest / runner-up
+                const uint32_t sm = submask_of(s0) | (s1 < 8u ? submask_of(s1) : 0u);
+                for (uint32_t m = sm; m; m &= m - 1u) {
+                    const uint32_t pos = (uint32_t)__builtin_ctz(m);
+                    const float4 c = s_cc[pos];
+                    const uint32_t u0 = (float_to_bits(cie94_key(pt0, c.x, c.y, c.z, c.w)) & ~31u) | pos;
+                    const uint32_t u1 = (float_to_bits(cie94_key(pt1, c.x, c.y, c.z, c.w)) & ~31u) | pos;
+                    r0 = umed3(u0, b0, r0); b0 = min(b0, u0);
+                    r1 = umed3(u1, b1, r1); b1 = min(b1, u1);
                 }
-                best0 = lt0 ? d0 : best0; ix0 = lt0 ? j : ix0;
-                best1 = lt1 ? d1 : best1; ix1 = lt1 ? j : ix1;
-            };
-            auto for_candidates = [&](auto &&f) {
-                if (listed) {
-                    uint32_t m = sm;
-                    while (m) {
-                        const uint32_t pos = (uint32_t)__builtin_ctz(m);
-                        m &= m - 1u;
-                        f(lane_value(my_cand, pos), lane_value(my_c.x, pos), lane_value(my_c.y, pos), lane_value(my_c.z, pos),
-                          lane_value(my_c.w, pos));
-                    }
-                } else {
-                    for (uint32_t w = 0; w < (k + 63u) / 64u; ++w) {
-                        unsigned long long m = uniform_u64(cmask[w]);
-                        while (m) {
-                            const uint32_t j = w * 64u + (uint32_t)__builtin_ctzll(m);
-                            m &= m - 1ull;
-                            const float4 c = s_cent[j];
-                            f(j, c.x, c.y, c.z, c.w);
-                        }
-                    }
-                }
-            };
-            for_candidates(visit);
-            if (kLiteralArgmin) {
+                uint32_t p0 = b0 & 31u, p1 = b1 & 31u;
                 // near-tie repair (kmg_math.h): rare; decided by the literal distance, first minimum wins
-                const float thr0 = tie_threshold(best0), thr1 = tie_threshold(best1);
-                const bool near0 = second0 <= thr0, near1 = second1 <= thr1;
+                const float thr0 = tie_threshold(bits_to_float(b0 & ~31u)), thr1 = tie_threshold(bits_to_float(b1 & ~31u));
+                const bool near0 = bits_to_float(r0 & ~31u) <= thr0, near1 = bits_to_float(r1 & ~31u) <= thr1;
                 if (__ballot(near0 || near1)) {
                     float lb0 = 100000.0f, lb1 = 100000.0f;       // find_centroid.wgsl:29-30
                     uint32_t li0 = 0u, li1 = 0u;
-                    auto revisit = [&](uint32_t j, float cL, float ca, float cbb, float cC) {
-                        if (near0 && cie94_key(pt0, cL, ca, cbb, cC) <= thr0) {
-                            const float d = cie94_c(v0.x, v0.y, v0.z, v0.w, cL, ca, cbb, cC);
-                            if (d < lb0) { lb0 = d; li0 = j; }
+                    for (uint32_t m = sm; m; m &= m - 1u) {
+                        const uint32_t pos = (uint32_t)__builtin_ctz(m);
+                        const float4 c = s_cc[pos];
+                        if (near0 && cie94_key(pt0, c.x, c.y, c.z, c.w) <= thr0) {
+                            const float d = cie94_c(v0.x, v0.y, v0.z, v0.w, c.x, c.y, c.z, c.w);
+                            if (d < lb0) { lb0 = d; li0 = pos; }
                         }
-                        if (near1 && cie94_key(pt1, cL, ca, cbb, cC) <= thr1) {
-                            const float d = cie94_c(v1.x, v1.y, v1.z, v1.w, cL, ca, cbb, cC);
-                            if (d < lb1) { lb1 = d; li1 = j; }
+                        if (near1 && cie94_key(pt1, c.x, c.y, c.z, c.w) <= thr1) {
+                            const float d = cie94_c(v1.x, v1.y, v1.z, v1.w, c.x, c.y, c.z, c.w);
+                            if (d < lb1) { lb1 = d; li1 = pos; }
                         }
-                    };
-                    for_candidates(revisit);
+                    }
+                    p0 = near0 ? li0 : p0;
+                    p1 = near1 ? li1 : p1;
+                }
+                ix0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(p0 << 2), (int)my_cand);
+                ix1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(p1 << 2), (int)my_cand);
+            } else {
+                // more than kMaxListed candidates (a handful of cells): every candidate of the cell, from the masks
+                float best0 = 1.0e10f, second0 = 1.0e10f, best1 = 1.0e10f, second1 = 1.0e10f;
+                for (uint32_t w = 0; w < (k + 63u) / 64u; ++w) {
+                    for (unsigned long long m = uniform_u64(cmask[w]); m; m &= m - 1ull) {
+                        const uint32_t j = w * 64u + (uint32_t)__builtin_ctzll(m);
+                        const float4 c = s_cent[j];
+                        const float d0 = cie94_key(pt0, c.x, c.y, c.z, c.w), d1 = cie94_key(pt1, c.x, c.y, c.z, c.w);
+                        second0 = __builtin_amdgcn_fmed3f(d0, best0, second0);
+                        second1 = __builtin_amdgcn_fmed3f(d1, best1, second1);
+                        if (d0 < best0) { best0 = d0; ix0 = j; }
+                        if (d1 < best1) { best1 = d1; ix1 = j; }
+                    }
+                }
+                const float thr0 = tie_threshold(best0), thr1 = tie_threshold(best1);
+                const bool near0 = second0 <= thr0, near1 = second1 <= thr1;
+                if (__ballot(near0 || near1)) {
+                    float lb0 = 100000.0f, lb1 = 100000.0f;
+                    uint32_t li0 = 0u, li1 = 0u;
+                    for (uint32_t w = 0; w < (k + 63u) / 64u; ++w) {
+                        for (unsigned long long m = uniform_u64(cmask[w]); m; m &= m - 1ull) {
+                            const uint32_t j = w * 64u + (uint32_t)__builtin_ctzll(m);
+                            const float4 c = s_cent[j];
+                            if (near0 && cie94_key(pt0, c.x, c.y, c.z, c.w) <= thr0) {
+                                const float d = cie94_c(v0.x, v0.y, v0.z, v0.w, c.x, c.y, c.z, c.w);
+                                if (d < lb0) { lb0 = d; li0 = j; }
+                            }
+                            if (near1 && cie94_key(pt1, c.x, c.y, c.z, c.w) <= thr1) {
+                                const float d = cie94_c(v1.x, v1.y, v1.z, v1.w, c.x, c.y, c.z, c.w);
+                                if (d < lb1) { lb1 = d; li1 = j; }
+                            }
+                        }
+                    }
                     ix0 = near0 ? li0 : ix0;
                     ix1 = near1 ? li1 : ix1;
                 }
             }
-            // what a scanned sub-cell leaves behind: labels (registers, stored at the end of the cell), sums, summary
+            // what a scanned sub-cell leaves behind: labels (staged in LDS, stored at the end of the cell), sums, summary
             auto finish = [&](uint32_t s, uint32_t ix, uint32_t cnt, float vL, float va, float vb) {
-#pragma unroll
-                for (uint32_t q = 0; q < 8u; ++q) idx[q] = (s == q) ? ix : idx[q];
+                s_lbl[s * 64u + lane] = (LabelT)ix;
                 label_set |= 1u << s;
                 const bool counts = cnt != 0u;
                 // sums: the sub-cell's total (sub-cell table) goes to a reference label R; a colour with another
@@ -643,11 +669,15 @@ __global__ __launch_bounds__(kBlock) void k_cube_scan(const uint32_t *__restrict
             if (A_s0 >= 8u) break;
         }
 #undef KMG_REQUEST_COLOURS
-        if (!(flags & 0x2000u)) {
-#pragma unroll
-            for (uint32_t s = 0; s < 8u; ++s)
-                if ((label_set >> s) & 1u) store_labels64(cell_labels + s * 64u, idx[s], lane);
+        // the labels of the scanned sub-cells: lane l owns the colours 8 l .. 8 l + 7 (sub-cell l >> 3), one store
+        __builtin_amdgcn_wave_barrier();
+        if (!(flags & 0x2000u) && ((label_set >> (lane >> 3)) & 1u)) {
+            if (sizeof(LabelT) == 1)
+                *reinterpret_cast<uint2 *>(cell_labels + lane * 8u) = *reinterpret_cast<const uint2 *>(s_lbl + lane * 8u);
+            else
+                *reinterpret_cast<uint4 *>(cell_labels + lane * 8u) = *reinterpret_cast<const uint4 *>(s_lbl + lane * 8u);
         }
+        __builtin_amdgcn_wave_barrier();
     }
     if (SUMS) flush_bins(bins, k, repl, bin_stride, sums, n_rows);
 }
@@ -719,7 +749,8 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
     if (const char *e = getenv("KMG_CUBE_FLAGS")) flags |= (uint32_t)strtoul(e, nullptr, 0) & 0xFF00u;
     const size_t lds_stage = sizeof(float4) * kpad + (with_sums ? sizeof(unsigned long long) * 4ull * k : 0) +
                              sizeof(uint32_t) * (kBlock / 64) * kMaxListed + sizeof(unsigned long long) * (kBlock / 64) * (kpad / 64u);
-    const size_t lds_scan = sizeof(float4) * kpad + (with_sums ? sizeof(unsigned long long) * (4ull * k + 4ull) * repl : 0);
+    const size_t lds_scan = sizeof(float4) * kpad + (with_sums ? sizeof(unsigned long long) * (4ull * k + 4ull) * repl : 0) +
+                            sizeof(float4) * (kBlock / 64) * kMaxListed + (k <= 256 ? 1u : 2u) * (kBlock / 64) * kCellColours;
     static const uint32_t g_stage = env_grid("KMG_CUBE_GRID", kCubeGrid), g_scan = env_grid("KMG_SCAN_GRID", kCubeGrid),
                           g_pairs = env_grid("KMG_PAIRS_GRID", kCubeGrid);
     CellWork *cw = (CellWork *)cell_work;

@@ -106,6 +106,21 @@ KMG_HD PixelTerms pixel_terms_c(float L, float a, float b, float C)
 
 KMG_HD PixelTerms pixel_terms(float L, float a, float b) { return pixel_terms_c(L, a, b, chroma(a, b)); }
 
+#if defined(__HIPCC__)
+// The same terms with hardware reciprocals (1 ulp) instead of two IEEE divides (~47 issue cycles each on
+// gfx950): the weights move by a few u, far inside the tie slack -- for kernels that ORDER by the key and
+// settle near-ties with the literal distance ("near-tie repair" below).  Never for values that are used.
+__device__ __forceinline__ PixelTerms pixel_terms_fast(float L, float a, float b, float C)
+{
+    PixelTerms p;
+    p.L = L; p.a = a; p.b = b; p.C = C;
+    const float iSC = __builtin_amdgcn_rcpf(fmaf(0.045f, C, 1.0f)), iSH = __builtin_amdgcn_rcpf(fmaf(0.015f, C, 1.0f));
+    p.wC = iSC * iSC;
+    p.wH = iSH * iSH;
+    return p;
+}
+#endif
+
 // Squared CIE94 used only for ordering: dL^2 + dC^2 wC + max(da^2 + db^2 - dC^2, 0) wH.
 KMG_HD float cie94_key(const PixelTerms &p, float L2, float a2, float b2, float C2)
 {
@@ -142,6 +157,9 @@ KMG_HD float cie94_c(float L1, float a1, float b1, float C1, float L2, float a2,
 //   hence |key - T| <= 63u T and |literal^2 - T| <= 66u T, and a centroid j can have
 //   literal_j <= literal_best only if key_j <= key_best (1 + 66u)(1 + 63u) / ((1 - 66u)(1 - 63u))
 //   < key_best (1 + 260u) = key_best (1 + 1.6e-5).
+// Kernels that also (a) take the weights from hardware reciprocals (pixel_terms_fast: +6u on two terms) and
+// (b) keep a 5-bit candidate position in the low mantissa bits of the key so that arg-min and runner-up are one
+// integer min / med3 each (k_cube_scan: the key loses up to 2^-18 = 64u) stay below key_best (1 + 560u) = 3.4e-5.
 // The kernels use kTieSlack = 2^-13 = 1.2e-4 (8x that): while scanning they keep the second smallest key; a
 // pixel whose second smallest key is <= best (1 + kTieSlack) is re-decided with the literal distance among
 // the centroids whose key is within that threshold, in index order with strict '<' -- exactly the

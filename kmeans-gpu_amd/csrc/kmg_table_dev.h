@@ -124,6 +124,14 @@ __device__ __forceinline__ uint32_t wave_add_u32(uint32_t v)
     return lane_value(v, 0) + lane_value(v, 16) + lane_value(v, 32) + lane_value(v, 48);
 }
 
+// median of three unsigned values (one v_med3_u32; clang has a builtin for the float form only)
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // number of set bits of m below this lane's bit
 __device__ __forceinline__ uint32_t bits_below_lane(unsigned long long m)
 {
