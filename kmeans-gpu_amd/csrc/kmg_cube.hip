@@ -125,10 +125,11 @@ __device__ __forceinline__ uint32_t cell_pair_entry(const uint32_t idx[8], uint3
     packed = __builtin_elementwise_min(packed, __builtin_bit_cast(u16x2, dpp_u32<kDppXor2>(__builtin_bit_cast(uint32_t, packed))));
     packed = __builtin_elementwise_min(packed, __builtin_bit_cast(u16x2, dpp_u32<kDppHalfMirror>(__builtin_bit_cast(uint32_t, packed))));
     packed = __builtin_elementwise_min(packed, __builtin_bit_cast(u16x2, dpp_u32<kDppMirror>(__builtin_bit_cast(uint32_t, packed))));
-    const uint32_t pk = __builtin_bit_cast(uint32_t, packed);
-    const uint32_t r0 = lane_value(pk, 0), r1 = lane_value(pk, 16), r2 = lane_value(pk, 32), r3 = lane_value(pk, 48);
-    const int tlo = (int)min(min(r0 & 0xFFFFu, r1 & 0xFFFFu), min(r2 & 0xFFFFu, r3 & 0xFFFFu));
-    const int thi = 63 - (int)min(min(r0 >> 16, r1 >> 16), min(r2 >> 16, r3 >> 16));
+    packed = __builtin_elementwise_min(packed, __builtin_bit_cast(u16x2, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)__builtin_bit_cast(uint32_t, packed), 0x142, 0xA, 0xF, false)));
+    packed = __builtin_elementwise_min(packed, __builtin_bit_cast(u16x2, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)__builtin_bit_cast(uint32_t, packed), 0x143, 0xC, 0xF, false)));
+    const uint32_t pk = lane_value(__builtin_bit_cast(uint32_t, packed), 63);
+    const int tlo = (int)(pk & 0xFFFFu);
+    const int thi = 63 - (int)(pk >> 16);
     const int w = thi + 1 > tlo ? thi + 1 - tlo : 0;
     const uint32_t code = pair_dir_code(nx, ny, nz);
     if (w <= 6) return pair_entry(labA, labB, code, (uint32_t)tlo, (uint32_t)w);
@@ -243,30 +244,29 @@ __global__ __launch_bounds__(kBlock) void k_cube_stage(const int64_t *__restrict
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / 64) + wv);
     const uint32_t n_waves = gridDim.x * (kBlock / 64);
     const uint32_t sub_of_lane = lane >> 3, cand_of_lane = lane & 7u;
-    const float *bf = reinterpret_cast<const float *>(bounds);
     unsigned long long st_single = 0, st_multi = 0, st_decided = 0, st_scanned = 0, st_cands = 0, st_unlisted = 0;
 
     const uint32_t n_work = SUMS ? __builtin_amdgcn_readfirstlane(work[0]) : kCells;
     // the small per-cell data of the NEXT cell are requested while the current one is worked on
     uint32_t cell_n = 0;
-    float bv_n = 0.0f;
-    long long sagg_n = 0, cagg_n = 0;
+    CellBounds cb_n;                                               // uniform address: scalar loads, no cross-lane traffic
+    long long sagg_n = 0, cagg_n = 0, scnt_n = 1;
 #define KMG_REQUEST_CELL(wi_)                                                                                    \
     do {                                                                                                         \
-        if ((wi_) < n_work) {                                                                                    \
-            cell_n = SUMS ? __builtin_amdgcn_readfirstlane(work[1u + (wi_)]) : (wi_);                            \
-            bv_n = bf[(uint64_t)cell_n * 16u + (lane & 15u)];                                                    \
-            if (SUMS) {                                                                                          \
-                sagg_n = sub_agg[(uint64_t)cell_n * 32u + (lane & 31u)];    /* lane 4 s + j: sum j of sub-cell s */ \
-                cagg_n = agg[4ull * cell_n + (lane & 3u)];                                                       \
-            }                                                                                                    \
+        const uint32_t w_ = (wi_) < n_work ? (wi_) : wave;          /* past the end: a harmless repeat */        \
+        cell_n = SUMS ? __builtin_amdgcn_readfirstlane(work[1u + w_]) : w_;                                      \
+        cb_n = bounds[cell_n];                                                                                   \
+        if (SUMS) {                                                                                              \
+            sagg_n = sub_agg[(uint64_t)cell_n * 32u + (lane & 31u)];        /* lane 4 s + j: sum j of sub-cell s */ \
+            scnt_n = sub_agg[(uint64_t)cell_n * 32u + 4u * (lane & 7u) + 3u];   /* lane s < 8: pixels in sub-cell s */ \
+            cagg_n = agg[4ull * cell_n + (lane & 3u)];                                                           \
         }                                                                                                        \
     } while (0)
     KMG_REQUEST_CELL(wave);
     for (uint32_t wi = wave; wi < n_work; wi += n_waves) {
         const uint32_t cell = cell_n;
-        const float bv = bv_n;
-        const long long sagg = sagg_n, cagg = cagg_n;
+        const CellBounds cb = cb_n;
+        const long long sagg = sagg_n, cagg = cagg_n, scnt = scnt_n;
         KMG_REQUEST_CELL(wi + n_waves);
         // the sub-cell bounds of THIS cell: requested now, needed after the cell's candidates are known
         const float4 *sbp = reinterpret_cast<const float4 *>(sub_bounds + (uint64_t)cell * 8u + sub_of_lane);
@@ -279,10 +279,6 @@ __global__ __launch_bounds__(kBlock) void k_cube_stage(const int64_t *__restrict
         CellWork *cw = cell_work + cell;
 
         // ---- 1. candidates of the cell ----
-        CellBounds cb;
-        cb.L0 = lane_value(bv, 0); cb.L1 = lane_value(bv, 1); cb.a0 = lane_value(bv, 2); cb.a1 = lane_value(bv, 3);
-        cb.b0 = lane_value(bv, 4); cb.b1 = lane_value(bv, 5); cb.C0 = lane_value(bv, 6); cb.C1 = lane_value(bv, 7);
-        cb.wC0 = lane_value(bv, 8); cb.wC1 = lane_value(bv, 9); cb.wH0 = lane_value(bv, 10); cb.wH1 = lane_value(bv, 11);
         unsigned long long mw[4] = {0ull, 0ull, 0ull, 0ull};      // the mask itself when words <= 4 (k <= 256)
         uint32_t npop = 0, first = 0;
         if (words <= 4u) {
@@ -407,39 +403,50 @@ __global__ __launch_bounds__(kBlock) void k_cube_stage(const int64_t *__restrict
             st_unlisted += 1;
         }
 
-        // what each sub-cell needs: empty / decided as a whole (one candidate) / scan its colours
-        uint32_t scan_set = 0u;
-        uint32_t cell_state = kSubEmpty;
+        // what each sub-cell needs -- empty / decided as a whole (one candidate) / scan its colours -- for all
+        // eight at once: lane s < 8 is sub-cell s (a scalar loop over the sub-cells costs ~10x the issue slots)
+        uint32_t sm_v = 0u;                                         // lane s: candidates (list positions) sub-cell s keeps
+        if (lane < 8u) {
 #pragma unroll
-        for (uint32_t s = 0; s < 8u; ++s) {
-            const bool occupied = SUMS ? (lane_value64(sagg, 4u * s + 3u) != 0) : true;
-            if (!occupied) {
-                if (sizeof(LabelT) != 1 && lane == 0u) sub[s] = kSubEmpty;
-                continue;
-            }
-            uint32_t sm = 0u;
-#pragma unroll
-            for (uint32_t r = 0; r < 4u; ++r) sm |= ((uint32_t)(br[r] >> (8u * s)) & 0xFFu) << (8u * r);
-            if (listed && __builtin_popcount(sm) == 1) {
-                const uint32_t X = lane_value(my_cand, (uint32_t)__builtin_ctz(sm));
-                store_labels64(cell_labels + s * 64u, X, lane);
-                if (SUMS && !(flags & 0x200u) && (lane >> 2) == s) atomicAdd(bins + 4ull * X + (lane & 3u), (unsigned long long)sagg);
-                if (sizeof(LabelT) != 1) {
-                    if (lane == 0u) sub[s] = (uint16_t)X;
-                    cell_state = merge_state(cell_state, X);
+            for (uint32_t r = 0; r < 4u; ++r) sm_v |= ((uint32_t)(br[r] >> (8u * lane)) & 0xFFu) << (8u * r);
+        }
+        const bool occupied_v = lane < 8u && (SUMS ? scnt != 0 : true);
+        const bool decided_v = occupied_v && listed && __builtin_popcount(sm_v) == 1;
+        const uint32_t decided_set = (uint32_t)__ballot(decided_v);
+        const uint32_t scan_set = (flags & 0x400u) ? 0u : (uint32_t)__ballot(occupied_v && !decided_v);
+        // label of a decided sub-cell, at lane s
+        const uint32_t X_v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((sm_v ? (uint32_t)__builtin_ctz(sm_v) : 0u)) << 2), (int)my_cand);
+        {
+            // its 64 labels: lane l owns the colours 8 l .. 8 l + 7 of the cell (sub-cell l >> 3), one store
+            const uint32_t X = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane >> 3) << 2), (int)X_v);
+            if ((decided_set >> (lane >> 3)) & 1u) {
+                if (sizeof(LabelT) == 1) {
+                    const uint32_t x4 = X * 0x01010101u;
+                    *reinterpret_cast<uint2 *>(cell_labels + lane * 8u) = make_uint2(x4, x4);
+                } else {
+                    const uint32_t x2 = X * 0x00010001u;
+                    *reinterpret_cast<uint4 *>(cell_labels + lane * 8u) = make_uint4(x2, x2, x2, x2);
                 }
-                st_decided += 1;
-            } else if (!(flags & 0x400u)) {
-                scan_set |= 1u << s;
-                st_scanned += 1;
-                st_cands += listed ? (uint32_t)__builtin_popcount(sm) : npop;
             }
+            // its sums: lane 4 s + j holds sum j of sub-cell s
+            const uint32_t Xs = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane >> 2) & 7u) << 2), (int)X_v);
+            if (SUMS && !(flags & 0x200u) && lane < 32u && ((decided_set >> (lane >> 2)) & 1u))
+                atomicAdd(bins + 4ull * Xs + (lane & 3u), (unsigned long long)sagg);
+        }
+        if (sizeof(LabelT) != 1) {
+            // summaries: decided -> the label, empty -> kSubEmpty; scanned ones are written by k_cube_scan
+            if (lane < 8u && !((scan_set >> lane) & 1u)) sub[lane] = (uint16_t)(decided_v ? X_v : (uint32_t)kSubEmpty);
+        }
+        st_decided += (uint32_t)__builtin_popcount(decided_set);
+        st_scanned += (uint32_t)__builtin_popcount(scan_set);
+        if (stats) {
+            const uint32_t c = (scan_set >> (lane & 7u)) & 1u ? (listed ? (uint32_t)__builtin_popcount(sm_v) : npop) : 0u;
+            st_cands += wave_add_u32(lane < 8u ? c : 0u);
         }
         if (lane == 0u) {
             cw->npop = npop;
             cw->scan_set = scan_set | (listed ? 0x100u : 0u);
             if (sizeof(LabelT) == 1) *pair_entry_ptr = kPairPending;
-            else *cell_entry = (uint16_t)cell_state;               // k_cube_pairs merges the scanned sub-cells in
         }
     }
 #undef KMG_REQUEST_CELL
@@ -751,7 +758,8 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
                              sizeof(uint32_t) * (kBlock / 64) * kMaxListed + sizeof(unsigned long long) * (kBlock / 64) * (kpad / 64u);
     const size_t lds_scan = sizeof(float4) * kpad + (with_sums ? sizeof(unsigned long long) * (4ull * k + 4ull) * repl : 0) +
                             sizeof(float4) * (kBlock / 64) * kMaxListed + (k <= 256 ? 1u : 2u) * (kBlock / 64) * kCellColours;
-    static const uint32_t g_stage = env_grid("KMG_CUBE_GRID", kCubeGrid), g_scan = env_grid("KMG_SCAN_GRID", kCubeGrid),
+    // (the scan kernel's cells differ a lot in cost: finer hand-out, 2 cells per wave, measured 83 -> 75 us)
+    static const uint32_t g_stage = env_grid("KMG_CUBE_GRID", kCubeGrid), g_scan = env_grid("KMG_SCAN_GRID", 2u * kCubeGrid),
                           g_pairs = env_grid("KMG_PAIRS_GRID", kCubeGrid);
     CellWork *cw = (CellWork *)cell_work;
     if (!n_rows) n_rows = 1u;

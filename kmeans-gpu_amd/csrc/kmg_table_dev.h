@@ -103,8 +103,11 @@ __device__ __forceinline__ float group8_min(float v)
 __device__ __forceinline__ float wave_min(float v)
 {
     v = group8_min(v);
-    v = fminf(v, dpp_f32<kDppMirror>(v));
-    return fminf(fminf(lane_value(v, 0), lane_value(v, 16)), fminf(lane_value(v, 32), lane_value(v, 48)));
+    v = fminf(v, dpp_f32<kDppMirror>(v));                        // every lane: the minimum of its row of 16
+    const float big = 3.0e38f;
+    v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, big), __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false)));
+    v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, big), __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false)));
+    return lane_value(v, 63);
 }
 
 template <int CTRL>
@@ -120,8 +123,12 @@ __device__ __forceinline__ uint32_t wave_add_u32(uint32_t v)
     v += dpp_u32<kDppXor1>(v);
     v += dpp_u32<kDppXor2>(v);
     v += dpp_u32<kDppHalfMirror>(v);
-    v += dpp_u32<kDppMirror>(v);
-    return lane_value(v, 0) + lane_value(v, 16) + lane_value(v, 32) + lane_value(v, 48);
+    v += dpp_u32<kDppMirror>(v);                                 // every lane: the sum of its row of 16
+    // rows 1 and 3 take in rows 0 and 2 (row_bcast:15), then rows 2 and 3 the sum of rows 0 + 1 (row_bcast:31):
+    // lane 63 holds the total -- one v_readlane (8 issue cycles on gfx950) instead of four
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
+    return lane_value(v, 63);
 }
 
 // median of three unsigned values (one v_med3_u32; clang has a builtin for the float form only)
