@@ -8,8 +8,9 @@ like the reference's find_centroid dispatch) and the per-cluster sums of the new
 for N > 1 the RCCL all-reduce of the k x 4 int64 accumulators.
 
 N = 1: synthetic 8192x8192 RGBA (splitmix64 seed 0x5EED0003), k = 256.
-N > 1: weak scaling -- the image is 8192 x (8192*N), row-sharded so every rank owns one 8192x8192
-band; the iteration is still ONE k-means problem (one all-reduce per iteration).
+N > 1, --scaling weak (default): the image is 8192 x (8192*N), row-sharded so every rank owns one
+       8192x8192 band; the iteration is still ONE k-means problem (one all-reduce per iteration).
+N > 1, --scaling strong: the ONE 8192x8192 image is split into N row bands of 8192/N rows.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
@@ -30,6 +31,9 @@ ROWS_PER_GPU = 8192
 K = 256
 ALGORITHMIC_BYTES_PER_PIXEL = 8          # 4 B RGBA8 read + 4 B u32 label write
 HBM_PEAK_GBPS = 8000.0                   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+HBM_ACHIEVABLE_GBPS = 6290.0             # same guide: 6.29 TB/s measured with a float4 copy
+FP32_VECTOR_PEAK_TFLOPS = 157.3          # same guide: peak FP32 (vector)
+FLOP_PER_PAIR, FLOP_PER_PIXEL = 17, 50   # SURVEY.md 8d "algorithmic flops": literal CIE94 per (pixel, centroid) + Lab conversion
 
 
 def algorithmic_bytes(kernel, n_pixels, k):
@@ -39,6 +43,78 @@ def algorithmic_bytes(kernel, n_pixels, k):
     if kernel == "k_cube":
         return (1 << 24) * (4 + (1 if k <= 256 else 2))      # colour counts in, colour labels out
     return None
+
+
+def synthetic_image(kind, n_pixels, first, k, seed):
+    """uint8 (n, 4) tensor on the GPU: `uniform` (headline), `blobs` (k Gaussian clusters, sigma 12),
+    `photo` (the 768x513 fixture tiled to the width with a slow gradient so that tiles differ)"""
+    import numpy as np
+    import torch
+    from kmeans_gpu_amd import synth
+    if kind == "uniform":
+        return synth.uniform_rgba_torch(seed, n_pixels, first=first, device="cuda")
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed & 0x7FFFFFFF)
+    if kind == "blobs":
+        centres = torch.randint(0, 256, (k, 3), generator=g, device="cuda", dtype=torch.int32)
+        out = torch.empty((n_pixels, 4), dtype=torch.uint8, device="cuda")
+        for c0 in range(0, n_pixels, 1 << 24):
+            m = min(1 << 24, n_pixels - c0)
+            which = torch.randint(0, k, (m,), generator=g, device="cuda")
+            px = centres[which].to(torch.float32) + 12.0 * torch.randn((m, 3), generator=g, device="cuda")
+            out[c0:c0 + m, :3] = px.round().clamp_(0, 255).to(torch.uint8)
+            out[c0:c0 + m, 3] = 255
+        return out
+    from PIL import Image
+    tokyo = np.array(Image.open(os.path.join(ROOT, "tests", "golden", "tokyo.png")).convert("RGBA"))
+    rows = n_pixels // WIDTH
+    big = np.tile(tokyo, (rows // tokyo.shape[0] + 1, WIDTH // tokyo.shape[1] + 1, 1))[:rows, :WIDTH].copy()
+    yy, xx = np.mgrid[0:rows, 0:WIDTH]
+    big[..., 0] = np.clip(big[..., 0].astype(int) + (xx >> 9), 0, 255).astype(np.uint8)
+    big[..., 1] = np.clip(big[..., 1].astype(int) + (yy >> 9), 0, 255).astype(np.uint8)
+    return torch.from_numpy(big.reshape(-1, 4)).cuda()
+
+
+def other_distributions(proc, k, n_pixels, stream, steps=10):
+    """SURVEY 8d secondary inputs, not part of `value`: the same iteration on `blobs` and on a tiled
+    photograph, with the share of the pixels the label pass resolves from its LDS table alone."""
+    import numpy as np
+    import torch
+    import kmeans_gpu_amd as kg
+    from kmeans_gpu_amd.sharded import ShardedLloyd
+    extra = {}
+    for kind in ("blobs", "photo"):
+        rgba = synthetic_image(kind, n_pixels, 0, k, 0x5EED0B10)
+        labels = torch.empty(n_pixels, dtype=torch.int32, device="cuda")
+        sel = rgba[(torch.arange(k, device="cuda") * (n_pixels // k))].contiguous()
+        lab = torch.empty((k, 3), dtype=torch.float32, device="cuda")
+        proc.rgb_to_lab(sel.data_ptr(), k, lab.data_ptr(), stream)
+        torch.cuda.synchronize()
+        cent = np.ones((k, 4), np.float32)
+        cent[:, :3] = lab.cpu().numpy()
+        s = kg.Lloyd(proc, k)
+        s.set_centroids(cent, stream)
+        strategy = s.prepare(rgba.data_ptr(), n_pixels, True, stream)
+        sh = ShardedLloyd(s, k, rgba, labels, stream=stream)
+        sh.split_labels = strategy == "table"
+        sh.pipeline = False
+        sh.prime()
+        for _ in range(3):
+            sh.iterate()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(steps):
+            sh.iterate()
+        sh.flush()
+        torch.cuda.synchronize()
+        extra[f"{kind}_ms_per_step"] = (time.perf_counter() - t) / steps * 1e3
+        extra[f"{kind}_strategy"] = strategy
+        if strategy == "table" and k <= 256:
+            _, resolved, total = s.debug_check_pairs(stream)
+            extra[f"{kind}_pixels_resolved_in_lds"] = resolved / max(total, 1)
+        s.close()
+        del rgba, labels
+    return extra
 
 
 def output_pass_timing(proc, rgba, n_pixels, stream, sh=None):
@@ -66,6 +142,10 @@ def output_pass_timing(proc, rgba, n_pixels, stream, sh=None):
             extra[f"{name}_k{len(pal)}_ms"] = ms
             extra[f"{name}_k{len(pal)}_hbm_frac"] = ALGORITHMIC_BYTES_PER_PIXEL * n_pixels / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
         if sh is not None:
+            if sh.split_labels and k_of(sh) <= 256:
+                _, resolved, total = sh.backend.debug_check_pairs(stream)
+                extra["uniform_pixels_resolved_in_lds"] = resolved / max(total, 1)
+
             # what kmg_lloyd_run executes per iteration: sums only, the label map is written once at the end
             def sums_only(iters):
                 for _ in range(iters):
@@ -97,9 +177,15 @@ def output_pass_timing(proc, rgba, n_pixels, stream, sh=None):
         extra["cfg3_dither_ms"], _ = stage(lambda: proc.apply(rgba.data_ptr(), WIDTH, n_pixels // WIDTH, 0, cent3,
                                                               kg.ReduceMode.Dither, out.data_ptr(), stream))
         s3.close()
+        del labels, out
+        extra.update(other_distributions(proc, k3, n_pixels, stream))
     except Exception as e:      # the extras must never break the benchmark line
         extra["error"] = repr(e)
     return extra
+
+
+def k_of(sh):
+    return int(sh.k)
 
 
 def cpu_baseline(k, centroids4, seed, target_seconds=12.0):
@@ -124,7 +210,7 @@ def cpu_baseline(k, centroids4, seed, target_seconds=12.0):
     dt = time.perf_counter() - t
     return {"value": n / dt, "unit": "pixels/s", "cores": O.num_threads(), "kind": "port",
             "sample": f"first {n} pixels ({n // WIDTH} rows of {WIDTH}) of the same image, k={k}, "
-                      f"one assign+accumulate pass (per-pixel scan), {dt:.2f} s"}
+                      f"one assign+accumulate pass (per-pixel scan, literal CIE94 arg-min), {dt:.2f} s"}
 
 
 def main():
@@ -133,12 +219,16 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--k", type=int, default=K)
-    ap.add_argument("--rows", type=int, default=ROWS_PER_GPU, help="rows per GPU (default 8192)")
+    ap.add_argument("--rows", type=int, default=None, help="rows per GPU (default 8192; --scaling strong: 8192 / gpus)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: one 8192-row band per GPU; strong: ONE 8192x8192 image split into row bands")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the untimed extra measurements (use under rocprofv3 to keep kernel averages clean)")
-    ap.add_argument("--no-overlap", action="store_true",
-                    help="run the label pass of an iteration before the next iteration's cube pass instead of beside it")
+    ap.add_argument("--overlap", action="store_true",
+                    help="run the label pass of an iteration beside the next iteration's cube pass (kmg_lloyd_iterate) "
+                         "instead of before it")
+    ap.add_argument("--no-overlap", action="store_true", help="(the default) kept for scripts")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the all-reduce even with one rank (sanity check)")
     ap.add_argument("--strategy", choices=["auto", "scan", "table"], default="auto",
@@ -171,7 +261,13 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     k = args.k
-    n_local = WIDTH * args.rows
+    if args.rows is not None:
+        rows = args.rows
+    elif args.scaling == "strong":
+        rows = ROWS_PER_GPU // world
+    else:
+        rows = ROWS_PER_GPU
+    n_local = WIDTH * rows
     seed = synth.SEED_CFG3
     if args.strategy != "auto":
         os.environ["KMG_STRATEGY"] = {"scan": "brute", "table": "table"}[args.strategy]
@@ -180,7 +276,8 @@ def main():
     labels = torch.empty(n_local, dtype=torch.int32, device="cuda")
 
     # initial centroids: shader Lab of the pixels at linear index j * floor(N/k) of band 0
-    sel = synth.uniform_rgba_at(seed, np.arange(k, dtype=np.uint64) * np.uint64(n_local // k))
+    n_first = WIDTH * ROWS_PER_GPU if (args.scaling == "strong" and args.rows is None) else n_local
+    sel = synth.uniform_rgba_at(seed, np.arange(k, dtype=np.uint64) * np.uint64(n_first // k))
     d_sel = torch.from_numpy(sel).cuda()
     lab = torch.empty((k, 3), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
@@ -201,7 +298,7 @@ def main():
 
     sh = ShardedLloyd(lloyd, k, rgba, labels, stream=stream)
     sh.split_labels = strategy == "table"     # the all-reduce overlaps the label-gather pass
-    sh.pipeline = not args.no_overlap
+    sh.pipeline = bool(args.overlap) and not args.no_overlap
     if args.force_dist:
         sh.world = 2          # take the collective path even though the group has one rank
     sh.prime()
@@ -209,12 +306,13 @@ def main():
         sh.iterate()
 
     def fence():
+        sh.flush()
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # HIP events around the heavy launches, on the launch stream (the three tiny kernels are left
+    # HIP events around the heavy launches, on the launch stream (the tiny kernels are left
     # untimed: every timed launch costs two event records inside the measured region)
     lloyd.profile(["k_assign", "k_cube", "k_labels"])
     fence()
@@ -232,6 +330,7 @@ def main():
 
     if rank == 0:
         total_pixels = n_local * world
+        height = rows * world
         ms_per_step = elapsed * 1e3 / args.steps
         kernels = {name: {"ms_per_launch": ms / cnt, "launches": cnt} for name, (ms, cnt) in prof.items()}
         dominant = max((nm for nm in prof if algorithmic_bytes(nm, n_local, k) is not None),
@@ -239,33 +338,47 @@ def main():
         k_ms = kernels[dominant]["ms_per_launch"]
         abytes = algorithmic_bytes(dominant, n_local, k)
         achieved = abytes / (k_ms * 1e-3) / 1e9
-        traffic = None
+        step_gbps = ALGORITHMIC_BYTES_PER_PIXEL * total_pixels / (ms_per_step * 1e-3) / 1e9
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and k == K and args.rows == ROWS_PER_GPU:
+        if os.path.exists(tpath) and k == K and rows == ROWS_PER_GPU:
             with open(tpath) as f:
-                traffic = json.load(f).get("bytes_per_launch", {}).get(dominant)
+                tj = json.load(f)
+            traffic = tj.get("bytes_per_launch", {}).get(dominant)
+            traffic_source = tj.get("source", {}).get(dominant, "profiles/traffic.json (rocprofv3 PMC passes, not this run)")
+        flops = total_pixels * (FLOP_PER_PAIR * k + FLOP_PER_PIXEL)
         out = {
-            "metric": "pixels/sec per Lloyd iteration (8192x8192, k=256)",
+            "metric": f"pixels/sec per Lloyd iteration ({WIDTH}x{height}, k={k})",
             "value": total_pixels * args.steps / elapsed,
             "unit": "pixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"synthetic uniform RGBA {WIDTH}x{args.rows * world} (seed 0x5EED0003), "
+            "config": {"workload": f"synthetic uniform RGBA {WIDTH}x{height} (seed 0x5EED0003), "
                                    f"k={k}, one Lloyd iteration = update + assign (labels written every "
                                    f"iteration) + accumulate"
                                    + (" + RCCL all-reduce of k x 4 int64" if world > 1 else ""),
-                       "width": WIDTH, "height": args.rows * world, "k": k,
-                       "sharding": f"row bands, {args.rows} rows per GPU",
-                       "strategy": strategy, "prepare_ms": t_prep * 1e3},
+                       "width": WIDTH, "height": height, "k": k,
+                       "sharding": f"row bands, {rows} rows per GPU",
+                       "strategy": strategy, "prepare_ms": t_prep * 1e3,
+                       "label_pass": "beside the next iteration's cube pass" if sh.pipeline else "before the next iteration"},
             "roofline": {"bound": "hbm", "kernel": dominant,
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel_ms": k_ms, "algorithmic_bytes_per_launch": abytes},
+                         "frac": achieved / HBM_PEAK_GBPS,
+                         "peak_achievable": HBM_ACHIEVABLE_GBPS, "frac_achievable": achieved / HBM_ACHIEVABLE_GBPS,
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel_ms": k_ms, "algorithmic_bytes_per_launch": abytes,
+                         # the whole iteration (all kernels, gaps, collective): 8 B/px over ms_per_step
+                         "achieved_iteration": step_gbps, "frac_iteration": step_gbps / HBM_PEAK_GBPS,
+                         "frac_iteration_achievable": step_gbps / HBM_ACHIEVABLE_GBPS,
+                         # SURVEY 8d's second roof: flops of the literal per-pixel scan (17 k + 50 per pixel) over the
+                         # fp32 vector peak; > 1 means the colour table does not perform them
+                         "valu_fraction": flops / (ms_per_step * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
+                         "valu_peak_tflops": FP32_VECTOR_PEAK_TFLOPS},
             "kernels": kernels,
         }
-        if world == 1 and args.rows == ROWS_PER_GPU and not args.no_extras:
+        if world == 1 and rows == ROWS_PER_GPU and not args.no_extras:
             out["extra"] = output_pass_timing(proc, rgba, n_local, stream, sh)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(k, cent, seed)

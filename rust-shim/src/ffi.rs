@@ -1,0 +1,75 @@
+//! `extern "C"` view of `include/kmeans_hip.h` -- the host-buffer API, i.e. exactly what
+//! `ImageProcessor::{new, palette, find, reduce}` (reference `core/src/lib.rs:38-164`) need.
+//! Every item below is checked against the header by `tests/test_rust_shim.py`.
+#![allow(non_camel_case_types)]
+
+use std::os::raw::{c_char, c_int};
+
+/// Opaque `kmg_processor` (include/kmeans_hip.h).
+#[repr(C)]
+pub struct kmg_processor {
+    _private: [u8; 0],
+}
+
+/// `kmg_options` (include/kmeans_hip.h); `kmg_default_options` fills in the reference's constants
+/// (structures.rs:23, modules.rs:765-766, lib.rs:189-194).
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct kmg_options {
+    pub struct_size: u32,
+    pub device: i32,
+    pub shrink_max_dim: u32,
+    pub max_iterations: u32,
+    pub check_period: u32,
+    pub convergence: f32,
+}
+
+pub const KMG_OK: c_int = 0;
+pub const KMG_ALGO_KMEANS: c_int = 0;
+pub const KMG_ALGO_OCTREE: c_int = 1;
+pub const KMG_MODE_REPLACE: c_int = 0;
+pub const KMG_MODE_DITHER: c_int = 1;
+pub const KMG_MODE_MELD: c_int = 2;
+
+extern "C" {
+    pub fn kmg_last_error() -> *const c_char;
+    pub fn kmg_version() -> *const c_char;
+    pub fn kmg_default_options(opt: *mut kmg_options);
+    // ImageProcessor::new -- lib.rs:38-65
+    pub fn kmg_processor_create(out: *mut *mut kmg_processor) -> c_int;
+    pub fn kmg_processor_create_ex(opt: *const kmg_options, out: *mut *mut kmg_processor) -> c_int;
+    pub fn kmg_processor_destroy(p: *mut kmg_processor);
+    // ImageProcessor::palette -- lib.rs:67-77
+    pub fn kmg_palette(
+        p: *mut kmg_processor,
+        rgba: *const u8,
+        width: u32,
+        height: u32,
+        color_count: u32,
+        algo: c_int,
+        out_rgba: *mut u8,
+        out_count: *mut u32,
+    ) -> c_int;
+    // ImageProcessor::find -- lib.rs:79-114
+    pub fn kmg_find(
+        p: *mut kmg_processor,
+        rgba: *const u8,
+        width: u32,
+        height: u32,
+        palette_rgba: *const u8,
+        n_colors: u32,
+        mode: c_int,
+        out_rgba: *mut u8,
+    ) -> c_int;
+    // ImageProcessor::reduce -- lib.rs:116-164
+    pub fn kmg_reduce(
+        p: *mut kmg_processor,
+        rgba: *const u8,
+        width: u32,
+        height: u32,
+        color_count: u32,
+        algo: c_int,
+        mode: c_int,
+        out_rgba: *mut u8,
+    ) -> c_int;
+}
