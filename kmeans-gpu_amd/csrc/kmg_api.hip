@@ -193,6 +193,16 @@ extern "C" int kmg_processor_create_ex(const kmg_options *opt, kmg_processor **o
     p->d_bounds = nullptr;
     p->d_sub_bounds = nullptr;
     p->d_lab_table = nullptr;
+    {
+        // per-call scratch comes from the device's stream-ordered pool: keep what has been freed instead of handing
+        // it back to the driver at every synchronisation (the default threshold is 0, which makes each call of the
+        // host-buffer API pay for fresh allocations again: find -m replace at 8192^2 0.65 -> 0.3 ms)
+        hipMemPool_t pool = nullptr;
+        if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
+            uint64_t keep = ~0ull;
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+        }
+    }
     float lut[256];
     build_srgb_lut100(lut);
     hipError_t e1 = hipMalloc((void **)&p->d_lut, sizeof lut);

@@ -39,8 +39,7 @@ inline void shader_lab_to_rgba8(const float lab[3], uint8_t out[4])
         return t3 > 0.008856f ? t3 : (t - 16.0f / 116.0f) / 7.787f;
     };
     auto encode = [](float c) {
-        return c > 0.0031308f ? 1.055f * (float)pow((double)c, (double)(1.0f / 2.4f)) - 0.055f
-                              : 12.92f * c;
+        return c > 0.0031308f ? 1.055f * pow_inv_2p4(c) - 0.055f : 12.92f * c;   // kmg_math.h: shared with the device
     };
     float y = (lab[0] + 16.0f) / 116.0f;
     float x = lab[1] / 500.0f + y;

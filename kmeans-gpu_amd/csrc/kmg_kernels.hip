@@ -691,8 +691,8 @@ hipError_t launch_apply(const uint32_t *rgba, uint32_t w, uint32_t rows, uint32_
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float srgb_encode_dev(float c)
 {
-    // lab_to_rgb.wgsl:21-35; pow(c, 1/2.4) correctly rounded via f64
-    return c > 0.0031308f ? 1.055f * (float)pow((double)c, (double)(1.0f / 2.4f)) - 0.055f : 12.92f * c;
+    // lab_to_rgb.wgsl:21-35; pow(c, 1/2.4): the shared-source routine of kmg_math.h (same bytes as host and oracle)
+    return c > 0.0031308f ? 1.055f * pow_inv_2p4(c) - 0.055f : 12.92f * c;
 }
 
 __device__ __forceinline__ float lab_finv_dev(float t)

@@ -50,6 +50,29 @@ KMG_HD float cbrt_cr(float x)
     return (float)yd;
 }
 
+// lab_to_rgb.wgsl:21-35 `pow(c, 1.0 / 2.4)` for c in (0.0031308, 1): ONE definition shared by the device kernels
+// (meld output pass), the host palette code and -- restated operation by operation -- the oracle, so that their
+// bytes agree (two different libm / ocml `pow` implementations disagree on ~1e-5 of the channels).
+// The shader's exponent is the binary32 value y = f32(1 / 2.4) = 5/12 - d, d = 9.93e-9:
+//   c^y = c^(5/12) * exp(-d ln c),   c^(1/12) = sqrt(sqrt(cbrt(c))),   ln c = 24 atanh((s - 1) / (s + 1)), s = c^(1/12)
+// in binary64 with IEEE +, -, *, /, sqrt only (compile with -ffp-contract=off): relative error ~1e-15 before the
+// single rounding to binary32.  c >= 1 gives 1 (the caller clamps to 255 anyway).
+KMG_HD float pow_inv_2p4(float c)
+{
+    if (!(c < 1.0f)) return 1.0f;
+    const double x = (double)c;
+    double y = (double)cbrt_cr(c < 1.0e-3f ? 1.0e-3f : c);        // binary32 cube root as the seed (c > 0.0031308 here)
+    for (int i = 0; i < 2; ++i) y = y - (((y * y) * y) - x) / ((3.0 * y) * y);
+    const double s = sqrt(sqrt(y));                               // c^(1/12)
+    const double s2 = s * s, s4 = s2 * s2, p = s4 * s;            // c^(5/12)
+    const double z = (s - 1.0) / (s + 1.0), z2 = z * z;
+    const double series = 1.0 + z2 * (1.0 / 3.0 + z2 * (1.0 / 5.0 + z2 * (1.0 / 7.0 + z2 * (1.0 / 9.0 + z2 * (1.0 / 11.0 + z2 * (1.0 / 13.0 + z2 * (1.0 / 15.0)))))));
+    const double ln_c = 24.0 * (z * series);
+    const double d = 5.0 / 12.0 - (double)(1.0f / 2.4f);
+    const double t = -(d * ln_c);
+    return (float)(p * (1.0 + t + (0.5 * t) * t));
+}
+
 // rgb_to_lab.wgsl:44-58
 KMG_HD float lab_f(float t)
 {

@@ -12,7 +12,7 @@ pass needs no exchange at all (kmg_dev_apply takes the band's first row).
 import torch
 import torch.distributed as dist
 
-__all__ = ["band_rows", "sharded_init", "ShardedLloyd", "ShardedBatch"]
+__all__ = ["band_rows", "images_of_rank", "sharded_init", "ShardedLloyd", "ShardedBatch", "PlacedBatch"]
 
 
 def _require_current_stream(tensor, stream):
@@ -31,6 +31,12 @@ def _require_current_stream(tensor, stream):
 def band_rows(height, rank, world):
     """Rows [r0, r1) owned by `rank`."""
     return (rank * height) // world, ((rank + 1) * height) // world
+
+
+def images_of_rank(n_images, rank, world):
+    """Whole-image placement of a batch (BASELINE config 4 when the batch is at least as large as the
+    node): image i lives on rank i % world."""
+    return list(range(int(rank), int(n_images), int(world)))
 
 
 def sharded_init(backend, k, band, width, height, row0, group=None, stream=0):
@@ -76,7 +82,7 @@ class ShardedLloyd:
     labels   : int32 tensor (rows*width,) or None
     """
 
-    def __init__(self, backend, k, rgba, labels=None, group=None, stream=0, collective=None):
+    def __init__(self, backend, k, rgba, labels=None, group=None, stream=0, collective=None, local_only=False):
         self.backend = backend
         self.k = int(k)
         self.rgba = rgba
@@ -86,6 +92,8 @@ class ShardedLloyd:
         self.stream = stream
         self.acc = torch.zeros((self.k, 4), dtype=torch.int64, device=rgba.device)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if local_only:
+            self.world = 1            # the whole image is here (PlacedBatch): no exchange step at all
         # collective(acc) -> None replaces the SUM all-reduce (tests: the other ranks' share computed locally)
         self.collective = collective
         if collective is not None:
@@ -234,3 +242,26 @@ class ShardedBatch:
                         self.active[i] = False
                         self.acc[i].zero_()      # its rows stay in the collective but carry nothing
         return list(self.iterations)
+
+
+class PlacedBatch:
+    """A batch of images with WHOLE images per rank (images_of_rank): every image is an independent k-means
+    problem that never leaves its GPU, so the batch needs no collective at all -- the right split whenever the
+    batch has at least as many images as the node has GPUs (BASELINE config 4: 16 images over 8 GPUs = 2 each).
+    Tiling every image over all ranks instead (ShardedBatch) would repeat the colour-table cube pass, whose cost
+    does not depend on the number of pixels, once per image on EVERY rank and add an all-reduce per iteration.
+
+    backends : Lloyd-like objects of THIS rank's images (centroids already set), images / labels likewise
+    """
+
+    def __init__(self, backends, k, images, labels=None, stream=0, split_labels=None):
+        assert len(backends) == len(images)
+        labels = list(labels) if labels is not None else [None] * len(images)
+        self.loops = [ShardedLloyd(be, k, img, lab, stream=stream, local_only=True)
+                      for be, img, lab in zip(backends, images, labels)]
+        for i, loop in enumerate(self.loops):
+            loop.split_labels = bool(split_labels[i]) if split_labels is not None else False
+
+    def run(self, max_iterations=128, check_period=8):
+        """every image to its own convergence (modules.rs:763-840); returns the iteration each one stopped at"""
+        return [loop.run(max_iterations, check_period) for loop in self.loops]

@@ -517,10 +517,32 @@ void orc_meld(const float *lab3, uint32_t w, uint32_t h, const float *centroids4
 /* S9  Lab -> RGBA8          core/shaders/converters/lab_to_rgb.wgsl                     */
 /* ------------------------------------------------------------------------------------ */
 
+/* lab_to_rgb.wgsl:21-35 `pow(c, 1.0 / 2.4)`, c in (0.0031308, 1).  WGSL leaves pow's precision to the driver;
+ * the definition fixed here is the following binary64 evaluation (IEEE +, -, *, /, sqrt; relative error ~1e-15
+ * before the single rounding to binary32; equal to (float)pow((double)c, (double)(1.0f / 2.4f)) of a correctly
+ * rounded libm except on ~1e-8 of the inputs, tests/test_oracle_golden.py), which the GPU library restates
+ * operation by operation so that the bytes of meld outputs agree:
+ *   y = f32(1 / 2.4) = 5/12 - d;  c^y = c^(5/12) exp(-d ln c);  c^(1/12) = sqrt(sqrt(cbrt c));
+ *   ln c = 24 atanh((s - 1) / (s + 1)), s = c^(1/12)                                                   */
+float orc_pow_inv_2p4(float c)
+{
+    if (!(c < 1.0f)) return 1.0f;                         /* clamps to 255 in the caller anyway */
+    const double x = (double)c;
+    double y = (double)orc_cbrt(c < 1.0e-3f ? 1.0e-3f : c);
+    for (int i = 0; i < 2; ++i) y = y - (((y * y) * y) - x) / ((3.0 * y) * y);
+    const double s = sqrt(sqrt(y));
+    const double s2 = s * s, s4 = s2 * s2, p = s4 * s;
+    const double z = (s - 1.0) / (s + 1.0), z2 = z * z;
+    const double series = 1.0 + z2 * (1.0 / 3.0 + z2 * (1.0 / 5.0 + z2 * (1.0 / 7.0 + z2 * (1.0 / 9.0 + z2 * (1.0 / 11.0 + z2 * (1.0 / 13.0 + z2 * (1.0 / 15.0)))))));
+    const double ln_c = 24.0 * (z * series);
+    const double d = 5.0 / 12.0 - (double)(1.0f / 2.4f);
+    const double t = -(d * ln_c);
+    return (float)(p * (1.0 + t + (0.5 * t) * t));
+}
+
 static inline float srgb_encode(float c)
 {
-    /* lab_to_rgb.wgsl:21-35; pow(c, 1/2.4) fixed as correctly rounded */
-    if (c > 0.0031308f) return 1.055f * (float)pow((double)c, (double)(1.0f / 2.4f)) - 0.055f;
+    if (c > 0.0031308f) return 1.055f * orc_pow_inv_2p4(c) - 0.055f;
     return 12.92f * c;
 }
 

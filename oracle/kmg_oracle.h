@@ -51,6 +51,7 @@ enum { ORC_MODE_REPLACE = 0, ORC_MODE_DITHER = 1, ORC_MODE_MELD = 2 };
 /* ---- S1: RGBA8 -> Lab (core/shaders/converters/rgb_to_lab.wgsl:11-80) ---- */
 void  orc_srgb_lut(float lut100[256]);            /* (srgb decode) * 100 for each byte */
 float orc_cbrt(float x);                          /* correctly rounded cube root     */
+float orc_pow_inv_2p4(float c);                   /* lab_to_rgb.wgsl pow(c, 1/2.4), the fixed binary64 evaluation */
 void  orc_rgb_to_lab(const uint8_t *rgba, uint64_t n, float *lab3);
 
 /* ---- S3: CIE94 (core/shaders/functions/delta_e.wgsl:1-22) ---- */

@@ -46,6 +46,7 @@ def _declare(L):
                              C.POINTER(C.c_float), C.POINTER(C.c_int64))
     L.orc_srgb_lut.argtypes = [f32p]
     L.orc_cbrt.argtypes = [C.c_float]; L.orc_cbrt.restype = C.c_float
+    L.orc_pow_inv_2p4.argtypes = [C.c_float]; L.orc_pow_inv_2p4.restype = C.c_float
     L.orc_rgb_to_lab.argtypes = [u8p, C.c_uint64, f32p]
     L.orc_cie94.argtypes = [f32p, f32p]; L.orc_cie94.restype = C.c_float
     L.orc_cie94_key.argtypes = [f32p, f32p]; L.orc_cie94_key.restype = C.c_float
@@ -96,6 +97,10 @@ def srgb_lut():
 
 def cbrt(x):
     return float(lib().orc_cbrt(C.c_float(x)))
+
+
+def pow_inv_2p4(c):
+    return float(lib().orc_pow_inv_2p4(C.c_float(c)))
 
 
 def rgb_to_lab(rgba):

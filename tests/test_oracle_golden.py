@@ -130,6 +130,20 @@ def test_hoisted_literal_equals_plain_literal_and_key_is_only_a_filter(oracle, t
     assert 0 < int((want != oracle.assign(lab, grey, literal=2)).sum()) < 200
 
 
+def test_pow_inv_2p4_is_the_rounded_double_pow(oracle):
+    """lab_to_rgb.wgsl:21-35: the oracle's fixed evaluation of pow(c, f32(1/2.4)) agrees with a correctly
+    rounded binary64 pow rounded to binary32 (numpy / libm) on all but a vanishing share of inputs, and is
+    within 1 ulp always; shader_tests.rs:231-240's pow KAT style check (pow(2.1, 7) there) is about the WGSL
+    builtin -- here the function itself is pinned."""
+    rng = np.random.default_rng(7)
+    c = np.concatenate([rng.uniform(0.0031308, 1.0, 200000), np.linspace(0.0031309, 0.99999, 50000)]).astype(np.float32)
+    got = np.array([oracle.pow_inv_2p4(float(v)) for v in c[:20000]], np.float32)
+    want = np.power(c[:20000].astype(np.float64), np.float64(np.float32(1.0) / np.float32(2.4))).astype(np.float32)
+    ulp = np.abs(got.view(np.int32) - want.view(np.int32))
+    assert ulp.max() <= 1 and (ulp > 0).mean() < 1e-3
+    assert oracle.pow_inv_2p4(1.0) == 1.0 and oracle.pow_inv_2p4(7.5) == 1.0
+
+
 def test_shrunk_dims_rule(oracle):
     """core/src/structures.rs:79-89"""
     assert oracle.resized_dims(3184, 2126) == (256, 170)

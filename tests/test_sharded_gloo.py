@@ -167,6 +167,67 @@ def test_sharded_batch_equals_per_image_oracle(oracle):
             assert np.array_equal(labs[j], want_labels[r0 * w:r1 * w])
 
 
+def _placed_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "kmeans-gpu_amd", "python"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    from kmeans_gpu_amd.sharded import PlacedBatch, images_of_rank
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        O.set_num_threads(2)
+
+        def no_collective(*a, **kw):
+            raise AssertionError("whole-image placement must not communicate")
+        dist.all_reduce = no_collective
+        k, shapes = 5, [(64, 40), (33, 57), (80, 21), (17, 90), (50, 50)]
+        mine = images_of_rank(len(shapes), rank, world)
+        backends, images, labels = [], [], []
+        for j in mine:
+            w, h = shapes[j]
+            img = O.synth_uniform(700 + j, w * h).reshape(h, w, 4)
+            backends.append(OracleBackend(O, k, O.init_centroids(O.rgb_to_lab(img), w, h, k)))
+            images.append(torch.from_numpy(np.ascontiguousarray(img).reshape(-1, 4)))
+            labels.append(torch.zeros(w * h, dtype=torch.int32))
+        its = PlacedBatch(backends, k, images, labels).run(128, 8)
+        q.put((rank, mine, its, [b.cent.copy() for b in backends], [l.numpy().view(np.uint32).copy() for l in labels]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_placed_batch_whole_images_no_collective(oracle, world):
+    """BASELINE config 4 as shipped when the batch is at least as large as the node: image i on rank
+    i % world, every image an independent loop, NO collective -- results equal the per-image oracle"""
+    from kmeans_gpu_amd.sharded import images_of_rank
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_placed_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    k, shapes = 5, [(64, 40), (33, 57), (80, 21), (17, 90), (50, 50)]
+    seen = []
+    for rank, mine, its, cents, labs in res:
+        assert mine == images_of_rank(len(shapes), rank, world)
+        for slot, j in enumerate(mine):
+            w, h = shapes[j]
+            img = oracle.synth_uniform(700 + j, w * h).reshape(h, w, 4)
+            lab = oracle.rgb_to_lab(img)
+            want_c, want_labels, want_it = oracle.lloyd(lab, oracle.init_centroids(lab, w, h, k))
+            assert its[slot] == want_it
+            assert np.array_equal(cents[slot].view(np.uint32), want_c.view(np.uint32))
+            assert np.array_equal(labs[slot], want_labels)
+            seen.append(j)
+    assert sorted(seen) == list(range(len(shapes)))
+
+
 class OracleInitBackend(OracleBackend):
     """adds the sharded-init steps (kmg_lloyd_init_step / _init_pick_band / _set_centroid_rgba)"""
 
