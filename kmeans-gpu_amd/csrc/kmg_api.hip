@@ -126,7 +126,7 @@ struct ColourTable {
     // farthest-point init over the colours (built on demand by the init entry points)
     uint32_t *d_tie = nullptr;       // 2^24: 1 + largest low half of the init key per colour, 0 = unoccupied
     float *d_cdist = nullptr;        // 2^24 running min-distance per colour
-    unsigned long long *d_cell_key = nullptr;   // kCells: largest init key of each cell's colours
+    void *d_init_cells = nullptr;    // init_cells_bytes(): the passes' cell records (largest key + its Lab) and slots
     bool tie_valid = false;          // d_tie describes (rgba, n, tie_first)
     bool bound_by_init = false;      // the binding was made by the initialisation of the current problem
     bool bound_by_caller = false;    // kmg_lloyd_bind_image / kmg_lloyd_prepare: the caller vouches for the buffer's contents
@@ -357,7 +357,7 @@ static void free_table(ColourTable &t)
     if (t.d_sub_alt) (void)hipFree(t.d_sub_alt);
     if (t.d_tie) (void)hipFree(t.d_tie);
     if (t.d_cdist) (void)hipFree(t.d_cdist);
-    if (t.d_cell_key) (void)hipFree(t.d_cell_key);
+    if (t.d_init_cells) (void)hipFree(t.d_init_cells);
     t = ColourTable();
 }
 
@@ -504,7 +504,7 @@ static int bind_image_impl(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, void
         }
     }
     if (want_tie) {
-        HIP_TRY(hipMemsetAsync(t.d_cell_key, 0, sizeof(unsigned long long) * kCells, S(stream)));
+        HIP_TRY(hipMemsetAsync(t.d_init_cells, 0, init_cells_bytes(), S(stream)));
         t.tie_valid = true;
         t.tie_first = first_index;
     }
@@ -929,7 +929,7 @@ static int init_over_colours(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, ui
     if (!t.d_tie) {
         hipError_t e = hipMalloc((void **)&t.d_tie, sizeof(uint32_t) << 24);
         if (e == hipSuccess) e = hipMalloc((void **)&t.d_cdist, sizeof(float) << 24);
-        if (e == hipSuccess) e = hipMalloc((void **)&t.d_cell_key, sizeof(unsigned long long) * kCells);
+        if (e == hipSuccess) e = hipMalloc(&t.d_init_cells, init_cells_bytes());
         if (e != hipSuccess)
             return fail(e == hipErrorOutOfMemory ? KMG_ERR_OUT_OF_MEMORY : KMG_ERR_HIP, "init tables allocation failed: %s", hipGetErrorString(e));
     }
@@ -967,10 +967,12 @@ extern "C" int kmg_lloyd_init_centroids(kmg_lloyd *s, const uint8_t *d_rgba, uin
                               : hipMalloc((void **)&s->d_dist, sizeof(float) * n));
             s->dist_cap = n;
         }
-        for (uint32_t j = 1; j < s->k; ++j) {   // modules.rs:1211-1246
+        for (uint32_t j = 1; j < s->k + (colours ? 1u : 0u); ++j) {   // modules.rs:1211-1246
             if (colours) {
-                HIP_TRY(launch_init_pass_cells(s->tab.d_work, s->tab.d_tie, s->p->d_lab_table, s->p->d_bounds, s->d_cent, j,
-                                               s->tab.d_cdist, s->tab.d_cell_key, s->d_key, rgba, s->p->d_lut, S(stream)));
+                // launch j picks centroid j - 1 and runs pass j; launch k only picks
+                HIP_TRY(launch_init_pass_cells(s->tab.d_work, s->tab.d_tie, s->tab.d_occ, s->p->d_lab_table, s->p->d_bounds, s->d_cent, j,
+                                               j < s->k ? 1 : 0, s->tab.d_cdist, s->tab.d_init_cells, nullptr, rgba, s->p->d_lut,
+                                               S(stream)));
             } else {
                 HIP_TRY(launch_init_pass(rgba, n, s->p->d_lut, s->d_cent, j, s->d_dist, s->d_key, 0, S(stream)));
                 HIP_TRY(launch_init_pick(rgba, s->p->d_lut, s->d_key, s->d_cent, j, S(stream)));
@@ -1003,8 +1005,8 @@ extern "C" int kmg_lloyd_init_step(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t
         const ColourTable &t = s->tab;
         if (t.rgba != d_rgba || t.n != n_local || !t.tie_valid || t.tie_first != first_index)
             return fail(KMG_ERR_INVALID_ARGUMENT, "init_step: the band changed since step j = 1");
-        HIP_TRY(launch_init_pass_cells(t.d_work, t.d_tie, s->p->d_lab_table, s->p->d_bounds, s->d_cent, j, t.d_cdist, t.d_cell_key,
-                                       (unsigned long long *)d_key, nullptr, nullptr, S(stream)));
+        HIP_TRY(launch_init_pass_cells(t.d_work, t.d_tie, t.d_occ, s->p->d_lab_table, s->p->d_bounds, s->d_cent, j, 1, t.d_cdist,
+                                       t.d_init_cells, (unsigned long long *)d_key, nullptr, nullptr, S(stream)));
         return KMG_OK;
     }
     if (s->dist_cap < n_local) {

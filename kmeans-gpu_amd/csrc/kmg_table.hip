@@ -385,117 +385,244 @@ __device__ __forceinline__ float cie94_lower_bound(const CellBounds &cb, float L
     return sqrtf(tL * tL + tC * tC + tH * tH);
 }
 
-// One init pass, one wave per occupied cell.  cell_key[cell] caches the largest key of the cell's
-// colours; a new centroid can only lower the running distances, and it cannot lower any distance of a
-// cell whose lower bound to it is not below the cell's largest running distance -- such a cell (most of
-// them once a few dozen centroids exist) is skipped and its cached key stays valid.  A wave owns up to
-// four cells per round and tests them together (lanes 0..3) before it works on the ones it must visit.
-__global__ __launch_bounds__(kBlock) void k_init_pass_cells(const uint32_t *__restrict__ work,
-                                                            const uint32_t *__restrict__ tie,
-                                                            const float4 *__restrict__ lab_table,
-                                                            const CellBounds *__restrict__ bounds,
-                                                            const Centroid *__restrict__ cent, uint32_t j,
-                                                            float *__restrict__ dist,
-                                                            unsigned long long *__restrict__ cell_key)
+// One init pass = ONE launch (kInitGrid workgroups of kInitBlock threads).
+//
+// cells[cell] caches the largest key of the cell's colours together with the Lab of the colour that holds it.  A
+// new centroid can only lower the running distances, and it cannot lower any distance of a cell whose lower bound
+// to it is not below the cell's largest running distance -- such a cell (most of them once a few dozen centroids
+// exist) is skipped and its cached record stays valid.
+//
+// Who does what.  The cells a centroid reaches are neighbours in colour space, i.e. runs in the work list: the
+// list is dealt out so that an 8 x 8 x 4 block of cells goes to 256 DIFFERENT workgroups (slot_work_index), each
+// workgroup tests its 128 cells with one lane per cell, pools the reached ones in LDS and its 16 waves take them
+// in turn -- a pass costs what the busiest workgroup costs, and that is ~1/16 of what the busiest wave cost when
+// every wave visited its own cells (measured: 28 -> ~12 us per pass once a few dozen centroids exist).
+// A visit reads the running distances, the occupancy byte and the Lab of the cell's colours; the tie keys (which
+// pixel of a colour) are only read for the colours that hold the cell's largest distance, normally one.
+//
+// The arg-max over the cells is split between two launches: every workgroup leaves the largest record it met in
+// slots[j & 1][workgroup]; the NEXT launch starts by reducing the kInitGrid slots (every workgroup does, 8 KiB
+// from L2) and so knows centroid j -- the Lab of the winning colour travels with the key, no pixel is fetched
+// (plus_plus_init.wgsl:172-181 `pick`; all distances zero: pixel 0).  Launch j therefore is
+//     [PICK: centroid j - 1 <- slots of launch j - 1]  ->  [pass against centroid j - 1 -> slots]
+// and launch k (do_pass = 0) only picks the last centroid: k launches for k - 1 passes instead of 2 (k - 1), and
+// the loads a pass starts with (work list, cell records, bounds) are in flight while the slots are reduced.
+// PICK = false (band of a sharded image: the pick is an all-reduce between two launches): centroid j - 1 is read
+// from cent[], and k_init_reduce_slots turns the slots into the band's key.
+constexpr uint32_t kInitGrid = 256, kInitBlock = 1024;
+static_assert(kInitGrid * (kInitBlock / 64) * 8 == kCells, "one test slot per cell");
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    const uint32_t n_waves = gridDim.x * (kBlock / 64);
-    const Centroid c = cent[j - 1];
-    const uint32_t n_work = __builtin_amdgcn_readfirstlane(work[0]);
-    for (uint32_t w0 = wave; w0 < n_work; w0 += 4u * n_waves) {
-        const uint32_t wi = w0 + (lane & 3u) * n_waves;
-        uint32_t my_cell = 0;
-        bool reached = false;
-        if (lane < 4u && wi < n_work) {
-            my_cell = work[1u + wi];
-            reached = true;
-            if (j != 1) {
-                const float cell_max = __uint_as_float((uint32_t)(cell_key[my_cell] >> 32));
-                reached = cie94_lower_bound(bounds[my_cell], c.L, c.a, c.b, c.C) < cell_max;
-            }
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+    for (int off = 32; off > 0; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off, 64));
+    return v;
+}
+
+// test slot q (0..127) of workgroup g (0..255) -> index into the work list: with every cell occupied the index
+// is the cell [r:5][g:5][b:5], and g = [r1 r0][g2 g1 g0][b2 b1 b0], q = [r4 r3 r2][g4 g3][b4 b3]
+__device__ __forceinline__ uint32_t slot_work_index(uint32_t g, uint32_t q)
+{
+    const uint32_t b = (g & 7u) | ((q & 3u) << 3), gg = ((g >> 3) & 7u) | (((q >> 2) & 3u) << 3), r = (g >> 6) | ((q >> 4) << 2);
+    return (r << 10) | (gg << 5) | b;
+}
+
+template <bool PICK>
+__global__ __launch_bounds__(kInitBlock) void k_init_fused(const uint32_t *__restrict__ work,
+                                                           const uint32_t *__restrict__ tie,
+                                                           const uint8_t *__restrict__ occ_bits,
+                                                           const float4 *__restrict__ lab_table,
+                                                           const CellBounds *__restrict__ bounds,
+                                                           Centroid *__restrict__ cent, uint32_t j, int do_pass,
+                                                           float *__restrict__ dist, InitCell *__restrict__ cells,
+                                                           InitCell *__restrict__ slots,
+                                                           const uint32_t *__restrict__ rgba,
+                                                           const float *__restrict__ lut)
+{
+    __shared__ unsigned long long s_key[kInitBlock / 64];
+    __shared__ float4 s_lab[kInitBlock / 64];
+    __shared__ float4 s_cent;
+    __shared__ uint32_t s_list[(kInitBlock / 64) * 8], s_count;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+
+    // what the test needs and does not depend on the new centroid: requested before the pick
+    const uint32_t n_work = do_pass ? __builtin_amdgcn_readfirstlane(work[0]) : 0u;
+    const uint32_t wi = slot_work_index(blockIdx.x, wv * 8u + (lane & 7u));
+    const bool tester = lane < 8u && wi < n_work;
+    uint32_t my_cell = 0;
+    InitCell rec; rec.key = 0ull; rec.lab = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    CellBounds cb = {};
+    if (tester) {
+        my_cell = work[1u + wi];
+        if (j != 1) { rec.key = cells[my_cell].key; rec.lab = cells[my_cell].lab; }
+        cb = bounds[my_cell];
+    }
+    if (threadIdx.x == 0) s_count = 0u;
+
+    Centroid c;
+    if (PICK && j >= 2u) {
+        // centroid j - 1 = the largest record of the previous launch
+        const InitCell *prev = slots + ((j - 1u) & 1u) * kInitGrid;
+        unsigned long long key = 0ull;
+        float4 lab = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (threadIdx.x < kInitGrid) { key = prev[threadIdx.x].key; lab = prev[threadIdx.x].lab; }
+        if (wv < kInitGrid / 64u) {
+            const unsigned long long best = wave_max_u64(key);
+            const uint32_t src = (uint32_t)__builtin_ctzll(__ballot(key == best));
+            if (lane == src) { s_key[wv] = best; s_lab[wv] = lab; }
         }
-        unsigned long long todo = __ballot(reached);
-        while (todo) {
-            const uint32_t src = (uint32_t)__builtin_ctzll(todo);
-            todo &= todo - 1;
-            const uint32_t cell = (uint32_t)__builtin_amdgcn_readlane((int)my_cell, (int)src);
-            const uint32_t base = cell * kCellColours + lane * 8;
-            const uint4 t0 = *reinterpret_cast<const uint4 *>(tie + base), t1 = *reinterpret_cast<const uint4 *>(tie + base + 4);
-            float4 d0 = make_float4(1000000.0f, 1000000.0f, 1000000.0f, 1000000.0f), d1 = d0;   // kmeans++_calc_diff.wgsl:26-30
-            if (j != 1) {
-                d0 = *reinterpret_cast<const float4 *>(dist + base);
-                d1 = *reinterpret_cast<const float4 *>(dist + base + 4);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t w = 0;
+            for (uint32_t q = 1; q < kInitGrid / 64u; ++q) if (s_key[q] > s_key[w]) w = q;
+            float4 v = s_lab[w];
+            if ((s_key[w] >> 32) == 0ull) {
+                // Candidate(0, 0.0): every distance is 0 -> pixel 0
+                const uint32_t px = rgba[0];
+                linear100_to_lab(lut[px & 255u], lut[(px >> 8) & 255u], lut[(px >> 16) & 255u], v.x, v.y, v.z);
             }
-            const uint32_t t[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-            float m[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
-            unsigned long long best = 0ull;
+            v.w = chroma(v.y, v.z);
+            s_cent = v;
+            if (blockIdx.x == 0) { Centroid o; o.L = v.x; o.a = v.y; o.b = v.z; o.C = v.w; cent[j - 1u] = o; }
+        }
+        __syncthreads();
+        const float4 v = s_cent;
+        c.L = v.x; c.a = v.y; c.b = v.z; c.C = v.w;
+    } else {
+        c = cent[j - 1u];
+    }
+    if (!do_pass) return;
+    __syncthreads();                                               // s_count is zero, s_key / s_lab are free again
+
+    unsigned long long run_key = 0ull;                             // the largest record this lane has met
+    float4 run_lab = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (tester) {
+        bool reached = true;
+        if (j != 1) {
+            const float cell_max = __uint_as_float((uint32_t)(rec.key >> 32));
+            reached = cie94_lower_bound(cb, c.L, c.a, c.b, c.C) < cell_max;
+        }
+        if (reached) s_list[atomicAdd(&s_count, 1u)] = my_cell;
+        else { run_key = rec.key; run_lab = rec.lab; }
+    }
+    __syncthreads();
+    const uint32_t count = s_count;
+
+    // visits: wave wv takes entries wv, wv + 16, ...; the next cell's occupancy and distances are requested
+    // (unconditionally: past the end the current cell again, unused) before the current cell's Lab values are waited for
+    uint32_t idx = wv;
+    uint32_t cell = idx < count ? s_list[idx] : 0u;
+    uint32_t base = cell * kCellColours + lane * 8u;
+    uint32_t occ = occ_bits[(uint64_t)cell * 64u + lane];
+    float4 d0 = *reinterpret_cast<const float4 *>(dist + base), d1 = *reinterpret_cast<const float4 *>(dist + base + 4);
+    while (idx < count) {
+        float4 v[8];
+        if (occ) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = lab_table[base + q];
+        }
+        const uint32_t idx_n = idx + kInitBlock / 64u;
+        const uint32_t cell_n = idx_n < count ? s_list[idx_n] : cell;
+        const uint32_t base_n = cell_n * kCellColours + lane * 8u;
+        const uint32_t occ_n = occ_bits[(uint64_t)cell_n * 64u + lane];
+        const float4 d0_n = *reinterpret_cast<const float4 *>(dist + base_n), d1_n = *reinterpret_cast<const float4 *>(dist + base_n + 4);
+
+        float m[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+        if (j == 1) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) m[q] = 1000000.0f;         // kmeans++_calc_diff.wgsl:26-30
+        }
+        uint32_t md = 0u;                                          // largest distance (bits) among this lane's colours
+        if (occ) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                if (t[q]) {
-                    const float4 v = lab_table[base + q];
-                    m[q] = fminf(m[q], cie94(v.x, v.y, v.z, c.L, c.a, c.b));
-                    const unsigned long long kk = ((unsigned long long)float_to_bits(m[q]) << 32) | (unsigned long long)(t[q] - 1u);
-                    best = kk > best ? kk : best;
+                if ((occ >> q) & 1u) {
+                    m[q] = fminf(m[q], cie94(v[q].x, v[q].y, v[q].z, c.L, c.a, c.b));
+                    md = max(md, float_to_bits(m[q]));
                 }
             }
             *reinterpret_cast<float4 *>(dist + base) = make_float4(m[0], m[1], m[2], m[3]);
             *reinterpret_cast<float4 *>(dist + base + 4) = make_float4(m[4], m[5], m[6], m[7]);
-            for (int off = 32; off > 0; off >>= 1) {
-                const unsigned long long o = __shfl_xor(best, off, 64);
-                best = o > best ? o : best;
+        } else if (j == 1) {
+            *reinterpret_cast<float4 *>(dist + base) = make_float4(m[0], m[1], m[2], m[3]);
+            *reinterpret_cast<float4 *>(dist + base + 4) = make_float4(m[4], m[5], m[6], m[7]);
+        }
+        // the cell's key = (largest distance, largest low half among the colours that hold it): only those colours'
+        // tie keys are read
+        const uint32_t wmd = wave_max_u32(md);
+        uint32_t low1 = 0u;                                        // 1 + low half; 0 = this lane does not hold the maximum
+        float4 best_lab = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (occ && md == wmd) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (((occ >> q) & 1u) && float_to_bits(m[q]) == wmd) {
+                    const uint32_t t = tie[base + q];
+                    if (t > low1) { low1 = t; best_lab = v[q]; }
+                }
             }
-            if (lane == 0) cell_key[cell] = best;
+        }
+        const uint32_t wlow1 = wave_max_u32(low1);
+        // (tie keys of occupied colours are distinct -- they name distinct pixels)
+        if (low1 == wlow1 && low1 != 0u) {
+            InitCell o; o.key = ((unsigned long long)wmd << 32) | (unsigned long long)(wlow1 - 1u); o.pad[0] = 0u; o.pad[1] = 0u; o.lab = best_lab;
+            cells[cell] = o;
+            if (o.key >= run_key) { run_key = o.key; run_lab = best_lab; }
+        }
+        idx = idx_n; cell = cell_n; base = base_n; occ = occ_n; d0 = d0_n; d1 = d1_n;
+    }
+    // the largest record of the workgroup
+    {
+        const unsigned long long wbest = wave_max_u64(run_key);
+        if (lane == (uint32_t)__builtin_ctzll(__ballot(run_key == wbest))) { s_key[wv] = wbest; s_lab[wv] = run_lab; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t w = 0;
+            for (uint32_t q = 1; q < kInitBlock / 64u; ++q) if (s_key[q] > s_key[w]) w = q;
+            InitCell o; o.key = s_key[w]; o.pad[0] = 0u; o.pad[1] = 0u; o.lab = s_lab[w];
+            slots[(j & 1u) * kInitGrid + blockIdx.x] = o;
         }
     }
 }
 
-// key = max over the cells' cached keys (one workgroup); with rgba != NULL also plus_plus_init.wgsl:172-181
-// `pick`: centroid j = Lab of the pixel the key names
-__global__ __launch_bounds__(1024) void k_init_reduce_cells(const unsigned long long *__restrict__ cell_key,
-                                                            unsigned long long *__restrict__ key,
-                                                            const uint32_t *__restrict__ rgba,
-                                                            const float *__restrict__ lut,
-                                                            Centroid *__restrict__ cent, uint32_t j)
+// key = the largest slot key of pass j (band of a sharded image: the caller all-reduces it)
+__global__ __launch_bounds__(kInitGrid) void k_init_reduce_slots(const InitCell *__restrict__ slots, uint32_t j,
+                                                                 unsigned long long *__restrict__ key)
 {
-    __shared__ unsigned long long s_key[16];
-    unsigned long long v[kCells / 1024];
-#pragma unroll
-    for (uint32_t i = 0; i < kCells / 1024; ++i) v[i] = cell_key[i * 1024 + threadIdx.x];   // 32 loads in flight
-    unsigned long long best = 0ull;
-#pragma unroll
-    for (uint32_t i = 0; i < kCells / 1024; ++i) best = v[i] > best ? v[i] : best;
-    for (int off = 32; off > 0; off >>= 1) {
-        const unsigned long long o = __shfl_xor(best, off, 64);
-        best = o > best ? o : best;
-    }
-    if ((threadIdx.x & 63) == 0) s_key[threadIdx.x >> 6] = best;
+    __shared__ unsigned long long s_key[kInitGrid / 64];
+    const unsigned long long best = wave_max_u64(slots[(j & 1u) * kInitGrid + threadIdx.x].key);
+    if ((threadIdx.x & 63u) == 0u) s_key[threadIdx.x >> 6] = best;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 16; ++w) best = s_key[w] > best ? s_key[w] : best;
-        *key = best;
-        if (rgba) {
-            uint32_t index = 0;                                   // Candidate(0, 0.0) when every distance is 0
-            if ((best >> 32) != 0ull) {
-                const uint32_t low = (uint32_t)best;
-                index = (low & ~15u) | (15u - (low & 15u));
-            }
-            const uint32_t px = rgba[index];
-            float L, a, b;
-            linear100_to_lab(lut[px & 255u], lut[(px >> 8) & 255u], lut[(px >> 16) & 255u], L, a, b);
-            Centroid c; c.L = L; c.a = a; c.b = b; c.C = chroma(a, b);
-            cent[j] = c;
-        }
+        unsigned long long b = s_key[0];
+        for (uint32_t q = 1; q < kInitGrid / 64u; ++q) b = s_key[q] > b ? s_key[q] : b;
+        *key = b;
     }
 }
 
-hipError_t launch_init_pass_cells(const uint32_t *work, const uint32_t *tie, const float4 *lab_table,
-                                  const CellBounds *bounds, Centroid *cent, uint32_t j, float *dist,
-                                  unsigned long long *cell_key, unsigned long long *key,
-                                  const uint32_t *pick_rgba, const float *lut, hipStream_t st)
+size_t init_cells_bytes() { return sizeof(InitCell) * ((size_t)kCells + 2u * kInitGrid); }
+
+hipError_t launch_init_pass_cells(const uint32_t *work, const uint32_t *tie, const uint8_t *occ_bits, const float4 *lab_table,
+                                  const CellBounds *bounds, Centroid *cent, uint32_t j, int do_pass, float *dist,
+                                  void *init_cells, unsigned long long *band_key, const uint32_t *pick_rgba,
+                                  const float *lut, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_init_pass_cells, dim3(2048), dim3(kBlock), 0, st, work, tie, lab_table, bounds, cent, j, dist, cell_key);
-    hipLaunchKernelGGL(k_init_reduce_cells, dim3(1), dim3(1024), 0, st, cell_key, key, pick_rgba, lut, cent, j);
+    InitCell *cells = (InitCell *)init_cells, *slots = cells + kCells;
+    if (band_key) {
+        hipLaunchKernelGGL(k_init_fused<false>, dim3(kInitGrid), dim3(kInitBlock), 0, st, work, tie, occ_bits, lab_table, bounds, cent, j, 1,
+                           dist, cells, slots, pick_rgba, lut);
+        hipLaunchKernelGGL(k_init_reduce_slots, dim3(1), dim3(kInitGrid), 0, st, slots, j, band_key);
+    } else {
+        hipLaunchKernelGGL(k_init_fused<true>, dim3(kInitGrid), dim3(kInitBlock), 0, st, work, tie, occ_bits, lab_table, bounds, cent, j, do_pass,
+                           dist, cells, slots, pick_rgba, lut);
+    }
     return hipGetLastError();
 }
 
