@@ -126,7 +126,7 @@ struct ColourTable {
     // farthest-point init over the colours (built on demand by the init entry points)
     uint32_t *d_tie = nullptr;       // 2^24: 1 + largest low half of the init key per colour, 0 = unoccupied
     float *d_cdist = nullptr;        // 2^24 running min-distance per colour
-    void *d_init_cells = nullptr;    // init_cells_bytes(): the passes' cell records (largest key + its Lab) and slots
+    void *d_init_cells = nullptr;    // init_scratch_bytes(): the passes' cell records and slots
     bool tie_valid = false;          // d_tie describes (rgba, n, tie_first)
     bool bound_by_init = false;      // the binding was made by the initialisation of the current problem
     bool bound_by_caller = false;    // kmg_lloyd_bind_image / kmg_lloyd_prepare: the caller vouches for the buffer's contents
@@ -504,12 +504,12 @@ static int bind_image_impl(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, void
         }
     }
     if (want_tie) {
-        HIP_TRY(hipMemsetAsync(t.d_init_cells, 0, init_cells_bytes(), S(stream)));
         t.tie_valid = true;
         t.tie_first = first_index;
     }
     HIP_TRY(launch_cell_aggregates(t.d_hist, s->p->d_lab_table, t.d_agg, t.d_sub_agg, t.d_occ, S(stream)));
     HIP_TRY(launch_work_list(t.d_agg, t.d_work, S(stream)));       // dense list of the occupied cells (static for this image)
+    if (want_tie) HIP_TRY(launch_init_records(t.d_work, s->p->d_bounds, t.d_init_cells, S(stream)));   // an initialisation follows
     t.rgba = d_rgba;
     t.n = n;
     return KMG_OK;
@@ -618,6 +618,29 @@ extern "C" int kmg_debug_check_dither_masks(kmg_processor *p, const float *c4, u
     HIP_TRY(hipMemcpyAsync(&h, viol.ptr, sizeof h, hipMemcpyDeviceToHost, S(stream)));
     HIP_TRY(hipStreamSynchronize(S(stream)));
     *violations = h;
+    if (getenv("KMG_DITHER_STATS")) {
+        // distribution of the candidate counts: per (cell, Bayer index) slot, and per cell over its 16 slots together
+        const uint32_t words = mask_words(k);
+        std::vector<uint64_t> hm((size_t)kCells * 16u * words);
+        HIP_TRY(hipMemcpy(hm.data(), masks.ptr, hm.size() * 8, hipMemcpyDeviceToHost));
+        uint64_t hs[34] = {0}, hu[34] = {0};
+        for (uint32_t c = 0; c < kCells; ++c) {
+            std::vector<uint64_t> u(words, 0);
+            for (uint32_t b = 0; b < 16; ++b) {
+                uint32_t n = 0;
+                for (uint32_t w = 0; w < words; ++w) { const uint64_t m = hm[((size_t)c * 16 + b) * words + w]; u[w] |= m; n += (uint32_t)__builtin_popcountll(m); }
+                hs[n < 33 ? n : 33]++;
+            }
+            uint32_t n = 0;
+            for (uint32_t w = 0; w < words; ++w) n += (uint32_t)__builtin_popcountll(u[w]);
+            hu[n < 33 ? n : 33]++;
+        }
+        fprintf(stderr, "dither candidates per slot :");
+        for (int i = 0; i < 34; ++i) fprintf(stderr, " %.4f", (double)hs[i] / (kCells * 16.0));
+        fprintf(stderr, "\ndither candidates per cell (union of 16 slots):");
+        for (int i = 0; i < 34; ++i) fprintf(stderr, " %.4f", (double)hu[i] / kCells);
+        fprintf(stderr, "\n");
+    }
     return KMG_OK;
 }
 
@@ -929,7 +952,7 @@ static int init_over_colours(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, ui
     if (!t.d_tie) {
         hipError_t e = hipMalloc((void **)&t.d_tie, sizeof(uint32_t) << 24);
         if (e == hipSuccess) e = hipMalloc((void **)&t.d_cdist, sizeof(float) << 24);
-        if (e == hipSuccess) e = hipMalloc(&t.d_init_cells, init_cells_bytes());
+        if (e == hipSuccess) e = hipMalloc(&t.d_init_cells, init_scratch_bytes());
         if (e != hipSuccess)
             return fail(e == hipErrorOutOfMemory ? KMG_ERR_OUT_OF_MEMORY : KMG_ERR_HIP, "init tables allocation failed: %s", hipGetErrorString(e));
     }
@@ -970,7 +993,7 @@ extern "C" int kmg_lloyd_init_centroids(kmg_lloyd *s, const uint8_t *d_rgba, uin
         for (uint32_t j = 1; j < s->k + (colours ? 1u : 0u); ++j) {   // modules.rs:1211-1246
             if (colours) {
                 // launch j picks centroid j - 1 and runs pass j; launch k only picks
-                HIP_TRY(launch_init_pass_cells(s->tab.d_work, s->tab.d_tie, s->tab.d_occ, s->p->d_lab_table, s->p->d_bounds, s->d_cent, j,
+                HIP_TRY(launch_init_pass_cells(s->tab.d_tie, s->tab.d_occ, s->p->d_lab_table, s->d_cent, j,
                                                j < s->k ? 1 : 0, s->tab.d_cdist, s->tab.d_init_cells, nullptr, rgba, s->p->d_lut,
                                                S(stream)));
             } else {
@@ -1005,7 +1028,7 @@ extern "C" int kmg_lloyd_init_step(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t
         const ColourTable &t = s->tab;
         if (t.rgba != d_rgba || t.n != n_local || !t.tie_valid || t.tie_first != first_index)
             return fail(KMG_ERR_INVALID_ARGUMENT, "init_step: the band changed since step j = 1");
-        HIP_TRY(launch_init_pass_cells(t.d_work, t.d_tie, t.d_occ, s->p->d_lab_table, s->p->d_bounds, s->d_cent, j, 1, t.d_cdist,
+        HIP_TRY(launch_init_pass_cells(t.d_tie, t.d_occ, s->p->d_lab_table, s->d_cent, j, 1, t.d_cdist,
                                        t.d_init_cells, (unsigned long long *)d_key, nullptr, nullptr, S(stream)));
         return KMG_OK;
     }

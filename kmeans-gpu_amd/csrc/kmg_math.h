@@ -27,11 +27,17 @@ KMG_HD uint32_t float_to_bits(float f) { union { uint32_t u; float f; } c; c.f =
 // Correctly rounded binary32 cube root for x in [1e-3, 2] (exhaustively verified against
 // libm on that range, tests/test_host_math.py; the Lab conversion only feeds it
 // t in (0.008856, 1.01]).  rgb_to_lab.wgsl:45,50,55 `pow(t, 1.0/3.0)`.
-//   1. r ~ x^(-1/3): bit-level seed, three Newton steps r <- r*(4/3 - (x/3) r^3) in f32
+//   1. r ~ x^(-1/3): host -- bit-level seed, three Newton steps r <- r*(4/3 - (x/3) r^3) in f32;
+//      device -- v_log_f32 / v_exp_f32 (rel. error ~1e-6: the two binary64 steps below square it twice)
 //   2. y0 = x r^2, g = r^2/3 ~ 1/(3 y^2)
 //   3. two Newton steps y <- y + (x - y^3) g in f64, round once to f32
+// Both seeds end in the correctly rounded result, hence in the same float: tools/lab_rate.hip compares the two
+// on the device over every binary32 in [1e-3, 2] (0 differences), tests/test_gpu_parity.py over every colour.
 KMG_HD float cbrt_cr(float x)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * -0.33333334f);
+#else
     uint32_t ir = 0x54A21D2Au - float_to_bits(x) / 3u;
     float r = bits_to_float(ir);
     float xt = x * 0.33333334f;
@@ -39,6 +45,7 @@ KMG_HD float cbrt_cr(float x)
         float r3 = r * r * r;
         r = r * fmaf(-xt, r3, 1.3333334f);
     }
+#endif
     float rr = r * r;
     double yd = (double)(x * rr);
     double gd = (double)(rr * 0.33333334f);
@@ -48,6 +55,23 @@ KMG_HD float cbrt_cr(float x)
         yd = fma(res, gd, yd);
     }
     return (float)yd;
+}
+
+// x / c for one of the three white-point constants.  Device: q0 = x RN(1/c), one residual correction
+// q = q0 + (x - q0 c) RN(1/c) -- 3 operations instead of the ~10 of an IEEE division (~47 issue cycles on
+// gfx950), and the same float: tools/lab_rate.hip compares it with x / c over every binary32 in [2^-20, 128)
+// for each constant (0 differences; X, Y, Z are 0 or in [5e-4, 109]).
+template <int WHICH>
+KMG_HD float div_white(float x)
+{
+    constexpr float c = WHICH == 0 ? 95.0489f : (WHICH == 1 ? 100.0f : 108.8840f);
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr float rc = 1.0f / c;
+    const float q0 = x * rc;
+    return fmaf(fmaf(-q0, c, x), rc, q0);
+#else
+    return x / c;
+#endif
 }
 
 // lab_to_rgb.wgsl:21-35 `pow(c, 1.0 / 2.4)` for c in (0.0031308, 1): ONE definition shared by the device kernels
@@ -85,9 +109,9 @@ KMG_HD void linear100_to_lab(float r, float g, float b, float &L, float &A, floa
     float X = fmaf(0.1804375f, b, fmaf(0.3575761f, g, 0.4124564f * r));
     float Y = fmaf(0.0721750f, b, fmaf(0.7151522f, g, 0.2126729f * r));
     float Z = fmaf(0.9503041f, b, fmaf(0.1191920f, g, 0.0193339f * r));
-    float fx = lab_f(X / 95.0489f);
-    float fy = lab_f(Y / 100.0f);
-    float fz = lab_f(Z / 108.8840f);
+    float fx = lab_f(div_white<0>(X));
+    float fy = lab_f(div_white<1>(Y));
+    float fz = lab_f(div_white<2>(Z));
     L = fmaf(116.0f, fy, -16.0f);
     A = 500.0f * (fx - fy);
     B = 200.0f * (fy - fz);

@@ -134,21 +134,19 @@ hipError_t launch_work_list(const int64_t *agg, uint32_t *work, hipStream_t st);
 // largest low half of the init key among the pixels of each colour (first_index = image-wide index of
 // rgba[0], first_index + n <= 0xFFFFFFF0).
 hipError_t launch_tie_keys(const uint32_t *rgba, uint64_t n, uint64_t first_index, uint32_t *tie, hipStream_t st);
-// what a pass caches per cell: its largest key and the Lab of the colour holding it
-struct alignas(16) InitCell { unsigned long long key; uint32_t pad[2]; float4 lab; };
-static_assert(sizeof(InitCell) == 32, "InitCell layout");
-size_t init_cells_bytes();      // scratch of the passes (cell records + the workgroups' slots), zero before pass 1
+size_t init_scratch_bytes();    // scratch of the passes: one record per occupied cell + the workgroups' slots
+// once per initialisation, after the image is bound: the records of its occupied cells (work), keys zero
+hipError_t launch_init_records(const uint32_t *work, const CellBounds *bounds, void *init_scratch, hipStream_t st);
 // Launch j = 1 .. k of an initialisation (kmg_table.hip, k_init_fused): centroid j - 1 is picked from what
 // launch j - 1 left behind (j >= 2; j = 1: cent[0] is there already), then -- do_pass != 0, j < k -- the
-// running min-distance per colour is lowered against it for the cells it can reach (work: the bound image's
-// occupied cells; occ_bits: one bit per colour of it).  Launch k (do_pass = 0) only picks centroid k - 1.  pick_rgba / lut: pixel 0 and the
+// running min-distance per colour is lowered against it for the cells it can reach (occ_bits: one bit per colour
+// of the bound image).  Launch k (do_pass = 0) only picks centroid k - 1.  pick_rgba / lut: pixel 0 and the
 // sRGB table (Candidate(0, 0.0) when every distance is zero).
 // band_key != NULL (band of a sharded image): pass j against cent[j - 1] as it stands, then *band_key = the
 // band's largest key -- the pick happens between the launches, by the caller's all-reduce.
-hipError_t launch_init_pass_cells(const uint32_t *work, const uint32_t *tie, const uint8_t *occ_bits, const float4 *lab_table,
-                                  const CellBounds *bounds, Centroid *cent, uint32_t j, int do_pass, float *dist,
-                                  void *init_cells, unsigned long long *band_key, const uint32_t *pick_rgba,
-                                  const float *lut, hipStream_t st);
+hipError_t launch_init_pass_cells(const uint32_t *tie, const uint8_t *occ_bits, const float4 *lab_table, Centroid *cent,
+                                  uint32_t j, int do_pass, float *dist, void *init_scratch, unsigned long long *band_key,
+                                  const uint32_t *pick_rgba, const float *lut, hipStream_t st);
 // per iteration (kmg_cube.hip): candidates + sub-cell stage, colour scan, pair entries -- three launches.
 // work: [0] = number of occupied cells of the bound image, [1..] = their indices (built at bind time).
 // masks: the cell candidate masks, mask_words(k) u64 per cell; cell_work: cube_work_bytes() of scratch (the

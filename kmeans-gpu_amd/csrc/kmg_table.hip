@@ -387,30 +387,48 @@ __device__ __forceinline__ float cie94_lower_bound(const CellBounds &cb, float L
 
 // One init pass = ONE launch (kInitGrid workgroups of kInitBlock threads).
 //
-// cells[cell] caches the largest key of the cell's colours together with the Lab of the colour that holds it.  A
-// new centroid can only lower the running distances, and it cannot lower any distance of a cell whose lower bound
-// to it is not below the cell's largest running distance -- such a cell (most of them once a few dozen centroids
-// exist) is skipped and its cached record stays valid.
+// records[i] (i = position in the work list of the bound image's occupied cells) holds everything the test of one
+// cell needs: the cell, its Lab bounds, and the largest key of the cell's colours together with the Lab of the
+// colour that holds it.  A new centroid can only lower the running distances, and it cannot lower any distance
+// of a cell whose lower bound to it is not below the cell's largest running distance -- such a cell (most of them
+// once a few dozen centroids exist) is skipped and its cached key stays valid.
 //
 // Who does what.  The cells a centroid reaches are neighbours in colour space, i.e. runs in the work list: the
 // list is dealt out so that an 8 x 8 x 4 block of cells goes to 256 DIFFERENT workgroups (slot_work_index), each
 // workgroup tests its 128 cells with one lane per cell, pools the reached ones in LDS and its 16 waves take them
-// in turn -- a pass costs what the busiest workgroup costs, and that is ~1/16 of what the busiest wave cost when
-// every wave visited its own cells (measured: 28 -> ~12 us per pass once a few dozen centroids exist).
+// in turn -- a pass costs what the busiest workgroup costs, ~1/16 of what the busiest wave cost when every wave
+// visited its own cells (measured: 28 -> 11 us per pass once a few dozen centroids exist).
 // A visit reads the running distances, the occupancy byte and the Lab of the cell's colours; the tie keys (which
-// pixel of a colour) are only read for the colours that hold the cell's largest distance, normally one.
+// pixel of a colour) are only needed for the colours that hold the cell's largest distance, normally one.
+//
+// A late pass is a chain of memory round trips, not work, so the chain is kept short: the records are the only
+// thing the test reads (no work list -> cell -> bounds indirection) and are requested before the pick; a visit
+// requests everything at once, and when no wave has a second visit to hide the latency behind (<= 16 reached
+// cells in the workgroup) that includes the tie keys.
 //
 // The arg-max over the cells is split between two launches: every workgroup leaves the largest record it met in
 // slots[j & 1][workgroup]; the NEXT launch starts by reducing the kInitGrid slots (every workgroup does, 8 KiB
 // from L2) and so knows centroid j -- the Lab of the winning colour travels with the key, no pixel is fetched
 // (plus_plus_init.wgsl:172-181 `pick`; all distances zero: pixel 0).  Launch j therefore is
 //     [PICK: centroid j - 1 <- slots of launch j - 1]  ->  [pass against centroid j - 1 -> slots]
-// and launch k (do_pass = 0) only picks the last centroid: k launches for k - 1 passes instead of 2 (k - 1), and
-// the loads a pass starts with (work list, cell records, bounds) are in flight while the slots are reduced.
+// and launch k (do_pass = 0) only picks the last centroid: k launches for k - 1 passes instead of 2 (k - 1).
 // PICK = false (band of a sharded image: the pick is an all-reduce between two launches): centroid j - 1 is read
 // from cent[], and k_init_reduce_slots turns the slots into the band's key.
 constexpr uint32_t kInitGrid = 256, kInitBlock = 1024;
 static_assert(kInitGrid * (kInitBlock / 64) * 8 == kCells, "one test slot per cell");
+constexpr uint32_t kNoCell = 0xFFFFFFFFu;
+
+struct alignas(16) InitSlot { unsigned long long key; uint32_t pad[2]; float4 lab; };
+struct alignas(16) InitRecord {
+    unsigned long long key;        // largest key of the cell's colours (0 before the first pass)
+    uint32_t cell;                 // kNoCell: past the end of the work list
+    uint32_t pad;
+    float4 lab;                    // Lab of the colour that holds it
+    CellBounds cb;
+};
+static_assert(sizeof(InitSlot) == 32 && sizeof(InitRecord) == 32 + sizeof(CellBounds), "init record layout");
+
+size_t init_scratch_bytes() { return sizeof(InitRecord) * (size_t)kCells + sizeof(InitSlot) * 2u * kInitGrid; }
 
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 {
@@ -435,42 +453,56 @@ __device__ __forceinline__ uint32_t slot_work_index(uint32_t g, uint32_t q)
     return (r << 10) | (gg << 5) | b;
 }
 
+// once per initialisation: the records of the bound image's occupied cells, keys zero
+__global__ __launch_bounds__(kBlock) void k_init_records(const uint32_t *__restrict__ work,
+                                                         const CellBounds *__restrict__ bounds,
+                                                         InitRecord *__restrict__ records, InitSlot *__restrict__ slots)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    InitRecord r;
+    r.key = 0ull; r.cell = kNoCell; r.pad = 0u; r.lab = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    r.cb = bounds[0];
+    if (i < work[0]) { r.cell = work[1u + i]; r.cb = bounds[r.cell]; }
+    records[i] = r;
+    if (i < 2u * kInitGrid) { InitSlot o; o.key = 0ull; o.pad[0] = 0u; o.pad[1] = 0u; o.lab = r.lab; slots[i] = o; }
+}
+
+hipError_t launch_init_records(const uint32_t *work, const CellBounds *bounds, void *init_scratch, hipStream_t st)
+{
+    InitRecord *records = (InitRecord *)init_scratch;
+    hipLaunchKernelGGL(k_init_records, dim3(kCells / kBlock), dim3(kBlock), 0, st, work, bounds, records, (InitSlot *)(records + kCells));
+    return hipGetLastError();
+}
+
 template <bool PICK>
-__global__ __launch_bounds__(kInitBlock) void k_init_fused(const uint32_t *__restrict__ work,
-                                                           const uint32_t *__restrict__ tie,
+__global__ __launch_bounds__(kInitBlock) void k_init_fused(const uint32_t *__restrict__ tie,
                                                            const uint8_t *__restrict__ occ_bits,
                                                            const float4 *__restrict__ lab_table,
-                                                           const CellBounds *__restrict__ bounds,
                                                            Centroid *__restrict__ cent, uint32_t j, int do_pass,
-                                                           float *__restrict__ dist, InitCell *__restrict__ cells,
-                                                           InitCell *__restrict__ slots,
+                                                           float *__restrict__ dist, InitRecord *__restrict__ records,
+                                                           InitSlot *__restrict__ slots,
                                                            const uint32_t *__restrict__ rgba,
                                                            const float *__restrict__ lut)
 {
     __shared__ unsigned long long s_key[kInitBlock / 64];
     __shared__ float4 s_lab[kInitBlock / 64];
     __shared__ float4 s_cent;
-    __shared__ uint32_t s_list[(kInitBlock / 64) * 8], s_count;
+    __shared__ uint2 s_list[(kInitBlock / 64) * 8];                // (cell, its position in the work list)
+    __shared__ uint32_t s_count;
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 
-    // what the test needs and does not depend on the new centroid: requested before the pick
-    const uint32_t n_work = do_pass ? __builtin_amdgcn_readfirstlane(work[0]) : 0u;
+    // what the test needs does not depend on the new centroid: requested before the pick
     const uint32_t wi = slot_work_index(blockIdx.x, wv * 8u + (lane & 7u));
-    const bool tester = lane < 8u && wi < n_work;
-    uint32_t my_cell = 0;
-    InitCell rec; rec.key = 0ull; rec.lab = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    CellBounds cb = {};
-    if (tester) {
-        my_cell = work[1u + wi];
-        if (j != 1) { rec.key = cells[my_cell].key; rec.lab = cells[my_cell].lab; }
-        cb = bounds[my_cell];
-    }
+    const bool tester = do_pass && lane < 8u;
+    InitRecord rec;
+    rec.key = 0ull; rec.cell = kNoCell;
+    if (tester) rec = records[wi];
     if (threadIdx.x == 0) s_count = 0u;
 
     Centroid c;
     if (PICK && j >= 2u) {
         // centroid j - 1 = the largest record of the previous launch
-        const InitCell *prev = slots + ((j - 1u) & 1u) * kInitGrid;
+        const InitSlot *prev = slots + ((j - 1u) & 1u) * kInitGrid;
         unsigned long long key = 0ull;
         float4 lab = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (threadIdx.x < kInitGrid) { key = prev[threadIdx.x].key; lab = prev[threadIdx.x].lab; }
@@ -504,79 +536,75 @@ __global__ __launch_bounds__(kInitBlock) void k_init_fused(const uint32_t *__res
 
     unsigned long long run_key = 0ull;                             // the largest record this lane has met
     float4 run_lab = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (tester) {
+    if (tester && rec.cell != kNoCell) {
         bool reached = true;
         if (j != 1) {
             const float cell_max = __uint_as_float((uint32_t)(rec.key >> 32));
-            reached = cie94_lower_bound(cb, c.L, c.a, c.b, c.C) < cell_max;
+            reached = cie94_lower_bound(rec.cb, c.L, c.a, c.b, c.C) < cell_max;
         }
-        if (reached) s_list[atomicAdd(&s_count, 1u)] = my_cell;
+        if (reached) s_list[atomicAdd(&s_count, 1u)] = make_uint2(rec.cell, wi);
         else { run_key = rec.key; run_lab = rec.lab; }
     }
     __syncthreads();
     const uint32_t count = s_count;
+    const bool eager = count <= kInitBlock / 64u;                  // one visit per wave at most: nothing to hide a round trip behind
 
     // visits: wave wv takes entries wv, wv + 16, ...; the next cell's occupancy and distances are requested
     // (unconditionally: past the end the current cell again, unused) before the current cell's Lab values are waited for
     uint32_t idx = wv;
-    uint32_t cell = idx < count ? s_list[idx] : 0u;
-    uint32_t base = cell * kCellColours + lane * 8u;
-    uint32_t occ = occ_bits[(uint64_t)cell * 64u + lane];
-    float4 d0 = *reinterpret_cast<const float4 *>(dist + base), d1 = *reinterpret_cast<const float4 *>(dist + base + 4);
+    uint2 ent = idx < count ? s_list[idx] : make_uint2(0u, 0u);
+    uint32_t base = ent.x * kCellColours + lane * 8u;
+    uint32_t occ = occ_bits[(uint64_t)ent.x * 64u + lane];
+    float4 d0 = make_float4(1000000.0f, 1000000.0f, 1000000.0f, 1000000.0f), d1 = d0;     // kmeans++_calc_diff.wgsl:26-30
+    if (j != 1) { d0 = *reinterpret_cast<const float4 *>(dist + base); d1 = *reinterpret_cast<const float4 *>(dist + base + 4); }
     while (idx < count) {
         float4 v[8];
-        if (occ) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = lab_table[base + q];
-        }
+        for (int q = 0; q < 8; ++q) v[q] = lab_table[base + q];    // (a static table: every address is readable)
+        uint4 t0 = make_uint4(0u, 0u, 0u, 0u), t1 = t0;
+        if (eager) { t0 = *reinterpret_cast<const uint4 *>(tie + base); t1 = *reinterpret_cast<const uint4 *>(tie + base + 4); }
         const uint32_t idx_n = idx + kInitBlock / 64u;
-        const uint32_t cell_n = idx_n < count ? s_list[idx_n] : cell;
-        const uint32_t base_n = cell_n * kCellColours + lane * 8u;
-        const uint32_t occ_n = occ_bits[(uint64_t)cell_n * 64u + lane];
-        const float4 d0_n = *reinterpret_cast<const float4 *>(dist + base_n), d1_n = *reinterpret_cast<const float4 *>(dist + base_n + 4);
+        const uint2 ent_n = idx_n < count ? s_list[idx_n] : ent;
+        const uint32_t base_n = ent_n.x * kCellColours + lane * 8u;
+        const uint32_t occ_n = occ_bits[(uint64_t)ent_n.x * 64u + lane];
+        float4 d0_n = d0, d1_n = d1;                               // (j = 1: the map starts at 1e6, nothing to read)
+        if (j != 1) { d0_n = *reinterpret_cast<const float4 *>(dist + base_n); d1_n = *reinterpret_cast<const float4 *>(dist + base_n + 4); }
 
         float m[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
-        if (j == 1) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) m[q] = 1000000.0f;         // kmeans++_calc_diff.wgsl:26-30
-        }
         uint32_t md = 0u;                                          // largest distance (bits) among this lane's colours
-        if (occ) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                if ((occ >> q) & 1u) {
-                    m[q] = fminf(m[q], cie94(v[q].x, v[q].y, v[q].z, c.L, c.a, c.b));
-                    md = max(md, float_to_bits(m[q]));
-                }
+        for (int q = 0; q < 8; ++q) {
+            if ((occ >> q) & 1u) {
+                m[q] = fminf(m[q], cie94(v[q].x, v[q].y, v[q].z, c.L, c.a, c.b));
+                md = max(md, float_to_bits(m[q]));
             }
-            *reinterpret_cast<float4 *>(dist + base) = make_float4(m[0], m[1], m[2], m[3]);
-            *reinterpret_cast<float4 *>(dist + base + 4) = make_float4(m[4], m[5], m[6], m[7]);
-        } else if (j == 1) {
+        }
+        if (occ || j == 1) {
             *reinterpret_cast<float4 *>(dist + base) = make_float4(m[0], m[1], m[2], m[3]);
             *reinterpret_cast<float4 *>(dist + base + 4) = make_float4(m[4], m[5], m[6], m[7]);
         }
-        // the cell's key = (largest distance, largest low half among the colours that hold it): only those colours'
-        // tie keys are read
+        // the cell's key = (largest distance, largest low half among the colours that hold it)
         const uint32_t wmd = wave_max_u32(md);
         uint32_t low1 = 0u;                                        // 1 + low half; 0 = this lane does not hold the maximum
         float4 best_lab = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (occ && md == wmd) {
+            if (!eager) { t0 = *reinterpret_cast<const uint4 *>(tie + base); t1 = *reinterpret_cast<const uint4 *>(tie + base + 4); }
+            const uint32_t t[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                if (((occ >> q) & 1u) && float_to_bits(m[q]) == wmd) {
-                    const uint32_t t = tie[base + q];
-                    if (t > low1) { low1 = t; best_lab = v[q]; }
-                }
+                if (((occ >> q) & 1u) && float_to_bits(m[q]) == wmd && t[q] > low1) { low1 = t[q]; best_lab = v[q]; }
             }
         }
         const uint32_t wlow1 = wave_max_u32(low1);
         // (tie keys of occupied colours are distinct -- they name distinct pixels)
         if (low1 == wlow1 && low1 != 0u) {
-            InitCell o; o.key = ((unsigned long long)wmd << 32) | (unsigned long long)(wlow1 - 1u); o.pad[0] = 0u; o.pad[1] = 0u; o.lab = best_lab;
-            cells[cell] = o;
-            if (o.key >= run_key) { run_key = o.key; run_lab = best_lab; }
+            const unsigned long long key = ((unsigned long long)wmd << 32) | (unsigned long long)(wlow1 - 1u);
+            InitRecord *r = records + ent.y;
+            r->key = key;
+            r->lab = best_lab;
+            if (key >= run_key) { run_key = key; run_lab = best_lab; }
         }
-        idx = idx_n; cell = cell_n; base = base_n; occ = occ_n; d0 = d0_n; d1 = d1_n;
+        idx = idx_n; ent = ent_n; base = base_n; occ = occ_n; d0 = d0_n; d1 = d1_n;
     }
     // the largest record of the workgroup
     {
@@ -586,14 +614,14 @@ __global__ __launch_bounds__(kInitBlock) void k_init_fused(const uint32_t *__res
         if (threadIdx.x == 0) {
             uint32_t w = 0;
             for (uint32_t q = 1; q < kInitBlock / 64u; ++q) if (s_key[q] > s_key[w]) w = q;
-            InitCell o; o.key = s_key[w]; o.pad[0] = 0u; o.pad[1] = 0u; o.lab = s_lab[w];
+            InitSlot o; o.key = s_key[w]; o.pad[0] = 0u; o.pad[1] = 0u; o.lab = s_lab[w];
             slots[(j & 1u) * kInitGrid + blockIdx.x] = o;
         }
     }
 }
 
 // key = the largest slot key of pass j (band of a sharded image: the caller all-reduces it)
-__global__ __launch_bounds__(kInitGrid) void k_init_reduce_slots(const InitCell *__restrict__ slots, uint32_t j,
+__global__ __launch_bounds__(kInitGrid) void k_init_reduce_slots(const InitSlot *__restrict__ slots, uint32_t j,
                                                                  unsigned long long *__restrict__ key)
 {
     __shared__ unsigned long long s_key[kInitGrid / 64];
@@ -607,21 +635,19 @@ __global__ __launch_bounds__(kInitGrid) void k_init_reduce_slots(const InitCell 
     }
 }
 
-size_t init_cells_bytes() { return sizeof(InitCell) * ((size_t)kCells + 2u * kInitGrid); }
-
-hipError_t launch_init_pass_cells(const uint32_t *work, const uint32_t *tie, const uint8_t *occ_bits, const float4 *lab_table,
-                                  const CellBounds *bounds, Centroid *cent, uint32_t j, int do_pass, float *dist,
-                                  void *init_cells, unsigned long long *band_key, const uint32_t *pick_rgba,
-                                  const float *lut, hipStream_t st)
+hipError_t launch_init_pass_cells(const uint32_t *tie, const uint8_t *occ_bits, const float4 *lab_table, Centroid *cent,
+                                  uint32_t j, int do_pass, float *dist, void *init_scratch, unsigned long long *band_key,
+                                  const uint32_t *pick_rgba, const float *lut, hipStream_t st)
 {
-    InitCell *cells = (InitCell *)init_cells, *slots = cells + kCells;
+    InitRecord *records = (InitRecord *)init_scratch;
+    InitSlot *slots = (InitSlot *)(records + kCells);
     if (band_key) {
-        hipLaunchKernelGGL(k_init_fused<false>, dim3(kInitGrid), dim3(kInitBlock), 0, st, work, tie, occ_bits, lab_table, bounds, cent, j, 1,
-                           dist, cells, slots, pick_rgba, lut);
+        hipLaunchKernelGGL(k_init_fused<false>, dim3(kInitGrid), dim3(kInitBlock), 0, st, tie, occ_bits, lab_table, cent, j, 1,
+                           dist, records, slots, pick_rgba, lut);
         hipLaunchKernelGGL(k_init_reduce_slots, dim3(1), dim3(kInitGrid), 0, st, slots, j, band_key);
     } else {
-        hipLaunchKernelGGL(k_init_fused<true>, dim3(kInitGrid), dim3(kInitBlock), 0, st, work, tie, occ_bits, lab_table, bounds, cent, j, do_pass,
-                           dist, cells, slots, pick_rgba, lut);
+        hipLaunchKernelGGL(k_init_fused<true>, dim3(kInitGrid), dim3(kInitBlock), 0, st, tie, occ_bits, lab_table, cent, j, do_pass,
+                           dist, records, slots, pick_rgba, lut);
     }
     return hipGetLastError();
 }
@@ -973,7 +999,7 @@ __global__ __launch_bounds__(kBlock) void k_dither_pruned(const uint32_t *__rest
                                                           uint32_t row0, const Centroid *__restrict__ cent, uint32_t k,
                                                           const float *__restrict__ lut, const uint32_t *__restrict__ pal,
                                                           float threshold, const uint64_t *__restrict__ masks,
-                                                          uint32_t *__restrict__ out, int aligned)
+                                                          uint32_t *__restrict__ out, int aligned, uint32_t knock)
 {
     extern __shared__ float4 smem4[];
     const uint32_t kpad = (k + 3u) & ~3u;
@@ -1005,7 +1031,7 @@ __global__ __launch_bounds__(kBlock) void k_dither_pruned(const uint32_t *__rest
             const uint32_t cell = (((px[q] >> 3) & 31u) << 10) | (((px[q] >> 11) & 31u) << 5) | ((px[q] >> 19) & 31u);
             slot[q] = cell * 16u + bi;
 #pragma unroll
-            for (int u = 0; u < UP; ++u) m0[q][u] = masks[(uint64_t)slot[q] * words + u];   // gathers in flight during the Lab conversion
+            for (int u = 0; u < UP; ++u) m0[q][u] = (knock & 1u) ? (0x0000100000100001ull << (px[q] & 7u)) : masks[(uint64_t)slot[q] * words + u];   // gathers in flight during the Lab conversion
             gx += 1;
             if (gx == w) { gx = 0; gy += 1; }
         }
@@ -1013,7 +1039,8 @@ __global__ __launch_bounds__(kBlock) void k_dither_pruned(const uint32_t *__rest
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float L, a, b;
-            px_to_lab(s_lut, px[q], L, a, b);
+            if (knock & 4u) { L = s_lut[px[q] & 255u]; a = s_lut[(px[q] >> 8) & 255u]; b = s_lut[(px[q] >> 16) & 255u]; }
+            else px_to_lab(s_lut, px[q], L, a, b);
             const float off = s_off[slot[q] & 15u];
             L = L + off; a = a + off; b = b + off;                   // mix_colors.wgsl:72
             const PixelTerms pt = pixel_terms(L, a, b);
@@ -1030,7 +1057,7 @@ __global__ __launch_bounds__(kBlock) void k_dither_pruned(const uint32_t *__rest
                 }
             };
 #pragma unroll
-            for (int u = 0; u < UP; ++u) scan_word(m0[q][u], (uint32_t)u);
+            for (int u = 0; u < UP; ++u) scan_word((knock & 2u) ? 0ull : m0[q][u], (uint32_t)u);
             if (WORDS == 0)
                 for (uint32_t wd = 1; wd < words; ++wd) scan_word(masks[(uint64_t)slot[q] * words + wd], wd);
             if (kLiteralArgmin && second <= tie_threshold(best)) {
@@ -1055,7 +1082,7 @@ __global__ __launch_bounds__(kBlock) void k_dither_pruned(const uint32_t *__rest
                     for (uint32_t wd = 1; wd < words; ++wd) rescan_word(masks[(uint64_t)slot[q] * words + wd], wd);
                 idx = li;
             }
-            res[q] = pal[idx];
+            res[q] = (knock & 8u) ? idx : pal[idx];
         }
         store4_stream(out, i0, n, aligned != 0, res);
     }
@@ -1073,7 +1100,9 @@ hipError_t launch_dither_pruned(const uint32_t *rgba, uint32_t w, uint32_t rows,
     const int aligned = ((reinterpret_cast<uintptr_t>(rgba) & 15u) == 0 &&
                          (reinterpret_cast<uintptr_t>(out) & 15u) == 0) ? 1 : 0;
 #define KMG_DP(W) hipLaunchKernelGGL(k_dither_pruned<W>, dim3(grid), dim3(kBlock), lds, st, rgba, w, n, row0, cent, k, lut, \
-                                     pal, threshold, masks, out, aligned)
+                                     pal, threshold, masks, out, aligned, knock)
+    uint32_t knock = 0;
+    if (const char *e = getenv("KMG_DITHER_KNOCK")) knock = (uint32_t)atoi(e);
     const uint32_t n_words = (k + 63u) / 64u;
     if (n_words == 1) KMG_DP(1); else if (n_words == 2) KMG_DP(2); else if (n_words == 4) KMG_DP(4); else KMG_DP(0);
 #undef KMG_DP
