@@ -101,6 +101,7 @@ struct kmg_processor {
     CellBounds *d_sub_bounds;   // kSubCells static bounds of the 4x4x4 sub-cells
     float4 *d_lab_table;     // 2^24 x (L, a, b, C): Lab of every colour (256 MiB, built with d_bounds)
     std::vector<hipStream_t> idle_streams;   // streams of finished host-buffer calls, reused by the next ones (mu)
+    std::vector<std::pair<void *, size_t>> idle_arenas;   // scratch blocks of finished output passes (mu), see ArenaGuard
 };
 
 struct ProfEvent { int id; hipEvent_t e0, e1; };
@@ -225,6 +226,7 @@ extern "C" void kmg_processor_destroy(kmg_processor *p)
     if (p->d_sub_bounds) (void)hipFree(p->d_sub_bounds);
     if (p->d_lab_table) (void)hipFree(p->d_lab_table);
     for (hipStream_t st : p->idle_streams) (void)hipStreamDestroy(st);
+    for (auto &a : p->idle_arenas) (void)hipFree(a.first);
     delete p;
 }
 
@@ -309,6 +311,43 @@ struct StreamBuf {
     hipStream_t st = nullptr;
     ~StreamBuf() { if (ptr) (void)hipFreeAsync(ptr, st); }
     hipError_t alloc(size_t bytes, hipStream_t stream) { st = stream; return hipMallocAsync(&ptr, bytes, stream); }
+};
+
+// The scratch of one output pass (kmg_dev_apply): ONE block per call, taken from / returned to the processor's idle
+// list and grown on demand, carved up by take().  Calls on one processor may run concurrently (examples/parallel.rs),
+// so each holds its own block; the call synchronises its stream before it returns, so a returned block is idle.
+// (Stream-ordered pool allocations were measured here first: a hipFreeAsync of a 16 MiB buffer takes up to 0.37 ms
+// of host time on this runtime whatever the pool's release threshold -- more than the kernels of a replace pass.)
+struct ArenaGuard {
+    kmg_processor *p = nullptr;
+    void *base = nullptr;
+    size_t cap = 0, used = 0;
+    hipError_t acquire(kmg_processor *proc, size_t bytes)
+    {
+        p = proc;
+        {
+            std::lock_guard<std::mutex> lock(p->mu);
+            if (!p->idle_arenas.empty()) { base = p->idle_arenas.back().first; cap = p->idle_arenas.back().second; p->idle_arenas.pop_back(); }
+        }
+        if (cap >= bytes) return hipSuccess;
+        if (base) { (void)hipFree(base); base = nullptr; cap = 0; }
+        const hipError_t e = hipMalloc(&base, bytes);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    static size_t padded(size_t bytes) { return (bytes + 255u) & ~(size_t)255u; }
+    void *take(size_t bytes)
+    {
+        void *r = (uint8_t *)base + used;
+        used += padded(bytes);
+        return used <= cap ? r : nullptr;
+    }
+    ~ArenaGuard()
+    {
+        if (!base) return;
+        std::lock_guard<std::mutex> lock(p->mu);
+        p->idle_arenas.emplace_back(base, cap);
+    }
 };
 
 // the private stream of one host-buffer call (every call has its own, so calls on one processor run
@@ -1343,60 +1382,70 @@ extern "C" int kmg_dev_apply(kmg_processor *p, const uint8_t *d_rgba, uint32_t w
     bool dither = (mode == KMG_MODE_DITHER) && k > 1;                 // mix_colors.wgsl:104-108
     float thr = dither ? dither_threshold(c4, k) : 0.0f;
 
-    // every scratch buffer of the call is stream-ordered and dies with it (the call synchronises)
-    StreamBuf tables, masks, colour_labels, sub;
-    // centroid table and palette travel in one block (one allocation, one copy)
-    std::vector<uint8_t> staged(sizeof(Centroid) * k + sizeof(uint32_t) * (k + 1));
+    // which route, and how much scratch it needs: one block per call (ArenaGuard)
+    const uint64_t n_px = (uint64_t)w * rows;
+    const bool meld_masks_pay = mode == KMG_MODE_MELD && k >= 2 && meld_pruning_pays(n_px, k);
+    const bool replace_table = mode != KMG_MODE_MELD && !dither && replace_table_pays(n_px, k);
+    const bool dither_pruned = mode != KMG_MODE_MELD && dither && dither_pruning_pays(n_px, k);
+    const size_t tables_bytes = sizeof(Centroid) * k + sizeof(uint32_t) * (k + 1);
+    const size_t sub_bytes = sizeof(uint16_t) * (kSubCells + kCells) + sizeof(uint32_t) * kCells;
+    const size_t labels_bytes = (size_t)(k <= 256 ? 1 : 2) << 24;
+    const size_t masks_bytes = sizeof(uint64_t) * (size_t)kCells * mask_words(k) * (dither_pruned ? 16u : 1u);
+    size_t need = ArenaGuard::padded(tables_bytes);
+    if (meld_masks_pay || dither_pruned) need += ArenaGuard::padded(masks_bytes);
+    if (replace_table) need += ArenaGuard::padded(labels_bytes) + ArenaGuard::padded(sub_bytes) + ArenaGuard::padded(masks_bytes) +
+                               ArenaGuard::padded(cube_work_bytes());
+    ArenaGuard arena;
+    hipError_t e = arena.acquire(p, need);
+    // centroid table and palette travel in one block (one copy)
+    std::vector<uint8_t> staged(tables_bytes);
     memcpy(staged.data(), hc.data(), sizeof(Centroid) * k);
     memcpy(staged.data() + sizeof(Centroid) * k, pal.data(), sizeof(uint32_t) * (k + 1));
-    hipError_t e = tables.alloc(staged.size(), S(stream));
-    Centroid *d_cent = (Centroid *)tables.ptr;
-    uint32_t *d_pal = (uint32_t *)((uint8_t *)tables.ptr + sizeof(Centroid) * k);
-    if (e == hipSuccess) e = hipMemcpyAsync(tables.ptr, staged.data(), staged.size(), hipMemcpyHostToDevice, S(stream));
-    const uint64_t n_px = (uint64_t)w * rows;
+    Centroid *d_cent = nullptr;
+    uint32_t *d_pal = nullptr;
+    if (e == hipSuccess) {
+        d_cent = (Centroid *)arena.take(tables_bytes);
+        d_pal = (uint32_t *)((uint8_t *)d_cent + sizeof(Centroid) * k);
+        e = hipMemcpyAsync(d_cent, staged.data(), staged.size(), hipMemcpyHostToDevice, S(stream));
+    }
     int rc = KMG_OK;
     if (e != hipSuccess) {
         // fall through to the error report
     } else if (mode == KMG_MODE_MELD) {
         const uint64_t *meld_masks = nullptr;
-        if (k >= 2 && meld_pruning_pays(n_px, k)) {
+        if (meld_masks_pay) {
             // large image: per colour cell, the centroids that can be one of a pixel's two closest
             if ((rc = ensure_bounds(p, S(stream))) == KMG_OK) {
-                e = masks.alloc(sizeof(uint64_t) * (size_t)kCells * mask_words(k), S(stream));
-                if (e == hipSuccess) e = launch_meld_candidates(p->d_bounds, d_cent, k, (uint64_t *)masks.ptr, S(stream));
-                meld_masks = (const uint64_t *)masks.ptr;
+                uint64_t *m = (uint64_t *)arena.take(masks_bytes);
+                e = launch_meld_candidates(p->d_bounds, d_cent, k, m, S(stream));
+                meld_masks = m;
             }
         }
         if (rc == KMG_OK && e == hipSuccess)
             e = launch_meld((const uint32_t *)d_rgba, n_px, d_cent, k, p->d_lut, meld_masks, (uint32_t *)d_out, S(stream));
-    } else if (!dither && replace_table_pays(n_px, k)) {
+    } else if (replace_table) {
         // replace mode on a large image: the label of a pixel depends on its colour only, so label the
         // colour cube once (candidate masks + cube pass without sums) and emit pal[label] through the
         // label tables -- the same bit-exact machinery as the Lloyd label pass
         if ((rc = ensure_bounds(p, S(stream))) == KMG_OK) {
-            const size_t sub_bytes = sizeof(uint16_t) * (kSubCells + kCells) + sizeof(uint32_t) * kCells;
-            StreamBuf cwork;
-            e = colour_labels.alloc((size_t)(k <= 256 ? 1 : 2) << 24, S(stream));
-            if (e == hipSuccess) e = sub.alloc(sub_bytes, S(stream));
-            if (e == hipSuccess) e = masks.alloc(sizeof(uint64_t) * (size_t)kCells * mask_words(k), S(stream));
-            if (e == hipSuccess) e = cwork.alloc(cube_work_bytes(), S(stream));
+            void *colour_labels = arena.take(labels_bytes);
+            uint16_t *sub = (uint16_t *)arena.take(sub_bytes);
+            uint64_t *m = (uint64_t *)arena.take(masks_bytes);
+            void *cwork = arena.take(cube_work_bytes());
+            e = launch_cube(nullptr, nullptr, nullptr, nullptr, nullptr, p->d_bounds, p->d_sub_bounds, d_cent, k, p->d_lab_table,
+                            m, cwork, colour_labels, sub, nullptr, 0, 0u, nullptr, S(stream));
             if (e == hipSuccess)
-                e = launch_cube(nullptr, nullptr, nullptr, nullptr, nullptr, p->d_bounds, p->d_sub_bounds, d_cent, k, p->d_lab_table,
-                                (uint64_t *)masks.ptr, cwork.ptr, colour_labels.ptr, (uint16_t *)sub.ptr, nullptr, 0, 0u, nullptr,
-                                S(stream));
-            if (e == hipSuccess)
-                e = launch_labels((const uint32_t *)d_rgba, n_px, colour_labels.ptr, (const uint16_t *)sub.ptr, k, d_pal,
-                                  (uint32_t *)d_out, S(stream));
+                e = launch_labels((const uint32_t *)d_rgba, n_px, colour_labels, sub, k, d_pal, (uint32_t *)d_out, S(stream));
         }
-    } else if (dither && dither_pruning_pays(n_px, k)) {
+    } else if (dither_pruned) {
         // dither on a large image: candidate masks per (colour cell, Bayer index), then a scan of the
         // pixel's candidates only
         if ((rc = ensure_bounds(p, S(stream))) == KMG_OK) {
-            e = masks.alloc(sizeof(uint64_t) * (size_t)kCells * 16u * mask_words(k), S(stream));
-            if (e == hipSuccess) e = launch_offset_candidates(p->d_bounds, d_cent, k, thr, (uint64_t *)masks.ptr, S(stream));
+            uint64_t *m = (uint64_t *)arena.take(masks_bytes);
+            e = launch_offset_candidates(p->d_bounds, d_cent, k, thr, m, S(stream));
             if (e == hipSuccess)
-                e = launch_dither_pruned((const uint32_t *)d_rgba, w, rows, row0, d_cent, k, p->d_lut, d_pal, thr,
-                                         (const uint64_t *)masks.ptr, (uint32_t *)d_out, S(stream));
+                e = launch_dither_pruned((const uint32_t *)d_rgba, w, rows, row0, d_cent, k, p->d_lut, d_pal, thr, m,
+                                         (uint32_t *)d_out, S(stream));
         }
     } else {
         e = launch_apply((const uint32_t *)d_rgba, w, rows, row0, d_cent, k, p->d_lut, d_pal, dither, thr,
