@@ -1043,7 +1043,8 @@ __global__ __launch_bounds__(kBlock) void k_dither_pruned(const uint32_t *__rest
             else px_to_lab(s_lut, px[q], L, a, b);
             const float off = s_off[slot[q] & 15u];
             L = L + off; a = a + off; b = b + off;                   // mix_colors.wgsl:72
-            const PixelTerms pt = pixel_terms(L, a, b);
+            // (the weights only order the candidates: hardware reciprocals, near-ties are settled by the literal distance)
+            const PixelTerms pt = kLiteralArgmin ? pixel_terms_fast(L, a, b, chroma(a, b)) : pixel_terms(L, a, b);
             float best = cie94_key(pt, 10000.0f, 10000.0f, 10000.0f, sentinel_C), second = 3.0e38f;
             uint32_t idx = k;
             auto scan_word = [&](unsigned long long m, uint32_t wd) {
