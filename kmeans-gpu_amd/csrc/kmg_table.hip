@@ -1089,6 +1089,180 @@ __global__ __launch_bounds__(kBlock) void k_dither_pruned(const uint32_t *__rest
     }
 }
 
+// The same pass with the pixels of a tile SORTED by the length of their candidate list (k <= 256).
+// On noise the lanes of a wave see unrelated slots, and a wave's candidate loop runs to its longest list: ~12
+// iterations for 5.3 candidates on average (64-entry palette), ~2x the work that is needed.  Here a workgroup
+// converts a tile of 256 x PPT pixels, counting-sorts them in LDS by popcount(mask) (32 buckets: LDS atomics for the
+// rank, one wave for the prefix), and then scans them in sorted order -- the 64 pixels of a wave have (nearly) equal
+// list lengths; the results go back through LDS to their pixels' places so that the store stays coalesced.  What
+// is computed per pixel is exactly what k_dither_pruned computes: only the lane a pixel is scanned by changes.
+// LDS per workgroup: PPT x 256 x (12 B Lab + 8 B x WORDS mask + 2 B origin + 4 B result) = 26.5 KiB (WORDS = 1, PPT = 4).
+constexpr uint32_t kSortCounters = 512;      // 32 list lengths x 16 counters (= 2 per thread of a 256-thread workgroup)
+
+template <int WORDS, int PPT>
+__global__ __launch_bounds__(kBlock) void k_dither_sorted(const uint32_t *__restrict__ rgba, uint32_t w, uint64_t n,
+                                                          uint32_t row0, const Centroid *__restrict__ cent, uint32_t k,
+                                                          const float *__restrict__ lut, const uint32_t *__restrict__ pal,
+                                                          float threshold, const uint64_t *__restrict__ masks,
+                                                          uint32_t *__restrict__ out, int aligned)
+{
+    constexpr uint32_t TILE = kBlock * PPT;
+    extern __shared__ float4 smem4[];
+    const uint32_t kpad = (k + 3u) & ~3u;
+    float4 *s_cent = smem4;
+    unsigned long long *s_m = reinterpret_cast<unsigned long long *>(smem4 + kpad);    // [WORDS][TILE]
+    float *s_L = reinterpret_cast<float *>(s_m + (size_t)WORDS * TILE), *s_a = s_L + TILE, *s_b = s_a + TILE;
+    uint32_t *s_out = reinterpret_cast<uint32_t *>(s_b + TILE);
+    float *s_lut = reinterpret_cast<float *>(s_out + TILE);
+    float *s_off = s_lut + 256;
+    uint32_t *s_pal = reinterpret_cast<uint32_t *>(s_off + 16);                          // k + 1 output colours
+    uint32_t *s_hist = s_pal + ((k + 4u) & ~3u), *s_wsum = s_hist + kSortCounters;   // counts, then (in place) bases
+    uint16_t *s_org = reinterpret_cast<uint16_t *>(s_wsum + 4);
+    s_lut[threadIdx.x] = lut[threadIdx.x];
+    stage_centroids(s_cent, cent, k, kpad);
+    for (uint32_t i = threadIdx.x; i <= k; i += kBlock) s_pal[i] = pal[i];
+    if (threadIdx.x < 16) s_off[threadIdx.x] = threshold * (bayer16(threadIdx.x) / 16.0f - 0.5f);
+    for (uint32_t i = threadIdx.x; i < kSortCounters; i += kBlock) s_hist[i] = 0u;
+    __syncthreads();
+    const float sentinel_C = chroma(10000.0f, 10000.0f);
+    const uint32_t lane = threadIdx.x & 63u;
+
+    const uint64_t tiles = (n + TILE - 1) / TILE;
+    for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        // ---- 1. convert this thread's pixels, fetch their masks, rank them inside their bucket ----
+        const uint64_t i0 = tile * TILE + (uint64_t)threadIdx.x * PPT;
+        uint32_t px[4] = {0u, 0u, 0u, 0u};
+        if (PPT == 4) load4_stream(rgba, i0, n, aligned != 0, px);
+        else {
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) px[q] = i0 + q < n ? __builtin_nontemporal_load(rgba + i0 + q) : 0u;
+        }
+        const uint32_t i32 = (uint32_t)i0;                          // n < 2^32
+        uint32_t gy = i32 / w, gx = i32 - gy * w;
+        gy += row0;
+        unsigned long long m[PPT][WORDS];
+        uint32_t bi[PPT];
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            bi[q] = (gx & 3u) + ((gy & 3u) << 2);
+            const uint32_t cell = (((px[q] >> 3) & 31u) << 10) | (((px[q] >> 11) & 31u) << 5) | ((px[q] >> 19) & 31u);
+            const uint64_t slot = (uint64_t)cell * 16u + bi[q];
+#pragma unroll
+            for (int u = 0; u < WORDS; ++u) m[q][u] = i0 + q < n ? masks[slot * WORDS + u] : 0ull;
+            gx += 1;
+            if (gx == w) { gx = 0; gy += 1; }
+        }
+        float L[PPT], a[PPT], b[PPT];
+        uint32_t pc[PPT], rank[PPT];
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            px_to_lab(s_lut, px[q], L[q], a[q], b[q]);
+            const float off = s_off[bi[q]];
+            L[q] = L[q] + off; a[q] = a[q] + off; b[q] = b[q] + off;   // mix_colors.wgsl:72
+        }
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            uint32_t c = 0;
+#pragma unroll
+            for (int u = 0; u < WORDS; ++u) c += (uint32_t)__builtin_popcountll(m[q][u]);
+            // 16 counters per list length, chosen by the lane: 64 lanes with ~10 distinct lengths would otherwise queue
+            // up on ~10 addresses (same-address LDS atomics are served one after the other)
+            pc[q] = (c < 31u ? c : 31u) * 16u + (lane & 15u);
+            rank[q] = atomicAdd(&s_hist[pc[q]], 1u);
+        }
+        __syncthreads();
+        // ---- 2. counter bases (exclusive prefix over the 512 counters: two per thread), records to their sorted places ----
+        {
+            const uint32_t c0 = s_hist[2u * threadIdx.x], c1 = s_hist[2u * threadIdx.x + 1u];
+            uint32_t incl = c0 + c1;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
+                if ((int)lane >= o) incl += t;
+            }
+            if (lane == 63u) s_wsum[threadIdx.x >> 6] = incl;
+            __syncthreads();
+            uint32_t before = 0;
+#pragma unroll
+            for (uint32_t v = 0; v < kBlock / 64u; ++v) before += v < (threadIdx.x >> 6) ? s_wsum[v] : 0u;
+            const uint32_t excl = before + incl - (c0 + c1);
+            s_hist[2u * threadIdx.x] = excl;
+            s_hist[2u * threadIdx.x + 1u] = excl + c0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const uint32_t pos = s_hist[pc[q]] + rank[q];
+            s_L[pos] = L[q]; s_a[pos] = a[q]; s_b[pos] = b[q];
+#pragma unroll
+            for (int u = 0; u < WORDS; ++u) s_m[(size_t)u * TILE + pos] = m[q][u];
+            s_org[pos] = (uint16_t)(threadIdx.x * PPT + q);
+        }
+        __syncthreads();
+        s_hist[2u * threadIdx.x] = 0u;                              // the bases are consumed: counters of the next tile
+        s_hist[2u * threadIdx.x + 1u] = 0u;
+        // ---- 3. scan in sorted order: wave v of batch q takes places [q 256 + 64 v, + 64) ----
+#pragma unroll 1
+        for (int q = 0; q < PPT; ++q) {
+            const uint32_t pos = (uint32_t)q * kBlock + threadIdx.x;
+            const float pL = s_L[pos], pa = s_a[pos], pb = s_b[pos];
+            unsigned long long mm[WORDS];
+#pragma unroll
+            for (int u = 0; u < WORDS; ++u) mm[u] = s_m[(size_t)u * TILE + pos];
+            // (the weights only order the candidates: hardware reciprocals, near-ties are settled by the literal distance)
+            const PixelTerms pt = kLiteralArgmin ? pixel_terms_fast(pL, pa, pb, chroma(pa, pb)) : pixel_terms(pL, pa, pb);
+            float best = cie94_key(pt, 10000.0f, 10000.0f, 10000.0f, sentinel_C), second = 3.0e38f;
+            uint32_t idx = k;
+#pragma unroll
+            for (int u = 0; u < WORDS; ++u) {
+                unsigned long long mw = mm[u];
+                while (mw) {
+                    const uint32_t j = (uint32_t)u * 64u + (uint32_t)__builtin_ctzll(mw);
+                    mw &= mw - 1;
+                    const float4 c = s_cent[j];
+                    const float d = cie94_key(pt, c.x, c.y, c.z, c.w);
+                    if (kLiteralArgmin) second = __builtin_amdgcn_fmed3f(d, best, second);
+                    if (d < best) { best = d; idx = j; }
+                }
+            }
+            if (kLiteralArgmin && second <= tie_threshold(best)) {
+                // near-tie (kmg_math.h): mix_colors.wgsl:73-80 with the literal distance, the sentinel first
+                const float thr = tie_threshold(best);
+                float lb = cie94_c(pt.L, pt.a, pt.b, pt.C, 10000.0f, 10000.0f, 10000.0f, sentinel_C);
+                uint32_t li = k;
+#pragma unroll
+                for (int u = 0; u < WORDS; ++u) {
+                    unsigned long long mw = mm[u];
+                    while (mw) {
+                        const uint32_t j = (uint32_t)u * 64u + (uint32_t)__builtin_ctzll(mw);
+                        mw &= mw - 1;
+                        const float4 c = s_cent[j];
+                        if (cie94_key(pt, c.x, c.y, c.z, c.w) <= thr) {
+                            const float d = cie94_c(pt.L, pt.a, pt.b, pt.C, c.x, c.y, c.z, c.w);
+                            if (d < lb) { lb = d; li = j; }
+                        }
+                    }
+                }
+                idx = li;
+            }
+            s_out[s_org[pos]] = s_pal[idx];
+        }
+        __syncthreads();
+        // ---- 4. results back in pixel order ----
+        if (PPT == 4) {
+            const uint4 r = *reinterpret_cast<const uint4 *>(s_out + threadIdx.x * 4u);
+            const uint32_t res[4] = {r.x, r.y, r.z, r.w};
+            store4_stream(out, i0, n, aligned != 0, res);
+        } else {
+#pragma unroll
+            for (int q = 0; q < PPT; ++q)
+                if (i0 + q < n) __builtin_nontemporal_store(s_out[threadIdx.x * PPT + q], out + i0 + q);
+        }
+        // (the next tile's first LDS writes are its ranks: the counters were cleared before the last barrier; its records
+        // and results are rewritten only after its own barriers)
+    }
+}
+
 hipError_t launch_dither_pruned(const uint32_t *rgba, uint32_t w, uint32_t rows, uint32_t row0, const Centroid *cent,
                                 uint32_t k, const float *lut, const uint32_t *pal, float threshold,
                                 const uint64_t *masks, uint32_t *out, hipStream_t st)
@@ -1105,6 +1279,23 @@ hipError_t launch_dither_pruned(const uint32_t *rgba, uint32_t w, uint32_t rows,
     uint32_t knock = 0;
     if (const char *e = getenv("KMG_DITHER_KNOCK")) knock = (uint32_t)atoi(e);
     const uint32_t n_words = (k + 63u) / 64u;
+    static const bool sorted = !(getenv("KMG_DITHER_SORT") && atoi(getenv("KMG_DITHER_SORT")) == 0);
+    if (sorted && !knock && n_words == 1u) {
+        // the pixels of a tile sorted by candidate-list length (k_dither_sorted): 8192^2, 64-entry palette 0.95 -> 0.88 ms.
+        // With more mask words the records outgrow the LDS a well-occupied CU can give them (k = 256, 2 pixels per
+        // thread: 1.56 -> 1.72 ms), so those keep k_dither_pruned.
+        const uint32_t ppt = n_words == 4u ? 2u : 4u;
+        const uint32_t tile = kBlock * ppt;
+        const uint64_t tiles_s = (n + tile - 1) / tile;
+        const uint32_t grid_s = (uint32_t)(tiles_s < 4096 ? (tiles_s ? tiles_s : 1) : 4096);
+        const size_t lds_s = sizeof(float4) * kpad + (size_t)tile * (8u * n_words + 12u + 4u + 2u) + (256 + 16) * sizeof(float) +
+                             sizeof(uint32_t) * (((k + 4u) & ~3u) + 512u + 4u);
+#define KMG_DS(W, P) hipLaunchKernelGGL((k_dither_sorted<W, P>), dim3(grid_s), dim3(kBlock), lds_s, st, rgba, w, n, row0, cent, k, \
+                                        lut, pal, threshold, masks, out, aligned)
+        if (n_words == 1) KMG_DS(1, 4); else if (n_words == 2) KMG_DS(2, 4); else KMG_DS(4, 2);
+#undef KMG_DS
+        return hipGetLastError();
+    }
     if (n_words == 1) KMG_DP(1); else if (n_words == 2) KMG_DP(2); else if (n_words == 4) KMG_DP(4); else KMG_DP(0);
 #undef KMG_DP
     return hipGetLastError();
