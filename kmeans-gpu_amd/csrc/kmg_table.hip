@@ -885,7 +885,7 @@ hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_la
 // The dithered colour of a pixel is Lab(colour) + off, off = one of the 16 Bayer offsets of the
 // pass, so its nearest centroid depends on (colour, Bayer index) only.  For every (cell, Bayer
 // index) k_offset_candidates builds the same kind of conservative candidate mask as
-// k_cell_candidates, from the static cell bounds shifted by the offset; the output pass then
+// k_cube_stage (kmg_cube.hip), from the static cell bounds shifted by the offset; the output pass then
 // scans, per pixel, only the candidates of its (cell, Bayer index) instead of all k centroids.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float bayer16(uint32_t i)            // mix_colors.wgsl:13-16
