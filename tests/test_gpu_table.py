@@ -758,3 +758,41 @@ def test_cfg5_full_size_find_dither(torch_cuda, oracle, monkeypatch):
     head = rgba[: rows * w].cpu().numpy().reshape(rows, w, 4)
     want = oracle.find(head, pal, oracle.MODE_DITHER)
     assert np.array_equal(outs["table"][: rows * w].cpu().numpy().reshape(rows, w, 4), want)
+
+
+@pytest.mark.gpu
+def test_concurrent_output_passes_share_one_processor(torch_cuda, oracle, monkeypatch):
+    """core/examples/parallel.rs: calls on one ImageProcessor run concurrently.  The table / pruned output passes take
+    their scratch from per-processor blocks (one per call in flight): six threads, three modes, two palettes on the same
+    processor must return what the same calls return one after the other."""
+    import threading
+    import kmeans_gpu_amd as kg
+    monkeypatch.setenv("KMG_STRATEGY", "table")
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, (384, 512, 4), dtype=np.uint8)
+    img[..., 3] = 255
+    pals = [rng.integers(0, 256, (k, 4), dtype=np.uint8) for k in (24, 200)]
+    for p in pals:
+        p[:, 3] = 255
+    proc = kg.ImageProcessor(shrink_max_dim=0)
+    jobs = [(pi, mode) for pi in range(2) for mode in (kg.ReduceMode.Replace, kg.ReduceMode.Dither, kg.ReduceMode.Meld)]
+    serial = {j: proc.find(img, pals[j[0]], j[1]) for j in jobs}
+    results, errors = {}, []
+
+    def work(j):
+        try:
+            for _ in range(3):
+                results[j] = proc.find(img, pals[j[0]], j[1])
+        except Exception as e:      # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(j,)) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors
+    for j in jobs:
+        assert np.array_equal(results[j], serial[j]), j
+    want = oracle.find(img, pals[0], int(kg.ReduceMode.Dither))
+    assert np.array_equal(serial[(0, kg.ReduceMode.Dither)], want)
