@@ -345,6 +345,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # what a plain device-to-device copy of the same 2 x 4 B/px reaches on THIS box, for the "achievable" column
+    copy_gbps = None
+    if rank == 0:
+        scratch = torch.empty_like(labels)
+        for _ in range(2):
+            scratch.copy_(labels)
+        torch.cuda.synchronize()
+        t_c = time.perf_counter()
+        for _ in range(5):
+            scratch.copy_(labels)
+        torch.cuda.synchronize()
+        copy_gbps = 2.0 * labels.numel() * 4 * 5 / (time.perf_counter() - t_c) / 1e9
+        del scratch
+
     if rank == 0:
         total_pixels = n_local * world
         height = rows * world
@@ -384,6 +398,7 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS,
                          "peak_achievable": HBM_ACHIEVABLE_GBPS, "frac_achievable": achieved / HBM_ACHIEVABLE_GBPS,
+                         "copy_measured": copy_gbps,      # torch copy_ of the label map on this box, read + write, GB/s
                          "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": abytes,
                          # the whole iteration (all kernels, gaps, collective): 8 B/px over ms_per_step
