@@ -474,6 +474,63 @@ hipError_t launch_init_records(const uint32_t *work, const CellBounds *bounds, v
     return hipGetLastError();
 }
 
+// One PART of a cell's visit: 64 lanes x N colours (N = 4: a half, N = 2: a quarter of the cell).  When a workgroup has
+// few cells to visit, several of its 16 waves share a cell: the literal CIE94 of a lane's colours is a serial chain
+// (~250 operations per colour), so 2 colours per lane instead of 8 take a quarter of the time.  The part's key is the
+// largest key of its colours (distance, then low half), exactly as for a whole cell; the cell's key is the largest
+// part key.  Returns the key in the lane that holds it (0 elsewhere) and that colour's Lab.
+template <int N>
+__device__ __forceinline__ unsigned long long init_visit_part(uint32_t cell, uint32_t part, uint32_t lane, uint32_t j, const Centroid &c,
+                                                              const uint32_t *__restrict__ tie, const uint8_t *__restrict__ occ_bits,
+                                                              const float4 *__restrict__ lab_table, float *__restrict__ dist,
+                                                              float4 &lab_out)
+{
+    constexpr uint32_t kParts = 8u / N;
+    const uint32_t within = part * (kCellColours / kParts) + lane * N;          // first colour of this lane inside the cell
+    const uint32_t base = cell * kCellColours + within;
+    const uint32_t occ = ((uint32_t)occ_bits[(uint64_t)cell * 64u + (within >> 3)] >> (within & 7u)) & ((1u << N) - 1u);
+    float4 v[N];
+#pragma unroll
+    for (int q = 0; q < N; ++q) v[q] = lab_table[base + q];
+    uint32_t t[N];
+    float m[N];
+    if (N == 4) {
+        const uint4 tt = *reinterpret_cast<const uint4 *>(tie + base);
+        t[0] = tt.x; t[1] = tt.y; t[2 % N] = tt.z; t[3 % N] = tt.w;
+        float4 d = make_float4(1000000.0f, 1000000.0f, 1000000.0f, 1000000.0f);   // kmeans++_calc_diff.wgsl:26-30
+        if (j != 1) d = *reinterpret_cast<const float4 *>(dist + base);
+        m[0] = d.x; m[1] = d.y; m[2 % N] = d.z; m[3 % N] = d.w;
+    } else {
+        const uint2 tt = *reinterpret_cast<const uint2 *>(tie + base);
+        t[0] = tt.x; t[1] = tt.y;
+        float2 d = make_float2(1000000.0f, 1000000.0f);
+        if (j != 1) d = *reinterpret_cast<const float2 *>(dist + base);
+        m[0] = d.x; m[1] = d.y;
+    }
+    uint32_t md = 0u;
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        if ((occ >> q) & 1u) {
+            m[q] = fminf(m[q], cie94(v[q].x, v[q].y, v[q].z, c.L, c.a, c.b));
+            md = max(md, float_to_bits(m[q]));
+        }
+    }
+    if (occ || j == 1) {
+        if (N == 4) *reinterpret_cast<float4 *>(dist + base) = make_float4(m[0], m[1], m[2 % N], m[3 % N]);
+        else *reinterpret_cast<float2 *>(dist + base) = make_float2(m[0], m[1]);
+    }
+    const uint32_t wmd = wave_max_u32(md);
+    uint32_t low1 = 0u;
+    lab_out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (occ && md == wmd) {
+#pragma unroll
+        for (int q = 0; q < N; ++q)
+            if (((occ >> q) & 1u) && float_to_bits(m[q]) == wmd && t[q] > low1) { low1 = t[q]; lab_out = v[q]; }
+    }
+    const uint32_t wlow1 = wave_max_u32(low1);
+    return (low1 == wlow1 && low1 != 0u) ? (((unsigned long long)wmd << 32) | (unsigned long long)(wlow1 - 1u)) : 0ull;
+}
+
 template <bool PICK>
 __global__ __launch_bounds__(kInitBlock) void k_init_fused(const uint32_t *__restrict__ tie,
                                                            const uint8_t *__restrict__ occ_bits,
@@ -489,6 +546,8 @@ __global__ __launch_bounds__(kInitBlock) void k_init_fused(const uint32_t *__res
     __shared__ float4 s_cent;
     __shared__ uint2 s_list[(kInitBlock / 64) * 8];                // (cell, its position in the work list)
     __shared__ uint32_t s_count;
+    __shared__ unsigned long long s_pkey[kInitBlock / 64];         // split visits: the waves' part keys
+    __shared__ float4 s_plab[kInitBlock / 64];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 
     // what the test needs does not depend on the new centroid: requested before the pick
@@ -549,9 +608,34 @@ __global__ __launch_bounds__(kInitBlock) void k_init_fused(const uint32_t *__res
     const uint32_t count = s_count;
     const bool eager = count <= kInitBlock / 64u;                  // one visit per wave at most: nothing to hide a round trip behind
 
+    if (count <= 8u) {
+        // few cells: 4 (count <= 4) or 2 waves per cell, each a part of its colours (init_visit_part)
+        const uint32_t shift = count <= 4u ? 2u : 1u;              // log2(waves per cell)
+        const uint32_t my = wv >> shift, part = wv & ((1u << shift) - 1u);
+        unsigned long long pk = 0ull;
+        float4 pl = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (my < count) {
+            const uint32_t cell = s_list[my].x;
+            pk = shift == 2u ? init_visit_part<2>(cell, part, lane, j, c, tie, occ_bits, lab_table, dist, pl)
+                             : init_visit_part<4>(cell, part, lane, j, c, tie, occ_bits, lab_table, dist, pl);
+        }
+        if (lane == 0u) s_pkey[wv] = 0ull;
+        if (pk != 0ull) { s_pkey[wv] = pk; s_plab[wv] = pl; }     // (same wave, after the 0: LDS writes of a wave stay in order)
+        __syncthreads();
+        if (part == 0u && my < count && lane == 0u) {
+            uint32_t w = wv;
+            for (uint32_t q = 1; q < (1u << shift); ++q) if (s_pkey[wv + q] > s_pkey[w]) w = wv + q;
+            const unsigned long long key = s_pkey[w];
+            const float4 lab = s_plab[w];
+            InitRecord *r = records + s_list[my].y;
+            r->key = key;
+            r->lab = lab;
+            if (key >= run_key) { run_key = key; run_lab = lab; }
+        }
+    }
     // visits: wave wv takes entries wv, wv + 16, ...; the next cell's occupancy and distances are requested
     // (unconditionally: past the end the current cell again, unused) before the current cell's Lab values are waited for
-    uint32_t idx = wv;
+    uint32_t idx = count <= 8u ? count : wv;
     uint2 ent = idx < count ? s_list[idx] : make_uint2(0u, 0u);
     uint32_t base = ent.x * kCellColours + lane * 8u;
     uint32_t occ = occ_bits[(uint64_t)ent.x * 64u + lane];
