@@ -117,6 +117,50 @@ def other_distributions(proc, k, n_pixels, stream, steps=10):
     return extra
 
 
+def cfg4_rank_share(proc, k, n_pixels, stream, steps=5):
+    """BASELINE config 4 (16 images of 8192 x 8192 over 8 GPUs) as this build places it: WHOLE images per GPU, zero
+    collectives (sharded.PlacedBatch).  One rank's share = two images; time of one Lloyd iteration of both, label maps
+    included.  Not part of `value`."""
+    import numpy as np
+    import torch
+    import kmeans_gpu_amd as kg
+    from kmeans_gpu_amd import synth
+    from kmeans_gpu_amd.sharded import PlacedBatch, images_of_rank
+    mine = images_of_rank(16, 0, 8)
+    images = [synth.uniform_rgba_torch(0x5EED0400 + i, n_pixels, device="cuda") for i in mine]
+    labels = [torch.empty(n_pixels, dtype=torch.int32, device="cuda") for _ in mine]
+    lloyds, split = [], []
+    for img in images:
+        sel = img[(torch.arange(k, device="cuda") * (n_pixels // k))].contiguous()
+        lab = torch.empty((k, 3), dtype=torch.float32, device="cuda")
+        proc.rgb_to_lab(sel.data_ptr(), k, lab.data_ptr(), stream)
+        torch.cuda.synchronize()
+        cent = np.ones((k, 4), np.float32)
+        cent[:, :3] = lab.cpu().numpy()
+        s = kg.Lloyd(proc, k)
+        s.set_centroids(cent, stream)
+        split.append(s.prepare(img.data_ptr(), n_pixels, True, stream) == "table")
+        lloyds.append(s)
+    batch = PlacedBatch(lloyds, k, images, labels, stream=stream, split_labels=split)
+    for loop in batch.loops:
+        loop.pipeline = False
+        loop.prime()
+        loop.iterate()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(steps):
+        for loop in batch.loops:
+            loop.iterate()
+    for loop in batch.loops:
+        loop.flush()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t) / steps * 1e3
+    for s in lloyds:
+        s.close()
+    return {"cfg4_images_per_rank": len(mine), "cfg4_rank_share_ms_per_iteration": ms,
+            "cfg4_collectives_per_iteration": 0}
+
+
 def output_pass_timing(proc, rgba, n_pixels, stream, sh=None):
     """Not part of `value`: the other kernel family of the path, BASELINE config 5 -- find + ordered
     dither with the 64-entry resurrect_64 palette on the same 8192x8192 pixels (8 B/px algorithmic:
@@ -179,6 +223,7 @@ def output_pass_timing(proc, rgba, n_pixels, stream, sh=None):
         s3.close()
         del labels, out
         extra.update(other_distributions(proc, k3, n_pixels, stream))
+        extra.update(cfg4_rank_share(proc, k3, n_pixels, stream))
     except Exception as e:      # the extras must never break the benchmark line
         extra["error"] = repr(e)
     return extra
