@@ -194,6 +194,12 @@ KMG_API int kmg_debug_check_meld_masks(kmg_processor *p, const float *centroids4
  * bound image whose label tables are current (an assign pass ran since the last centroid change) this
  * is just the label-gather pass.                                                                 */
 KMG_API int kmg_lloyd_labels(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n_pixels, uint32_t *d_labels, void *stream);
+/* The label pass of the colour-table strategy (k <= 256) runs one 1024-thread workgroup per compute unit for its whole
+ * duration.  A kernel launched beside it on another stream -- the RCCL all-reduce of the sums that a sharded loop issues
+ * asynchronously: 256 threads, 20 KiB LDS, 280 registers per lane -- finds no CU it fits on and would run
+ * BEHIND the pass.  n_cus > 0 leaves that many CUs without a label workgroup (n_cus / 256 of the pass's throughput) so
+ * that the collective runs beside it.  0 (default): all CUs.                                                          */
+KMG_API int kmg_lloyd_reserve_cus(kmg_lloyd *s, uint32_t n_cus);
 
 /* The two halves of kmg_lloyd_assign_accumulate, for callers that time or batch them:
  * _assign_partials runs the fused per-pixel kernel (labels + per-workgroup partial sums kept in

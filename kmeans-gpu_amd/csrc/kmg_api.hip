@@ -146,6 +146,7 @@ struct kmg_lloyd {
     uint64_t dist_cap;
     uint32_t last_rows;          // rows of d_partials written by the last assign pass
     bool init_colours;           // the running sharded init (kmg_lloyd_init_step) walks colours, not pixels
+    uint32_t reserve_cus = 0;    // CUs the label pass leaves free (kmg_lloyd_reserve_cus)
     bool pooled;                 // workspace came from the stream-ordered pool of `pool_stream` (internal per-call objects)
     hipStream_t pool_stream;
     ColourTable tab;
@@ -855,7 +856,7 @@ static int table_assign(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_
                                                d_sums, rows, 0u, nullptr, st));
     t.tables_valid = true;
     if (d_labels)
-        PROF_LAUNCH(s, KMG_K_LABELS, st, launch_labels((const uint32_t *)d_rgba, n, t.d_colour_labels, t.d_sub, s->k, nullptr, d_labels, st));
+        PROF_LAUNCH(s, KMG_K_LABELS, st, launch_labels((const uint32_t *)d_rgba, n, t.d_colour_labels, t.d_sub, s->k, nullptr, d_labels, st, s->reserve_cus));
     return KMG_OK;
 }
 
@@ -1151,6 +1152,13 @@ extern "C" int kmg_lloyd_assign_partials(kmg_lloyd *s, const uint8_t *d_rgba, ui
     return assign_pass(s, d_rgba, n, d_labels, true, S(stream));
 }
 
+extern "C" int kmg_lloyd_reserve_cus(kmg_lloyd *s, uint32_t n_cus)
+{
+    if (!s || n_cus > 128u) return fail(KMG_ERR_INVALID_ARGUMENT, "bad reserve_cus arguments");
+    s->reserve_cus = n_cus;
+    return KMG_OK;
+}
+
 extern "C" int kmg_lloyd_labels(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_t *d_labels, void *stream)
 {
     if (!s || !d_rgba || !d_labels || n == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad labels arguments");
@@ -1159,7 +1167,7 @@ extern "C" int kmg_lloyd_labels(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n,
         int rc_;
         if ((rc_ = side_flush(s, S(stream))) != KMG_OK) return rc_;
         PROF_LAUNCH(s, KMG_K_LABELS, S(stream), launch_labels((const uint32_t *)d_rgba, n, s->tab.d_colour_labels,
-                                                              s->tab.d_sub, s->k, nullptr, d_labels, S(stream)));
+                                                              s->tab.d_sub, s->k, nullptr, d_labels, S(stream), s->reserve_cus));
         return KMG_OK;
     }
     PROF_LAUNCH(s, KMG_K_ASSIGN, S(stream), launch_assign((const uint32_t *)d_rgba, n, s->d_cent, s->k, s->p->d_lut,
@@ -1287,7 +1295,7 @@ extern "C" int kmg_lloyd_iterate(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n
     HIP_TRY(hipEventRecord(s->ev_cube, st));
     HIP_TRY(hipStreamWaitEvent(s->side, s->ev_cube, 0));
     PROF_LAUNCH(s, KMG_K_LABELS, s->side, launch_labels((const uint32_t *)d_rgba, n, t.d_colour_labels, t.d_sub, s->k, nullptr,
-                                                        d_labels, s->side));
+                                                        d_labels, s->side, s->reserve_cus));
     HIP_TRY(hipEventRecord(s->ev_lab[s->set], s->side));
     s->lab_pending[s->set] = true;
     return KMG_OK;
@@ -1344,7 +1352,7 @@ extern "C" int kmg_lloyd_run(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, ui
     }
     if (table && d_labels)   // the label tables of the last pass belong to the final centroids
         PROF_LAUNCH(s, KMG_K_LABELS, S(stream), launch_labels((const uint32_t *)d_rgba, n, s->tab.d_colour_labels,
-                                                              s->tab.d_sub, s->k, nullptr, d_labels, S(stream)));
+                                                              s->tab.d_sub, s->k, nullptr, d_labels, S(stream), s->reserve_cus));
     HIP_TRY(hipStreamSynchronize(S(stream)));
     if (table && !callers) { s->tab.rgba = nullptr; s->tab.tables_valid = false; }
     if (iterations) *iterations = it < o.max_iterations ? it : o.max_iterations - 1;

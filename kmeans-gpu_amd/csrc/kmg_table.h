@@ -164,9 +164,10 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
                        uint16_t *sub_table, int64_t *sums, uint32_t n_rows, uint32_t flags, unsigned long long *stats,
                        hipStream_t st);
 // pal == NULL: labels[i] = label; pal != NULL: labels[i] = pal[label] (RGBA8 output of replace mode).
+// reserve_cus: compute units left without a workgroup of the k <= 256 label pass (kmg_lloyd_reserve_cus)
 hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_labels,
                          const uint16_t *sub_table, uint32_t k, const uint32_t *pal, uint32_t *labels,
-                         hipStream_t st);
+                         hipStream_t st, uint32_t reserve_cus = 0);
 
 // ordered-dither output pass with candidate pruning: masks[(cell * 16 + Bayer index) * words + w] are the
 // centroids that can be the arg-min of Lab(colour) + threshold * (M[Bayer index] / 16 - 0.5) for any

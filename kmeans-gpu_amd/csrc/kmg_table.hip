@@ -942,11 +942,12 @@ __global__ __launch_bounds__(kLabelBlock) void k_labels_pairs(const uint32_t *__
 }
 
 hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_labels, const uint16_t *sub_table,
-                         uint32_t k, const uint32_t *pal, uint32_t *labels, hipStream_t st)
+                         uint32_t k, const uint32_t *pal, uint32_t *labels, hipStream_t st, uint32_t reserve_cus)
 {
     if (k <= 256) {
         const uint64_t tiles = (n + kLabelBlock * 8 - 1) / (kLabelBlock * 8);
-        const uint32_t grid = (uint32_t)(tiles < 256 ? (tiles ? tiles : 1) : 256);   // 1 workgroup per CU
+        const uint32_t cus = 256u - (reserve_cus < 128u ? reserve_cus : 128u);       // 1 workgroup per CU, reserve_cus left free
+        const uint32_t grid = (uint32_t)(tiles < cus ? (tiles ? tiles : 1) : cus);
         const int aligned = ((reinterpret_cast<uintptr_t>(rgba) & 15u) == 0 &&
                              (reinterpret_cast<uintptr_t>(labels) & 15u) == 0) ? 1 : 0;
         hipLaunchKernelGGL(k_labels_pairs, dim3(grid), dim3(kLabelBlock), 0, st, rgba, n,

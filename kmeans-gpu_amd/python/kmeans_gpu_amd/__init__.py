@@ -67,7 +67,7 @@ SYMBOLS = [
     "kmg_dev_resize", "kmg_lloyd_create", "kmg_lloyd_destroy", "kmg_lloyd_set_centroids",
     "kmg_lloyd_get_centroids", "kmg_lloyd_init_centroids", "kmg_lloyd_init_step", "kmg_lloyd_init_pick_band",
     "kmg_lloyd_set_centroid_rgba", "kmg_init_first_key", "kmg_lloyd_assign_accumulate",
-    "kmg_lloyd_assign_partials", "kmg_lloyd_reduce_partials", "kmg_lloyd_labels", "kmg_lloyd_bind_image",
+    "kmg_lloyd_assign_partials", "kmg_lloyd_reduce_partials", "kmg_lloyd_labels", "kmg_lloyd_reserve_cus", "kmg_lloyd_bind_image",
     "kmg_lloyd_unbind_image", "kmg_lloyd_prepare", "kmg_debug_check_table", "kmg_debug_table_stats", "kmg_debug_check_pairs", "kmg_debug_check_dither_masks", "kmg_debug_check_meld_masks", "kmg_kernel_name",
     "kmg_lloyd_profile", "kmg_lloyd_profile_read",
     "kmg_lloyd_update", "kmg_lloyd_converged_count", "kmg_lloyd_iterate", "kmg_lloyd_flush", "kmg_lloyd_run", "kmg_dev_apply",
@@ -127,6 +127,7 @@ def lib():
     L.kmg_lloyd_assign_partials.argtypes = [vp, u8p, C.c_uint64, u32p, vp]
     L.kmg_lloyd_reduce_partials.argtypes = [vp, C.c_uint64, i64p, vp]
     L.kmg_lloyd_labels.argtypes = [vp, u8p, C.c_uint64, u32p, vp]
+    L.kmg_lloyd_reserve_cus.argtypes = [vp, C.c_uint32]
     L.kmg_lloyd_bind_image.argtypes = [vp, u8p, C.c_uint64, vp]
     L.kmg_debug_table_stats.argtypes = [vp, C.POINTER(C.c_uint64), vp]
     L.kmg_debug_check_pairs.argtypes = [vp, C.POINTER(C.c_uint64), vp]
@@ -362,6 +363,10 @@ class Lloyd:
     def labels(self, d_rgba, n_pixels, d_labels, stream=0):
         """labels only, for the current centroid table"""
         _check(lib().kmg_lloyd_labels(self._h, C.c_void_p(d_rgba), n_pixels, C.c_void_p(d_labels), C.c_void_p(stream)))
+
+    def reserve_cus(self, n_cus):
+        """leave n_cus compute units without a label-pass workgroup, for a collective that runs beside the pass"""
+        _check(lib().kmg_lloyd_reserve_cus(self._h, int(n_cus)))
 
     def reduce_partials(self, n_pixels, d_acc4, stream=0):
         _check(lib().kmg_lloyd_reduce_partials(self._h, n_pixels, C.c_void_p(d_acc4), C.c_void_p(stream)))

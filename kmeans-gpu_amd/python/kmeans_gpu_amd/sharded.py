@@ -73,6 +73,9 @@ def sharded_init(backend, k, band, width, height, row0, group=None, stream=0):
         publish(j)
 
 
+RESERVED_CUS = 8     # compute units the label pass leaves to the collective when the loop really exchanges sums
+
+
 class ShardedLloyd:
     """Drives one `Lloyd`-like backend per rank.
 
@@ -103,6 +106,10 @@ class ShardedLloyd:
         self.split_labels = False
         # label pass of iteration t beside the cube pass of iteration t + 1 (Lloyd.iterate); False: step by step
         self.pipeline = True
+        # the asynchronous all-reduce is meant to run BESIDE the label pass, but RCCL's kernel (256 threads, 20 KiB LDS,
+        # 280 registers per lane) does not fit on a CU that hosts a label workgroup: leave a few CUs to it
+        if dist.is_initialized() and self.world > 1 and collective is None and hasattr(backend, "reserve_cus"):
+            backend.reserve_cus(RESERVED_CUS)
 
     def _pass(self):
         """labels + sums of the current centroids, and the exchange of the sums.

@@ -33,8 +33,10 @@ def run(mode, steps=40):
     elif mode == "sync":                      # all-reduce on the compute stream, in order
         sh.world = 2; sh.collective = None
         sh.exchange = lambda async_op=False: dist.all_reduce(sh.acc, op=dist.ReduceOp.SUM) and None
-    elif mode == "async":                     # as ShardedLloyd does it with world > 1
+    elif mode in ("async", "async+8cu"):      # as ShardedLloyd does it with world > 1
         sh.world = 2
+        if mode == "async+8cu":               # ... including the CUs it leaves to the collective
+            s.reserve_cus(8)
     sh.prime()
     for _ in range(5): sh.iterate()
     torch.cuda.synchronize()
@@ -46,7 +48,7 @@ def run(mode, steps=40):
     s.close()
     return (t1 - t0) / steps * 1e3, (t2 - t0) / steps * 1e3
 
-for mode in ("none", "sync", "async", "none"):
+for mode in ("none", "sync", "async", "async+8cu", "none"):
     host, total = run(mode)
-    print(f"{mode:6s} host enqueue {host:.3f} ms/step   wall {total:.3f} ms/step", flush=True)
+    print(f"{mode:9s} host enqueue {host:.3f} ms/step   wall {total:.3f} ms/step", flush=True)
 dist.destroy_process_group()
