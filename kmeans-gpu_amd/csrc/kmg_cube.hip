@@ -251,13 +251,19 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
     const uint32_t n_work = SUMS ? __builtin_amdgcn_readfirstlane(work[0]) : kCells;
     // the small per-cell data of the NEXT cell are requested while the current one is worked on
     uint32_t cell_n = 0;
-    CellBounds cb_n;                                               // uniform address: scalar loads, no cross-lane traffic
+    // All of it through VECTOR loads (kmg_table_dev.h opaque_vgpr_zero): as scalar loads the requests were waited for at
+    // the first LDS access of the current cell.  The work-list entry is requested one cell further ahead still, so that no
+    // request starts with a load it has to wait for.  (34.5 -> 32 us)
+    const uint32_t vz = opaque_vgpr_zero();
+    float cbv_n = 0.0f;                                            // lane i < 12: float i of the next cell's bounds
     long long sagg_n = 0, cagg_n = 0, scnt_n = 1;
+    uint32_t cell_nn = SUMS ? work[1u + wave + vz] : wave;
 #define KMG_REQUEST_CELL(wi_)                                                                                    \
     do {                                                                                                         \
-        const uint32_t w_ = (wi_) < n_work ? (wi_) : wave;          /* past the end: a harmless repeat */        \
-        cell_n = SUMS ? __builtin_amdgcn_readfirstlane(work[1u + w_]) : w_;                                      \
-        cb_n = bounds[cell_n];                                                                                   \
+        cell_n = __builtin_amdgcn_readfirstlane(cell_nn);           /* requested one call earlier */             \
+        const uint32_t w2_ = (wi_) + n_waves < n_work ? (wi_) + n_waves : wave;   /* past the end: a harmless repeat */ \
+        cell_nn = SUMS ? work[1u + w2_ + vz] : w2_;                                                              \
+        cbv_n = reinterpret_cast<const float *>(bounds + cell_n)[lane & 15u];   /* lane i: float i (VMEM: not tied to LDS waits) */ \
         if (SUMS) {                                                                                              \
             sagg_n = sub_agg[(uint64_t)cell_n * 32u + (lane & 31u)];        /* lane 4 s + j: sum j of sub-cell s */ \
             scnt_n = sub_agg[(uint64_t)cell_n * 32u + 4u * (lane & 7u) + 3u];   /* lane s < 8: pixels in sub-cell s */ \
@@ -267,7 +273,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
     KMG_REQUEST_CELL(wave);
     for (uint32_t wi = wave; wi < n_work; wi += n_waves) {
         const uint32_t cell = cell_n;
-        const CellBounds cb = cb_n;
+        CellBounds cb;
+        cb.L0 = lane_value(cbv_n, 0); cb.L1 = lane_value(cbv_n, 1); cb.a0 = lane_value(cbv_n, 2); cb.a1 = lane_value(cbv_n, 3);
+        cb.b0 = lane_value(cbv_n, 4); cb.b1 = lane_value(cbv_n, 5); cb.C0 = lane_value(cbv_n, 6); cb.C1 = lane_value(cbv_n, 7);
+        cb.wC0 = lane_value(cbv_n, 8); cb.wC1 = lane_value(cbv_n, 9); cb.wH0 = lane_value(cbv_n, 10); cb.wH1 = lane_value(cbv_n, 11);
         const long long sagg = sagg_n, cagg = cagg_n, scnt = scnt_n;
         KMG_REQUEST_CELL(wi + n_waves);
         // the sub-cell bounds of THIS cell: requested now, needed after the cell's candidates are known
@@ -504,6 +513,8 @@ __global__ __launch_bounds__(kBlock) void k_cube_scan(const uint32_t *__restrict
     LabelT *s_lbl = s_lbl_all + wv * kCellColours;
 
     const uint32_t n_work = SUMS ? __builtin_amdgcn_readfirstlane(work[0]) : kCells;
+    // (Requesting the NEXT cell's work record ahead -- one vector load, lane i = dword i -- was measured: the 8 registers
+    // it holds cost a wave per SIMD, 73.6 -> 76.6 us.)
     for (uint32_t wi = wave; wi < n_work; wi += n_waves) {
         const uint32_t cell = SUMS ? __builtin_amdgcn_readfirstlane(work[1u + wi]) : wi;
         const CellWork *cw = cell_work + cell;

@@ -140,6 +140,16 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c)
 }
 
 // number of set bits of m below this lane's bit
+// A zero the compiler cannot see through, in a VGPR: added to a wave-uniform index it turns the load into a VECTOR
+// memory load.  Scalar loads share their wait counter with LDS and return out of order, so a prefetch issued as a
+// scalar load is waited for -- in full -- at the next LDS access; a vector load is not.
+__device__ __forceinline__ uint32_t opaque_vgpr_zero()
+{
+    uint32_t z = 0u;
+    asm volatile("" : "+v"(z));
+    return z;
+}
+
 __device__ __forceinline__ uint32_t bits_below_lane(unsigned long long m)
 {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
