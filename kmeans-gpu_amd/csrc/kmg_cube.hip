@@ -257,11 +257,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
     const uint32_t vz = opaque_vgpr_zero();
     float cbv_n = 0.0f;                                            // lane i < 12: float i of the next cell's bounds
     long long sagg_n = 0, cagg_n = 0, scnt_n = 1;
-    uint32_t cell_nn = SUMS ? work[1u + wave + vz] : wave;
+    // (a wave beyond the end of the work list must not use what lies behind it as a cell: entry 0 is always valid)
+    const uint32_t safe_w = wave < n_work ? wave : 0u;
+    uint32_t cell_nn = SUMS ? work[1u + safe_w + vz] : safe_w;
 #define KMG_REQUEST_CELL(wi_)                                                                                    \
     do {                                                                                                         \
         cell_n = __builtin_amdgcn_readfirstlane(cell_nn);           /* requested one call earlier */             \
-        const uint32_t w2_ = (wi_) + n_waves < n_work ? (wi_) + n_waves : wave;   /* past the end: a harmless repeat */ \
+        const uint32_t w2_ = (wi_) + n_waves < n_work ? (wi_) + n_waves : safe_w;   /* past the end: a harmless repeat */ \
         cell_nn = SUMS ? work[1u + w2_ + vz] : w2_;                                                              \
         cbv_n = reinterpret_cast<const float *>(bounds + cell_n)[lane & 15u];   /* lane i: float i (VMEM: not tied to LDS waits) */ \
         if (SUMS) {                                                                                              \
@@ -716,6 +718,7 @@ __global__ __launch_bounds__(kBlock) void k_cube_pairs(const uint32_t *__restric
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
     const uint32_t n_waves = gridDim.x * (kBlock / 64);
     const uint32_t n_work = with_work ? __builtin_amdgcn_readfirstlane(work[0]) : kCells;
+    // (Requesting the next cell's flag, labels and occupancy ahead was measured: no change, 21.5 us either way.)
     for (uint32_t wi = wave; wi < n_work; wi += n_waves) {
         const uint32_t cell = with_work ? __builtin_amdgcn_readfirstlane(work[1u + wi]) : wi;
         if (sizeof(LabelT) == 1) {
