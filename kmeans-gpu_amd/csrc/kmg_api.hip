@@ -401,16 +401,17 @@ static void free_table(ColourTable &t)
     t = ColourTable();
 }
 
-// Cost model (seconds per iteration on MI355X; constants fitted to tools/strategy_sweep.py, round 1):
-//   per-pixel scan : 1.4e-5 + n * (7.0e-12 + 2.25e-13 k)
-//   colour table   : 9.0e-5 + 2.7e-7 k                       candidates + cube pass (independent of n)
-//                    + n * (1.7e-12 + 2.3e-15 k)              label pass, k <= 256 (6.7e-12 for u16 labels)
+// Cost model (seconds per iteration on MI355X; constants fitted to tools/strategy_sweep.py, refitted in round 2 --
+// the cube pass got cheaper, the per-pixel scan tracks the runner-up key for the literal arg-min):
+//   per-pixel scan : 1.4e-5 + 3.3e-7 k + n * (6.8e-12 + 2.45e-13 k)     (the k term: partial-sum slab and its reduction)
+//   colour table   : 8.6e-5 + 1.85e-7 k                      cube pass (independent of n)
+//                    + n * (1.8e-12 + 2.0e-15 k)              label pass, k <= 256 (6.7e-12 for u16 labels)
 //                    + bind_seconds(n) / 16                   one-off histogram + cell sums, spread over ~16 passes
 // one-off cost of binding an image: partitioned histogram (n >= 2^21) or one global atomic per pixel, + cell sums
 static double bind_seconds(uint64_t n)
 {
     const double N = (double)n;
-    return n >= (1ull << 21) ? 4.0e-4 + N * 9.0e-12 : 3.5e-4 + N * 4.1e-11;
+    return n >= (1ull << 21) ? 2.5e-4 + N * 4.1e-12 : 2.0e-4 + N * 4.0e-11;
 }
 
 static bool table_pays(uint64_t n, uint32_t k, bool labels)
@@ -420,14 +421,14 @@ static bool table_pays(uint64_t n, uint32_t k, bool labels)
         if (!strcmp(e, "table")) return true;
     }
     const double N = (double)n;
-    const double brute = 1.4e-5 + N * (7.0e-12 + 2.25e-13 * k);
-    const double label_pass = labels ? N * (k <= 256 ? 1.7e-12 + 2.3e-15 * k : 6.7e-12) : 0.0;
-    const double table = 9.0e-5 + 2.7e-7 * k + label_pass + bind_seconds(n) / 16.0;
+    const double brute = 1.4e-5 + 3.3e-7 * k + N * (6.8e-12 + 2.45e-13 * k);
+    const double label_pass = labels ? N * (k <= 256 ? 1.8e-12 + 2.0e-15 * k : 6.7e-12) : 0.0;
+    const double table = 8.6e-5 + 1.85e-7 * k + label_pass + bind_seconds(n) / 16.0;
     return table < brute;
 }
 
-// Same model for the replace-mode output pass (no histogram: every cell is labelled; the three
-// scratch buffers are allocated per call, ~0.25 ms).
+// Same model for the replace-mode output pass (no histogram: every cell is labelled; scratch from the processor's
+// blocks).
 static bool replace_table_pays(uint64_t n, uint32_t k)
 {
     if (const char *e = getenv("KMG_STRATEGY")) {
@@ -435,8 +436,8 @@ static bool replace_table_pays(uint64_t n, uint32_t k)
         if (!strcmp(e, "table")) return true;
     }
     const double N = (double)n;
-    const double brute = N * (8.1e-12 + 2.2e-13 * k);
-    const double table = 3.8e-4 + 2.3e-7 * k + N * (k <= 256 ? 1.7e-12 + 6.0e-15 * k : 6.6e-12);
+    const double brute = N * (8.1e-12 + 2.45e-13 * k);
+    const double table = 9.0e-5 + 1.85e-7 * k + N * (k <= 256 ? 1.8e-12 + 2.0e-15 * k : 6.6e-12);
     return table < brute;
 }
 
@@ -958,11 +959,11 @@ extern "C" int kmg_lloyd_get_centroids(kmg_lloyd *s, float *c4, void *stream)
     return KMG_OK;
 }
 
-// Farthest-point init: k - 1 passes over the pixels (n * 7.0e-12 s each: sRGB->Lab + literal CIE94 per
-// pixel) or over the image's colours (1.1e-4 s for a pass that reaches every cell -- the first ~20 --
-// falling to ~4e-5 s once most cells are skipped) after binding the image (bind_seconds; the tie keys
-// come with the partitioned histogram, or cost another atomic per pixel on small images); MI355X,
-// tools/cfg3_probe.py.
+// Farthest-point init: k - 1 passes over the pixels (two launches, ~8e-6 s, + n * 7.0e-12 s each: sRGB->Lab + literal
+// CIE94 per pixel) or over the image's colours (one launch per pass: ~1.05e-5 s once most cells are skipped, ~3e-5 s
+// more for each of the first ~16 passes, which reach every cell) after binding the image (bind_seconds, x 1.5 with the
+// tie keys that come with the partitioned histogram, or another atomic per pixel on small images); MI355X,
+// tools/cfg3_probe.py / tools/init_phases.sh, round 2.
 static bool init_table_pays(uint64_t n, uint32_t k)
 {
     if (const char *e = getenv("KMG_STRATEGY")) {
@@ -970,8 +971,8 @@ static bool init_table_pays(uint64_t n, uint32_t k)
         if (!strcmp(e, "table")) return true;
     }
     const double N = (double)n, passes = (double)(k - 1);
-    const double pixels = passes * N * 7.0e-12;
-    const double colours = passes * 4.5e-5 + (passes < 20.0 ? passes : 20.0) * 7.0e-5 + bind_seconds(n) +
+    const double pixels = passes * (8.0e-6 + N * 7.0e-12);
+    const double colours = passes * 1.05e-5 + (passes < 16.0 ? passes : 16.0) * 3.0e-5 + 1.5 * bind_seconds(n) +
                            (n >= (1ull << 21) ? 0.0 : 1.0e-4 + N * 3.7e-11);
     return colours < pixels;
 }
