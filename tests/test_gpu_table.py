@@ -796,3 +796,34 @@ def test_concurrent_output_passes_share_one_processor(torch_cuda, oracle, monkey
         assert np.array_equal(results[j], serial[j]), j
     want = oracle.find(img, pals[0], int(kg.ReduceMode.Dither))
     assert np.array_equal(serial[(0, kg.ReduceMode.Dither)], want)
+
+
+@pytest.mark.gpu
+def test_label_pass_with_reserved_compute_units(torch_cuda, oracle, monkeypatch):
+    """kmg_lloyd_reserve_cus: the label pass on fewer CUs (room for a collective beside it) writes the same label map."""
+    import kmeans_gpu_amd as kg
+    torch = torch_cuda
+    monkeypatch.setenv("KMG_STRATEGY", "table")
+    rng = np.random.default_rng(5)
+    n, k = 3_000_017, 200                                     # not a multiple of the tile size
+    rgba = rng.integers(0, 256, (n, 4), dtype=np.uint8)
+    cent = oracle.centroids4(oracle.rgb_to_lab(rgba[:k]))
+    d = _dev(torch, rgba)
+    proc = kg.ImageProcessor(shrink_max_dim=0)
+    maps = []
+    for reserve in (0, 8, 128):
+        s = kg.Lloyd(proc, k)
+        s.set_centroids(cent, _stream(torch))
+        assert s.prepare(d.data_ptr(), n, True, _stream(torch)) == "table"
+        s.reserve_cus(reserve)
+        labels = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+        acc = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
+        s.assign_accumulate(d.data_ptr(), n, labels.data_ptr(), acc.data_ptr(), _stream(torch))
+        torch.cuda.synchronize()
+        maps.append(labels.cpu().numpy())
+        s.close()
+    assert np.array_equal(maps[0], maps[1]) and np.array_equal(maps[0], maps[2])
+    want, _ = oracle.assign_accumulate_rgba(rgba[:200_000], cent)
+    assert np.array_equal(maps[0][:200_000].view(np.uint32), want)
+    with pytest.raises(kg.KmgError):
+        kg.Lloyd(proc, k).reserve_cus(129)
