@@ -415,7 +415,7 @@ def main():
         abytes = algorithmic_bytes(dominant, n_local, k)
         achieved = abytes / (k_ms * 1e-3) / 1e9
         step_gbps = ALGORITHMIC_BYTES_PER_PIXEL * total_pixels / (ms_per_step * 1e-3) / 1e9
-        traffic, traffic_source = None, None
+        traffic, traffic_source, tj = None, None, {}
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath) and k == K and rows == ROWS_PER_GPU:
             with open(tpath) as f:
@@ -454,6 +454,12 @@ def main():
                          "valu_fraction": flops / (ms_per_step * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
                          "valu_peak_tflops": FP32_VECTOR_PEAK_TFLOPS},
             "kernels": kernels,
+            # every timed kernel against the HBM roof, from its own algorithmic bytes (k_cube: 2^24 counts in, 2^24 labels out)
+            "kernels_roofline": {nm: {"algorithmic_bytes_per_launch": algorithmic_bytes(nm, n_local, k),
+                                      "achieved_GBps": algorithmic_bytes(nm, n_local, k) / (v["ms_per_launch"] * 1e-3) / 1e9,
+                                      "frac": algorithmic_bytes(nm, n_local, k) / (v["ms_per_launch"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                      "traffic": (tj.get("bytes_per_launch", {}).get(nm) if traffic is not None else None)}
+                                 for nm, v in kernels.items() if algorithmic_bytes(nm, n_local, k) is not None},
             "kernels_note": "HIP events on the launch stream; the dominant kernel inside the timed region, k_cube in a loop of "
                             "its own right after it (same state, same launches)",
         }
