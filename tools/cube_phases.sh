@@ -14,4 +14,9 @@ for r in csv.DictReader(open(f)):
         n = r["Name"].split("(")[0].replace("void ", "")[:44]
         print(f"{n:46s} calls {r['Calls']:>4s} avg {float(r['AverageNs'])/1e3:8.1f} us  min {float(r['MinNs'])/1e3:8.1f} max {float(r['MaxNs'])/1e3:8.1f}")
 PY
-tail -1 $ROOT/gpurun_out/${TAG}_prof.log | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('ms_per_step', d['ms_per_step'])" >> $ROOT/gpurun_out/${TAG}_phases.txt
+python3 - $ROOT/gpurun_out/${TAG}_prof.log >> $ROOT/gpurun_out/${TAG}_phases.txt <<'PY'
+import json, sys
+for line in open(sys.argv[1]):
+    if line.startswith('{"metric"'):
+        print('ms_per_step', json.loads(line)['ms_per_step'])
+PY
