@@ -161,7 +161,74 @@ def cfg4_rank_share(proc, k, n_pixels, stream, steps=5):
             "cfg4_collectives_per_iteration": 0}
 
 
-def output_pass_timing(proc, rgba, n_pixels, stream, sh=None):
+def cfg4_tiled_rank_share(proc, k, width, height, stream, steps=3, images=16, world=8, rank=3):
+    """BASELINE config 4 split the way north_star words it: every image tiled over the 8 GPUs in row bands, one all-reduce
+    of images x k x 4 int64 per iteration (sharded.ShardedBatch) -- exactly the configuration of
+    tests/test_gpu_scale.py::test_cfg4_one_ranks_share_of_the_batch: rank 3's 16 bands of 8192 x 1024, one batched
+    accumulator tensor; the collective is replaced by the addition of a precomputed tensor of the same shape (one GPU
+    here).  Time of one Lloyd iteration of the rank's share, label maps included.  Not part of `value`."""
+    import numpy as np
+    import torch
+    import kmeans_gpu_amd as kg
+    from kmeans_gpu_amd import synth
+    from kmeans_gpu_amd.sharded import ShardedBatch, band_rows
+    r0, r1 = band_rows(height, rank, world)
+    n_band, n = (r1 - r0) * width, width * height
+    bands, labels, backends = [], [], []
+    for i in range(images):
+        band = synth.uniform_rgba_torch(0x5EED0400 + i, n_band, first=r0 * width, device="cuda")
+        sel = synth.uniform_rgba_at(0x5EED0400 + i, np.arange(k, dtype=np.uint64) * np.uint64(n // k))
+        d_sel = torch.from_numpy(sel).cuda()
+        lab = torch.empty((k, 3), dtype=torch.float32, device="cuda")
+        proc.rgb_to_lab(d_sel.data_ptr(), k, lab.data_ptr(), stream)
+        torch.cuda.synchronize()
+        cent = np.ones((k, 4), np.float32)
+        cent[:, :3] = lab.cpu().numpy()
+        s = kg.Lloyd(proc, k)
+        s.set_centroids(cent, stream)
+        s.prepare(band.data_ptr(), n_band, True, stream)
+        bands.append(band); backends.append(s)
+        labels.append(torch.empty(n_band, dtype=torch.int32, device="cuda"))
+    others = torch.ones((images, k, 4), dtype=torch.int64, device="cuda")     # stand-in for the other seven ranks' sums
+
+    def exchange(acc, active):
+        acc += others
+
+    batch = ShardedBatch(backends, k, bands, labels, stream=stream, collective=exchange)
+
+    def iteration():
+        for i, be in enumerate(batch.backends):
+            be.update(batch.acc[i].data_ptr(), stream)
+        batch._pass()
+    batch._pass()
+    iteration()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(steps):
+        iteration()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t) / steps * 1e3
+    for s in backends:
+        s.close()
+    return {"cfg4_tiled_rank_share_ms_per_iteration": ms, "cfg4_tiled_bands_per_rank": images,
+            "cfg4_tiled_collectives_per_iteration": 1}
+
+
+def reduce_end_to_end(proc, rgba, width, height, k):
+    """kmg_reduce (lib.rs:116-164) of the full-resolution image from and to HOST buffers: upload, initialisation, Lloyd loop,
+    dither output pass, download -- PCIe included, never part of `value`.  The second call (warm processor: streams, blocks
+    and pool memory are there) is the one reported."""
+    import kmeans_gpu_amd as kg
+    host = rgba.cpu().numpy().reshape(height, width, 4)
+    out = {}
+    for name in ("cold", "warm"):
+        t = time.perf_counter()
+        proc.reduce(k, host, reduce_mode=kg.ReduceMode.Dither)
+        out[f"reduce_host_to_host_{name}_ms"] = (time.perf_counter() - t) * 1e3
+    return out
+
+
+def output_pass_timing(proc, rgba, n_pixels, stream, sh=None, steps=3):
     """Not part of `value`: the other kernel family of the path, BASELINE config 5 -- find + ordered
     dither with the 64-entry resurrect_64 palette on the same 8192x8192 pixels (8 B/px algorithmic:
     4 B in, 4 B RGBA8 out), and the iteration without the per-pixel label map."""
@@ -179,10 +246,10 @@ def output_pass_timing(proc, rgba, n_pixels, stream, sh=None):
             proc.apply(rgba.data_ptr(), WIDTH, n_pixels // WIDTH, 0, cent, mode, out.data_ptr(), stream)
             torch.cuda.synchronize()
             t = time.perf_counter()
-            for _ in range(3):
+            for _ in range(steps):
                 proc.apply(rgba.data_ptr(), WIDTH, n_pixels // WIDTH, 0, cent, mode, out.data_ptr(), stream)
             torch.cuda.synchronize()
-            ms = (time.perf_counter() - t) / 3 * 1e3
+            ms = (time.perf_counter() - t) / steps * 1e3
             extra[f"{name}_k{len(pal)}_ms"] = ms
             extra[f"{name}_k{len(pal)}_hbm_frac"] = ALGORITHMIC_BYTES_PER_PIXEL * n_pixels / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
         if sh is not None:
@@ -222,10 +289,13 @@ def output_pass_timing(proc, rgba, n_pixels, stream, sh=None):
                                                               kg.ReduceMode.Dither, out.data_ptr(), stream))
         s3.close()
         del labels, out
-        extra.update(other_distributions(proc, k3, n_pixels, stream))
-        extra.update(cfg4_rank_share(proc, k3, n_pixels, stream))
-    except Exception as e:      # the extras must never break the benchmark line
-        extra["error"] = repr(e)
+        extra.update(other_distributions(proc, k3, n_pixels, stream, steps=max(steps, 2) * 3))
+        extra.update(cfg4_rank_share(proc, k3, n_pixels, stream, steps=steps))
+        extra.update(cfg4_tiled_rank_share(proc, k3, WIDTH, n_pixels // WIDTH, stream, steps=steps))
+        extra.update(reduce_end_to_end(proc, rgba, WIDTH, n_pixels // WIDTH, k3))
+    except Exception as e:      # the extras must never break the benchmark line (tests/test_gpu_bench.py fails on it instead)
+        import traceback
+        extra["error"] = repr(e) + " | " + traceback.format_exc().strip().splitlines()[-3].strip()
     return extra
 
 
@@ -331,15 +401,21 @@ def main():
     cent = np.ones((k, 4), np.float32)
     cent[:, :3] = lab.cpu().numpy()
 
-    lloyd = kg.Lloyd(proc, k)
-    lloyd.set_centroids(cent, stream)
     # one-time per-image preparation (the counterpart of the reference's one-time Lab conversion
-    # pass, operations.rs:63-71): outside the per-iteration timing, reported separately
-    torch.cuda.synchronize()
-    t_prep = time.perf_counter()
-    strategy = lloyd.prepare(rgba.data_ptr(), n_local, True, stream)
-    torch.cuda.synchronize()
-    t_prep = time.perf_counter() - t_prep
+    # pass, operations.rs:63-71): outside the per-iteration timing, reported separately -- on a cold processor (first
+    # image: every block is a fresh hipMalloc, the static colour tables are built) and on a warm one (the second
+    # image of a frame loop / of a rank's share of a batch: the first image's blocks are reused)
+    def prepared():
+        s = kg.Lloyd(proc, k)
+        s.set_centroids(cent, stream)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        how = s.prepare(rgba.data_ptr(), n_local, True, stream)
+        torch.cuda.synchronize()
+        return s, how, time.perf_counter() - t
+    first, _, t_prep_cold = prepared()
+    first.close()
+    lloyd, strategy, t_prep = prepared()
 
     sh = ShardedLloyd(lloyd, k, rgba, labels, stream=stream)
     sh.split_labels = strategy == "table"     # the all-reduce overlaps the label-gather pass
@@ -437,7 +513,7 @@ def main():
                                    + (" + RCCL all-reduce of k x 4 int64" if world > 1 else ""),
                        "width": WIDTH, "height": height, "k": k,
                        "sharding": f"row bands, {rows} rows per GPU",
-                       "strategy": strategy, "prepare_ms": t_prep * 1e3,
+                       "strategy": strategy, "prepare_ms": t_prep * 1e3, "prepare_cold_ms": t_prep_cold * 1e3,
                        "label_pass": "beside the next iteration's cube pass" if sh.pipeline else "before the next iteration"},
             "roofline": {"bound": "hbm", "kernel": dominant,
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -449,6 +525,7 @@ def main():
                          # the whole iteration (all kernels, gaps, collective): 8 B/px over ms_per_step
                          "achieved_iteration": step_gbps, "frac_iteration": step_gbps / HBM_PEAK_GBPS,
                          "frac_iteration_achievable": step_gbps / HBM_ACHIEVABLE_GBPS,
+                         "frac_iteration_of_copy": (step_gbps / copy_gbps) if copy_gbps else None,
                          # SURVEY 8d's second roof: flops of the literal per-pixel scan (17 k + 50 per pixel) over the
                          # fp32 vector peak; > 1 means the colour table does not perform them
                          "valu_fraction": flops / (ms_per_step * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
@@ -465,6 +542,15 @@ def main():
         }
         if world == 1 and rows == ROWS_PER_GPU and not args.no_extras:
             out["extra"] = output_pass_timing(proc, rgba, n_local, stream, sh)
+            for name in ("find_dither_k64", "find_replace_k64"):          # the output passes of BASELINE config 5, same roof
+                if name + "_ms" in out["extra"]:
+                    ms = out["extra"][name + "_ms"]
+                    out["kernels_roofline"][name] = {
+                        "algorithmic_bytes_per_launch": ALGORITHMIC_BYTES_PER_PIXEL * n_local,
+                        "achieved_GBps": ALGORITHMIC_BYTES_PER_PIXEL * n_local / (ms * 1e-3) / 1e9,
+                        "frac": ALGORITHMIC_BYTES_PER_PIXEL * n_local / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                        "traffic": tj.get("bytes_per_launch", {}).get(name),
+                        "note": "whole kmg_dev_apply call (all its launches), host clock over 3 calls"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(k, cent, seed)
         line = json.dumps(out)

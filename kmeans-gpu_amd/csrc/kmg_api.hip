@@ -101,8 +101,44 @@ struct kmg_processor {
     CellBounds *d_sub_bounds;   // kSubCells static bounds of the 4x4x4 sub-cells
     float4 *d_lab_table;     // 2^24 x (L, a, b, C): Lab of every colour (256 MiB, built with d_bounds)
     std::vector<hipStream_t> idle_streams;   // streams of finished host-buffer calls, reused by the next ones (mu)
-    std::vector<std::pair<void *, size_t>> idle_arenas;   // scratch blocks of finished output passes (mu), see ArenaGuard
+    // Device blocks the processor keeps between uses (mu): output-pass scratch, colour tables and workspaces of finished
+    // kmg_lloyd objects.  A block is handed out again to the next request it is large enough for (block_take), so a second
+    // image on a warm processor -- a frame loop, the two images per rank of BASELINE config 4 -- binds without a hipMalloc
+    // (nine of them cost 1.4 ms per 8192^2 image in round 2, three times the kernels of the binding).
+    std::vector<std::pair<void *, size_t>> idle_arenas;
+    hipMemPool_t pool;       // private stream-ordered pool for per-call scratch (never the device's default pool)
 };
+
+// smallest idle block that is large enough, else a fresh one
+static hipError_t block_take(kmg_processor *p, size_t bytes, void **ptr, size_t *cap)
+{
+    {
+        std::lock_guard<std::mutex> lock(p->mu);
+        size_t best = p->idle_arenas.size();
+        for (size_t i = 0; i < p->idle_arenas.size(); ++i)
+            if (p->idle_arenas[i].second >= bytes && (best == p->idle_arenas.size() || p->idle_arenas[i].second < p->idle_arenas[best].second))
+                best = i;
+        if (best != p->idle_arenas.size()) {
+            *ptr = p->idle_arenas[best].first;
+            *cap = p->idle_arenas[best].second;
+            p->idle_arenas.erase(p->idle_arenas.begin() + (long)best);
+            return hipSuccess;
+        }
+    }
+    const hipError_t e = hipMalloc(ptr, bytes);
+    if (e == hipSuccess) *cap = bytes;
+    return e;
+}
+
+// the caller guarantees that no kernel still uses the block
+static void block_give(kmg_processor *p, void *ptr, size_t cap)
+{
+    if (!ptr) return;
+    std::lock_guard<std::mutex> lock(p->mu);
+    p->idle_arenas.emplace_back(ptr, cap);
+}
+
+static inline size_t pad256(size_t bytes) { return (bytes + 255u) & ~(size_t)255u; }
 
 struct ProfEvent { int id; hipEvent_t e0, e1; };
 
@@ -132,6 +168,10 @@ struct ColourTable {
     bool bound_by_init = false;      // the binding was made by the initialisation of the current problem
     bool bound_by_caller = false;    // kmg_lloyd_bind_image / kmg_lloyd_prepare: the caller vouches for the buffer's contents
     uint64_t tie_first = 0;
+    // the three blocks all of the above are carved from (kmg_processor::idle_arenas): the tables proper, the second label-table
+    // set of kmg_lloyd_iterate, the tables of the initialisation
+    void *blk = nullptr, *blk_alt = nullptr, *blk_init = nullptr;
+    size_t blk_cap = 0, blk_alt_cap = 0, blk_init_cap = 0;
 };
 
 struct kmg_lloyd {
@@ -142,8 +182,11 @@ struct kmg_lloyd {
     int64_t *d_acc;              // k x 4 (used by kmg_lloyd_run)
     uint32_t *d_nconv;           // 1
     unsigned long long *d_key;   // 1 (init arg-max)
-    float *d_dist;               // init distance map, grown on demand
+    float *d_dist;               // init distance map, grown on demand (a block of its own)
     uint64_t dist_cap;
+    size_t dist_blk_cap;
+    void *ws;                    // the block d_cent .. d_key are carved from (kmg_processor::idle_arenas)
+    size_t ws_cap;
     uint32_t last_rows;          // rows of d_partials written by the last assign pass
     bool init_colours;           // the running sharded init (kmg_lloyd_init_step) walks colours, not pixels
     uint32_t reserve_cus = 0;    // CUs the label pass leaves free (kmg_lloyd_reserve_cus)
@@ -195,14 +238,25 @@ extern "C" int kmg_processor_create_ex(const kmg_options *opt, kmg_processor **o
     p->d_bounds = nullptr;
     p->d_sub_bounds = nullptr;
     p->d_lab_table = nullptr;
+    p->pool = nullptr;
     {
-        // per-call scratch comes from the device's stream-ordered pool: keep what has been freed instead of handing
-        // it back to the driver at every synchronisation (the default threshold is 0, which makes each call of the
-        // host-buffer API pay for fresh allocations again: find -m replace at 8192^2 0.65 -> 0.3 ms)
+        // per-call scratch comes from a stream-ordered pool of the processor's own that keeps what has been freed instead
+        // of handing it back to the driver at every synchronisation (with the default threshold of 0 each call of the
+        // host-buffer API pays for fresh allocations again: find -m replace at 8192^2 0.65 -> 0.3 ms).  The device's
+        // default pool is left alone: its settings belong to the host application.
+        hipMemPoolProps props;
+        memset(&props, 0, sizeof props);
+        props.allocType = hipMemAllocationTypePinned;
+        props.handleTypes = hipMemHandleTypeNone;
+        props.location.type = hipMemLocationTypeDevice;
+        props.location.id = dev;
         hipMemPool_t pool = nullptr;
-        if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
+        if (hipMemPoolCreate(&pool, &props) == hipSuccess && pool) {
             uint64_t keep = ~0ull;
             (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+            p->pool = pool;
+        } else {
+            (void)hipGetLastError();      // no private pool on this runtime: per-call scratch falls back to the default pool
         }
     }
     float lut[256];
@@ -228,6 +282,7 @@ extern "C" void kmg_processor_destroy(kmg_processor *p)
     if (p->d_lab_table) (void)hipFree(p->d_lab_table);
     for (hipStream_t st : p->idle_streams) (void)hipStreamDestroy(st);
     for (auto &a : p->idle_arenas) (void)hipFree(a.first);
+    if (p->pool) (void)hipMemPoolDestroy(p->pool);
     delete p;
 }
 
@@ -307,11 +362,16 @@ struct DevBuf {
 
 // scratch that lives for one call on one stream: stream-ordered allocation from the device's memory
 // pool (a reused block after the first call instead of a ~0.1 ms hipMalloc + hipFree pair)
+static hipError_t pool_alloc(kmg_processor *p, void **ptr, size_t bytes, hipStream_t stream)
+{
+    return p->pool ? hipMallocFromPoolAsync(ptr, bytes, p->pool, stream) : hipMallocAsync(ptr, bytes, stream);
+}
+
 struct StreamBuf {
     void *ptr = nullptr;
     hipStream_t st = nullptr;
     ~StreamBuf() { if (ptr) (void)hipFreeAsync(ptr, st); }
-    hipError_t alloc(size_t bytes, hipStream_t stream) { st = stream; return hipMallocAsync(&ptr, bytes, stream); }
+    hipError_t alloc(kmg_processor *p, size_t bytes, hipStream_t stream) { st = stream; return pool_alloc(p, &ptr, bytes, stream); }
 };
 
 // The scratch of one output pass (kmg_dev_apply): ONE block per call, taken from / returned to the processor's idle
@@ -326,29 +386,16 @@ struct ArenaGuard {
     hipError_t acquire(kmg_processor *proc, size_t bytes)
     {
         p = proc;
-        {
-            std::lock_guard<std::mutex> lock(p->mu);
-            if (!p->idle_arenas.empty()) { base = p->idle_arenas.back().first; cap = p->idle_arenas.back().second; p->idle_arenas.pop_back(); }
-        }
-        if (cap >= bytes) return hipSuccess;
-        if (base) { (void)hipFree(base); base = nullptr; cap = 0; }
-        const hipError_t e = hipMalloc(&base, bytes);
-        if (e == hipSuccess) cap = bytes;
-        return e;
+        return block_take(p, bytes, &base, &cap);
     }
-    static size_t padded(size_t bytes) { return (bytes + 255u) & ~(size_t)255u; }
+    static size_t padded(size_t bytes) { return pad256(bytes); }
     void *take(size_t bytes)
     {
         void *r = (uint8_t *)base + used;
         used += padded(bytes);
         return used <= cap ? r : nullptr;
     }
-    ~ArenaGuard()
-    {
-        if (!base) return;
-        std::lock_guard<std::mutex> lock(p->mu);
-        p->idle_arenas.emplace_back(base, cap);
-    }
+    ~ArenaGuard() { if (base) block_give(p, base, cap); }
 };
 
 // the private stream of one host-buffer call (every call has its own, so calls on one processor run
@@ -382,23 +429,23 @@ static void drop_events(kmg_lloyd *s);
 static void destroy_events(kmg_lloyd *s);
 static int debug_refresh(kmg_lloyd *s, hipStream_t st, unsigned long long stage[6]);
 static int side_flush(kmg_lloyd *s, hipStream_t st);
-static void free_table(ColourTable &t)
+// The table's blocks go back to the processor for the next image.  The caller has made sure that no kernel still uses them.
+static void free_table(kmg_processor *p, ColourTable &t)
 {
-    if (t.d_hist) (void)hipFree(t.d_hist);
-    if (t.d_agg) (void)hipFree(t.d_agg);
-    if (t.d_sub_agg) (void)hipFree(t.d_sub_agg);
-    if (t.d_occ) (void)hipFree(t.d_occ);
-    if (t.d_cell_work) (void)hipFree(t.d_cell_work);
-    if (t.d_masks) (void)hipFree(t.d_masks);
-    if (t.d_work) (void)hipFree(t.d_work);
-    if (t.d_colour_labels) (void)hipFree(t.d_colour_labels);
-    if (t.d_sub) (void)hipFree(t.d_sub);
-    if (t.d_colour_labels_alt) (void)hipFree(t.d_colour_labels_alt);
-    if (t.d_sub_alt) (void)hipFree(t.d_sub_alt);
-    if (t.d_tie) (void)hipFree(t.d_tie);
-    if (t.d_cdist) (void)hipFree(t.d_cdist);
-    if (t.d_init_cells) (void)hipFree(t.d_init_cells);
+    block_give(p, t.blk, t.blk_cap);
+    block_give(p, t.blk_alt, t.blk_alt_cap);
+    block_give(p, t.blk_init, t.blk_init_cap);
     t = ColourTable();
+}
+
+static inline size_t sub_table_bytes() { return sizeof(uint16_t) * (kSubCells + kCells) + sizeof(uint32_t) * kCells; }
+
+// carve `bytes` (256-byte granules) off a block
+static inline void *carve(void *base, size_t &off, size_t bytes)
+{
+    void *r = (uint8_t *)base + off;
+    off += pad256(bytes);
+    return r;
 }
 
 // Cost model (seconds per iteration on MI355X; constants fitted to tools/strategy_sweep.py, refitted in round 2 --
@@ -503,20 +550,28 @@ static int bind_image_impl(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, void
     ColourTable &t = s->tab;
     const uint32_t words = mask_words(s->k);
     if (!t.d_hist) {
-        hipError_t e = hipMalloc((void **)&t.d_hist, sizeof(uint32_t) << 24);
-        if (e == hipSuccess) e = hipMalloc((void **)&t.d_agg, sizeof(int64_t) * 4ull * kCells);
-        if (e == hipSuccess) e = hipMalloc((void **)&t.d_sub_agg, sizeof(int64_t) * 4ull * kSubCells);
-        if (e == hipSuccess) e = hipMalloc((void **)&t.d_occ, (size_t)1 << 21);
-        if (e == hipSuccess) e = hipMalloc(&t.d_cell_work, cube_work_bytes());
-        if (e == hipSuccess) e = hipMalloc((void **)&t.d_masks, sizeof(uint64_t) * (size_t)kCells * words);
-        if (e == hipSuccess) e = hipMalloc((void **)&t.d_work, sizeof(uint32_t) * (kCells + 1));
-        if (e == hipSuccess) e = hipMalloc(&t.d_colour_labels, (size_t)(s->k <= 256 ? 1 : 2) << 24);
-        if (e == hipSuccess) e = hipMalloc((void **)&t.d_sub, sizeof(uint16_t) * (kSubCells + kCells) + sizeof(uint32_t) * kCells);
+        // one block for all tables, from the processor's idle blocks when one fits (no hipMalloc on a warm processor)
+        const size_t sizes[9] = {sizeof(uint32_t) << 24, sizeof(int64_t) * 4ull * kCells, sizeof(int64_t) * 4ull * kSubCells,
+                                 (size_t)1 << 21, cube_work_bytes(), sizeof(uint64_t) * (size_t)kCells * words,
+                                 sizeof(uint32_t) * (kCells + 1), (size_t)(s->k <= 256 ? 1 : 2) << 24, sub_table_bytes()};
+        size_t need = 0;
+        for (size_t b : sizes) need += pad256(b);
+        const hipError_t e = block_take(s->p, need, &t.blk, &t.blk_cap);
         if (e != hipSuccess) {
-            free_table(t);
+            t.blk = nullptr; t.blk_cap = 0;
             return fail(e == hipErrorOutOfMemory ? KMG_ERR_OUT_OF_MEMORY : KMG_ERR_HIP,
                         "colour table allocation failed: %s", hipGetErrorString(e));
         }
+        size_t off = 0;
+        t.d_hist = (uint32_t *)carve(t.blk, off, sizes[0]);
+        t.d_agg = (int64_t *)carve(t.blk, off, sizes[1]);
+        t.d_sub_agg = (int64_t *)carve(t.blk, off, sizes[2]);
+        t.d_occ = (uint8_t *)carve(t.blk, off, sizes[3]);
+        t.d_cell_work = carve(t.blk, off, sizes[4]);
+        t.d_masks = (uint64_t *)carve(t.blk, off, sizes[5]);
+        t.d_work = (uint32_t *)carve(t.blk, off, sizes[6]);
+        t.d_colour_labels = carve(t.blk, off, sizes[7]);
+        t.d_sub = (uint16_t *)carve(t.blk, off, sizes[8]);
     }
     t.rgba = nullptr;
     t.tables_valid = false;
@@ -524,13 +579,14 @@ static int bind_image_impl(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, void
     t.bound_by_init = false;
     t.bound_by_caller = false;
     // entries of cells no pixel falls into are never read by the label pass; 0xFF.. = "empty"
-    HIP_TRY(hipMemsetAsync(t.d_sub, 0xFF, sizeof(uint16_t) * (kSubCells + kCells) + sizeof(uint32_t) * kCells, S(stream)));
+    HIP_TRY(hipMemsetAsync(t.d_sub, 0xFF, sub_table_bytes(), S(stream)));
+    if (t.d_sub_alt) HIP_TRY(hipMemsetAsync(t.d_sub_alt, 0xFF, sub_table_bytes(), S(stream)));
     if (n >= (1ull << 21)) {
         // partition + per-partition LDS histograms: no global atomic per pixel (kmg_table.hip)
         StreamBuf small, elems, keys;
-        hipError_t e = small.alloc(sizeof(uint32_t) * (4 * 1024 + 1), S(stream));
-        if (e == hipSuccess) e = elems.alloc(sizeof(uint16_t) * n, S(stream));
-        if (e == hipSuccess && want_tie) e = keys.alloc(sizeof(uint32_t) * n, S(stream));
+        hipError_t e = small.alloc(s->p, sizeof(uint32_t) * (4 * 1024 + 1), S(stream));
+        if (e == hipSuccess) e = elems.alloc(s->p, sizeof(uint16_t) * n, S(stream));
+        if (e == hipSuccess && want_tie) e = keys.alloc(s->p, sizeof(uint32_t) * n, S(stream));
         if (e == hipSuccess)
             e = launch_partitioned_histogram((const uint32_t *)d_rgba, n, first_index, (uint32_t *)small.ptr, (uint16_t *)elems.ptr,
                                              (uint32_t *)keys.ptr, t.d_hist, t.d_tie, S(stream));
@@ -595,8 +651,9 @@ extern "C" int kmg_lloyd_unbind_image(kmg_lloyd *s)
 {
     if (!s) return fail(KMG_ERR_INVALID_ARGUMENT, "bad unbind_image arguments");
     HIP_TRY(hipSetDevice(s->p->device));
-    HIP_TRY(hipDeviceSynchronize());
-    free_table(s->tab);
+    HIP_TRY(hipDeviceSynchronize());                                 // nothing uses the tables any more
+    s->lab_pending[0] = s->lab_pending[1] = false;                   // (their label passes included)
+    free_table(s->p, s->tab);
     return KMG_OK;
 }
 
@@ -880,19 +937,28 @@ static int lloyd_create_impl(kmg_processor *p, uint32_t k, kmg_lloyd **out, hipS
     s->lab_pending[0] = s->lab_pending[1] = false; s->set = 0;
     s->pooled = pool_stream != nullptr;
     s->pool_stream = pool_stream;
-    auto alloc = [&](void **ptr, size_t bytes) {
-        return s->pooled ? hipMallocAsync(ptr, bytes, pool_stream) : hipMalloc(ptr, bytes);
-    };
-    auto zero = [&](void *ptr, size_t bytes) {
-        return s->pooled ? hipMemsetAsync(ptr, 0, bytes, pool_stream) : hipMemset(ptr, 0, bytes);
-    };
-    hipError_t e = alloc((void **)&s->d_cent, sizeof(Centroid) * k);
-    if (e == hipSuccess) e = zero(s->d_cent, sizeof(Centroid) * k);   // structures.rs:501-521
-    if (e == hipSuccess) e = alloc((void **)&s->d_partials, sizeof(int64_t) * 4ull * k * 2048ull);
-    if (e == hipSuccess) e = alloc((void **)&s->d_acc, sizeof(int64_t) * 4ull * k);
-    if (e == hipSuccess) e = alloc((void **)&s->d_nconv, sizeof(uint32_t));
-    if (e == hipSuccess) e = zero(s->d_nconv, sizeof(uint32_t));
-    if (e == hipSuccess) e = alloc((void **)&s->d_key, sizeof(unsigned long long));
+    s->ws = nullptr; s->ws_cap = 0; s->dist_blk_cap = 0;
+    // one block from the processor's idle blocks (a warm processor creates a kmg_lloyd without a hipMalloc)
+    const size_t sizes[5] = {sizeof(Centroid) * k, sizeof(int64_t) * 4ull * k * 2048ull, sizeof(int64_t) * 4ull * k, sizeof(uint32_t),
+                             sizeof(unsigned long long)};
+    size_t need = 0;
+    for (size_t b : sizes) need += pad256(b);
+    hipError_t e = block_take(p, need, &s->ws, &s->ws_cap);
+    if (e == hipSuccess) {
+        size_t off = 0;
+        s->d_cent = (Centroid *)carve(s->ws, off, sizes[0]);
+        s->d_partials = (int64_t *)carve(s->ws, off, sizes[1]);
+        s->d_acc = (int64_t *)carve(s->ws, off, sizes[2]);
+        s->d_nconv = (uint32_t *)carve(s->ws, off, sizes[3]);
+        s->d_key = (unsigned long long *)carve(s->ws, off, sizes[4]);
+        auto zero = [&](void *ptr, size_t bytes) {
+            return s->pooled ? hipMemsetAsync(ptr, 0, bytes, pool_stream) : hipMemset(ptr, 0, bytes);
+        };
+        e = zero(s->d_cent, sizeof(Centroid) * k);                    // structures.rs:501-521
+        if (e == hipSuccess) e = zero(s->d_nconv, sizeof(uint32_t));
+    } else {
+        s->ws = nullptr; s->ws_cap = 0;
+    }
     if (e != hipSuccess) {
         kmg_lloyd_destroy(s);
         return fail(e == hipErrorOutOfMemory ? KMG_ERR_OUT_OF_MEMORY : KMG_ERR_HIP,
@@ -911,22 +977,17 @@ extern "C" void kmg_lloyd_destroy(kmg_lloyd *s)
 {
     if (!s) return;
     (void)hipSetDevice(s->p->device);
-    auto release = [&](void *ptr) {
-        if (!ptr) return;
-        if (s->pooled) (void)hipFreeAsync(ptr, s->pool_stream); else (void)hipFree(ptr);
-    };
     if (s->side) {
         (void)hipStreamSynchronize(s->side);
         (void)hipStreamDestroy(s->side);
         (void)hipEventDestroy(s->ev_cube); (void)hipEventDestroy(s->ev_lab[0]); (void)hipEventDestroy(s->ev_lab[1]);
     }
-    release(s->d_cent);
-    release(s->d_partials);
-    release(s->d_acc);
-    release(s->d_nconv);
-    release(s->d_key);
-    release(s->d_dist);
-    free_table(s->tab);
+    // The blocks go back to the processor; nothing may still be using them.  Per-call objects of the host-buffer API live
+    // on one private stream; for a caller's object every stream counts, as with the hipFree this replaces.
+    if (s->pooled) (void)hipStreamSynchronize(s->pool_stream); else (void)hipDeviceSynchronize();
+    block_give(s->p, s->ws, s->ws_cap);
+    block_give(s->p, s->d_dist, s->dist_blk_cap);
+    free_table(s->p, s->tab);
     destroy_events(s);
     delete s;
 }
@@ -991,11 +1052,16 @@ static int init_over_colours(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, ui
     }
     ColourTable &t = s->tab;
     if (!t.d_tie) {
-        hipError_t e = hipMalloc((void **)&t.d_tie, sizeof(uint32_t) << 24);
-        if (e == hipSuccess) e = hipMalloc((void **)&t.d_cdist, sizeof(float) << 24);
-        if (e == hipSuccess) e = hipMalloc(&t.d_init_cells, init_scratch_bytes());
-        if (e != hipSuccess)
+        const size_t need = pad256(sizeof(uint32_t) << 24) + pad256(sizeof(float) << 24) + pad256(init_scratch_bytes());
+        const hipError_t e = block_take(s->p, need, &t.blk_init, &t.blk_init_cap);
+        if (e != hipSuccess) {
+            t.blk_init = nullptr; t.blk_init_cap = 0;
             return fail(e == hipErrorOutOfMemory ? KMG_ERR_OUT_OF_MEMORY : KMG_ERR_HIP, "init tables allocation failed: %s", hipGetErrorString(e));
+        }
+        size_t off = 0;
+        t.d_tie = (uint32_t *)carve(t.blk_init, off, sizeof(uint32_t) << 24);
+        t.d_cdist = (float *)carve(t.blk_init, off, sizeof(float) << 24);
+        t.d_init_cells = carve(t.blk_init, off, init_scratch_bytes());
     }
     int rc;
     if ((rc = bind_image_impl(s, d_rgba, n, stream, true, first_index)) != KMG_OK) return rc;
@@ -1024,11 +1090,10 @@ extern "C" int kmg_lloyd_init_centroids(kmg_lloyd *s, const uint8_t *d_rgba, uin
         if (!colours && s->dist_cap < n) {
             if (s->d_dist) {
                 HIP_TRY(hipStreamSynchronize(S(stream)));
-                HIP_TRY(s->pooled ? hipFreeAsync(s->d_dist, s->pool_stream) : hipFree(s->d_dist));
-                s->d_dist = nullptr; s->dist_cap = 0;
+                block_give(s->p, s->d_dist, s->dist_blk_cap);
+                s->d_dist = nullptr; s->dist_cap = 0; s->dist_blk_cap = 0;
             }
-            HIP_TRY(s->pooled ? hipMallocAsync((void **)&s->d_dist, sizeof(float) * n, s->pool_stream)
-                              : hipMalloc((void **)&s->d_dist, sizeof(float) * n));
+            HIP_TRY(block_take(s->p, sizeof(float) * n, (void **)&s->d_dist, &s->dist_blk_cap));
             s->dist_cap = n;
         }
         for (uint32_t j = 1; j < s->k + (colours ? 1u : 0u); ++j) {   // modules.rs:1211-1246
@@ -1077,11 +1142,10 @@ extern "C" int kmg_lloyd_init_step(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t
         if (j != 1) return fail(KMG_ERR_INVALID_ARGUMENT, "init_step: the distance map of this band was never started (j = 1)");
         if (s->d_dist) {
             HIP_TRY(hipStreamSynchronize(S(stream)));
-            HIP_TRY(s->pooled ? hipFreeAsync(s->d_dist, s->pool_stream) : hipFree(s->d_dist));
-            s->d_dist = nullptr; s->dist_cap = 0;
+            block_give(s->p, s->d_dist, s->dist_blk_cap);
+            s->d_dist = nullptr; s->dist_cap = 0; s->dist_blk_cap = 0;
         }
-        HIP_TRY(s->pooled ? hipMallocAsync((void **)&s->d_dist, sizeof(float) * n_local, s->pool_stream)
-                          : hipMalloc((void **)&s->d_dist, sizeof(float) * n_local));
+        HIP_TRY(block_take(s->p, sizeof(float) * n_local, (void **)&s->d_dist, &s->dist_blk_cap));
         s->dist_cap = n_local;
     }
     HIP_TRY(launch_init_pass((const uint32_t *)d_rgba, n_local, s->p->d_lut, s->d_cent, j, s->d_dist,
@@ -1126,6 +1190,9 @@ static int assign_pass(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_t
         s->last_rows = kMergeRows;
         return table_assign(s, d_rgba, n, d_labels, s->d_partials, kMergeRows, st);
     }
+    // a label pass kmg_lloyd_iterate left on the side stream may still be writing d_labels
+    int rc_;
+    if ((rc_ = side_flush(s, st)) != KMG_OK) return rc_;
     s->last_rows = assign_grid(n);
     PROF_LAUNCH(s, KMG_K_ASSIGN, st, launch_assign((const uint32_t *)d_rgba, n, s->d_cent, s->k, s->p->d_lut, d_labels,
                                                   sums ? s->d_partials : nullptr, st));
@@ -1164,9 +1231,9 @@ extern "C" int kmg_lloyd_labels(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n,
 {
     if (!s || !d_rgba || !d_labels || n == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad labels arguments");
     HIP_TRY(hipSetDevice(s->p->device));
+    int rc_;
+    if ((rc_ = side_flush(s, S(stream))) != KMG_OK) return rc_;      // both branches write d_labels
     if (table_bound(s, d_rgba, n) && s->tab.tables_valid) {
-        int rc_;
-        if ((rc_ = side_flush(s, S(stream))) != KMG_OK) return rc_;
         PROF_LAUNCH(s, KMG_K_LABELS, S(stream), launch_labels((const uint32_t *)d_rgba, n, s->tab.d_colour_labels,
                                                               s->tab.d_sub, s->k, nullptr, d_labels, S(stream), s->reserve_cus));
         return KMG_OK;
@@ -1271,27 +1338,42 @@ extern "C" int kmg_lloyd_iterate(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n
         HIP_TRY(hipEventCreateWithFlags(&s->ev_lab[0], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&s->ev_lab[1], hipEventDisableTiming));
     }
-    const size_t sub_bytes = sizeof(uint16_t) * (kSubCells + kCells) + sizeof(uint32_t) * kCells;
+    const size_t sub_bytes = sub_table_bytes();
     if (!t.d_colour_labels_alt) {
-        HIP_TRY(hipMalloc(&t.d_colour_labels_alt, (size_t)(s->k <= 256 ? 1 : 2) << 24));
-        HIP_TRY(hipMalloc((void **)&t.d_sub_alt, sub_bytes));
+        const size_t lab_bytes = (size_t)(s->k <= 256 ? 1 : 2) << 24;
+        HIP_TRY(block_take(s->p, pad256(lab_bytes) + pad256(sub_bytes), &t.blk_alt, &t.blk_alt_cap));
+        size_t off = 0;
+        t.d_colour_labels_alt = carve(t.blk_alt, off, lab_bytes);
+        t.d_sub_alt = (uint16_t *)carve(t.blk_alt, off, sub_bytes);
         HIP_TRY(hipMemsetAsync(t.d_sub_alt, 0xFF, sub_bytes, st));     // as bind_image_impl does for the first set
     }
-    // write the other set; its last reader (the label pass of two iterations ago) must be through
+    // write the other set; its last reader (the label pass of two iterations ago) must be through.  Until the cube
+    // pass has been issued the set holds the tables of two iterations ago (or nothing): not valid.  If a call in between
+    // fails, the swap is undone, so a later label pass never gathers from that set.
     std::swap(t.d_colour_labels, t.d_colour_labels_alt);
     std::swap(t.d_sub, t.d_sub_alt);
     s->set ^= 1;
-    if (s->lab_pending[s->set]) {
-        HIP_TRY(hipStreamWaitEvent(st, s->ev_lab[s->set], 0));
-        s->lab_pending[s->set] = false;
-    }
+    t.tables_valid = false;
     t.bound_by_init = false;
-    if (update_first)
-        PROF_LAUNCH(s, KMG_K_UPDATE, st, launch_update(d_acc4, s->k, s->p->opt.convergence, s->d_cent, s->d_nconv, st));
-    HIP_TRY(hipMemsetAsync(d_acc4, 0, sizeof(int64_t) * 4ull * s->k, st));
-    PROF_LAUNCH(s, KMG_K_CUBE, st, launch_cube(t.d_hist, t.d_agg, t.d_sub_agg, t.d_occ, t.d_work, s->p->d_bounds, s->p->d_sub_bounds,
-                                               s->d_cent, s->k, s->p->d_lab_table, t.d_masks, t.d_cell_work, t.d_colour_labels, t.d_sub,
-                                               d_acc4, 1u, 0u, nullptr, st));
+    auto issue = [&]() -> int {
+        if (s->lab_pending[s->set]) {
+            HIP_TRY(hipStreamWaitEvent(st, s->ev_lab[s->set], 0));
+            s->lab_pending[s->set] = false;
+        }
+        if (update_first)
+            PROF_LAUNCH(s, KMG_K_UPDATE, st, launch_update(d_acc4, s->k, s->p->opt.convergence, s->d_cent, s->d_nconv, st));
+        HIP_TRY(hipMemsetAsync(d_acc4, 0, sizeof(int64_t) * 4ull * s->k, st));
+        PROF_LAUNCH(s, KMG_K_CUBE, st, launch_cube(t.d_hist, t.d_agg, t.d_sub_agg, t.d_occ, t.d_work, s->p->d_bounds, s->p->d_sub_bounds,
+                                                   s->d_cent, s->k, s->p->d_lab_table, t.d_masks, t.d_cell_work, t.d_colour_labels, t.d_sub,
+                                                   d_acc4, 1u, 0u, nullptr, st));
+        return KMG_OK;
+    };
+    if ((rc = issue()) != KMG_OK) {
+        std::swap(t.d_colour_labels, t.d_colour_labels_alt);
+        std::swap(t.d_sub, t.d_sub_alt);
+        s->set ^= 1;
+        return rc;
+    }
     t.tables_valid = true;
     HIP_TRY(hipEventRecord(s->ev_cube, st));
     HIP_TRY(hipStreamWaitEvent(s->side, s->ev_cube, 0));
@@ -1497,7 +1579,7 @@ int extract_palette_kmeans(kmg_processor *p, const uint8_t *d_rgba, uint32_t w, 
     const uint32_t m = p->opt.shrink_max_dim;
     if (m && (w > m || h > m)) {                                       // structures.rs:67-74
         kmg_resized_dims(w, h, m, &sw, &sh);
-        HIP_TRY(small.alloc((size_t)sw * sh * 4, st));
+        HIP_TRY(small.alloc(p, (size_t)sw * sh * 4, st));
         if ((rc = kmg_dev_resize(p, d_rgba, w, h, sw, sh, (uint8_t *)small.ptr, st)) != KMG_OK) return rc;
         src = (const uint8_t *)small.ptr;
     }
@@ -1523,10 +1605,10 @@ int extract_palette_kmeans(kmg_processor *p, const uint8_t *d_rgba, uint32_t w, 
     return KMG_OK;
 }
 
-int upload_image(const uint8_t *rgba, uint32_t w, uint32_t h, hipStream_t st, StreamBuf &buf)
+int upload_image(kmg_processor *p, const uint8_t *rgba, uint32_t w, uint32_t h, hipStream_t st, StreamBuf &buf)
 {
     const size_t bytes = (size_t)w * h * 4;
-    HIP_TRY(buf.alloc(bytes, st));
+    HIP_TRY(buf.alloc(p, bytes, st));
     HIP_TRY(hipMemcpyAsync(buf.ptr, rgba, bytes, hipMemcpyHostToDevice, st));   // structures.rs:31-65
     return KMG_OK;
 }
@@ -1538,7 +1620,7 @@ int apply_and_download(kmg_processor *p, const uint8_t *d_rgba, uint32_t w, uint
     int rc;
     StreamBuf out;
     const size_t bytes = (size_t)w * h * 4;
-    HIP_TRY(out.alloc(bytes, st));
+    HIP_TRY(out.alloc(p, bytes, st));
     if ((rc = kmg_dev_apply(p, d_rgba, w, h, 0, c4, k, mode, (uint8_t *)out.ptr, st)) != KMG_OK) return rc;
     HIP_TRY(hipMemcpyAsync(out_rgba, out.ptr, bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -1557,7 +1639,7 @@ int octree_palette_of(kmg_processor *p, const uint8_t *d_rgba, uint32_t w, uint3
     StreamBuf small;
     if (w > MAX_SIZE || h > MAX_SIZE) {
         kmg_resized_dims(w, h, MAX_SIZE, &sw, &sh);
-        HIP_TRY(small.alloc((size_t)sw * sh * 4, st));
+        HIP_TRY(small.alloc(p, (size_t)sw * sh * 4, st));
         if ((rc = kmg_dev_resize(p, d_rgba, w, h, sw, sh, (uint8_t *)small.ptr, st)) != KMG_OK) return rc;
         src = (const uint8_t *)small.ptr;
     }
@@ -1606,7 +1688,7 @@ extern "C" int kmg_find(kmg_processor *p, const uint8_t *rgba, uint32_t w, uint3
     std::vector<float> c4(4 * (size_t)n_colors);
     if ((rc = kmg_palette_to_centroids(palette_rgba, n_colors, c4.data())) != KMG_OK) return rc;  // lib.rs:86-87
     StreamBuf img;
-    if ((rc = upload_image(rgba, w, h, sg.st, img)) != KMG_OK) return rc;
+    if ((rc = upload_image(p, rgba, w, h, sg.st, img)) != KMG_OK) return rc;
     return apply_and_download(p, (const uint8_t *)img.ptr, w, h, c4.data(), n_colors, mode, sg.st, out_rgba);
 }
 
@@ -1625,7 +1707,7 @@ extern "C" int kmg_reduce(kmg_processor *p, const uint8_t *rgba, uint32_t w, uin
     StreamGuard sg;
     HIP_TRY(sg.acquire(p));
     StreamBuf img;
-    if ((rc = upload_image(rgba, w, h, sg.st, img)) != KMG_OK) return rc;
+    if ((rc = upload_image(p, rgba, w, h, sg.st, img)) != KMG_OK) return rc;
     if (algo == KMG_ALGO_OCTREE) {                                     // lib.rs:133-136
         std::vector<std::array<uint8_t, 4>> colors;
         if ((rc = octree_palette_of(p, (const uint8_t *)img.ptr, w, h, color_count, sg.st, colors)) != KMG_OK) return rc;
@@ -1652,7 +1734,7 @@ extern "C" int kmg_palette(kmg_processor *p, const uint8_t *rgba, uint32_t w, ui
     StreamGuard sg;
     HIP_TRY(sg.acquire(p));
     StreamBuf img;
-    if ((rc = upload_image(rgba, w, h, sg.st, img)) != KMG_OK) return rc;
+    if ((rc = upload_image(p, rgba, w, h, sg.st, img)) != KMG_OK) return rc;
     if (algo == KMG_ALGO_OCTREE) {                                     // lib.rs:288-331
         std::vector<std::array<uint8_t, 4>> colors;
         if ((rc = octree_palette_of(p, (const uint8_t *)img.ptr, w, h, color_count, sg.st, colors)) != KMG_OK) return rc;

@@ -774,6 +774,16 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
                              sizeof(uint32_t) * (kBlock / 64) * kMaxListed + sizeof(unsigned long long) * (kBlock / 64) * (kpad / 64u);
     const size_t lds_scan = sizeof(float4) * kpad + (with_sums ? sizeof(unsigned long long) * (4ull * k + 4ull) * repl : 0) +
                             sizeof(float4) * (kBlock / 64) * kMaxListed + (k <= 256 ? 1u : 2u) * (kBlock / 64) * kCellColours;
+    {
+        // the largest k (KMG_MAX_K) takes ~150 KiB per workgroup: refuse a launch the device cannot hold instead of failing in it
+        static const size_t lds_max = [] {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v <= 0)
+                v = 65536;
+            return (size_t)v;
+        }();
+        if (lds_stage > lds_max || lds_scan > lds_max) return hipErrorInvalidValue;
+    }
     // (the scan kernel's cells differ a lot in cost: finer hand-out, 2 cells per wave, measured 83 -> 75 us)
     static const uint32_t g_stage = env_grid("KMG_CUBE_GRID", kCubeGrid), g_scan = env_grid("KMG_SCAN_GRID", 2u * kCubeGrid),
                           g_pairs = env_grid("KMG_PAIRS_GRID", kCubeGrid);

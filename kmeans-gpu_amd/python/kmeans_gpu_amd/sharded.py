@@ -73,7 +73,10 @@ def sharded_init(backend, k, band, width, height, row0, group=None, stream=0):
         publish(j)
 
 
-RESERVED_CUS = 8     # compute units the label pass leaves to the collective when the loop really exchanges sums
+# Compute units the label pass can leave to the collective (ShardedLloyd(reserve_cus=...)).  Opt-in: with one rank the
+# reservation costs 5 us per iteration and buys nothing (profiles/r02_dist_overhead.txt); beyond one rank it has never
+# been measured.
+RESERVED_CUS = 0
 
 
 class ShardedLloyd:
@@ -85,7 +88,8 @@ class ShardedLloyd:
     labels   : int32 tensor (rows*width,) or None
     """
 
-    def __init__(self, backend, k, rgba, labels=None, group=None, stream=0, collective=None, local_only=False):
+    def __init__(self, backend, k, rgba, labels=None, group=None, stream=0, collective=None, local_only=False,
+                 reserve_cus=RESERVED_CUS):
         self.backend = backend
         self.k = int(k)
         self.rgba = rgba
@@ -104,12 +108,17 @@ class ShardedLloyd:
         # True when the backend produces labels with a separate pass (kmeans_gpu_amd.Lloyd after
         # prepare() chose the colour table): lets the collective overlap that pass
         self.split_labels = False
-        # label pass of iteration t beside the cube pass of iteration t + 1 (Lloyd.iterate); False: step by step
-        self.pipeline = True
-        # the asynchronous all-reduce is meant to run BESIDE the label pass, but RCCL's kernel (256 threads, 20 KiB LDS,
-        # 280 registers per lane) does not fit on a CU that hosts a label workgroup: leave a few CUs to it
-        if dist.is_initialized() and self.world > 1 and collective is None and hasattr(backend, "reserve_cus"):
-            backend.reserve_cus(RESERVED_CUS)
+        # label pass of iteration t beside the cube pass of iteration t + 1 (Lloyd.iterate); False (the measured path:
+        # the two passes time-slice a CU rather than overlap, profiles/r03_overlap_shapes.txt): step by step
+        self.pipeline = False
+        # The asynchronous all-reduce is issued to run beside the label pass, but RCCL's kernel (256 threads, 20 KiB LDS,
+        # 280 registers per lane) does not fit on a CU that hosts a label workgroup; reserve_cus > 0 launches the label pass
+        # with that many workgroups fewer than CUs.  Reset in close().
+        self._reserved = 0
+        if (reserve_cus and dist.is_initialized() and self.world > 1 and collective is None
+                and hasattr(backend, "reserve_cus")):
+            backend.reserve_cus(int(reserve_cus))
+            self._reserved = int(reserve_cus)
 
     def _pass(self):
         """labels + sums of the current centroids, and the exchange of the sums.
@@ -173,6 +182,13 @@ class ShardedLloyd:
         if hasattr(self.backend, "flush"):
             self.backend.flush(self.stream)
 
+    def close(self):
+        """hand the backend back as it was found (a reservation of compute units is the loop's, not the backend's)"""
+        self.flush()
+        if self._reserved:
+            self.backend.reserve_cus(0)
+            self._reserved = 0
+
     def run(self, max_iterations=128, check_period=8):
         """ChooseCentroidModule::compute (modules.rs:763-840) over all bands.  Returns the
         iteration at which the loop stopped."""
@@ -184,7 +200,7 @@ class ShardedLloyd:
                 # identical on every rank: all ranks updated from the same global sums
                 if self.backend.converged_count(self.stream) >= self.k:
                     break
-        self.flush()
+        self.close()
         return it
 
 

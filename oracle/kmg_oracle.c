@@ -330,34 +330,55 @@ void orc_init_centroids(const float *lab3, uint32_t w, uint32_t h, uint32_t k,
     float *dist = (float *)malloc(sizeof(float) * n);
     for (uint64_t i = 0; i < n; ++i) dist[i] = 1000000.0f;      /* calc_diff.wgsl:26 */
 
+    /* The arg-max below is a fold over blocks of 16 pixels (one per GPU thread of the reference) in ascending
+     * order with "a later block wins a tie"; its result is the LAST block attaining the largest block value.
+     * Folding contiguous ranges of blocks separately (one per OpenMP thread, each from Candidate(0, 0.0)) and
+     * then the range results in ascending order with the same rule gives exactly that block: same tie rule,
+     * any number of threads.                                                                              */
+    const int64_t n_blocks = (int64_t)((n + 15) / 16);
+    int n_thr = omp_get_max_threads();
+    if (n_thr < 1) n_thr = 1;
+    float *part_d = (float *)malloc(sizeof(float) * (size_t)n_thr);
+    uint32_t *part_i = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)n_thr);
+
     for (uint32_t j = 1; j < k; ++j) {
         /* kmeans++_calc_diff.wgsl:27-30: min over centroids 0..j-1 of cie94(pixel, c).
          * min is exact, so keeping the running minimum equals recomputing it.           */
         const float *c = centroids4 + 4 * (j - 1);
-#pragma omp parallel for schedule(static)
-        for (int64_t i = 0; i < (int64_t)n; ++i) {
-            float d = orc_cie94(lab3 + 3 * i, c);
-            dist[i] = fminf(dist[i], d);
-        }
         /* plus_plus_init.wgsl:62-68,84-143: arg-max.  selectCandidate(a,b) returns b only
          * when a.distance < b.distance.  Each thread folds its N_SEQ=16 consecutive pixels
          * starting from Candidate(0, 0.0) with the accumulator as `a` (earliest maximum
          * wins inside a thread); threads / workgroups are folded with the LATER one as `a`
          * (latest maximum wins across threads).                                          */
-        uint32_t best_idx = 0; float best_d = 0.0f;
-        for (uint64_t s = 0; s < n; s += 16) {
-            uint32_t l_idx = 0; float l_d = 0.0f;
-            uint64_t e = s + 16 < n ? s + 16 : n;
-            for (uint64_t i = s; i < e; ++i)
-                if (l_d < dist[i]) { l_d = dist[i]; l_idx = (uint32_t)i; }
-            if (!(l_d < best_d)) { best_d = l_d; best_idx = l_idx; }
+        for (int t = 0; t < n_thr; ++t) { part_d[t] = -1.0f; part_i[t] = 0; }   /* -1: range without blocks */
+#pragma omp parallel num_threads(n_thr)
+        {
+            const int t = omp_get_thread_num(), nt = omp_get_num_threads();
+            const int64_t b0 = n_blocks * t / nt, b1 = n_blocks * (t + 1) / nt;
+            uint32_t best_idx = 0; float best_d = 0.0f;
+            for (int64_t b = b0; b < b1; ++b) {
+                uint64_t s0 = (uint64_t)b * 16, e = s0 + 16 < n ? s0 + 16 : n;
+                uint32_t l_idx = 0; float l_d = 0.0f;
+                for (uint64_t i = s0; i < e; ++i) {
+                    float d = fminf(dist[i], orc_cie94(lab3 + 3 * i, c));
+                    dist[i] = d;
+                    if (l_d < d) { l_d = d; l_idx = (uint32_t)i; }
+                }
+                if (!(l_d < best_d)) { best_d = l_d; best_idx = l_idx; }
+            }
+            if (b1 > b0) { part_d[t] = best_d; part_i[t] = best_idx; }
         }
+        uint32_t best_idx = 0; float best_d = 0.0f;
+        for (int t = 0; t < n_thr; ++t)
+            if (part_d[t] >= 0.0f && !(part_d[t] < best_d)) { best_d = part_d[t]; best_idx = part_i[t]; }
         /* plus_plus_init.wgsl:172-181 `pick` */
         centroids4[4 * j + 0] = lab3[3 * (uint64_t)best_idx + 0];
         centroids4[4 * j + 1] = lab3[3 * (uint64_t)best_idx + 1];
         centroids4[4 * j + 2] = lab3[3 * (uint64_t)best_idx + 2];
         centroids4[4 * j + 3] = 1.0f;
     }
+    free(part_d);
+    free(part_i);
     free(dist);
 }
 

@@ -172,6 +172,71 @@ def test_dither_of_every_colour_takes_the_literal_argmin(torch_cuda, oracle, mon
         p.close()
 
 
+def test_cfg3_init_at_full_resolution_vs_oracle(torch_cuda, oracle, monkeypatch):
+    """BASELINE config 3's own initialisation: the farthest-point init (plus_plus_init.wgsl:62-68,84-143,161-181,
+    kmeans++_calc_diff.wgsl) of the WHOLE 8192x8192 image, k=256 -- 255 passes over 67 M pixels in the oracle --
+    against the device init walking the image's colours (table strategy: k_init_fused, cell skipping, slots) and
+    walking its pixels (k_init_pass): all 256 centroids bit-equal, in order."""
+    import kmeans_gpu_amd as kg
+    from kmeans_gpu_amd import synth
+    torch = torch_cuda
+    st = _stream(torch)
+    w = h = 8192
+    n, k = w * h, 256
+    rgba = synth.uniform_rgba_torch(synth.SEED_CFG3, n, device="cuda")
+    lab = oracle.rgb_to_lab(rgba.cpu().numpy())
+    want = oracle.init_centroids(lab, w, h, k)
+    del lab
+    for strategy in ("table", "brute"):
+        monkeypatch.setenv("KMG_STRATEGY", strategy)
+        p = kg.ImageProcessor(shrink_max_dim=0)
+        s = kg.Lloyd(p, k)
+        s.init_centroids(rgba.data_ptr(), w, h, st)
+        got = s.get_centroids(st)
+        diff = np.flatnonzero((got.view(np.uint32) != want.view(np.uint32)).any(axis=1))
+        assert diff.size == 0, f"{strategy}: first differing centroid {int(diff[0])} of {diff.size}: {got[diff[0]]} != {want[diff[0]]}"
+        s.close()
+        p.close()
+
+
+def test_cfg3_dither_k256_rows_vs_oracle(torch_cuda, oracle, monkeypatch):
+    """BASELINE config 3's output pass: ordered dither (mix_colors.wgsl:50-83) with the k=256 centroids the cfg3 loop
+    ends with (init at full resolution + Lloyd to convergence on the device), 8192x8192: the first 1024 rows, 1028 rows
+    from row 4000 and the last 1028 rows equal the oracle's, for the pruned pass (default at this size) and the scan of
+    all 256 centroids on the first band."""
+    import kmeans_gpu_amd as kg
+    from kmeans_gpu_amd import synth
+    torch = torch_cuda
+    st = _stream(torch)
+    w = h = 8192
+    n, k = w * h, 256
+    rgba = synth.uniform_rgba_torch(synth.SEED_CFG3, n, device="cuda")
+    p = kg.ImageProcessor(shrink_max_dim=0)
+    s = kg.Lloyd(p, k)
+    s.init_centroids(rgba.data_ptr(), w, h, st)
+    s.run(rgba.data_ptr(), n, 0, st)
+    cent = s.get_centroids(st)
+    s.close()
+    out = torch.zeros((n, 4), dtype=torch.uint8, device="cuda")
+    p.apply(rgba.data_ptr(), w, h, 0, cent, kg.ReduceMode.Dither, out.data_ptr(), st)
+    torch.cuda.synchronize()
+    first_want = None
+    for r0, rows in ((0, 1024), (4000, 1028), (h - 1028, 1028)):     # r0 % 4 == 0: the oracle's Bayer rows line up
+        src = rgba[r0 * w:(r0 + rows) * w].cpu().numpy().reshape(rows, w, 4)
+        want = oracle.apply(src, cent, oracle.MODE_DITHER)
+        got = out[r0 * w:(r0 + rows) * w].cpu().numpy().reshape(rows, w, 4)
+        assert np.array_equal(got, want), f"rows {r0}..{r0 + rows}: {int((got != want).any(-1).sum())} pixels differ"
+        if first_want is None:
+            first_want = want
+    # the same band through the per-pixel scan of all centroids (k_apply<DITHER>)
+    monkeypatch.setenv("KMG_STRATEGY", "brute")
+    p.apply(rgba.data_ptr(), w, 1024, 0, cent, kg.ReduceMode.Dither, out.data_ptr(), st)
+    torch.cuda.synchronize()
+    got = out[:1024 * w].cpu().numpy().reshape(1024, w, 4)
+    assert np.array_equal(got, first_want), f"scan: {int((got != first_want).any(-1).sum())} pixels differ"
+    p.close()
+
+
 @pytest.mark.parametrize("palette", ["resurrect_64.png", "apollo-1x.png"])
 def test_cfg5_find_dither_1024_rows_and_tail_vs_oracle(torch_cuda, oracle, palette):
     """BASELINE config 5 (find -m dither, fixed palette, 8192x8192): the first 1024 rows, 1028 rows that

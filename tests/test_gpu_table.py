@@ -827,3 +827,32 @@ def test_label_pass_with_reserved_compute_units(torch_cuda, oracle, monkeypatch)
     assert np.array_equal(maps[0][:200_000].view(np.uint32), want)
     with pytest.raises(kg.KmgError):
         kg.Lloyd(proc, k).reserve_cus(129)
+
+
+@pytest.mark.parametrize("k", [1024, 3072])
+def test_large_k_through_the_colour_table(torch_cuda, oracle, monkeypatch, k):
+    """KMG_MAX_K = 3072 and a k between: the words > 4 candidate masks, u16 labels, cells beyond the listing limit and
+    ~150 KiB of LDS per cube workgroup.  One assign + accumulate pass of a bound image equals the oracle, and the
+    exhaustive check of the cube pass (bounds, masks, per-colour labels over all 2^24 colours) finds nothing."""
+    import kmeans_gpu_amd as kg
+    torch = torch_cuda
+    st = _stream(torch)
+    monkeypatch.setenv("KMG_STRATEGY", "table")
+    n = 300_000
+    img = oracle.synth_uniform(5, n)
+    cent = oracle.centroids4(oracle.rgb_to_lab(img[:k]))
+    want_l, want_a = oracle.assign_accumulate_rgba(img, cent)
+    d = _dev(torch, img)
+    p = kg.ImageProcessor(shrink_max_dim=0)
+    s = kg.Lloyd(p, k)
+    s.set_centroids(cent, st)
+    assert s.prepare(d.data_ptr(), n, True, st) == "table"
+    labels = torch.zeros(n, dtype=torch.int32, device="cuda")
+    acc = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
+    s.assign_accumulate(d.data_ptr(), n, labels.data_ptr(), acc.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert np.array_equal(labels.cpu().numpy().view(np.uint32), want_l)
+    assert np.array_equal(acc.cpu().numpy(), want_a)
+    assert s.debug_check_table(st) == (0, 0, 0)
+    s.close()
+    p.close()

@@ -150,3 +150,26 @@ def test_shrunk_dims_rule(oracle):
     assert oracle.resized_dims(100, 5000) == (5, 256)
     assert oracle.resized_dims(5000, 3) == (256, 1)
     assert oracle.resized_dims(300, 300) == (256, 256)
+
+
+def test_init_argmax_is_independent_of_the_thread_count(oracle, tokyo):
+    """orc_init_centroids folds the arg-max per OpenMP thread and then across threads with the reference's tie
+    rule (plus_plus_init.wgsl:62-68: a later thread / workgroup wins a tie): the picks must not depend on how many
+    threads share the fold.  Few colours -> many exact ties at the maximum; an image of ONE colour -> every
+    distance 0 -> Candidate(0, 0.0), i.e. pixel 0, k times."""
+    img = tokyo[100:180, 200:331].copy()                            # 80 x 131: not a multiple of 16 pixels
+    img[..., :3] &= 0xC0                                            # 64 colours at most
+    flat = np.zeros((33, 47, 4), np.uint8); flat[...] = (10, 200, 30, 255)
+    threads = oracle.num_threads()
+    try:
+        for im, k in ((img, 12), (flat, 4)):
+            h, w = im.shape[:2]
+            lab = oracle.rgb_to_lab(im)
+            got = []
+            for t in (1, 2, 3, 7, 8):
+                oracle.set_num_threads(t)
+                got.append(oracle.init_centroids(lab, w, h, k))
+            for g in got[1:]:
+                assert np.array_equal(g.view(np.uint32), got[0].view(np.uint32))
+    finally:
+        oracle.set_num_threads(threads)
