@@ -98,6 +98,7 @@ def other_distributions(proc, k, n_pixels, stream, steps=10):
         sh = ShardedLloyd(s, k, rgba, labels, stream=stream)
         sh.split_labels = strategy == "table"
         sh.pipeline = False
+        sh.fused = True
         sh.prime()
         for _ in range(3):
             sh.iterate()
@@ -144,6 +145,7 @@ def cfg4_rank_share(proc, k, n_pixels, stream, steps=5):
     batch = PlacedBatch(lloyds, k, images, labels, stream=stream, split_labels=split)
     for loop in batch.loops:
         loop.pipeline = False
+        loop.fused = True
         loop.prime()
         loop.iterate()
     torch.cuda.synchronize()
@@ -344,6 +346,8 @@ def main():
                     help="run the label pass of an iteration beside the next iteration's cube pass (kmg_lloyd_iterate) "
                          "instead of before it")
     ap.add_argument("--no-overlap", action="store_true", help="(the default) kept for scripts")
+    ap.add_argument("--separate-update", action="store_true",
+                    help="centroid update as a launch of its own (k_update + memset) instead of on the assign pass's last launch")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the all-reduce even with one rank (sanity check)")
     ap.add_argument("--strategy", choices=["auto", "scan", "table"], default="auto",
@@ -420,6 +424,7 @@ def main():
     sh = ShardedLloyd(lloyd, k, rgba, labels, stream=stream)
     sh.split_labels = strategy == "table"     # the all-reduce overlaps the label-gather pass
     sh.pipeline = bool(args.overlap) and not args.no_overlap
+    sh.fused = not args.separate_update       # one rank + colour table: the update rides on the assign pass's last launch
     if args.force_dist:
         sh.world = 2          # take the collective path even though the group has one rank
     sh.prime()
@@ -514,7 +519,9 @@ def main():
                        "width": WIDTH, "height": height, "k": k,
                        "sharding": f"row bands, {rows} rows per GPU",
                        "strategy": strategy, "prepare_ms": t_prep * 1e3, "prepare_cold_ms": t_prep_cold * 1e3,
-                       "label_pass": "beside the next iteration's cube pass" if sh.pipeline else "before the next iteration"},
+                       "label_pass": "beside the next iteration's cube pass" if sh.pipeline else "before the next iteration",
+                       "update": "by the last launch of the assign pass (kmg_lloyd_assign_update)" if sh._fused()
+                                 else "k_update launch"},
             "roofline": {"bound": "hbm", "kernel": dominant,
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS,

@@ -227,6 +227,14 @@ KMG_API int kmg_lloyd_profile_read(kmg_lloyd *s, double total_ms[KMG_K_COUNT], u
 /* choose_centroid.wgsl:180-206 `pick` for all k at once: centroid <- sum/count, convergence
  * flags.  d_acc4 holds the (all-reduced) accumulators.                                        */
 KMG_API int kmg_lloyd_update(kmg_lloyd *s, const int64_t *d_acc4, void *stream);
+/* The loop body of ChooseCentroidModule::compute (modules.rs:769-800) shifted by half a step: the assign pass of
+ * kmg_lloyd_assign_accumulate (labels optional, sums into d_acc4) and then -- do_update != 0 -- kmg_lloyd_update from
+ * those sums.  Same results as the two calls; with a bound image (colour table) the update is done by the last launch of
+ * the assign pass itself (one launch and one memset fewer per iteration).  d_acc4 holds the sums on return, the label
+ * tables keep describing the assignment just made.  Sharded images need the all-reduce between the two halves and use
+ * the separate calls.                                                                           */
+KMG_API int kmg_lloyd_assign_update(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n_pixels, uint32_t *d_labels,
+                                    int64_t *d_acc4, int do_update, void *stream);
 /* convergence[K] of choose_centroid.wgsl:196-202 after the last update (synchronises).       */
 KMG_API int kmg_lloyd_converged_count(kmg_lloyd *s, uint32_t *count, void *stream);
 

@@ -180,6 +180,9 @@ struct kmg_lloyd {
     Centroid *d_cent;            // k
     int64_t *d_partials;         // 2048 x k x 4
     int64_t *d_acc;              // k x 4 (used by kmg_lloyd_run)
+    int64_t *d_acc_int;          // k x 4: where the cube pass accumulates; ZERO between passes (its last launch hands the sums
+                                 // over and clears it, kmg_table.h CubeTail) -- no memset launch per pass
+    bool acc_int_dirty;          // a pass was interrupted: clear d_acc_int before the next one
     uint32_t *d_nconv;           // 1
     unsigned long long *d_key;   // 1 (init arg-max)
     float *d_dist;               // init distance map, grown on demand (a block of its own)
@@ -902,19 +905,40 @@ static bool table_bound(const kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n)
 // rows of `d_sums` (k x 4 int64 each): the caller's accumulators directly (rows = 1, no reduction pass), or
 // the partial slab for the two-step entry points.
 static int table_assign(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_t *d_labels, int64_t *d_sums,
-                        uint32_t rows, hipStream_t st)
+                        uint32_t rows, hipStream_t st, bool update_after = false)
 {
     ColourTable &t = s->tab;
     t.bound_by_init = false;      // only a prepare() that directly follows the initialisation may reuse its binding
     int rc_;
     if ((rc_ = side_flush(s, st)) != KMG_OK) return rc_;
-    HIP_TRY(hipMemsetAsync(d_sums, 0, sizeof(int64_t) * 4ull * s->k * rows, st));
-    PROF_LAUNCH(s, KMG_K_CUBE, st, launch_cube(t.d_hist, t.d_agg, t.d_sub_agg, t.d_occ, t.d_work, s->p->d_bounds, s->p->d_sub_bounds,
-                                               s->d_cent, s->k, s->p->d_lab_table, t.d_masks, t.d_cell_work, t.d_colour_labels, t.d_sub,
-                                               d_sums, rows, 0u, nullptr, st));
+    if (rows == 1u) {
+        // the sums accumulate in the state's own buffer, which is zero between passes: the last launch of the cube pass
+        // hands them over to d_sums, clears the buffer again and -- update_after -- updates the centroids from them
+        // (CubeTail): neither a memset nor a k_update launch
+        if (s->acc_int_dirty) HIP_TRY(hipMemsetAsync(s->d_acc_int, 0, sizeof(int64_t) * 4ull * s->k, st));
+        s->acc_int_dirty = true;
+        CubeTail tail;
+        tail.acc_out = d_sums;
+        tail.do_update = update_after ? 1 : 0;
+        tail.convergence = s->p->opt.convergence;
+        tail.cent = s->d_cent;
+        tail.n_converged = s->d_nconv;
+        PROF_LAUNCH(s, KMG_K_CUBE, st, launch_cube(t.d_hist, t.d_agg, t.d_sub_agg, t.d_occ, t.d_work, s->p->d_bounds, s->p->d_sub_bounds,
+                                                   s->d_cent, s->k, s->p->d_lab_table, t.d_masks, t.d_cell_work, t.d_colour_labels, t.d_sub,
+                                                   s->d_acc_int, 1u, 0u, nullptr, st, &tail));
+        s->acc_int_dirty = false;
+    } else {
+        if (update_after) return fail(KMG_ERR_INVALID_ARGUMENT, "table_assign: update_after needs the final sums");
+        HIP_TRY(hipMemsetAsync(d_sums, 0, sizeof(int64_t) * 4ull * s->k * rows, st));
+        PROF_LAUNCH(s, KMG_K_CUBE, st, launch_cube(t.d_hist, t.d_agg, t.d_sub_agg, t.d_occ, t.d_work, s->p->d_bounds, s->p->d_sub_bounds,
+                                                   s->d_cent, s->k, s->p->d_lab_table, t.d_masks, t.d_cell_work, t.d_colour_labels, t.d_sub,
+                                                   d_sums, rows, 0u, nullptr, st));
+    }
     t.tables_valid = true;
     if (d_labels)
         PROF_LAUNCH(s, KMG_K_LABELS, st, launch_labels((const uint32_t *)d_rgba, n, t.d_colour_labels, t.d_sub, s->k, nullptr, d_labels, st, s->reserve_cus));
+    // (after an update the tables still describe the assignment just made, not the new centroids)
+    if (update_after) t.tables_valid = false;
     return KMG_OK;
 }
 
@@ -939,8 +963,8 @@ static int lloyd_create_impl(kmg_processor *p, uint32_t k, kmg_lloyd **out, hipS
     s->pool_stream = pool_stream;
     s->ws = nullptr; s->ws_cap = 0; s->dist_blk_cap = 0;
     // one block from the processor's idle blocks (a warm processor creates a kmg_lloyd without a hipMalloc)
-    const size_t sizes[5] = {sizeof(Centroid) * k, sizeof(int64_t) * 4ull * k * 2048ull, sizeof(int64_t) * 4ull * k, sizeof(uint32_t),
-                             sizeof(unsigned long long)};
+    const size_t sizes[6] = {sizeof(Centroid) * k, sizeof(int64_t) * 4ull * k * 2048ull, sizeof(int64_t) * 4ull * k, sizeof(uint32_t),
+                             sizeof(unsigned long long), sizeof(int64_t) * 4ull * k};
     size_t need = 0;
     for (size_t b : sizes) need += pad256(b);
     hipError_t e = block_take(p, need, &s->ws, &s->ws_cap);
@@ -951,6 +975,8 @@ static int lloyd_create_impl(kmg_processor *p, uint32_t k, kmg_lloyd **out, hipS
         s->d_acc = (int64_t *)carve(s->ws, off, sizes[2]);
         s->d_nconv = (uint32_t *)carve(s->ws, off, sizes[3]);
         s->d_key = (unsigned long long *)carve(s->ws, off, sizes[4]);
+        s->d_acc_int = (int64_t *)carve(s->ws, off, sizes[5]);
+        s->acc_int_dirty = true;                                      // cleared in stream order by the first pass
         auto zero = [&](void *ptr, size_t bytes) {
             return s->pooled ? hipMemsetAsync(ptr, 0, bytes, pool_stream) : hipMemset(ptr, 0, bytes);
         };
@@ -1311,6 +1337,18 @@ extern "C" int kmg_lloyd_update(kmg_lloyd *s, const int64_t *d_acc4, void *strea
     return KMG_OK;
 }
 
+// Assign, then update (include/kmeans_hip.h).  With a bound image the update rides on the last launch of the cube pass.
+extern "C" int kmg_lloyd_assign_update(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_t *d_labels, int64_t *d_acc4,
+                                       int do_update, void *stream)
+{
+    if (!s || !d_rgba || n == 0 || !d_acc4) return fail(KMG_ERR_INVALID_ARGUMENT, "bad assign_update arguments");
+    HIP_TRY(hipSetDevice(s->p->device));
+    if (table_bound(s, d_rgba, n)) return table_assign(s, d_rgba, n, d_labels, d_acc4, 1u, S(stream), do_update != 0);
+    int rc;
+    if ((rc = kmg_lloyd_assign_accumulate(s, d_rgba, n, d_labels, d_acc4, stream)) != KMG_OK) return rc;
+    return do_update ? kmg_lloyd_update(s, d_acc4, stream) : KMG_OK;
+}
+
 // One Lloyd iteration with the label pass taken off the critical path (modules.rs:769-800: update, then
 // re-assign).  The loop only depends on the sums; with the colour table they come from the cube pass, and the
 // label pass that turns the cube pass's tables into the per-pixel label map feeds nothing.  So the label pass
@@ -1418,13 +1456,27 @@ extern "C" int kmg_lloyd_run(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, ui
         if ((rc = prepare_impl(s, d_rgba, n, 0, nullptr, stream, false)) != KMG_OK) return rc;
     const bool table = table_bound(s, d_rgba, n);
     uint32_t *loop_labels = table ? nullptr : d_labels;
-    // operations.rs:75-83 initial assignment (fused with the sums the first update needs)
-    if ((rc = kmg_lloyd_assign_accumulate(s, d_rgba, n, loop_labels, s->d_acc, stream)) != KMG_OK) return rc;
+    // operations.rs:75-83 initial assignment (fused with the sums the first update needs), then modules.rs:769-800:
+    // update (:773-788), re-assign (:793-800), every check_period-th iteration read the convergence count (:802-836).
+    // The update of iteration `it` rides on the assign pass before it (kmg_lloyd_assign_update) unless the loop may stop
+    // in between -- i.e. unless that pass is the one a convergence check follows: after the last update nothing but the
+    // re-assignment may happen.
+    auto checked = [&](uint32_t it) { return it > 0 && it % o.check_period == 0; };
+    // pass(it) = the assign pass of iteration it (it = -1: the initial one); its update-after is iteration it + 1's update
+    auto pass = [&](long it) -> int {
+        const bool may_stop_here = it >= 0 && checked((uint32_t)it);          // a check follows this pass
+        const bool last = it + 1 >= (long)o.max_iterations;
+        const bool fuse = !may_stop_here && !last;
+        return kmg_lloyd_assign_update(s, d_rgba, n, loop_labels, s->d_acc, fuse ? 1 : 0, stream);
+    };
+    if ((rc = pass(-1)) != KMG_OK) return rc;
     uint32_t it = 0;
     for (it = 0; it < o.max_iterations; ++it) {                       // modules.rs:769
-        if ((rc = kmg_lloyd_update(s, s->d_acc, stream)) != KMG_OK) return rc;           // :773-788
-        if ((rc = kmg_lloyd_assign_accumulate(s, d_rgba, n, loop_labels, s->d_acc, stream)) != KMG_OK) return rc;  // :793-800
-        if (it > 0 && it % o.check_period == 0) {                    // :802
+        // the update of this iteration: already done by the previous pass unless that pass was followed by a check
+        const bool fused_before = !(it >= 1 && checked(it - 1));
+        if (!fused_before && (rc = kmg_lloyd_update(s, s->d_acc, stream)) != KMG_OK) return rc;   // :773-788
+        if ((rc = pass((long)it)) != KMG_OK) return rc;                                            // :793-800
+        if (checked(it)) {                                           // :802
             uint32_t conv = 0;
             if ((rc = kmg_lloyd_converged_count(s, &conv, stream)) != KMG_OK) return rc;
             if (conv >= s->k) {                                      // :826-831

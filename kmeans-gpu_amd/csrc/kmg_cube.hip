@@ -712,8 +712,17 @@ template <typename LabelT>
 __global__ __launch_bounds__(kBlock) void k_cube_pairs(const uint32_t *__restrict__ work, int with_work,
                                                        const uint8_t *__restrict__ occ_bits,
                                                        const LabelT *__restrict__ colour_labels,
-                                                       uint16_t *__restrict__ sub_table, uint32_t flags)
+                                                       uint16_t *__restrict__ sub_table, uint32_t flags,
+                                                       int64_t *__restrict__ sums, uint32_t k, CubeTail tail)
 {
+    // the tail of the pass (kmg_table.h CubeTail): the stage and scan launches have completed, so the sums are final
+    if (tail.acc_out && blockIdx.x == gridDim.x - 1u) {
+        __shared__ uint32_t s_count;
+        for (uint32_t i = threadIdx.x; i < 4u * k; i += kBlock) tail.acc_out[i] = sums[i];
+        if (tail.do_update) update_centroids(sums, k, tail.convergence, tail.cent, tail.n_converged, &s_count, kBlock);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < 4u * k; i += kBlock) sums[i] = 0;      // ready for the next pass
+    }
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
     const uint32_t n_waves = gridDim.x * (kBlock / 64);
@@ -750,9 +759,9 @@ static uint32_t env_grid(const char *name, uint32_t dflt)
 
 uint32_t cube_replicas(uint32_t k)
 {
-    // copies of the scan kernel's LDS bins (lanes spread their atomic adds over them); one by default: two
-    // workgroups then fit into the LDS a label-pass workgroup leaves free on its CU
-    uint32_t r = 1;
+    // copies of the scan kernel's LDS bins (lanes spread their atomic adds over them).  Measured at k = 256 (round 3,
+    // profiles/r03_*): 1 copy 73.4 us, 2 copies 69.5 us, 4 copies 97.6 us (the bins then take the LDS of a workgroup per CU)
+    uint32_t r = 2;
     if (const char *e = getenv("KMG_CUBE_REPL")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) r = (uint32_t)v; }
     while (r > 1u && (uint64_t)r * (k * 32ull + 32ull) > 33024ull) r >>= 1;
     return r;
@@ -764,8 +773,9 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
                        const uint32_t *work, const CellBounds *bounds, const CellBounds *sub_bounds, const Centroid *cent,
                        uint32_t k, const float4 *lab_table, uint64_t *masks, void *cell_work, void *colour_labels,
                        uint16_t *sub_table, int64_t *sums, uint32_t n_rows, uint32_t flags, unsigned long long *stats,
-                       hipStream_t st)
+                       hipStream_t st, const CubeTail *tail)
 {
+    const CubeTail tl = (tail && hist && n_rows <= 1u) ? *tail : CubeTail();
     const uint32_t kpad = (k + 63u) & ~63u;
     const bool with_sums = hist != nullptr;
     const uint32_t repl = with_sums ? cube_replicas(k) : 1u;
@@ -797,7 +807,7 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
             hipLaunchKernelGGL((k_cube_scan<T, S>), dim3(g_scan), dim3(kBlock), lds_scan, st, hist, sub_agg, work, cent, k, \
                                lab_table, masks, cw, (T *)colour_labels, sub_table, sums, n_rows, repl, flags);             \
         hipLaunchKernelGGL((k_cube_pairs<T>), dim3(g_pairs), dim3(kBlock), 0, st, work, S ? 1 : 0, occ_bits,               \
-                           (const T *)colour_labels, sub_table, flags);                                                     \
+                           (const T *)colour_labels, sub_table, flags, sums, k, tl);                                        \
     } while (0)
     if (k <= 256) { if (with_sums) KMG_CUBE(uint8_t, true); else KMG_CUBE(uint8_t, false); }
     else          { if (with_sums) KMG_CUBE(uint16_t, true); else KMG_CUBE(uint16_t, false); }

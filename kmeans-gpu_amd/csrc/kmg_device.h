@@ -86,5 +86,35 @@ __device__ __forceinline__ void stage_centroids(float4 *s_cent, const Centroid *
     }
 }
 
+// choose_centroid.wgsl:180-206 `pick` for all clusters by ONE workgroup of `block` threads (s_count: a word of LDS):
+// centroid <- sum / count where count > 0, *n_converged = number of clusters that moved less than `convergence`
+// (literal CIE94 of the new against the previous centroid); an empty cluster keeps its centroid and counts as not converged.
+__device__ __forceinline__ void update_centroids(const int64_t *acc, uint32_t k, float convergence, Centroid *cent,
+                                                 uint32_t *n_converged, uint32_t *s_count, uint32_t block)
+{
+    if (threadIdx.x == 0) *s_count = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (uint32_t c = threadIdx.x; c < k; c += block) {
+        const long long count = acc[4ull * c + 3];
+        if (count > 0) {                                         // :185
+            float nw[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                double mean = ((double)acc[4ull * c + j] / (double)count) * (1.0 / 1048576.0);
+                nw[j] = (float)mean;                             // :186
+            }
+            const Centroid prev = cent[c];
+            Centroid nc;
+            nc.L = nw[0]; nc.a = nw[1]; nc.b = nw[2]; nc.C = chroma(nw[1], nw[2]);
+            cent[c] = nc;
+            // :191 distance_cie94(new, previous) < settings.convergence
+            if (cie94(nw[0], nw[1], nw[2], prev.L, prev.a, prev.b) < convergence) mine += 1;
+        }                                                        // :192-194 empty: unchanged, 0
+    }
+    if (mine) atomicAdd(s_count, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) *n_converged = *s_count;               // :196-202
+}
 
 }  // namespace kmg

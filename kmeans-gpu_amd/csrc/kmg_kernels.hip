@@ -342,29 +342,7 @@ __global__ __launch_bounds__(kBlock) void k_update(const int64_t *__restrict__ a
                                                    uint32_t *__restrict__ n_converged)
 {
     __shared__ uint32_t s_count;
-    if (threadIdx.x == 0) s_count = 0;
-    __syncthreads();
-    uint32_t mine = 0;
-    for (uint32_t c = threadIdx.x; c < k; c += kBlock) {
-        const long long count = acc[4ull * c + 3];
-        if (count > 0) {                                         // :185
-            float nw[3];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                double mean = ((double)acc[4ull * c + j] / (double)count) * (1.0 / 1048576.0);
-                nw[j] = (float)mean;                             // :186
-            }
-            const Centroid prev = cent[c];
-            Centroid nc;
-            nc.L = nw[0]; nc.a = nw[1]; nc.b = nw[2]; nc.C = chroma(nw[1], nw[2]);
-            cent[c] = nc;
-            // :191 distance_cie94(new, previous) < settings.convergence
-            if (cie94(nw[0], nw[1], nw[2], prev.L, prev.a, prev.b) < convergence) mine += 1;
-        }                                                        // :192-194 empty: unchanged, 0
-    }
-    if (mine) atomicAdd(&s_count, mine);
-    __syncthreads();
-    if (threadIdx.x == 0) *n_converged = s_count;                // :196-202
+    update_centroids(acc, k, convergence, cent, n_converged, &s_count, kBlock);
 }
 
 hipError_t launch_update(const int64_t *acc, uint32_t k, float convergence, Centroid *cent,

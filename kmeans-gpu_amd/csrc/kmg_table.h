@@ -158,11 +158,21 @@ hipError_t launch_init_pass_cells(const uint32_t *tie, const uint8_t *occ_bits, 
 // stats (optional, 6 x u64, zero on entry): single-candidate cells, other cells, sub-cells decided by their
 // bounds, sub-cells scanned, candidates summed over the scanned sub-cells, cells beyond the listing limit.
 size_t cube_work_bytes();
+// What the LAST launch of the cube pass does on top (one of its workgroups, once the sums are complete): hand the k x 4
+// sums over from the pass's own accumulation buffer `sums` (which it leaves zeroed for the next pass -- no memset launch),
+// and -- do_update -- the centroid update of choose_centroid.wgsl:180-206 from them (no k_update launch).
+struct CubeTail {
+    int64_t *acc_out = nullptr;      // receives the sums (NULL: `sums` is the caller's buffer, nothing is handed over)
+    int do_update = 0;
+    float convergence = 0.0f;
+    Centroid *cent = nullptr;        // updated in place
+    uint32_t *n_converged = nullptr;
+};
 hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *sub_agg, const uint8_t *occ_bits,
                        const uint32_t *work, const CellBounds *bounds, const CellBounds *sub_bounds, const Centroid *cent,
                        uint32_t k, const float4 *lab_table, uint64_t *masks, void *cell_work, void *colour_labels,
                        uint16_t *sub_table, int64_t *sums, uint32_t n_rows, uint32_t flags, unsigned long long *stats,
-                       hipStream_t st);
+                       hipStream_t st, const CubeTail *tail = nullptr);
 // pal == NULL: labels[i] = label; pal != NULL: labels[i] = pal[label] (RGBA8 output of replace mode).
 // reserve_cus: compute units left without a workgroup of the k <= 256 label pass (kmg_lloyd_reserve_cus)
 hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_labels,

@@ -70,7 +70,7 @@ SYMBOLS = [
     "kmg_lloyd_assign_partials", "kmg_lloyd_reduce_partials", "kmg_lloyd_labels", "kmg_lloyd_reserve_cus", "kmg_lloyd_bind_image",
     "kmg_lloyd_unbind_image", "kmg_lloyd_prepare", "kmg_debug_check_table", "kmg_debug_table_stats", "kmg_debug_check_pairs", "kmg_debug_check_dither_masks", "kmg_debug_check_meld_masks", "kmg_kernel_name",
     "kmg_lloyd_profile", "kmg_lloyd_profile_read",
-    "kmg_lloyd_update", "kmg_lloyd_converged_count", "kmg_lloyd_iterate", "kmg_lloyd_flush", "kmg_lloyd_run", "kmg_dev_apply",
+    "kmg_lloyd_update", "kmg_lloyd_assign_update", "kmg_lloyd_converged_count", "kmg_lloyd_iterate", "kmg_lloyd_flush", "kmg_lloyd_run", "kmg_dev_apply",
     "kmg_dither_threshold",
 ]
 
@@ -141,6 +141,7 @@ def lib():
     L.kmg_lloyd_prepare.argtypes = [vp, u8p, C.c_uint64, C.c_int, C.POINTER(C.c_int), vp]
     L.kmg_debug_check_table.argtypes = [vp, C.POINTER(C.c_uint64), vp]
     L.kmg_lloyd_update.argtypes = [vp, i64p, vp]
+    L.kmg_lloyd_assign_update.argtypes = [vp, u8p, C.c_uint64, u32p, i64p, C.c_int, vp]
     L.kmg_lloyd_converged_count.argtypes = [vp, C.POINTER(C.c_uint32), vp]
     L.kmg_lloyd_iterate.argtypes = [vp, u8p, C.c_uint64, u32p, i64p, C.c_int, vp]
     L.kmg_lloyd_flush.argtypes = [vp, vp]
@@ -432,6 +433,11 @@ class Lloyd:
 
     def update(self, d_acc4, stream=0):
         _check(lib().kmg_lloyd_update(self._h, C.c_void_p(d_acc4), C.c_void_p(stream)))
+
+    def assign_update(self, d_rgba, n_pixels, d_labels, d_acc4, do_update=True, stream=0):
+        """assign (labels optional, sums into d_acc4), then -- do_update -- the centroid update from those sums"""
+        _check(lib().kmg_lloyd_assign_update(self._h, C.c_void_p(d_rgba), n_pixels, C.c_void_p(d_labels or None),
+                                             C.c_void_p(d_acc4), int(bool(do_update)), C.c_void_p(stream)))
 
     def iterate(self, d_rgba, n_pixels, d_labels, d_acc4, update_first=True, stream=0):
         """one Lloyd iteration, asynchronous; the label map is complete after flush() (or a device sync)"""

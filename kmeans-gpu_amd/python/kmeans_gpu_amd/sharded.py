@@ -111,6 +111,11 @@ class ShardedLloyd:
         # label pass of iteration t beside the cube pass of iteration t + 1 (Lloyd.iterate); False (the measured path:
         # the two passes time-slice a CU rather than overlap, profiles/r03_overlap_shapes.txt): step by step
         self.pipeline = False
+        # One rank, colour table: prime() / iterate() as "assign, then update" (Lloyd.assign_update: the update rides on the
+        # last launch of the assign pass -- no k_update launch, no memset).  Each call still performs one assignment with its
+        # label map and sums and one centroid update, but a convergence count read between two calls belongs to the update
+        # that FOLLOWED the last assignment; run() therefore never uses it.  Opt-in.
+        self.fused = False
         # The asynchronous all-reduce is issued to run beside the label pass, but RCCL's kernel (256 threads, 20 KiB LDS,
         # 280 registers per lane) does not fit on a CU that hosts a label workgroup; reserve_cus > 0 launches the label pass
         # with that many workgroups fewer than CUs.  Reset in close().
@@ -158,9 +163,20 @@ class ShardedLloyd:
         return (self.pipeline and self.split_labels and self.labels is not None and self.n_local > 0
                 and hasattr(self.backend, "iterate"))
 
+    def _fused(self):
+        return (self.fused and self.world == 1 and self.split_labels and self.labels is not None and self.n_local > 0
+                and hasattr(self.backend, "assign_update") and not self._pipelined())
+
+    def _assign_then_update(self):
+        _require_current_stream(self.acc, self.stream)
+        self.backend.assign_update(self.rgba.data_ptr(), self.n_local, self.labels.data_ptr(), self.acc.data_ptr(), True,
+                                   self.stream)
+
     def prime(self):
         """initial assignment (operations.rs:75-83), fused with the sums of the first update"""
-        if self._pipelined():
+        if self._fused():
+            self._assign_then_update()
+        elif self._pipelined():
             _require_current_stream(self.acc, self.stream)
             self.backend.iterate(self.rgba.data_ptr(), self.n_local, self.labels.data_ptr(), self.acc.data_ptr(), False, self.stream)
             self.exchange()
@@ -169,7 +185,9 @@ class ShardedLloyd:
 
     def iterate(self):
         """one Lloyd iteration (modules.rs:769-800): update from the global sums, re-assign"""
-        if self._pipelined():
+        if self._fused():
+            self._assign_then_update()
+        elif self._pipelined():
             _require_current_stream(self.acc, self.stream)
             self.backend.iterate(self.rgba.data_ptr(), self.n_local, self.labels.data_ptr(), self.acc.data_ptr(), True, self.stream)
             self.exchange()
@@ -192,6 +210,7 @@ class ShardedLloyd:
     def run(self, max_iterations=128, check_period=8):
         """ChooseCentroidModule::compute (modules.rs:763-840) over all bands.  Returns the
         iteration at which the loop stopped."""
+        self.fused = False        # the loop reads the convergence count between update and re-assignment
         self.prime()
         it = 0
         for it in range(max_iterations):

@@ -856,3 +856,53 @@ def test_large_k_through_the_colour_table(torch_cuda, oracle, monkeypatch, k):
     assert s.debug_check_table(st) == (0, 0, 0)
     s.close()
     p.close()
+
+
+@pytest.mark.parametrize("k", [24, 300])
+@pytest.mark.parametrize("strategy", ["table", "brute"])
+def test_assign_update_equals_the_two_calls(torch_cuda, oracle, monkeypatch, k, strategy):
+    """kmg_lloyd_assign_update (the update rides on the last launch of the colour-table assign pass; no memset, no
+    k_update launch) == kmg_lloyd_assign_accumulate + kmg_lloyd_update == the oracle: labels, sums, centroids and the
+    convergence count after every iteration; with do_update = 0 the centroids stay."""
+    import kmeans_gpu_amd as kg
+    torch = torch_cuda
+    st = _stream(torch)
+    monkeypatch.setenv("KMG_STRATEGY", strategy)
+    w, h = 640, 400
+    n = w * h
+    img = _blobs(np.random.default_rng(7 * k), n, 40, sigma=25.0)
+    lab = oracle.rgb_to_lab(img)
+    init = oracle.centroids4(lab[np.random.default_rng(2).choice(n, k, replace=False)])
+    d = _dev(torch, img)
+    p = kg.ImageProcessor(shrink_max_dim=0)
+    a, b = kg.Lloyd(p, k), kg.Lloyd(p, k)
+    for s in (a, b):
+        s.set_centroids(init, st)
+        assert s.prepare(d.data_ptr(), n, True, st) == ("table" if strategy == "table" else "scan")
+    la, lb = (torch.zeros(n, dtype=torch.int32, device="cuda") for _ in range(2))
+    acc_a, acc_b = (torch.full((k, 4), 7, dtype=torch.int64, device="cuda") for _ in range(2))   # stale contents must not matter
+    cent = init
+    for it in range(5):
+        a.assign_accumulate(d.data_ptr(), n, la.data_ptr(), acc_a.data_ptr(), st)
+        a.update(acc_a.data_ptr(), st)
+        b.assign_update(d.data_ptr(), n, lb.data_ptr(), acc_b.data_ptr(), True, st)
+        torch.cuda.synchronize()
+        wl, wa = oracle.assign_accumulate_rgba(img, cent)
+        cent, conv = oracle.finalize(wa, cent)
+        assert torch.equal(la, lb) and np.array_equal(lb.cpu().numpy().view(np.uint32), wl), it
+        assert torch.equal(acc_a, acc_b) and np.array_equal(acc_b.cpu().numpy(), wa), it
+        assert np.array_equal(a.get_centroids(st).view(np.uint32), b.get_centroids(st).view(np.uint32)), it
+        assert np.array_equal(b.get_centroids(st).view(np.uint32), cent.view(np.uint32)), it
+        assert a.converged_count(st) == b.converged_count(st) == conv, it
+    before = b.get_centroids(st).copy()
+    b.assign_update(d.data_ptr(), n, lb.data_ptr(), acc_b.data_ptr(), False, st)
+    torch.cuda.synchronize()
+    wl, wa = oracle.assign_accumulate_rgba(img, cent)
+    assert np.array_equal(lb.cpu().numpy().view(np.uint32), wl) and np.array_equal(acc_b.cpu().numpy(), wa)
+    assert np.array_equal(b.get_centroids(st).view(np.uint32), before.view(np.uint32))
+    # the label tables still describe that assignment: a labels-only pass reproduces it
+    lb.zero_()
+    b.labels(d.data_ptr(), n, lb.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert np.array_equal(lb.cpu().numpy().view(np.uint32), wl)
+    a.close(); b.close(); p.close()
