@@ -111,6 +111,7 @@ def other_distributions(proc, k, n_pixels, stream, steps=10):
         extra[f"{kind}_ms_per_step"] = (time.perf_counter() - t) / steps * 1e3
         extra[f"{kind}_strategy"] = strategy
         if strategy == "table" and k <= 256:
+            s.assign_accumulate(rgba.data_ptr(), n_pixels, 0, sh.acc.data_ptr(), stream)    # label tables of the current centroids
             _, resolved, total = s.debug_check_pairs(stream)
             extra[f"{kind}_pixels_resolved_in_lds"] = resolved / max(total, 1)
         s.close()
@@ -256,6 +257,7 @@ def output_pass_timing(proc, rgba, n_pixels, stream, sh=None, steps=3):
             extra[f"{name}_k{len(pal)}_hbm_frac"] = ALGORITHMIC_BYTES_PER_PIXEL * n_pixels / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
         if sh is not None:
             if sh.split_labels and k_of(sh) <= 256:
+                sh.backend.assign_accumulate(rgba.data_ptr(), n_pixels, 0, sh.acc.data_ptr(), stream)   # label tables of the current centroids
                 _, resolved, total = sh.backend.debug_check_pairs(stream)
                 extra["uniform_pixels_resolved_in_lds"] = resolved / max(total, 1)
 

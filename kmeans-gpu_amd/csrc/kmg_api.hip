@@ -152,7 +152,8 @@ struct ColourTable {
     uint8_t *d_occ = nullptr;        // 2^24 bits: colours the image has pixels of
     void *d_cell_work = nullptr;     // cube_work_bytes(): records the cube pass's stage kernel leaves for its scan kernel
     uint64_t *d_masks = nullptr;     // kCells x words candidate masks
-    uint32_t *d_work = nullptr;      // 1 + kCells: dense list of the occupied cells
+    uint32_t *d_work = nullptr;      // kWorkWords: dense list of the occupied cells, then the hot cells (kmg_table.h)
+    uint32_t n_hot = 0;              // host copy of the number of hot cells of the bound image
     bool tables_valid = false;       // label tables describe the CURRENT centroid table
     void *d_colour_labels = nullptr; // 2^24 x u8 (k <= 256) or u16
     uint16_t *d_sub = nullptr;       // kSubCells 4x4x4 summaries (u16), kCells 8x8x8 summaries (u16), kCells pair entries (u32)
@@ -556,7 +557,7 @@ static int bind_image_impl(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, void
         // one block for all tables, from the processor's idle blocks when one fits (no hipMalloc on a warm processor)
         const size_t sizes[9] = {sizeof(uint32_t) << 24, sizeof(int64_t) * 4ull * kCells, sizeof(int64_t) * 4ull * kSubCells,
                                  (size_t)1 << 21, cube_work_bytes(), sizeof(uint64_t) * (size_t)kCells * words,
-                                 sizeof(uint32_t) * (kCells + 1), (size_t)(s->k <= 256 ? 1 : 2) << 24, sub_table_bytes()};
+                                 sizeof(uint32_t) * kWorkWords, (size_t)(s->k <= 256 ? 1 : 2) << 24, sub_table_bytes()};
         size_t need = 0;
         for (size_t b : sizes) need += pad256(b);
         const hipError_t e = block_take(s->p, need, &t.blk, &t.blk_cap);
@@ -608,7 +609,12 @@ static int bind_image_impl(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, void
         t.tie_first = first_index;
     }
     HIP_TRY(launch_cell_aggregates(t.d_hist, s->p->d_lab_table, t.d_agg, t.d_sub_agg, t.d_occ, S(stream)));
-    HIP_TRY(launch_work_list(t.d_agg, t.d_work, S(stream)));       // dense list of the occupied cells (static for this image)
+    // dense list of the occupied cells and the hot cells (static for this image); the label pass has a kernel variant for
+    // images with hot cells, so the host needs their number: 4 bytes back, the one synchronisation of a binding
+    HIP_TRY(launch_work_list(t.d_agg, t.d_work, s->k <= 256 ? n : 0, S(stream)));
+    HIP_TRY(hipMemcpyAsync(&t.n_hot, t.d_work + kCells + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, S(stream)));
+    HIP_TRY(hipStreamSynchronize(S(stream)));
+    if (const char *e = getenv("KMG_HOT_CELLS")) { if (e[0] == '0') t.n_hot = 0; }      // probes
     if (want_tie) HIP_TRY(launch_init_records(t.d_work, s->p->d_bounds, t.d_init_cells, S(stream)));   // an initialisation follows
     t.rgba = d_rgba;
     t.n = n;
@@ -852,9 +858,20 @@ extern "C" int kmg_debug_check_pairs(kmg_lloyd *s, uint64_t out[3], void *stream
     HIP_TRY(hipMemcpy(labels.data(), s->tab.d_colour_labels, labels.size(), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(pairs.data(), reinterpret_cast<const uint32_t *>(s->tab.d_sub + kSubCells + kCells),
                       pairs.size() * 4, hipMemcpyDeviceToHost));
+    // the label pass answers the colours of a hot cell from a copy of the per-colour table in LDS (unless the cell's entry
+    // already resolves all of them): resolved, and right by construction
+    std::vector<uint32_t> hot(1 + kHotMax, 0u);
+    if (s->tab.n_hot) HIP_TRY(hipMemcpy(hot.data(), s->tab.d_work + kCells + 1, sizeof(uint32_t) * (1 + kHotMax), hipMemcpyDeviceToHost));
+    std::vector<uint8_t> in_lds(kCells, 0);
+    for (uint32_t h = 0; h < s->tab.n_hot && h < kHotMax; ++h) {
+        const uint32_t e = pairs[hot[1 + h]];
+        const bool one_label = (e & 0xFFu) == ((e >> 8) & 0xFFu) && (e >> 23) == 0u;
+        if (!one_label) in_lds[hot[1 + h]] = 1;
+    }
     out[0] = out[1] = out[2] = 0;
     for (uint32_t c = 0; c < (1u << 24); ++c) {
         if (!hist[c]) continue;
+        if (in_lds[c >> 9]) { out[1] += hist[c]; out[2] += hist[c]; continue; }
         uint32_t r, g, b;
         index_to_rgb(c, r, g, b);
         const uint32_t e = pairs[c >> 9];
@@ -936,7 +953,7 @@ static int table_assign(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_
     }
     t.tables_valid = true;
     if (d_labels)
-        PROF_LAUNCH(s, KMG_K_LABELS, st, launch_labels((const uint32_t *)d_rgba, n, t.d_colour_labels, t.d_sub, s->k, nullptr, d_labels, st, s->reserve_cus));
+        PROF_LAUNCH(s, KMG_K_LABELS, st, launch_labels((const uint32_t *)d_rgba, n, t.d_colour_labels, t.d_sub, s->k, nullptr, d_labels, st, s->reserve_cus, t.n_hot ? t.d_work + kCells + 1 : nullptr));
     // (after an update the tables still describe the assignment just made, not the new centroids)
     if (update_after) t.tables_valid = false;
     return KMG_OK;
@@ -1261,7 +1278,8 @@ extern "C" int kmg_lloyd_labels(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n,
     if ((rc_ = side_flush(s, S(stream))) != KMG_OK) return rc_;      // both branches write d_labels
     if (table_bound(s, d_rgba, n) && s->tab.tables_valid) {
         PROF_LAUNCH(s, KMG_K_LABELS, S(stream), launch_labels((const uint32_t *)d_rgba, n, s->tab.d_colour_labels,
-                                                              s->tab.d_sub, s->k, nullptr, d_labels, S(stream), s->reserve_cus));
+                                                              s->tab.d_sub, s->k, nullptr, d_labels, S(stream), s->reserve_cus,
+                                                              s->tab.n_hot ? s->tab.d_work + kCells + 1 : nullptr));
         return KMG_OK;
     }
     PROF_LAUNCH(s, KMG_K_ASSIGN, S(stream), launch_assign((const uint32_t *)d_rgba, n, s->d_cent, s->k, s->p->d_lut,
@@ -1416,7 +1434,7 @@ extern "C" int kmg_lloyd_iterate(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n
     HIP_TRY(hipEventRecord(s->ev_cube, st));
     HIP_TRY(hipStreamWaitEvent(s->side, s->ev_cube, 0));
     PROF_LAUNCH(s, KMG_K_LABELS, s->side, launch_labels((const uint32_t *)d_rgba, n, t.d_colour_labels, t.d_sub, s->k, nullptr,
-                                                        d_labels, s->side, s->reserve_cus));
+                                                        d_labels, s->side, s->reserve_cus, t.n_hot ? t.d_work + kCells + 1 : nullptr));
     HIP_TRY(hipEventRecord(s->ev_lab[s->set], s->side));
     s->lab_pending[s->set] = true;
     return KMG_OK;
@@ -1487,7 +1505,8 @@ extern "C" int kmg_lloyd_run(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, ui
     }
     if (table && d_labels)   // the label tables of the last pass belong to the final centroids
         PROF_LAUNCH(s, KMG_K_LABELS, S(stream), launch_labels((const uint32_t *)d_rgba, n, s->tab.d_colour_labels,
-                                                              s->tab.d_sub, s->k, nullptr, d_labels, S(stream), s->reserve_cus));
+                                                              s->tab.d_sub, s->k, nullptr, d_labels, S(stream), s->reserve_cus,
+                                                              s->tab.n_hot ? s->tab.d_work + kCells + 1 : nullptr));
     HIP_TRY(hipStreamSynchronize(S(stream)));
     if (table && !callers) { s->tab.rgba = nullptr; s->tab.tables_valid = false; }
     if (iterations) *iterations = it < o.max_iterations ? it : o.max_iterations - 1;

@@ -33,6 +33,12 @@ constexpr uint32_t kCellColours = 512;
 constexpr uint32_t kSubCells = kCells * 8;  // 4x4x4 sub-cells (64 colours)
 constexpr uint32_t kCubeGrid = 2048;      // workgroups of k_cube (4 waves each, a wave walks cells wave, wave + n_waves, ...)
 constexpr uint32_t kMergeRows = 64;       // rows of the partial slab the cube workgroups add their sums into
+// "hot" cells of a bound image: the (at most kHotMax) cells that hold the largest share of its pixels, chosen once per image
+// when together they hold at least a tenth of them.  The k <= 256 label pass keeps their 512 per-colour labels in the LDS its
+// pair table leaves free: on a photograph a few dozen dark cells hold more than half of the pixels AND most of the centroids,
+// so their pair entries resolve almost nothing (28 % of the pixels of the test photograph against 84 % of a noise image).
+constexpr uint32_t kHotMax = 56;
+constexpr uint32_t kWorkWords = kCells + 1 + 1 + kHotMax;   // work list: [n][cells ...] then [n_hot][hot cells ...]
 
 // sub-cell table entry (u16): a label, or one of
 constexpr uint16_t kSubEmpty = 0xFFFF;    // no pixel of the image has a colour in this sub-cell
@@ -128,8 +134,9 @@ hipError_t launch_partitioned_histogram(const uint32_t *rgba, uint64_t n, uint64
 // image has pixels of this colour
 hipError_t launch_cell_aggregates(const uint32_t *hist, const float4 *lab_table, int64_t *agg, int64_t *sub_agg, uint8_t *occ_bits,
                                   hipStream_t st);
-// once per image: work[0] = number of occupied cells, work[1..] = their indices in ascending order
-hipError_t launch_work_list(const int64_t *agg, uint32_t *work, hipStream_t st);
+// once per image: work[0] = number of occupied cells, work[1..] = their indices in ascending order;
+// work[kCells + 1] = number of hot cells (n_pixels = 0: none wanted), work[kCells + 2 ..] = their indices (kWorkWords in all)
+hipError_t launch_work_list(const int64_t *agg, uint32_t *work, uint64_t n_pixels, hipStream_t st);
 // farthest-point initialisation over the colours of a large image: tie[2^24] (zero on entry) = 1 + the
 // largest low half of the init key among the pixels of each colour (first_index = image-wide index of
 // rgba[0], first_index + n <= 0xFFFFFFF0).
@@ -175,9 +182,10 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
                        hipStream_t st, const CubeTail *tail = nullptr);
 // pal == NULL: labels[i] = label; pal != NULL: labels[i] = pal[label] (RGBA8 output of replace mode).
 // reserve_cus: compute units left without a workgroup of the k <= 256 label pass (kmg_lloyd_reserve_cus)
+// hot: NULL, or the image's hot cells ([n_hot][cells ...], n_hot > 0 known to the host): k <= 256 keeps their labels in LDS
 hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_labels,
                          const uint16_t *sub_table, uint32_t k, const uint32_t *pal, uint32_t *labels,
-                         hipStream_t st, uint32_t reserve_cus = 0);
+                         hipStream_t st, uint32_t reserve_cus = 0, const uint32_t *hot = nullptr);
 
 // ordered-dither output pass with candidate pruning: masks[(cell * 16 + Bayer index) * words + w] are the
 // centroids that can be the arg-min of Lab(colour) + threshold * (M[Bayer index] / 16 - 0.5) for any

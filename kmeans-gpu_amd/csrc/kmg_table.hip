@@ -788,10 +788,14 @@ hipError_t launch_cell_aggregates(const uint32_t *hist, const float4 *lab_table,
     return hipGetLastError();
 }
 
-// dense list of the occupied cells in ascending order (once per image): work[0] = count, work[1..] = cells
-__global__ __launch_bounds__(1024) void k_work_list(const int64_t *__restrict__ agg, uint32_t *__restrict__ work)
+// dense list of the occupied cells in ascending order (once per image): work[0] = count, work[1..] = cells; behind it the
+// hot cells (kmg_table.h): the cells holding at least n_pixels >> j pixels for the smallest share (largest j <= 10) that
+// leaves at most kHotMax of them, in ascending order -- none if together they hold less than a tenth of the pixels
+__global__ __launch_bounds__(1024) void k_work_list(const int64_t *__restrict__ agg, uint32_t *__restrict__ work, uint64_t n_pixels)
 {
     __shared__ uint32_t s_n[1024];
+    __shared__ uint32_t s_above[5];                                // cells with at least n >> (6 + 2 j) pixels... see thresholds below
+    __shared__ unsigned long long s_hot_pixels;
     constexpr uint32_t PER = kCells / 1024;                        // 32 consecutive cells per thread
     const uint32_t c0 = threadIdx.x * PER;
     uint32_t occupied = 0;                                         // bit i = cell c0 + i has pixels
@@ -800,7 +804,29 @@ __global__ __launch_bounds__(1024) void k_work_list(const int64_t *__restrict__ 
     for (uint32_t i = 0; i < PER; ++i) cnt[i] = agg[4ull * (c0 + i) + 3];      // all 32 loads in flight
 #pragma unroll
     for (uint32_t i = 0; i < PER; ++i) occupied |= (cnt[i] != 0 ? 1u : 0u) << i;
-    const uint32_t mine = (uint32_t)__builtin_popcount(occupied);
+    if (threadIdx.x < 5) s_above[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) s_hot_pixels = 0ull;
+    __syncthreads();
+    // thresholds n / 64, n / 128, n / 256, n / 512, n / 1024 (a cell of a noise image holds n / 32768)
+    uint32_t above[5] = {0u, 0u, 0u, 0u, 0u};
+    if (n_pixels) {
+#pragma unroll
+        for (uint32_t i = 0; i < PER; ++i)
+#pragma unroll
+            for (uint32_t j = 0; j < 5; ++j) above[j] += ((uint64_t)cnt[i] >= ((n_pixels >> (6u + j)) | 1ull)) ? 1u : 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < 5; ++j)
+            if (above[j]) atomicAdd(&s_above[j], above[j]);
+    }
+    __syncthreads();
+    uint32_t jsel = 0;                                              // the lowest threshold that still leaves at most kHotMax cells
+    for (uint32_t j = 1; j < 5; ++j)
+        if (s_above[j] <= kHotMax) jsel = j;
+    const uint64_t thr = n_pixels ? ((n_pixels >> (6u + jsel)) | 1ull) : ~0ull;
+    uint32_t hot = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < PER; ++i) hot |= ((uint64_t)cnt[i] >= thr ? 1u : 0u) << i;
+    const uint32_t mine = (uint32_t)__builtin_popcount(occupied) | ((uint32_t)__builtin_popcount(hot) << 16);
     s_n[threadIdx.x] = mine;
     __syncthreads();
     for (uint32_t off = 1; off < 1024; off <<= 1) {
@@ -809,15 +835,29 @@ __global__ __launch_bounds__(1024) void k_work_list(const int64_t *__restrict__ 
         s_n[threadIdx.x] += a;
         __syncthreads();
     }
-    uint32_t at = 1u + s_n[threadIdx.x] - mine;
+    const uint32_t before = s_n[threadIdx.x] - mine;
+    uint32_t at = 1u + (before & 0xFFFFu);
     for (uint32_t i = 0; i < PER; ++i)
         if ((occupied >> i) & 1u) work[at++] = c0 + i;
-    if (threadIdx.x == 1023) work[0] = s_n[1023];
+    uint32_t hat = before >> 16;                                    // hot cells before this thread's
+    unsigned long long hot_px = 0ull;
+    for (uint32_t i = 0; i < PER; ++i)
+        if ((hot >> i) & 1u) {
+            if (hat < kHotMax) { work[kCells + 2u + hat] = c0 + i; hot_px += (unsigned long long)cnt[i]; }
+            ++hat;
+        }
+    if (hot_px) atomicAdd(&s_hot_pixels, hot_px);
+    __syncthreads();
+    if (threadIdx.x == 1023) {
+        work[0] = s_n[1023] & 0xFFFFu;
+        const uint32_t n_hot = min(s_n[1023] >> 16, kHotMax);
+        work[kCells + 1u] = (s_hot_pixels * 10ull >= n_pixels) ? n_hot : 0u;
+    }
 }
 
-hipError_t launch_work_list(const int64_t *agg, uint32_t *work, hipStream_t st)
+hipError_t launch_work_list(const int64_t *agg, uint32_t *work, uint64_t n_pixels, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_work_list, dim3(1), dim3(1024), 0, st, agg, work);
+    hipLaunchKernelGGL(k_work_list, dim3(1), dim3(1024), 0, st, agg, work, n_pixels);
     return hipGetLastError();
 }
 
@@ -885,23 +925,53 @@ __global__ __launch_bounds__(kLabelBlock) void k_labels(const uint32_t *__restri
 // colours carry it.  Pixels of other sub-cells (mixed, or a third label) go to the per-colour table.
 // Divergent global gathers retire at ~1 per 2 clocks per CU whether they hit L2 or not
 // (tools/gather_rate.hip), so resolving ~2/3 of the pixels from LDS is what pays.
+// HOT: the image has hot cells (kmg_table.h): their 512 per-colour labels are copied into LDS behind the pair table and their
+// pair entries (in this workgroup's LDS copy only) become [block : 8][block : 8][direction code 127] = "look the colour up in
+// block `block`" -- the per-colour table itself, so right by construction.  A hot cell whose entry already resolves every
+// colour (one label) keeps it: the cube pass does not write per-colour labels for single-candidate cells.
+constexpr uint32_t kHotCode = 127u;                                // direction codes 0..124 are planes
+constexpr size_t kLabelLdsPlain = sizeof(uint32_t) * (kCells + 256 + 128);
+constexpr size_t kLabelLdsHot = kLabelLdsPlain + (size_t)kHotMax * kCellColours + sizeof(uint32_t) * 64;
+
+template <bool HOT>
 __global__ __launch_bounds__(kLabelBlock) void k_labels_pairs(const uint32_t *__restrict__ rgba, uint64_t n,
                                                               const uint8_t *__restrict__ colour_labels,
                                                               const uint32_t *__restrict__ pair_table,
                                                               const uint32_t *__restrict__ pal, uint32_t k,
-                                                              uint32_t *__restrict__ labels, int aligned)
+                                                              uint32_t *__restrict__ labels, int aligned,
+                                                              const uint32_t *__restrict__ hot)
 {
-    __shared__ uint32_t s_pair[kCells];
-    __shared__ uint32_t s_pal[256];
-    __shared__ uint32_t s_dir[128];
+    extern __shared__ uint32_t s_label_lds[];
+    uint32_t *s_pair = s_label_lds, *s_pal = s_label_lds + kCells, *s_dir = s_label_lds + kCells + 256;
+    uint8_t *s_hot = reinterpret_cast<uint8_t *>(s_label_lds + kCells + 256 + 128);
+    uint32_t *s_hcell = reinterpret_cast<uint32_t *>(s_hot + (size_t)kHotMax * kCellColours);
     if (pal && threadIdx.x < k) s_pal[threadIdx.x] = pal[threadIdx.x];
-    if (threadIdx.x < kPairDirs) s_dir[threadIdx.x] = pair_dir_word(threadIdx.x);
+    if (threadIdx.x < 128) s_dir[threadIdx.x] = threadIdx.x < kPairDirs ? pair_dir_word(threadIdx.x) : 0u;
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(pair_table);
         uint4 *dst = reinterpret_cast<uint4 *>(s_pair);
         for (uint32_t i = threadIdx.x; i < kCells / 4; i += kLabelBlock) dst[i] = src[i];
     }
     __syncthreads();
+    if (HOT) {
+        const uint32_t n_hot = min(hot[0], kHotMax);
+        if (threadIdx.x < n_hot) {
+            const uint32_t cell = hot[1u + threadIdx.x];
+            const uint32_t e = s_pair[cell];
+            const bool one_label = (e & 0xFFu) == ((e >> 8) & 0xFFu) && (e >> 23) == 0u;     // A == B, tlo = 0, w = 0
+            s_hcell[threadIdx.x] = one_label ? 0xFFFFFFFFu : cell;
+        }
+        __syncthreads();
+        const uint32_t *lab32 = reinterpret_cast<const uint32_t *>(colour_labels);
+        uint32_t *hot32 = reinterpret_cast<uint32_t *>(s_hot);
+        for (uint32_t i = threadIdx.x; i < n_hot * (kCellColours / 4u); i += kLabelBlock) {
+            const uint32_t cell = s_hcell[i / (kCellColours / 4u)];
+            if (cell != 0xFFFFFFFFu) hot32[i] = lab32[(uint64_t)cell * (kCellColours / 4u) + (i % (kCellColours / 4u))];
+        }
+        if (threadIdx.x < n_hot && s_hcell[threadIdx.x] != 0xFFFFFFFFu)
+            s_pair[s_hcell[threadIdx.x]] = threadIdx.x | (threadIdx.x << 8) | (kHotCode << 16);
+        __syncthreads();
+    }
     constexpr uint64_t TILE = (uint64_t)kLabelBlock * 8;
     const uint64_t tiles = (n + TILE - 1) / TILE;
     for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
@@ -923,11 +993,15 @@ __global__ __launch_bounds__(kLabelBlock) void k_labels_pairs(const uint32_t *__
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             const uint32_t e = s_pair[ci[p] >> 9];
-            const int proj = __builtin_amdgcn_sdot4((int)xyz[p], (int)s_dir[(e >> 16) & 127u], 0, false);
+            const uint32_t code = (e >> 16) & 127u;
+            const int proj = __builtin_amdgcn_sdot4((int)xyz[p], (int)s_dir[code], 0, false);
             const int tlo = (int)((e >> 23) & 63u), w = (int)(e >> 29);
             const bool inA = proj < tlo, inB = proj >= tlo + w + (w == 7 ? 64 : 0);
             lab[p] = inA ? (e & 0xFFu) : ((e >> 8) & 0xFFu);
             fine[p] = !(inA || inB);
+            if (HOT && code == kHotCode) {                           // (tlo = w = 0: the line above said "B", not "fine")
+                lab[p] = (uint32_t)s_hot[(e & 0xFFu) * kCellColours + (ci[p] & (kCellColours - 1u))];
+            }
         }
 #pragma unroll
         for (int p = 0; p < 8; ++p)
@@ -951,7 +1025,7 @@ static uint32_t device_cus()
 }
 
 hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_labels, const uint16_t *sub_table,
-                         uint32_t k, const uint32_t *pal, uint32_t *labels, hipStream_t st, uint32_t reserve_cus)
+                         uint32_t k, const uint32_t *pal, uint32_t *labels, hipStream_t st, uint32_t reserve_cus, const uint32_t *hot)
 {
     if (k <= 256) {
         const uint64_t tiles = (n + kLabelBlock * 8 - 1) / (kLabelBlock * 8);
@@ -962,9 +1036,13 @@ hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_la
         const uint32_t grid = (uint32_t)(tiles < cus ? (tiles ? tiles : 1) : cus);
         const int aligned = ((reinterpret_cast<uintptr_t>(rgba) & 15u) == 0 &&
                              (reinterpret_cast<uintptr_t>(labels) & 15u) == 0) ? 1 : 0;
-        hipLaunchKernelGGL(k_labels_pairs, dim3(grid), dim3(kLabelBlock), 0, st, rgba, n,
-                           (const uint8_t *)colour_labels,
-                           reinterpret_cast<const uint32_t *>(sub_table + kSubCells + kCells), pal, k, labels, aligned);
+        const uint32_t *pairs = reinterpret_cast<const uint32_t *>(sub_table + kSubCells + kCells);
+        if (hot)
+            hipLaunchKernelGGL(k_labels_pairs<true>, dim3(grid), dim3(kLabelBlock), kLabelLdsHot, st, rgba, n,
+                               (const uint8_t *)colour_labels, pairs, pal, k, labels, aligned, hot);
+        else
+            hipLaunchKernelGGL(k_labels_pairs<false>, dim3(grid), dim3(kLabelBlock), kLabelLdsPlain, st, rgba, n,
+                               (const uint8_t *)colour_labels, pairs, pal, k, labels, aligned, hot);
         return hipGetLastError();
     }
     const uint64_t tiles = (n + kLabelBlock * 8 - 1) / (kLabelBlock * 8);
