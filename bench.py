@@ -348,6 +348,9 @@ def main():
                     help="run the label pass of an iteration beside the next iteration's cube pass (kmg_lloyd_iterate) "
                          "instead of before it")
     ap.add_argument("--no-overlap", action="store_true", help="(the default) kept for scripts")
+    ap.add_argument("--cells", action="store_true",
+                    help="N > 1: shard the cube pass by cells of the colour cube as well (ShardedLloyd(cells=True): histogram "
+                         "all-reduce once, all-gather of the label tables per iteration); default: row bands only")
     ap.add_argument("--separate-update", action="store_true",
                     help="centroid update as a launch of its own (k_update + memset) instead of on the assign pass's last launch")
     ap.add_argument("--force-dist", action="store_true",
@@ -423,7 +426,10 @@ def main():
     first.close()
     lloyd, strategy, t_prep = prepared()
 
-    sh = ShardedLloyd(lloyd, k, rgba, labels, stream=stream)
+    cells = bool(args.cells) and world > 1 and strategy == "table" and k <= 256
+    sh = ShardedLloyd(lloyd, k, rgba, labels, stream=stream, cells=cells)
+    if cells:
+        sh.bind_cells(n_local * world)        # once per image: band histograms all-reduced, this rank's share of the cube
     sh.split_labels = strategy == "table"     # the all-reduce overlaps the label-gather pass
     sh.pipeline = bool(args.overlap) and not args.no_overlap
     sh.fused = not args.separate_update       # one rank + colour table: the update rides on the assign pass's last launch
@@ -519,7 +525,7 @@ def main():
                                    f"iteration) + accumulate"
                                    + (" + RCCL all-reduce of k x 4 int64" if world > 1 else ""),
                        "width": WIDTH, "height": height, "k": k,
-                       "sharding": f"row bands, {rows} rows per GPU",
+                       "sharding": f"row bands, {rows} rows per GPU" + (", cube pass sharded by cells" if sh.cells else ""),
                        "strategy": strategy, "prepare_ms": t_prep * 1e3, "prepare_cold_ms": t_prep_cold * 1e3,
                        "label_pass": "beside the next iteration's cube pass" if sh.pipeline else "before the next iteration",
                        "update": "by the last launch of the assign pass (kmg_lloyd_assign_update)" if sh._fused()

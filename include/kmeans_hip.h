@@ -194,6 +194,26 @@ KMG_API int kmg_debug_check_meld_masks(kmg_processor *p, const float *centroids4
  * bound image whose label tables are current (an assign pass ran since the last centroid change) this
  * is just the label-gather pass.                                                                 */
 KMG_API int kmg_lloyd_labels(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n_pixels, uint32_t *d_labels, void *stream);
+/* Cell-sharded cube pass, for ONE image sharded over `parts` ranks (strong scaling; no counterpart in the reference, which
+ * is single-device: core/src/lib.rs:38-65).  Every rank binds the WHOLE image's colour histogram (its band's histogram,
+ * all-reduced) and labels the colours of one share of the colour cube per iteration: after _set_cell_share(part, parts)
+ * the assign passes of a bound image visit only the cells at positions [n part / parts, n (part + 1) / parts) of the
+ * image's list of occupied cells -- the sums they return are those of the share's colours (the all-reduce of the k x 4
+ * accumulators makes them the image's), and only the share's per-colour labels and cell entries are (re)written.  The
+ * ranks then exchange their shares of the label tables (_table_buffers: the per-colour labels, cell-major, 512 per cell,
+ * and the cell entries) and write their band's label map with _labels_from_tables, which applies the tables as they
+ * stand to ANY pixels whose colours occur in the bound image.  parts = 1 restores the whole list.                    */
+KMG_API int kmg_lloyd_set_cell_share(kmg_lloyd *s, uint32_t part, uint32_t parts, void *stream);
+/* The bound image's colour histogram (2^24 u32 counts in the library's cell-major colour order) for the all-reduce that
+ * turns the band's histogram into the image's, and the call that re-derives everything a binding derives from it (cell
+ * sums, occupied and hot cells; synchronises) -- n_pixels = the pixels the histogram now counts (< 2^32).            */
+KMG_API int kmg_lloyd_histogram_buffer(kmg_lloyd *s, void **hist, uint64_t *bytes);
+KMG_API int kmg_lloyd_rebuild_from_histogram(kmg_lloyd *s, uint64_t n_pixels, void *stream);
+KMG_API int kmg_lloyd_labels_from_tables(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n_pixels, uint32_t *d_labels,
+                                         void *stream);
+KMG_API int kmg_lloyd_table_buffers(kmg_lloyd *s, void **colour_labels, uint64_t *colour_label_bytes, void **entries,
+                                    uint64_t *entry_bytes);
+
 /* The label pass of the colour-table strategy (k <= 256) runs one 1024-thread workgroup per compute unit for its whole
  * duration.  A kernel launched beside it on another stream -- the RCCL all-reduce of the sums that a sharded loop issues
  * asynchronously: 256 threads, 20 KiB LDS, 280 registers per lane -- finds no CU it fits on and would run

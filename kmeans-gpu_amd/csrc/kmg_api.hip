@@ -154,6 +154,8 @@ struct ColourTable {
     uint64_t *d_masks = nullptr;     // kCells x words candidate masks
     uint32_t *d_work = nullptr;      // kWorkWords: dense list of the occupied cells, then the hot cells (kmg_table.h)
     uint32_t n_hot = 0;              // host copy of the number of hot cells of the bound image
+    uint32_t *share_buf = nullptr;   // storage of d_work_share
+    uint32_t *d_work_share = nullptr;   // 1 + kCells: this rank's share of the work list (kmg_lloyd_set_cell_share), or NULL = all of it
     bool tables_valid = false;       // label tables describe the CURRENT centroid table
     void *d_colour_labels = nullptr; // 2^24 x u8 (k <= 256) or u16
     uint16_t *d_sub = nullptr;       // kSubCells 4x4x4 summaries (u16), kCells 8x8x8 summaries (u16), kCells pair entries (u32)
@@ -539,6 +541,22 @@ static int ensure_bounds(kmg_processor *p, hipStream_t st)
     return KMG_OK;
 }
 
+// everything a binding derives from the histogram: per-cell and per-sub-cell sums, occupancy bits, the list of occupied
+// cells and the hot cells (n_pixels = the pixels the histogram counts)
+static int tables_from_histogram(kmg_lloyd *s, uint64_t n_pixels, hipStream_t st)
+{
+    ColourTable &t = s->tab;
+    HIP_TRY(launch_cell_aggregates(t.d_hist, s->p->d_lab_table, t.d_agg, t.d_sub_agg, t.d_occ, st));
+    // dense list of the occupied cells and the hot cells (static for this image); the label pass has a kernel variant for
+    // images with hot cells, so the host needs their number: 4 bytes back, the one synchronisation of a binding
+    HIP_TRY(launch_work_list(t.d_agg, t.d_work, s->k <= 256 ? n_pixels : 0, st));
+    HIP_TRY(hipMemcpyAsync(&t.n_hot, t.d_work + kCells + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (const char *e = getenv("KMG_HOT_CELLS")) { if (e[0] == '0') t.n_hot = 0; }      // probes
+    t.d_work_share = nullptr;
+    return KMG_OK;
+}
+
 // want_tie: also build the init tie keys (ColourTable::d_tie, allocated by the caller) for an image whose
 // first pixel has the image-wide index first_index
 static int bind_image_impl(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, void *stream, bool want_tie, uint64_t first_index)
@@ -555,9 +573,10 @@ static int bind_image_impl(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, void
     const uint32_t words = mask_words(s->k);
     if (!t.d_hist) {
         // one block for all tables, from the processor's idle blocks when one fits (no hipMalloc on a warm processor)
-        const size_t sizes[9] = {sizeof(uint32_t) << 24, sizeof(int64_t) * 4ull * kCells, sizeof(int64_t) * 4ull * kSubCells,
-                                 (size_t)1 << 21, cube_work_bytes(), sizeof(uint64_t) * (size_t)kCells * words,
-                                 sizeof(uint32_t) * kWorkWords, (size_t)(s->k <= 256 ? 1 : 2) << 24, sub_table_bytes()};
+        const size_t sizes[10] = {sizeof(uint32_t) << 24, sizeof(int64_t) * 4ull * kCells, sizeof(int64_t) * 4ull * kSubCells,
+                                  (size_t)1 << 21, cube_work_bytes(), sizeof(uint64_t) * (size_t)kCells * words,
+                                  sizeof(uint32_t) * kWorkWords, (size_t)(s->k <= 256 ? 1 : 2) << 24, sub_table_bytes(),
+                                  sizeof(uint32_t) * (kCells + 1)};
         size_t need = 0;
         for (size_t b : sizes) need += pad256(b);
         const hipError_t e = block_take(s->p, need, &t.blk, &t.blk_cap);
@@ -576,7 +595,9 @@ static int bind_image_impl(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, void
         t.d_work = (uint32_t *)carve(t.blk, off, sizes[6]);
         t.d_colour_labels = carve(t.blk, off, sizes[7]);
         t.d_sub = (uint16_t *)carve(t.blk, off, sizes[8]);
+        t.share_buf = (uint32_t *)carve(t.blk, off, sizes[9]);
     }
+    t.d_work_share = nullptr;                                        // a new image: the whole work list again
     t.rgba = nullptr;
     t.tables_valid = false;
     t.tie_valid = false;
@@ -608,13 +629,8 @@ static int bind_image_impl(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, void
         t.tie_valid = true;
         t.tie_first = first_index;
     }
-    HIP_TRY(launch_cell_aggregates(t.d_hist, s->p->d_lab_table, t.d_agg, t.d_sub_agg, t.d_occ, S(stream)));
-    // dense list of the occupied cells and the hot cells (static for this image); the label pass has a kernel variant for
-    // images with hot cells, so the host needs their number: 4 bytes back, the one synchronisation of a binding
-    HIP_TRY(launch_work_list(t.d_agg, t.d_work, s->k <= 256 ? n : 0, S(stream)));
-    HIP_TRY(hipMemcpyAsync(&t.n_hot, t.d_work + kCells + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, S(stream)));
-    HIP_TRY(hipStreamSynchronize(S(stream)));
-    if (const char *e = getenv("KMG_HOT_CELLS")) { if (e[0] == '0') t.n_hot = 0; }      // probes
+    int rc_agg;
+    if ((rc_agg = tables_from_histogram(s, n, S(stream))) != KMG_OK) return rc_agg;
     if (want_tie) HIP_TRY(launch_init_records(t.d_work, s->p->d_bounds, t.d_init_cells, S(stream)));   // an initialisation follows
     t.rgba = d_rgba;
     t.n = n;
@@ -940,7 +956,8 @@ static int table_assign(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_
         tail.convergence = s->p->opt.convergence;
         tail.cent = s->d_cent;
         tail.n_converged = s->d_nconv;
-        PROF_LAUNCH(s, KMG_K_CUBE, st, launch_cube(t.d_hist, t.d_agg, t.d_sub_agg, t.d_occ, t.d_work, s->p->d_bounds, s->p->d_sub_bounds,
+        PROF_LAUNCH(s, KMG_K_CUBE, st, launch_cube(t.d_hist, t.d_agg, t.d_sub_agg, t.d_occ, t.d_work_share ? t.d_work_share : t.d_work,
+                                                   s->p->d_bounds, s->p->d_sub_bounds,
                                                    s->d_cent, s->k, s->p->d_lab_table, t.d_masks, t.d_cell_work, t.d_colour_labels, t.d_sub,
                                                    s->d_acc_int, 1u, 0u, nullptr, st, &tail));
         s->acc_int_dirty = false;
@@ -1284,6 +1301,63 @@ extern "C" int kmg_lloyd_labels(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n,
     }
     PROF_LAUNCH(s, KMG_K_ASSIGN, S(stream), launch_assign((const uint32_t *)d_rgba, n, s->d_cent, s->k, s->p->d_lut,
                                                           d_labels, nullptr, S(stream)));
+    return KMG_OK;
+}
+
+// Cell-sharded cube pass (include/kmeans_hip.h)
+extern "C" int kmg_lloyd_set_cell_share(kmg_lloyd *s, uint32_t part, uint32_t parts, void *stream)
+{
+    if (!s || parts == 0 || part >= parts) return fail(KMG_ERR_INVALID_ARGUMENT, "bad set_cell_share arguments");
+    if (!s->tab.rgba || !s->tab.d_hist) return fail(KMG_ERR_INVALID_ARGUMENT, "set_cell_share: no bound image");
+    HIP_TRY(hipSetDevice(s->p->device));
+    ColourTable &t = s->tab;
+    if (parts == 1u) { t.d_work_share = nullptr; return KMG_OK; }
+    HIP_TRY(launch_work_share(t.d_work, part, parts, t.share_buf, S(stream)));
+    t.d_work_share = t.share_buf;
+    return KMG_OK;
+}
+
+extern "C" int kmg_lloyd_labels_from_tables(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_t *d_labels, void *stream)
+{
+    if (!s || !d_rgba || !d_labels || n == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad labels_from_tables arguments");
+    if (!s->tab.rgba || !s->tab.d_hist) return fail(KMG_ERR_INVALID_ARGUMENT, "labels_from_tables: no bound image");
+    HIP_TRY(hipSetDevice(s->p->device));
+    int rc_;
+    if ((rc_ = side_flush(s, S(stream))) != KMG_OK) return rc_;
+    PROF_LAUNCH(s, KMG_K_LABELS, S(stream), launch_labels((const uint32_t *)d_rgba, n, s->tab.d_colour_labels, s->tab.d_sub, s->k,
+                                                          nullptr, d_labels, S(stream), s->reserve_cus,
+                                                          s->tab.n_hot ? s->tab.d_work + kCells + 1 : nullptr));
+    return KMG_OK;
+}
+
+extern "C" int kmg_lloyd_histogram_buffer(kmg_lloyd *s, void **hist, uint64_t *bytes)
+{
+    if (!s || !s->tab.d_hist || !s->tab.rgba) return fail(KMG_ERR_INVALID_ARGUMENT, "histogram_buffer: no bound image");
+    if (hist) *hist = s->tab.d_hist;
+    if (bytes) *bytes = sizeof(uint32_t) << 24;
+    return KMG_OK;
+}
+
+extern "C" int kmg_lloyd_rebuild_from_histogram(kmg_lloyd *s, uint64_t n_pixels, void *stream)
+{
+    if (!s || !s->tab.d_hist || !s->tab.rgba || n_pixels == 0 || n_pixels > 0xFFFFFFFFull)
+        return fail(KMG_ERR_INVALID_ARGUMENT, "bad rebuild_from_histogram arguments");
+    HIP_TRY(hipSetDevice(s->p->device));
+    int rc_;
+    if ((rc_ = side_flush(s, S(stream))) != KMG_OK) return rc_;
+    s->tab.tables_valid = false;
+    s->tab.tie_valid = false;                                        // the init's tie keys belong to the band's own histogram
+    return tables_from_histogram(s, n_pixels, S(stream));
+}
+
+extern "C" int kmg_lloyd_table_buffers(kmg_lloyd *s, void **colour_labels, uint64_t *colour_label_bytes, void **entries,
+                                       uint64_t *entry_bytes)
+{
+    if (!s || !s->tab.d_hist) return fail(KMG_ERR_INVALID_ARGUMENT, "table_buffers: no bound image");
+    if (colour_labels) *colour_labels = s->tab.d_colour_labels;
+    if (colour_label_bytes) *colour_label_bytes = (uint64_t)(s->k <= 256 ? 1 : 2) << 24;
+    if (entries) *entries = s->tab.d_sub;
+    if (entry_bytes) *entry_bytes = sub_table_bytes();
     return KMG_OK;
 }
 

@@ -855,6 +855,29 @@ __global__ __launch_bounds__(1024) void k_work_list(const int64_t *__restrict__ 
     }
 }
 
+__global__ __launch_bounds__(1024) void k_work_share(const uint32_t *__restrict__ work, uint32_t part, uint32_t parts,
+                                                     uint32_t *__restrict__ out)
+{
+    // share `part` = the occupied cells with index in [kCells part / parts, kCells (part + 1) / parts): equal ranges of the
+    // CUBE, so that the shares' pieces of the label tables are equal, contiguous chunks (an in-place all-gather)
+    const uint32_t n = work[0];
+    const uint32_t c_lo = (uint32_t)((uint64_t)kCells * part / parts), c_hi = (uint32_t)((uint64_t)kCells * (part + 1u) / parts);
+    auto lower_bound = [&](uint32_t cell) {                        // first position whose cell is >= `cell` (the list ascends)
+        uint32_t lo = 0, hi = n;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (work[1u + mid] < cell) lo = mid + 1u; else hi = mid; }
+        return lo;
+    };
+    const uint32_t lo = lower_bound(c_lo), hi = lower_bound(c_hi);
+    for (uint32_t i = blockIdx.x * 1024u + threadIdx.x; i < hi - lo; i += gridDim.x * 1024u) out[1u + i] = work[1u + lo + i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[0] = hi - lo;
+}
+
+hipError_t launch_work_share(const uint32_t *work, uint32_t part, uint32_t parts, uint32_t *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_work_share, dim3(32), dim3(1024), 0, st, work, part, parts, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_work_list(const int64_t *agg, uint32_t *work, uint64_t n_pixels, hipStream_t st)
 {
     hipLaunchKernelGGL(k_work_list, dim3(1), dim3(1024), 0, st, agg, work, n_pixels);

@@ -30,6 +30,17 @@ _PKG_ROOT = os.path.dirname(os.path.dirname(_HERE))          # .../kmeans-gpu_am
 _LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libkmeans_hip.so")
 
 
+class _RawDeviceArray:
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def _alias_tensor(ptr, n, typestr):
+    """torch tensor over device memory the library owns (no copy): valid while the owning object lives"""
+    import torch
+    return torch.as_tensor(_RawDeviceArray(ptr, n, typestr), device="cuda")
+
+
 class KmgError(RuntimeError):
     def __init__(self, status, message):
         super().__init__(f"kmeans_hip error {status}: {message}")
@@ -70,7 +81,8 @@ SYMBOLS = [
     "kmg_lloyd_assign_partials", "kmg_lloyd_reduce_partials", "kmg_lloyd_labels", "kmg_lloyd_reserve_cus", "kmg_lloyd_bind_image",
     "kmg_lloyd_unbind_image", "kmg_lloyd_prepare", "kmg_debug_check_table", "kmg_debug_table_stats", "kmg_debug_check_pairs", "kmg_debug_check_dither_masks", "kmg_debug_check_meld_masks", "kmg_kernel_name",
     "kmg_lloyd_profile", "kmg_lloyd_profile_read",
-    "kmg_lloyd_update", "kmg_lloyd_assign_update", "kmg_lloyd_converged_count", "kmg_lloyd_iterate", "kmg_lloyd_flush", "kmg_lloyd_run", "kmg_dev_apply",
+    "kmg_lloyd_update", "kmg_lloyd_assign_update", "kmg_lloyd_set_cell_share", "kmg_lloyd_labels_from_tables",
+    "kmg_lloyd_table_buffers", "kmg_lloyd_histogram_buffer", "kmg_lloyd_rebuild_from_histogram", "kmg_lloyd_converged_count", "kmg_lloyd_iterate", "kmg_lloyd_flush", "kmg_lloyd_run", "kmg_dev_apply",
     "kmg_dither_threshold",
 ]
 
@@ -142,6 +154,11 @@ def lib():
     L.kmg_debug_check_table.argtypes = [vp, C.POINTER(C.c_uint64), vp]
     L.kmg_lloyd_update.argtypes = [vp, i64p, vp]
     L.kmg_lloyd_assign_update.argtypes = [vp, u8p, C.c_uint64, u32p, i64p, C.c_int, vp]
+    L.kmg_lloyd_set_cell_share.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
+    L.kmg_lloyd_labels_from_tables.argtypes = [vp, u8p, C.c_uint64, u32p, vp]
+    L.kmg_lloyd_histogram_buffer.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    L.kmg_lloyd_rebuild_from_histogram.argtypes = [vp, C.c_uint64, vp]
+    L.kmg_lloyd_table_buffers.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     L.kmg_lloyd_converged_count.argtypes = [vp, C.POINTER(C.c_uint32), vp]
     L.kmg_lloyd_iterate.argtypes = [vp, u8p, C.c_uint64, u32p, i64p, C.c_int, vp]
     L.kmg_lloyd_flush.argtypes = [vp, vp]
@@ -433,6 +450,45 @@ class Lloyd:
 
     def update(self, d_acc4, stream=0):
         _check(lib().kmg_lloyd_update(self._h, C.c_void_p(d_acc4), C.c_void_p(stream)))
+
+    def set_cell_share(self, part, parts, stream=0):
+        """cell-sharded cube pass: later assign passes of the bound image visit share `part` of `parts` of its occupied cells"""
+        _check(lib().kmg_lloyd_set_cell_share(self._h, int(part), int(parts), C.c_void_p(stream)))
+
+    def labels_from_tables(self, d_rgba, n_pixels, d_labels, stream=0):
+        """the label pass with the label tables as they stand, on any pixels whose colours occur in the bound image"""
+        _check(lib().kmg_lloyd_labels_from_tables(self._h, C.c_void_p(d_rgba), n_pixels, C.c_void_p(d_labels), C.c_void_p(stream)))
+
+    def histogram_buffer(self):
+        """(pointer, bytes) of the bound image's colour histogram (2^24 u32, cell-major colour order)"""
+        a, na = C.c_void_p(), C.c_uint64()
+        _check(lib().kmg_lloyd_histogram_buffer(self._h, C.byref(a), C.byref(na)))
+        return a.value, na.value
+
+    def rebuild_from_histogram(self, n_pixels, stream=0):
+        """re-derive the binding from the (all-reduced) histogram, which now counts n_pixels pixels"""
+        _check(lib().kmg_lloyd_rebuild_from_histogram(self._h, int(n_pixels), C.c_void_p(stream)))
+
+    def histogram_tensor(self):
+        """the bound image's colour histogram as a torch tensor that ALIASES the library's buffer (int32 [2^24]) -- for the
+        all-reduce of a cell-sharded loop (kmeans_gpu_amd.sharded)"""
+        ptr, nbytes = self.histogram_buffer()
+        return _alias_tensor(ptr, nbytes // 4, "<i4")
+
+    def table_tensors(self):
+        """(per-colour labels uint8 [2^24], cell entries int32 [32768]) of the bound image, k <= 256, as torch tensors that
+        ALIAS the library's label tables -- for the all-gather of a cell-sharded loop"""
+        lab, nlab, ent, nent = self.table_buffers()
+        if nlab != 1 << 24:
+            raise KmgError("table_tensors: the cell-sharded loop needs k <= 256")
+        n_cells, n_sub = 32768, 32768 * 8
+        return _alias_tensor(lab, nlab, "|u1"), _alias_tensor(ent + 2 * (n_sub + n_cells), n_cells, "<i4")
+
+    def table_buffers(self):
+        """(per-colour label table pointer, bytes, cell entry table pointer, bytes) of the bound image"""
+        a, na, b, nb = C.c_void_p(), C.c_uint64(), C.c_void_p(), C.c_uint64()
+        _check(lib().kmg_lloyd_table_buffers(self._h, C.byref(a), C.byref(na), C.byref(b), C.byref(nb)))
+        return a.value, na.value, b.value, nb.value
 
     def assign_update(self, d_rgba, n_pixels, d_labels, d_acc4, do_update=True, stream=0):
         """assign (labels optional, sums into d_acc4), then -- do_update -- the centroid update from those sums"""

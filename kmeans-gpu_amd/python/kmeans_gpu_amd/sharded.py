@@ -12,7 +12,10 @@ pass needs no exchange at all (kmg_dev_apply takes the band's first row).
 import torch
 import torch.distributed as dist
 
-__all__ = ["band_rows", "images_of_rank", "sharded_init", "ShardedLloyd", "ShardedBatch", "PlacedBatch"]
+__all__ = ["band_rows", "images_of_rank", "cell_range", "sharded_init", "ShardedLloyd", "ShardedBatch", "PlacedBatch"]
+
+CELLS = 32768             # 8x8x8 colour cells of the cube (kmg_table.h kCells), 512 colours each
+CELL_COLOURS = 512
 
 
 def _require_current_stream(tensor, stream):
@@ -31,6 +34,11 @@ def _require_current_stream(tensor, stream):
 def band_rows(height, rank, world):
     """Rows [r0, r1) owned by `rank`."""
     return (rank * height) // world, ((rank + 1) * height) // world
+
+
+def cell_range(rank, world):
+    """cells [c0, c1) whose colours `rank` labels in a cell-sharded loop (kmg_lloyd_set_cell_share uses the same rule)"""
+    return (CELLS * int(rank)) // int(world), (CELLS * (int(rank) + 1)) // int(world)
 
 
 def images_of_rank(n_images, rank, world):
@@ -89,7 +97,7 @@ class ShardedLloyd:
     """
 
     def __init__(self, backend, k, rgba, labels=None, group=None, stream=0, collective=None, local_only=False,
-                 reserve_cus=RESERVED_CUS):
+                 reserve_cus=RESERVED_CUS, cells=False, cell_hooks=None, rank=None):
         self.backend = backend
         self.k = int(k)
         self.rgba = rgba
@@ -119,11 +127,77 @@ class ShardedLloyd:
         # The asynchronous all-reduce is issued to run beside the label pass, but RCCL's kernel (256 threads, 20 KiB LDS,
         # 280 registers per lane) does not fit on a CU that hosts a label workgroup; reserve_cus > 0 launches the label pass
         # with that many workgroups fewer than CUs.  Reset in close().
+        # CELL-SHARDED cube pass (strong scaling of one image; colour-table strategy, k <= 256): row bands alone leave the cube
+        # pass -- which works on the image's COLOURS -- at full size on every rank.  With cells=True every rank binds the whole
+        # image's colour histogram (its band's, all-reduced once), labels one share of the colour cube per iteration
+        # (cell_range) and receives the other ranks' shares of the label tables by all-gather before it writes its band's
+        # label map; the sums stay the k x 4 all-reduce.  Same labels and centroids as the unsharded loop, bit for bit.
+        # Measured per-rank on one GPU (tools/strong_cells_per_rank.py): 1.70 / 2.54 / 3.71x at N = 2 / 4 / 8 against
+        # 1.35 / 1.60 / 1.83x for row bands alone.
+        # cell_hooks (tests, one process): object with reduce_histogram(t), gather_tables(lab_t, ent_t), world, rank.
+        self.cells = bool(cells)
+        self.cell_hooks = cell_hooks
+        self.rank = int(rank) if rank is not None else (dist.get_rank(group) if dist.is_initialized() else 0)
+        if cell_hooks is not None:
+            self.world = max(self.world, int(cell_hooks.world))
+            self.rank = int(cell_hooks.rank)
+        self._cells_bound = False
         self._reserved = 0
         if (reserve_cus and dist.is_initialized() and self.world > 1 and collective is None
                 and hasattr(backend, "reserve_cus")):
             backend.reserve_cus(int(reserve_cus))
             self._reserved = int(reserve_cus)
+
+    def bind_cells(self, n_total=None):
+        """once per image (cells=True): the band's histogram, all-reduced into the image's; this rank's share of the cube"""
+        be = self.backend
+        _require_current_stream(self.acc, self.stream)
+        be.bind_image(self.rgba.data_ptr(), self.n_local, self.stream)
+        hist = be.histogram_tensor()
+        if n_total is None:
+            t = torch.tensor([self.n_local], dtype=torch.int64, device=self.acc.device)
+            if self.cell_hooks is not None:
+                self.cell_hooks.reduce_count(t)
+            elif self.world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            n_total = int(t.item())
+        if self.cell_hooks is not None:
+            self.cell_hooks.reduce_histogram(hist)
+        elif self.world > 1:
+            dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=self.group)
+        be.rebuild_from_histogram(n_total, self.stream)
+        be.set_cell_share(self.rank, self.world, self.stream)
+        self._lab_t, self._ent_t = be.table_tensors()
+        self._cells_bound = True
+
+    def _gather_tables(self):
+        """every rank's share of the per-colour labels and cell entries -> all ranks (in place)"""
+        if self.cell_hooks is not None:
+            self.cell_hooks.gather_tables(self._lab_t, self._ent_t)
+            return
+        if self.world == 1:
+            return
+        ranges = [cell_range(r, self.world) for r in range(self.world)]
+        for t, per_cell in ((self._lab_t, CELL_COLOURS), (self._ent_t, 1)):
+            views = [t[c0 * per_cell:c1 * per_cell] for c0, c1 in ranges]
+            if CELLS % self.world == 0:
+                dist.all_gather(views, views[self.rank], group=self.group)
+            else:                                   # unequal shares: one broadcast per owner
+                for r, v in enumerate(views):
+                    dist.broadcast(v, src=dist.get_global_rank(self.group, r) if self.group is not None else r, group=self.group)
+
+    def _pass_cells(self):
+        lab_ptr = self.labels.data_ptr() if self.labels is not None else 0
+        _require_current_stream(self.acc, self.stream)
+        if not self._cells_bound:
+            self.bind_cells()
+        self.backend.assign_accumulate(self.rgba.data_ptr(), self.n_local, 0, self.acc.data_ptr(), self.stream)
+        work = self.exchange(async_op=True)
+        if lab_ptr:
+            self._gather_tables()
+            self.backend.labels_from_tables(self.rgba.data_ptr(), self.n_local, lab_ptr, self.stream)
+        if work is not None:
+            work.wait()
 
     def _pass(self):
         """labels + sums of the current centroids, and the exchange of the sums.
@@ -131,6 +205,8 @@ class ShardedLloyd:
         With the colour-table strategy (`split_labels`) the sums come from the cube pass and the
         label map from a separate gather pass that does not feed the collective: the all-reduce is
         issued asynchronously right after the sums and overlaps the label pass."""
+        if self.cells:
+            return self._pass_cells()
         lab_ptr = self.labels.data_ptr() if self.labels is not None else 0
         _require_current_stream(self.acc, self.stream)
         if self.n_local == 0:
@@ -160,12 +236,12 @@ class ShardedLloyd:
     def _pipelined(self):
         """kmeans_gpu_amd.Lloyd.iterate: the label pass of iteration t runs beside the update + cube pass of
         iteration t + 1 on the library's own stream (colour-table strategy with a label map)"""
-        return (self.pipeline and self.split_labels and self.labels is not None and self.n_local > 0
+        return (self.pipeline and not self.cells and self.split_labels and self.labels is not None and self.n_local > 0
                 and hasattr(self.backend, "iterate"))
 
     def _fused(self):
-        return (self.fused and self.world == 1 and self.split_labels and self.labels is not None and self.n_local > 0
-                and hasattr(self.backend, "assign_update") and not self._pipelined())
+        return (self.fused and self.world == 1 and not self.cells and self.split_labels and self.labels is not None
+                and self.n_local > 0 and hasattr(self.backend, "assign_update") and not self._pipelined())
 
     def _assign_then_update(self):
         _require_current_stream(self.acc, self.stream)

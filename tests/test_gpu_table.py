@@ -906,3 +906,68 @@ def test_assign_update_equals_the_two_calls(torch_cuda, oracle, monkeypatch, k, 
     torch.cuda.synchronize()
     assert np.array_equal(lb.cpu().numpy().view(np.uint32), wl)
     a.close(); b.close(); p.close()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_cell_sharded_cube_pass_equals_unsharded(torch_cuda, oracle, tokyo, monkeypatch, world):
+    """The cell-sharded loop of kmeans_gpu_amd.sharded (ShardedLloyd(cells=True)) with the real kernels, `world` ranks emulated
+    on one GPU in lockstep: band histograms summed into every rank's table (histogram_tensor / rebuild_from_histogram), each
+    rank's cube pass over its share of the cube (set_cell_share), the k x 4 sums added up, the ranks' shares of the label
+    tables copied to all (table_tensors), every band's label map from labels_from_tables -- labels, sums and centroids
+    of five iterations equal the unsharded run and the oracle.  The photograph has hot cells (kmg_table.h)."""
+    import kmeans_gpu_amd as kg
+    from kmeans_gpu_amd.sharded import band_rows, cell_range
+    torch = torch_cuda
+    st = _stream(torch)
+    monkeypatch.setenv("KMG_STRATEGY", "table")
+    k = 40
+    img = tokyo[:500, :700].copy()
+    h, w = img.shape[:2]
+    n = w * h
+    lab = oracle.rgb_to_lab(img)
+    init = oracle.centroids4(lab.reshape(-1, 3)[np.random.default_rng(5).choice(n, k, replace=False)])
+    d = _dev(torch, img).reshape(-1, 4)
+    p = kg.ImageProcessor(shrink_max_dim=0)
+    ranks = []
+    for r in range(world):
+        r0, r1 = band_rows(h, r, world)
+        band = d[r0 * w:r1 * w]
+        s = kg.Lloyd(p, k)
+        s.set_centroids(init, st)
+        s.bind_image(band.data_ptr(), (r1 - r0) * w, st)
+        ranks.append((s, band, (r1 - r0) * w, torch.zeros((r1 - r0) * w, dtype=torch.int32, device="cuda"),
+                      torch.zeros((k, 4), dtype=torch.int64, device="cuda")))
+    hists = [s.histogram_tensor() for s, *_ in ranks]
+    total_hist = torch.stack(hists).sum(0).to(torch.int32)
+    assert int(total_hist.sum()) == n
+    for r, (s, *_rest) in enumerate(ranks):
+        hists[r].copy_(total_hist)                                  # the all-reduce
+        s.rebuild_from_histogram(n, st)
+        s.set_cell_share(r, world, st)
+    tables = [s.table_tensors() for s, *_ in ranks]
+    cent = init
+    for it in range(5):
+        total = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
+        for s, band, nb, labels, acc in ranks:
+            s.assign_accumulate(band.data_ptr(), nb, 0, acc.data_ptr(), st)
+            total += acc
+        for r in range(world):                                      # the all-gather of the label tables
+            c0, c1 = cell_range(r, world)
+            for q in range(world):
+                if q != r:
+                    tables[q][0][c0 * 512:c1 * 512].copy_(tables[r][0][c0 * 512:c1 * 512])
+                    tables[q][1][c0:c1].copy_(tables[r][1][c0:c1])
+        want_l, want_a = oracle.assign_accumulate_rgba(img, cent)
+        assert np.array_equal(total.cpu().numpy(), want_a), it
+        for r, (s, band, nb, labels, acc) in enumerate(ranks):
+            s.labels_from_tables(band.data_ptr(), nb, labels.data_ptr(), st)
+            r0, r1 = band_rows(h, r, world)
+            torch.cuda.synchronize()
+            assert np.array_equal(labels.cpu().numpy().view(np.uint32), want_l[r0 * w:r1 * w]), (it, r)
+            s.update(total.data_ptr(), st)
+        cent, _ = oracle.finalize(want_a, cent)
+        for s, *_rest in ranks:
+            assert np.array_equal(s.get_centroids(st).view(np.uint32), cent.view(np.uint32)), it
+    for s, *_rest in ranks:
+        s.close()
+    p.close()

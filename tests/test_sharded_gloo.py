@@ -318,3 +318,117 @@ def test_sharded_init_then_lloyd_equals_oracle(oracle):
     for rank, init, it, cent in res:
         assert np.array_equal(init.view(np.uint32), want_init.view(np.uint32))
         assert it == want_it and np.array_equal(cent.view(np.uint32), want_c.view(np.uint32))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# cell-sharded cube pass (ShardedLloyd(cells=True)): the data flow of the GPU loop with an oracle-backed stand-in
+# ---------------------------------------------------------------------------------------------------------------
+def _colour_index(px):
+    """kmg_table.h colour_index: cell-major, sub-cell-major order of the 2^24 colours"""
+    r, g, b = (px[:, i].astype(np.uint32) for i in range(3))
+    return (((r >> 3) << 19) | ((g >> 3) << 14) | ((b >> 3) << 9) | (((r >> 2) & 1) << 8) | (((g >> 2) & 1) << 7) |
+            (((b >> 2) & 1) << 6) | ((r & 3) << 4) | ((g & 3) << 2) | (b & 3))
+
+
+def _index_to_rgba(idx):
+    idx = idx.astype(np.uint32)
+    out = np.empty((idx.size, 4), np.uint8)
+    out[:, 0] = (((idx >> 19) & 31) << 3) | (((idx >> 8) & 1) << 2) | ((idx >> 4) & 3)
+    out[:, 1] = (((idx >> 14) & 31) << 3) | (((idx >> 7) & 1) << 2) | ((idx >> 2) & 3)
+    out[:, 2] = (((idx >> 9) & 31) << 3) | (((idx >> 6) & 1) << 2) | (idx & 3)
+    out[:, 3] = 255
+    return out
+
+
+class OracleCellBackend(OracleBackend):
+    """The cell-sharded interface of kmeans_gpu_amd.Lloyd on the CPU: colour histogram, a share of the cube per rank,
+    per-colour label table.  The label of a colour comes from the oracle's arg-min, the sums from the oracle's integer
+    accumulation weighted with the histogram's counts."""
+
+    def bind_image(self, d_rgba, n, stream=0):
+        px = self._view(d_rgba, (n, 4), np.uint8)
+        self.hist = np.bincount(_colour_index(px), minlength=1 << 24).astype(np.int32)
+        self.lab_table = np.zeros(1 << 24, np.uint8)
+        self.entries = np.zeros(32768, np.int32)
+
+    def histogram_tensor(self):
+        return torch.from_numpy(self.hist)
+
+    def rebuild_from_histogram(self, n_total, stream=0):
+        assert int(self.hist.sum()) == n_total
+        self.colours = np.flatnonzero(self.hist).astype(np.uint32)
+        self.share = self.colours
+
+    def set_cell_share(self, part, parts, stream=0):
+        c0, c1 = (32768 * part) // parts, (32768 * (part + 1)) // parts
+        cell = self.colours >> 9
+        self.share = self.colours[(cell >= c0) & (cell < c1)]
+
+    def table_tensors(self):
+        return torch.from_numpy(self.lab_table), torch.from_numpy(self.entries)
+
+    def assign_accumulate(self, d_rgba, n, d_labels, d_acc, stream=0):
+        assert not d_labels
+        acc = np.zeros((self.k, 4), np.int64)
+        if self.share.size:
+            lab = self.O.rgb_to_lab(_index_to_rgba(self.share))
+            labels = self.O.assign(lab, self.cent)
+            self.lab_table[self.share] = labels.astype(np.uint8)
+            counts = self.hist[self.share]
+            acc = self.O.accumulate(np.repeat(lab, counts, axis=0), np.repeat(labels, counts), self.k)
+        self._view(d_acc, (self.k, 4), np.int64)[:] = acc
+
+    def labels_from_tables(self, d_rgba, n, d_labels, stream=0):
+        px = self._view(d_rgba, (n, 4), np.uint8)
+        self._view(d_labels, (n,), np.uint32)[:] = self.lab_table[_colour_index(px)]
+
+
+def _cells_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "kmeans-gpu_amd", "python"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    from kmeans_gpu_amd.sharded import ShardedLloyd, band_rows
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        O.set_num_threads(2)
+        w, h, k = 96, 61, 7
+        img = O.synth_uniform(4242, w * h).reshape(h, w, 4)
+        lab = O.rgb_to_lab(img)
+        init = O.init_centroids(lab, w, h, k)
+        r0, r1 = band_rows(h, rank, world)
+        band = torch.from_numpy(np.ascontiguousarray(img[r0:r1]).reshape(-1, 4))
+        labels = torch.zeros((r1 - r0) * w, dtype=torch.int32)
+        be = OracleCellBackend(O, k, init)
+        sh = ShardedLloyd(be, k, band, labels, cells=True)
+        it = sh.run(128, 8)
+        q.put((rank, it, be.cent.copy(), labels.numpy().view(np.uint32).copy(), (r0, r1)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_cell_sharded_lloyd_equals_unsharded(oracle, world):
+    """ShardedLloyd(cells=True) over gloo: histogram all-reduce at bind, per iteration the k x 4 all-reduce and the
+    all-gather (world 2: equal shares) / per-owner broadcasts (world 3: 32768 cells do not divide) of the label tables --
+    iteration count, centroids and every rank's band of the label map equal the unsharded oracle bit for bit."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cells_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=240) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    w, h, k = 96, 61, 7
+    img = oracle.synth_uniform(4242, w * h).reshape(h, w, 4)
+    lab = oracle.rgb_to_lab(img)
+    want_c, want_labels, want_it = oracle.lloyd(lab, oracle.init_centroids(lab, w, h, k))
+    for rank, it, cent, labels, (r0, r1) in res:
+        assert it == want_it
+        assert np.array_equal(cent.view(np.uint32), want_c.view(np.uint32))
+        assert np.array_equal(labels, want_labels[r0 * w:r1 * w])
