@@ -6,14 +6,15 @@ tag = sys.argv[1]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 for name in ("bench.json", "kernel_stats.csv", "pmc_fetch_write.csv", "pmc_units.txt", "init.txt", "table_stats.txt",
-             "dither_knock.txt", "dither_stats.txt", "lab_rate.txt"):
+             "dither_knock.txt", "dither_stats.txt", "lab_rate.txt", "apply_kernel_stats.csv", "apply_pmc.txt", "apply_host.txt",
+             "strong_cells_per_rank.json"):
     src = os.path.join(G, f"{tag}_{name}")
     if os.path.exists(src):
         shutil.copy(src, os.path.join(P, f"{tag}_{name}"))
 rows = list(csv.DictReader(open(os.path.join(P, f"{tag}_pmc_fetch_write.csv"))))
 acc = collections.defaultdict(list)
 for r in rows:
-    acc[(r["Kernel_Name"].split("(")[0].replace("void ", "").replace("kmg::", ""), r["Counter_Name"])].append(float(r["Counter_Value"]))
+    acc[(r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "").replace("kmg::", ""), r["Counter_Name"])].append(float(r["Counter_Value"]))
 kernels = {}
 for (k, c), v in sorted(acc.items()):
     kernels.setdefault(k, {})[c + "_KiB"] = statistics.mean(v)
