@@ -734,7 +734,7 @@ extern "C" int kmg_debug_check_dither_masks(kmg_processor *p, const float *c4, u
     HIP_TRY(viol.alloc(sizeof(unsigned long long)));
     HIP_TRY(hipMemcpyAsync(cent.ptr, hc.data(), sizeof(Centroid) * k, hipMemcpyHostToDevice, S(stream)));
     HIP_TRY(hipMemsetAsync(viol.ptr, 0, sizeof(unsigned long long), S(stream)));
-    HIP_TRY(launch_offset_candidates(p->d_bounds, (const Centroid *)cent.ptr, k, thr, (uint64_t *)masks.ptr, S(stream)));
+    HIP_TRY(launch_offset_candidates(p->d_bounds, (const Centroid *)cent.ptr, k, thr, (uint64_t *)masks.ptr, nullptr, S(stream)));
     HIP_TRY(launch_check_offset_masks((const Centroid *)cent.ptr, k, (const uint64_t *)masks.ptr, p->d_lut, thr,
                                       (unsigned long long *)viol.ptr, S(stream)));
     unsigned long long h = 0;
@@ -1628,7 +1628,7 @@ extern "C" int kmg_dev_apply(kmg_processor *p, const uint8_t *d_rgba, uint32_t w
     const size_t labels_bytes = (size_t)(k <= 256 ? 1 : 2) << 24;
     const size_t masks_bytes = sizeof(uint64_t) * (size_t)kCells * mask_words(k) * (dither_pruned ? 16u : 1u);
     size_t need = ArenaGuard::padded(tables_bytes);
-    if (meld_masks_pay || dither_pruned) need += ArenaGuard::padded(masks_bytes);
+    if (meld_masks_pay || dither_pruned) need += ArenaGuard::padded(masks_bytes) + ArenaGuard::padded(kListTableBytes);
     if (replace_table) need += ArenaGuard::padded(labels_bytes) + ArenaGuard::padded(sub_bytes) + ArenaGuard::padded(masks_bytes) +
                                ArenaGuard::padded(cube_work_bytes());
     ArenaGuard arena;
@@ -1678,9 +1678,10 @@ extern "C" int kmg_dev_apply(kmg_processor *p, const uint8_t *d_rgba, uint32_t w
         // pixel's candidates only
         if ((rc = ensure_bounds(p, S(stream))) == KMG_OK) {
             uint64_t *m = (uint64_t *)arena.take(masks_bytes);
-            e = launch_offset_candidates(p->d_bounds, d_cent, k, thr, m, S(stream));
+            uint8_t *lst = (k > 64 && k <= 256) ? (uint8_t *)arena.take(kListTableBytes) : nullptr;   // byte lists (k_dither_lists)
+            e = launch_offset_candidates(p->d_bounds, d_cent, k, thr, m, lst, S(stream));
             if (e == hipSuccess)
-                e = launch_dither_pruned((const uint32_t *)d_rgba, w, rows, row0, d_cent, k, p->d_lut, d_pal, thr, m,
+                e = launch_dither_pruned((const uint32_t *)d_rgba, w, rows, row0, d_cent, k, p->d_lut, d_pal, thr, m, lst,
                                          (uint32_t *)d_out, S(stream));
         }
     } else {

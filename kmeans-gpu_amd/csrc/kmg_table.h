@@ -193,11 +193,16 @@ hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_la
 // ordered-dither output pass with candidate pruning: masks[(cell * 16 + Bayer index) * words + w] are the
 // centroids that can be the arg-min of Lab(colour) + threshold * (M[Bayer index] / 16 - 0.5) for any
 // colour of the cell; the pass scans only those (pal: k + 1 RGBA8 words, entry k = the sentinel)
+// lists (optional, k <= 256, 2 x kCells * 16 records of kListBytes): the same candidates as a byte list per (cell, Bayer
+// index), ascending: record r of the first half = [count][the first 31 indices], record r of the second half = indices
+// 31 .. 62 of the (few) slots with more than 31 candidates; count = 255: more than kListMax (the pass then scans all centroids)
+constexpr uint32_t kListBytes = 32, kListMax = 2 * kListBytes - 1;
+constexpr size_t kListTableBytes = 2ull * kCells * 16ull * kListBytes;
 hipError_t launch_offset_candidates(const CellBounds *bounds, const Centroid *cent, uint32_t k, float threshold,
-                                    uint64_t *masks, hipStream_t st);
+                                    uint64_t *masks, uint8_t *lists, hipStream_t st);
 hipError_t launch_dither_pruned(const uint32_t *rgba, uint32_t w, uint32_t rows, uint32_t row0, const Centroid *cent,
                                 uint32_t k, const float *lut, const uint32_t *pal, float threshold,
-                                const uint64_t *masks, uint32_t *out, hipStream_t st);
+                                const uint64_t *masks, const uint8_t *lists, uint32_t *out, hipStream_t st);
 // test support: number of (colour, Bayer index) pairs whose arg-min over the candidates differs from
 // the brute-force dither arg-min
 hipError_t launch_check_offset_masks(const Centroid *cent, uint32_t k, const uint64_t *masks, const float *lut,
