@@ -956,7 +956,9 @@ constexpr uint32_t kHotCode = 127u;                                // direction 
 constexpr size_t kLabelLdsPlain = sizeof(uint32_t) * (kCells + 256 + 128);
 constexpr size_t kLabelLdsHot = kLabelLdsPlain + (size_t)kHotMax * kCellColours + sizeof(uint32_t) * 64;
 
-template <bool HOT>
+// KNOCK (tools only, results wrong): 1 = gathers from a 64 KiB window of the table, 2 = from LDS instead, 3 = none,
+// 4 = plain non-temporal gathers
+template <bool HOT, int KNOCK = 0>
 __global__ __launch_bounds__(kLabelBlock) void k_labels_pairs(const uint32_t *__restrict__ rgba, uint64_t n,
                                                               const uint8_t *__restrict__ colour_labels,
                                                               const uint32_t *__restrict__ pair_table,
@@ -1028,7 +1030,12 @@ __global__ __launch_bounds__(kLabelBlock) void k_labels_pairs(const uint32_t *__
         }
 #pragma unroll
         for (int p = 0; p < 8; ++p)
-            if (fine[p]) lab[p] = (uint32_t)colour_labels[ci[p]];
+            if (fine[p]) {
+                if (KNOCK == 0) lab[p] = (uint32_t)colour_labels[ci[p]];
+                else if (KNOCK == 1) lab[p] = (uint32_t)colour_labels[ci[p] & 0xFFFFu];
+                else if (KNOCK == 2) lab[p] = (uint32_t)reinterpret_cast<const uint8_t *>(s_pair)[ci[p] & 0x1FFFFu];
+                else if (KNOCK == 4) lab[p] = (uint32_t)__builtin_nontemporal_load(colour_labels + ci[p]);
+            }
         if (pal) {
 #pragma unroll
             for (int p = 0; p < 8; ++p) lab[p] = s_pal[lab[p]];
@@ -1060,7 +1067,12 @@ hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_la
         const int aligned = ((reinterpret_cast<uintptr_t>(rgba) & 15u) == 0 &&
                              (reinterpret_cast<uintptr_t>(labels) & 15u) == 0) ? 1 : 0;
         const uint32_t *pairs = reinterpret_cast<const uint32_t *>(sub_table + kSubCells + kCells);
-        if (hot)
+        static const int knock = getenv("KMG_LABEL_KNOCK") ? atoi(getenv("KMG_LABEL_KNOCK")) : 0;       // tools only
+#define KMG_LK(K) hipLaunchKernelGGL((k_labels_pairs<false, K>), dim3(grid), dim3(kLabelBlock), kLabelLdsPlain, st, rgba, n, \
+                                     (const uint8_t *)colour_labels, pairs, pal, k, labels, aligned, hot)
+        if (knock == 1) KMG_LK(1); else if (knock == 2) KMG_LK(2); else if (knock == 3) KMG_LK(3); else if (knock == 4) KMG_LK(4);
+#undef KMG_LK
+        else if (hot)
             hipLaunchKernelGGL(k_labels_pairs<true>, dim3(grid), dim3(kLabelBlock), kLabelLdsHot, st, rgba, n,
                                (const uint8_t *)colour_labels, pairs, pal, k, labels, aligned, hot);
         else
