@@ -138,6 +138,23 @@ def analyse(name, rgba):
             sideC = (P > t_hi[..., None]) & rest[:, None, :]
             r2 = ((sideB | sideC) * w[:, None, :]).sum(-1)
             res2[c0:c0 + 256] = r2.amax(1)
+        # ONE plane, both sides: p < tlo -> A, p > thi -> B (thi = highest p of a colour that is not B), for the 125 directions
+        # and for the 18 directions with components -1..1 and at most two of them non-zero (p <= 14: two 4-bit thresholds)
+        for nm, dirs in (("125 directions", directions(2)),
+                         ("18 directions (4-bit thresholds)", directions(1)[(directions(1) != 0).sum(1) <= 2])):
+            p_all = (xyz.float() @ dirs.float().T).T.contiguous()
+            p_all = p_all - p_all.amin(1, keepdim=True)
+            both = torch.zeros(Lc.shape[0], device=dev)
+            for c0 in range(0, Lc.shape[0], 256):
+                l = Lc[c0:c0 + 256]; w = Wc[c0:c0 + 256]; o = w > 0
+                a = A[c0:c0 + 256, None]; b2 = B[c0:c0 + 256, None]
+                P = p_all[None]
+                tlo = torch.where(((l != a) & o)[:, None, :], P, torch.full_like(P, 1e9)).amin(-1)
+                thi = torch.where(((l != b2) & o)[:, None, :], P, torch.full_like(P, -1e9)).amax(-1)
+                res = (((P < tlo[..., None]) | (P > thi[..., None])) & o[:, None, :]) * w[:, None, :]
+                both[c0:c0 + 256] = res.sum(-1).amax(1)
+            print(f"   cells with 3+ labels, ONE plane with an A side and a B side, {nm}: resolves {float(both.sum()) / w3:.4f} of their pixels; "
+                  f"left to the gather {float((w3 - both.sum()) / tot):.4f} of all pixels")
         print(f"   cells with 3+ labels: A side of the best first plane resolves {float(res1.sum()) / w3:.4f} of their pixels; "
               f"a second plane (B | C) {float(res2.sum()) / w3:.4f} more; left to the gather {1 - float((res1 + res2).sum()) / w3:.4f} "
               f"= {float((w3 - (res1 + res2).sum()) / tot):.4f} of all pixels (today's entries leave {float((w3 - res1.sum()) / tot):.4f} at best)")
