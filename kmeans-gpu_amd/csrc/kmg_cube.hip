@@ -795,7 +795,8 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
         if (lds_stage > lds_max || lds_scan > lds_max) return hipErrorInvalidValue;
     }
     // (the scan kernel's cells differ a lot in cost: finer hand-out, 2 cells per wave, measured 83 -> 75 us)
-    static const uint32_t g_stage = env_grid("KMG_CUBE_GRID", kCubeGrid), g_scan = env_grid("KMG_SCAN_GRID", 2u * kCubeGrid),
+    // (stage: 1536 workgroups = one full round at its 6 waves per SIMD: 33 -> 30-31 us against 2048, round 3)
+    static const uint32_t g_stage = env_grid("KMG_CUBE_GRID", 1536u), g_scan = env_grid("KMG_SCAN_GRID", 2u * kCubeGrid),
                           g_pairs = env_grid("KMG_PAIRS_GRID", kCubeGrid);
     CellWork *cw = (CellWork *)cell_work;
     if (!n_rows) n_rows = 1u;
