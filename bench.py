@@ -261,7 +261,9 @@ def output_pass_timing(proc, rgba, n_pixels, stream, sh=None, steps=3):
                 _, resolved, total = sh.backend.debug_check_pairs(stream)
                 extra["uniform_pixels_resolved_in_lds"] = resolved / max(total, 1)
 
-            # what kmg_lloyd_run executes per iteration: sums only, the label map is written once at the end
+            # the iteration without its label map (update + sums).  kmg_lloyd_run's own iterations are cheaper still: the update
+            # rides on the assign pass and the label pass's pair entries are derived once, before the final label map
+            # (cfg3_lloyd_and_labels_ms / cfg3_iterations)
             def sums_only(iters):
                 for _ in range(iters):
                     sh.backend.update(sh.acc.data_ptr(), stream)

@@ -157,6 +157,7 @@ struct ColourTable {
     uint32_t *share_buf = nullptr;   // storage of d_work_share
     uint32_t *d_work_share = nullptr;   // 1 + kCells: this rank's share of the work list (kmg_lloyd_set_cell_share), or NULL = all of it
     bool tables_valid = false;       // label tables describe the CURRENT centroid table
+    bool entries_valid = false;      // ... including the cells' pair entries / summaries (kmg_lloyd_run defers them to its last pass)
     void *d_colour_labels = nullptr; // 2^24 x u8 (k <= 256) or u16
     uint16_t *d_sub = nullptr;       // kSubCells 4x4x4 summaries (u16), kCells 8x8x8 summaries (u16), kCells pair entries (u32)
     // second set of label tables (kmg_lloyd_iterate): the cube pass of iteration t + 1 writes one set while the
@@ -913,6 +914,7 @@ static int debug_refresh(kmg_lloyd *s, hipStream_t st, unsigned long long stage[
     HIP_TRY(hipMemsetAsync(s->d_partials, 0, sizeof(int64_t) * (4ull * s->k + 6ull), st));
     HIP_TRY(launch_cube(t.d_hist, t.d_agg, t.d_sub_agg, t.d_occ, t.d_work, s->p->d_bounds, s->p->d_sub_bounds, s->d_cent, s->k,
                         s->p->d_lab_table, t.d_masks, t.d_cell_work, t.d_colour_labels, t.d_sub, s->d_partials, 1u, 1u, d_stage, st));
+    t.entries_valid = true;
     if (stage) HIP_TRY(hipMemcpyAsync(stage, d_stage, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return KMG_OK;
@@ -937,9 +939,20 @@ static bool table_bound(const kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n)
 // labels (optional) + sums through the colour table.  The cube workgroups add their sums into `rows` shared
 // rows of `d_sums` (k x 4 int64 each): the caller's accumulators directly (rows = 1, no reduction pass), or
 // the partial slab for the two-step entry points.
-static int table_assign(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_t *d_labels, int64_t *d_sums,
-                        uint32_t rows, hipStream_t st, bool update_after = false)
+// the label pass's first-level tables (pair entries / cell summaries) of the current per-colour labels, if a pass deferred them
+static int ensure_entries(kmg_lloyd *s, hipStream_t st)
 {
+    ColourTable &t = s->tab;
+    if (t.entries_valid) return KMG_OK;
+    HIP_TRY(launch_cube_entries(t.d_work_share ? t.d_work_share : t.d_work, t.d_occ, t.d_colour_labels, t.d_sub, s->k, st));
+    t.entries_valid = true;
+    return KMG_OK;
+}
+
+static int table_assign(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_t *d_labels, int64_t *d_sums,
+                        uint32_t rows, hipStream_t st, bool update_after = false, bool defer_entries = false)
+{
+    if (d_labels) defer_entries = false;
     ColourTable &t = s->tab;
     t.bound_by_init = false;      // only a prepare() that directly follows the initialisation may reuse its binding
     int rc_;
@@ -959,14 +972,16 @@ static int table_assign(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_
         PROF_LAUNCH(s, KMG_K_CUBE, st, launch_cube(t.d_hist, t.d_agg, t.d_sub_agg, t.d_occ, t.d_work_share ? t.d_work_share : t.d_work,
                                                    s->p->d_bounds, s->p->d_sub_bounds,
                                                    s->d_cent, s->k, s->p->d_lab_table, t.d_masks, t.d_cell_work, t.d_colour_labels, t.d_sub,
-                                                   s->d_acc_int, 1u, 0u, nullptr, st, &tail));
+                                                   s->d_acc_int, 1u, defer_entries ? kCubeNoEntries : 0u, nullptr, st, &tail));
         s->acc_int_dirty = false;
+        t.entries_valid = !defer_entries;
     } else {
         if (update_after) return fail(KMG_ERR_INVALID_ARGUMENT, "table_assign: update_after needs the final sums");
         HIP_TRY(hipMemsetAsync(d_sums, 0, sizeof(int64_t) * 4ull * s->k * rows, st));
         PROF_LAUNCH(s, KMG_K_CUBE, st, launch_cube(t.d_hist, t.d_agg, t.d_sub_agg, t.d_occ, t.d_work, s->p->d_bounds, s->p->d_sub_bounds,
                                                    s->d_cent, s->k, s->p->d_lab_table, t.d_masks, t.d_cell_work, t.d_colour_labels, t.d_sub,
                                                    d_sums, rows, 0u, nullptr, st));
+        t.entries_valid = true;
     }
     t.tables_valid = true;
     if (d_labels)
@@ -1294,6 +1309,7 @@ extern "C" int kmg_lloyd_labels(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n,
     int rc_;
     if ((rc_ = side_flush(s, S(stream))) != KMG_OK) return rc_;      // both branches write d_labels
     if (table_bound(s, d_rgba, n) && s->tab.tables_valid) {
+        if ((rc_ = ensure_entries(s, S(stream))) != KMG_OK) return rc_;
         PROF_LAUNCH(s, KMG_K_LABELS, S(stream), launch_labels((const uint32_t *)d_rgba, n, s->tab.d_colour_labels,
                                                               s->tab.d_sub, s->k, nullptr, d_labels, S(stream), s->reserve_cus,
                                                               s->tab.n_hot ? s->tab.d_work + kCells + 1 : nullptr));
@@ -1324,6 +1340,7 @@ extern "C" int kmg_lloyd_labels_from_tables(kmg_lloyd *s, const uint8_t *d_rgba,
     HIP_TRY(hipSetDevice(s->p->device));
     int rc_;
     if ((rc_ = side_flush(s, S(stream))) != KMG_OK) return rc_;
+    if ((rc_ = ensure_entries(s, S(stream))) != KMG_OK) return rc_;
     PROF_LAUNCH(s, KMG_K_LABELS, S(stream), launch_labels((const uint32_t *)d_rgba, n, s->tab.d_colour_labels, s->tab.d_sub, s->k,
                                                           nullptr, d_labels, S(stream), s->reserve_cus,
                                                           s->tab.n_hot ? s->tab.d_work + kCells + 1 : nullptr));
@@ -1430,15 +1447,21 @@ extern "C" int kmg_lloyd_update(kmg_lloyd *s, const int64_t *d_acc4, void *strea
 }
 
 // Assign, then update (include/kmeans_hip.h).  With a bound image the update rides on the last launch of the cube pass.
-extern "C" int kmg_lloyd_assign_update(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_t *d_labels, int64_t *d_acc4,
-                                       int do_update, void *stream)
+static int assign_update_impl(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_t *d_labels, int64_t *d_acc4,
+                              int do_update, void *stream, bool defer_entries)
 {
     if (!s || !d_rgba || n == 0 || !d_acc4) return fail(KMG_ERR_INVALID_ARGUMENT, "bad assign_update arguments");
     HIP_TRY(hipSetDevice(s->p->device));
-    if (table_bound(s, d_rgba, n)) return table_assign(s, d_rgba, n, d_labels, d_acc4, 1u, S(stream), do_update != 0);
+    if (table_bound(s, d_rgba, n)) return table_assign(s, d_rgba, n, d_labels, d_acc4, 1u, S(stream), do_update != 0, defer_entries);
     int rc;
     if ((rc = kmg_lloyd_assign_accumulate(s, d_rgba, n, d_labels, d_acc4, stream)) != KMG_OK) return rc;
     return do_update ? kmg_lloyd_update(s, d_acc4, stream) : KMG_OK;
+}
+
+extern "C" int kmg_lloyd_assign_update(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_t *d_labels, int64_t *d_acc4,
+                                       int do_update, void *stream)
+{
+    return assign_update_impl(s, d_rgba, n, d_labels, d_acc4, do_update, stream, false);
 }
 
 // One Lloyd iteration with the label pass taken off the critical path (modules.rs:769-800: update, then
@@ -1505,6 +1528,7 @@ extern "C" int kmg_lloyd_iterate(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n
         return rc;
     }
     t.tables_valid = true;
+    t.entries_valid = true;
     HIP_TRY(hipEventRecord(s->ev_cube, st));
     HIP_TRY(hipStreamWaitEvent(s->side, s->ev_cube, 0));
     PROF_LAUNCH(s, KMG_K_LABELS, s->side, launch_labels((const uint32_t *)d_rgba, n, t.d_colour_labels, t.d_sub, s->k, nullptr,
@@ -1559,7 +1583,9 @@ extern "C" int kmg_lloyd_run(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, ui
         const bool may_stop_here = it >= 0 && checked((uint32_t)it);          // a check follows this pass
         const bool last = it + 1 >= (long)o.max_iterations;
         const bool fuse = !may_stop_here && !last;
-        return kmg_lloyd_assign_update(s, d_rgba, n, loop_labels, s->d_acc, fuse ? 1 : 0, stream);
+        // (with the table the loop needs only the sums: the pair entries of the label pass are derived once, before the
+        // final label pass -- 19 us per iteration at k = 256)
+        return assign_update_impl(s, d_rgba, n, loop_labels, s->d_acc, fuse ? 1 : 0, stream, true);
     };
     if ((rc = pass(-1)) != KMG_OK) return rc;
     uint32_t it = 0;
@@ -1577,6 +1603,7 @@ extern "C" int kmg_lloyd_run(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, ui
             }
         }
     }
+    if (table && d_labels && (rc = ensure_entries(s, S(stream))) != KMG_OK) return rc;
     if (table && d_labels)   // the label tables of the last pass belong to the final centroids
         PROF_LAUNCH(s, KMG_K_LABELS, S(stream), launch_labels((const uint32_t *)d_rgba, n, s->tab.d_colour_labels,
                                                               s->tab.d_sub, s->k, nullptr, d_labels, S(stream), s->reserve_cus,

@@ -723,6 +723,7 @@ __global__ __launch_bounds__(kBlock) void k_cube_pairs(const uint32_t *__restric
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < 4u * k; i += kBlock) sums[i] = 0;      // ready for the next pass
     }
+    if (flags & kCubeNoEntries) return;                             // the tail only (one workgroup): launch_cube_entries comes later
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
     const uint32_t n_waves = gridDim.x * (kBlock / 64);
@@ -807,12 +808,25 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
         if (!(flags & 0xC00u))                                                                                              \
             hipLaunchKernelGGL((k_cube_scan<T, S>), dim3(g_scan), dim3(kBlock), lds_scan, st, hist, sub_agg, work, cent, k, \
                                lab_table, masks, cw, (T *)colour_labels, sub_table, sums, n_rows, repl, flags);             \
-        hipLaunchKernelGGL((k_cube_pairs<T>), dim3(g_pairs), dim3(kBlock), 0, st, work, S ? 1 : 0, occ_bits,               \
-                           (const T *)colour_labels, sub_table, flags, sums, k, tl);                                        \
+        hipLaunchKernelGGL((k_cube_pairs<T>), dim3((flags & kCubeNoEntries) ? 1u : g_pairs), dim3(kBlock), 0, st, work,   \
+                           S ? 1 : 0, occ_bits, (const T *)colour_labels, sub_table, flags, sums, k, tl);                   \
     } while (0)
     if (k <= 256) { if (with_sums) KMG_CUBE(uint8_t, true); else KMG_CUBE(uint8_t, false); }
     else          { if (with_sums) KMG_CUBE(uint16_t, true); else KMG_CUBE(uint16_t, false); }
 #undef KMG_CUBE
+    return hipGetLastError();
+}
+
+hipError_t launch_cube_entries(const uint32_t *work, const uint8_t *occ_bits, const void *colour_labels, uint16_t *sub_table,
+                               uint32_t k, hipStream_t st)
+{
+    static const uint32_t g_pairs = env_grid("KMG_PAIRS_GRID", kCubeGrid);
+    if (k <= 256)
+        hipLaunchKernelGGL((k_cube_pairs<uint8_t>), dim3(g_pairs), dim3(kBlock), 0, st, work, work ? 1 : 0, occ_bits,
+                           (const uint8_t *)colour_labels, sub_table, 0u, (int64_t *)nullptr, k, CubeTail());
+    else
+        hipLaunchKernelGGL((k_cube_pairs<uint16_t>), dim3(g_pairs), dim3(kBlock), 0, st, work, work ? 1 : 0, occ_bits,
+                           (const uint16_t *)colour_labels, sub_table, 0u, (int64_t *)nullptr, k, CubeTail());
     return hipGetLastError();
 }
 

@@ -168,6 +168,11 @@ hipError_t launch_init_pass_cells(const uint32_t *tie, const uint8_t *occ_bits, 
 // stats (optional, 6 x u64, zero on entry): single-candidate cells, other cells, sub-cells decided by their
 // bounds, sub-cells scanned, candidates summed over the scanned sub-cells, cells beyond the listing limit.
 size_t cube_work_bytes();
+// flags bit 16: the pass leaves the cells' pair entries / summaries (what the LABEL pass reads first) to a later
+// launch_cube_entries -- a loop that only needs the sums (kmg_lloyd_run) pays for them once, after its last iteration
+constexpr uint32_t kCubeNoEntries = 0x10000u;
+hipError_t launch_cube_entries(const uint32_t *work, const uint8_t *occ_bits, const void *colour_labels, uint16_t *sub_table,
+                               uint32_t k, hipStream_t st);
 // What the LAST launch of the cube pass does on top (one of its workgroups, once the sums are complete): hand the k x 4
 // sums over from the pass's own accumulation buffer `sums` (which it leaves zeroed for the next pass -- no memset launch),
 // and -- do_update -- the centroid update of choose_centroid.wgsl:180-206 from them (no k_update launch).
