@@ -73,6 +73,9 @@ KMG_API void kmg_default_options(kmg_options *opt);
 KMG_API int kmg_processor_create(kmg_processor **out);
 KMG_API int kmg_processor_create_ex(const kmg_options *opt, kmg_processor **out);
 KMG_API void kmg_processor_destroy(kmg_processor *p);
+/* Test support: out[0] = device blocks the processor has allocated with hipMalloc so far, out[1] = blocks it has handed out
+ * again (colour tables, workspaces and output-pass scratch of finished objects are kept and reused).                 */
+KMG_API int kmg_debug_block_counts(kmg_processor *p, uint64_t out[2]);
 
 /* ---- ImageProcessor::palette  (core/src/lib.rs:67-77, 255-286) -------------------------
  * out_rgba: capacity color_count*4 bytes; *out_count receives the number of colours

@@ -106,6 +106,7 @@ struct kmg_processor {
     // image on a warm processor -- a frame loop, the two images per rank of BASELINE config 4 -- binds without a hipMalloc
     // (nine of them cost 1.4 ms per 8192^2 image in round 2, three times the kernels of the binding).
     std::vector<std::pair<void *, size_t>> idle_arenas;
+    uint64_t n_block_malloc = 0, n_block_reuse = 0;   // block_take: fresh hipMallocs / blocks handed out again (kmg_debug_block_counts)
     hipMemPool_t pool;       // private stream-ordered pool for per-call scratch (never the device's default pool)
 };
 
@@ -115,15 +116,20 @@ static hipError_t block_take(kmg_processor *p, size_t bytes, void **ptr, size_t 
     {
         std::lock_guard<std::mutex> lock(p->mu);
         size_t best = p->idle_arenas.size();
+        // (not a block more than four times too large: a 256 MiB distance map must not end up as a 20 MiB workspace)
+        const size_t too_large = 4u * bytes + ((size_t)1 << 20);
         for (size_t i = 0; i < p->idle_arenas.size(); ++i)
-            if (p->idle_arenas[i].second >= bytes && (best == p->idle_arenas.size() || p->idle_arenas[i].second < p->idle_arenas[best].second))
+            if (p->idle_arenas[i].second >= bytes && p->idle_arenas[i].second <= too_large &&
+                (best == p->idle_arenas.size() || p->idle_arenas[i].second < p->idle_arenas[best].second))
                 best = i;
         if (best != p->idle_arenas.size()) {
             *ptr = p->idle_arenas[best].first;
             *cap = p->idle_arenas[best].second;
             p->idle_arenas.erase(p->idle_arenas.begin() + (long)best);
+            p->n_block_reuse += 1;
             return hipSuccess;
         }
+        p->n_block_malloc += 1;
     }
     const hipError_t e = hipMalloc(ptr, bytes);
     if (e == hipSuccess) *cap = bytes;
@@ -276,6 +282,15 @@ extern "C" int kmg_processor_create_ex(const kmg_options *opt, kmg_processor **o
         return fail(KMG_ERR_HIP, "processor setup failed: %s", hipGetErrorString(e1));
     }
     *out = p;
+    return KMG_OK;
+}
+
+extern "C" int kmg_debug_block_counts(kmg_processor *p, uint64_t out[2])
+{
+    if (!p || !out) return fail(KMG_ERR_INVALID_ARGUMENT, "bad block_counts arguments");
+    std::lock_guard<std::mutex> lock(p->mu);
+    out[0] = p->n_block_malloc;
+    out[1] = p->n_block_reuse;
     return KMG_OK;
 }
 

@@ -82,7 +82,7 @@ SYMBOLS = [
     "kmg_lloyd_unbind_image", "kmg_lloyd_prepare", "kmg_debug_check_table", "kmg_debug_table_stats", "kmg_debug_check_pairs", "kmg_debug_check_dither_masks", "kmg_debug_check_meld_masks", "kmg_kernel_name",
     "kmg_lloyd_profile", "kmg_lloyd_profile_read",
     "kmg_lloyd_update", "kmg_lloyd_assign_update", "kmg_lloyd_set_cell_share", "kmg_lloyd_labels_from_tables",
-    "kmg_lloyd_table_buffers", "kmg_lloyd_histogram_buffer", "kmg_lloyd_rebuild_from_histogram", "kmg_lloyd_converged_count", "kmg_lloyd_iterate", "kmg_lloyd_flush", "kmg_lloyd_run", "kmg_dev_apply",
+    "kmg_lloyd_table_buffers", "kmg_lloyd_histogram_buffer", "kmg_lloyd_rebuild_from_histogram", "kmg_debug_block_counts", "kmg_lloyd_converged_count", "kmg_lloyd_iterate", "kmg_lloyd_flush", "kmg_lloyd_run", "kmg_dev_apply",
     "kmg_dither_threshold",
 ]
 
@@ -156,6 +156,7 @@ def lib():
     L.kmg_lloyd_assign_update.argtypes = [vp, u8p, C.c_uint64, u32p, i64p, C.c_int, vp]
     L.kmg_lloyd_set_cell_share.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
     L.kmg_lloyd_labels_from_tables.argtypes = [vp, u8p, C.c_uint64, u32p, vp]
+    L.kmg_debug_block_counts.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.kmg_lloyd_histogram_buffer.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     L.kmg_lloyd_rebuild_from_histogram.argtypes = [vp, C.c_uint64, vp]
     L.kmg_lloyd_table_buffers.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
@@ -304,6 +305,12 @@ class ImageProcessor:
         c = np.ascontiguousarray(centroids4, np.float32).reshape(-1, 4)
         _check(lib().kmg_dev_apply(self._h, C.c_void_p(d_rgba), width, rows, row0, _np_ptr(c), c.shape[0],
                                    int(mode), C.c_void_p(d_out), C.c_void_p(stream)))
+
+    def debug_block_counts(self):
+        """(device blocks allocated with hipMalloc so far, blocks handed out again)"""
+        out = (C.c_uint64 * 2)()
+        _check(lib().kmg_debug_block_counts(self._h, out))
+        return int(out[0]), int(out[1])
 
     def debug_check_dither_masks(self, centroids4, stream=0):
         """exhaustive check of the pruned dither pass's candidate masks; returns the violation count"""

@@ -971,3 +971,37 @@ def test_cell_sharded_cube_pass_equals_unsharded(torch_cuda, oracle, tokyo, monk
     for s, *_rest in ranks:
         s.close()
     p.close()
+
+
+def test_second_image_binds_without_a_hipmalloc(torch_cuda, oracle, monkeypatch):
+    """The processor keeps the device blocks of finished kmg_lloyd objects (colour table, workspace, init tables): a second
+    image on a warm processor -- a frame loop, the second image of a rank's share of a batch -- initialises, binds and runs
+    without a single fresh block, and gives the same result as on a cold processor."""
+    import kmeans_gpu_amd as kg
+    torch = torch_cuda
+    st = _stream(torch)
+    monkeypatch.setenv("KMG_STRATEGY", "table")
+    w, h, k = 640, 480, 32
+    imgs = [_blobs(np.random.default_rng(s), w * h, 30, sigma=20.0) for s in (1, 2)]
+    p = kg.ImageProcessor(shrink_max_dim=0)
+    results = []
+    counts = []
+    for img in imgs + imgs[:1]:
+        d = _dev(torch, img)
+        labels = torch.zeros(w * h, dtype=torch.int32, device="cuda")
+        s = kg.Lloyd(p, k)
+        s.init_centroids(d.data_ptr(), w, h, st)
+        it = s.run(d.data_ptr(), w * h, labels.data_ptr(), st)
+        results.append((it, s.get_centroids(st).copy(), labels.cpu().numpy().copy()))
+        s.close()
+        counts.append(p.debug_block_counts())
+    assert counts[0][0] > 0 and counts[0][1] == 0                   # cold: fresh blocks only
+    assert counts[1][0] == counts[0][0] and counts[2][0] == counts[0][0], counts     # warm: not one more hipMalloc
+    assert counts[2][1] > counts[1][1] > 0
+    assert results[0][0] == results[2][0] and np.array_equal(results[0][1].view(np.uint32), results[2][1].view(np.uint32))
+    assert np.array_equal(results[0][2], results[2][2])
+    lab = oracle.rgb_to_lab(imgs[1].reshape(h, w, 4))
+    want_c, want_l, want_it = oracle.lloyd(lab, oracle.init_centroids(lab, w, h, k))
+    assert results[1][0] == want_it and np.array_equal(results[1][1].view(np.uint32), want_c.view(np.uint32))
+    assert np.array_equal(results[1][2].view(np.uint32), want_l)
+    p.close()
