@@ -590,7 +590,7 @@ static int bind_image_impl(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, void
     if (!t.d_hist) {
         // one block for all tables, from the processor's idle blocks when one fits (no hipMalloc on a warm processor)
         const size_t sizes[10] = {sizeof(uint32_t) << 24, sizeof(int64_t) * 4ull * kCells, sizeof(int64_t) * 4ull * kSubCells,
-                                  (size_t)1 << 21, cube_work_bytes(), sizeof(uint64_t) * (size_t)kCells * words,
+                                  (size_t)1 << 21, cube_work_bytes(), cube_masks_bytes(s->k),
                                   sizeof(uint32_t) * kWorkWords, (size_t)(s->k <= 256 ? 1 : 2) << 24, sub_table_bytes(),
                                   sizeof(uint32_t) * (kCells + 1)};
         size_t need = 0;
@@ -709,9 +709,8 @@ extern "C" int kmg_debug_check_table(kmg_lloyd *s, uint64_t out[3], void *stream
     HIP_TRY(hipSetDevice(s->p->device));
     int rc;
     if ((rc = ensure_bounds(s->p, S(stream))) != KMG_OK) return rc;
-    const uint32_t words = mask_words(s->k);
     DevBuf masks, viol, labels, sub, cwork;
-    HIP_TRY(masks.alloc(sizeof(uint64_t) * (size_t)kCells * words));
+    HIP_TRY(masks.alloc(cube_masks_bytes(s->k)));
     HIP_TRY(cwork.alloc(cube_work_bytes()));
     HIP_TRY(viol.alloc(3 * sizeof(unsigned long long)));
     HIP_TRY(labels.alloc((size_t)(s->k <= 256 ? 1 : 2) << 24));
@@ -1671,7 +1670,7 @@ extern "C" int kmg_dev_apply(kmg_processor *p, const uint8_t *d_rgba, uint32_t w
     const size_t masks_bytes = sizeof(uint64_t) * (size_t)kCells * mask_words(k) * (dither_pruned ? 16u : 1u);
     size_t need = ArenaGuard::padded(tables_bytes);
     if (meld_masks_pay || dither_pruned) need += ArenaGuard::padded(masks_bytes) + ArenaGuard::padded(kListTableBytes);
-    if (replace_table) need += ArenaGuard::padded(labels_bytes) + ArenaGuard::padded(sub_bytes) + ArenaGuard::padded(masks_bytes) +
+    if (replace_table) need += ArenaGuard::padded(labels_bytes) + ArenaGuard::padded(sub_bytes) + ArenaGuard::padded(cube_masks_bytes(k)) +
                                ArenaGuard::padded(cube_work_bytes());
     ArenaGuard arena;
     hipError_t e = arena.acquire(p, need);
@@ -1708,7 +1707,7 @@ extern "C" int kmg_dev_apply(kmg_processor *p, const uint8_t *d_rgba, uint32_t w
         if ((rc = ensure_bounds(p, S(stream))) == KMG_OK) {
             void *colour_labels = arena.take(labels_bytes);
             uint16_t *sub = (uint16_t *)arena.take(sub_bytes);
-            uint64_t *m = (uint64_t *)arena.take(masks_bytes);
+            uint64_t *m = (uint64_t *)arena.take(cube_masks_bytes(k));
             void *cwork = arena.take(cube_work_bytes());
             e = launch_cube(nullptr, nullptr, nullptr, nullptr, nullptr, p->d_bounds, p->d_sub_bounds, d_cent, k, p->d_lab_table,
                             m, cwork, colour_labels, sub, nullptr, 0, 0u, nullptr, S(stream));

@@ -30,6 +30,12 @@ namespace kmg {
 namespace {
 
 constexpr uint32_t kMaxListed = 32;       // candidates per cell the sub-cell stage handles (4 rounds of 8 lanes)
+// Cells with more candidates (photographs: the centroids crowd into the few dark cells that hold most of the pixels -- 866
+// cells of the test photograph at k = 256, up to 215 candidates) are bounded per sub-cell all the same, from a list of up to
+// kMaxLong candidates; their per-sub-cell candidate sets leave as k-bit masks behind the cell masks (kmg_table.h
+// cube_masks_bytes), and the scan kernel visits a sub-cell's own set instead of every candidate of the cell.  k <= 256.
+constexpr uint32_t kMaxLong = 256;
+constexpr uint32_t kLongFlag = 0x200u;    // CellWork::scan_set: the cell's sub-cells have masks of their own
 
 __device__ __forceinline__ uint32_t sel3(uint32_t i, uint32_t x0, uint32_t x1, uint32_t x2)
 {
@@ -193,6 +199,60 @@ __device__ __forceinline__ void flush_bins(const unsigned long long *bins, uint3
     }
 }
 
+// The sub-cell stage of a cell with more than kMaxListed candidates (k_cube_stage, "long list"): the candidates' mask words
+// wait in s_masks; on return s_sub[4 s + w] = word w of the candidates sub-cell s keeps, and lane s < 8 gets
+// (number of candidates sub-cell s keeps, the candidate itself if it is one).
+__device__ __forceinline__ uint2 long_list_stage(const float4 *s_cent, const unsigned long long *s_masks, uint16_t *s_long,
+                                              unsigned long long *s_sub, float4 sb0, float4 sb1, float4 sb2, uint32_t npop,
+                                              uint32_t words, uint64_t *sub_masks_cell)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t sub_of_lane = lane >> 3, cand_of_lane = lane & 7u;
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < words; ++w) {
+        const unsigned long long m = uniform_u64(s_masks[w]);
+        if ((m >> lane) & 1ull) s_long[base + bits_below_lane(m)] = (uint16_t)(w * 64u + lane);
+        base += (uint32_t)__builtin_popcountll(m);
+    }
+    if (lane < 32u) s_sub[lane] = 0ull;
+    __builtin_amdgcn_wave_barrier();
+    CellBounds sb;
+    sb.L0 = sb0.x; sb.L1 = sb0.y; sb.a0 = sb0.z; sb.a1 = sb0.w;
+    sb.b0 = sb1.x; sb.b1 = sb1.y; sb.C0 = sb1.z; sb.C1 = sb1.w;
+    sb.wC0 = sb2.x; sb.wC1 = sb2.y; sb.wH0 = sb2.z; sb.wH1 = sb2.w;
+    // two sweeps, eight candidates per round: the threshold of a sub-cell needs every candidate's upper bound first
+    const uint32_t rounds = (npop + 7u) >> 3;
+    float Usub = 3.0e38f;
+    for (uint32_t r = 0; r < rounds; ++r) {
+        const uint32_t pos = r * 8u + cand_of_lane;
+        if (pos < npop) {
+            const float4 c = s_cent[s_long[pos]];
+            Usub = fminf(Usub, key_range(sb, c.x, c.y, c.z, c.w).hi);
+        }
+    }
+    const float Us = mask_threshold(group8_min(Usub));
+    for (uint32_t r = 0; r < rounds; ++r) {
+        const uint32_t pos = r * 8u + cand_of_lane;
+        if (pos < npop) {
+            const uint32_t j = s_long[pos];
+            const float4 c = s_cent[j];
+            if (key_range(sb, c.x, c.y, c.z, c.w).lo <= Us) atomicOr(&s_sub[sub_of_lane * 4u + (j >> 6)], 1ull << (j & 63u));
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // lane 4 s + w holds word w of sub-cell s: stored (the scan kernel reads them), counted, and the single survivor named
+    const unsigned long long mine = lane < 32u ? s_sub[lane] : 0ull;
+    if (lane < 32u) sub_masks_cell[lane] = mine;
+    uint32_t cnt = (uint32_t)__builtin_popcountll(mine);
+    uint32_t one = mine ? (lane & 3u) * 64u + (uint32_t)__builtin_ctzll(mine) : 0u;
+    cnt += dpp_u32<kDppXor1>(cnt); one += dpp_u32<kDppXor1>(one);
+    cnt += dpp_u32<kDppXor2>(cnt); one += dpp_u32<kDppXor2>(one);      // every lane of the four: the sub-cell's count / its one candidate
+    uint2 r;
+    r.x = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane * 4u) << 2), (int)cnt);      // -> lane s < 8
+    r.y = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane * 4u) << 2), (int)one);
+    return r;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -230,6 +290,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
     const uint32_t n_bins = SUMS ? 4u * k : 0u;
     uint32_t *s_list_all = reinterpret_cast<uint32_t *>(bins + n_bins);
     unsigned long long *s_masks_all = reinterpret_cast<unsigned long long *>(s_list_all + (kBlock / 64) * kMaxListed);
+    // long lists (k <= 256): [4 waves][kMaxLong] u16 candidate list, [4 waves][8 sub-cells][4 words] u64 masks
+    unsigned long long *s_sub_all = s_masks_all + (kBlock / 64) * words;
+    uint16_t *s_long_all = reinterpret_cast<uint16_t *>(s_sub_all + (kBlock / 64) * 32u);
 
     for (uint32_t i = threadIdx.x; i < kpad; i += kBlock) {
         float4 v = make_float4(1.0e18f, 0.0f, 0.0f, 0.0f);       // key ~ 1e36: never a candidate
@@ -243,6 +306,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
     const uint32_t wv = threadIdx.x >> 6;
     uint32_t *s_list = s_list_all + wv * kMaxListed;
     unsigned long long *s_masks = s_masks_all + wv * words;
+    unsigned long long *s_sub = s_sub_all + wv * 32u;
+    uint16_t *s_long = s_long_all + wv * kMaxLong;
+    uint64_t *sub_masks_out = masks_out + (uint64_t)kCells * ((k + 63u) / 64u);      // [cell][8][4], k <= 256
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / 64) + wv);
     const uint32_t n_waves = gridDim.x * (kBlock / 64);
     const uint32_t sub_of_lane = lane >> 3, cand_of_lane = lane & 7u;
@@ -365,6 +431,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         const bool listed = npop <= kMaxListed && !(flags & 0x1000u);
         uint32_t my_cand = 0;                                       // lane p < npop: the p-th candidate
         unsigned long long br[4] = {0ull, 0ull, 0ull, 0ull};       // round r: bit 8 s + c = sub-cell s keeps candidate 8 r + c
+        bool long_cell = false;
+        uint32_t long_cnt = 0u, long_one = 0u;                      // long list: lane s < 8 = candidates sub-cell s keeps / the one if it is one
         if (listed) {
             uint32_t base = 0;
             if (words <= 4u) {
@@ -412,6 +480,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
             for (uint32_t r = 0; r < 4u; ++r)
                 if (r < rounds) br[r] = __ballot(lo[r] <= Us);
             if (lane < 4u) cw->br[lane] = lane == 0u ? br[0] : (lane == 1u ? br[1] : (lane == 2u ? br[2] : br[3]));
+        } else if (words <= 4u && npop <= kMaxLong && !(flags & 0x1000u)) {
+            // long list (rare on noise, the heavy cells of a photograph): long_list_stage
+            long_cell = true;
+#pragma unroll
+            for (uint32_t w = 0; w < 4u; ++w)
+                if (w < words && lane == 0u) s_masks[w] = mw[w];
+            __builtin_amdgcn_wave_barrier();
+            const uint2 lr = long_list_stage(s_cent, s_masks, s_long, s_sub, sb0, sb1, sb2, npop, words, sub_masks_out + (uint64_t)cell * 32u);
+            long_cnt = lr.x;
+            long_one = lr.y;
+            st_unlisted += 1;
         } else {
             st_unlisted += 1;
         }
@@ -424,11 +503,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
             for (uint32_t r = 0; r < 4u; ++r) sm_v |= ((uint32_t)(br[r] >> (8u * lane)) & 0xFFu) << (8u * r);
         }
         const bool occupied_v = lane < 8u && (SUMS ? scnt != 0 : true);
-        const bool decided_v = occupied_v && listed && __builtin_popcount(sm_v) == 1;
+        const bool decided_v = occupied_v && ((listed && __builtin_popcount(sm_v) == 1) || (long_cell && long_cnt == 1u));
         const uint32_t decided_set = (uint32_t)__ballot(decided_v);
         const uint32_t scan_set = (flags & 0x400u) ? 0u : (uint32_t)__ballot(occupied_v && !decided_v);
         // label of a decided sub-cell, at lane s
-        const uint32_t X_v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((sm_v ? (uint32_t)__builtin_ctz(sm_v) : 0u)) << 2), (int)my_cand);
+        uint32_t X_v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((sm_v ? (uint32_t)__builtin_ctz(sm_v) : 0u)) << 2), (int)my_cand);
+        if (long_cell) X_v = long_one;
         {
             // its 64 labels: lane l owns the colours 8 l .. 8 l + 7 of the cell (sub-cell l >> 3), one store
             const uint32_t X = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane >> 3) << 2), (int)X_v);
@@ -453,12 +533,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         st_decided += (uint32_t)__builtin_popcount(decided_set);
         st_scanned += (uint32_t)__builtin_popcount(scan_set);
         if (stats) {
-            const uint32_t c = (scan_set >> (lane & 7u)) & 1u ? (listed ? (uint32_t)__builtin_popcount(sm_v) : npop) : 0u;
+            const uint32_t c = (scan_set >> (lane & 7u)) & 1u ? (listed ? (uint32_t)__builtin_popcount(sm_v) : (long_cell ? long_cnt : npop)) : 0u;
             st_cands += wave_add_u32(lane < 8u ? c : 0u);
         }
         if (lane == 0u) {
             cw->npop = npop;
-            cw->scan_set = scan_set | (listed ? 0x100u : 0u);
+            cw->scan_set = scan_set | (listed ? 0x100u : 0u) | (long_cell ? kLongFlag : 0u);
             if (sizeof(LabelT) == 1) *pair_entry_ptr = kPairPending;
         }
     }
@@ -523,6 +603,7 @@ __global__ __launch_bounds__(kBlock) void k_cube_scan(const uint32_t *__restrict
         uint32_t scan_set = __builtin_amdgcn_readfirstlane(cw->scan_set);
         if ((scan_set & 0xFFu) == 0u) continue;                     // one candidate, or every sub-cell decided
         const bool listed = (scan_set & 0x100u) != 0u;
+        const bool long_cell = (scan_set & kLongFlag) != 0u;
         scan_set &= 0xFFu;
         const uint32_t npop = __builtin_amdgcn_readfirstlane(cw->npop);
         const uint32_t my_cand = listed ? (uint32_t)cw->list[lane & (kMaxListed - 1u)] : 0u;   // lane p: the p-th candidate ...
@@ -530,6 +611,7 @@ __global__ __launch_bounds__(kBlock) void k_cube_scan(const uint32_t *__restrict
         const unsigned long long br2 = listed ? uniform_u64(cw->br[2]) : 0ull, br3 = listed ? uniform_u64(cw->br[3]) : 0ull;
         const long long sagg = SUMS ? sub_agg[(uint64_t)cell * 32u + (lane & 31u)] : 0;      // lane 4 s + j: sum j of sub-cell s
         const uint64_t *cmask = masks + (uint64_t)cell * ((k + 63u) / 64u);
+        const uint64_t *smask = masks + (uint64_t)kCells * ((k + 63u) / 64u) + (uint64_t)cell * 32u;   // long cells: [8][4]
         uint16_t *sub = sub_table + cell * 8u;
         LabelT *cell_labels = colour_labels + (uint64_t)cell * kCellColours;
         auto submask_of = [&](uint32_t s) {                        // bit p = the sub-cell keeps candidate p of the list
@@ -611,8 +693,12 @@ __global__ __launch_bounds__(kBlock) void k_cube_scan(const uint32_t *__restrict
             } else {
                 // more than kMaxListed candidates (a handful of cells): every candidate of the cell, from the masks
                 float best0 = 1.0e10f, second0 = 1.0e10f, best1 = 1.0e10f, second1 = 1.0e10f;
+                // (long cells: the candidates of the two sub-cells of this step, not of the whole cell)
+                auto cand_word = [&](uint32_t w) {
+                    return long_cell ? uniform_u64(smask[s0 * 4u + w] | (s1 < 8u ? smask[s1 * 4u + w] : 0ull)) : uniform_u64(cmask[w]);
+                };
                 for (uint32_t w = 0; w < (k + 63u) / 64u; ++w) {
-                    for (unsigned long long m = uniform_u64(cmask[w]); m; m &= m - 1ull) {
+                    for (unsigned long long m = cand_word(w); m; m &= m - 1ull) {
                         const uint32_t j = w * 64u + (uint32_t)__builtin_ctzll(m);
                         const float4 c = s_cent[j];
                         const float d0 = cie94_key(pt0, c.x, c.y, c.z, c.w), d1 = cie94_key(pt1, c.x, c.y, c.z, c.w);
@@ -628,7 +714,7 @@ __global__ __launch_bounds__(kBlock) void k_cube_scan(const uint32_t *__restrict
                     float lb0 = 100000.0f, lb1 = 100000.0f;
                     uint32_t li0 = 0u, li1 = 0u;
                     for (uint32_t w = 0; w < (k + 63u) / 64u; ++w) {
-                        for (unsigned long long m = uniform_u64(cmask[w]); m; m &= m - 1ull) {
+                        for (unsigned long long m = cand_word(w); m; m &= m - 1ull) {
                             const uint32_t j = w * 64u + (uint32_t)__builtin_ctzll(m);
                             const float4 c = s_cent[j];
                             if (near0 && cie94_key(pt0, c.x, c.y, c.z, c.w) <= thr0) {
@@ -782,7 +868,8 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
     const uint32_t repl = with_sums ? cube_replicas(k) : 1u;
     if (const char *e = getenv("KMG_CUBE_FLAGS")) flags |= (uint32_t)strtoul(e, nullptr, 0) & 0xFF00u;
     const size_t lds_stage = sizeof(float4) * kpad + (with_sums ? sizeof(unsigned long long) * 4ull * k : 0) +
-                             sizeof(uint32_t) * (kBlock / 64) * kMaxListed + sizeof(unsigned long long) * (kBlock / 64) * (kpad / 64u);
+                             sizeof(uint32_t) * (kBlock / 64) * kMaxListed + sizeof(unsigned long long) * (kBlock / 64) * (kpad / 64u) +
+                             (k <= 256 ? (kBlock / 64) * (32u * sizeof(unsigned long long) + kMaxLong * sizeof(uint16_t)) : 0u);
     const size_t lds_scan = sizeof(float4) * kpad + (with_sums ? sizeof(unsigned long long) * (4ull * k + 4ull) * repl : 0) +
                             sizeof(float4) * (kBlock / 64) * kMaxListed + (k <= 256 ? 1u : 2u) * (kBlock / 64) * kCellColours;
     {

@@ -68,6 +68,12 @@ __host__ __device__ inline void index_to_rgb(uint32_t idx, uint32_t &r, uint32_t
 }
 
 inline uint32_t mask_words(uint32_t k) { return (k + 63u) / 64u; }
+// bytes of the cube pass's `masks` buffer: the cell candidate masks (kCells x mask_words(k) u64) and, for k <= 256, behind
+// them the per-SUB-CELL candidate masks (kCells x 8 x 4 u64) of the cells with more candidates than the sub-cell stage lists
+inline size_t cube_masks_bytes(uint32_t k)
+{
+    return sizeof(uint64_t) * ((size_t)kCells * mask_words(k) + (k <= 256 ? (size_t)kCells * 8u * 4u : 0u));
+}
 
 // ---- pair entries (k <= 256): one u32 per 8x8x8 cell, all 32768 of them live in LDS during the
 // label pass.  [label A:8][label B:8][direction:7][tlo:6][w:3]
