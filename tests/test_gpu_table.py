@@ -1005,3 +1005,40 @@ def test_second_image_binds_without_a_hipmalloc(torch_cuda, oracle, monkeypatch)
     assert results[1][0] == want_it and np.array_equal(results[1][1].view(np.uint32), want_c.view(np.uint32))
     assert np.array_equal(results[1][2].view(np.uint32), want_l)
     p.close()
+
+
+def test_crowded_centroids_take_the_long_candidate_lists(torch_cuda, oracle, monkeypatch):
+    """k = 256 centroids crowded into the dark corner of the cube (what a photograph does to k-means): the cells there have
+    far more than 32 candidates, so the stage kernel bounds them per sub-cell from its long list (long_list_stage) and the
+    scan kernel visits the sub-cells' own sets.  Exhaustive check of the cube pass over all 2^24 colours, and labels / sums /
+    two iterations of an image drawn from that corner against the oracle."""
+    import kmeans_gpu_amd as kg
+    torch = torch_cuda
+    st = _stream(torch)
+    monkeypatch.setenv("KMG_STRATEGY", "table")
+    rng = np.random.default_rng(77)
+    k, n = 256, 400_000
+    pal = np.zeros((k, 4), np.uint8); pal[:, :3] = rng.integers(0, 48, (k, 3)); pal[:, 3] = 255
+    cent = oracle.centroids4(oracle.rgb_to_lab(pal))
+    img = np.zeros((n, 4), np.uint8); img[:, :3] = rng.integers(0, 64, (n, 3)); img[:, 3] = 255
+    d = _dev(torch, img)
+    p = kg.ImageProcessor(shrink_max_dim=0)
+    s = kg.Lloyd(p, k)
+    s.set_centroids(cent, st)
+    assert s.prepare(d.data_ptr(), n, True, st) == "table"
+    labels = torch.zeros(n, dtype=torch.int32, device="cuda")
+    acc = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
+    for it in range(2):
+        s.assign_accumulate(d.data_ptr(), n, labels.data_ptr(), acc.data_ptr(), st)
+        torch.cuda.synchronize()
+        want_l, want_a = oracle.assign_accumulate_rgba(img, cent)
+        assert np.array_equal(labels.cpu().numpy().view(np.uint32), want_l), it
+        assert np.array_equal(acc.cpu().numpy(), want_a), it
+        stats = s.debug_table_stats(st)
+        assert stats["max_candidates"] > 32 and stats["cells_unlisted"] > 0, stats     # the long path really ran
+        assert s.debug_check_table(st) == (0, 0, 0)
+        assert s.debug_check_pairs(st)[0] == 0
+        s.update(acc.data_ptr(), st)
+        cent, _ = oracle.finalize(want_a, cent)
+    s.close()
+    p.close()
