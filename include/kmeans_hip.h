@@ -76,6 +76,10 @@ KMG_API void kmg_processor_destroy(kmg_processor *p);
 /* Test support: out[0] = device blocks the processor has allocated with hipMalloc so far, out[1] = blocks it has handed out
  * again (colour tables, workspaces and output-pass scratch of finished objects are kept and reused).                 */
 KMG_API int kmg_debug_block_counts(kmg_processor *p, uint64_t out[2]);
+/* Test support: the meld pass turns a linear channel value into its sRGB8 byte with a 255-entry threshold table made on
+ * the device by the encode of lab_to_rgb.wgsl:21-35 itself; *mismatches = the float values (every bit pattern, NaN aside)
+ * for which table and encode give different bytes (0 = the table IS the encode).                                     */
+KMG_API int kmg_debug_encode_table_check(kmg_processor *p, uint64_t *mismatches);
 
 /* ---- ImageProcessor::palette  (core/src/lib.rs:67-77, 255-286) -------------------------
  * out_rgba: capacity color_count*4 bytes; *out_count receives the number of colours

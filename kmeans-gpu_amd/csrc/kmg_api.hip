@@ -95,7 +95,7 @@ extern "C" void kmg_default_options(kmg_options *opt)
 struct kmg_processor {
     int device;
     kmg_options opt;
-    float *d_lut;            // 256 x f32: sRGB decode * 100
+    float *d_lut;            // 256 x f32: sRGB decode * 100, then 256 x f32: thresholds of the sRGB8 encode (k_meld)
     std::mutex mu;           // guards the lazily built static tables below
     CellBounds *d_bounds;    // kCells static cell bounds of the colour-table strategy
     CellBounds *d_sub_bounds;   // kSubCells static bounds of the 4x4x4 sub-cells
@@ -274,8 +274,10 @@ extern "C" int kmg_processor_create_ex(const kmg_options *opt, kmg_processor **o
     }
     float lut[256];
     build_srgb_lut100(lut);
-    hipError_t e1 = hipMalloc((void **)&p->d_lut, sizeof lut);
+    hipError_t e1 = hipMalloc((void **)&p->d_lut, 2 * sizeof lut);
     if (e1 == hipSuccess) e1 = hipMemcpy(p->d_lut, lut, sizeof lut, hipMemcpyHostToDevice);
+    if (e1 == hipSuccess) e1 = launch_encode_thresholds(p->d_lut + 256, nullptr);
+    if (e1 == hipSuccess) e1 = hipDeviceSynchronize();
     if (e1 != hipSuccess) {
         if (p->d_lut) (void)hipFree(p->d_lut);
         delete p;
@@ -291,6 +293,20 @@ extern "C" int kmg_debug_block_counts(kmg_processor *p, uint64_t out[2])
     std::lock_guard<std::mutex> lock(p->mu);
     out[0] = p->n_block_malloc;
     out[1] = p->n_block_reuse;
+    return KMG_OK;
+}
+
+extern "C" int kmg_debug_encode_table_check(kmg_processor *p, uint64_t *mismatches)
+{
+    if (!p || !mismatches) return fail(KMG_ERR_INVALID_ARGUMENT, "bad encode_table_check arguments");
+    unsigned long long *d_bad = nullptr, bad = 0;
+    hipError_t e = hipMalloc((void **)&d_bad, sizeof bad);
+    if (e == hipSuccess) e = hipMemset(d_bad, 0, sizeof bad);
+    if (e == hipSuccess) e = launch_encode_check(p->d_lut + 256, d_bad, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost);
+    if (d_bad) (void)hipFree(d_bad);
+    if (e != hipSuccess) return fail(KMG_ERR_HIP, "encode table check failed: %s", hipGetErrorString(e));
+    *mismatches = bad;
     return KMG_OK;
 }
 

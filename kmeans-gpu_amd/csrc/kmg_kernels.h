@@ -55,7 +55,11 @@ hipError_t launch_apply(const uint32_t *rgba, uint32_t w, uint32_t rows, uint32_
                         const Centroid *cent, uint32_t k, const float *lut, const uint32_t *pal,
                         bool dither, float threshold, uint32_t *out, hipStream_t st);
 
-// meld output pass (mix_colors.wgsl main_meld + lab_to_rgb.wgsl)
+// thr[256] (device): the linear-channel thresholds of the 256 sRGB8 output bytes (k_meld), made by the device's own encode
+hipError_t launch_encode_thresholds(float *thr, hipStream_t st);
+// *bad (device, zeroed by the caller) += the floats (all of them, NaN aside) whose table byte is not the encode's byte
+hipError_t launch_encode_check(const float *thr, unsigned long long *bad, hipStream_t st);
+// meld output pass (mix_colors.wgsl main_meld + lab_to_rgb.wgsl); lut: 256 decode entries followed by the 256 thresholds
 // masks: NULL, or per colour cell the candidate centroids of kmg_table.h's launch_meld_candidates
 hipError_t launch_meld(const uint32_t *rgba, uint64_t n, const Centroid *cent, uint32_t k, const float *lut,
                        const uint64_t *masks, uint32_t *out, hipStream_t st);

@@ -679,7 +679,65 @@ __device__ __forceinline__ float lab_finv_dev(float t)
     return t3 > 0.008856f ? t3 : (t - 16.0f / 116.0f) / 7.787f;
 }
 
-__device__ __forceinline__ uint32_t lab_to_rgba8_dev(float L, float a, float b)
+// The byte of a linear channel value c: unorm8(srgb_encode_dev(c)) is a monotone step function of the FLOAT c, so it equals the
+// number of thresholds T[1..255] (T[b] = the smallest float whose byte is >= b) that do not exceed c -- eight steps of a
+// binary search in a 1 KiB table instead of ~120 binary64 operations of pow_inv_2p4.  The table is made on the device, by
+// that very function (k_encode_thresholds), so the bytes are the same by construction.
+__device__ __forceinline__ uint32_t encode_byte(const float *s_thr, float c)
+{
+    uint32_t b = 0;
+#pragma unroll
+    for (uint32_t step = 128u; step > 0u; step >>= 1)
+        b += c >= s_thr[b + step] ? step : 0u;
+    return b;
+}
+
+// thr[0] unused, thr[b] for b = 1 .. 255: the smallest float c with unorm8(srgb_encode_dev(c)) >= b (found by bisection over
+// the bit patterns of the non-negative floats, which order like the values)
+__global__ void k_encode_thresholds(float *__restrict__ thr)
+{
+    const uint32_t b = threadIdx.x;
+    if (b == 0u) { thr[0] = -3.0e38f; return; }
+    uint32_t lo = 0u, hi = 0x3F800000u;                           // byte(0.0) = 0 < b <= 255 = byte(1.0)
+    while (hi - lo > 1u) {
+        const uint32_t mid = lo + (hi - lo) / 2u;
+        if (unorm8(srgb_encode_dev(bits_to_float(mid))) >= b) hi = mid; else lo = mid;
+    }
+    thr[b] = bits_to_float(hi);
+}
+
+hipError_t launch_encode_thresholds(float *thr, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_encode_thresholds, dim3(1), dim3(256), 0, st, thr);
+    return hipGetLastError();
+}
+
+// Test support: over EVERY non-negative float bit pattern up to +inf (2^31 - 2^23 + 1 values) and their negatives, the
+// number of values whose table byte differs from the byte the encode itself gives.
+__global__ __launch_bounds__(kBlock) void k_encode_check(const float *__restrict__ thr, unsigned long long *__restrict__ bad)
+{
+    __shared__ float s_thr[257];
+    s_thr[threadIdx.x] = thr[threadIdx.x];
+    if (threadIdx.x == 0) s_thr[256] = 3.0e38f;
+    __syncthreads();
+    uint32_t mine = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t v = (uint64_t)blockIdx.x * kBlock + threadIdx.x; v <= 0x7F800000ull; v += stride) {
+        const float c = bits_to_float((uint32_t)v);
+        mine += encode_byte(s_thr, c) != unorm8(srgb_encode_dev(c));
+        mine += encode_byte(s_thr, -c) != unorm8(srgb_encode_dev(-c));
+    }
+    if (mine) atomicAdd(bad, (unsigned long long)mine);
+}
+
+hipError_t launch_encode_check(const float *thr, unsigned long long *bad, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_encode_check, dim3(256 * 16), dim3(kBlock), 0, st, thr, bad);
+    return hipGetLastError();
+}
+
+template <bool TABLE>
+__device__ __forceinline__ uint32_t lab_to_rgba8_dev(float L, float a, float b, const float *s_thr = nullptr)
 {
     float y = (L + 16.0f) / 116.0f;
     float x = a / 500.0f + y;
@@ -689,6 +747,7 @@ __device__ __forceinline__ uint32_t lab_to_rgba8_dev(float L, float a, float b)
     const float r = fmaf(-0.4985314f, z, fmaf(-1.5371385f, y, 3.2404542f * x));
     const float g = fmaf(0.0415560f, z, fmaf(1.8760108f, y, -0.9692660f * x));
     const float bl = fmaf(1.0572252f, z, fmaf(-0.2040259f, y, 0.0556434f * x));
+    if (TABLE) return encode_byte(s_thr, r) | (encode_byte(s_thr, g) << 8) | (encode_byte(s_thr, bl) << 16) | 0xFF000000u;
     return unorm8(srgb_encode_dev(r)) | (unorm8(srgb_encode_dev(g)) << 8) | (unorm8(srgb_encode_dev(bl)) << 16) |
            0xFF000000u;
 }
@@ -704,7 +763,10 @@ __global__ __launch_bounds__(kBlock) void k_meld(const uint32_t *__restrict__ rg
     const uint32_t kpad = (k + 3u) & ~3u;
     float4 *s_cent = smem4;
     float *s_lut = reinterpret_cast<float *>(smem4 + kpad);
+    float *s_thr = s_lut + 256;                                    // the encode thresholds live behind the decode table
     s_lut[threadIdx.x] = lut[threadIdx.x];
+    s_thr[threadIdx.x] = lut[256 + threadIdx.x];
+    if (threadIdx.x == 0) s_thr[256] = 3.0e38f;
     stage_centroids(s_cent, cent, k, kpad);
     __syncthreads();
     const uint32_t words = (k + 63u) / 64u;
@@ -715,15 +777,18 @@ __global__ __launch_bounds__(kBlock) void k_meld(const uint32_t *__restrict__ rg
         px_to_lab(s_lut, px, L, a, b);
         if (k == 1) {                                            // mix_colors.wgsl:127-131
             const float4 c = s_cent[0];
-            out[i] = lab_to_rgba8_dev(c.x, c.y, c.z);
+            out[i] = lab_to_rgba8_dev<true>(c.x, c.y, c.z, s_thr);
             continue;
         }
         // :30-31 closest = second_closest = vec4(10000.0)
         float cL = 10000.0f, ca = 10000.0f, cb = 10000.0f, sL = 10000.0f, sa = 10000.0f, sb = 10000.0f;
         float d_closest = cie94(L, a, b, cL, ca, cb), d_second = d_closest;
+        // (the two chromas of delta_e.wgsl:8-9 are the pixel's, computed once, and the centroid's, kept in the table:
+        // cie94_c performs the same operations on them, hence returns the same float -- two square roots fewer per visit)
+        const float C1 = chroma(a, b);
         auto visit = [&](uint32_t j) {
             const float4 c = s_cent[j];
-            const float d = cie94(L, a, b, c.x, c.y, c.z);
+            const float d = cie94_c(L, a, b, C1, c.x, c.y, c.z, c.w);
             if (d < d_closest) {                                 // :36-38
                 sL = cL; sa = ca; sb = cb; d_second = d_closest;
                 cL = c.x; ca = c.y; cb = c.z; d_closest = d;
@@ -760,7 +825,7 @@ __global__ __launch_bounds__(kBlock) void k_meld(const uint32_t *__restrict__ rg
         const float oL = factor * cL + (1.0f - factor) * sL;
         const float oa = factor * ca + (1.0f - factor) * sa;
         const float ob = factor * cb + (1.0f - factor) * sb;
-        out[i] = lab_to_rgba8_dev(oL, oa, ob);
+        out[i] = lab_to_rgba8_dev<true>(oL, oa, ob, s_thr);
     }
 }
 
@@ -770,7 +835,7 @@ hipError_t launch_meld(const uint32_t *rgba, uint64_t n, const Centroid *cent, u
     const uint64_t blocks = (n + kBlock - 1) / kBlock;
     const uint32_t grid = (uint32_t)(blocks < 8192 ? (blocks ? blocks : 1) : 8192);
     const uint32_t kpad = (k + 3u) & ~3u;
-    const size_t lds = sizeof(float4) * kpad + 256 * sizeof(float);
+    const size_t lds = sizeof(float4) * kpad + (256 + 257) * sizeof(float);
     hipLaunchKernelGGL(k_meld, dim3(grid), dim3(kBlock), lds, st, rgba, n, cent, k, lut, masks, out);
     return hipGetLastError();
 }

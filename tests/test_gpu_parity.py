@@ -275,6 +275,12 @@ def test_meld_matches_oracle(processor, oracle, tokyo, k):
     assert np.all(got[..., 3] == 255)
 
 
+def test_meld_encode_table_is_the_encode_for_every_float(processor):
+    """the meld pass reads the sRGB8 byte of a linear channel value from a threshold table (made on the device by the
+    encode itself): compared with the encode for EVERY float bit pattern of either sign, NaN aside"""
+    assert processor.debug_encode_table_check() == 0
+
+
 def test_reduce_meld_end_to_end(processor, oracle, tokyo):
     got = processor.reduce(6, tokyo, reduce_mode=2)
     want = oracle.reduce(tokyo, 6, oracle.MODE_MELD)
