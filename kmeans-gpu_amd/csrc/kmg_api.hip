@@ -747,6 +747,14 @@ extern "C" int kmg_debug_check_table(kmg_lloyd *s, uint64_t out[3], void *stream
 // test support: exhaustive validation of the dither candidate masks (kmg_table.hip) for a centroid
 // table: over all 2^24 colours x 16 Bayer offsets, the arg-min over the candidates must equal the
 // brute-force arg-min.  *violations must come back 0.
+// Which pruned dither pass?  k <= 256: byte lists per cell of a grid over Lab (kmg_dither.hip); larger k: mask words per (RGB
+// cell, Bayer index) (kmg_table.hip).  KMG_DITHER_LISTS = 0 sends every k to the mask words, 1 (tools) keeps k <= 64 there.
+static bool dither_takes_lists(uint32_t k)
+{
+    static const int mode = getenv("KMG_DITHER_LISTS") ? atoi(getenv("KMG_DITHER_LISTS")) : 2;
+    return mode != 0 && k <= 256u && (k > 64u || mode == 2);
+}
+
 extern "C" int kmg_debug_check_dither_masks(kmg_processor *p, const float *c4, uint32_t k, uint64_t *violations, void *stream)
 {
     if (!p || !c4 || !violations || k < 2 || k > KMG_MAX_K) return fail(KMG_ERR_INVALID_ARGUMENT, "bad check_dither_masks arguments");
@@ -765,9 +773,17 @@ extern "C" int kmg_debug_check_dither_masks(kmg_processor *p, const float *c4, u
     HIP_TRY(viol.alloc(sizeof(unsigned long long)));
     HIP_TRY(hipMemcpyAsync(cent.ptr, hc.data(), sizeof(Centroid) * k, hipMemcpyHostToDevice, S(stream)));
     HIP_TRY(hipMemsetAsync(viol.ptr, 0, sizeof(unsigned long long), S(stream)));
-    HIP_TRY(launch_offset_candidates(p->d_bounds, (const Centroid *)cent.ptr, k, thr, (uint64_t *)masks.ptr, nullptr, S(stream)));
+    HIP_TRY(launch_offset_candidates(p->d_bounds, (const Centroid *)cent.ptr, k, thr, (uint64_t *)masks.ptr, S(stream)));
     HIP_TRY(launch_check_offset_masks((const Centroid *)cent.ptr, k, (const uint64_t *)masks.ptr, p->d_lut, thr,
                                       (unsigned long long *)viol.ptr, S(stream)));
+    if (k <= 256u) {                                        // the byte lists over Lab cells (kmg_dither.hip), same counter
+        DevBuf lists;
+        HIP_TRY(lists.alloc(kLabListBytes));
+        HIP_TRY(launch_lab_candidates((const Centroid *)cent.ptr, k, (uint8_t *)lists.ptr, S(stream)));
+        HIP_TRY(launch_check_lab_lists((const Centroid *)cent.ptr, k, (const uint8_t *)lists.ptr, p->d_lut, thr,
+                                       (unsigned long long *)viol.ptr, S(stream)));
+        HIP_TRY(hipStreamSynchronize(S(stream)));
+    }
     unsigned long long h = 0;
     HIP_TRY(hipMemcpyAsync(&h, viol.ptr, sizeof h, hipMemcpyDeviceToHost, S(stream)));
     HIP_TRY(hipStreamSynchronize(S(stream)));
@@ -1685,7 +1701,9 @@ extern "C" int kmg_dev_apply(kmg_processor *p, const uint8_t *d_rgba, uint32_t w
     const size_t labels_bytes = (size_t)(k <= 256 ? 1 : 2) << 24;
     const size_t masks_bytes = sizeof(uint64_t) * (size_t)kCells * mask_words(k) * (dither_pruned ? 16u : 1u);
     size_t need = ArenaGuard::padded(tables_bytes);
-    if (meld_masks_pay || dither_pruned) need += ArenaGuard::padded(masks_bytes) + ArenaGuard::padded(kListTableBytes);
+    const bool dither_lists = dither_pruned && dither_takes_lists(k);      // byte lists over Lab cells instead of mask words
+    if (meld_masks_pay || (dither_pruned && !dither_lists)) need += ArenaGuard::padded(masks_bytes);
+    if (dither_lists) need += ArenaGuard::padded(kLabListBytes);
     if (replace_table) need += ArenaGuard::padded(labels_bytes) + ArenaGuard::padded(sub_bytes) + ArenaGuard::padded(cube_masks_bytes(k)) +
                                ArenaGuard::padded(cube_work_bytes());
     ArenaGuard arena;
@@ -1733,12 +1751,17 @@ extern "C" int kmg_dev_apply(kmg_processor *p, const uint8_t *d_rgba, uint32_t w
     } else if (dither_pruned) {
         // dither on a large image: candidate masks per (colour cell, Bayer index), then a scan of the
         // pixel's candidates only
-        if ((rc = ensure_bounds(p, S(stream))) == KMG_OK) {
-            uint64_t *m = (uint64_t *)arena.take(masks_bytes);
-            uint8_t *lst = (k > 64 && k <= 256) ? (uint8_t *)arena.take(kListTableBytes) : nullptr;   // byte lists (k_dither_lists)
-            e = launch_offset_candidates(p->d_bounds, d_cent, k, thr, m, lst, S(stream));
+        if (dither_lists) {
+            uint8_t *lst = (uint8_t *)arena.take(kLabListBytes);
+            e = launch_lab_candidates(d_cent, k, lst, S(stream));
             if (e == hipSuccess)
-                e = launch_dither_pruned((const uint32_t *)d_rgba, w, rows, row0, d_cent, k, p->d_lut, d_pal, thr, m, lst,
+                e = launch_dither_lists((const uint32_t *)d_rgba, w, rows, row0, d_cent, k, p->d_lut, d_pal, thr, lst,
+                                        (uint32_t *)d_out, S(stream));
+        } else if ((rc = ensure_bounds(p, S(stream))) == KMG_OK) {
+            uint64_t *m = (uint64_t *)arena.take(masks_bytes);
+            e = launch_offset_candidates(p->d_bounds, d_cent, k, thr, m, S(stream));
+            if (e == hipSuccess)
+                e = launch_dither_pruned((const uint32_t *)d_rgba, w, rows, row0, d_cent, k, p->d_lut, d_pal, thr, m,
                                          (uint32_t *)d_out, S(stream));
         }
     } else {

@@ -1,0 +1,378 @@
+// kmg_dither.hip -- the ordered-dither output pass on large images with k <= 256 (mix_colors.wgsl:50-83): candidate lists per
+// cell of a grid over Lab, and the pass that walks them.
+//
+// A dithered pixel is compared with the centroids at Lab(pixel) + off (1, 1, 1), off one of 16 Bayer offsets.  Rounds 1-3a
+// pruned per (RGB cell, Bayer index): 2^19 slots whose 32-byte records (16.7 MiB) are fetched once per pixel from all over the
+// table -- 3.3 GB of Infinity Cache traffic per 8192^2 image at k = 256 (profiles/r03c_apply_pmc.txt), which bounded the pass at
+// 1.15 ms however few instructions the list walk took.  The shifted point is an ordinary point of Lab, so the lists here belong to
+// cells of a 4 x 4 x 4 grid over Lab itself: no Bayer dimension, a tighter box than an RGB cell swept by 16 offsets, and the
+// cells an image can reach (the sRGB gamut widened by the offsets: ~20 000 of 207 360) make a table of well under 1 MiB that
+// stays in every XCD's L2.
+//
+// Exactness is the near-tie scheme of kmg_math.h: the lists keep every centroid whose lower key bound over the cell is not above
+// (1 + kMaskSlack) times the smallest upper bound, the pass orders by a key and re-decides near-ties with the literal distance.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "kmg_table_dev.h"
+
+namespace kmg {
+
+// ---- the grid ---------------------------------------------------------------------------------------------------------------
+// L in [-24, 136), a and b in [-144, 144): 40 x 72 x 72 cells of 4 units.  sRGB spans L 0..100, a -87..99, b -108..95; the
+// offsets are threshold (bayer / 16 - 1/2) with threshold = palette diameter / sqrt(k) (<= 37 for k >= 16).  Cells on the rim
+// of the grid are unbounded outwards and are marked "scan everything" (count 255): exact for any input, merely slow.
+constexpr int kLabNL = 40, kLabNA = 72;
+static_assert(kLabCells == (uint32_t)(kLabNL * kLabNA * kLabNA), "grid size (kmg_table.h)");
+constexpr float kLabStep = 4.0f, kLabL0 = -24.0f, kLabA0 = -144.0f;
+
+__device__ __forceinline__ uint32_t lab_axis_index(float x, float origin, int n)
+{
+    // (x - origin) / 4 clamped to [0, n - 1], rounded down; NaN -> a rim cell
+    const float t = (x - origin) * (1.0f / kLabStep);
+    return (uint32_t)__builtin_amdgcn_fmed3f(t, 0.0f, (float)(n - 1));
+}
+
+__device__ __forceinline__ uint32_t lab_cell_index(float L, float a, float b)
+{
+    const uint32_t iL = lab_axis_index(L, kLabL0, kLabNL), ia = lab_axis_index(a, kLabA0, kLabNA), ib = lab_axis_index(b, kLabA0, kLabNA);
+    return (iL * (uint32_t)kLabNA + ia) * (uint32_t)kLabNA + ib;
+}
+
+// bounds of the per-pixel terms over the points that lab_cell_index sends to interior cell (iL, ia, ib): the cell's box widened
+// by 2^-10 on every side (x - origin rounds once, by at most 2^-17 at these magnitudes; the scaling by 1/4 is exact)
+__device__ __forceinline__ CellBounds lab_cell_bounds(uint32_t iL, uint32_t ia, uint32_t ib)
+{
+    constexpr float e = 0.0009765625f;
+    CellBounds s;
+    s.L0 = kLabL0 + kLabStep * (float)iL - e; s.L1 = kLabL0 + kLabStep * (float)(iL + 1u) + e;
+    s.a0 = kLabA0 + kLabStep * (float)ia - e; s.a1 = kLabA0 + kLabStep * (float)(ia + 1u) + e;
+    s.b0 = kLabA0 + kLabStep * (float)ib - e; s.b1 = kLabA0 + kLabStep * (float)(ib + 1u) + e;
+    float ma, Ma, mb, Mb;
+    abs_range(s.a0, s.a1, 0.0f, ma, Ma);
+    abs_range(s.b0, s.b1, 0.0f, mb, Mb);
+    s.C0 = chroma(ma, mb);                                      // sqrtf(a*a + b*b) is monotone in |a|, |b|
+    s.C1 = chroma(Ma, Mb);
+    const PixelTerms lo = pixel_terms_c(0.0f, 0.0f, 0.0f, s.C0), hi = pixel_terms_c(0.0f, 0.0f, 0.0f, s.C1);
+    s.wC0 = hi.wC; s.wC1 = lo.wC;                               // the weights decrease with C
+    s.wH0 = hi.wH; s.wH1 = lo.wH;
+    s.pad[0] = s.pad[1] = s.pad[2] = s.pad[3] = 0.0f;
+    return s;
+}
+
+// ---- candidate lists --------------------------------------------------------------------------------------------------------
+// lists: 2 x kLabCells records of kListBytes.  Record c: [count][index 0 .. 30], record kLabCells + c: [index 31 .. 62] (written
+// for every cell, read only when count > 31); count 255 = scan all centroids (more than kListMax candidates, or a rim cell).
+// Every byte behind the entries names a centroid OUTSIDE the list -- its key is above (1 + kMaskSlack) times the best one's, so
+// it can neither win nor look like a near-tie --, or index 255 when k < 256, which the pass keeps far away: the pass walks whole
+// list words without asking which bytes are entries.
+// One wave per cell; lane j (+ 64, 128, 192) bounds centroid j over the cell (key_range, kmg_table_dev.h).
+__global__ __launch_bounds__(kBlock) void k_lab_candidates(const Centroid *__restrict__ cent, uint32_t k, uint8_t *__restrict__ lists)
+{
+    __shared__ uint8_t s_rec_all[kBlock / 64][2 * kListBytes];
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint8_t *s_rec = s_rec_all[wv];
+    const uint32_t cell = blockIdx.x * (kBlock / 64) + wv;
+    if (cell >= kLabCells) return;
+    const uint32_t ib = cell % (uint32_t)kLabNA, ia = (cell / (uint32_t)kLabNA) % (uint32_t)kLabNA, iL = cell / (uint32_t)(kLabNA * kLabNA);
+    const bool rim = iL == 0u || iL == (uint32_t)kLabNL - 1u || ia == 0u || ia == (uint32_t)kLabNA - 1u || ib == 0u || ib == (uint32_t)kLabNA - 1u;
+    uint4 *first = reinterpret_cast<uint4 *>(lists + (uint64_t)cell * kListBytes);
+    if (rim) {                                                      // (uniform: one wave, one cell)
+        if (lane < 2u) first[lane] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        return;
+    }
+    const CellBounds cb = lab_cell_bounds(iL, ia, ib);
+    const uint32_t words = (k + 63u) / 64u;
+    float U = 3.0e38f, lo[4];
+#pragma unroll
+    for (uint32_t w = 0; w < 4u; ++w) {
+        lo[w] = 3.0e38f;
+        const uint32_t j = w * 64u + lane;
+        if (w < words && j < k) {
+            const Centroid c = cent[j];
+            const KeyRange r = key_range(cb, c.L, c.a, c.b, c.C);
+            lo[w] = r.lo;
+            U = fminf(U, r.hi);
+        }
+    }
+    U = mask_threshold(wave_min(U));                                // keep what can still be a near-tie (kmg_math.h)
+    unsigned long long m[4];
+    uint32_t n_cand = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 4u; ++w) {
+        m[w] = __ballot(lo[w] <= U);                                // (lo = 3e38 beyond k)
+        n_cand += (uint32_t)__builtin_popcountll(m[w]);
+    }
+    uint32_t pad = 255u;
+    if (k == 256u) {
+#pragma unroll
+        for (int w = 3; w >= 0; --w)
+            if (~m[w]) pad = (uint32_t)w * 64u + (uint32_t)__builtin_ctzll(~m[w]);
+    }
+    if (lane < 16u) reinterpret_cast<uint32_t *>(s_rec)[lane] = pad * 0x01010101u;
+    __builtin_amdgcn_wave_barrier();
+    if (n_cand <= kListMax) {
+        uint32_t base = 1u;                                         // byte 0 is the count
+#pragma unroll
+        for (uint32_t w = 0; w < 4u; ++w) {
+            if ((m[w] >> lane) & 1ull) s_rec[base + bits_below_lane(m[w])] = (uint8_t)(w * 64u + lane);
+            base += (uint32_t)__builtin_popcountll(m[w]);
+        }
+    }
+    if (lane == 0u) s_rec[0] = (uint8_t)(n_cand <= kListMax ? n_cand : 255u);
+    __builtin_amdgcn_wave_barrier();
+    const uint4 *src = reinterpret_cast<const uint4 *>(s_rec);
+    if (lane < 2u) first[lane] = src[lane];
+    else if (lane < 4u) reinterpret_cast<uint4 *>(lists + ((uint64_t)kLabCells + cell) * kListBytes)[lane - 2u] = src[lane];
+}
+
+hipError_t launch_lab_candidates(const Centroid *cent, uint32_t k, uint8_t *lists, hipStream_t st)
+{
+    if (k > 256u) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_lab_candidates, dim3((kLabCells + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, st, cent, k, lists);
+    return hipGetLastError();
+}
+
+// ---- the pass ---------------------------------------------------------------------------------------------------------------
+// The pass is bound by vector issue (4 cycles per wave instruction), so the list walk is written for instruction count:
+//   * the key of a candidate in 8 instructions instead of 12: the centroid's (L, a) and (b, C) are the register pairs its 16-byte
+//     LDS read returns, and v_pk_add / v_pk_mul / v_pk_fma_f32 work on (dL, da) and (db, dC) at once (pair_key);
+//   * the candidate's index travels in the low byte of its key (one v_perm_b32, which also extracts it from the list word), so the
+//     running minimum and runner-up are one v_min_u32 and one v_med3_u32, and the index needs no register of its own;
+//   * the walk is unrolled by list WORDS (the wave leaves it after its longest list's last word): byte positions are compile-time
+//     constants (the LDS address of byte P's centroid is one sub-dword shift) and the reads of a word are in flight together.
+// The key orders only: near-ties (kmg_math.h; the packed byte costs 2^-15 = 512u of the 2048u slack, the pair form one more
+// rounding) are settled with the literal distance as everywhere else.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct PixelPairs { f32x2 La, bC, wC1; float wH; };
+
+// (dL^2 + dC^2 wC + max(da^2 + db^2 - dC^2, 0) wH) against the centroid at byte offset j16 of the LDS table
+// (the table starts at LDS address 0 -- k_dither_lists checks --, so the offset is the address: no add per read)
+typedef const float4 __attribute__((address_space(3))) *LdsFloat4Ptr;
+__device__ __forceinline__ float pair_key(uint32_t j16, const PixelPairs &pp)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float4 c = *(LdsFloat4Ptr)j16;
+#else
+    const float4 c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);          // (host pass: never called)
+#endif
+    const f32x2 cxy = {c.x, c.y}, czw = {c.z, c.w};
+    const f32x2 d0 = pp.La - cxy, d1 = pp.bC - czw;               // (dL, da), (db, dC)
+    const f32x2 s0 = d0 * d0, s1 = d1 * d1;                       // (dL^2, da^2), (db^2, dC^2)
+    const f32x2 s1s = {s1.y, s1.x};
+    const f32x2 rt = __builtin_elementwise_fma(s1s, pp.wC1, s0);  // (dC^2 wC + dL^2, db^2 + da^2)
+    const float h = fmaxf(rt.y - s1.y, 0.0f);
+    return fmaf(h, pp.wH, rt.x);
+}
+
+// byte P of list word wd -> that centroid's key with its index in the low byte
+template <int P>
+__device__ __forceinline__ uint32_t list_entry_key(uint32_t wd, const PixelPairs &pp)
+{
+    uint32_t j16;                                                   // (byte P) << 4 in one instruction (sub-dword operand select)
+    if (P == 0) asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(j16) : "v"(wd));
+    else if (P == 1) asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(j16) : "v"(wd));
+    else if (P == 2) asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(j16) : "v"(wd));
+    else asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(j16) : "v"(wd));
+    const float key = pair_key(j16, pp);
+    return __builtin_amdgcn_perm(__float_as_uint(key), wd, 0x07060500u | (uint32_t)P);
+}
+
+// best <- min(best, kp), second <- the runner-up (best <= second before and after)
+__device__ __forceinline__ void min_and_runner_up(uint32_t kp, uint32_t &best, uint32_t &second)
+{
+    asm("v_med3_u32 %0, %2, %1, %0\n\tv_min_u32 %1, %1, %2" : "+v"(second), "+v"(best) : "v"(kp));
+}
+
+__global__ __launch_bounds__(kBlock) void k_dither_lists(const uint32_t *__restrict__ rgba, uint32_t w, uint64_t n,
+                                                         uint32_t row0, const Centroid *__restrict__ cent, uint32_t k,
+                                                         const float *__restrict__ lut, const uint32_t *__restrict__ pal,
+                                                         float threshold, const uint8_t *__restrict__ lists,
+                                                         uint32_t *__restrict__ out, int aligned)
+{
+    extern __shared__ float4 smem4[];
+    constexpr uint32_t kpad = 256u;                                // every byte value indexes the table: entries k .. 255 are far away
+    float4 *s_cent = smem4;
+    // the kernel has no static LDS, so its dynamic LDS -- the centroid table first -- starts at LDS address 0 (pair_key)
+    if ((uint32_t)reinterpret_cast<uintptr_t>(s_cent) != 0u) __builtin_trap();
+    float *s_lut = reinterpret_cast<float *>(smem4 + kpad);
+    float *s_off = s_lut + 256;
+    const float sentinel_C = chroma(10000.0f, 10000.0f);
+    s_lut[threadIdx.x] = lut[threadIdx.x];
+    static_assert(kBlock == 256, "one table entry per thread");
+    {
+        float4 c = make_float4(1.0e18f, 0.0f, 0.0f, 0.0f);       // key ~ 1e36: far above the sentinel's
+        if (threadIdx.x < k) { const Centroid ce = cent[threadIdx.x]; c = make_float4(ce.L, ce.a, ce.b, ce.C); }
+        s_cent[threadIdx.x] = c;
+    }
+    if (threadIdx.x < 16) s_off[threadIdx.x] = threshold * (bayer16(threadIdx.x) / 16.0f - 0.5f);
+    __syncthreads();
+    constexpr uint64_t TILE = (uint64_t)kBlock * 4;
+    const uint64_t tiles = (n + TILE - 1) / TILE;
+    for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const uint64_t i0 = tile * TILE + (uint64_t)threadIdx.x * 4;
+        uint32_t px[4];
+        load4_stream(rgba, i0, n, aligned != 0, px);
+        const uint32_t i32 = (uint32_t)i0;                          // n < 2^32
+        uint32_t gy = i32 / w, gx = i32 - gy * w;
+        gy += row0;
+        float pL[4], pa[4], pb[4];
+        uint32_t cell[4];
+        uint4 rec[4][2];                                            // the four pixels' lists
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t bi = (gx & 3u) + ((gy & 3u) << 2);
+            px_to_lab(s_lut, px[q], pL[q], pa[q], pb[q]);
+            const float off = s_off[bi];
+            pL[q] = pL[q] + off; pa[q] = pa[q] + off; pb[q] = pb[q] + off;   // mix_colors.wgsl:72
+            cell[q] = lab_cell_index(pL[q], pa[q], pb[q]);
+            const uint4 *r = reinterpret_cast<const uint4 *>(lists + (uint64_t)cell[q] * kListBytes);
+            rec[q][0] = r[0]; rec[q][1] = r[1];
+            gx += 1;
+            if (gx == w) { gx = 0; gy += 1; }
+        }
+        uint32_t res[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const PixelTerms pt = pixel_terms_fast(pL[q], pa[q], pb[q], chroma(pa[q], pb[q]));
+            PixelPairs pp;
+            pp.La = f32x2{pt.L, pt.a}; pp.bC = f32x2{pt.b, pt.C}; pp.wC1 = f32x2{pt.wC, 1.0f}; pp.wH = pt.wH;
+            // mix_colors.wgsl:73-80 starts the scan at the sentinel (10000, 10000, 10000), index k.  Its key is not computed here: a
+            // pixel whose smallest key is not below kSentinelFloor -- (10000 - L)^2 alone is above that for every L < 9000, and no
+            // centroid of a palette in Lab is 1000 units from a pixel -- goes to the literal scan below, which starts at the
+            // sentinel and is exact for any input.
+            constexpr uint32_t kSentinelFloor = 0x49742400u;          // 1.0e6f
+            uint32_t best = 0x7F7FFF00u, second = 0x7F7FFFFFu;
+            const uint32_t cnt_raw = rec[q][0].x & 255u;
+            const bool over = cnt_raw == 255u;
+            const uint32_t cnt = over ? 0u : cnt_raw;
+            uint4 more0 = make_uint4(0u, 0u, 0u, 0u), more1 = more0;    // the continuation record of a long list
+            if (cnt >= kListBytes) {
+                const uint4 *r = reinterpret_cast<const uint4 *>(lists + ((uint64_t)kLabCells + cell[q]) * kListBytes);
+                more0 = r[0]; more1 = r[1];
+            }
+            // byte t of the list's 64 bytes: [count][index 0 .. 62]; a word the list reaches holds entries and, behind them, bytes
+            // that name a centroid outside the list (k_lab_candidates), so all four of its bytes are scanned
+            const uint32_t rw[16] = {rec[q][0].x, rec[q][0].y, rec[q][0].z, rec[q][0].w, rec[q][1].x, rec[q][1].y, rec[q][1].z, rec[q][1].w,
+                                     more0.x, more0.y, more0.z, more0.w, more1.x, more1.y, more1.z, more1.w};
+            const uint32_t longest = wave_max_u32_dpp(cnt);          // the wave's longest list
+#define KMG_LIST_ENTRY(WORD, P) min_and_runner_up(list_entry_key<P>(rw[WORD], pp), best, second);
+            if (longest) {
+                if (cnt) { KMG_LIST_ENTRY(0, 1) KMG_LIST_ENTRY(0, 2) KMG_LIST_ENTRY(0, 3) }
+            }
+#pragma unroll
+            for (int wd = 1; wd < 16; ++wd) {
+                if ((uint32_t)(wd * 4) > longest) break;
+                if ((uint32_t)(wd * 4) <= cnt) { KMG_LIST_ENTRY(wd, 0) KMG_LIST_ENTRY(wd, 1) KMG_LIST_ENTRY(wd, 2) KMG_LIST_ENTRY(wd, 3) }
+            }
+#undef KMG_LIST_ENTRY
+            if (__ballot(over)) {                                   // no list (too long, or a rim cell): every centroid, in order
+                for (uint32_t j = 0; j < k; ++j) {
+                    if (over) min_and_runner_up((__float_as_uint(pair_key(j << 4, pp)) & ~255u) | j, best, second);
+                }
+            }
+            uint32_t idx = best & 255u;
+            const float thr = tie_threshold(__uint_as_float(best));
+            const bool near = __uint_as_float(second) <= thr || best >= kSentinelFloor || !(pt.L < 9000.0f);
+            if (__ballot(near)) {
+                // near-tie (kmg_math.h): mix_colors.wgsl:73-80 with the literal distance, the sentinel first, same order
+                float lb = cie94_c(pt.L, pt.a, pt.b, pt.C, 10000.0f, 10000.0f, 10000.0f, sentinel_C);
+                uint32_t li = k;
+                for (uint32_t i = 0; i < kListMax; ++i) {
+                    if (i >= longest) break;
+                    if (near && i < cnt) {
+                        const uint32_t j = (rw[(i + 1u) >> 2] >> (8u * ((i + 1u) & 3u))) & 255u;
+                        const float4 c = s_cent[j];
+                        if (cie94_key(pt, c.x, c.y, c.z, c.w) <= thr) {
+                            const float d = cie94_c(pt.L, pt.a, pt.b, pt.C, c.x, c.y, c.z, c.w);
+                            if (d < lb) { lb = d; li = j; }
+                        }
+                    }
+                }
+                if (__ballot(near && over)) {
+                    for (uint32_t j = 0; j < k; ++j) {
+                        if (near && over) {
+                            const float4 c = s_cent[j];
+                            if (cie94_key(pt, c.x, c.y, c.z, c.w) <= thr) {
+                                const float d = cie94_c(pt.L, pt.a, pt.b, pt.C, c.x, c.y, c.z, c.w);
+                                if (d < lb) { lb = d; li = j; }
+                            }
+                        }
+                    }
+                }
+                if (near) idx = li;
+            }
+            res[q] = pal[idx];
+        }
+        store4_stream(out, i0, n, aligned != 0, res);
+    }
+}
+
+hipError_t launch_dither_lists(const uint32_t *rgba, uint32_t w, uint32_t rows, uint32_t row0, const Centroid *cent, uint32_t k,
+                               const float *lut, const uint32_t *pal, float threshold, const uint8_t *lists, uint32_t *out,
+                               hipStream_t st)
+{
+    if (k > 256u) return hipErrorInvalidValue;
+    const uint64_t n = (uint64_t)w * rows;
+    const uint64_t tiles = (n + kBlock * 4 - 1) / (kBlock * 4);
+    const uint32_t grid = (uint32_t)(tiles < 8192 ? (tiles ? tiles : 1) : 8192);
+    const size_t lds = sizeof(float4) * 256 + (256 + 16) * sizeof(float);
+    const int aligned = ((reinterpret_cast<uintptr_t>(rgba) & 15u) == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(k_dither_lists, dim3(grid), dim3(kBlock), lds, st, rgba, w, n, row0, cent, k, lut, pal, threshold, lists, out,
+                       aligned);
+    return hipGetLastError();
+}
+
+// ---- test support -----------------------------------------------------------------------------------------------------------
+// violations += #(colour, Bayer index) whose brute-force dither arg-min (literal distance, sentinel included) differs from the
+// arg-min over the list of its Lab cell; one workgroup per RGB cell as in the other exhaustive checks
+__global__ __launch_bounds__(kBlock) void k_check_lab_lists(const Centroid *__restrict__ cent, uint32_t k,
+                                                            const uint8_t *__restrict__ lists, const float *__restrict__ lut,
+                                                            float threshold, unsigned long long *__restrict__ violations)
+{
+    __shared__ float s_lut[256];
+    s_lut[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    const uint32_t rgb_cell = blockIdx.x;
+    const float sentinel_C = chroma(10000.0f, 10000.0f);
+    unsigned long long bad = 0;
+    for (uint32_t c = threadIdx.x; c < kCellColours; c += kBlock) {
+        float L0, a0, b0;
+        colour_to_lab(s_lut, rgb_cell * kCellColours + c, L0, a0, b0);
+        for (uint32_t bi = 0; bi < 16u; ++bi) {
+            const float off = threshold * (bayer16(bi) / 16.0f - 0.5f);
+            const PixelTerms pt = pixel_terms(L0 + off, a0 + off, b0 + off);
+            const uint32_t cell = lab_cell_index(pt.L, pt.a, pt.b);
+            const uint8_t *rec = lists + (uint64_t)cell * kListBytes, *more = lists + ((uint64_t)kLabCells + cell) * kListBytes;
+            const uint32_t cnt = rec[0];
+            const float start = cie94_c(pt.L, pt.a, pt.b, pt.C, 10000.0f, 10000.0f, 10000.0f, sentinel_C);
+            float best = start, bestp = start;
+            uint32_t idx = k, idxp = k;
+            for (uint32_t j = 0; j < k; ++j) {
+                const Centroid ce = cent[j];
+                const float d = cie94_c(pt.L, pt.a, pt.b, pt.C, ce.L, ce.a, ce.b, ce.C);
+                if (d < best) { best = d; idx = j; }
+            }
+            if (cnt == 255u) continue;                               // the pass scans everything
+            for (uint32_t i = 0; i < cnt; ++i) {
+                const uint32_t j = i < kListBytes - 1u ? rec[1u + i] : more[i - (kListBytes - 1u)];
+                const Centroid ce = cent[j];
+                const float d = cie94_c(pt.L, pt.a, pt.b, pt.C, ce.L, ce.a, ce.b, ce.C);
+                if (d < bestp) { bestp = d; idxp = j; }
+            }
+            bad += idx != idxp;
+        }
+    }
+    if (bad) atomicAdd(violations, bad);
+}
+
+hipError_t launch_check_lab_lists(const Centroid *cent, uint32_t k, const uint8_t *lists, const float *lut, float threshold,
+                                  unsigned long long *violations, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_check_lab_lists, dim3(kCells), dim3(kBlock), 0, st, cent, k, lists, lut, threshold, violations);
+    return hipGetLastError();
+}
+
+}  // namespace kmg

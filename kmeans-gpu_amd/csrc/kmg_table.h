@@ -204,16 +204,25 @@ hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_la
 // ordered-dither output pass with candidate pruning: masks[(cell * 16 + Bayer index) * words + w] are the
 // centroids that can be the arg-min of Lab(colour) + threshold * (M[Bayer index] / 16 - 0.5) for any
 // colour of the cell; the pass scans only those (pal: k + 1 RGBA8 words, entry k = the sentinel)
-// lists (optional, k <= 256, 2 x kCells * 16 records of kListBytes): the same candidates as a byte list per (cell, Bayer
-// index), ascending: record r of the first half = [count][the first 31 indices], record r of the second half = indices
-// 31 .. 62 of the (few) slots with more than 31 candidates; count = 255: more than kListMax (the pass then scans all centroids)
-constexpr uint32_t kListBytes = 32, kListMax = 2 * kListBytes - 1;
-constexpr size_t kListTableBytes = 2ull * kCells * 16ull * kListBytes;
 hipError_t launch_offset_candidates(const CellBounds *bounds, const Centroid *cent, uint32_t k, float threshold,
-                                    uint64_t *masks, uint8_t *lists, hipStream_t st);
+                                    uint64_t *masks, hipStream_t st);
 hipError_t launch_dither_pruned(const uint32_t *rgba, uint32_t w, uint32_t rows, uint32_t row0, const Centroid *cent,
                                 uint32_t k, const float *lut, const uint32_t *pal, float threshold,
-                                const uint64_t *masks, const uint8_t *lists, uint32_t *out, hipStream_t st);
+                                const uint64_t *masks, uint32_t *out, hipStream_t st);
+
+// The same pass for k <= 256 over byte lists per cell of a 4 x 4 x 4 grid over Lab (kmg_dither.hip): lists = 2 x kLabCells
+// records of kListBytes, record c = [count][the first 31 candidate indices, ascending], record kLabCells + c = indices 31 .. 62;
+// count 255: scan all centroids.  No image-independent table is needed (no CellBounds): the cells are boxes of Lab.
+constexpr uint32_t kListBytes = 32, kListMax = 2 * kListBytes - 1;
+constexpr uint32_t kLabCells = 40u * 72u * 72u;
+constexpr size_t kLabListBytes = 2ull * kLabCells * kListBytes;
+hipError_t launch_lab_candidates(const Centroid *cent, uint32_t k, uint8_t *lists, hipStream_t st);
+hipError_t launch_dither_lists(const uint32_t *rgba, uint32_t w, uint32_t rows, uint32_t row0, const Centroid *cent, uint32_t k,
+                               const float *lut, const uint32_t *pal, float threshold, const uint8_t *lists, uint32_t *out,
+                               hipStream_t st);
+// test support: number of (colour, Bayer index) pairs (all 2^24 x 16) whose literal arg-min is not the arg-min over the list
+hipError_t launch_check_lab_lists(const Centroid *cent, uint32_t k, const uint8_t *lists, const float *lut, float threshold,
+                                  unsigned long long *violations, hipStream_t st);
 // test support: number of (colour, Bayer index) pairs whose arg-min over the candidates differs from
 // the brute-force dither arg-min
 hipError_t launch_check_offset_masks(const Centroid *cent, uint32_t k, const uint64_t *masks, const float *lut,

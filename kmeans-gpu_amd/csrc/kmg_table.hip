@@ -1098,12 +1098,6 @@ hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_la
 // k_cube_stage (kmg_cube.hip), from the static cell bounds shifted by the offset; the output pass then
 // scans, per pixel, only the candidates of its (cell, Bayer index) instead of all k centroids.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float bayer16(uint32_t i)            // mix_colors.wgsl:13-16
-{
-    constexpr uint64_t M = 0x5D7F91B36E4CA280ull;               // 0 8 2 10 12 4 14 6 3 11 1 9 15 7 13 5, 4 bits each
-    return (float)((M >> (4u * i)) & 15ull);
-}
-
 // bounds of the per-pixel terms after adding `off` to L, a and b of every colour of the cell
 __device__ __forceinline__ CellBounds shifted_bounds(const CellBounds &cb, float off)
 {
@@ -1132,16 +1126,13 @@ __device__ __forceinline__ CellBounds shifted_bounds(const CellBounds &cb, float
 // minimiser of the upper bounds is in S the threshold is the same: identical masks, ~10x fewer interval evaluations.
 __global__ __launch_bounds__(kBlock) void k_offset_candidates(const CellBounds *__restrict__ bounds,
                                                               const Centroid *__restrict__ cent, uint32_t k,
-                                                              float threshold, uint64_t *__restrict__ masks,
-                                                              uint8_t *__restrict__ lists)
+                                                              float threshold, uint64_t *__restrict__ masks)
 {
     __shared__ uint32_t s_list_all[kBlock / 64][64];
     __shared__ unsigned long long s_out_all[kBlock / 64][16 * 4];
-    __shared__ uint8_t s_rec_all[kBlock / 64][2 * 16 * kListBytes];  // the cell's 16 byte lists: first records, continuation records
     const uint32_t wv = threadIdx.x >> 6;
     uint32_t *s_list = s_list_all[wv];
     unsigned long long *s_out = s_out_all[wv];
-    uint8_t *s_rec = s_rec_all[wv];
     const uint32_t cell = blockIdx.x * (kBlock / 64) + wv;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t words = (k + 63u) / 64u;
@@ -1209,7 +1200,6 @@ __global__ __launch_bounds__(kBlock) void k_offset_candidates(const CellBounds *
             const uint32_t p = lane & (G - 1u);
             const uint32_t j = s_list[p < n_s ? p : 0u];
             const Centroid cj = cent[j];
-            bool any_long = false;
             for (uint32_t o0 = 0; o0 < 16u; o0 += per_step) {
                 const uint32_t bi = o0 + lane / G;
                 // the shifted bounds of Bayer index bi were derived once, by lane bi (12 permutes instead of two square roots
@@ -1227,25 +1217,8 @@ __global__ __launch_bounds__(kBlock) void k_offset_candidates(const CellBounds *
                 Ug = mask_threshold(Ug);
                 const bool keep = p < n_s && r.lo <= Ug;
                 if (keep) atomicOr(&s_out[bi * 4u + (j >> 6)], 1ull << (j & 63u));
-                if (lists) {
-                    // the kept members of this offset in list order (S ascends with p): position = kept lanes before, in the group
-                    const unsigned long long kept = __ballot(keep);
-                    const unsigned long long grp = (G == 64u ? ~0ull : ((1ull << G) - 1ull)) << ((lane / G) * G);
-                    const uint32_t pos = (uint32_t)__builtin_popcountll(kept & grp & ((1ull << lane) - 1ull));
-                    const uint32_t cnt = (uint32_t)__builtin_popcountll(kept & grp);
-                    if (keep && pos < kListMax)
-                        s_rec[pos < kListBytes - 1u ? bi * kListBytes + 1u + pos : 16u * kListBytes + bi * kListBytes + (pos - (kListBytes - 1u))] = (uint8_t)j;
-                    if (p == 0u) s_rec[bi * kListBytes] = (uint8_t)(cnt <= kListMax ? cnt : 255u);
-                    if (cnt >= kListBytes) any_long = true;
-                }
             }
             __builtin_amdgcn_wave_barrier();
-            if (lists) {
-                const uint4 *src = reinterpret_cast<const uint4 *>(s_rec);
-                if (lane < 32u) reinterpret_cast<uint4 *>(lists + (uint64_t)cell * 16u * kListBytes)[lane] = src[lane];
-                if (__ballot(any_long) && lane >= 32u)               // continuation records (read only by slots whose count says so)
-                    reinterpret_cast<uint4 *>(lists + ((uint64_t)kCells + cell) * 16u * kListBytes)[lane - 32u] = src[lane];
-            }
             // the cell's 16 x words mask words are contiguous
             const uint32_t bi = lane >> 2, w = lane & 3u;
             const unsigned long long mw = s_out[lane];
@@ -1283,16 +1256,9 @@ __global__ __launch_bounds__(kBlock) void k_offset_candidates(const CellBounds *
                 const unsigned long long m = __ballot(w * 64 + lane < k && lo[w] <= U);
                 if (w < words && lane == 0) out[w] = m;
                 if (w < words) {
-                    if (lists && ((m >> lane) & 1ull)) {
-                        const uint32_t pos = n_cand + bits_below_lane(m);
-                        if (pos < kListBytes - 1u) lists[((uint64_t)cell * 16u + bi) * kListBytes + 1u + pos] = (uint8_t)(w * 64u + lane);
-                        else if (pos < kListMax)
-                            lists[(((uint64_t)kCells + cell) * 16u + bi) * kListBytes + (pos - (kListBytes - 1u))] = (uint8_t)(w * 64u + lane);
-                    }
                     n_cand += (uint32_t)__builtin_popcountll(m);
                 }
             }
-            if (lists && lane == 0) lists[((uint64_t)cell * 16u + bi) * kListBytes] = (uint8_t)(n_cand <= kListMax ? n_cand : 255u);
             continue;
         }
         for (uint32_t j = lane; j < k; j += 64) {
@@ -1316,135 +1282,11 @@ __global__ __launch_bounds__(kBlock) void k_offset_candidates(const CellBounds *
 }
 
 hipError_t launch_offset_candidates(const CellBounds *bounds, const Centroid *cent, uint32_t k, float threshold,
-                                    uint64_t *masks, uint8_t *lists, hipStream_t st)
+                                    uint64_t *masks, hipStream_t st)
 {
     hipLaunchKernelGGL(k_offset_candidates, dim3(kCells / (kBlock / 64)), dim3(kBlock), 0, st, bounds, cent, k,
-                       threshold, masks, k <= 256 ? lists : nullptr);
+                       threshold, masks);
     return hipGetLastError();
-}
-
-// The pruned dither pass over byte LISTS (64 < k <= 256).  The pass is VALU-bound, and walking a 256-bit mask costs ~30 vector
-// instructions per candidate (64-bit find-first / clear per lane); a list entry costs ~20 -- one bit-field extract with a
-// compile-time position (the loop is fully unrolled, a wave leaves it at its longest list) instead of the bit scan.
-// Same candidates in the same (ascending) order as the masks, so the same result; a slot with more than kListMax candidates
-// (count byte 255) scans all centroids.
-__global__ __launch_bounds__(kBlock) void k_dither_lists(const uint32_t *__restrict__ rgba, uint32_t w, uint64_t n,
-                                                         uint32_t row0, const Centroid *__restrict__ cent, uint32_t k,
-                                                         const float *__restrict__ lut, const uint32_t *__restrict__ pal,
-                                                         float threshold, const uint8_t *__restrict__ lists,
-                                                         uint32_t *__restrict__ out, int aligned)
-{
-    extern __shared__ float4 smem4[];
-    const uint32_t kpad = (k + 3u) & ~3u;
-    float4 *s_cent = smem4;
-    float *s_lut = reinterpret_cast<float *>(smem4 + kpad);
-    float *s_off = s_lut + 256;
-    s_lut[threadIdx.x] = lut[threadIdx.x];
-    stage_centroids(s_cent, cent, k, kpad);
-    if (threadIdx.x < 16) s_off[threadIdx.x] = threshold * (bayer16(threadIdx.x) / 16.0f - 0.5f);
-    __syncthreads();
-    const float sentinel_C = chroma(10000.0f, 10000.0f);
-    constexpr uint64_t TILE = (uint64_t)kBlock * 4;
-    const uint64_t tiles = (n + TILE - 1) / TILE;
-    for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const uint64_t i0 = tile * TILE + (uint64_t)threadIdx.x * 4;
-        uint32_t px[4];
-        load4_stream(rgba, i0, n, aligned != 0, px);
-        const uint32_t i32 = (uint32_t)i0;                          // n < 2^32
-        uint32_t gy = i32 / w, gx = i32 - gy * w;
-        gy += row0;
-        uint32_t slot[4];
-        uint4 rec[4][2];                                            // the four pixels' lists, in flight during the Lab conversions
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t bi = (gx & 3u) + ((gy & 3u) << 2);
-            const uint32_t cell = (((px[q] >> 3) & 31u) << 10) | (((px[q] >> 11) & 31u) << 5) | ((px[q] >> 19) & 31u);
-            slot[q] = cell * 16u + bi;
-            const uint4 *r = reinterpret_cast<const uint4 *>(lists + (uint64_t)slot[q] * kListBytes);
-            rec[q][0] = r[0]; rec[q][1] = r[1];
-            gx += 1;
-            if (gx == w) { gx = 0; gy += 1; }
-        }
-        uint32_t res[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float L, a, b;
-            px_to_lab(s_lut, px[q], L, a, b);
-            const float off = s_off[slot[q] & 15u];
-            L = L + off; a = a + off; b = b + off;                   // mix_colors.wgsl:72
-            const PixelTerms pt = pixel_terms_fast(L, a, b, chroma(a, b));
-            float best = cie94_key(pt, 10000.0f, 10000.0f, 10000.0f, sentinel_C), second = 3.0e38f;
-            uint32_t idx = k;
-            const uint32_t cnt_raw = rec[q][0].x & 255u;
-            const bool over = cnt_raw == 255u;
-            const uint32_t cnt = over ? 0u : cnt_raw;
-            uint4 more0 = make_uint4(0u, 0u, 0u, 0u), more1 = more0;    // the continuation record of a long list
-            if (cnt >= kListBytes) {
-                const uint4 *r = reinterpret_cast<const uint4 *>(lists + ((uint64_t)kCells * 16u + slot[q]) * kListBytes);
-                more0 = r[0]; more1 = r[1];
-            }
-            // byte t of the list's 64 bytes: [count][index 0 .. 62]
-            const uint32_t rw[16] = {rec[q][0].x, rec[q][0].y, rec[q][0].z, rec[q][0].w, rec[q][1].x, rec[q][1].y, rec[q][1].z, rec[q][1].w,
-                                     more0.x, more0.y, more0.z, more0.w, more1.x, more1.y, more1.z, more1.w};
-            uint32_t longest = cnt;                                 // the wave's longest list
-            for (int o = 32; o > 0; o >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, o, 64));
-            longest = __builtin_amdgcn_readfirstlane(longest);
-#pragma unroll
-            for (uint32_t i = 0; i < kListMax; ++i) {
-                if (i >= longest) break;
-                if (i < cnt) {
-                    const uint32_t j = (rw[(i + 1u) >> 2] >> (8u * ((i + 1u) & 3u))) & 255u;
-                    const float4 c = s_cent[j];
-                    const float d = cie94_key(pt, c.x, c.y, c.z, c.w);
-                    second = __builtin_amdgcn_fmed3f(d, best, second);
-                    if (d < best) { best = d; idx = j; }
-                }
-            }
-            if (__ballot(over)) {                                   // a list that did not fit: every centroid, in order
-                for (uint32_t j = 0; j < k; ++j) {
-                    if (over) {
-                        const float4 c = s_cent[j];
-                        const float d = cie94_key(pt, c.x, c.y, c.z, c.w);
-                        second = __builtin_amdgcn_fmed3f(d, best, second);
-                        if (d < best) { best = d; idx = j; }
-                    }
-                }
-            }
-            const float thr = tie_threshold(best);
-            const bool near = second <= thr;
-            if (__ballot(near)) {
-                // near-tie (kmg_math.h): mix_colors.wgsl:73-80 with the literal distance, the sentinel first, same order
-                float lb = cie94_c(pt.L, pt.a, pt.b, pt.C, 10000.0f, 10000.0f, 10000.0f, sentinel_C);
-                uint32_t li = k;
-#pragma unroll
-                for (uint32_t i = 0; i < kListMax; ++i) {
-                    if (i >= longest) break;
-                    if (near && i < cnt) {
-                        const uint32_t j = (rw[(i + 1u) >> 2] >> (8u * ((i + 1u) & 3u))) & 255u;
-                        const float4 c = s_cent[j];
-                        if (cie94_key(pt, c.x, c.y, c.z, c.w) <= thr) {
-                            const float d = cie94_c(pt.L, pt.a, pt.b, pt.C, c.x, c.y, c.z, c.w);
-                            if (d < lb) { lb = d; li = j; }
-                        }
-                    }
-                }
-                if (__ballot(near && over)) {
-                    for (uint32_t j = 0; j < k; ++j) {
-                        if (near && over) {
-                            const float4 c = s_cent[j];
-                            if (cie94_key(pt, c.x, c.y, c.z, c.w) <= thr) {
-                                const float d = cie94_c(pt.L, pt.a, pt.b, pt.C, c.x, c.y, c.z, c.w);
-                                if (d < lb) { lb = d; li = j; }
-                            }
-                        }
-                    }
-                }
-                if (near) idx = li;
-            }
-            res[q] = pal[idx];
-        }
-        store4_stream(out, i0, n, aligned != 0, res);
-    }
 }
 
 // out[i] = pal[arg-min over the candidates of (cell, Bayer index) of the key of Lab(pixel) + off];
@@ -1722,7 +1564,7 @@ __global__ __launch_bounds__(kBlock) void k_dither_sorted(const uint32_t *__rest
 
 hipError_t launch_dither_pruned(const uint32_t *rgba, uint32_t w, uint32_t rows, uint32_t row0, const Centroid *cent,
                                 uint32_t k, const float *lut, const uint32_t *pal, float threshold,
-                                const uint64_t *masks, const uint8_t *lists, uint32_t *out, hipStream_t st)
+                                const uint64_t *masks, uint32_t *out, hipStream_t st)
 {
     const uint64_t n = (uint64_t)w * rows;
     const uint64_t tiles = (n + kBlock * 4 - 1) / (kBlock * 4);
@@ -1733,16 +1575,6 @@ hipError_t launch_dither_pruned(const uint32_t *rgba, uint32_t w, uint32_t rows,
                          (reinterpret_cast<uintptr_t>(out) & 15u) == 0) ? 1 : 0;
     uint32_t knock = 0;
     if (const char *e = getenv("KMG_DITHER_KNOCK")) knock = (uint32_t)atoi(e);
-    static const bool use_lists = !(getenv("KMG_DITHER_LISTS") && atoi(getenv("KMG_DITHER_LISTS")) == 0);
-    if (lists && use_lists && !knock && k > 64 && k <= 256) {
-        // 64 < k <= 256: byte lists instead of mask words.  Measured on 8192^2, k = 256 (round 3, profiles/r03*_apply_*): mask
-        // words 1.44 ms, mask words with the tile sorted by list length and the words re-fetched in sorted order 1.38, lists with
-        // the tile sorted 1.41 (84 registers), lists unsorted 1.35 -- every variant lands within 6 %: at this k the pass is bound
-        // by the divergent 16-byte LDS reads of the candidates' centroids as much as by vector issue.
-        hipLaunchKernelGGL(k_dither_lists, dim3(grid), dim3(kBlock), lds, st, rgba, w, n, row0, cent, k, lut, pal, threshold, lists,
-                           out, aligned);
-        return hipGetLastError();
-    }
 #define KMG_DP(W) hipLaunchKernelGGL(k_dither_pruned<W>, dim3(grid), dim3(kBlock), lds, st, rgba, w, n, row0, cent, k, lut, \
                                      pal, threshold, masks, out, aligned, knock)
     const uint32_t n_words = (k + 63u) / 64u;
@@ -1750,7 +1582,7 @@ hipError_t launch_dither_pruned(const uint32_t *rgba, uint32_t w, uint32_t rows,
     if (sorted && !knock && n_words == 1u) {
         // the pixels of a tile sorted by candidate-list length (k_dither_sorted): 8192^2, 64-entry palette 0.95 -> 0.88 ms.
         // With more mask words the records outgrow the LDS a well-occupied CU can give them (k = 256, 2 pixels per
-        // thread: 1.56 -> 1.72 ms), so those take the byte lists above.
+        // thread: 1.56 -> 1.72 ms); k <= 256 takes the byte lists of kmg_dither.hip.
         const uint32_t ppt = 4u;
         const uint32_t tile = kBlock * ppt;
         const uint64_t tiles_s = (n + tile - 1) / tile;

@@ -131,6 +131,24 @@ __device__ __forceinline__ uint32_t wave_add_u32(uint32_t v)
     return lane_value(v, 63);
 }
 
+// max over the wave of a per-lane u32 (uniform result): six DPP steps and one v_readlane, no LDS permutes
+__device__ __forceinline__ uint32_t wave_max_u32_dpp(uint32_t v)
+{
+    v = max(v, dpp_u32<kDppXor1>(v));
+    v = max(v, dpp_u32<kDppXor2>(v));
+    v = max(v, dpp_u32<kDppHalfMirror>(v));
+    v = max(v, dpp_u32<kDppMirror>(v));                          // every lane: the maximum of its row of 16
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false));
+    return lane_value(v, 63);
+}
+
+__device__ __forceinline__ float bayer16(uint32_t i)            // mix_colors.wgsl:13-16
+{
+    constexpr uint64_t M = 0x5D7F91B36E4CA280ull;               // 0 8 2 10 12 4 14 6 3 11 1 9 15 7 13 5, 4 bits each
+    return (float)((M >> (4u * i)) & 15ull);
+}
+
 // median of three unsigned values (one v_med3_u32; clang has a builtin for the float form only)
 __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c)
 {
