@@ -779,7 +779,7 @@ extern "C" int kmg_debug_check_dither_masks(kmg_processor *p, const float *c4, u
     if (k <= 256u) {                                        // the byte lists over Lab cells (kmg_dither.hip), same counter
         DevBuf lists;
         HIP_TRY(lists.alloc(kLabListBytes));
-        HIP_TRY(launch_lab_candidates((const Centroid *)cent.ptr, k, (uint8_t *)lists.ptr, S(stream)));
+        HIP_TRY(launch_lab_candidates((const Centroid *)cent.ptr, k, thr, (uint8_t *)lists.ptr, S(stream)));
         HIP_TRY(launch_check_lab_lists((const Centroid *)cent.ptr, k, (const uint8_t *)lists.ptr, p->d_lut, thr,
                                        (unsigned long long *)viol.ptr, S(stream)));
         HIP_TRY(hipStreamSynchronize(S(stream)));
@@ -1753,7 +1753,7 @@ extern "C" int kmg_dev_apply(kmg_processor *p, const uint8_t *d_rgba, uint32_t w
         // pixel's candidates only
         if (dither_lists) {
             uint8_t *lst = (uint8_t *)arena.take(kLabListBytes);
-            e = launch_lab_candidates(d_cent, k, lst, S(stream));
+            e = launch_lab_candidates(d_cent, k, thr, lst, S(stream));
             if (e == hipSuccess)
                 e = launch_dither_lists((const uint32_t *)d_rgba, w, rows, row0, d_cent, k, p->d_lut, d_pal, thr, lst,
                                         (uint32_t *)d_out, S(stream));

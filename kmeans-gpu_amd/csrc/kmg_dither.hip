@@ -68,7 +68,10 @@ __device__ __forceinline__ CellBounds lab_cell_bounds(uint32_t iL, uint32_t ia, 
 // it can neither win nor look like a near-tie --, or index 255 when k < 256, which the pass keeps far away: the pass walks whole
 // list words without asking which bytes are entries.
 // One wave per cell; lane j (+ 64, 128, 192) bounds centroid j over the cell (key_range, kmg_table_dev.h).
-__global__ __launch_bounds__(kBlock) void k_lab_candidates(const Centroid *__restrict__ cent, uint32_t k, uint8_t *__restrict__ lists)
+struct LabReach { float L0, L1, a0, a1, b0, b1; };                // the part of Lab an image can reach (launch_lab_candidates)
+
+__global__ __launch_bounds__(kBlock) void k_lab_candidates(const Centroid *__restrict__ cent, uint32_t k, LabReach reach,
+                                                           uint8_t *__restrict__ lists)
 {
     __shared__ uint8_t s_rec_all[kBlock / 64][2 * kListBytes];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -76,7 +79,13 @@ __global__ __launch_bounds__(kBlock) void k_lab_candidates(const Centroid *__res
     const uint32_t cell = blockIdx.x * (kBlock / 64) + wv;
     if (cell >= kLabCells) return;
     const uint32_t ib = cell % (uint32_t)kLabNA, ia = (cell / (uint32_t)kLabNA) % (uint32_t)kLabNA, iL = cell / (uint32_t)(kLabNA * kLabNA);
-    const bool rim = iL == 0u || iL == (uint32_t)kLabNL - 1u || ia == 0u || ia == (uint32_t)kLabNA - 1u || ib == 0u || ib == (uint32_t)kLabNA - 1u;
+    bool rim = iL == 0u || iL == (uint32_t)kLabNL - 1u || ia == 0u || ia == (uint32_t)kLabNA - 1u || ib == 0u || ib == (uint32_t)kLabNA - 1u;
+    {
+        // cells no pixel of an sRGB image comes near under this threshold get no list either (two thirds of the grid; a pixel
+        // that lands there all the same scans everything)
+        const float L = kLabL0 + kLabStep * (float)iL, a = kLabA0 + kLabStep * (float)ia, b = kLabA0 + kLabStep * (float)ib;
+        rim = rim || L + kLabStep < reach.L0 || L > reach.L1 || a + kLabStep < reach.a0 || a > reach.a1 || b + kLabStep < reach.b0 || b > reach.b1;
+    }
     uint4 *first = reinterpret_cast<uint4 *>(lists + (uint64_t)cell * kListBytes);
     if (rim) {                                                      // (uniform: one wave, one cell)
         if (lane < 2u) first[lane] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
@@ -127,10 +136,15 @@ __global__ __launch_bounds__(kBlock) void k_lab_candidates(const Centroid *__res
     else if (lane < 4u) reinterpret_cast<uint4 *>(lists + ((uint64_t)kLabCells + cell) * kListBytes)[lane - 2u] = src[lane];
 }
 
-hipError_t launch_lab_candidates(const Centroid *cent, uint32_t k, uint8_t *lists, hipStream_t st)
+hipError_t launch_lab_candidates(const Centroid *cent, uint32_t k, float threshold, uint8_t *lists, hipStream_t st)
 {
     if (k > 256u) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_lab_candidates, dim3((kLabCells + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, st, cent, k, lists);
+    // sRGB in the shader's Lab: L 0 .. 100, a -86.2 .. 98.3, b -107.9 .. 94.5 (one cell of margin), moved by the 16 offsets
+    // threshold (0 .. 15) / 16 - threshold / 2.  Only speed depends on this box.
+    const float t = threshold == threshold ? threshold : 0.0f;
+    const float o0 = fminf(t * -0.5f, t * 0.4375f), o1 = fmaxf(t * -0.5f, t * 0.4375f);
+    const LabReach reach = {-4.0f + o0, 104.0f + o1, -91.0f + o0, 103.0f + o1, -112.0f + o0, 99.0f + o1};
+    hipLaunchKernelGGL(k_lab_candidates, dim3((kLabCells + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, st, cent, k, reach, lists);
     return hipGetLastError();
 }
 

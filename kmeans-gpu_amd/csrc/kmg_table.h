@@ -216,7 +216,7 @@ hipError_t launch_dither_pruned(const uint32_t *rgba, uint32_t w, uint32_t rows,
 constexpr uint32_t kListBytes = 32, kListMax = 2 * kListBytes - 1;
 constexpr uint32_t kLabCells = 40u * 72u * 72u;
 constexpr size_t kLabListBytes = 2ull * kLabCells * kListBytes;
-hipError_t launch_lab_candidates(const Centroid *cent, uint32_t k, uint8_t *lists, hipStream_t st);
+hipError_t launch_lab_candidates(const Centroid *cent, uint32_t k, float threshold, uint8_t *lists, hipStream_t st);
 hipError_t launch_dither_lists(const uint32_t *rgba, uint32_t w, uint32_t rows, uint32_t row0, const Centroid *cent, uint32_t k,
                                const float *lut, const uint32_t *pal, float threshold, const uint8_t *lists, uint32_t *out,
                                hipStream_t st);

@@ -28,7 +28,7 @@ for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
         kn = r["Kernel_Name"].split("(")[0]
         acc[kn][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for kn, d in sorted(acc.items()):
-    if not any(t in kn for t in ("k_dither", "k_offset", "k_meld", "k_labels", "k_cube", "k_apply")): continue
+    if not any(t in kn for t in ("k_dither", "k_offset", "k_lab_", "k_meld", "k_labels", "k_cube", "k_apply")): continue
     print(kn)
     for c, v in sorted(d.items()):
         print(f"  {c:36s} mean/launch {sum(v)/len(v):16.1f}  launches {len(v)}")
