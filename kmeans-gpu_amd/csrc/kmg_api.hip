@@ -526,17 +526,20 @@ static bool replace_table_pays(uint64_t n, uint32_t k)
     return table < brute;
 }
 
-// Dither output pass: per-pixel scan of all k centroids, or of the candidates of the pixel's
-// (colour cell, Bayer index) only.  Measured on MI355X (tools/dither_probe.py): building the 2^19
-// masks costs 0.11 ms per 64 centroids, the pruned pass then saves 13 ps (k = 64) .. 28 ps (k = 256)
-// per pixel of a noise image (more on photographs); below k = 32 the scan of all centroids wins.
+// Dither output pass: per-pixel scan of all k centroids, or of the candidates of the pixel's cell only (k <= 256: byte lists per
+// cell of a grid over Lab, kmg_dither.hip; above: mask words per (RGB cell, Bayer index)).  Measured on MI355X, noise images,
+// random palettes (tools/dither_crossover.py -> profiles/r03_dither_crossover.txt): the scan costs 6.5 + 0.275 k ps per pixel,
+// the list pass 6.8 + 0.02 k ps per pixel after ~45 us for the lists and their launch; with k >= 128 the scan's own latency
+// (one wave walks all k) makes the lists win on any image.
 static bool dither_pruning_pays(uint64_t n, uint32_t k)
 {
     if (const char *e = getenv("KMG_STRATEGY")) {
         if (!strcmp(e, "brute")) return false;
         if (!strcmp(e, "table")) return true;
     }
-    return k >= 32 && n >= (k >= 128 ? 6000000ull : 12000000ull);   // per-pixel saving grows with k, 43 ps at k = 256
+    if (k > 256u) return n >= 4000000ull;                  // mask words: 0.55 ms of masks at k = 512
+    if (k >= 128u) return n >= 16384ull;
+    return (double)n * (0.255 * k - 0.3) > 45.0e6;          // ps saved per pixel x pixels > 45 us
 }
 
 // Meld output pass: ordered scan of all k centroids per pixel, or of the candidates of the pixel's colour

@@ -34,6 +34,7 @@ def _centroid_sets(oracle, rng):
     sets["duplicates"] = np.concatenate([lab[:8], lab[:8], lab[3:4]])
     sets["tight"] = (lab[5] + rng.normal(0, 0.5, (40, 3))).astype(np.float32)
     sets["outside"] = np.array([[150, 0, 0], [-50, 0, 0], [50, 300, -300], [50, 0.001, -0.001]], np.float32)
+    sets["crowded100"] = np.concatenate([(lab[7] + rng.normal(0, 0.3, (100, 3))).astype(np.float32), lab[100:256]])   # > 63 candidates
     return {k: oracle.centroids4(v) for k, v in sets.items()}
 
 
@@ -472,6 +473,37 @@ def test_dither_output_pass_pruned_equals_scan(torch_cuda, oracle, monkeypatch, 
         assert np.array_equal(out.cpu().numpy().reshape(h, w, 4), want), strategy
         assert np.array_equal(band.cpu().numpy().reshape(r1 - r0, w, 4), want[r0:r1]), strategy
         p.close()
+
+
+@pytest.mark.parametrize("name", ["black_white", "crowded45", "crowded200"])
+def test_dither_lists_continued_overflowing_and_missing(torch_cuda, oracle, monkeypatch, name):
+    """the list pass (k <= 256, kmg_dither.hip) where its lists are not one plain record: a two-colour palette whose threshold
+    throws dark pixels off the grid over Lab (no list: every centroid is scanned), 45 near-identical colours (continuation
+    records), 200 of them (more than 63 candidates: no list) -- bytes equal the oracle's"""
+    import kmeans_gpu_amd as kg
+    torch = torch_cuda
+    rng = np.random.default_rng(len(name))
+    w, h = 640, 301
+    img = np.concatenate([_blobs(rng, w * 150, 12, sigma=30.0), oracle.synth_uniform(77, w * 151)]).reshape(h, w, 4)
+    if name == "black_white":
+        pal = np.array([[0, 0, 0, 255], [255, 255, 255, 255]], np.uint8)
+    else:
+        m = 45 if name == "crowded45" else 200
+        block = np.array([(120 + i % 6, 130 + (i // 6) % 6, 90 + i // 36, 255) for i in range(m)], np.uint8)
+        rest = oracle.synth_uniform(5, 256 - m)
+        pal = np.array(sorted(set(map(tuple, np.concatenate([block, rest])))), np.uint8)
+        img[:100, :, :3] = np.clip(rng.normal((122, 132, 92), 6.0, (100, w, 3)), 0, 255).astype(np.uint8)   # pixels among the crowd
+    cent = kg.palette_to_centroids(pal)
+    monkeypatch.setenv("KMG_STRATEGY", "table")
+    p = kg.ImageProcessor()
+    d = _dev(torch, img.reshape(-1, 4))
+    out = torch.zeros((w * h, 4), dtype=torch.uint8, device="cuda")
+    p.apply(d.data_ptr(), w, h, 0, cent, kg.ReduceMode.Dither, out.data_ptr(), _stream(torch))
+    torch.cuda.synchronize()
+    want = oracle.find(img, pal, oracle.MODE_DITHER)
+    got = out.cpu().numpy().reshape(h, w, 4)
+    assert np.array_equal(got, want), f"{int((got != want).any(-1).sum())} pixels differ"
+    p.close()
 
 
 @pytest.mark.parametrize("kind,w,h,k", [("tokyo", 256, 171, 2), ("tokyo", 256, 171, 33), ("few", 67, 41, 6),
