@@ -80,6 +80,11 @@ KMG_API int kmg_debug_block_counts(kmg_processor *p, uint64_t out[2]);
  * the device by the encode of lab_to_rgb.wgsl:21-35 itself; *mismatches = the float values (every bit pattern, NaN aside)
  * for which table and encode give different bytes (0 = the table IS the encode).                                     */
 KMG_API int kmg_debug_encode_table_check(kmg_processor *p, uint64_t *mismatches);
+/* Test support: the device divides by the constants of lab_to_rgb.wgsl:45-59 (116, 500, 200, 100, 7.787) and of
+ * rgb_to_lab.wgsl (the white point) with a reciprocal and one residual correction; out[0] = the number of binary32 x (every
+ * bit pattern, NaN aside) for which that is not the IEEE quotient x / c, out[1] / out[2] = the smallest / largest |x| bit
+ * pattern among them (out[1] = 2^64 - 1 when there is none).                                                          */
+KMG_API int kmg_debug_division_check(kmg_processor *p, float c, uint64_t out[3]);
 
 /* ---- ImageProcessor::palette  (core/src/lib.rs:67-77, 255-286) -------------------------
  * out_rgba: capacity color_count*4 bytes; *out_count receives the number of colours

@@ -310,6 +310,21 @@ extern "C" int kmg_debug_encode_table_check(kmg_processor *p, uint64_t *mismatch
     return KMG_OK;
 }
 
+extern "C" int kmg_debug_division_check(kmg_processor *p, float c, uint64_t out[3])
+{
+    if (!p || !out) return fail(KMG_ERR_INVALID_ARGUMENT, "bad division_check arguments");
+    HIP_TRY(hipSetDevice(p->device));
+    unsigned long long *d = nullptr, h[3] = {0ull, ~0ull, 0ull};
+    hipError_t e = hipMalloc((void **)&d, sizeof h);
+    if (e == hipSuccess) e = hipMemcpy(d, h, sizeof h, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_division_check(c, d, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
+    if (d) (void)hipFree(d);
+    if (e != hipSuccess) return fail(KMG_ERR_HIP, "division check failed: %s", hipGetErrorString(e));
+    out[0] = h[0]; out[1] = h[1]; out[2] = h[2];
+    return KMG_OK;
+}
+
 extern "C" void kmg_processor_destroy(kmg_processor *p)
 {
     if (!p) return;
@@ -527,7 +542,7 @@ static bool replace_table_pays(uint64_t n, uint32_t k)
 }
 
 // Dither output pass: per-pixel scan of all k centroids, or of the candidates of the pixel's cell only (k <= 256: byte lists per
-// cell of a grid over Lab, kmg_dither.hip; above: mask words per (RGB cell, Bayer index)).  Measured on MI355X, noise images,
+// cell of a grid over Lab, kmg_lists.hip; above: mask words per (RGB cell, Bayer index)).  Measured on MI355X, noise images,
 // random palettes (tools/dither_crossover.py -> profiles/r03_dither_crossover.txt): the scan costs 6.5 + 0.275 k ps per pixel,
 // the list pass 6.8 + 0.02 k ps per pixel after ~45 us for the lists and their launch; with k >= 128 the scan's own latency
 // (one wave walks all k) makes the lists win on any image.
@@ -750,7 +765,7 @@ extern "C" int kmg_debug_check_table(kmg_lloyd *s, uint64_t out[3], void *stream
 // test support: exhaustive validation of the dither candidate masks (kmg_table.hip) for a centroid
 // table: over all 2^24 colours x 16 Bayer offsets, the arg-min over the candidates must equal the
 // brute-force arg-min.  *violations must come back 0.
-// Which pruned dither pass?  k <= 256: byte lists per cell of a grid over Lab (kmg_dither.hip); larger k: mask words per (RGB
+// Which pruned dither pass?  k <= 256: byte lists per cell of a grid over Lab (kmg_lists.hip); larger k: mask words per (RGB
 // cell, Bayer index) (kmg_table.hip).  KMG_DITHER_LISTS = 0 sends every k to the mask words, 1 (tools) keeps k <= 64 there.
 static bool dither_takes_lists(uint32_t k)
 {
@@ -779,10 +794,10 @@ extern "C" int kmg_debug_check_dither_masks(kmg_processor *p, const float *c4, u
     HIP_TRY(launch_offset_candidates(p->d_bounds, (const Centroid *)cent.ptr, k, thr, (uint64_t *)masks.ptr, S(stream)));
     HIP_TRY(launch_check_offset_masks((const Centroid *)cent.ptr, k, (const uint64_t *)masks.ptr, p->d_lut, thr,
                                       (unsigned long long *)viol.ptr, S(stream)));
-    if (k <= 256u) {                                        // the byte lists over Lab cells (kmg_dither.hip), same counter
+    if (k <= 256u) {                                        // the byte lists over Lab cells (kmg_lists.hip), same counter
         DevBuf lists;
         HIP_TRY(lists.alloc(kLabListBytes));
-        HIP_TRY(launch_lab_candidates((const Centroid *)cent.ptr, k, thr, (uint8_t *)lists.ptr, S(stream)));
+        HIP_TRY(launch_lab_candidates((const Centroid *)cent.ptr, k, thr, false, (uint8_t *)lists.ptr, S(stream)));
         HIP_TRY(launch_check_lab_lists((const Centroid *)cent.ptr, k, (const uint8_t *)lists.ptr, p->d_lut, thr,
                                        (unsigned long long *)viol.ptr, S(stream)));
         HIP_TRY(hipStreamSynchronize(S(stream)));
@@ -839,6 +854,13 @@ extern "C" int kmg_debug_check_meld_masks(kmg_processor *p, const float *c4, uin
     HIP_TRY(launch_meld_candidates(p->d_bounds, (const Centroid *)cent.ptr, k, (uint64_t *)masks.ptr, S(stream)));
     HIP_TRY(launch_check_meld_masks((const Centroid *)cent.ptr, k, (const uint64_t *)masks.ptr, p->d_lut,
                                     (unsigned long long *)viol.ptr, S(stream)));
+    DevBuf lists;
+    if (k <= 256u) {                                        // the byte lists over Lab cells (kmg_lists.hip), same counter
+        HIP_TRY(lists.alloc(kLabListBytes));
+        HIP_TRY(launch_lab_candidates((const Centroid *)cent.ptr, k, 0.0f, true, (uint8_t *)lists.ptr, S(stream)));
+        HIP_TRY(launch_check_lab_lists_two((const Centroid *)cent.ptr, k, (const uint8_t *)lists.ptr, p->d_lut,
+                                           (unsigned long long *)viol.ptr, S(stream)));
+    }
     unsigned long long h = 0;
     HIP_TRY(hipMemcpyAsync(&h, viol.ptr, sizeof h, hipMemcpyDeviceToHost, S(stream)));
     HIP_TRY(hipStreamSynchronize(S(stream)));
@@ -1705,8 +1727,9 @@ extern "C" int kmg_dev_apply(kmg_processor *p, const uint8_t *d_rgba, uint32_t w
     const size_t masks_bytes = sizeof(uint64_t) * (size_t)kCells * mask_words(k) * (dither_pruned ? 16u : 1u);
     size_t need = ArenaGuard::padded(tables_bytes);
     const bool dither_lists = dither_pruned && dither_takes_lists(k);      // byte lists over Lab cells instead of mask words
-    if (meld_masks_pay || (dither_pruned && !dither_lists)) need += ArenaGuard::padded(masks_bytes);
-    if (dither_lists) need += ArenaGuard::padded(kLabListBytes);
+    const bool meld_lists = meld_masks_pay && dither_takes_lists(k);       // the same for the meld pass's two closest
+    if ((meld_masks_pay && !meld_lists) || (dither_pruned && !dither_lists)) need += ArenaGuard::padded(masks_bytes);
+    if (dither_lists || meld_lists) need += ArenaGuard::padded(kLabListBytes);
     if (replace_table) need += ArenaGuard::padded(labels_bytes) + ArenaGuard::padded(sub_bytes) + ArenaGuard::padded(cube_masks_bytes(k)) +
                                ArenaGuard::padded(cube_work_bytes());
     ArenaGuard arena;
@@ -1727,7 +1750,12 @@ extern "C" int kmg_dev_apply(kmg_processor *p, const uint8_t *d_rgba, uint32_t w
         // fall through to the error report
     } else if (mode == KMG_MODE_MELD) {
         const uint64_t *meld_masks = nullptr;
-        if (meld_masks_pay) {
+        if (meld_lists) {
+            uint8_t *lst = (uint8_t *)arena.take(kLabListBytes);
+            e = launch_lab_candidates(d_cent, k, 0.0f, true, lst, S(stream));
+            if (e == hipSuccess)
+                e = launch_meld_lists((const uint32_t *)d_rgba, n_px, d_cent, k, p->d_lut, lst, (uint32_t *)d_out, S(stream));
+        } else if (meld_masks_pay) {
             // large image: per colour cell, the centroids that can be one of a pixel's two closest
             if ((rc = ensure_bounds(p, S(stream))) == KMG_OK) {
                 uint64_t *m = (uint64_t *)arena.take(masks_bytes);
@@ -1735,7 +1763,7 @@ extern "C" int kmg_dev_apply(kmg_processor *p, const uint8_t *d_rgba, uint32_t w
                 meld_masks = m;
             }
         }
-        if (rc == KMG_OK && e == hipSuccess)
+        if (rc == KMG_OK && e == hipSuccess && !meld_lists)
             e = launch_meld((const uint32_t *)d_rgba, n_px, d_cent, k, p->d_lut, meld_masks, (uint32_t *)d_out, S(stream));
     } else if (replace_table) {
         // replace mode on a large image: the label of a pixel depends on its colour only, so label the
@@ -1756,7 +1784,7 @@ extern "C" int kmg_dev_apply(kmg_processor *p, const uint8_t *d_rgba, uint32_t w
         // pixel's candidates only
         if (dither_lists) {
             uint8_t *lst = (uint8_t *)arena.take(kLabListBytes);
-            e = launch_lab_candidates(d_cent, k, thr, lst, S(stream));
+            e = launch_lab_candidates(d_cent, k, thr, false, lst, S(stream));
             if (e == hipSuccess)
                 e = launch_dither_lists((const uint32_t *)d_rgba, w, rows, row0, d_cent, k, p->d_lut, d_pal, thr, lst,
                                         (uint32_t *)d_out, S(stream));

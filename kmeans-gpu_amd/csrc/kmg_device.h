@@ -117,4 +117,54 @@ __device__ __forceinline__ void update_centroids(const int64_t *acc, uint32_t k,
     if (threadIdx.x == 0) *n_converged = *s_count;               // :196-202
 }
 
+// ---- Lab -> sRGB8 on the device (meld output pass: lab_to_rgb.wgsl per pixel) ------------------------------------------------
+// rgba8unorm store of a float in [0, 1]
+__device__ __forceinline__ uint32_t unorm8(float v)
+{
+    v = v > 0.0f ? v : 0.0f;
+    v = v > 1.0f ? 1.0f : v;
+    return (uint32_t)rintf(v * 255.0f);
+}
+
+__device__ __forceinline__ float srgb_encode_dev(float c)
+{
+    // lab_to_rgb.wgsl:21-35; pow(c, 1/2.4): the shared-source routine of kmg_math.h (same bytes as host and oracle)
+    return c > 0.0031308f ? 1.055f * pow_inv_2p4(c) - 0.055f : 12.92f * c;
+}
+
+__device__ __forceinline__ float lab_finv_dev(float t)
+{
+    const float t3 = t * t * t;                                  // lab_to_rgb.wgsl:45-59
+    return t3 > 0.008856f ? t3 : KMG_DIV(t - 16.0f / 116.0f, 7.787f);
+}
+
+// The byte of a linear channel value c: unorm8(srgb_encode_dev(c)) is a monotone step function of the FLOAT c, so it equals the
+// number of thresholds T[1..255] (T[b] = the smallest float whose byte is >= b) that do not exceed c -- eight steps of a
+// binary search in a 1 KiB table instead of ~120 binary64 operations of pow_inv_2p4.  The table is made on the device, by
+// that very function (k_encode_thresholds), so the bytes are the same by construction.
+__device__ __forceinline__ uint32_t encode_byte(const float *s_thr, float c)
+{
+    uint32_t b = 0;
+#pragma unroll
+    for (uint32_t step = 128u; step > 0u; step >>= 1)
+        b += c >= s_thr[b + step] ? step : 0u;
+    return b;
+}
+
+template <bool TABLE>
+__device__ __forceinline__ uint32_t lab_to_rgba8_dev(float L, float a, float b, const float *s_thr = nullptr)
+{
+    float y = KMG_DIV(L + 16.0f, 116.0f);
+    float x = KMG_DIV(a, 500.0f) + y;
+    float z = y - KMG_DIV(b, 200.0f);
+    const float X = lab_finv_dev(x) * 95.0489f, Y = lab_finv_dev(y) * 100.0f, Z = lab_finv_dev(z) * 108.8840f;
+    x = KMG_DIV(X, 100.0f); y = KMG_DIV(Y, 100.0f); z = KMG_DIV(Z, 100.0f);
+    const float r = fmaf(-0.4985314f, z, fmaf(-1.5371385f, y, 3.2404542f * x));
+    const float g = fmaf(0.0415560f, z, fmaf(1.8760108f, y, -0.9692660f * x));
+    const float bl = fmaf(1.0572252f, z, fmaf(-0.2040259f, y, 0.0556434f * x));
+    if (TABLE) return encode_byte(s_thr, r) | (encode_byte(s_thr, g) << 8) | (encode_byte(s_thr, bl) << 16) | 0xFF000000u;
+    return unorm8(srgb_encode_dev(r)) | (unorm8(srgb_encode_dev(g)) << 8) | (unorm8(srgb_encode_dev(bl)) << 16) |
+           0xFF000000u;
+}
+
 }  // namespace kmg

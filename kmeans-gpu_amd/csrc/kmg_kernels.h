@@ -57,6 +57,9 @@ hipError_t launch_apply(const uint32_t *rgba, uint32_t w, uint32_t rows, uint32_
 
 // thr[256] (device): the linear-channel thresholds of the 256 sRGB8 output bytes (k_meld), made by the device's own encode
 hipError_t launch_encode_thresholds(float *thr, hipStream_t st);
+// out[0..2] (device; the caller sets {0, ~0, 0}): mismatches of div_const(x, c) against x / c over every binary32 x, and the
+// smallest / largest |x| bit pattern among them
+hipError_t launch_division_check(float c, unsigned long long *out, hipStream_t st);
 // *bad (device, zeroed by the caller) += the floats (all of them, NaN aside) whose table byte is not the encode's byte
 hipError_t launch_encode_check(const float *thr, unsigned long long *bad, hipStream_t st);
 // meld output pass (mix_colors.wgsl main_meld + lab_to_rgb.wgsl); lut: 256 decode entries followed by the 256 thresholds

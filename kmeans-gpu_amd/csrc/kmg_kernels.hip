@@ -507,12 +507,6 @@ hipError_t launch_init_pick(const uint32_t *rgba, const float *lut, unsigned lon
 // Bilinear shrink (resize.wgsl:7-18 + the sampler of structures.rs:121-131): uv = gid / dims,
 // clamp-to-edge, linear filter with exact f32 weights, x first then y, rgba8unorm store.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t unorm8(float v)
-{
-    v = v > 0.0f ? v : 0.0f;
-    v = v > 1.0f ? 1.0f : v;
-    return (uint32_t)rintf(v * 255.0f);
-}
 
 __global__ __launch_bounds__(kBlock) void k_resize(const uint32_t *__restrict__ rgba, uint32_t w,
                                                    uint32_t h, uint32_t nw, uint32_t nh,
@@ -667,31 +661,6 @@ hipError_t launch_apply(const uint32_t *rgba, uint32_t w, uint32_t rows, uint32_
 // meld output pass: mix_colors.wgsl:29-48 two_closest_colors, :85-90 meld, :117-135 main_meld,
 // then lab_to_rgb.wgsl per pixel.  Literal CIE94 throughout (the values themselves are used).
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float srgb_encode_dev(float c)
-{
-    // lab_to_rgb.wgsl:21-35; pow(c, 1/2.4): the shared-source routine of kmg_math.h (same bytes as host and oracle)
-    return c > 0.0031308f ? 1.055f * pow_inv_2p4(c) - 0.055f : 12.92f * c;
-}
-
-__device__ __forceinline__ float lab_finv_dev(float t)
-{
-    const float t3 = t * t * t;                                  // lab_to_rgb.wgsl:45-59
-    return t3 > 0.008856f ? t3 : (t - 16.0f / 116.0f) / 7.787f;
-}
-
-// The byte of a linear channel value c: unorm8(srgb_encode_dev(c)) is a monotone step function of the FLOAT c, so it equals the
-// number of thresholds T[1..255] (T[b] = the smallest float whose byte is >= b) that do not exceed c -- eight steps of a
-// binary search in a 1 KiB table instead of ~120 binary64 operations of pow_inv_2p4.  The table is made on the device, by
-// that very function (k_encode_thresholds), so the bytes are the same by construction.
-__device__ __forceinline__ uint32_t encode_byte(const float *s_thr, float c)
-{
-    uint32_t b = 0;
-#pragma unroll
-    for (uint32_t step = 128u; step > 0u; step >>= 1)
-        b += c >= s_thr[b + step] ? step : 0u;
-    return b;
-}
-
 // thr[0] unused, thr[b] for b = 1 .. 255: the smallest float c with unorm8(srgb_encode_dev(c)) >= b (found by bisection over
 // the bit patterns of the non-negative floats, which order like the values)
 __global__ void k_encode_thresholds(float *__restrict__ thr)
@@ -736,20 +705,34 @@ hipError_t launch_encode_check(const float *thr, unsigned long long *bad, hipStr
     return hipGetLastError();
 }
 
-template <bool TABLE>
-__device__ __forceinline__ uint32_t lab_to_rgba8_dev(float L, float a, float b, const float *s_thr = nullptr)
+// Test support: for one constant c, over EVERY binary32 x (NaN aside): out[0] += #x with div_const(x, c) != x / c (bit patterns;
+// -0 and +0 differ), out[1] = the smallest and out[2] = the largest |x| (bit pattern) among them
+__global__ __launch_bounds__(kBlock) void k_division_check(float c, float rc, unsigned long long *__restrict__ out)
 {
-    float y = (L + 16.0f) / 116.0f;
-    float x = a / 500.0f + y;
-    float z = y - b / 200.0f;
-    const float X = lab_finv_dev(x) * 95.0489f, Y = lab_finv_dev(y) * 100.0f, Z = lab_finv_dev(z) * 108.8840f;
-    x = X / 100.0f; y = Y / 100.0f; z = Z / 100.0f;
-    const float r = fmaf(-0.4985314f, z, fmaf(-1.5371385f, y, 3.2404542f * x));
-    const float g = fmaf(0.0415560f, z, fmaf(1.8760108f, y, -0.9692660f * x));
-    const float bl = fmaf(1.0572252f, z, fmaf(-0.2040259f, y, 0.0556434f * x));
-    if (TABLE) return encode_byte(s_thr, r) | (encode_byte(s_thr, g) << 8) | (encode_byte(s_thr, bl) << 16) | 0xFF000000u;
-    return unorm8(srgb_encode_dev(r)) | (unorm8(srgb_encode_dev(g)) << 8) | (unorm8(srgb_encode_dev(bl)) << 16) |
-           0xFF000000u;
+    unsigned long long bad = 0;
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t v = (uint64_t)blockIdx.x * kBlock + threadIdx.x; v < (1ull << 32); v += stride) {
+        const float x = bits_to_float((uint32_t)v);
+        if (x != x) continue;
+        const float q = div_const(x, c, rc), want = x / c;
+        if (float_to_bits(q) != float_to_bits(want)) {
+            ++bad;
+            const uint32_t m = (uint32_t)v & 0x7FFFFFFFu;
+            lo = m < lo ? m : lo; hi = m > hi ? m : hi;
+        }
+    }
+    if (bad) {
+        atomicAdd(out, bad);
+        atomicMin(out + 1, (unsigned long long)lo);
+        atomicMax(out + 2, (unsigned long long)hi);
+    }
+}
+
+hipError_t launch_division_check(float c, unsigned long long *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_division_check, dim3(256 * 16), dim3(kBlock), 0, st, c, 1.0f / c, out);
+    return hipGetLastError();
 }
 
 // masks != NULL: per colour cell, the centroids that can be among the pixel's two closest (kmg_table.hip,

@@ -1,5 +1,5 @@
-// kmg_dither.hip -- the ordered-dither output pass on large images with k <= 256 (mix_colors.wgsl:50-83): candidate lists per
-// cell of a grid over Lab, and the pass that walks them.
+// kmg_lists.hip -- the ordered-dither and meld output passes on large images with k <= 256 (mix_colors.wgsl:50-83, :29-48 + :85-90):
+// candidate lists per cell of a grid over Lab, and the passes that walk them.
 //
 // A dithered pixel is compared with the centroids at Lab(pixel) + off (1, 1, 1), off one of 16 Bayer offsets.  Rounds 1-3a
 // pruned per (RGB cell, Bayer index): 2^19 slots whose 32-byte records (16.7 MiB) are fetched once per pixel from all over the
@@ -7,10 +7,12 @@
 // 1.15 ms however few instructions the list walk took.  The shifted point is an ordinary point of Lab, so the lists here belong to
 // cells of a 4 x 4 x 4 grid over Lab itself: no Bayer dimension, a tighter box than an RGB cell swept by 16 offsets, and the
 // cells an image can reach (the sRGB gamut widened by the offsets: ~20 000 of 207 360) make a table of well under 1 MiB that
-// stays in every XCD's L2.
+// stays in every XCD's L2.  The meld pass needs a pixel's two closest centroids: the same grid (no offset), lists that keep
+// whatever can be among the two.
 //
 // Exactness is the near-tie scheme of kmg_math.h: the lists keep every centroid whose lower key bound over the cell is not above
-// (1 + kMaskSlack) times the smallest upper bound, the pass orders by a key and re-decides near-ties with the literal distance.
+// (1 + kMaskSlack) times the smallest (meld: second smallest) upper bound, the passes order by a key and re-decide near-ties
+// with the literal distance.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -68,8 +70,19 @@ __device__ __forceinline__ CellBounds lab_cell_bounds(uint32_t iL, uint32_t ia, 
 // it can neither win nor look like a near-tie --, or index 255 when k < 256, which the pass keeps far away: the pass walks whole
 // list words without asking which bytes are entries.
 // One wave per cell; lane j (+ 64, 128, 192) bounds centroid j over the cell (key_range, kmg_table_dev.h).
+// TWO: the lists of the meld pass -- every centroid that can be one of the two closest: lower bound not above (1 + kMaskSlack)
+// times the SECOND smallest upper bound (k >= 2).
 struct LabReach { float L0, L1, a0, a1, b0, b1; };                // the part of Lab an image can reach (launch_lab_candidates)
 
+// (m1 <= m2) <- the two smallest of {m1, m2, o1, o2}, o1 <= o2
+__device__ __forceinline__ void two_smallest(float &m1, float &m2, float o1, float o2)
+{
+    const float lo = fminf(m1, o1), hi = fmaxf(m1, o1);
+    m2 = fminf(hi, fminf(m2, o2));
+    m1 = lo;
+}
+
+template <bool TWO>
 __global__ __launch_bounds__(kBlock) void k_lab_candidates(const Centroid *__restrict__ cent, uint32_t k, LabReach reach,
                                                            uint8_t *__restrict__ lists)
 {
@@ -93,7 +106,7 @@ __global__ __launch_bounds__(kBlock) void k_lab_candidates(const Centroid *__res
     }
     const CellBounds cb = lab_cell_bounds(iL, ia, ib);
     const uint32_t words = (k + 63u) / 64u;
-    float U = 3.0e38f, lo[4];
+    float U = 3.0e38f, U2 = 3.0e38f, lo[4];
 #pragma unroll
     for (uint32_t w = 0; w < 4u; ++w) {
         lo[w] = 3.0e38f;
@@ -102,10 +115,18 @@ __global__ __launch_bounds__(kBlock) void k_lab_candidates(const Centroid *__res
             const Centroid c = cent[j];
             const KeyRange r = key_range(cb, c.L, c.a, c.b, c.C);
             lo[w] = r.lo;
-            U = fminf(U, r.hi);
+            if (TWO) two_smallest(U, U2, r.hi, 3.0e38f); else U = fminf(U, r.hi);
         }
     }
-    U = mask_threshold(wave_min(U));                                // keep what can still be a near-tie (kmg_math.h)
+    if (TWO) {
+        for (int off = 32; off > 0; off >>= 1) {
+            const float o1 = __shfl_xor(U, off, 64), o2 = __shfl_xor(U2, off, 64);
+            two_smallest(U, U2, o1, o2);
+        }
+        U = mask_threshold(U2);
+    } else {
+        U = mask_threshold(wave_min(U));                            // keep what can still be a near-tie (kmg_math.h)
+    }
     unsigned long long m[4];
     uint32_t n_cand = 0;
 #pragma unroll
@@ -136,15 +157,17 @@ __global__ __launch_bounds__(kBlock) void k_lab_candidates(const Centroid *__res
     else if (lane < 4u) reinterpret_cast<uint4 *>(lists + ((uint64_t)kLabCells + cell) * kListBytes)[lane - 2u] = src[lane];
 }
 
-hipError_t launch_lab_candidates(const Centroid *cent, uint32_t k, float threshold, uint8_t *lists, hipStream_t st)
+hipError_t launch_lab_candidates(const Centroid *cent, uint32_t k, float threshold, bool two_closest, uint8_t *lists, hipStream_t st)
 {
-    if (k > 256u) return hipErrorInvalidValue;
+    if (k > 256u || (two_closest && k < 2u)) return hipErrorInvalidValue;
     // sRGB in the shader's Lab: L 0 .. 100, a -86.2 .. 98.3, b -107.9 .. 94.5 (one cell of margin), moved by the 16 offsets
     // threshold (0 .. 15) / 16 - threshold / 2.  Only speed depends on this box.
     const float t = threshold == threshold ? threshold : 0.0f;
     const float o0 = fminf(t * -0.5f, t * 0.4375f), o1 = fmaxf(t * -0.5f, t * 0.4375f);
     const LabReach reach = {-4.0f + o0, 104.0f + o1, -91.0f + o0, 103.0f + o1, -112.0f + o0, 99.0f + o1};
-    hipLaunchKernelGGL(k_lab_candidates, dim3((kLabCells + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, st, cent, k, reach, lists);
+    const dim3 grid((kLabCells + kBlock / 64 - 1) / (kBlock / 64));
+    if (two_closest) hipLaunchKernelGGL(k_lab_candidates<true>, grid, dim3(kBlock), 0, st, cent, k, reach, lists);
+    else hipLaunchKernelGGL(k_lab_candidates<false>, grid, dim3(kBlock), 0, st, cent, k, reach, lists);
     return hipGetLastError();
 }
 
@@ -339,6 +362,145 @@ hipError_t launch_dither_lists(const uint32_t *rgba, uint32_t w, uint32_t rows, 
     return hipGetLastError();
 }
 
+// ---- the meld pass ----------------------------------------------------------------------------------------------------------
+// mix_colors.wgsl:29-48 keeps, over an ordered scan with `<`, the two closest centroids of a pixel under the literal distance:
+// the two smallest in (distance, index) order, the sentinel (10000, 10000, 10000) filling a slot no centroid takes.  Here the
+// walk keeps the THREE smallest packed keys (index in the low byte): when the first two are separated from their successors by
+// more than the tie slack, key order is literal order and nothing outside the list is closer (k_lab_candidates<true>), so the
+// two winners are known after 13 instructions per candidate instead of the ~45 of a literal distance; their two literal
+// distances (the values mix_colors.wgsl:86-89 uses) are then computed once.  Any pixel that fails that test -- or whose second
+// key is not far below the sentinel's -- is re-scanned literally over its list, in order, exactly as the reference does.
+__device__ __forceinline__ void three_smallest(uint32_t kp, uint32_t &b, uint32_t &s, uint32_t &t)
+{
+    asm("v_med3_u32 %0, %3, %1, %0\n\tv_med3_u32 %1, %3, %2, %1\n\tv_min_u32 %2, %2, %3" : "+v"(t), "+v"(s), "+v"(b) : "v"(kp));
+}
+
+__global__ __launch_bounds__(kBlock) void k_meld_lists(const uint32_t *__restrict__ rgba, uint64_t n,
+                                                       const Centroid *__restrict__ cent, uint32_t k,
+                                                       const float *__restrict__ lut, const uint8_t *__restrict__ lists,
+                                                       uint32_t *__restrict__ out, int aligned)
+{
+    extern __shared__ float4 smem4[];
+    float4 *s_cent = smem4;
+    if ((uint32_t)reinterpret_cast<uintptr_t>(s_cent) != 0u) __builtin_trap();   // (pair_key reads the table at LDS address 0)
+    float *s_lut = reinterpret_cast<float *>(smem4 + 256);
+    float *s_thr = s_lut + 256;                                    // the thresholds of the sRGB8 encode (kmg_device.h)
+    s_lut[threadIdx.x] = lut[threadIdx.x];
+    s_thr[threadIdx.x] = lut[256 + threadIdx.x];
+    if (threadIdx.x == 0) s_thr[256] = 3.0e38f;
+    {
+        float4 c = make_float4(1.0e18f, 0.0f, 0.0f, 0.0f);
+        if (threadIdx.x < k) { const Centroid ce = cent[threadIdx.x]; c = make_float4(ce.L, ce.a, ce.b, ce.C); }
+        s_cent[threadIdx.x] = c;
+    }
+    __syncthreads();
+    const float sentinel_C = chroma(10000.0f, 10000.0f);
+    constexpr uint64_t TILE = (uint64_t)kBlock * 4;
+    const uint64_t tiles = (n + TILE - 1) / TILE;
+    for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const uint64_t i0 = tile * TILE + (uint64_t)threadIdx.x * 4;
+        uint32_t px[4];
+        load4_stream(rgba, i0, n, aligned != 0, px);
+        float pL[4], pa[4], pb[4];
+        uint32_t cell[4];
+        uint4 rec[4][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            px_to_lab(s_lut, px[q], pL[q], pa[q], pb[q]);
+            cell[q] = lab_cell_index(pL[q], pa[q], pb[q]);
+            const uint4 *r = reinterpret_cast<const uint4 *>(lists + (uint64_t)cell[q] * kListBytes);
+            rec[q][0] = r[0]; rec[q][1] = r[1];
+        }
+        uint32_t res[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float L = pL[q], a = pa[q], b = pb[q];
+            const PixelTerms pt = pixel_terms_fast(L, a, b, chroma(a, b));
+            PixelPairs pp;
+            pp.La = f32x2{pt.L, pt.a}; pp.bC = f32x2{pt.b, pt.C}; pp.wC1 = f32x2{pt.wC, 1.0f}; pp.wH = pt.wH;
+            constexpr uint32_t kSentinelFloor = 0x49742400u;          // 1.0e6f (see k_dither_lists)
+            uint32_t k1 = 0x7F7FFF00u, k2 = 0x7F7FFF00u, k3 = 0x7F7FFFFFu;
+            const uint32_t cnt_raw = rec[q][0].x & 255u;
+            const bool over = cnt_raw == 255u;
+            const uint32_t cnt = over ? 0u : cnt_raw;
+            uint4 more0 = make_uint4(0u, 0u, 0u, 0u), more1 = more0;
+            if (cnt >= kListBytes) {
+                const uint4 *r = reinterpret_cast<const uint4 *>(lists + ((uint64_t)kLabCells + cell[q]) * kListBytes);
+                more0 = r[0]; more1 = r[1];
+            }
+            const uint32_t rw[16] = {rec[q][0].x, rec[q][0].y, rec[q][0].z, rec[q][0].w, rec[q][1].x, rec[q][1].y, rec[q][1].z, rec[q][1].w,
+                                     more0.x, more0.y, more0.z, more0.w, more1.x, more1.y, more1.z, more1.w};
+            const uint32_t longest = wave_max_u32_dpp(cnt);
+#define KMG_LIST_ENTRY(WORD, P) three_smallest(list_entry_key<P>(rw[WORD], pp), k1, k2, k3);
+            if (longest) {
+                if (cnt) { KMG_LIST_ENTRY(0, 1) KMG_LIST_ENTRY(0, 2) KMG_LIST_ENTRY(0, 3) }
+            }
+#pragma unroll
+            for (int wd = 1; wd < 16; ++wd) {
+                if ((uint32_t)(wd * 4) > longest) break;
+                if ((uint32_t)(wd * 4) <= cnt) { KMG_LIST_ENTRY(wd, 0) KMG_LIST_ENTRY(wd, 1) KMG_LIST_ENTRY(wd, 2) KMG_LIST_ENTRY(wd, 3) }
+            }
+#undef KMG_LIST_ENTRY
+            if (__ballot(over)) {
+                for (uint32_t j = 0; j < k; ++j) {
+                    if (over) three_smallest((__float_as_uint(pair_key(j << 4, pp)) & ~255u) | j, k1, k2, k3);
+                }
+            }
+            // the two winners, unless something is within the tie slack of one of them
+            float cL, ca, cb, cC, sL, sa, sb, sC;                     // (.C: the chroma kept in the table -- cie94_c, kmg_math.h)
+            {
+                const float4 c1 = s_cent[k1 & 255u], c2 = s_cent[k2 & 255u];
+                cL = c1.x; ca = c1.y; cb = c1.z; cC = c1.w; sL = c2.x; sa = c2.y; sb = c2.z; sC = c2.w;
+            }
+            const bool near = __uint_as_float(k2) <= tie_threshold(__uint_as_float(k1)) ||
+                              __uint_as_float(k3) <= tie_threshold(__uint_as_float(k2)) || k2 >= kSentinelFloor || !(pt.L < 9000.0f);
+            if (__ballot(near)) {
+                // mix_colors.wgsl:30-41, literally, over the list (k_meld of kmg_kernels.hip does the same over mask words)
+                float xL = 10000.0f, xa = 10000.0f, xb = 10000.0f, xC = sentinel_C, yL = 10000.0f, ya = 10000.0f, yb = 10000.0f, yC = sentinel_C;
+                float d_closest = cie94_c(L, a, b, pt.C, xL, xa, xb, xC), d_second = d_closest;
+                auto visit = [&](uint32_t j) {
+                    const float4 c = s_cent[j];
+                    const float d = cie94_c(L, a, b, pt.C, c.x, c.y, c.z, c.w);
+                    if (d < d_closest) {
+                        yL = xL; ya = xa; yb = xb; yC = xC; d_second = d_closest;
+                        xL = c.x; xa = c.y; xb = c.z; xC = c.w; d_closest = d;
+                    } else if (d < d_second) {
+                        yL = c.x; ya = c.y; yb = c.z; yC = c.w; d_second = d;
+                    }
+                };
+                for (uint32_t i = 0; i < kListMax; ++i) {
+                    if (i >= longest) break;
+                    if (near && i < cnt) visit((rw[(i + 1u) >> 2] >> (8u * ((i + 1u) & 3u))) & 255u);
+                }
+                if (__ballot(near && over)) {
+                    for (uint32_t j = 0; j < k; ++j)
+                        if (near && over) visit(j);
+                }
+                if (near) { cL = xL; ca = xa; cb = xb; cC = xC; sL = yL; sa = ya; sb = yb; sC = yC; }
+            }
+            // :86-89
+            const float factor = cie94_c(L, a, b, pt.C, sL, sa, sb, sC) / cie94_c(cL, ca, cb, cC, sL, sa, sb, sC);
+            const float oL = factor * cL + (1.0f - factor) * sL;
+            const float oa = factor * ca + (1.0f - factor) * sa;
+            const float ob = factor * cb + (1.0f - factor) * sb;
+            res[q] = lab_to_rgba8_dev<true>(oL, oa, ob, s_thr);
+        }
+        store4_stream(out, i0, n, aligned != 0, res);
+    }
+}
+
+hipError_t launch_meld_lists(const uint32_t *rgba, uint64_t n, const Centroid *cent, uint32_t k, const float *lut,
+                             const uint8_t *lists, uint32_t *out, hipStream_t st)
+{
+    if (k < 2u || k > 256u) return hipErrorInvalidValue;
+    const uint64_t tiles = (n + kBlock * 4 - 1) / (kBlock * 4);
+    const uint32_t grid = (uint32_t)(tiles < 8192 ? (tiles ? tiles : 1) : 8192);
+    const size_t lds = sizeof(float4) * 256 + (256 + 257) * sizeof(float);
+    const int aligned = ((reinterpret_cast<uintptr_t>(rgba) & 15u) == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(k_meld_lists, dim3(grid), dim3(kBlock), lds, st, rgba, n, cent, k, lut, lists, out, aligned);
+    return hipGetLastError();
+}
+
 // ---- test support -----------------------------------------------------------------------------------------------------------
 // violations += #(colour, Bayer index) whose brute-force dither arg-min (literal distance, sentinel included) differs from the
 // arg-min over the list of its Lab cell; one workgroup per RGB cell as in the other exhaustive checks
@@ -380,6 +542,50 @@ __global__ __launch_bounds__(kBlock) void k_check_lab_lists(const Centroid *__re
         }
     }
     if (bad) atomicAdd(violations, bad);
+}
+
+// violations += #colours whose two closest centroids (mix_colors.wgsl:29-48, literal distance, sentinel included) differ
+// between the scan of all centroids and the scan of the list of the colour's Lab cell
+__global__ __launch_bounds__(kBlock) void k_check_lab_lists_two(const Centroid *__restrict__ cent, uint32_t k,
+                                                                const uint8_t *__restrict__ lists, const float *__restrict__ lut,
+                                                                unsigned long long *__restrict__ violations)
+{
+    __shared__ float s_lut[256];
+    s_lut[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    const uint32_t rgb_cell = blockIdx.x;
+    unsigned long long bad = 0;
+    for (uint32_t c = threadIdx.x; c < kCellColours; c += kBlock) {
+        float L, a, b;
+        colour_to_lab(s_lut, rgb_cell * kCellColours + c, L, a, b);
+        const uint32_t cell = lab_cell_index(L, a, b);
+        const uint8_t *rec = lists + (uint64_t)cell * kListBytes, *more = lists + ((uint64_t)kLabCells + cell) * kListBytes;
+        const uint32_t cnt = rec[0];
+        if (cnt == 255u) continue;                                   // the pass scans everything
+        const float d0 = cie94(L, a, b, 10000.0f, 10000.0f, 10000.0f);
+        float dc = d0, ds = d0, pc = d0, ps = d0;
+        uint32_t ic = k, is = k, jc = k, js = k;
+        for (uint32_t j = 0; j < k; ++j) {
+            const Centroid ce = cent[j];
+            const float d = cie94(L, a, b, ce.L, ce.a, ce.b);
+            if (d < dc) { ds = dc; is = ic; dc = d; ic = j; } else if (d < ds) { ds = d; is = j; }
+        }
+        for (uint32_t i = 0; i < cnt; ++i) {
+            const uint32_t j = i < kListBytes - 1u ? rec[1u + i] : more[i - (kListBytes - 1u)];
+            const Centroid ce = cent[j];
+            const float d = cie94(L, a, b, ce.L, ce.a, ce.b);
+            if (d < pc) { ps = pc; js = jc; pc = d; jc = j; } else if (d < ps) { ps = d; js = j; }
+        }
+        bad += (ic != jc) || (is != js);
+    }
+    if (bad) atomicAdd(violations, bad);
+}
+
+hipError_t launch_check_lab_lists_two(const Centroid *cent, uint32_t k, const uint8_t *lists, const float *lut,
+                                      unsigned long long *violations, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_check_lab_lists_two, dim3(kCells), dim3(kBlock), 0, st, cent, k, lists, lut, violations);
+    return hipGetLastError();
 }
 
 hipError_t launch_check_lab_lists(const Centroid *cent, uint32_t k, const uint8_t *lists, const float *lut, float threshold,

@@ -74,6 +74,26 @@ KMG_HD float div_white(float x)
 #endif
 }
 
+// x / c for the constants of lab_to_rgb.wgsl (116, 500, 200, 100, 7.787) on the device: the same three operations.  For which
+// x they give the IEEE quotient is not argued but counted: kmg_debug_division_check (tests/test_gpu_parity.py) tries every
+// binary32 x for every constant; outside [kDivLo, kDivHi] in magnitude (where the residual or the quotient leaves the normal
+// range) the division itself is used.
+constexpr float kDivLo = 1.0e-30f, kDivHi = 1.0e30f;
+KMG_HD float div_const(float x, float c, float rc)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float ax = __builtin_fabsf(x);
+    if (ax >= kDivLo && ax <= kDivHi) {
+        const float q0 = x * rc;
+        return fmaf(fmaf(-q0, c, x), rc, q0);
+    }
+#else
+    (void)rc;
+#endif
+    return x / c;
+}
+#define KMG_DIV(x, c) ::kmg::div_const((x), (c), 1.0f / (c))
+
 // lab_to_rgb.wgsl:21-35 `pow(c, 1.0 / 2.4)` for c in (0.0031308, 1): ONE definition shared by the device kernels
 // (meld output pass), the host palette code and -- restated operation by operation -- the oracle, so that their
 // bytes agree (two different libm / ocml `pow` implementations disagree on ~1e-5 of the channels).

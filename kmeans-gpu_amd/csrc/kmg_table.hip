@@ -1582,7 +1582,7 @@ hipError_t launch_dither_pruned(const uint32_t *rgba, uint32_t w, uint32_t rows,
     if (sorted && !knock && n_words == 1u) {
         // the pixels of a tile sorted by candidate-list length (k_dither_sorted): 8192^2, 64-entry palette 0.95 -> 0.88 ms.
         // With more mask words the records outgrow the LDS a well-occupied CU can give them (k = 256, 2 pixels per
-        // thread: 1.56 -> 1.72 ms); k <= 256 takes the byte lists of kmg_dither.hip.
+        // thread: 1.56 -> 1.72 ms); k <= 256 takes the byte lists of kmg_lists.hip.
         const uint32_t ppt = 4u;
         const uint32_t tile = kBlock * ppt;
         const uint64_t tiles_s = (n + tile - 1) / tile;

@@ -82,7 +82,7 @@ SYMBOLS = [
     "kmg_lloyd_unbind_image", "kmg_lloyd_prepare", "kmg_debug_check_table", "kmg_debug_table_stats", "kmg_debug_check_pairs", "kmg_debug_check_dither_masks", "kmg_debug_check_meld_masks", "kmg_kernel_name",
     "kmg_lloyd_profile", "kmg_lloyd_profile_read",
     "kmg_lloyd_update", "kmg_lloyd_assign_update", "kmg_lloyd_set_cell_share", "kmg_lloyd_labels_from_tables",
-    "kmg_lloyd_table_buffers", "kmg_lloyd_histogram_buffer", "kmg_lloyd_rebuild_from_histogram", "kmg_debug_block_counts", "kmg_debug_encode_table_check", "kmg_lloyd_converged_count", "kmg_lloyd_iterate", "kmg_lloyd_flush", "kmg_lloyd_run", "kmg_dev_apply",
+    "kmg_lloyd_table_buffers", "kmg_lloyd_histogram_buffer", "kmg_lloyd_rebuild_from_histogram", "kmg_debug_block_counts", "kmg_debug_encode_table_check", "kmg_debug_division_check", "kmg_lloyd_converged_count", "kmg_lloyd_iterate", "kmg_lloyd_flush", "kmg_lloyd_run", "kmg_dev_apply",
     "kmg_dither_threshold",
 ]
 
@@ -158,6 +158,7 @@ def lib():
     L.kmg_lloyd_labels_from_tables.argtypes = [vp, u8p, C.c_uint64, u32p, vp]
     L.kmg_debug_block_counts.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.kmg_debug_encode_table_check.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.kmg_debug_division_check.argtypes = [vp, C.c_float, C.POINTER(C.c_uint64)]
     L.kmg_lloyd_histogram_buffer.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     L.kmg_lloyd_rebuild_from_histogram.argtypes = [vp, C.c_uint64, vp]
     L.kmg_lloyd_table_buffers.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
@@ -318,6 +319,12 @@ class ImageProcessor:
         out = C.c_uint64(0)
         _check(lib().kmg_debug_encode_table_check(self._h, C.byref(out)))
         return int(out.value)
+
+    def debug_division_check(self, c):
+        """(mismatches, smallest |x| bits, largest |x| bits) of the device's x / c against IEEE division over every float x"""
+        out = (C.c_uint64 * 3)()
+        _check(lib().kmg_debug_division_check(self._h, C.c_float(c), out))
+        return int(out[0]), int(out[1]), int(out[2])
 
     def debug_check_dither_masks(self, centroids4, stream=0):
         """exhaustive check of the pruned dither pass's candidate masks; returns the violation count"""

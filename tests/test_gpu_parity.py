@@ -281,6 +281,14 @@ def test_meld_encode_table_is_the_encode_for_every_float(processor):
     assert processor.debug_encode_table_check() == 0
 
 
+@pytest.mark.parametrize("c", [116.0, 500.0, 200.0, 100.0, 7.787, 95.0489, 108.8840])
+def test_device_division_by_the_shader_constants_is_the_ieee_quotient(processor, c):
+    """lab_to_rgb.wgsl:45-59 / rgb_to_lab.wgsl divide by constants; the device multiplies by the reciprocal and corrects once
+    with the residual (kmg_math.h div_const / div_white).  Compared with x / c for EVERY float x"""
+    bad, lo, hi = processor.debug_division_check(c)
+    assert bad == 0, f"{bad} of 2^32 quotients differ, |x| bit patterns {lo:#x} .. {hi:#x}"
+
+
 def test_reduce_meld_end_to_end(processor, oracle, tokyo):
     got = processor.reduce(6, tokyo, reduce_mode=2)
     want = oracle.reduce(tokyo, 6, oracle.MODE_MELD)

@@ -477,7 +477,7 @@ def test_dither_output_pass_pruned_equals_scan(torch_cuda, oracle, monkeypatch, 
 
 @pytest.mark.parametrize("name", ["black_white", "crowded45", "crowded200"])
 def test_dither_lists_continued_overflowing_and_missing(torch_cuda, oracle, monkeypatch, name):
-    """the list pass (k <= 256, kmg_dither.hip) where its lists are not one plain record: a two-colour palette whose threshold
+    """the list pass (k <= 256, kmg_lists.hip) where its lists are not one plain record: a two-colour palette whose threshold
     throws dark pixels off the grid over Lab (no list: every centroid is scanned), 45 near-identical colours (continuation
     records), 200 of them (more than 63 candidates: no list) -- bytes equal the oracle's"""
     import kmeans_gpu_amd as kg
