@@ -603,18 +603,19 @@ def test_run_twice_on_one_buffer_with_set_centroids(torch_cuda, oracle, monkeypa
     p.close()
 
 
-@pytest.mark.parametrize("k", [24, 300])
-def test_pipelined_iterate_equals_step_by_step(torch_cuda, oracle, monkeypatch, k):
-    """kmg_lloyd_iterate (label pass of iteration t on the side stream beside the cube pass of t + 1, two
-    alternating sets of label tables) gives the same centroids, sums and -- after every iteration -- the same
-    label map as update + assign_accumulate step by step, and as the oracle."""
+@pytest.mark.parametrize("k,kind", [(24, "blobs"), (300, "blobs"), (64, "uniform"), (256, "uniform")])
+def test_pipelined_iterate_equals_step_by_step(torch_cuda, oracle, monkeypatch, k, kind):
+    """kmg_lloyd_iterate (label pass of iteration t on the side stream beside the scan of iteration t + 1, issued by the
+    next call or by a flush; two alternating sets of label tables) gives the same centroids, sums and -- after every
+    iteration -- the same label map as update + assign_accumulate step by step, and as the oracle.  Noise has no hot cells
+    (the label pass shares its compute units); blobs have them, and k = 300 has no pair tables (serial order inside)."""
     import kmeans_gpu_amd as kg
     torch = torch_cuda
     st = _stream(torch)
     monkeypatch.setenv("KMG_STRATEGY", "table")
     w, h = 700, 500
     n = w * h
-    img = _blobs(np.random.default_rng(k), n, 40, sigma=25.0)
+    img = _blobs(np.random.default_rng(k), n, 40, sigma=25.0) if kind == "blobs" else oracle.synth_uniform(k, n)
     lab = oracle.rgb_to_lab(img)
     init = oracle.centroids4(lab[np.random.default_rng(1).choice(n, k, replace=False)])
     d = _dev(torch, img)
