@@ -72,7 +72,8 @@ __device__ __forceinline__ CellBounds lab_cell_bounds(uint32_t iL, uint32_t ia, 
 // One wave per cell; lane j (+ 64, 128, 192) bounds centroid j over the cell (key_range, kmg_table_dev.h).
 // TWO: the lists of the meld pass -- every centroid that can be one of the two closest: lower bound not above (1 + kMaskSlack)
 // times the SECOND smallest upper bound (k >= 2).
-struct LabReach { float L0, L1, a0, a1, b0, b1; };                // the part of Lab an image can reach (launch_lab_candidates)
+// the part of the grid an image can reach (launch_lab_candidates): cells [L0, L0 + nL) x [a0, a0 + nA) x [b0, b0 + nB), all interior
+struct LabReach { uint32_t L0, a0, b0, nL, nA, nB; };
 
 // (m1 <= m2) <- the two smallest of {m1, m2, o1, o2}, o1 <= o2
 __device__ __forceinline__ void two_smallest(float &m1, float &m2, float o1, float o2)
@@ -89,21 +90,12 @@ __global__ __launch_bounds__(kBlock) void k_lab_candidates(const Centroid *__res
     __shared__ uint8_t s_rec_all[kBlock / 64][2 * kListBytes];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     uint8_t *s_rec = s_rec_all[wv];
-    const uint32_t cell = blockIdx.x * (kBlock / 64) + wv;
-    if (cell >= kLabCells) return;
-    const uint32_t ib = cell % (uint32_t)kLabNA, ia = (cell / (uint32_t)kLabNA) % (uint32_t)kLabNA, iL = cell / (uint32_t)(kLabNA * kLabNA);
-    bool rim = iL == 0u || iL == (uint32_t)kLabNL - 1u || ia == 0u || ia == (uint32_t)kLabNA - 1u || ib == 0u || ib == (uint32_t)kLabNA - 1u;
-    {
-        // cells no pixel of an sRGB image comes near under this threshold get no list either (two thirds of the grid; a pixel
-        // that lands there all the same scans everything)
-        const float L = kLabL0 + kLabStep * (float)iL, a = kLabA0 + kLabStep * (float)ia, b = kLabA0 + kLabStep * (float)ib;
-        rim = rim || L + kLabStep < reach.L0 || L > reach.L1 || a + kLabStep < reach.a0 || a > reach.a1 || b + kLabStep < reach.b0 || b > reach.b1;
-    }
+    // one wave per cell of the reachable box (the rest of the table says "scan everything": the launcher's memset)
+    const uint32_t idx = blockIdx.x * (kBlock / 64) + wv;
+    if (idx >= reach.nL * reach.nA * reach.nB) return;
+    const uint32_t ib = reach.b0 + idx % reach.nB, ia = reach.a0 + (idx / reach.nB) % reach.nA, iL = reach.L0 + idx / (reach.nB * reach.nA);
+    const uint32_t cell = (iL * (uint32_t)kLabNA + ia) * (uint32_t)kLabNA + ib;
     uint4 *first = reinterpret_cast<uint4 *>(lists + (uint64_t)cell * kListBytes);
-    if (rim) {                                                      // (uniform: one wave, one cell)
-        if (lane < 2u) first[lane] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-        return;
-    }
     const CellBounds cb = lab_cell_bounds(iL, ia, ib);
     const uint32_t words = (k + 63u) / 64u;
     float U = 3.0e38f, U2 = 3.0e38f, lo[4];
@@ -161,11 +153,21 @@ hipError_t launch_lab_candidates(const Centroid *cent, uint32_t k, float thresho
 {
     if (k > 256u || (two_closest && k < 2u)) return hipErrorInvalidValue;
     // sRGB in the shader's Lab: L 0 .. 100, a -86.2 .. 98.3, b -107.9 .. 94.5 (one cell of margin), moved by the 16 offsets
-    // threshold (0 .. 15) / 16 - threshold / 2.  Only speed depends on this box.
+    // threshold (0 .. 15) / 16 - threshold / 2; clipped to the interior of the grid (its rim cells are unbounded outwards).
+    // Cells outside get no list -- count 255, "scan everything": exact for any pixel that lands there all the same, so only
+    // speed depends on this box (two thirds of the grid lie outside it).
     const float t = threshold == threshold ? threshold : 0.0f;
     const float o0 = fminf(t * -0.5f, t * 0.4375f), o1 = fmaxf(t * -0.5f, t * 0.4375f);
-    const LabReach reach = {-4.0f + o0, 104.0f + o1, -91.0f + o0, 103.0f + o1, -112.0f + o0, 99.0f + o1};
-    const dim3 grid((kLabCells + kBlock / 64 - 1) / (kBlock / 64));
+    auto lo_cell = [](float x, float origin, int n) { const float c = floorf((x - origin) / kLabStep); return (uint32_t)(c < 1.0f ? 1.0f : (c > (float)(n - 2) ? (float)(n - 2) : c)); };
+    LabReach reach;
+    reach.L0 = lo_cell(-4.0f + o0, kLabL0, kLabNL);   const uint32_t L1 = lo_cell(104.0f + o1, kLabL0, kLabNL);
+    reach.a0 = lo_cell(-91.0f + o0, kLabA0, kLabNA);  const uint32_t a1 = lo_cell(103.0f + o1, kLabA0, kLabNA);
+    reach.b0 = lo_cell(-112.0f + o0, kLabA0, kLabNA); const uint32_t b1 = lo_cell(99.0f + o1, kLabA0, kLabNA);
+    reach.nL = L1 - reach.L0 + 1u; reach.nA = a1 - reach.a0 + 1u; reach.nB = b1 - reach.b0 + 1u;
+    hipError_t e = hipMemsetAsync(lists, 0xFF, (size_t)kLabCells * kListBytes, st);
+    if (e != hipSuccess) return e;
+    const uint32_t n_cells = reach.nL * reach.nA * reach.nB;
+    const dim3 grid((n_cells + kBlock / 64 - 1) / (kBlock / 64));
     if (two_closest) hipLaunchKernelGGL(k_lab_candidates<true>, grid, dim3(kBlock), 0, st, cent, k, reach, lists);
     else hipLaunchKernelGGL(k_lab_candidates<false>, grid, dim3(kBlock), 0, st, cent, k, reach, lists);
     return hipGetLastError();
