@@ -42,13 +42,20 @@ __device__ __forceinline__ uint32_t lab_cell_index(float L, float a, float b)
     return (iL * (uint32_t)kLabNA + ia) * (uint32_t)kLabNA + ib;
 }
 
+// (the L interval of a cell alone: what changes along a column of the grid)
+__device__ __forceinline__ void lab_cell_L_bounds(uint32_t iL, CellBounds &s)
+{
+    constexpr float e = 0.0009765625f;
+    s.L0 = kLabL0 + kLabStep * (float)iL - e; s.L1 = kLabL0 + kLabStep * (float)(iL + 1u) + e;
+}
+
 // bounds of the per-pixel terms over the points that lab_cell_index sends to interior cell (iL, ia, ib): the cell's box widened
 // by 2^-10 on every side (x - origin rounds once, by at most 2^-17 at these magnitudes; the scaling by 1/4 is exact)
 __device__ __forceinline__ CellBounds lab_cell_bounds(uint32_t iL, uint32_t ia, uint32_t ib)
 {
     constexpr float e = 0.0009765625f;
     CellBounds s;
-    s.L0 = kLabL0 + kLabStep * (float)iL - e; s.L1 = kLabL0 + kLabStep * (float)(iL + 1u) + e;
+    lab_cell_L_bounds(iL, s);
     s.a0 = kLabA0 + kLabStep * (float)ia - e; s.a1 = kLabA0 + kLabStep * (float)(ia + 1u) + e;
     s.b0 = kLabA0 + kLabStep * (float)ib - e; s.b1 = kLabA0 + kLabStep * (float)(ib + 1u) + e;
     float ma, Ma, mb, Mb;
@@ -74,6 +81,7 @@ __device__ __forceinline__ CellBounds lab_cell_bounds(uint32_t iL, uint32_t ia, 
 // times the SECOND smallest upper bound (k >= 2).
 // the part of the grid an image can reach (launch_lab_candidates): cells [L0, L0 + nL) x [a0, a0 + nA) x [b0, b0 + nB), all interior
 struct LabReach { uint32_t L0, a0, b0, nL, nA, nB; };
+constexpr uint32_t kCellsPerWave = 8;
 
 // (m1 <= m2) <- the two smallest of {m1, m2, o1, o2}, o1 <= o2
 __device__ __forceinline__ void two_smallest(float &m1, float &m2, float o1, float o2)
@@ -90,63 +98,74 @@ __global__ __launch_bounds__(kBlock) void k_lab_candidates(const Centroid *__res
     __shared__ uint8_t s_rec_all[kBlock / 64][2 * kListBytes];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     uint8_t *s_rec = s_rec_all[wv];
-    // one wave per cell of the reachable box (the rest of the table says "scan everything": the launcher's memset)
-    const uint32_t idx = blockIdx.x * (kBlock / 64) + wv;
-    if (idx >= reach.nL * reach.nA * reach.nB) return;
-    const uint32_t ib = reach.b0 + idx % reach.nB, ia = reach.a0 + (idx / reach.nB) % reach.nA, iL = reach.L0 + idx / (reach.nB * reach.nA);
-    const uint32_t cell = (iL * (uint32_t)kLabNA + ia) * (uint32_t)kLabNA + ib;
-    uint4 *first = reinterpret_cast<uint4 *>(lists + (uint64_t)cell * kListBytes);
-    const CellBounds cb = lab_cell_bounds(iL, ia, ib);
+    // a wave takes kCellsPerWave cells of the reachable box that differ in L only (the rest of the table says "scan everything":
+    // the launcher's memset): its centroids stay in registers, and so do the chroma bounds and weights of its (a, b) column
+    const uint32_t groups_L = (reach.nL + kCellsPerWave - 1u) / kCellsPerWave;
+    const uint32_t wave = blockIdx.x * (kBlock / 64) + wv;
+    if (wave >= groups_L * reach.nA * reach.nB) return;
+    const uint32_t gL = wave % groups_L, ib = reach.b0 + (wave / groups_L) % reach.nB, ia = reach.a0 + wave / (groups_L * reach.nB);
+    CellBounds cb = lab_cell_bounds(reach.L0, ia, ib);
     const uint32_t words = (k + 63u) / 64u;
-    float U = 3.0e38f, U2 = 3.0e38f, lo[4];
+    Centroid c[4];
 #pragma unroll
     for (uint32_t w = 0; w < 4u; ++w) {
-        lo[w] = 3.0e38f;
         const uint32_t j = w * 64u + lane;
-        if (w < words && j < k) {
-            const Centroid c = cent[j];
-            const KeyRange r = key_range(cb, c.L, c.a, c.b, c.C);
-            lo[w] = r.lo;
-            if (TWO) two_smallest(U, U2, r.hi, 3.0e38f); else U = fminf(U, r.hi);
-        }
+        c[w] = cent[w < words && j < k ? j : 0u];
     }
-    if (TWO) {
-        for (int off = 32; off > 0; off >>= 1) {
-            const float o1 = __shfl_xor(U, off, 64), o2 = __shfl_xor(U2, off, 64);
-            two_smallest(U, U2, o1, o2);
-        }
-        U = mask_threshold(U2);
-    } else {
-        U = mask_threshold(wave_min(U));                            // keep what can still be a near-tie (kmg_math.h)
-    }
-    unsigned long long m[4];
-    uint32_t n_cand = 0;
-#pragma unroll
-    for (uint32_t w = 0; w < 4u; ++w) {
-        m[w] = __ballot(lo[w] <= U);                                // (lo = 3e38 beyond k)
-        n_cand += (uint32_t)__builtin_popcountll(m[w]);
-    }
-    uint32_t pad = 255u;
-    if (k == 256u) {
-#pragma unroll
-        for (int w = 3; w >= 0; --w)
-            if (~m[w]) pad = (uint32_t)w * 64u + (uint32_t)__builtin_ctzll(~m[w]);
-    }
-    if (lane < 16u) reinterpret_cast<uint32_t *>(s_rec)[lane] = pad * 0x01010101u;
-    __builtin_amdgcn_wave_barrier();
-    if (n_cand <= kListMax) {
-        uint32_t base = 1u;                                         // byte 0 is the count
+    for (uint32_t u = 0; u < kCellsPerWave; ++u) {
+        if (gL * kCellsPerWave + u >= reach.nL) return;
+        const uint32_t iL = reach.L0 + gL * kCellsPerWave + u;
+        const uint32_t cell = (iL * (uint32_t)kLabNA + ia) * (uint32_t)kLabNA + ib;
+        lab_cell_L_bounds(iL, cb);
+        float U = 3.0e38f, U2 = 3.0e38f, lo[4];
 #pragma unroll
         for (uint32_t w = 0; w < 4u; ++w) {
-            if ((m[w] >> lane) & 1ull) s_rec[base + bits_below_lane(m[w])] = (uint8_t)(w * 64u + lane);
-            base += (uint32_t)__builtin_popcountll(m[w]);
+            lo[w] = 3.0e38f;
+            if (w < words && w * 64u + lane < k) {
+                const KeyRange r = key_range(cb, c[w].L, c[w].a, c[w].b, c[w].C);
+                lo[w] = r.lo;
+                if (TWO) two_smallest(U, U2, r.hi, 3.0e38f); else U = fminf(U, r.hi);
+            }
         }
+        if (TWO) {
+            for (int off = 32; off > 0; off >>= 1) {
+                const float o1 = __shfl_xor(U, off, 64), o2 = __shfl_xor(U2, off, 64);
+                two_smallest(U, U2, o1, o2);
+            }
+            U = mask_threshold(U2);
+        } else {
+            U = mask_threshold(wave_min(U));                        // keep what can still be a near-tie (kmg_math.h)
+        }
+        unsigned long long m[4];
+        uint32_t n_cand = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 4u; ++w) {
+            m[w] = __ballot(lo[w] <= U);                            // (lo = 3e38 beyond k)
+            n_cand += (uint32_t)__builtin_popcountll(m[w]);
+        }
+        uint32_t pad = 255u;
+        if (k == 256u) {
+#pragma unroll
+            for (int w = 3; w >= 0; --w)
+                if (~m[w]) pad = (uint32_t)w * 64u + (uint32_t)__builtin_ctzll(~m[w]);
+        }
+        __builtin_amdgcn_wave_barrier();                            // (the previous cell's record has left)
+        if (lane < 16u) reinterpret_cast<uint32_t *>(s_rec)[lane] = pad * 0x01010101u;
+        __builtin_amdgcn_wave_barrier();
+        if (n_cand <= kListMax) {
+            uint32_t base = 1u;                                     // byte 0 is the count
+#pragma unroll
+            for (uint32_t w = 0; w < 4u; ++w) {
+                if ((m[w] >> lane) & 1ull) s_rec[base + bits_below_lane(m[w])] = (uint8_t)(w * 64u + lane);
+                base += (uint32_t)__builtin_popcountll(m[w]);
+            }
+        }
+        if (lane == 0u) s_rec[0] = (uint8_t)(n_cand <= kListMax ? n_cand : 255u);
+        __builtin_amdgcn_wave_barrier();
+        const uint4 *src = reinterpret_cast<const uint4 *>(s_rec);
+        if (lane < 2u) reinterpret_cast<uint4 *>(lists + (uint64_t)cell * kListBytes)[lane] = src[lane];
+        else if (lane < 4u) reinterpret_cast<uint4 *>(lists + ((uint64_t)kLabCells + cell) * kListBytes)[lane - 2u] = src[lane];
     }
-    if (lane == 0u) s_rec[0] = (uint8_t)(n_cand <= kListMax ? n_cand : 255u);
-    __builtin_amdgcn_wave_barrier();
-    const uint4 *src = reinterpret_cast<const uint4 *>(s_rec);
-    if (lane < 2u) first[lane] = src[lane];
-    else if (lane < 4u) reinterpret_cast<uint4 *>(lists + ((uint64_t)kLabCells + cell) * kListBytes)[lane - 2u] = src[lane];
 }
 
 hipError_t launch_lab_candidates(const Centroid *cent, uint32_t k, float threshold, bool two_closest, uint8_t *lists, hipStream_t st)
@@ -166,56 +185,53 @@ hipError_t launch_lab_candidates(const Centroid *cent, uint32_t k, float thresho
     reach.nL = L1 - reach.L0 + 1u; reach.nA = a1 - reach.a0 + 1u; reach.nB = b1 - reach.b0 + 1u;
     hipError_t e = hipMemsetAsync(lists, 0xFF, (size_t)kLabCells * kListBytes, st);
     if (e != hipSuccess) return e;
-    const uint32_t n_cells = reach.nL * reach.nA * reach.nB;
-    const dim3 grid((n_cells + kBlock / 64 - 1) / (kBlock / 64));
+    const uint32_t n_waves = ((reach.nL + kCellsPerWave - 1u) / kCellsPerWave) * reach.nA * reach.nB;
+    const dim3 grid((n_waves + kBlock / 64 - 1) / (kBlock / 64));
     if (two_closest) hipLaunchKernelGGL(k_lab_candidates<true>, grid, dim3(kBlock), 0, st, cent, k, reach, lists);
     else hipLaunchKernelGGL(k_lab_candidates<false>, grid, dim3(kBlock), 0, st, cent, k, reach, lists);
     return hipGetLastError();
 }
 
 // ---- the pass ---------------------------------------------------------------------------------------------------------------
-// The pass is bound by vector issue (4 cycles per wave instruction), so the list walk is written for instruction count:
-//   * the key of a candidate in 8 instructions instead of 12: the centroid's (L, a) and (b, C) are the register pairs its 16-byte
-//     LDS read returns, and v_pk_add / v_pk_mul / v_pk_fma_f32 work on (dL, da) and (db, dC) at once (pair_key);
+// With the table in L2 the pass is bound by vector issue (profiles/r03d_apply_pmc.txt: ~350 vector instructions per pixel, the
+// vector units busy for the whole kernel), so the list walk is written for instruction count -- 13 per candidate instead of 20:
 //   * the candidate's index travels in the low byte of its key (one v_perm_b32, which also extracts it from the list word), so the
 //     running minimum and runner-up are one v_min_u32 and one v_med3_u32, and the index needs no register of its own;
 //   * the walk is unrolled by list WORDS (the wave leaves it after its longest list's last word): byte positions are compile-time
-//     constants (the LDS address of byte P's centroid is one sub-dword shift) and the reads of a word are in flight together.
-// The key orders only: near-ties (kmg_math.h; the packed byte costs 2^-15 = 512u of the 2048u slack, the pair form one more
-// rounding) are settled with the literal distance as everywhere else.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-struct PixelPairs { f32x2 La, bC, wC1; float wH; };
-
+//     constants (the LDS address of byte P's centroid is one sub-dword shift), the reads of a word are in flight together, and
+//     bytes behind a list's last entry need no test (they name a centroid that cannot matter, k_lab_candidates).
+// (The key itself stays cie94_key's twelve plain operations: written for the register PAIRS a 16-byte LDS read returns -- v_pk_add /
+// v_pk_mul / v_pk_fma_f32 on (dL, da) and (db, dC), eight instructions -- it was measured 6 % SLOWER, 644 against 602 us: packed
+// fp32 operations issue at half rate on gfx950, tools/valu_rate.hip.)
+// The key orders only: near-ties (kmg_math.h; the packed byte costs 2^-15 = 512u of the 2048u slack) are settled with the
+// literal distance as everywhere else.
 // (dL^2 + dC^2 wC + max(da^2 + db^2 - dC^2, 0) wH) against the centroid at byte offset j16 of the LDS table
-// (the table starts at LDS address 0 -- k_dither_lists checks --, so the offset is the address: no add per read)
+// = cie94_key (kmg_math.h).  The table starts at LDS address 0 -- the kernels check --, so the offset is the address: no add per read
 typedef const float4 __attribute__((address_space(3))) *LdsFloat4Ptr;
-__device__ __forceinline__ float pair_key(uint32_t j16, const PixelPairs &pp)
+__device__ __forceinline__ float entry_key(uint32_t j16, const PixelTerms &pp)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     const float4 c = *(LdsFloat4Ptr)j16;
 #else
     const float4 c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);          // (host pass: never called)
 #endif
-    const f32x2 cxy = {c.x, c.y}, czw = {c.z, c.w};
-    const f32x2 d0 = pp.La - cxy, d1 = pp.bC - czw;               // (dL, da), (db, dC)
-    const f32x2 s0 = d0 * d0, s1 = d1 * d1;                       // (dL^2, da^2), (db^2, dC^2)
-    const f32x2 s1s = {s1.y, s1.x};
-    const f32x2 rt = __builtin_elementwise_fma(s1s, pp.wC1, s0);  // (dC^2 wC + dL^2, db^2 + da^2)
-    const float h = fmaxf(rt.y - s1.y, 0.0f);
-    return fmaf(h, pp.wH, rt.x);
+    const float dL = pp.L - c.x, da = pp.a - c.y, db = pp.b - c.z, dC = pp.C - c.w;
+    const float dC2 = dC * dC;
+    const float t = fmaf(db, db, da * da);
+    const float h = fmaxf(t - dC2, 0.0f);
+    return fmaf(h, pp.wH, fmaf(dC2, pp.wC, dL * dL));
 }
 
 // byte P of list word wd -> that centroid's key with its index in the low byte
 template <int P>
-__device__ __forceinline__ uint32_t list_entry_key(uint32_t wd, const PixelPairs &pp)
+__device__ __forceinline__ uint32_t list_entry_key(uint32_t wd, const PixelTerms &pp)
 {
     uint32_t j16;                                                   // (byte P) << 4 in one instruction (sub-dword operand select)
     if (P == 0) asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(j16) : "v"(wd));
     else if (P == 1) asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(j16) : "v"(wd));
     else if (P == 2) asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(j16) : "v"(wd));
     else asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(j16) : "v"(wd));
-    const float key = pair_key(j16, pp);
+    const float key = entry_key(j16, pp);
     return __builtin_amdgcn_perm(__float_as_uint(key), wd, 0x07060500u | (uint32_t)P);
 }
 
@@ -234,7 +250,7 @@ __global__ __launch_bounds__(kBlock) void k_dither_lists(const uint32_t *__restr
     extern __shared__ float4 smem4[];
     constexpr uint32_t kpad = 256u;                                // every byte value indexes the table: entries k .. 255 are far away
     float4 *s_cent = smem4;
-    // the kernel has no static LDS, so its dynamic LDS -- the centroid table first -- starts at LDS address 0 (pair_key)
+    // the kernel has no static LDS, so its dynamic LDS -- the centroid table first -- starts at LDS address 0 (entry_key)
     if ((uint32_t)reinterpret_cast<uintptr_t>(s_cent) != 0u) __builtin_trap();
     float *s_lut = reinterpret_cast<float *>(smem4 + kpad);
     float *s_off = s_lut + 256;
@@ -276,8 +292,7 @@ __global__ __launch_bounds__(kBlock) void k_dither_lists(const uint32_t *__restr
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const PixelTerms pt = pixel_terms_fast(pL[q], pa[q], pb[q], chroma(pa[q], pb[q]));
-            PixelPairs pp;
-            pp.La = f32x2{pt.L, pt.a}; pp.bC = f32x2{pt.b, pt.C}; pp.wC1 = f32x2{pt.wC, 1.0f}; pp.wH = pt.wH;
+            const PixelTerms &pp = pt;
             // mix_colors.wgsl:73-80 starts the scan at the sentinel (10000, 10000, 10000), index k.  Its key is not computed here: a
             // pixel whose smallest key is not below kSentinelFloor -- (10000 - L)^2 alone is above that for every L < 9000, and no
             // centroid of a palette in Lab is 1000 units from a pixel -- goes to the literal scan below, which starts at the
@@ -309,7 +324,7 @@ __global__ __launch_bounds__(kBlock) void k_dither_lists(const uint32_t *__restr
 #undef KMG_LIST_ENTRY
             if (__ballot(over)) {                                   // no list (too long, or a rim cell): every centroid, in order
                 for (uint32_t j = 0; j < k; ++j) {
-                    if (over) min_and_runner_up((__float_as_uint(pair_key(j << 4, pp)) & ~255u) | j, best, second);
+                    if (over) min_and_runner_up((__float_as_uint(entry_key(j << 4, pp)) & ~255u) | j, best, second);
                 }
             }
             uint32_t idx = best & 255u;
@@ -384,7 +399,7 @@ __global__ __launch_bounds__(kBlock) void k_meld_lists(const uint32_t *__restric
 {
     extern __shared__ float4 smem4[];
     float4 *s_cent = smem4;
-    if ((uint32_t)reinterpret_cast<uintptr_t>(s_cent) != 0u) __builtin_trap();   // (pair_key reads the table at LDS address 0)
+    if ((uint32_t)reinterpret_cast<uintptr_t>(s_cent) != 0u) __builtin_trap();   // (entry_key reads the table at LDS address 0)
     float *s_lut = reinterpret_cast<float *>(smem4 + 256);
     float *s_thr = s_lut + 256;                                    // the thresholds of the sRGB8 encode (kmg_device.h)
     s_lut[threadIdx.x] = lut[threadIdx.x];
@@ -418,8 +433,7 @@ __global__ __launch_bounds__(kBlock) void k_meld_lists(const uint32_t *__restric
         for (int q = 0; q < 4; ++q) {
             const float L = pL[q], a = pa[q], b = pb[q];
             const PixelTerms pt = pixel_terms_fast(L, a, b, chroma(a, b));
-            PixelPairs pp;
-            pp.La = f32x2{pt.L, pt.a}; pp.bC = f32x2{pt.b, pt.C}; pp.wC1 = f32x2{pt.wC, 1.0f}; pp.wH = pt.wH;
+            const PixelTerms &pp = pt;
             constexpr uint32_t kSentinelFloor = 0x49742400u;          // 1.0e6f (see k_dither_lists)
             uint32_t k1 = 0x7F7FFF00u, k2 = 0x7F7FFF00u, k3 = 0x7F7FFFFFu;
             const uint32_t cnt_raw = rec[q][0].x & 255u;
@@ -445,7 +459,7 @@ __global__ __launch_bounds__(kBlock) void k_meld_lists(const uint32_t *__restric
 #undef KMG_LIST_ENTRY
             if (__ballot(over)) {
                 for (uint32_t j = 0; j < k; ++j) {
-                    if (over) three_smallest((__float_as_uint(pair_key(j << 4, pp)) & ~255u) | j, k1, k2, k3);
+                    if (over) three_smallest((__float_as_uint(entry_key(j << 4, pp)) & ~255u) | j, k1, k2, k3);
                 }
             }
             // the two winners, unless something is within the tie slack of one of them
