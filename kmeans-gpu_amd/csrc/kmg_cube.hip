@@ -662,7 +662,9 @@ __global__ __launch_bounds__(kBlock) void k_cube_scan(const uint32_t *__restrict
                 uint32_t b0 = 0x7F7FFFFFu, r0 = 0x7F7FFFFFu, b1 = 0x7F7FFFFFu, r1 = 0x7F7FFFFFu;   // smallest / runner-up
                 const uint32_t sm = submask_of(s0) | (s1 < 8u ? submask_of(s1) : 0u);
                 // the two colours of a lane as the halves of packed-f32 operands: cie94_key's operations in the same order (the
-                // same two floats), 13 vector instructions for the pair instead of 24
+                // same two floats), 13 vector instructions for the pair instead of 24.  Packed fp32 issues at half rate on gfx950
+                // (tools/valu_rate.hip), so the arithmetic takes as long; what this kernel is short of is issue slots (53 % VALU
+                // busy beside as many scalar instructions): cube pass 121 -> 119 us.
                 const f32x2 qL = {pt0.L, pt1.L}, qa = {pt0.a, pt1.a}, qb = {pt0.b, pt1.b}, qC = {pt0.C, pt1.C};
                 const f32x2 qwC = {pt0.wC, pt1.wC}, qwH = {pt0.wH, pt1.wH};
                 for (uint32_t m = sm; m; m &= m - 1u) {
