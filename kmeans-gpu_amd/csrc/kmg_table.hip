@@ -957,7 +957,7 @@ constexpr size_t kLabelLdsPlain = sizeof(uint32_t) * (kCells + 256 + 128);
 constexpr size_t kLabelLdsHot = kLabelLdsPlain + (size_t)kHotMax * kCellColours + sizeof(uint32_t) * 64;
 
 // KNOCK (tools only, results wrong): 1 = gathers from a 64 KiB window of the table, 2 = from LDS instead, 3 = none,
-// 4 = plain non-temporal gathers
+// 4 = plain non-temporal gathers, 5 = gathers from a table a quarter the size
 template <bool HOT, int KNOCK = 0>
 __global__ __launch_bounds__(kLabelBlock) void k_labels_pairs(const uint32_t *__restrict__ rgba, uint64_t n,
                                                               const uint8_t *__restrict__ colour_labels,
@@ -1035,6 +1035,7 @@ __global__ __launch_bounds__(kLabelBlock) void k_labels_pairs(const uint32_t *__
                 else if (KNOCK == 1) lab[p] = (uint32_t)colour_labels[ci[p] & 0xFFFFu];
                 else if (KNOCK == 2) lab[p] = (uint32_t)reinterpret_cast<const uint8_t *>(s_pair)[ci[p] & 0x1FFFFu];
                 else if (KNOCK == 4) lab[p] = (uint32_t)__builtin_nontemporal_load(colour_labels + ci[p]);
+                else if (KNOCK == 5) lab[p] = (uint32_t)colour_labels[ci[p] >> 2];        // a table a quarter the size (2 bits per colour)
             }
         if (pal) {
 #pragma unroll
@@ -1071,6 +1072,7 @@ hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_la
 #define KMG_LK(K) hipLaunchKernelGGL((k_labels_pairs<false, K>), dim3(grid), dim3(kLabelBlock), kLabelLdsPlain, st, rgba, n, \
                                      (const uint8_t *)colour_labels, pairs, pal, k, labels, aligned, hot)
         if (knock == 1) KMG_LK(1); else if (knock == 2) KMG_LK(2); else if (knock == 3) KMG_LK(3); else if (knock == 4) KMG_LK(4);
+        else if (knock == 5) KMG_LK(5);
 #undef KMG_LK
         else if (hot)
             hipLaunchKernelGGL(k_labels_pairs<true>, dim3(grid), dim3(kLabelBlock), kLabelLdsHot, st, rgba, n,
