@@ -264,6 +264,33 @@ def test_cfg5_find_dither_1024_rows_and_tail_vs_oracle(torch_cuda, oracle, palet
     p.close()
 
 
+def test_full_size_find_meld_rows_vs_oracle(torch_cuda, oracle):
+    """find -m meld with the 64-entry palette on the 8192x8192 image of config 5 (the list pass over Lab cells,
+    kmg_lists.hip): the first 512 rows, 516 rows from inside the image and the last 512 rows equal the oracle's bytes
+    (mix_colors.wgsl:29-48, :85-90, lab_to_rgb.wgsl)."""
+    import kmeans_gpu_amd as kg
+    from kmeans_gpu_amd import synth
+    from PIL import Image
+    torch = torch_cuda
+    st = _stream(torch)
+    w = h = 8192
+    n = w * h
+    px = np.array(Image.open(os.path.join(os.path.dirname(__file__), "golden", "resurrect_64.png")).convert("RGBA")).reshape(-1, 4)
+    pal = np.array(sorted(set(map(tuple, px))), np.uint8)
+    cent = kg.palette_to_centroids(pal)
+    rgba = synth.uniform_rgba_torch(synth.SEED_CFG5, n, device="cuda")
+    p = kg.ImageProcessor()
+    out = torch.zeros((n, 4), dtype=torch.uint8, device="cuda")
+    p.apply(rgba.data_ptr(), w, h, 0, cent, kg.ReduceMode.Meld, out.data_ptr(), st)
+    torch.cuda.synchronize()
+    for r0, rows in ((0, 512), (4001, 516), (h - 512, 512)):
+        src = rgba[r0 * w:(r0 + rows) * w].cpu().numpy().reshape(rows, w, 4)
+        want = oracle.find(src, pal, oracle.MODE_MELD)
+        got = out[r0 * w:(r0 + rows) * w].cpu().numpy().reshape(rows, w, 4)
+        assert np.array_equal(got, want), f"rows {r0}..{r0 + rows}: {int((got != want).any(-1).sum())} pixels differ"
+    p.close()
+
+
 def test_cfg4_one_ranks_share_of_the_batch(torch_cuda, oracle):
     """BASELINE config 4: 16 images of 8192x8192 (seeds 0x5EED0400 + i), k=256, each tiled over 8 GPUs in row
     bands; this is rank 3's share -- 16 bands of 8192x1024 through ShardedBatch (one accumulator tensor, one
