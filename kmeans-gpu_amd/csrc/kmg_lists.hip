@@ -213,6 +213,7 @@ __device__ __forceinline__ float entry_key(uint32_t j16, const PixelTerms &pp)
 #if defined(__HIP_DEVICE_COMPILE__)
     const float4 c = *(LdsFloat4Ptr)j16;
 #else
+    (void)j16;
     const float4 c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);          // (host pass: never called)
 #endif
     const float dL = pp.L - c.x, da = pp.a - c.y, db = pp.b - c.z, dC = pp.C - c.w;
