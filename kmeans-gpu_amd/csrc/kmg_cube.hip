@@ -574,7 +574,6 @@ __global__ __launch_bounds__(kBlock) void k_cube_scan(const uint32_t *__restrict
 {
     extern __shared__ float4 smem4[];
     const uint32_t kpad = (k + 63u) & ~63u;
-    const uint32_t words = kpad / 64u;
     float4 *s_cent = smem4;
     unsigned long long *bins = reinterpret_cast<unsigned long long *>(smem4 + kpad);
     const uint32_t bin_stride = 4u * k + 4u;                      // u64 per copy (+ 32 B: next copy, other banks)

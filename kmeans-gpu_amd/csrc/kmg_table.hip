@@ -1238,7 +1238,6 @@ __global__ __launch_bounds__(kBlock) void k_offset_candidates(const CellBounds *
         sb.wH0 = lane_value(mine.wH0, bi); sb.wH1 = lane_value(mine.wH1, bi);
         uint64_t *out = masks + ((uint64_t)cell * 16u + bi) * words;
         float U = 3.0e38f;
-        uint32_t n_cand = 0;
         if (words <= 4u) {
             // k <= 256: one evaluation per centroid, the lower bounds wait in registers for U
             float lo[4];
@@ -1257,9 +1256,6 @@ __global__ __launch_bounds__(kBlock) void k_offset_candidates(const CellBounds *
             for (uint32_t w = 0; w < 4u; ++w) {
                 const unsigned long long m = __ballot(w * 64 + lane < k && lo[w] <= U);
                 if (w < words && lane == 0) out[w] = m;
-                if (w < words) {
-                    n_cand += (uint32_t)__builtin_popcountll(m);
-                }
             }
             continue;
         }
@@ -1278,7 +1274,6 @@ __global__ __launch_bounds__(kBlock) void k_offset_candidates(const CellBounds *
             }
             const unsigned long long m = __ballot(keep);
             if (lane == 0) out[w] = m;
-            n_cand += (uint32_t)__builtin_popcountll(m);
         }
     }
 }
