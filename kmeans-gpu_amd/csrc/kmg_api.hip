@@ -620,7 +620,6 @@ static int bind_image_impl(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, void
     int rc;
     if ((rc = ensure_bounds(s->p, S(stream))) != KMG_OK) return rc;
     ColourTable &t = s->tab;
-    const uint32_t words = mask_words(s->k);
     if (!t.d_hist) {
         // one block for all tables, from the processor's idle blocks when one fits (no hipMalloc on a warm processor)
         const size_t sizes[10] = {sizeof(uint32_t) << 24, sizeof(int64_t) * 4ull * kCells, sizeof(int64_t) * 4ull * kSubCells,
