@@ -12,13 +12,9 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include <sys/mman.h>
-#include <unistd.h>
-
 #include <algorithm>
 #include <mutex>
 #include <new>
-#include <thread>
 #include <vector>
 
 #include "kmg_color.h"
@@ -1865,46 +1861,12 @@ int extract_palette_kmeans(kmg_processor *p, const uint8_t *d_rgba, uint32_t w, 
     return KMG_OK;
 }
 
-// The caller's output image is usually fresh memory: its pages do not exist until the download touches them, and a 256 MiB
-// download into such a buffer takes 16 ms instead of 4.7 (11 ms of page faults on the copying thread, tools/reduce_host_probe.py).
-// The pages are asked for (MADV_POPULATE_WRITE: contents untouched) by a few threads while the upload and the GPU work run;
-// on a kernel without it, or for a buffer that has its pages already, this does nothing.
-#ifndef MADV_POPULATE_WRITE
-#define MADV_POPULATE_WRITE 23
-#endif
-struct PageWarmer {
-    std::vector<std::thread> threads;
-    void start(void *ptr, size_t bytes)
-    {
-        const long page = sysconf(_SC_PAGESIZE);
-        if (bytes < ((size_t)8 << 20) || page <= 0) return;
-        uintptr_t a = ((uintptr_t)ptr + (uintptr_t)page - 1u) & ~((uintptr_t)page - 1u);
-        const uintptr_t b = ((uintptr_t)ptr + bytes) & ~((uintptr_t)page - 1u);
-        if (b <= a) return;
-        const unsigned n = 4;
-        const size_t share = (((b - a) / n) + (size_t)page - 1u) & ~((size_t)page - 1u);
-        try {
-            for (unsigned i = 0; i < n && a < b; ++i, a += share) {
-                const size_t len = std::min<size_t>(share, b - a);
-                threads.emplace_back([a, len] { (void)madvise((void *)a, len, MADV_POPULATE_WRITE); });
-            }
-        } catch (...) {
-            // no thread: the download faults the pages in itself
-        }
-    }
-    void wait()
-    {
-        for (std::thread &t : threads)
-            if (t.joinable()) t.join();
-        threads.clear();
-    }
-    ~PageWarmer() { wait(); }
-};
-
 // An image between a caller's (pageable) buffer and the device.  The calls that use this return when the work is done, so a large
 // image goes through the blocking hipMemcpy once `st` has drained: the runtime pipelines it through pinned staging at PCIe
-// rate (256 MiB: 4.7 ms each way on the MI355X box), where hipMemcpyAsync of pageable memory takes 16-20 ms
-// (tools/host_copy_probe.py, tools/reduce_host_probe.py).
+// rate (256 MiB: 4.7 ms each way on the MI355X box between touched buffers), where hipMemcpyAsync of pageable memory takes
+// 16-20 ms (tools/host_copy_probe.py, tools/reduce_host_probe.py).  A download into a result buffer whose pages do not exist yet
+// still takes 16-40 ms, the caller's page faults; asking for those pages ahead (MADV_POPULATE_WRITE on helper threads during
+// the GPU work) was measured and is not in: -6 ms per call in a fresh process, +8 ms in a long-running one.
 static hipError_t copy_host_image(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t st)
 {
     if (bytes < ((size_t)1 << 20)) return hipMemcpyAsync(dst, src, bytes, kind, st);
@@ -1922,14 +1884,13 @@ int upload_image(kmg_processor *p, const uint8_t *rgba, uint32_t w, uint32_t h, 
 
 // find_colors / dither_colors + OutputTexture::pull_image (structures.rs:441-470)
 int apply_and_download(kmg_processor *p, const uint8_t *d_rgba, uint32_t w, uint32_t h, const float *c4,
-                       uint32_t k, int mode, hipStream_t st, uint8_t *out_rgba, PageWarmer *warm)
+                       uint32_t k, int mode, hipStream_t st, uint8_t *out_rgba)
 {
     int rc;
     StreamBuf out;
     const size_t bytes = (size_t)w * h * 4;
     HIP_TRY(out.alloc(p, bytes, st));
     if ((rc = kmg_dev_apply(p, d_rgba, w, h, 0, c4, k, mode, (uint8_t *)out.ptr, st)) != KMG_OK) return rc;
-    if (warm) warm->wait();
     HIP_TRY(copy_host_image(out_rgba, out.ptr, bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return KMG_OK;
@@ -1995,11 +1956,9 @@ extern "C" int kmg_find(kmg_processor *p, const uint8_t *rgba, uint32_t w, uint3
     HIP_TRY(sg.acquire(p));
     std::vector<float> c4(4 * (size_t)n_colors);
     if ((rc = kmg_palette_to_centroids(palette_rgba, n_colors, c4.data())) != KMG_OK) return rc;  // lib.rs:86-87
-    PageWarmer warm;
-    warm.start(out_rgba, (size_t)w * h * 4);
     StreamBuf img;
     if ((rc = upload_image(p, rgba, w, h, sg.st, img)) != KMG_OK) return rc;
-    return apply_and_download(p, (const uint8_t *)img.ptr, w, h, c4.data(), n_colors, mode, sg.st, out_rgba, &warm);
+    return apply_and_download(p, (const uint8_t *)img.ptr, w, h, c4.data(), n_colors, mode, sg.st, out_rgba);
 }
 
 extern "C" int kmg_reduce(kmg_processor *p, const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t color_count,
@@ -2016,8 +1975,6 @@ extern "C" int kmg_reduce(kmg_processor *p, const uint8_t *rgba, uint32_t w, uin
     HIP_TRY(hipSetDevice(p->device));
     StreamGuard sg;
     HIP_TRY(sg.acquire(p));
-    PageWarmer warm;
-    warm.start(out_rgba, (size_t)w * h * 4);
     StreamBuf img;
     if ((rc = upload_image(p, rgba, w, h, sg.st, img)) != KMG_OK) return rc;
     if (algo == KMG_ALGO_OCTREE) {                                     // lib.rs:133-136
@@ -2025,11 +1982,11 @@ extern "C" int kmg_reduce(kmg_processor *p, const uint8_t *rgba, uint32_t w, uin
         if ((rc = octree_palette_of(p, (const uint8_t *)img.ptr, w, h, color_count, sg.st, colors)) != KMG_OK) return rc;
         std::vector<float> oc4(4 * colors.size());
         if ((rc = kmg_palette_to_centroids(colors[0].data(), (uint32_t)colors.size(), oc4.data())) != KMG_OK) return rc;
-        return apply_and_download(p, (const uint8_t *)img.ptr, w, h, oc4.data(), (uint32_t)colors.size(), mode, sg.st, out_rgba, &warm);
+        return apply_and_download(p, (const uint8_t *)img.ptr, w, h, oc4.data(), (uint32_t)colors.size(), mode, sg.st, out_rgba);
     }
     std::vector<float> c4(4 * (size_t)color_count);
     if ((rc = extract_palette_kmeans(p, (const uint8_t *)img.ptr, w, h, color_count, sg.st, c4.data())) != KMG_OK) return rc;
-    return apply_and_download(p, (const uint8_t *)img.ptr, w, h, c4.data(), color_count, mode, sg.st, out_rgba, &warm);
+    return apply_and_download(p, (const uint8_t *)img.ptr, w, h, c4.data(), color_count, mode, sg.st, out_rgba);
 }
 
 extern "C" int kmg_palette(kmg_processor *p, const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t color_count,
