@@ -768,7 +768,8 @@ extern "C" int kmg_debug_check_table(kmg_lloyd *s, uint64_t out[3], void *stream
 // cell, Bayer index) (kmg_table.hip).  KMG_DITHER_LISTS = 0 sends every k to the mask words, 1 (tools) keeps k <= 64 there.
 static bool dither_takes_lists(uint32_t k)
 {
-    static const int mode = getenv("KMG_DITHER_LISTS") ? atoi(getenv("KMG_DITHER_LISTS")) : 2;
+    const char *e = getenv("KMG_DITHER_LISTS");                     // (read per call: the tests switch it)
+    const int mode = e ? atoi(e) : 2;
     return mode != 0 && k <= 256u && (k > 64u || mode == 2);
 }
 

@@ -475,6 +475,28 @@ def test_dither_output_pass_pruned_equals_scan(torch_cuda, oracle, monkeypatch, 
         p.close()
 
 
+@pytest.mark.parametrize("k,mode", [(46, 0), (64, 0), (65, 0), (200, 0), (33, 2), (64, 2)])
+def test_mask_word_output_passes_for_small_k_still_equal_the_oracle(torch_cuda, oracle, monkeypatch, k, mode):
+    """k <= 256 takes the lists over Lab cells by default; the mask words per (RGB cell, Bayer index) -- the path of k > 256,
+    with its sorted (k <= 64) and multi-word kernels -- stay selectable (KMG_DITHER_LISTS=0) and stay right: dither and meld"""
+    import kmeans_gpu_amd as kg
+    torch = torch_cuda
+    monkeypatch.setenv("KMG_STRATEGY", "table")
+    monkeypatch.setenv("KMG_DITHER_LISTS", str(mode))
+    w, h = 777, 400
+    img = np.concatenate([_blobs(np.random.default_rng(k), w * 200, 20, sigma=20.0), oracle.synth_uniform(k, w * 200)]).reshape(h, w, 4)
+    pal = np.array(sorted(set(map(tuple, oracle.synth_uniform(k + 3, k)))), np.uint8)
+    cent = kg.palette_to_centroids(pal)
+    p = kg.ImageProcessor()
+    d = _dev(torch, img.reshape(-1, 4))
+    for m, om in ((kg.ReduceMode.Dither, oracle.MODE_DITHER), (kg.ReduceMode.Meld, oracle.MODE_MELD)):
+        out = torch.zeros((w * h, 4), dtype=torch.uint8, device="cuda")
+        p.apply(d.data_ptr(), w, h, 0, cent, m, out.data_ptr(), _stream(torch))
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().reshape(h, w, 4), oracle.find(img, pal, om)), m
+    p.close()
+
+
 @pytest.mark.parametrize("name", ["black_white", "crowded45", "crowded200"])
 def test_dither_lists_continued_overflowing_and_missing(torch_cuda, oracle, monkeypatch, name):
     """the list pass (k <= 256, kmg_lists.hip) where its lists are not one plain record: a two-colour palette whose threshold
