@@ -552,7 +552,7 @@ static bool dither_pruning_pays(uint64_t n, uint32_t k)
         if (!strcmp(e, "brute")) return false;
         if (!strcmp(e, "table")) return true;
     }
-    if (k > 256u) return n >= 4000000ull;                  // mask words: 0.55 ms of masks at k = 512
+    if (k > kLabListMaxK) return n >= 4000000ull;          // mask words: 0.55 ms of masks at k = 512
     if (k >= 128u) return n >= 16384ull;
     return (double)n * (0.255 * k - 0.3) > 45.0e6;          // ps saved per pixel x pixels > 45 us
 }
@@ -764,13 +764,13 @@ extern "C" int kmg_debug_check_table(kmg_lloyd *s, uint64_t out[3], void *stream
 // test support: exhaustive validation of the dither candidate masks (kmg_table.hip) for a centroid
 // table: over all 2^24 colours x 16 Bayer offsets, the arg-min over the candidates must equal the
 // brute-force arg-min.  *violations must come back 0.
-// Which pruned dither pass?  k <= 256: byte lists per cell of a grid over Lab (kmg_lists.hip); larger k: mask words per (RGB
+// Which pruned dither pass?  k <= 512 (meld: 256): byte lists per cell of a grid over Lab (kmg_lists.hip); larger k: mask words per (RGB
 // cell, Bayer index) (kmg_table.hip).  KMG_DITHER_LISTS = 0 sends every k to the mask words, 1 (tools) keeps k <= 64 there.
 static bool dither_takes_lists(uint32_t k)
 {
     const char *e = getenv("KMG_DITHER_LISTS");                     // (read per call: the tests switch it)
     const int mode = e ? atoi(e) : 2;
-    return mode != 0 && k <= 256u && (k > 64u || mode == 2);
+    return mode != 0 && k <= kLabListMaxK && (k > 64u || mode == 2);
 }
 
 extern "C" int kmg_debug_check_dither_masks(kmg_processor *p, const float *c4, uint32_t k, uint64_t *violations, void *stream)
@@ -794,9 +794,9 @@ extern "C" int kmg_debug_check_dither_masks(kmg_processor *p, const float *c4, u
     HIP_TRY(launch_offset_candidates(p->d_bounds, (const Centroid *)cent.ptr, k, thr, (uint64_t *)masks.ptr, S(stream)));
     HIP_TRY(launch_check_offset_masks((const Centroid *)cent.ptr, k, (const uint64_t *)masks.ptr, p->d_lut, thr,
                                       (unsigned long long *)viol.ptr, S(stream)));
-    if (k <= 256u) {                                        // the byte lists over Lab cells (kmg_lists.hip), same counter
+    if (k <= kLabListMaxK) {                                // the byte lists over Lab cells (kmg_lists.hip), same counter
         DevBuf lists;
-        HIP_TRY(lists.alloc(kLabListBytes));
+        HIP_TRY(lists.alloc(lab_list_bytes(k)));
         HIP_TRY(launch_lab_candidates((const Centroid *)cent.ptr, k, thr, false, (uint8_t *)lists.ptr, S(stream)));
         HIP_TRY(launch_check_lab_lists((const Centroid *)cent.ptr, k, (const uint8_t *)lists.ptr, p->d_lut, thr,
                                        (unsigned long long *)viol.ptr, S(stream)));
@@ -1727,9 +1727,9 @@ extern "C" int kmg_dev_apply(kmg_processor *p, const uint8_t *d_rgba, uint32_t w
     const size_t masks_bytes = sizeof(uint64_t) * (size_t)kCells * mask_words(k) * (dither_pruned ? 16u : 1u);
     size_t need = ArenaGuard::padded(tables_bytes);
     const bool dither_lists = dither_pruned && dither_takes_lists(k);      // byte lists over Lab cells instead of mask words
-    const bool meld_lists = meld_masks_pay && dither_takes_lists(k);       // the same for the meld pass's two closest
+    const bool meld_lists = meld_masks_pay && k <= 256u && dither_takes_lists(k);   // the same for the meld pass's two closest
     if ((meld_masks_pay && !meld_lists) || (dither_pruned && !dither_lists)) need += ArenaGuard::padded(masks_bytes);
-    if (dither_lists || meld_lists) need += ArenaGuard::padded(kLabListBytes);
+    if (dither_lists || meld_lists) need += ArenaGuard::padded(lab_list_bytes(k));
     if (replace_table) need += ArenaGuard::padded(labels_bytes) + ArenaGuard::padded(sub_bytes) + ArenaGuard::padded(cube_masks_bytes(k)) +
                                ArenaGuard::padded(cube_work_bytes());
     ArenaGuard arena;
@@ -1783,7 +1783,7 @@ extern "C" int kmg_dev_apply(kmg_processor *p, const uint8_t *d_rgba, uint32_t w
         // dither on a large image: candidate masks per (colour cell, Bayer index), then a scan of the
         // pixel's candidates only
         if (dither_lists) {
-            uint8_t *lst = (uint8_t *)arena.take(kLabListBytes);
+            uint8_t *lst = (uint8_t *)arena.take(lab_list_bytes(k));
             e = launch_lab_candidates(d_cent, k, thr, false, lst, S(stream));
             if (e == hipSuccess)
                 e = launch_dither_lists((const uint32_t *)d_rgba, w, rows, row0, d_cent, k, p->d_lut, d_pal, thr, lst,

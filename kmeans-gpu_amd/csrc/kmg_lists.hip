@@ -1,4 +1,4 @@
-// kmg_lists.hip -- the ordered-dither and meld output passes on large images with k <= 256 (mix_colors.wgsl:50-83, :29-48 + :85-90):
+// kmg_lists.hip -- the ordered-dither (k <= 512) and meld (k <= 256) output passes on large images (mix_colors.wgsl:50-83, :29-48 + :85-90):
 // candidate lists per cell of a grid over Lab, and the passes that walk them.
 //
 // A dithered pixel is compared with the centroids at Lab(pixel) + off (1, 1, 1), off one of 16 Bayer offsets.  Rounds 1-3a
@@ -91,13 +91,21 @@ __device__ __forceinline__ void two_smallest(float &m1, float &m2, float o1, flo
     m1 = lo;
 }
 
-template <bool TWO>
+// HALVES = 2 (256 < k <= 512, dither only): the centroids 0 .. 255 and 256 .. k - 1 have a list each -- bytes again, index - 256
+// in the second --, laid out [first records of half 0][of half 1][continuation records of half 0][of half 1].
+__host__ __device__ __forceinline__ size_t list_record_offset(uint32_t halves, uint32_t half, uint32_t part, uint32_t cell)
+{
+    return ((size_t)(part * halves + half) * kLabCells + cell) * kListBytes;
+}
+
+template <bool TWO, int HALVES>
 __global__ __launch_bounds__(kBlock) void k_lab_candidates(const Centroid *__restrict__ cent, uint32_t k, LabReach reach,
                                                            uint8_t *__restrict__ lists)
 {
-    __shared__ uint8_t s_rec_all[kBlock / 64][2 * kListBytes];
+    static_assert(!TWO || HALVES == 1, "the meld lists cover k <= 256");
+    constexpr uint32_t W = 4u * HALVES;
+    __shared__ uint8_t s_rec_all[kBlock / 64][HALVES][2 * kListBytes];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    uint8_t *s_rec = s_rec_all[wv];
     // a wave takes kCellsPerWave cells of the reachable box that differ in L only (the rest of the table says "scan everything":
     // the launcher's memset): its centroids stay in registers, and so do the chroma bounds and weights of its (a, b) column
     const uint32_t groups_L = (reach.nL + kCellsPerWave - 1u) / kCellsPerWave;
@@ -105,23 +113,22 @@ __global__ __launch_bounds__(kBlock) void k_lab_candidates(const Centroid *__res
     if (wave >= groups_L * reach.nA * reach.nB) return;
     const uint32_t gL = wave % groups_L, ib = reach.b0 + (wave / groups_L) % reach.nB, ia = reach.a0 + wave / (groups_L * reach.nB);
     CellBounds cb = lab_cell_bounds(reach.L0, ia, ib);
-    const uint32_t words = (k + 63u) / 64u;
-    Centroid c[4];
+    Centroid c[W];
 #pragma unroll
-    for (uint32_t w = 0; w < 4u; ++w) {
+    for (uint32_t w = 0; w < W; ++w) {
         const uint32_t j = w * 64u + lane;
-        c[w] = cent[w < words && j < k ? j : 0u];
+        c[w] = cent[j < k ? j : 0u];
     }
     for (uint32_t u = 0; u < kCellsPerWave; ++u) {
         if (gL * kCellsPerWave + u >= reach.nL) return;
         const uint32_t iL = reach.L0 + gL * kCellsPerWave + u;
         const uint32_t cell = (iL * (uint32_t)kLabNA + ia) * (uint32_t)kLabNA + ib;
         lab_cell_L_bounds(iL, cb);
-        float U = 3.0e38f, U2 = 3.0e38f, lo[4];
+        float U = 3.0e38f, U2 = 3.0e38f, lo[W];
 #pragma unroll
-        for (uint32_t w = 0; w < 4u; ++w) {
+        for (uint32_t w = 0; w < W; ++w) {
             lo[w] = 3.0e38f;
-            if (w < words && w * 64u + lane < k) {
+            if (w * 64u + lane < k) {
                 const KeyRange r = key_range(cb, c[w].L, c[w].a, c[w].b, c[w].C);
                 lo[w] = r.lo;
                 if (TWO) two_smallest(U, U2, r.hi, 3.0e38f); else U = fminf(U, r.hi);
@@ -136,41 +143,48 @@ __global__ __launch_bounds__(kBlock) void k_lab_candidates(const Centroid *__res
         } else {
             U = mask_threshold(wave_min(U));                        // keep what can still be a near-tie (kmg_math.h)
         }
-        unsigned long long m[4];
-        uint32_t n_cand = 0;
+        unsigned long long m[W];
 #pragma unroll
-        for (uint32_t w = 0; w < 4u; ++w) {
-            m[w] = __ballot(lo[w] <= U);                            // (lo = 3e38 beyond k)
-            n_cand += (uint32_t)__builtin_popcountll(m[w]);
-        }
-        uint32_t pad = 255u;
-        if (k == 256u) {
+        for (uint32_t w = 0; w < W; ++w) m[w] = __ballot(lo[w] <= U);   // (lo = 3e38 beyond k)
+        __builtin_amdgcn_wave_barrier();                            // (the previous cell's records have left)
 #pragma unroll
-            for (int w = 3; w >= 0; --w)
-                if (~m[w]) pad = (uint32_t)w * 64u + (uint32_t)__builtin_ctzll(~m[w]);
-        }
-        __builtin_amdgcn_wave_barrier();                            // (the previous cell's record has left)
-        if (lane < 16u) reinterpret_cast<uint32_t *>(s_rec)[lane] = pad * 0x01010101u;
-        __builtin_amdgcn_wave_barrier();
-        if (n_cand <= kListMax) {
-            uint32_t base = 1u;                                     // byte 0 is the count
+        for (uint32_t h = 0; h < (uint32_t)HALVES; ++h) {
+            uint8_t *s_rec = s_rec_all[wv][h];
+            uint32_t n_cand = 0;
 #pragma unroll
-            for (uint32_t w = 0; w < 4u; ++w) {
-                if ((m[w] >> lane) & 1ull) s_rec[base + bits_below_lane(m[w])] = (uint8_t)(w * 64u + lane);
-                base += (uint32_t)__builtin_popcountll(m[w]);
+            for (uint32_t w = 0; w < 4u; ++w) n_cand += (uint32_t)__builtin_popcountll(m[4u * h + w]);
+            // a byte that is no entry: a centroid of this half outside the list, or -- the half has fewer than 256 -- index 255
+            uint32_t pad = 255u;
+            if (k >= 256u * (h + 1u)) {
+#pragma unroll
+                for (int w = 3; w >= 0; --w)
+                    if (~m[4u * h + w]) pad = (uint32_t)w * 64u + (uint32_t)__builtin_ctzll(~m[4u * h + w]);
             }
+            if (lane < 16u) reinterpret_cast<uint32_t *>(s_rec)[lane] = pad * 0x01010101u;
+            __builtin_amdgcn_wave_barrier();
+            if (n_cand <= kListMax) {
+                uint32_t base = 1u;                                 // byte 0 is the count
+#pragma unroll
+                for (uint32_t w = 0; w < 4u; ++w) {
+                    const unsigned long long mw = m[4u * h + w];
+                    if ((mw >> lane) & 1ull) s_rec[base + bits_below_lane(mw)] = (uint8_t)(w * 64u + lane);
+                    base += (uint32_t)__builtin_popcountll(mw);
+                }
+            }
+            if (lane == 0u) s_rec[0] = (uint8_t)(n_cand <= kListMax ? n_cand : 255u);
+            __builtin_amdgcn_wave_barrier();
+            const uint4 *src = reinterpret_cast<const uint4 *>(s_rec);
+            if (lane < 2u) reinterpret_cast<uint4 *>(lists + list_record_offset(HALVES, h, 0u, cell))[lane] = src[lane];
+            else if (lane < 4u) reinterpret_cast<uint4 *>(lists + list_record_offset(HALVES, h, 1u, cell))[lane - 2u] = src[lane];
         }
-        if (lane == 0u) s_rec[0] = (uint8_t)(n_cand <= kListMax ? n_cand : 255u);
-        __builtin_amdgcn_wave_barrier();
-        const uint4 *src = reinterpret_cast<const uint4 *>(s_rec);
-        if (lane < 2u) reinterpret_cast<uint4 *>(lists + (uint64_t)cell * kListBytes)[lane] = src[lane];
-        else if (lane < 4u) reinterpret_cast<uint4 *>(lists + ((uint64_t)kLabCells + cell) * kListBytes)[lane - 2u] = src[lane];
     }
 }
 
+size_t lab_list_bytes(uint32_t k) { return (k > 256u ? 2u : 1u) * kLabListBytes; }
+
 hipError_t launch_lab_candidates(const Centroid *cent, uint32_t k, float threshold, bool two_closest, uint8_t *lists, hipStream_t st)
 {
-    if (k > 256u || (two_closest && k < 2u)) return hipErrorInvalidValue;
+    if (k > (two_closest ? 256u : kLabListMaxK) || (two_closest && k < 2u)) return hipErrorInvalidValue;
     // sRGB in the shader's Lab: L 0 .. 100, a -86.2 .. 98.3, b -107.9 .. 94.5 (one cell of margin), moved by the 16 offsets
     // threshold (0 .. 15) / 16 - threshold / 2; clipped to the interior of the grid (its rim cells are unbounded outwards).
     // Cells outside get no list -- count 255, "scan everything": exact for any pixel that lands there all the same, so only
@@ -183,12 +197,14 @@ hipError_t launch_lab_candidates(const Centroid *cent, uint32_t k, float thresho
     reach.a0 = lo_cell(-91.0f + o0, kLabA0, kLabNA);  const uint32_t a1 = lo_cell(103.0f + o1, kLabA0, kLabNA);
     reach.b0 = lo_cell(-112.0f + o0, kLabA0, kLabNA); const uint32_t b1 = lo_cell(99.0f + o1, kLabA0, kLabNA);
     reach.nL = L1 - reach.L0 + 1u; reach.nA = a1 - reach.a0 + 1u; reach.nB = b1 - reach.b0 + 1u;
-    hipError_t e = hipMemsetAsync(lists, 0xFF, (size_t)kLabCells * kListBytes, st);
+    const uint32_t halves = k > 256u ? 2u : 1u;
+    hipError_t e = hipMemsetAsync(lists, 0xFF, (size_t)halves * kLabCells * kListBytes, st);     // every first record
     if (e != hipSuccess) return e;
     const uint32_t n_waves = ((reach.nL + kCellsPerWave - 1u) / kCellsPerWave) * reach.nA * reach.nB;
     const dim3 grid((n_waves + kBlock / 64 - 1) / (kBlock / 64));
-    if (two_closest) hipLaunchKernelGGL(k_lab_candidates<true>, grid, dim3(kBlock), 0, st, cent, k, reach, lists);
-    else hipLaunchKernelGGL(k_lab_candidates<false>, grid, dim3(kBlock), 0, st, cent, k, reach, lists);
+    if (two_closest) hipLaunchKernelGGL((k_lab_candidates<true, 1>), grid, dim3(kBlock), 0, st, cent, k, reach, lists);
+    else if (halves == 2u) hipLaunchKernelGGL((k_lab_candidates<false, 2>), grid, dim3(kBlock), 0, st, cent, k, reach, lists);
+    else hipLaunchKernelGGL((k_lab_candidates<false, 1>), grid, dim3(kBlock), 0, st, cent, k, reach, lists);
     return hipGetLastError();
 }
 
@@ -225,14 +241,14 @@ __device__ __forceinline__ float entry_key(uint32_t j16, const PixelTerms &pp)
 
 // byte P of list word wd -> that centroid's key with its index in the low byte
 template <int P>
-__device__ __forceinline__ uint32_t list_entry_key(uint32_t wd, const PixelTerms &pp)
+__device__ __forceinline__ uint32_t list_entry_key(uint32_t wd, uint32_t lds0, const PixelTerms &pp)
 {
     uint32_t j16;                                                   // (byte P) << 4 in one instruction (sub-dword operand select)
     if (P == 0) asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(j16) : "v"(wd));
     else if (P == 1) asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(j16) : "v"(wd));
     else if (P == 2) asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(j16) : "v"(wd));
     else asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(j16) : "v"(wd));
-    const float key = entry_key(j16, pp);
+    const float key = entry_key(j16 + lds0, pp);                     // (lds0: a constant that lands in the read's offset field)
     return __builtin_amdgcn_perm(__float_as_uint(key), wd, 0x07060500u | (uint32_t)P);
 }
 
@@ -242,6 +258,45 @@ __device__ __forceinline__ void min_and_runner_up(uint32_t kp, uint32_t &best, u
     asm("v_med3_u32 %0, %2, %1, %0\n\tv_min_u32 %1, %1, %2" : "+v"(second), "+v"(best) : "v"(kp));
 }
 
+// One half's list of one pixel: the smallest and second smallest packed key over it (kept in best / second).  rec0 / rec1 = the
+// first record; more than 31 entries: the continuation record is fetched here.
+template <int HALVES>
+__device__ __forceinline__ void walk_list(const uint8_t *__restrict__ lists, uint32_t cell, uint32_t half, uint4 rec0, uint4 rec1,
+                                          const PixelTerms &pp, uint32_t k, uint32_t &best, uint32_t &second)
+{
+    const uint32_t cnt_raw = rec0.x & 255u;
+    const bool over = cnt_raw == 255u;
+    const uint32_t cnt = over ? 0u : cnt_raw;
+    uint4 more0 = make_uint4(0u, 0u, 0u, 0u), more1 = more0;        // the continuation record of a long list
+    if (cnt >= kListBytes) {
+        const uint4 *r = reinterpret_cast<const uint4 *>(lists + list_record_offset(HALVES, half, 1u, cell));
+        more0 = r[0]; more1 = r[1];
+    }
+    // byte t of the list's 64 bytes: [count][index 0 .. 62]; a word the list reaches holds entries and, behind them, bytes
+    // that name a centroid outside the list (k_lab_candidates), so all four of its bytes are scanned
+    const uint32_t rw[16] = {rec0.x, rec0.y, rec0.z, rec0.w, rec1.x, rec1.y, rec1.z, rec1.w,
+                             more0.x, more0.y, more0.z, more0.w, more1.x, more1.y, more1.z, more1.w};
+    const uint32_t longest = wave_max_u32_dpp(cnt);                  // the wave's longest list
+    const uint32_t lds0 = half * 4096u;                              // this half's 256 table entries
+#define KMG_LIST_ENTRY(WORD, P) min_and_runner_up(list_entry_key<P>(rw[WORD], lds0, pp), best, second);
+    if (longest) {
+        if (cnt) { KMG_LIST_ENTRY(0, 1) KMG_LIST_ENTRY(0, 2) KMG_LIST_ENTRY(0, 3) }
+    }
+#pragma unroll
+    for (int wd = 1; wd < 16; ++wd) {
+        if ((uint32_t)(wd * 4) > longest) break;
+        if ((uint32_t)(wd * 4) <= cnt) { KMG_LIST_ENTRY(wd, 0) KMG_LIST_ENTRY(wd, 1) KMG_LIST_ENTRY(wd, 2) KMG_LIST_ENTRY(wd, 3) }
+    }
+#undef KMG_LIST_ENTRY
+    if (__ballot(over)) {                                           // no list (too long, or a rim cell): every centroid of the half
+        const uint32_t n_half = min(k - half * 256u, 256u);
+        for (uint32_t j = 0; j < n_half; ++j) {
+            if (over) min_and_runner_up((__float_as_uint(entry_key(lds0 + (j << 4), pp)) & ~255u) | j, best, second);
+        }
+    }
+}
+
+template <int HALVES>
 __global__ __launch_bounds__(kBlock) void k_dither_lists(const uint32_t *__restrict__ rgba, uint32_t w, uint64_t n,
                                                          uint32_t row0, const Centroid *__restrict__ cent, uint32_t k,
                                                          const float *__restrict__ lut, const uint32_t *__restrict__ pal,
@@ -249,7 +304,7 @@ __global__ __launch_bounds__(kBlock) void k_dither_lists(const uint32_t *__restr
                                                          uint32_t *__restrict__ out, int aligned)
 {
     extern __shared__ float4 smem4[];
-    constexpr uint32_t kpad = 256u;                                // every byte value indexes the table: entries k .. 255 are far away
+    constexpr uint32_t kpad = 256u * HALVES;                       // every (half, byte) indexes the table: entries k .. are far away
     float4 *s_cent = smem4;
     // the kernel has no static LDS, so its dynamic LDS -- the centroid table first -- starts at LDS address 0 (entry_key)
     if ((uint32_t)reinterpret_cast<uintptr_t>(s_cent) != 0u) __builtin_trap();
@@ -257,11 +312,13 @@ __global__ __launch_bounds__(kBlock) void k_dither_lists(const uint32_t *__restr
     float *s_off = s_lut + 256;
     const float sentinel_C = chroma(10000.0f, 10000.0f);
     s_lut[threadIdx.x] = lut[threadIdx.x];
-    static_assert(kBlock == 256, "one table entry per thread");
-    {
+    static_assert(kBlock == 256, "one table entry per thread and half");
+#pragma unroll
+    for (uint32_t h = 0; h < (uint32_t)HALVES; ++h) {
+        const uint32_t j = h * 256u + threadIdx.x;
         float4 c = make_float4(1.0e18f, 0.0f, 0.0f, 0.0f);       // key ~ 1e36: far above the sentinel's
-        if (threadIdx.x < k) { const Centroid ce = cent[threadIdx.x]; c = make_float4(ce.L, ce.a, ce.b, ce.C); }
-        s_cent[threadIdx.x] = c;
+        if (j < k) { const Centroid ce = cent[j]; c = make_float4(ce.L, ce.a, ce.b, ce.C); }
+        s_cent[j] = c;
     }
     if (threadIdx.x < 16) s_off[threadIdx.x] = threshold * (bayer16(threadIdx.x) / 16.0f - 0.5f);
     __syncthreads();
@@ -276,7 +333,7 @@ __global__ __launch_bounds__(kBlock) void k_dither_lists(const uint32_t *__restr
         gy += row0;
         float pL[4], pa[4], pb[4];
         uint32_t cell[4];
-        uint4 rec[4][2];                                            // the four pixels' lists
+        uint4 rec[4][2];                                            // the four pixels' lists (first half)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const uint32_t bi = (gx & 3u) + ((gy & 3u) << 2);
@@ -284,7 +341,7 @@ __global__ __launch_bounds__(kBlock) void k_dither_lists(const uint32_t *__restr
             const float off = s_off[bi];
             pL[q] = pL[q] + off; pa[q] = pa[q] + off; pb[q] = pb[q] + off;   // mix_colors.wgsl:72
             cell[q] = lab_cell_index(pL[q], pa[q], pb[q]);
-            const uint4 *r = reinterpret_cast<const uint4 *>(lists + (uint64_t)cell[q] * kListBytes);
+            const uint4 *r = reinterpret_cast<const uint4 *>(lists + list_record_offset(HALVES, 0u, 0u, cell[q]));
             rec[q][0] = r[0]; rec[q][1] = r[1];
             gx += 1;
             if (gx == w) { gx = 0; gy += 1; }
@@ -293,62 +350,44 @@ __global__ __launch_bounds__(kBlock) void k_dither_lists(const uint32_t *__restr
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const PixelTerms pt = pixel_terms_fast(pL[q], pa[q], pb[q], chroma(pa[q], pb[q]));
-            const PixelTerms &pp = pt;
             // mix_colors.wgsl:73-80 starts the scan at the sentinel (10000, 10000, 10000), index k.  Its key is not computed here: a
             // pixel whose smallest key is not below kSentinelFloor -- (10000 - L)^2 alone is above that for every L < 9000, and no
             // centroid of a palette in Lab is 1000 units from a pixel -- goes to the literal scan below, which starts at the
             // sentinel and is exact for any input.
             constexpr uint32_t kSentinelFloor = 0x49742400u;          // 1.0e6f
             uint32_t best = 0x7F7FFF00u, second = 0x7F7FFFFFu;
-            const uint32_t cnt_raw = rec[q][0].x & 255u;
-            const bool over = cnt_raw == 255u;
-            const uint32_t cnt = over ? 0u : cnt_raw;
-            uint4 more0 = make_uint4(0u, 0u, 0u, 0u), more1 = more0;    // the continuation record of a long list
-            if (cnt >= kListBytes) {
-                const uint4 *r = reinterpret_cast<const uint4 *>(lists + ((uint64_t)kLabCells + cell[q]) * kListBytes);
-                more0 = r[0]; more1 = r[1];
+            uint4 next0 = make_uint4(0u, 0u, 0u, 0u), next1 = next0;
+            if (HALVES == 2) {                                       // the second half's record, in flight during the first walk
+                const uint4 *r = reinterpret_cast<const uint4 *>(lists + list_record_offset(HALVES, 1u, 0u, cell[q]));
+                next0 = r[0]; next1 = r[1];
             }
-            // byte t of the list's 64 bytes: [count][index 0 .. 62]; a word the list reaches holds entries and, behind them, bytes
-            // that name a centroid outside the list (k_lab_candidates), so all four of its bytes are scanned
-            const uint32_t rw[16] = {rec[q][0].x, rec[q][0].y, rec[q][0].z, rec[q][0].w, rec[q][1].x, rec[q][1].y, rec[q][1].z, rec[q][1].w,
-                                     more0.x, more0.y, more0.z, more0.w, more1.x, more1.y, more1.z, more1.w};
-            const uint32_t longest = wave_max_u32_dpp(cnt);          // the wave's longest list
-#define KMG_LIST_ENTRY(WORD, P) min_and_runner_up(list_entry_key<P>(rw[WORD], pp), best, second);
-            if (longest) {
-                if (cnt) { KMG_LIST_ENTRY(0, 1) KMG_LIST_ENTRY(0, 2) KMG_LIST_ENTRY(0, 3) }
-            }
-#pragma unroll
-            for (int wd = 1; wd < 16; ++wd) {
-                if ((uint32_t)(wd * 4) > longest) break;
-                if ((uint32_t)(wd * 4) <= cnt) { KMG_LIST_ENTRY(wd, 0) KMG_LIST_ENTRY(wd, 1) KMG_LIST_ENTRY(wd, 2) KMG_LIST_ENTRY(wd, 3) }
-            }
-#undef KMG_LIST_ENTRY
-            if (__ballot(over)) {                                   // no list (too long, or a rim cell): every centroid, in order
-                for (uint32_t j = 0; j < k; ++j) {
-                    if (over) min_and_runner_up((__float_as_uint(entry_key(j << 4, pp)) & ~255u) | j, best, second);
-                }
-            }
+            walk_list<HALVES>(lists, cell[q], 0u, rec[q][0], rec[q][1], pt, k, best, second);
             uint32_t idx = best & 255u;
+            if (HALVES == 2) {
+                // the halves apart, then merged; packed keys that differ in their low byte only are a near-tie (decided below)
+                uint32_t best1 = 0x7F7FFF00u, second1 = 0x7F7FFFFFu;
+                walk_list<HALVES>(lists, cell[q], 1u, next0, next1, pt, k, best1, second1);
+                const bool from1 = best1 < best;
+                idx = from1 ? 256u + (best1 & 255u) : idx;
+                second = min(max(best, best1), min(second, second1));
+                best = min(best, best1);
+            }
             const float thr = tie_threshold(__uint_as_float(best));
             const bool near = __uint_as_float(second) <= thr || best >= kSentinelFloor || !(pt.L < 9000.0f);
             if (__ballot(near)) {
-                // near-tie (kmg_math.h): mix_colors.wgsl:73-80 with the literal distance, the sentinel first, same order
+                // near-tie (kmg_math.h): mix_colors.wgsl:73-80 with the literal distance, the sentinel first, same order.  Rare:
+                // the lists are read again, byte by byte
                 float lb = cie94_c(pt.L, pt.a, pt.b, pt.C, 10000.0f, 10000.0f, 10000.0f, sentinel_C);
                 uint32_t li = k;
-                for (uint32_t i = 0; i < kListMax; ++i) {
-                    if (i >= longest) break;
-                    if (near && i < cnt) {
-                        const uint32_t j = (rw[(i + 1u) >> 2] >> (8u * ((i + 1u) & 3u))) & 255u;
-                        const float4 c = s_cent[j];
-                        if (cie94_key(pt, c.x, c.y, c.z, c.w) <= thr) {
-                            const float d = cie94_c(pt.L, pt.a, pt.b, pt.C, c.x, c.y, c.z, c.w);
-                            if (d < lb) { lb = d; li = j; }
-                        }
-                    }
-                }
-                if (__ballot(near && over)) {
-                    for (uint32_t j = 0; j < k; ++j) {
-                        if (near && over) {
+                if (near) {
+                    for (uint32_t h = 0; h < (uint32_t)HALVES; ++h) {
+                        const uint8_t *first = lists + list_record_offset(HALVES, h, 0u, cell[q]);
+                        const uint8_t *cont = lists + list_record_offset(HALVES, h, 1u, cell[q]);
+                        const uint32_t cnt = first[0];
+                        const uint32_t n_half = min(k - h * 256u, 256u);
+                        const uint32_t steps = cnt == 255u ? n_half : cnt;
+                        for (uint32_t i = 0; i < steps; ++i) {
+                            const uint32_t j = h * 256u + (cnt == 255u ? i : (uint32_t)(i < kListBytes - 1u ? first[1u + i] : cont[i - (kListBytes - 1u)]));
                             const float4 c = s_cent[j];
                             if (cie94_key(pt, c.x, c.y, c.z, c.w) <= thr) {
                                 const float d = cie94_c(pt.L, pt.a, pt.b, pt.C, c.x, c.y, c.z, c.w);
@@ -356,8 +395,8 @@ __global__ __launch_bounds__(kBlock) void k_dither_lists(const uint32_t *__restr
                             }
                         }
                     }
+                    idx = li;
                 }
-                if (near) idx = li;
             }
             res[q] = pal[idx];
         }
@@ -369,14 +408,19 @@ hipError_t launch_dither_lists(const uint32_t *rgba, uint32_t w, uint32_t rows, 
                                const float *lut, const uint32_t *pal, float threshold, const uint8_t *lists, uint32_t *out,
                                hipStream_t st)
 {
-    if (k > 256u) return hipErrorInvalidValue;
+    if (k > kLabListMaxK) return hipErrorInvalidValue;
     const uint64_t n = (uint64_t)w * rows;
     const uint64_t tiles = (n + kBlock * 4 - 1) / (kBlock * 4);
     const uint32_t grid = (uint32_t)(tiles < 8192 ? (tiles ? tiles : 1) : 8192);
-    const size_t lds = sizeof(float4) * 256 + (256 + 16) * sizeof(float);
+    const uint32_t halves = k > 256u ? 2u : 1u;
+    const size_t lds = sizeof(float4) * 256 * halves + (256 + 16) * sizeof(float);
     const int aligned = ((reinterpret_cast<uintptr_t>(rgba) & 15u) == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0) ? 1 : 0;
-    hipLaunchKernelGGL(k_dither_lists, dim3(grid), dim3(kBlock), lds, st, rgba, w, n, row0, cent, k, lut, pal, threshold, lists, out,
-                       aligned);
+    if (halves == 2u)
+        hipLaunchKernelGGL(k_dither_lists<2>, dim3(grid), dim3(kBlock), lds, st, rgba, w, n, row0, cent, k, lut, pal, threshold, lists, out,
+                           aligned);
+    else
+        hipLaunchKernelGGL(k_dither_lists<1>, dim3(grid), dim3(kBlock), lds, st, rgba, w, n, row0, cent, k, lut, pal, threshold, lists, out,
+                           aligned);
     return hipGetLastError();
 }
 
@@ -448,7 +492,7 @@ __global__ __launch_bounds__(kBlock) void k_meld_lists(const uint32_t *__restric
             const uint32_t rw[16] = {rec[q][0].x, rec[q][0].y, rec[q][0].z, rec[q][0].w, rec[q][1].x, rec[q][1].y, rec[q][1].z, rec[q][1].w,
                                      more0.x, more0.y, more0.z, more0.w, more1.x, more1.y, more1.z, more1.w};
             const uint32_t longest = wave_max_u32_dpp(cnt);
-#define KMG_LIST_ENTRY(WORD, P) three_smallest(list_entry_key<P>(rw[WORD], pp), k1, k2, k3);
+#define KMG_LIST_ENTRY(WORD, P) three_smallest(list_entry_key<P>(rw[WORD], 0u, pp), k1, k2, k3);
             if (longest) {
                 if (cnt) { KMG_LIST_ENTRY(0, 1) KMG_LIST_ENTRY(0, 2) KMG_LIST_ENTRY(0, 3) }
             }
@@ -538,8 +582,7 @@ __global__ __launch_bounds__(kBlock) void k_check_lab_lists(const Centroid *__re
             const float off = threshold * (bayer16(bi) / 16.0f - 0.5f);
             const PixelTerms pt = pixel_terms(L0 + off, a0 + off, b0 + off);
             const uint32_t cell = lab_cell_index(pt.L, pt.a, pt.b);
-            const uint8_t *rec = lists + (uint64_t)cell * kListBytes, *more = lists + ((uint64_t)kLabCells + cell) * kListBytes;
-            const uint32_t cnt = rec[0];
+            const uint32_t halves = k > 256u ? 2u : 1u;
             const float start = cie94_c(pt.L, pt.a, pt.b, pt.C, 10000.0f, 10000.0f, 10000.0f, sentinel_C);
             float best = start, bestp = start;
             uint32_t idx = k, idxp = k;
@@ -548,12 +591,16 @@ __global__ __launch_bounds__(kBlock) void k_check_lab_lists(const Centroid *__re
                 const float d = cie94_c(pt.L, pt.a, pt.b, pt.C, ce.L, ce.a, ce.b, ce.C);
                 if (d < best) { best = d; idx = j; }
             }
-            if (cnt == 255u) continue;                               // the pass scans everything
-            for (uint32_t i = 0; i < cnt; ++i) {
-                const uint32_t j = i < kListBytes - 1u ? rec[1u + i] : more[i - (kListBytes - 1u)];
-                const Centroid ce = cent[j];
-                const float d = cie94_c(pt.L, pt.a, pt.b, pt.C, ce.L, ce.a, ce.b, ce.C);
-                if (d < bestp) { bestp = d; idxp = j; }
+            for (uint32_t h = 0; h < halves; ++h) {
+                const uint8_t *rec = lists + list_record_offset(halves, h, 0u, cell), *more = lists + list_record_offset(halves, h, 1u, cell);
+                const uint32_t cnt = rec[0];
+                const uint32_t steps = cnt == 255u ? min(k - h * 256u, 256u) : cnt;    // 255: the pass scans the whole half
+                for (uint32_t i = 0; i < steps; ++i) {
+                    const uint32_t j = h * 256u + (cnt == 255u ? i : (uint32_t)(i < kListBytes - 1u ? rec[1u + i] : more[i - (kListBytes - 1u)]));
+                    const Centroid ce = cent[j];
+                    const float d = cie94_c(pt.L, pt.a, pt.b, pt.C, ce.L, ce.a, ce.b, ce.C);
+                    if (d < bestp) { bestp = d; idxp = j; }
+                }
             }
             bad += idx != idxp;
         }

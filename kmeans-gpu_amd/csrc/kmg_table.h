@@ -210,12 +210,15 @@ hipError_t launch_dither_pruned(const uint32_t *rgba, uint32_t w, uint32_t rows,
                                 uint32_t k, const float *lut, const uint32_t *pal, float threshold,
                                 const uint64_t *masks, uint32_t *out, hipStream_t st);
 
-// The same pass for k <= 256 over byte lists per cell of a 4 x 4 x 4 grid over Lab (kmg_lists.hip): lists = 2 x kLabCells
+// The same pass for k <= 512 (meld: 256) over byte lists per cell of a 4 x 4 x 4 grid over Lab (kmg_lists.hip): lists = 2 x kLabCells
 // records of kListBytes, record c = [count][the first 31 candidate indices, ascending], record kLabCells + c = indices 31 .. 62;
 // count 255: scan all centroids.  No image-independent table is needed (no CellBounds): the cells are boxes of Lab.
 constexpr uint32_t kListBytes = 32, kListMax = 2 * kListBytes - 1;
 constexpr uint32_t kLabCells = 40u * 72u * 72u;
 constexpr size_t kLabListBytes = 2ull * kLabCells * kListBytes;
+// the dither pass also takes 256 < k <= kLabListMaxK: two byte lists per cell (centroids 0 .. 255 / 256 .. k - 1), twice the table
+constexpr uint32_t kLabListMaxK = 512;
+size_t lab_list_bytes(uint32_t k);
 // two_closest: the lists of the meld pass (whatever can be one of a pixel's TWO closest centroids; threshold 0)
 hipError_t launch_lab_candidates(const Centroid *cent, uint32_t k, float threshold, bool two_closest, uint8_t *lists, hipStream_t st);
 hipError_t launch_meld_lists(const uint32_t *rgba, uint64_t n, const Centroid *cent, uint32_t k, const float *lut,

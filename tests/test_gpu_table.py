@@ -34,6 +34,8 @@ def _centroid_sets(oracle, rng):
     sets["duplicates"] = np.concatenate([lab[:8], lab[:8], lab[3:4]])
     sets["tight"] = (lab[5] + rng.normal(0, 0.5, (40, 3))).astype(np.float32)
     sets["outside"] = np.array([[150, 0, 0], [-50, 0, 0], [50, 300, -300], [50, 0.001, -0.001]], np.float32)
+    sets["k512"] = oracle.rgb_to_lab(rng.integers(0, 256, (512, 4), dtype=np.uint8))                                   # two byte lists per cell
+    sets["crowded_high"] = np.concatenate([lab[:260], (lab[9] + rng.normal(0, 0.3, (90, 3))).astype(np.float32)])        # > 63 in the second
     sets["crowded100"] = np.concatenate([(lab[7] + rng.normal(0, 0.3, (100, 3))).astype(np.float32), lab[100:256]])   # > 63 candidates
     return {k: oracle.centroids4(v) for k, v in sets.items()}
 
@@ -448,7 +450,7 @@ def test_dither_masks_conservative_for_all_colours(torch_cuda, processor, oracle
         assert processor.debug_check_dither_masks(cent, _stream(torch_cuda)) == 0, name
 
 
-@pytest.mark.parametrize("k", [2, 3, 46, 64, 65, 300])
+@pytest.mark.parametrize("k", [2, 3, 46, 64, 65, 256, 257, 300, 512, 600])
 def test_dither_output_pass_pruned_equals_scan(torch_cuda, oracle, monkeypatch, k):
     """find / reduce in dither mode: candidate-pruned pass (forced) == scan of all centroids == oracle,
     for a whole image and for a row band that starts at an odd image row"""
@@ -475,7 +477,7 @@ def test_dither_output_pass_pruned_equals_scan(torch_cuda, oracle, monkeypatch, 
         p.close()
 
 
-@pytest.mark.parametrize("k,mode", [(46, 0), (64, 0), (65, 0), (200, 0), (33, 2), (64, 2)])
+@pytest.mark.parametrize("k,mode", [(46, 0), (64, 0), (65, 0), (200, 0), (300, 0), (33, 2), (64, 2)])
 def test_mask_word_output_passes_for_small_k_still_equal_the_oracle(torch_cuda, oracle, monkeypatch, k, mode):
     """k <= 256 takes the lists over Lab cells by default; the mask words per (RGB cell, Bayer index) -- the path of k > 256,
     with its sorted (k <= 64) and multi-word kernels -- stay selectable (KMG_DITHER_LISTS=0) and stay right: dither and meld"""
