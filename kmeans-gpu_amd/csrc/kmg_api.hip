@@ -764,7 +764,7 @@ extern "C" int kmg_debug_check_table(kmg_lloyd *s, uint64_t out[3], void *stream
 // test support: exhaustive validation of the dither candidate masks (kmg_table.hip) for a centroid
 // table: over all 2^24 colours x 16 Bayer offsets, the arg-min over the candidates must equal the
 // brute-force arg-min.  *violations must come back 0.
-// Which pruned dither pass?  k <= 512 (meld: 256): byte lists per cell of a grid over Lab (kmg_lists.hip); larger k: mask words per (RGB
+// Which pruned dither / meld pass?  k <= 512: byte lists per cell of a grid over Lab (kmg_lists.hip); larger k: mask words per (RGB
 // cell, Bayer index) (kmg_table.hip).  KMG_DITHER_LISTS = 0 sends every k to the mask words, 1 (tools) keeps k <= 64 there.
 static bool dither_takes_lists(uint32_t k)
 {
@@ -855,8 +855,8 @@ extern "C" int kmg_debug_check_meld_masks(kmg_processor *p, const float *c4, uin
     HIP_TRY(launch_check_meld_masks((const Centroid *)cent.ptr, k, (const uint64_t *)masks.ptr, p->d_lut,
                                     (unsigned long long *)viol.ptr, S(stream)));
     DevBuf lists;
-    if (k <= 256u) {                                        // the byte lists over Lab cells (kmg_lists.hip), same counter
-        HIP_TRY(lists.alloc(kLabListBytes));
+    if (k <= kLabListMaxK) {                                // the byte lists over Lab cells (kmg_lists.hip), same counter
+        HIP_TRY(lists.alloc(lab_list_bytes(k)));
         HIP_TRY(launch_lab_candidates((const Centroid *)cent.ptr, k, 0.0f, true, (uint8_t *)lists.ptr, S(stream)));
         HIP_TRY(launch_check_lab_lists_two((const Centroid *)cent.ptr, k, (const uint8_t *)lists.ptr, p->d_lut,
                                            (unsigned long long *)viol.ptr, S(stream)));
@@ -1727,7 +1727,7 @@ extern "C" int kmg_dev_apply(kmg_processor *p, const uint8_t *d_rgba, uint32_t w
     const size_t masks_bytes = sizeof(uint64_t) * (size_t)kCells * mask_words(k) * (dither_pruned ? 16u : 1u);
     size_t need = ArenaGuard::padded(tables_bytes);
     const bool dither_lists = dither_pruned && dither_takes_lists(k);      // byte lists over Lab cells instead of mask words
-    const bool meld_lists = meld_masks_pay && k <= 256u && dither_takes_lists(k);   // the same for the meld pass's two closest
+    const bool meld_lists = meld_masks_pay && dither_takes_lists(k);       // the same for the meld pass's two closest
     if ((meld_masks_pay && !meld_lists) || (dither_pruned && !dither_lists)) need += ArenaGuard::padded(masks_bytes);
     if (dither_lists || meld_lists) need += ArenaGuard::padded(lab_list_bytes(k));
     if (replace_table) need += ArenaGuard::padded(labels_bytes) + ArenaGuard::padded(sub_bytes) + ArenaGuard::padded(cube_masks_bytes(k)) +
@@ -1751,7 +1751,7 @@ extern "C" int kmg_dev_apply(kmg_processor *p, const uint8_t *d_rgba, uint32_t w
     } else if (mode == KMG_MODE_MELD) {
         const uint64_t *meld_masks = nullptr;
         if (meld_lists) {
-            uint8_t *lst = (uint8_t *)arena.take(kLabListBytes);
+            uint8_t *lst = (uint8_t *)arena.take(lab_list_bytes(k));
             e = launch_lab_candidates(d_cent, k, 0.0f, true, lst, S(stream));
             if (e == hipSuccess)
                 e = launch_meld_lists((const uint32_t *)d_rgba, n_px, d_cent, k, p->d_lut, lst, (uint32_t *)d_out, S(stream));

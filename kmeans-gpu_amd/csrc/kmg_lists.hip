@@ -1,4 +1,4 @@
-// kmg_lists.hip -- the ordered-dither (k <= 512) and meld (k <= 256) output passes on large images (mix_colors.wgsl:50-83, :29-48 + :85-90):
+// kmg_lists.hip -- the ordered-dither and meld output passes on large images with k <= 512 (mix_colors.wgsl:50-83, :29-48 + :85-90):
 // candidate lists per cell of a grid over Lab, and the passes that walk them.
 //
 // A dithered pixel is compared with the centroids at Lab(pixel) + off (1, 1, 1), off one of 16 Bayer offsets.  Rounds 1-3a
@@ -91,7 +91,7 @@ __device__ __forceinline__ void two_smallest(float &m1, float &m2, float o1, flo
     m1 = lo;
 }
 
-// HALVES = 2 (256 < k <= 512, dither only): the centroids 0 .. 255 and 256 .. k - 1 have a list each -- bytes again, index - 256
+// HALVES = 2 (256 < k <= 512): the centroids 0 .. 255 and 256 .. k - 1 have a list each -- bytes again, index - 256
 // in the second --, laid out [first records of half 0][of half 1][continuation records of half 0][of half 1].
 __host__ __device__ __forceinline__ size_t list_record_offset(uint32_t halves, uint32_t half, uint32_t part, uint32_t cell)
 {
@@ -102,7 +102,6 @@ template <bool TWO, int HALVES>
 __global__ __launch_bounds__(kBlock) void k_lab_candidates(const Centroid *__restrict__ cent, uint32_t k, LabReach reach,
                                                            uint8_t *__restrict__ lists)
 {
-    static_assert(!TWO || HALVES == 1, "the meld lists cover k <= 256");
     constexpr uint32_t W = 4u * HALVES;
     __shared__ uint8_t s_rec_all[kBlock / 64][HALVES][2 * kListBytes];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -184,7 +183,7 @@ size_t lab_list_bytes(uint32_t k) { return (k > 256u ? 2u : 1u) * kLabListBytes;
 
 hipError_t launch_lab_candidates(const Centroid *cent, uint32_t k, float threshold, bool two_closest, uint8_t *lists, hipStream_t st)
 {
-    if (k > (two_closest ? 256u : kLabListMaxK) || (two_closest && k < 2u)) return hipErrorInvalidValue;
+    if (k > kLabListMaxK || (two_closest && k < 2u)) return hipErrorInvalidValue;
     // sRGB in the shader's Lab: L 0 .. 100, a -86.2 .. 98.3, b -107.9 .. 94.5 (one cell of margin), moved by the 16 offsets
     // threshold (0 .. 15) / 16 - threshold / 2; clipped to the interior of the grid (its rim cells are unbounded outwards).
     // Cells outside get no list -- count 255, "scan everything": exact for any pixel that lands there all the same, so only
@@ -202,7 +201,8 @@ hipError_t launch_lab_candidates(const Centroid *cent, uint32_t k, float thresho
     if (e != hipSuccess) return e;
     const uint32_t n_waves = ((reach.nL + kCellsPerWave - 1u) / kCellsPerWave) * reach.nA * reach.nB;
     const dim3 grid((n_waves + kBlock / 64 - 1) / (kBlock / 64));
-    if (two_closest) hipLaunchKernelGGL((k_lab_candidates<true, 1>), grid, dim3(kBlock), 0, st, cent, k, reach, lists);
+    if (two_closest && halves == 2u) hipLaunchKernelGGL((k_lab_candidates<true, 2>), grid, dim3(kBlock), 0, st, cent, k, reach, lists);
+    else if (two_closest) hipLaunchKernelGGL((k_lab_candidates<true, 1>), grid, dim3(kBlock), 0, st, cent, k, reach, lists);
     else if (halves == 2u) hipLaunchKernelGGL((k_lab_candidates<false, 2>), grid, dim3(kBlock), 0, st, cent, k, reach, lists);
     else hipLaunchKernelGGL((k_lab_candidates<false, 1>), grid, dim3(kBlock), 0, st, cent, k, reach, lists);
     return hipGetLastError();
@@ -437,6 +437,42 @@ __device__ __forceinline__ void three_smallest(uint32_t kp, uint32_t &b, uint32_
     asm("v_med3_u32 %0, %3, %1, %0\n\tv_med3_u32 %1, %3, %2, %1\n\tv_min_u32 %2, %2, %3" : "+v"(t), "+v"(s), "+v"(b) : "v"(kp));
 }
 
+// one half's list of one pixel: its three smallest packed keys (walk_list with three_smallest)
+template <int HALVES>
+__device__ __forceinline__ void walk_list3(const uint8_t *__restrict__ lists, uint32_t cell, uint32_t half, uint4 rec0, uint4 rec1,
+                                           const PixelTerms &pp, uint32_t k, uint32_t &k1, uint32_t &k2, uint32_t &k3)
+{
+    const uint32_t cnt_raw = rec0.x & 255u;
+    const bool over = cnt_raw == 255u;
+    const uint32_t cnt = over ? 0u : cnt_raw;
+    uint4 more0 = make_uint4(0u, 0u, 0u, 0u), more1 = more0;
+    if (cnt >= kListBytes) {
+        const uint4 *r = reinterpret_cast<const uint4 *>(lists + list_record_offset(HALVES, half, 1u, cell));
+        more0 = r[0]; more1 = r[1];
+    }
+    const uint32_t rw[16] = {rec0.x, rec0.y, rec0.z, rec0.w, rec1.x, rec1.y, rec1.z, rec1.w,
+                             more0.x, more0.y, more0.z, more0.w, more1.x, more1.y, more1.z, more1.w};
+    const uint32_t longest = wave_max_u32_dpp(cnt);
+    const uint32_t lds0 = half * 4096u;
+#define KMG_LIST_ENTRY(WORD, P) three_smallest(list_entry_key<P>(rw[WORD], lds0, pp), k1, k2, k3);
+    if (longest) {
+        if (cnt) { KMG_LIST_ENTRY(0, 1) KMG_LIST_ENTRY(0, 2) KMG_LIST_ENTRY(0, 3) }
+    }
+#pragma unroll
+    for (int wd = 1; wd < 16; ++wd) {
+        if ((uint32_t)(wd * 4) > longest) break;
+        if ((uint32_t)(wd * 4) <= cnt) { KMG_LIST_ENTRY(wd, 0) KMG_LIST_ENTRY(wd, 1) KMG_LIST_ENTRY(wd, 2) KMG_LIST_ENTRY(wd, 3) }
+    }
+#undef KMG_LIST_ENTRY
+    if (__ballot(over)) {
+        const uint32_t n_half = min(k - half * 256u, 256u);
+        for (uint32_t j = 0; j < n_half; ++j) {
+            if (over) three_smallest((__float_as_uint(entry_key(lds0 + (j << 4), pp)) & ~255u) | j, k1, k2, k3);
+        }
+    }
+}
+
+template <int HALVES>
 __global__ __launch_bounds__(kBlock) void k_meld_lists(const uint32_t *__restrict__ rgba, uint64_t n,
                                                        const Centroid *__restrict__ cent, uint32_t k,
                                                        const float *__restrict__ lut, const uint8_t *__restrict__ lists,
@@ -445,15 +481,17 @@ __global__ __launch_bounds__(kBlock) void k_meld_lists(const uint32_t *__restric
     extern __shared__ float4 smem4[];
     float4 *s_cent = smem4;
     if ((uint32_t)reinterpret_cast<uintptr_t>(s_cent) != 0u) __builtin_trap();   // (entry_key reads the table at LDS address 0)
-    float *s_lut = reinterpret_cast<float *>(smem4 + 256);
+    float *s_lut = reinterpret_cast<float *>(smem4 + 256 * HALVES);
     float *s_thr = s_lut + 256;                                    // the thresholds of the sRGB8 encode (kmg_device.h)
     s_lut[threadIdx.x] = lut[threadIdx.x];
     s_thr[threadIdx.x] = lut[256 + threadIdx.x];
     if (threadIdx.x == 0) s_thr[256] = 3.0e38f;
-    {
+#pragma unroll
+    for (uint32_t h = 0; h < (uint32_t)HALVES; ++h) {
+        const uint32_t j = h * 256u + threadIdx.x;
         float4 c = make_float4(1.0e18f, 0.0f, 0.0f, 0.0f);
-        if (threadIdx.x < k) { const Centroid ce = cent[threadIdx.x]; c = make_float4(ce.L, ce.a, ce.b, ce.C); }
-        s_cent[threadIdx.x] = c;
+        if (j < k) { const Centroid ce = cent[j]; c = make_float4(ce.L, ce.a, ce.b, ce.C); }
+        s_cent[j] = c;
     }
     __syncthreads();
     const float sentinel_C = chroma(10000.0f, 10000.0f);
@@ -470,7 +508,7 @@ __global__ __launch_bounds__(kBlock) void k_meld_lists(const uint32_t *__restric
         for (int q = 0; q < 4; ++q) {
             px_to_lab(s_lut, px[q], pL[q], pa[q], pb[q]);
             cell[q] = lab_cell_index(pL[q], pa[q], pb[q]);
-            const uint4 *r = reinterpret_cast<const uint4 *>(lists + (uint64_t)cell[q] * kListBytes);
+            const uint4 *r = reinterpret_cast<const uint4 *>(lists + list_record_offset(HALVES, 0u, 0u, cell[q]));
             rec[q][0] = r[0]; rec[q][1] = r[1];
         }
         uint32_t res[4];
@@ -478,66 +516,59 @@ __global__ __launch_bounds__(kBlock) void k_meld_lists(const uint32_t *__restric
         for (int q = 0; q < 4; ++q) {
             const float L = pL[q], a = pa[q], b = pb[q];
             const PixelTerms pt = pixel_terms_fast(L, a, b, chroma(a, b));
-            const PixelTerms &pp = pt;
             constexpr uint32_t kSentinelFloor = 0x49742400u;          // 1.0e6f (see k_dither_lists)
             uint32_t k1 = 0x7F7FFF00u, k2 = 0x7F7FFF00u, k3 = 0x7F7FFFFFu;
-            const uint32_t cnt_raw = rec[q][0].x & 255u;
-            const bool over = cnt_raw == 255u;
-            const uint32_t cnt = over ? 0u : cnt_raw;
-            uint4 more0 = make_uint4(0u, 0u, 0u, 0u), more1 = more0;
-            if (cnt >= kListBytes) {
-                const uint4 *r = reinterpret_cast<const uint4 *>(lists + ((uint64_t)kLabCells + cell[q]) * kListBytes);
-                more0 = r[0]; more1 = r[1];
+            uint4 next0 = make_uint4(0u, 0u, 0u, 0u), next1 = next0;
+            if (HALVES == 2) {
+                const uint4 *r = reinterpret_cast<const uint4 *>(lists + list_record_offset(HALVES, 1u, 0u, cell[q]));
+                next0 = r[0]; next1 = r[1];
             }
-            const uint32_t rw[16] = {rec[q][0].x, rec[q][0].y, rec[q][0].z, rec[q][0].w, rec[q][1].x, rec[q][1].y, rec[q][1].z, rec[q][1].w,
-                                     more0.x, more0.y, more0.z, more0.w, more1.x, more1.y, more1.z, more1.w};
-            const uint32_t longest = wave_max_u32_dpp(cnt);
-#define KMG_LIST_ENTRY(WORD, P) three_smallest(list_entry_key<P>(rw[WORD], 0u, pp), k1, k2, k3);
-            if (longest) {
-                if (cnt) { KMG_LIST_ENTRY(0, 1) KMG_LIST_ENTRY(0, 2) KMG_LIST_ENTRY(0, 3) }
-            }
-#pragma unroll
-            for (int wd = 1; wd < 16; ++wd) {
-                if ((uint32_t)(wd * 4) > longest) break;
-                if ((uint32_t)(wd * 4) <= cnt) { KMG_LIST_ENTRY(wd, 0) KMG_LIST_ENTRY(wd, 1) KMG_LIST_ENTRY(wd, 2) KMG_LIST_ENTRY(wd, 3) }
-            }
-#undef KMG_LIST_ENTRY
-            if (__ballot(over)) {
-                for (uint32_t j = 0; j < k; ++j) {
-                    if (over) three_smallest((__float_as_uint(entry_key(j << 4, pp)) & ~255u) | j, k1, k2, k3);
-                }
+            walk_list3<HALVES>(lists, cell[q], 0u, rec[q][0], rec[q][1], pt, k, k1, k2, k3);
+            uint32_t i1 = k1 & 255u, i2 = k2 & 255u;                  // the winners' table entries
+            if (HALVES == 2) {
+                // the three smallest of the two sorted triples; a key of the second half carries index - 256 in its low byte
+                uint32_t c1 = 0x7F7FFF00u, c2 = 0x7F7FFF00u, c3 = 0x7F7FFFFFu;
+                walk_list3<HALVES>(lists, cell[q], 1u, next0, next1, pt, k, c1, c2, c3);
+                const uint32_t m1 = min(k1, c1), m2 = min(min(k2, c2), max(k1, c1));
+                const uint32_t m3 = min(min(k3, c3), min(max(k2, c1), max(k1, c2)));
+                // (keys of the two halves that are EQUAL are a near-tie: the literal scan below decides, whatever these say)
+                i1 = c1 < k1 ? 256u + (c1 & 255u) : (k1 & 255u);
+                i2 = (m2 == c1 || m2 == c2) ? 256u + (m2 & 255u) : (m2 & 255u);
+                k1 = m1; k2 = m2; k3 = m3;
             }
             // the two winners, unless something is within the tie slack of one of them
             float cL, ca, cb, cC, sL, sa, sb, sC;                     // (.C: the chroma kept in the table -- cie94_c, kmg_math.h)
             {
-                const float4 c1 = s_cent[k1 & 255u], c2 = s_cent[k2 & 255u];
+                const float4 c1 = s_cent[i1], c2 = s_cent[i2];
                 cL = c1.x; ca = c1.y; cb = c1.z; cC = c1.w; sL = c2.x; sa = c2.y; sb = c2.z; sC = c2.w;
             }
             const bool near = __uint_as_float(k2) <= tie_threshold(__uint_as_float(k1)) ||
                               __uint_as_float(k3) <= tie_threshold(__uint_as_float(k2)) || k2 >= kSentinelFloor || !(pt.L < 9000.0f);
             if (__ballot(near)) {
-                // mix_colors.wgsl:30-41, literally, over the list (k_meld of kmg_kernels.hip does the same over mask words)
+                // mix_colors.wgsl:30-41, literally, over the lists in index order (k_meld of kmg_kernels.hip does the same over mask
+                // words).  Rare: the lists are read again, byte by byte
                 float xL = 10000.0f, xa = 10000.0f, xb = 10000.0f, xC = sentinel_C, yL = 10000.0f, ya = 10000.0f, yb = 10000.0f, yC = sentinel_C;
                 float d_closest = cie94_c(L, a, b, pt.C, xL, xa, xb, xC), d_second = d_closest;
-                auto visit = [&](uint32_t j) {
-                    const float4 c = s_cent[j];
-                    const float d = cie94_c(L, a, b, pt.C, c.x, c.y, c.z, c.w);
-                    if (d < d_closest) {
-                        yL = xL; ya = xa; yb = xb; yC = xC; d_second = d_closest;
-                        xL = c.x; xa = c.y; xb = c.z; xC = c.w; d_closest = d;
-                    } else if (d < d_second) {
-                        yL = c.x; ya = c.y; yb = c.z; yC = c.w; d_second = d;
+                if (near) {
+                    for (uint32_t h = 0; h < (uint32_t)HALVES; ++h) {
+                        const uint8_t *first = lists + list_record_offset(HALVES, h, 0u, cell[q]);
+                        const uint8_t *cont = lists + list_record_offset(HALVES, h, 1u, cell[q]);
+                        const uint32_t cnt = first[0];
+                        const uint32_t steps = cnt == 255u ? min(k - h * 256u, 256u) : cnt;
+                        for (uint32_t i = 0; i < steps; ++i) {
+                            const uint32_t j = h * 256u + (cnt == 255u ? i : (uint32_t)(i < kListBytes - 1u ? first[1u + i] : cont[i - (kListBytes - 1u)]));
+                            const float4 c = s_cent[j];
+                            const float d = cie94_c(L, a, b, pt.C, c.x, c.y, c.z, c.w);
+                            if (d < d_closest) {
+                                yL = xL; ya = xa; yb = xb; yC = xC; d_second = d_closest;
+                                xL = c.x; xa = c.y; xb = c.z; xC = c.w; d_closest = d;
+                            } else if (d < d_second) {
+                                yL = c.x; ya = c.y; yb = c.z; yC = c.w; d_second = d;
+                            }
+                        }
                     }
-                };
-                for (uint32_t i = 0; i < kListMax; ++i) {
-                    if (i >= longest) break;
-                    if (near && i < cnt) visit((rw[(i + 1u) >> 2] >> (8u * ((i + 1u) & 3u))) & 255u);
+                    cL = xL; ca = xa; cb = xb; cC = xC; sL = yL; sa = ya; sb = yb; sC = yC;
                 }
-                if (__ballot(near && over)) {
-                    for (uint32_t j = 0; j < k; ++j)
-                        if (near && over) visit(j);
-                }
-                if (near) { cL = xL; ca = xa; cb = xb; cC = xC; sL = yL; sa = ya; sb = yb; sC = yC; }
             }
             // :86-89
             const float factor = cie94_c(L, a, b, pt.C, sL, sa, sb, sC) / cie94_c(cL, ca, cb, cC, sL, sa, sb, sC);
@@ -553,12 +584,14 @@ __global__ __launch_bounds__(kBlock) void k_meld_lists(const uint32_t *__restric
 hipError_t launch_meld_lists(const uint32_t *rgba, uint64_t n, const Centroid *cent, uint32_t k, const float *lut,
                              const uint8_t *lists, uint32_t *out, hipStream_t st)
 {
-    if (k < 2u || k > 256u) return hipErrorInvalidValue;
+    if (k < 2u || k > kLabListMaxK) return hipErrorInvalidValue;
     const uint64_t tiles = (n + kBlock * 4 - 1) / (kBlock * 4);
     const uint32_t grid = (uint32_t)(tiles < 8192 ? (tiles ? tiles : 1) : 8192);
-    const size_t lds = sizeof(float4) * 256 + (256 + 257) * sizeof(float);
+    const uint32_t halves = k > 256u ? 2u : 1u;
+    const size_t lds = sizeof(float4) * 256 * halves + (256 + 257) * sizeof(float);
     const int aligned = ((reinterpret_cast<uintptr_t>(rgba) & 15u) == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0) ? 1 : 0;
-    hipLaunchKernelGGL(k_meld_lists, dim3(grid), dim3(kBlock), lds, st, rgba, n, cent, k, lut, lists, out, aligned);
+    if (halves == 2u) hipLaunchKernelGGL(k_meld_lists<2>, dim3(grid), dim3(kBlock), lds, st, rgba, n, cent, k, lut, lists, out, aligned);
+    else hipLaunchKernelGGL(k_meld_lists<1>, dim3(grid), dim3(kBlock), lds, st, rgba, n, cent, k, lut, lists, out, aligned);
     return hipGetLastError();
 }
 
@@ -623,9 +656,7 @@ __global__ __launch_bounds__(kBlock) void k_check_lab_lists_two(const Centroid *
         float L, a, b;
         colour_to_lab(s_lut, rgb_cell * kCellColours + c, L, a, b);
         const uint32_t cell = lab_cell_index(L, a, b);
-        const uint8_t *rec = lists + (uint64_t)cell * kListBytes, *more = lists + ((uint64_t)kLabCells + cell) * kListBytes;
-        const uint32_t cnt = rec[0];
-        if (cnt == 255u) continue;                                   // the pass scans everything
+        const uint32_t halves = k > 256u ? 2u : 1u;
         const float d0 = cie94(L, a, b, 10000.0f, 10000.0f, 10000.0f);
         float dc = d0, ds = d0, pc = d0, ps = d0;
         uint32_t ic = k, is = k, jc = k, js = k;
@@ -634,11 +665,16 @@ __global__ __launch_bounds__(kBlock) void k_check_lab_lists_two(const Centroid *
             const float d = cie94(L, a, b, ce.L, ce.a, ce.b);
             if (d < dc) { ds = dc; is = ic; dc = d; ic = j; } else if (d < ds) { ds = d; is = j; }
         }
-        for (uint32_t i = 0; i < cnt; ++i) {
-            const uint32_t j = i < kListBytes - 1u ? rec[1u + i] : more[i - (kListBytes - 1u)];
-            const Centroid ce = cent[j];
-            const float d = cie94(L, a, b, ce.L, ce.a, ce.b);
-            if (d < pc) { ps = pc; js = jc; pc = d; jc = j; } else if (d < ps) { ps = d; js = j; }
+        for (uint32_t h = 0; h < halves; ++h) {
+            const uint8_t *rec = lists + list_record_offset(halves, h, 0u, cell), *more = lists + list_record_offset(halves, h, 1u, cell);
+            const uint32_t cnt = rec[0];
+            const uint32_t steps = cnt == 255u ? min(k - h * 256u, 256u) : cnt;        // 255: the pass scans the whole half
+            for (uint32_t i = 0; i < steps; ++i) {
+                const uint32_t j = h * 256u + (cnt == 255u ? i : (uint32_t)(i < kListBytes - 1u ? rec[1u + i] : more[i - (kListBytes - 1u)]));
+                const Centroid ce = cent[j];
+                const float d = cie94(L, a, b, ce.L, ce.a, ce.b);
+                if (d < pc) { ps = pc; js = jc; pc = d; jc = j; } else if (d < ps) { ps = d; js = j; }
+            }
         }
         bad += (ic != jc) || (is != js);
     }

@@ -687,7 +687,7 @@ def test_meld_masks_conservative_for_all_colours(torch_cuda, processor, oracle):
         assert processor.debug_check_meld_masks(cent, _stream(torch_cuda)) == 0, name
 
 
-@pytest.mark.parametrize("k", [2, 5, 46, 64, 65, 300])
+@pytest.mark.parametrize("k", [2, 3, 46, 64, 65, 256, 300, 512, 600])
 def test_meld_output_pass_pruned_equals_scan(torch_cuda, oracle, monkeypatch, k):
     """find / reduce in meld mode: candidate-pruned pass (forced) is byte-identical to the scan of all
     centroids (the oracle comparison of the scan itself is tests/test_gpu_parity.py::test_meld_matches_oracle)"""
