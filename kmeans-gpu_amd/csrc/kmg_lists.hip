@@ -209,7 +209,7 @@ hipError_t launch_lab_candidates(const Centroid *cent, uint32_t k, float thresho
 }
 
 // ---- the pass ---------------------------------------------------------------------------------------------------------------
-// With the table in L2 the pass is bound by vector issue (profiles/r03d_apply_pmc.txt: ~350 vector instructions per pixel, the
+// With the table in L2 the pass is bound by vector issue (profiles/r03e_apply_pmc.txt: ~350 vector instructions per pixel, the
 // vector units busy for the whole kernel), so the list walk is written for instruction count -- 13 per candidate instead of 20:
 //   * the candidate's index travels in the low byte of its key (one v_perm_b32, which also extracts it from the list word), so the
 //     running minimum and runner-up are one v_min_u32 and one v_med3_u32, and the index needs no register of its own;
