@@ -499,9 +499,9 @@ def test_mask_word_output_passes_for_small_k_still_equal_the_oracle(torch_cuda, 
     p.close()
 
 
-@pytest.mark.parametrize("name", ["black_white", "crowded45", "crowded200"])
+@pytest.mark.parametrize("name", ["black_white", "crowded45", "crowded200", "crowded_second_half"])
 def test_dither_lists_continued_overflowing_and_missing(torch_cuda, oracle, monkeypatch, name):
-    """the list pass (k <= 256, kmg_lists.hip) where its lists are not one plain record: a two-colour palette whose threshold
+    """the list passes (dither and meld, kmg_lists.hip) where their lists are not one plain record: a two-colour palette whose threshold
     throws dark pixels off the grid over Lab (no list: every centroid is scanned), 45 near-identical colours (continuation
     records), 200 of them (more than 63 candidates: no list) -- bytes equal the oracle's"""
     import kmeans_gpu_amd as kg
@@ -511,6 +511,13 @@ def test_dither_lists_continued_overflowing_and_missing(torch_cuda, oracle, monk
     img = np.concatenate([_blobs(rng, w * 150, 12, sigma=30.0), oracle.synth_uniform(77, w * 151)]).reshape(h, w, 4)
     if name == "black_white":
         pal = np.array([[0, 0, 0, 255], [255, 255, 255, 255]], np.uint8)
+    elif name == "crowded_second_half":
+        # k = 380: 280 colours with r < 120 sort in front of a crowd of 100 -- more than 63 candidates in the SECOND list of a cell
+        block = np.array([(120 + i % 6, 130 + (i // 6) % 6, 90 + i // 36, 255) for i in range(100)], np.uint8)
+        rest = oracle.synth_uniform(6, 900); rest = rest[rest[:, 0] < 120][:280]
+        pal = np.array(sorted(set(map(tuple, np.concatenate([block, rest])))), np.uint8)
+        assert pal.shape[0] > 300 and (pal[:256, 0] < 120).all()
+        img[:100, :, :3] = np.clip(rng.normal((122, 132, 92), 6.0, (100, w, 3)), 0, 255).astype(np.uint8)
     else:
         m = 45 if name == "crowded45" else 200
         block = np.array([(120 + i % 6, 130 + (i // 6) % 6, 90 + i // 36, 255) for i in range(m)], np.uint8)
@@ -522,11 +529,12 @@ def test_dither_lists_continued_overflowing_and_missing(torch_cuda, oracle, monk
     p = kg.ImageProcessor()
     d = _dev(torch, img.reshape(-1, 4))
     out = torch.zeros((w * h, 4), dtype=torch.uint8, device="cuda")
-    p.apply(d.data_ptr(), w, h, 0, cent, kg.ReduceMode.Dither, out.data_ptr(), _stream(torch))
-    torch.cuda.synchronize()
-    want = oracle.find(img, pal, oracle.MODE_DITHER)
-    got = out.cpu().numpy().reshape(h, w, 4)
-    assert np.array_equal(got, want), f"{int((got != want).any(-1).sum())} pixels differ"
+    for mode, omode in ((kg.ReduceMode.Dither, oracle.MODE_DITHER), (kg.ReduceMode.Meld, oracle.MODE_MELD)):
+        p.apply(d.data_ptr(), w, h, 0, cent, mode, out.data_ptr(), _stream(torch))
+        torch.cuda.synchronize()
+        want = oracle.find(img, pal, omode)
+        got = out.cpu().numpy().reshape(h, w, 4)
+        assert np.array_equal(got, want), f"{mode}: {int((got != want).any(-1).sum())} pixels differ"
     p.close()
 
 
