@@ -217,6 +217,101 @@ def cfg4_tiled_rank_share(proc, k, width, height, stream, steps=3, images=16, wo
             "cfg4_tiled_collectives_per_iteration": 1}
 
 
+CFG2_WIDTH, CFG2_HEIGHT, CFG2_K = 4096, 4096, 16
+VALU_LANE_OPS_PEAK = 78.6e12             # fp32 vector lane-operations per second (157.3 TF/s counts an FMA as two)
+
+
+def cfg2_timing(proc, stream, steps=20, strategies=("table", "scan"), profile_kernels=True):
+    """BASELINE config 2: synthetic 4096 x 4096 (seed 0x5EED0002), k = 16, assign + update only -- the configuration of
+    tests/test_gpu_table.py::test_cfg2_full_size_assign_update (centroids = shader Lab of the pixels at j * floor(N/k)).
+    One step = one assignment with its label map and sums + the centroid update.  Both strategies are timed (the library's
+    cost model picks one; `cfg2_strategy_auto` says which); the reported step is the auto choice's.  Not part of `value`."""
+    import numpy as np
+    import torch
+    import kmeans_gpu_amd as kg
+    from kmeans_gpu_amd import synth
+    n, k = CFG2_WIDTH * CFG2_HEIGHT, CFG2_K
+    rgba = synth.uniform_rgba_torch(synth.SEED_CFG2, n, device="cuda")
+    labels = torch.empty(n, dtype=torch.int32, device="cuda")
+    acc = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
+    sel = synth.uniform_rgba_at(synth.SEED_CFG2, np.arange(k, dtype=np.uint64) * np.uint64(n // k))
+    d_sel = torch.from_numpy(sel).cuda()
+    lab = torch.empty((k, 3), dtype=torch.float32, device="cuda")
+    proc.rgb_to_lab(d_sel.data_ptr(), k, lab.data_ptr(), stream)
+    torch.cuda.synchronize()
+    cent = np.ones((k, 4), np.float32)
+    cent[:, :3] = lab.cpu().numpy()
+    out = {}
+    old = os.environ.get("KMG_STRATEGY")
+    try:
+        os.environ.pop("KMG_STRATEGY", None)
+        s = kg.Lloyd(proc, k)
+        s.set_centroids(cent, stream)
+        out["cfg2_strategy_auto"] = s.prepare(rgba.data_ptr(), n, True, stream)
+        s.close()
+        for strategy in strategies:
+            os.environ["KMG_STRATEGY"] = {"scan": "brute", "table": "table"}[strategy]
+            s = kg.Lloyd(proc, k)
+            s.set_centroids(cent, stream)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            s.prepare(rgba.data_ptr(), n, True, stream)
+            torch.cuda.synchronize()
+            out[f"cfg2_{strategy}_prepare_ms"] = (time.perf_counter() - t) * 1e3
+
+            def step():
+                s.assign_update(rgba.data_ptr(), n, labels.data_ptr(), acc.data_ptr(), True, stream)
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize()
+            out[f"cfg2_{strategy}_ms_per_step"] = (time.perf_counter() - t) / steps * 1e3
+            if profile_kernels:
+                s.profile(True)
+                for _ in range(min(steps, 10)):
+                    step()
+                torch.cuda.synchronize()
+                out[f"cfg2_{strategy}_kernels_ms"] = {nm: ms / cnt for nm, (ms, cnt) in s.profile_read().items()}
+                s.profile(False)
+            s.close()
+    finally:
+        if old is None:
+            os.environ.pop("KMG_STRATEGY", None)
+        else:
+            os.environ["KMG_STRATEGY"] = old
+    auto = out["cfg2_strategy_auto"]
+    if f"cfg2_{auto}_ms_per_step" in out:
+        out["cfg2_ms_per_step"] = out[f"cfg2_{auto}_ms_per_step"]
+    del rgba, labels
+    return out
+
+
+def cfg2_roofline(extra, tj):
+    """both roofs of SURVEY 8d for config 2: 8 B/px over the step against HBM, and the vector instructions the step's
+    kernels execute (profiles/traffic.json `valu_wave_instructions`, rocprofv3 SQ_INSTS_VALU of the same loop) x 64 lanes
+    over the fp32 vector issue peak"""
+    if "cfg2_ms_per_step" not in extra:
+        return None
+    n = CFG2_WIDTH * CFG2_HEIGHT
+    ms = extra["cfg2_ms_per_step"]
+    r = {"algorithmic_bytes_per_launch": ALGORITHMIC_BYTES_PER_PIXEL * n,
+         "achieved_GBps": ALGORITHMIC_BYTES_PER_PIXEL * n / (ms * 1e-3) / 1e9,
+         "frac": ALGORITHMIC_BYTES_PER_PIXEL * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+         "hbm_floor_ms": ALGORITHMIC_BYTES_PER_PIXEL * n / (HBM_PEAK_GBPS * 1e9) * 1e3,
+         "valu_floor_ms_literal_scan": n * (FLOP_PER_PAIR * CFG2_K + FLOP_PER_PIXEL) / (FP32_VECTOR_PEAK_TFLOPS * 1e12) * 1e3,
+         "strategy": extra.get("cfg2_strategy_auto"),
+         "note": "whole step (all launches of assign + update), host clock over the loop; 4096x4096, k=16, seed 0x5EED0002"}
+    valu = tj.get("valu_wave_instructions", {}).get("cfg2_step")
+    if valu:
+        r["valu_wave_instructions"] = valu
+        r["valu"] = valu * 64 / (ms * 1e-3) / VALU_LANE_OPS_PEAK
+        r["traffic"] = tj.get("bytes_per_launch", {}).get("cfg2_step")
+    return r
+
+
 def reduce_end_to_end(proc, rgba, width, height, k):
     """kmg_reduce (lib.rs:116-164) of the full-resolution image from and to HOST buffers: upload, initialisation, Lloyd loop,
     dither output pass, download -- PCIe included, never part of `value`.  The second call (warm processor: streams, blocks
@@ -302,6 +397,7 @@ def output_pass_timing(proc, rgba, n_pixels, stream, sh=None, steps=3):
         extra.update(cfg4_rank_share(proc, k3, n_pixels, stream, steps=steps))
         extra.update(cfg4_tiled_rank_share(proc, k3, WIDTH, n_pixels // WIDTH, stream, steps=steps))
         extra.update(reduce_end_to_end(proc, rgba, WIDTH, n_pixels // WIDTH, k3))
+        extra.update(cfg2_timing(proc, stream, steps=max(steps, 2) * 5))
     except Exception as e:      # the extras must never break the benchmark line (tests/test_gpu_bench.py fails on it instead)
         import traceback
         extra["error"] = repr(e) + " | " + traceback.format_exc().strip().splitlines()[-3].strip()
@@ -360,6 +456,8 @@ def main():
                     help="centroid update as a launch of its own (k_update + memset) instead of on the assign pass's last launch")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the all-reduce even with one rank (sanity check)")
+    ap.add_argument("--only", choices=["cfg2"], default=None,
+                    help="run one secondary configuration alone and print its JSON (for rocprofv3 legs): cfg2 = 4096x4096, k=16")
     ap.add_argument("--strategy", choices=["auto", "scan", "table"], default="auto",
                     help="per-pixel scan, colour table, or the library's cost model (default)")
     args = ap.parse_args()
@@ -401,6 +499,14 @@ def main():
     if args.strategy != "auto":
         os.environ["KMG_STRATEGY"] = {"scan": "brute", "table": "table"}[args.strategy]
     proc = kg.ImageProcessor(device=local_rank, shrink_max_dim=0)
+    if args.only == "cfg2":
+        st = torch.cuda.current_stream().cuda_stream
+        which = ("table", "scan") if args.strategy == "auto" else (args.strategy,)
+        os.environ.pop("KMG_STRATEGY", None)
+        res = cfg2_timing(proc, st, steps=args.steps, strategies=which, profile_kernels=not args.no_extras)
+        proc.close()
+        print(json.dumps(res), flush=True)
+        return
     rgba = synth.uniform_rgba_torch(seed, n_local, first=rank * n_local, device="cuda")
     labels = torch.empty(n_local, dtype=torch.int32, device="cuda")
 
@@ -571,6 +677,9 @@ def main():
                         "frac": ALGORITHMIC_BYTES_PER_PIXEL * n_local / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                         "traffic": tj.get("bytes_per_launch", {}).get(name),
                         "note": "whole kmg_dev_apply call (all its launches), host clock over 3 calls"}
+            c2 = cfg2_roofline(out["extra"], tj)
+            if c2 is not None:
+                out["kernels_roofline"]["cfg2"] = c2
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(k, cent, seed)
         line = json.dumps(out)

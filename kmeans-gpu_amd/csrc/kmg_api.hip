@@ -100,6 +100,9 @@ struct kmg_processor {
     CellBounds *d_bounds;    // kCells static cell bounds of the colour-table strategy
     CellBounds *d_sub_bounds;   // kSubCells static bounds of the 4x4x4 sub-cells
     float4 *d_lab_table;     // 2^24 x (L, a, b, C): Lab of every colour (256 MiB, built with d_bounds)
+    float *d_sub_affine;     // sub_affine_bytes(): affine feature models per sub-cell (dominance test of k_cube_small), built on
+                             // the first colour-table pass with k <= 32
+    bool affine_failed;      // ... or not at all (allocation failed: the pass runs without the test)
     std::vector<hipStream_t> idle_streams;   // streams of finished host-buffer calls, reused by the next ones (mu)
     // Device blocks the processor keeps between uses (mu): output-pass scratch, colour tables and workspaces of finished
     // kmg_lloyd objects.  A block is handed out again to the next request it is large enough for (block_take), so a second
@@ -251,6 +254,8 @@ extern "C" int kmg_processor_create_ex(const kmg_options *opt, kmg_processor **o
     p->d_bounds = nullptr;
     p->d_sub_bounds = nullptr;
     p->d_lab_table = nullptr;
+    p->d_sub_affine = nullptr;
+    p->affine_failed = false;
     p->pool = nullptr;
     {
         // per-call scratch comes from a stream-ordered pool of the processor's own that keeps what has been freed instead
@@ -333,6 +338,7 @@ extern "C" void kmg_processor_destroy(kmg_processor *p)
     if (p->d_bounds) (void)hipFree(p->d_bounds);
     if (p->d_sub_bounds) (void)hipFree(p->d_sub_bounds);
     if (p->d_lab_table) (void)hipFree(p->d_lab_table);
+    if (p->d_sub_affine) (void)hipFree(p->d_sub_affine);
     for (hipStream_t st : p->idle_streams) (void)hipStreamDestroy(st);
     for (auto &a : p->idle_arenas) (void)hipFree(a.first);
     if (p->pool) (void)hipMemPoolDestroy(p->pool);
@@ -504,7 +510,7 @@ static inline void *carve(void *base, size_t &off, size_t bytes)
 // Cost model (seconds per iteration on MI355X; constants fitted to tools/strategy_sweep.py, refitted in round 2 --
 // the cube pass got cheaper, the per-pixel scan tracks the runner-up key for the literal arg-min):
 //   per-pixel scan : 1.4e-5 + 3.3e-7 k + n * (6.8e-12 + 2.45e-13 k)     (the k term: partial-sum slab and its reduction)
-//   colour table   : 8.6e-5 + 1.85e-7 k                      cube pass (independent of n)
+//   colour table   : 8.6e-5 + 1.85e-7 k                      cube pass (independent of n; k <= 32: 5.6e-5 + 2.0e-7 k, one launch)
 //                    + n * (1.8e-12 + 2.0e-15 k)              label pass, k <= 256 (6.7e-12 for u16 labels)
 //                    + bind_seconds(n) / 16                   one-off histogram + cell sums, spread over ~16 passes
 // one-off cost of binding an image: partitioned histogram (n >= 2^21) or one global atomic per pixel, + cell sums
@@ -523,7 +529,9 @@ static bool table_pays(uint64_t n, uint32_t k, bool labels)
     const double N = (double)n;
     const double brute = 1.4e-5 + 3.3e-7 * k + N * (6.8e-12 + 2.45e-13 * k);
     const double label_pass = labels ? N * (k <= 256 ? 1.8e-12 + 2.0e-15 * k : 6.7e-12) : 0.0;
-    const double table = 8.6e-5 + 1.85e-7 * k + label_pass + bind_seconds(n) / 16.0;
+    // (k <= 32: the one-launch cube pass of small centroid tables, k_cube_small -- 58 us at k = 16, round 4)
+    const double cube = k <= 32u ? 5.6e-5 + 2.0e-7 * k : 8.6e-5 + 1.85e-7 * k;
+    const double table = cube + label_pass + bind_seconds(n) / 16.0;
     return table < brute;
 }
 
@@ -589,6 +597,27 @@ static int ensure_bounds(kmg_processor *p, hipStream_t st)
     p->d_sub_bounds = sb;
     p->d_bounds = b;
     return KMG_OK;
+}
+
+// The dominance test's table (kmg_table.h), image independent, for passes with k <= 32: built once, after ensure_bounds.
+// NULL when it cannot be had -- the pass is exact without it, only slower.
+static const float *affine_for(kmg_processor *p, uint32_t k, hipStream_t st)
+{
+    if (k > 32u) return nullptr;
+    std::lock_guard<std::mutex> lock(p->mu);
+    if (p->d_sub_affine || p->affine_failed || !p->d_lab_table) return p->d_sub_affine;
+    float *a = nullptr;
+    hipError_t e = hipMalloc((void **)&a, sub_affine_bytes());
+    if (e == hipSuccess) e = launch_sub_affine(p->d_lab_table, a, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (a) (void)hipFree(a);
+        p->affine_failed = true;
+        return nullptr;
+    }
+    p->d_sub_affine = a;
+    return a;
 }
 
 // everything a binding derives from the histogram: per-cell and per-sub-cell sums, occupancy bits, the list of occupied
@@ -751,7 +780,7 @@ extern "C" int kmg_debug_check_table(kmg_lloyd *s, uint64_t out[3], void *stream
     HIP_TRY(hipMemsetAsync(viol.ptr, 0, 3 * sizeof(unsigned long long), S(stream)));
     HIP_TRY(launch_cube(nullptr, nullptr, nullptr, nullptr, nullptr, s->p->d_bounds, s->p->d_sub_bounds, s->d_cent, s->k,
                         s->p->d_lab_table, (uint64_t *)masks.ptr, cwork.ptr, labels.ptr, (uint16_t *)sub.ptr, nullptr, 0, 1u, nullptr,
-                        S(stream)));
+                        S(stream), nullptr, affine_for(s->p, s->k, S(stream))));
     HIP_TRY(launch_check_bounds(s->p->d_bounds, s->p->d_sub_bounds, s->d_cent, s->k, (const uint64_t *)masks.ptr, labels.ptr,
                                 s->p->d_lut, (unsigned long long *)viol.ptr, S(stream)));
     unsigned long long h[3];
@@ -984,7 +1013,8 @@ static int debug_refresh(kmg_lloyd *s, hipStream_t st, unsigned long long stage[
     unsigned long long *d_stage = reinterpret_cast<unsigned long long *>(s->d_partials) + 4ull * s->k;
     HIP_TRY(hipMemsetAsync(s->d_partials, 0, sizeof(int64_t) * (4ull * s->k + 6ull), st));
     HIP_TRY(launch_cube(t.d_hist, t.d_agg, t.d_sub_agg, t.d_occ, t.d_work, s->p->d_bounds, s->p->d_sub_bounds, s->d_cent, s->k,
-                        s->p->d_lab_table, t.d_masks, t.d_cell_work, t.d_colour_labels, t.d_sub, s->d_partials, 1u, 1u, d_stage, st));
+                        s->p->d_lab_table, t.d_masks, t.d_cell_work, t.d_colour_labels, t.d_sub, s->d_partials, 1u, 1u, d_stage, st,
+                        nullptr, affine_for(s->p, s->k, st)));
     t.entries_valid = true;
     if (stage) HIP_TRY(hipMemcpyAsync(stage, d_stage, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -1043,7 +1073,8 @@ static int table_assign(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_
         PROF_LAUNCH(s, KMG_K_CUBE, st, launch_cube(t.d_hist, t.d_agg, t.d_sub_agg, t.d_occ, t.d_work_share ? t.d_work_share : t.d_work,
                                                    s->p->d_bounds, s->p->d_sub_bounds,
                                                    s->d_cent, s->k, s->p->d_lab_table, t.d_masks, t.d_cell_work, t.d_colour_labels, t.d_sub,
-                                                   s->d_acc_int, 1u, defer_entries ? kCubeNoEntries : 0u, nullptr, st, &tail));
+                                                   s->d_acc_int, 1u, defer_entries ? kCubeNoEntries : 0u, nullptr, st, &tail,
+                                                   affine_for(s->p, s->k, st)));
         s->acc_int_dirty = false;
         t.entries_valid = !defer_entries;
     } else {
@@ -1051,7 +1082,7 @@ static int table_assign(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_
         HIP_TRY(hipMemsetAsync(d_sums, 0, sizeof(int64_t) * 4ull * s->k * rows, st));
         PROF_LAUNCH(s, KMG_K_CUBE, st, launch_cube(t.d_hist, t.d_agg, t.d_sub_agg, t.d_occ, t.d_work, s->p->d_bounds, s->p->d_sub_bounds,
                                                    s->d_cent, s->k, s->p->d_lab_table, t.d_masks, t.d_cell_work, t.d_colour_labels, t.d_sub,
-                                                   d_sums, rows, 0u, nullptr, st));
+                                                   d_sums, rows, 0u, nullptr, st, nullptr, affine_for(s->p, s->k, st)));
         t.entries_valid = true;
     }
     t.tables_valid = true;
@@ -1589,7 +1620,7 @@ extern "C" int kmg_lloyd_iterate(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n
         HIP_TRY(hipMemsetAsync(d_acc4, 0, sizeof(int64_t) * 4ull * s->k, st));
         PROF_LAUNCH(s, KMG_K_CUBE, st, launch_cube(t.d_hist, t.d_agg, t.d_sub_agg, t.d_occ, t.d_work, s->p->d_bounds, s->p->d_sub_bounds,
                                                    s->d_cent, s->k, s->p->d_lab_table, t.d_masks, t.d_cell_work, t.d_colour_labels, t.d_sub,
-                                                   d_acc4, 1u, 0u, nullptr, st));
+                                                   d_acc4, 1u, 0u, nullptr, st, nullptr, affine_for(s->p, s->k, st)));
         return KMG_OK;
     };
     if ((rc = issue()) != KMG_OK) {
@@ -1775,7 +1806,7 @@ extern "C" int kmg_dev_apply(kmg_processor *p, const uint8_t *d_rgba, uint32_t w
             uint64_t *m = (uint64_t *)arena.take(cube_masks_bytes(k));
             void *cwork = arena.take(cube_work_bytes());
             e = launch_cube(nullptr, nullptr, nullptr, nullptr, nullptr, p->d_bounds, p->d_sub_bounds, d_cent, k, p->d_lab_table,
-                            m, cwork, colour_labels, sub, nullptr, 0, 0u, nullptr, S(stream));
+                            m, cwork, colour_labels, sub, nullptr, 0, 0u, nullptr, S(stream), nullptr, affine_for(p, k, S(stream)));
             if (e == hipSuccess)
                 e = launch_labels((const uint32_t *)d_rgba, n_px, colour_labels, sub, k, d_pal, (uint32_t *)d_out, S(stream));
         }

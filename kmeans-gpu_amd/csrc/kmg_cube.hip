@@ -853,6 +853,556 @@ __global__ __launch_bounds__(kBlock) void k_cube_pairs(const uint32_t *__restric
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_cube_small (k <= kSmallMaxK = 32): the whole cube pass of a SMALL centroid table in one launch.
+//
+// With few centroids the three launches above are chains of per-cell round trips with little work in them (BASELINE
+// config 2, 4096^2, k = 16: stage 23.6 + scan 36.5 + pairs 17.4 us, 75 K scanned sub-cells of which 25 K are really mixed).
+// Here a workgroup of 16 waves owns 128 cells from start to finish and nothing but the results leaves it:
+//   1. stage -- one SUB-CELL per lane (a wave: 8 cells x 8 sub-cells): interval bounds of every centroid over the sub-cell's
+//      static bounds (key_range, the same monotone evaluation), U = min hi, candidates = {lo_j <= U (1 + slack)} as a k-bit
+//      word; then the DOMINANCE test below removes the candidates another candidate beats on every colour of the sub-cell.
+//      One candidate left -> the sub-cell belongs to it (sums from the per-sub-cell table; a cell whose occupied sub-cells
+//      all go to one centroid takes the per-cell sums and its pair entry at once, no per-colour traffic).
+//   2. scan -- the undecided sub-cells of the workgroup's cells as ONE list in LDS, dealt out to the waves two per step,
+//      one colour per lane, the next pair's colours requested while the current one is scanned.
+//   3. entries -- the pair entry of every cell with more than one label, from the 512 labels the workgroup holds in LDS
+//      (dealt out likewise); the labels leave as one 8-byte store per lane.
+// The cells of a wave are dealt out with stride n_work / 8 over the work list and the scan list is shared by 16 waves, so
+// that the boundary-heavy regions of the cube are spread evenly (one wave with its own 8 cells and its own list: the
+// slowest of the 4096 waves meets 64 undecided sub-cells, the average one 20 -- measured 73 us for the pass).
+// Candidate positions are the centroid indices themselves (5 bits in the key).  Sums go to kSmallRepl copies of the LDS
+// bins (lane & 15): with 16 clusters a single copy has 64 lanes on 16 addresses.
+// The pass's tail (sums hand-over, centroid update) stays with k_cube_pairs' tail workgroup, launched alone: finding the last
+// workgroup inside the launch needs a device-scope fence per workgroup, which on this part writes the XCD's L2 back -- measured
+// 63 -> 148 us.
+//
+// Dominance test (sub_affine != NULL).  With the per-colour terms of kmg_math.h as REAL numbers,
+//   K_j = (L - Lj)^2 + wC (C - Cj)^2 + wH max(h_j, 0),   h_j = (a - aj)^2 + (b - bj)^2 - (C - Cj)^2,
+// and h_j - h_i = (Nj - Ni) - 2 a (aj - ai) - 2 b (bj - bi) + 2 C (Cj - Ci), N = a^2 + b^2 - C^2 of the centroid, so that
+//   K_j - K_i >= c0 + sum_m w_m F_m(colour) - wH delta,   F = (L, wC, wC C, wH a, wH b, wH C, wH),
+//   c0 = Lj^2 - Li^2, w = (-2 (Lj - Li), Cj^2 - Ci^2, -2 (Cj - Ci), -2 (aj - ai), -2 (bj - bi), 2 (Cj - Ci), Nj - Ni)
+// (max(h_j, 0) >= h_j; max(h_i, 0) <= h_i + delta, delta = 2^-20 (C + Ci)^2 >= how far the rounding of the two chromas can
+// push h_i below zero: |C - Chat| <= 2.1 u Chat and the reverse triangle inequality).  The static table holds, per sub-cell
+// and feature, an affine model alpha + beta . (x - 1.5, y - 1.5, z - 1.5) over the 4 x 4 x 4 colours and the exact range
+// [Rmin, Rmax] of its residual (k_sub_affine), hence for every colour of the sub-cell
+//   K_j - K_i >= c0 + sum_m w_m alpha_m - 1.5 sum_d |sum_m w_m beta_md| + sum_m min(w_m Rmin_m, w_m Rmax_m) - wH1 delta.
+// Evaluated in binary64 (rounding ~1e-16 of the terms' magnitude, charged as 1e-9 of it).  A candidate j is dropped when this
+// lower bound is >= 2^-11 hi_i for the candidate i with the smallest upper bound hi_i: then K_j >= K_i (1 + 2^-11 (1 - 63u))
+// for every colour, and with |key - K| <= 560u K for the scan's keys (kmg_math.h) key_j > key_i (1 + 2^-12) -- j is neither
+// the arg-min nor within the tie threshold of it, exactly the property the interval test guarantees for what IT removes.
+// Skipped when a centroid lies outside |L|, |a|, |b| <= 1024 (the error budget above assumes colour-like magnitudes).
+// Honoured flags: bit 0 (labels of uniform cells too), kCubeNoEntries; knock-outs (tools, results WRONG): 9 no sums in the
+// scan, 10 no colour scan, 14 no entries phase, 15 no dominance test (that one is exact).
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kSmallMaxK = 32;
+constexpr uint32_t kSmallRepl = 16;
+constexpr int kSmallBlock = 512;
+constexpr uint32_t kSmallWaves = kSmallBlock / 64;
+constexpr uint32_t kSmallCells = kSmallWaves * 8u;               // cells of a workgroup
+constexpr uint32_t kSmallTests = 2048;                           // dominance tests a workgroup lists per round
+constexpr uint32_t kAffineFloats = 48;                            // per sub-cell: 7 features x (alpha, 3 beta, Rmin, Rmax), padded
+
+__device__ __forceinline__ uint32_t group8_or(uint32_t v)
+{
+    v |= dpp_u32<kDppXor1>(v);
+    v |= dpp_u32<kDppXor2>(v);
+    v |= dpp_u32<kDppHalfMirror>(v);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t group8_min_u32(uint32_t v)
+{
+    v = min(v, dpp_u32<kDppXor1>(v));
+    v = min(v, dpp_u32<kDppXor2>(v));
+    v = min(v, dpp_u32<kDppHalfMirror>(v));
+    return v;
+}
+
+__device__ __forceinline__ uint32_t group8_max_u32(uint32_t v)
+{
+    v = max(v, dpp_u32<kDppXor1>(v));
+    v = max(v, dpp_u32<kDppXor2>(v));
+    v = max(v, dpp_u32<kDppHalfMirror>(v));
+    return v;
+}
+
+// the 7 features of one colour (exact products of binary32 values in binary64)
+__device__ __forceinline__ void affine_features(const float4 v, double F[7])
+{
+    const PixelTerms p = pixel_terms_c(v.x, v.y, v.z, v.w);
+    F[0] = (double)p.L; F[1] = (double)p.wC; F[2] = (double)p.wC * (double)p.C;
+    F[3] = (double)p.wH * (double)p.a; F[4] = (double)p.wH * (double)p.b; F[5] = (double)p.wH * (double)p.C; F[6] = (double)p.wH;
+}
+
+// once per processor: the affine models of the dominance test, one thread per sub-cell
+__global__ __launch_bounds__(kBlock) void k_sub_affine(const float4 *__restrict__ lab_table, float *__restrict__ affine)
+{
+    const uint32_t sc = blockIdx.x * kBlock + threadIdx.x;
+    if (sc >= kSubCells) return;
+    const float4 *col = lab_table + (uint64_t)sc * 64u;
+    double S0[7], Sx[7], Sy[7], Sz[7];
+#pragma unroll
+    for (int m = 0; m < 7; ++m) S0[m] = Sx[m] = Sy[m] = Sz[m] = 0.0;
+    for (uint32_t q = 0; q < 64u; ++q) {
+        double F[7];
+        affine_features(col[q], F);
+        const double dx = (double)((q >> 4) & 3u) - 1.5, dy = (double)((q >> 2) & 3u) - 1.5, dz = (double)(q & 3u) - 1.5;
+#pragma unroll
+        for (int m = 0; m < 7; ++m) { S0[m] += F[m]; Sx[m] += F[m] * dx; Sy[m] += F[m] * dy; Sz[m] += F[m] * dz; }
+    }
+    float al[7], bx[7], by[7], bz[7];
+    double rmin[7], rmax[7];
+#pragma unroll
+    for (int m = 0; m < 7; ++m) {
+        // least squares on the regular grid: sum (x - 1.5)^2 over the 64 colours = 80
+        al[m] = (float)(S0[m] / 64.0); bx[m] = (float)(Sx[m] / 80.0); by[m] = (float)(Sy[m] / 80.0); bz[m] = (float)(Sz[m] / 80.0);
+        rmin[m] = 1.0e300; rmax[m] = -1.0e300;
+    }
+    // residuals against the ROUNDED model (the one the test uses)
+    for (uint32_t q = 0; q < 64u; ++q) {
+        double F[7];
+        affine_features(col[q], F);
+        const double dx = (double)((q >> 4) & 3u) - 1.5, dy = (double)((q >> 2) & 3u) - 1.5, dz = (double)(q & 3u) - 1.5;
+#pragma unroll
+        for (int m = 0; m < 7; ++m) {
+            const double r = F[m] - ((double)al[m] + ((double)bx[m] * dx + ((double)by[m] * dy + (double)bz[m] * dz)));
+            rmin[m] = fmin(rmin[m], r); rmax[m] = fmax(rmax[m], r);
+        }
+    }
+    float *out = affine + (uint64_t)sc * kAffineFloats;
+#pragma unroll
+    for (int m = 0; m < 7; ++m) {
+        // outward: the binary64 evaluation above is off by < 1e-15 of the terms; then one directed rounding to binary32
+        const double pad = 1.0e-12 * (fabs((double)al[m]) + 1.5 * (fabs((double)bx[m]) + fabs((double)by[m]) + fabs((double)bz[m])) + 1.0);
+        const double lo = rmin[m] - pad, hi = rmax[m] + pad;
+        float flo = (float)lo, fhi = (float)hi;
+        if ((double)flo > lo) flo = nextafterf(flo, -3.0e38f);
+        if ((double)fhi < hi) fhi = nextafterf(fhi, 3.0e38f);
+        out[6 * m + 0] = al[m]; out[6 * m + 1] = bx[m]; out[6 * m + 2] = by[m]; out[6 * m + 3] = bz[m];
+        out[6 * m + 4] = flo; out[6 * m + 5] = fhi;
+    }
+#pragma unroll
+    for (int m = 42; m < (int)kAffineFloats; ++m) out[m] = 0.0f;
+}
+
+size_t sub_affine_bytes() { return sizeof(float) * (size_t)kAffineFloats * kSubCells; }
+
+hipError_t launch_sub_affine(const float4 *lab_table, float *affine, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_sub_affine, dim3(kSubCells / kBlock), dim3(kBlock), 0, st, lab_table, affine);
+    return hipGetLastError();
+}
+
+// lower bound of K_j - K_i over the sub-cell whose model is `mdl` (see above), and the magnitude of its terms
+__device__ __forceinline__ double dominance_lower_bound(const float (&mdl)[44], const float4 cj, const float4 ci, float C1, float wH1,
+                                                        double &mag)
+{
+    const double Lj = cj.x, aj = cj.y, bj = cj.z, Cj = cj.w, Li = ci.x, ai = ci.y, bi = ci.z, Ci = ci.w;
+    const double Nj = aj * aj + bj * bj - Cj * Cj, Ni = ai * ai + bi * bi - Ci * Ci;
+    const double w[7] = {-2.0 * (Lj - Li), Cj * Cj - Ci * Ci, -2.0 * (Cj - Ci), -2.0 * (aj - ai), -2.0 * (bj - bi), 2.0 * (Cj - Ci), Nj - Ni};
+    double d = Lj * Lj - Li * Li, gx = 0.0, gy = 0.0, gz = 0.0;
+    mag = fabs(Lj * Lj) + fabs(Li * Li);
+#pragma unroll
+    for (int m = 0; m < 7; ++m) {
+        const double t = w[m] * (double)mdl[6 * m];
+        d += t;
+        mag += fabs(t);
+        gx += w[m] * (double)mdl[6 * m + 1]; gy += w[m] * (double)mdl[6 * m + 2]; gz += w[m] * (double)mdl[6 * m + 3];
+        d += fmin(w[m] * (double)mdl[6 * m + 4], w[m] * (double)mdl[6 * m + 5]);
+    }
+    d -= 1.5 * (fabs(gx) + fabs(gy) + fabs(gz));
+    const double cs = (double)C1 + Ci;
+    d -= (double)wH1 * (9.5367431640625e-07 * (cs * cs));         // delta = 2^-20 (C1 + Ci)^2
+    return d;
+}
+
+template <int KP, bool SUMS>
+__global__ __launch_bounds__(kSmallBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_cube_small(const uint32_t *__restrict__ hist, const int64_t *__restrict__ agg,
+                                                            const int64_t *__restrict__ sub_agg,
+                                                            const uint8_t *__restrict__ occ_bits,
+                                                            const uint32_t *__restrict__ work,
+                                                            const CellBounds *__restrict__ bounds,
+                                                            const CellBounds *__restrict__ sub_bounds,
+                                                            const float *__restrict__ sub_affine,
+                                                            const Centroid *__restrict__ cent, uint32_t k,
+                                                            const float4 *__restrict__ lab_table,
+                                                            uint64_t *__restrict__ masks_out,
+                                                            uint8_t *__restrict__ colour_labels,
+                                                            uint16_t *__restrict__ sub_table,
+                                                            int64_t *__restrict__ sums, uint32_t n_rows, uint32_t flags,
+                                                            unsigned long long *__restrict__ stats)
+{
+    extern __shared__ float4 smem4[];
+    float4 *s_cent = smem4;
+    unsigned long long *bins = reinterpret_cast<unsigned long long *>(smem4 + KP);
+    const uint32_t bin_stride = 4u * k + 4u;                       // u64 per copy (+ 32 B: the next copy starts in other banks)
+    const uint32_t n_bins = SUMS ? kSmallRepl * bin_stride : 0u;
+    uint8_t *s_lbl = reinterpret_cast<uint8_t *>(bins + n_bins);                     // [cells][512 labels]
+    uint32_t *s_mask = reinterpret_cast<uint32_t *>(s_lbl + kSmallCells * kCellColours);   // [sub-cells]: candidates
+    float *s_U = reinterpret_cast<float *>(s_mask + kSmallBlock);                    // [sub-cells]: smallest upper bound
+    uint32_t *s_cell = reinterpret_cast<uint32_t *>(s_U + kSmallBlock);              // [cells]: cell of slot (wave, ci)
+    uint32_t *s_count = s_cell + kSmallCells;                                        // [0] entries, [1] pending cells, [2] far centroid, [3] tests
+    uint16_t *s_ent = reinterpret_cast<uint16_t *>(s_count + 4);                     // [sub-cells]: sub-cells (thread ids) to scan
+    uint16_t *s_pend = s_ent + kSmallBlock;                                          // [cells]: slots whose cell needs an entry
+    uint16_t *s_test = s_pend + kSmallCells;                                         // [kSmallTests]: (sub-cell << 5) | candidate
+    uint8_t *s_istar = reinterpret_cast<uint8_t *>(s_test + kSmallTests);            // [sub-cells]: the candidate with that bound
+    // (requested first: the work list's length heads a chain of three dependent loads -- length, cell, bounds)
+    const uint32_t n_work_v = SUMS ? work[opaque_vgpr_zero()] : kCells;
+    for (uint32_t i = threadIdx.x; i < (uint32_t)KP; i += kSmallBlock) {
+        float4 v = make_float4(1.0e18f, 0.0f, 0.0f, 0.0f);        // key ~ 1e36: never a candidate
+        if (i < k) { const Centroid c = cent[i]; v = make_float4(c.L, c.a, c.b, c.C); }
+        s_cent[i] = v;
+    }
+    for (uint32_t i = threadIdx.x; i < n_bins; i += kSmallBlock) bins[i] = 0ull;
+    if (threadIdx.x < 4u) s_count[threadIdx.x] = 0u;
+    __syncthreads();
+    if (threadIdx.x < k) {
+        const float4 c = s_cent[threadIdx.x];
+        if (!(fabsf(c.x) <= 1024.0f && fabsf(c.y) <= 1024.0f && fabsf(c.z) <= 1024.0f)) s_count[2] = 1u;
+    }
+    __syncthreads();
+    const bool dominance = sub_affine != nullptr && s_count[2] == 0u && !(flags & 0x8000u);
+
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    unsigned long long *my_bins = bins + (uint64_t)(lane & (kSmallRepl - 1u)) * bin_stride;
+    uint32_t *pair_entries = reinterpret_cast<uint32_t *>(sub_table + kSubCells + kCells);
+    const uint32_t ci = lane >> 3, sub = lane & 7u, slot = wv * 8u + ci;
+    unsigned long long st_single = 0, st_multi = 0, st_decided = 0, st_scanned = 0, st_cands = 0;
+
+    const uint32_t n_work = __builtin_amdgcn_readfirstlane(n_work_v);
+    const uint32_t tasks = (n_work + 7u) >> 3;                     // wave tasks: task t = cells t, t + tasks, ... of the work list
+    for (uint32_t base = blockIdx.x * kSmallWaves; base < tasks; base += gridDim.x * kSmallWaves) {
+        // ---- 1a. stage: lane (ci, sub) = sub-cell `sub` of the wave's cell ci; candidates from interval bounds ----
+        const uint32_t task = base + wv;
+        const uint32_t pos = task + ci * tasks;
+        const bool valid = task < tasks && pos < n_work;
+        const uint32_t cell = valid ? (SUMS ? work[1u + pos] : pos) : 0u;
+        const uint32_t sc = cell * 8u + sub;
+        const float4 *cbp = reinterpret_cast<const float4 *>(bounds + cell);
+        const float4 cb0 = cbp[0], cb1 = cbp[1], cb2 = cbp[2];
+        const float4 *sbp = reinterpret_cast<const float4 *>(sub_bounds + sc);
+        const float4 sb0 = sbp[0], sb1 = sbp[1], sb2 = sbp[2];
+        // (the sums a decided sub-cell / a uniform cell will hand over are requested with the bounds, not after the decision)
+        longlong2 s01 = {0, 0}, s23 = {0, 1};
+        long long cell_sum = 0;
+        if (SUMS) {
+            const longlong2 *sp = reinterpret_cast<const longlong2 *>(sub_agg + (uint64_t)sc * 4u);
+            s01 = sp[0]; s23 = sp[1];
+            cell_sum = agg[4ull * cell + (sub & 3u)];
+        }
+        const bool occupied = valid && s23.y != 0;
+        uint32_t mask = 0u;
+        {
+            // the cell's candidates first, the eight lanes of the cell sharing the centroids (two sweeps each time: upper
+            // bounds, then lower bounds against the threshold -- each keeps half of key_range)
+            CellBounds cb;
+            cb.L0 = cb0.x; cb.L1 = cb0.y; cb.a0 = cb0.z; cb.a1 = cb0.w;
+            cb.b0 = cb1.x; cb.b1 = cb1.y; cb.C0 = cb1.z; cb.C1 = cb1.w;
+            cb.wC0 = cb2.x; cb.wC1 = cb2.y; cb.wH0 = cb2.z; cb.wH1 = cb2.w;
+            constexpr int PER = KP / 8;
+            float lo[PER], Uc = 3.0e38f;
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                const float4 c = s_cent[sub * PER + q];
+                const KeyRange kr = key_range(cb, c.x, c.y, c.z, c.w);
+                lo[q] = kr.lo;
+                Uc = fminf(Uc, kr.hi);
+            }
+            const float Ucs = mask_threshold(group8_min(Uc));
+            uint32_t bits = 0u;
+#pragma unroll
+            for (int q = 0; q < PER; ++q) bits |= (lo[q] <= Ucs ? 1u : 0u) << (sub * PER + q);
+            const uint32_t cmask = group8_or(bits);
+            // then the sub-cell's own bounds, over the cell's candidates
+            CellBounds sb;
+            sb.L0 = sb0.x; sb.L1 = sb0.y; sb.a0 = sb0.z; sb.a1 = sb0.w;
+            sb.b0 = sb1.x; sb.b1 = sb1.y; sb.C0 = sb1.z; sb.C1 = sb1.w;
+            sb.wC0 = sb2.x; sb.wC1 = sb2.y; sb.wH0 = sb2.z; sb.wH1 = sb2.w;
+            float U = 3.0e38f;
+            uint32_t istar = 0u;
+            for (uint32_t m = cmask; m; m &= m - 1u) {
+                const uint32_t j = (uint32_t)__builtin_ctz(m);
+                const float4 c = s_cent[j];
+                const float hi = key_range(sb, c.x, c.y, c.z, c.w).hi;
+                istar = hi < U ? j : istar;
+                U = fminf(U, hi);
+            }
+            const float Us = mask_threshold(U);
+            for (uint32_t m = cmask; m; m &= m - 1u) {
+                const uint32_t j = (uint32_t)__builtin_ctz(m);
+                const float4 c = s_cent[j];
+                mask |= (key_range(sb, c.x, c.y, c.z, c.w).lo <= Us ? 1u : 0u) << j;
+            }
+            s_mask[threadIdx.x] = mask;
+            // 1b. the dominance tests of this sub-cell: (sub-cell, candidate) for every candidate but the one with the smallest
+            // upper bound; a list that overflows drops tests, i.e. keeps candidates
+            const uint32_t others = mask & ~(1u << istar);
+            if (dominance && occupied && others) {
+                s_U[threadIdx.x] = U;
+                s_istar[threadIdx.x] = (uint8_t)istar;
+                const uint32_t nt = (uint32_t)__builtin_popcount(others);
+                uint32_t at = atomicAdd(&s_count[3], nt);
+                for (uint32_t m = others; m && at < kSmallTests; m &= m - 1u, ++at)
+                    s_test[at] = (uint16_t)((threadIdx.x << 5) | (uint32_t)__builtin_ctz(m));
+            }
+        }
+        if (sub == 0u) s_cell[slot] = cell;
+        __syncthreads();
+        if (dominance) {
+            const uint32_t n_tests = min(s_count[3], kSmallTests);
+            for (uint32_t t = threadIdx.x; t < n_tests; t += kSmallBlock) {
+                const uint32_t e = (uint32_t)s_test[t] >> 5, j = (uint32_t)s_test[t] & 31u;
+                const uint32_t tsc = s_cell[e >> 3] * 8u + (e & 7u);
+                const float4 *mp = reinterpret_cast<const float4 *>(sub_affine + (uint64_t)tsc * kAffineFloats);
+                float mdl[44];
+#pragma unroll
+                for (int q = 0; q < 11; ++q) {
+                    const float4 v = mp[q];
+                    mdl[4 * q] = v.x; mdl[4 * q + 1] = v.y; mdl[4 * q + 2] = v.z; mdl[4 * q + 3] = v.w;
+                }
+                const CellBounds *tb = sub_bounds + tsc;
+                const float C1 = tb->C1, wH1 = tb->wH1;
+                double mag;
+                const double d = dominance_lower_bound(mdl, s_cent[j], s_cent[s_istar[e]], C1, wH1, mag);
+                if (d >= 0.00048828125 * (double)s_U[e] + 1.0e-9 * mag) atomicAnd(&s_mask[e], ~(1u << j));   // 2^-11 hi_i
+            }
+            __syncthreads();
+            mask = s_mask[threadIdx.x];
+        }
+
+        // ---- 1c. what each sub-cell needs: empty / decided as a whole / scan its colours ----
+        const uint32_t np = (uint32_t)__builtin_popcount(mask);
+        const bool decided = occupied && np == 1u, scan = occupied && np > 1u;
+        const uint32_t X = (uint32_t)__builtin_ctz(mask | 0x80000000u);
+        const uint32_t um = group8_or(mask);                      // the cell's candidates
+        const uint32_t any_scan = group8_or(scan ? 1u : 0u);
+        const uint32_t xmin = group8_min_u32(decided ? X : 255u), xmax = group8_max_u32(decided ? X : 0u);
+        const bool uniform = valid && !any_scan && xmin == xmax;   // every occupied sub-cell goes to centroid xmin
+        if (valid && sub == 0u) masks_out[cell] = (uint64_t)um;
+        if (SUMS) {
+            if (uniform) {
+                if (sub < 4u) atomicAdd(my_bins + 4ull * xmin + sub, (unsigned long long)cell_sum);
+            } else if (decided) {
+                unsigned long long *to = my_bins + 4ull * X;
+                atomicAdd(to + 0, (unsigned long long)s01.x); atomicAdd(to + 1, (unsigned long long)s01.y);
+                atomicAdd(to + 2, (unsigned long long)s23.x); atomicAdd(to + 3, (unsigned long long)s23.y);
+            }
+        }
+        {
+            const uint32_t x4 = (decided ? X : 0u) * 0x01010101u;
+            const uint4 xv = make_uint4(x4, x4, x4, x4);
+            if (uniform) {
+                if (sub == 0u) pair_entries[cell] = pair_entry(xmin, xmin, 0u, 0u, 0u);
+                if (flags & 1u) {
+                    const uint32_t m4 = xmin * 0x01010101u;
+                    uint4 *dst = reinterpret_cast<uint4 *>(colour_labels + (uint64_t)cell * kCellColours + sub * 64u);
+                    dst[0] = dst[1] = dst[2] = dst[3] = make_uint4(m4, m4, m4, m4);
+                }
+            } else if (valid) {
+                uint4 *dst = reinterpret_cast<uint4 *>(s_lbl + slot * kCellColours + sub * 64u);
+                dst[0] = xv; dst[1] = xv; dst[2] = xv; dst[3] = xv;
+            }
+        }
+        {
+            // the workgroup's lists: undecided sub-cells (thread ids), cells that need an entry (slots)
+            const unsigned long long scan_b = __ballot(scan);
+            const unsigned long long pend_b = __ballot(valid && !uniform && sub == 0u);
+            uint32_t e_base = 0u, p_base = 0u;
+            if (lane == 0u) {
+                if (scan_b) e_base = atomicAdd(&s_count[0], (uint32_t)__builtin_popcountll(scan_b));
+                if (pend_b) p_base = atomicAdd(&s_count[1], (uint32_t)__builtin_popcountll(pend_b));
+            }
+            e_base = __builtin_amdgcn_readfirstlane(e_base);
+            p_base = __builtin_amdgcn_readfirstlane(p_base);
+            if (scan) s_ent[e_base + bits_below_lane(scan_b)] = (uint16_t)threadIdx.x;
+            if (valid && !uniform && sub == 0u) s_pend[p_base + bits_below_lane(pend_b)] = (uint16_t)slot;
+            if (stats) {
+                const unsigned long long single_b = __ballot(valid && sub == 0u && __builtin_popcount(um) == 1);
+                const unsigned long long multi_b = __ballot(valid && sub == 0u && __builtin_popcount(um) != 1);
+                const unsigned long long dec_b = __ballot(decided && __builtin_popcount(um) != 1);
+                st_single += (uint32_t)__builtin_popcountll(single_b);
+                st_multi += (uint32_t)__builtin_popcountll(multi_b);
+                st_decided += (uint32_t)__builtin_popcountll(dec_b);
+                st_scanned += (uint32_t)__builtin_popcountll(scan_b);
+                st_cands += wave_add_u32(scan ? np : 0u);
+            }
+        }
+        __syncthreads();
+        const uint32_t n_ent = (flags & 0x400u) ? 0u : s_count[0];
+        const uint32_t n_pend = (flags & 0x4000u) ? 0u : s_count[1];
+
+        // ---- 2. scan: the undecided sub-cells of the workgroup, pair p to wave p % 8, one colour per lane ----
+        // (its occupancy bytes for phase 3 are requested now: the scan hides their latency)
+        uint32_t occ_early[2] = {0xFFu, 0xFFu};
+        if (occ_bits && !(flags & kCubeNoEntries)) {
+#pragma unroll
+            for (uint32_t q = 0; q < 2u; ++q) {
+                const uint32_t pi = wv + q * kSmallWaves;
+                if (pi < n_pend) occ_early[q] = (uint32_t)occ_bits[(uint64_t)s_cell[s_pend[pi]] * 64u + lane];
+            }
+        }
+        if (2u * wv < n_ent) {
+            // three register sets, all requested before the first pair is scanned: a wave meets ~3 pairs, and with one pair
+            // in flight every step waited a full memory round trip (2-3 us) for 0.3 us of work
+            float4 A_v0, A_v1, B_v0, B_v1, C_v0, C_v1;
+            uint32_t A_c0 = 1u, A_c1 = 1u, B_c0 = 1u, B_c1 = 1u, C_c0 = 1u, C_c1 = 1u;
+            uint32_t A_e0 = 0u, A_e1 = 0u, B_e0 = 0u, B_e1 = 0u, C_e0 = 0u, C_e1 = 0u;
+            long long A_g0 = 0, A_g1 = 0, B_g0 = 0, B_g1 = 0, C_g0 = 0, C_g1 = 0;
+            bool A_h1 = false, B_h1 = false, C_h1 = false, A_ok = false, B_ok = false, C_ok = false;
+            uint32_t next = 2u * wv;
+            // (an exhausted slot re-requests entry 0, unused: a conditional request makes the compiler wait for the registers)
+#define KMG_REQUEST_PAIR(X)                                                                                       \
+            do {                                                                                                  \
+                X##_ok = next < n_ent;                                                                            \
+                X##_h1 = next + 1u < n_ent;                                                                       \
+                X##_e0 = __builtin_amdgcn_readfirstlane((uint32_t)s_ent[next < n_ent ? next : 0u]);               \
+                X##_e1 = __builtin_amdgcn_readfirstlane((uint32_t)s_ent[X##_h1 ? next + 1u : 0u]);                \
+                next += 2u * kSmallWaves;                                                                         \
+                const uint32_t cell0_ = __builtin_amdgcn_readfirstlane(s_cell[X##_e0 >> 3]);                      \
+                const uint32_t cell1_ = __builtin_amdgcn_readfirstlane(s_cell[X##_e1 >> 3]);                      \
+                const uint32_t c0_ = cell0_ * kCellColours + (X##_e0 & 7u) * 64u + lane;                          \
+                const uint32_t c1_ = cell1_ * kCellColours + (X##_e1 & 7u) * 64u + lane;                          \
+                X##_v0 = lab_table[c0_];                                                                          \
+                X##_v1 = lab_table[c1_];                                                                          \
+                if (SUMS) {                                                                                       \
+                    X##_c0 = hist[c0_]; X##_c1 = hist[c1_];                                                       \
+                    X##_g0 = sub_agg[((uint64_t)cell0_ * 8u + (X##_e0 & 7u)) * 4u + (lane & 3u)];                 \
+                    X##_g1 = sub_agg[((uint64_t)cell1_ * 8u + (X##_e1 & 7u)) * 4u + (lane & 3u)];                 \
+                }                                                                                                 \
+            } while (0)
+            // e = thread id of the sub-cell in the stage: slot e >> 3, sub-cell e & 7
+            auto scan_pair = [&](const uint32_t e0, const uint32_t e1, const bool has1, const float4 v0, const float4 v1,
+                                 const uint32_t cnt0, const uint32_t cnt1, const long long g0, const long long g1) {
+                const PixelTerms pt0 = pixel_terms_fast(v0.x, v0.y, v0.z, v0.w), pt1 = pixel_terms_fast(v1.x, v1.y, v1.z, v1.w);
+                uint32_t b0 = 0x7F7FFFFFu, r0 = 0x7F7FFFFFu, b1 = 0x7F7FFFFFu, r1 = 0x7F7FFFFFu;   // smallest / runner-up
+                const uint32_t sm = __builtin_amdgcn_readfirstlane(s_mask[e0] | (has1 ? s_mask[e1] : 0u));
+                // (the two colours of a lane as the halves of packed-f32 operands, as in k_cube_scan; position = centroid index)
+                const f32x2 qL = {pt0.L, pt1.L}, qa = {pt0.a, pt1.a}, qb = {pt0.b, pt1.b}, qC = {pt0.C, pt1.C};
+                const f32x2 qwC = {pt0.wC, pt1.wC}, qwH = {pt0.wH, pt1.wH};
+                for (uint32_t m = sm; m; m &= m - 1u) {
+                    const uint32_t pos = (uint32_t)__builtin_ctz(m);
+                    const float4 c = s_cent[pos];
+                    const f32x2 dL = qL - c.x, da = qa - c.y, db = qb - c.z, dC = qC - c.w;
+                    const f32x2 dC2 = dC * dC;
+                    const f32x2 t = __builtin_elementwise_fma(db, db, da * da);
+                    f32x2 h = t - dC2;
+                    h.x = fmaxf(h.x, 0.0f); h.y = fmaxf(h.y, 0.0f);
+                    const f32x2 key = __builtin_elementwise_fma(h, qwH, __builtin_elementwise_fma(dC2, qwC, dL * dL));
+                    uint32_t u0, u1;
+                    asm("v_bfi_b32 %0, 31, %1, %2" : "=v"(u0) : "s"(pos), "v"(float_to_bits(key.x)));
+                    asm("v_bfi_b32 %0, 31, %1, %2" : "=v"(u1) : "s"(pos), "v"(float_to_bits(key.y)));
+                    r0 = umed3(u0, b0, r0); b0 = min(b0, u0);
+                    r1 = umed3(u1, b1, r1); b1 = min(b1, u1);
+                }
+                uint32_t p0 = b0 & 31u, p1 = b1 & 31u;
+                // near-tie repair (kmg_math.h): rare; decided by the literal distance, first minimum wins
+                const float thr0 = tie_threshold(bits_to_float(b0 & ~31u)), thr1 = tie_threshold(bits_to_float(b1 & ~31u));
+                const bool near0 = bits_to_float(r0 & ~31u) <= thr0, near1 = bits_to_float(r1 & ~31u) <= thr1;
+                if (__ballot(near0 || near1)) {
+                    float lb0 = 100000.0f, lb1 = 100000.0f;       // find_centroid.wgsl:29-30
+                    uint32_t li0 = 0u, li1 = 0u;
+                    for (uint32_t m = sm; m; m &= m - 1u) {
+                        const uint32_t pos = (uint32_t)__builtin_ctz(m);
+                        const float4 c = s_cent[pos];
+                        if (near0 && cie94_key(pt0, c.x, c.y, c.z, c.w) <= thr0) {
+                            const float d = cie94_c(v0.x, v0.y, v0.z, v0.w, c.x, c.y, c.z, c.w);
+                            if (d < lb0) { lb0 = d; li0 = pos; }
+                        }
+                        if (near1 && cie94_key(pt1, c.x, c.y, c.z, c.w) <= thr1) {
+                            const float d = cie94_c(v1.x, v1.y, v1.z, v1.w, c.x, c.y, c.z, c.w);
+                            if (d < lb1) { lb1 = d; li1 = pos; }
+                        }
+                    }
+                    p0 = near0 ? li0 : p0;
+                    p1 = near1 ? li1 : p1;
+                }
+                // what a scanned sub-cell leaves behind: its labels (LDS) and sums -- the sub-cell's total goes to a reference
+                // label R, a colour with another label moves its own contribution from R to that label
+                auto finish = [&](uint32_t e, uint32_t ix, uint32_t cnt, long long g, float vL, float va, float vb) {
+                    s_lbl[(e >> 3) * kCellColours + (e & 7u) * 64u + lane] = (uint8_t)ix;
+                    if (!SUMS || (flags & 0x200u)) return;
+                    const bool counts = cnt != 0u;
+                    const unsigned long long occm = __ballot(counts);
+                    if (!occm) return;
+                    const uint32_t X0 = lane_value(ix, (uint32_t)__builtin_ctzll(occm));
+                    const unsigned long long other = __ballot(counts && ix != X0);
+                    uint32_t R = X0;
+                    if (other) {
+                        const uint32_t X1 = lane_value(ix, (uint32_t)__builtin_ctzll(other));
+                        if (__builtin_popcountll(__ballot(counts && ix == X1)) > __builtin_popcountll(occm & ~other)) R = X1;
+                    }
+                    if (lane < 4u) atomicAdd(my_bins + 4ull * R + lane, (unsigned long long)g);
+                    if (other && counts && ix != R) {
+                        const long long m = (long long)cnt;
+                        const long long c0 = m * (long long)lab_fix(vL), c1 = m * (long long)lab_fix(va), c2 = m * (long long)lab_fix(vb);
+                        unsigned long long *to = my_bins + 4ull * ix, *from = my_bins + 4ull * R;
+                        atomicAdd(to + 0, (unsigned long long)c0); atomicAdd(from + 0, (unsigned long long)(-c0));
+                        atomicAdd(to + 1, (unsigned long long)c1); atomicAdd(from + 1, (unsigned long long)(-c1));
+                        atomicAdd(to + 2, (unsigned long long)c2); atomicAdd(from + 2, (unsigned long long)(-c2));
+                        atomicAdd(to + 3, (unsigned long long)m);  atomicAdd(from + 3, (unsigned long long)(-m));
+                    }
+                };
+                finish(e0, p0, cnt0, g0, v0.x, v0.y, v0.z);
+                if (has1) finish(e1, p1, cnt1, g1, v1.x, v1.y, v1.z);
+            };
+            KMG_REQUEST_PAIR(A);
+            KMG_REQUEST_PAIR(B);
+            KMG_REQUEST_PAIR(C);
+            for (;;) {
+                scan_pair(A_e0, A_e1, A_h1, A_v0, A_v1, A_c0, A_c1, A_g0, A_g1);
+                if (!B_ok) break;
+                KMG_REQUEST_PAIR(A);
+                scan_pair(B_e0, B_e1, B_h1, B_v0, B_v1, B_c0, B_c1, B_g0, B_g1);
+                if (!C_ok) break;
+                KMG_REQUEST_PAIR(B);
+                scan_pair(C_e0, C_e1, C_h1, C_v0, C_v1, C_c0, C_c1, C_g0, C_g1);
+                if (!A_ok) break;
+                KMG_REQUEST_PAIR(C);
+            }
+#undef KMG_REQUEST_PAIR
+        }
+        __syncthreads();
+
+        // ---- 3. entries: cells with more than one label (or scanned sub-cells): pair entry from the 512 labels in LDS ----
+        for (uint32_t pi = wv; pi < n_pend; pi += kSmallWaves) {
+            const uint32_t ps = __builtin_amdgcn_readfirstlane((uint32_t)s_pend[pi]);
+            const uint32_t pcell = __builtin_amdgcn_readfirstlane(s_cell[ps]);
+            const uint2 lv = *reinterpret_cast<const uint2 *>(s_lbl + ps * kCellColours + lane * 8u);
+            uint32_t e = kPairPending;
+            if (!(flags & kCubeNoEntries)) {
+                const uint32_t round = (pi - wv) / kSmallWaves;
+                const uint32_t occ = round == 0u ? occ_early[0] : (round == 1u ? occ_early[1] :
+                                     (occ_bits ? (uint32_t)occ_bits[(uint64_t)pcell * 64u + lane] : 0xFFu));
+                uint32_t idx[8];
+#pragma unroll
+                for (uint32_t q = 0; q < 4u; ++q) { idx[q] = (lv.x >> (8u * q)) & 0xFFu; idx[4u + q] = (lv.y >> (8u * q)) & 0xFFu; }
+                e = cell_pair_entry(idx, occ, lane);
+            }
+            if (lane == 0u) pair_entries[pcell] = e;
+            *reinterpret_cast<uint2 *>(colour_labels + (uint64_t)pcell * kCellColours + lane * 8u) = lv;
+        }
+        __syncthreads();
+        if (threadIdx.x < 2u) s_count[threadIdx.x] = 0u;
+        if (threadIdx.x == 3u) s_count[3] = 0u;
+        __syncthreads();
+    }
+    if (stats && lane == 0u) {
+        atomicAdd(stats + 0, st_single); atomicAdd(stats + 1, st_multi); atomicAdd(stats + 2, st_decided);
+        atomicAdd(stats + 3, st_scanned); atomicAdd(stats + 4, st_cands);
+    }
+    if (SUMS) {
+        // (flush_bins for this block size)
+        __syncthreads();
+        unsigned long long *row = reinterpret_cast<unsigned long long *>(sums) + (uint64_t)(blockIdx.x % n_rows) * 4ull * k;
+        for (uint32_t i = threadIdx.x; i < 4u * k; i += kSmallBlock) {
+            unsigned long long v = 0ull;
+            for (uint32_t r = 0; r < kSmallRepl; ++r) v += bins[(uint64_t)r * bin_stride + i];
+            if (v) atomicAdd(row + i, v);
+        }
+    }
+}
+
 static uint32_t env_grid(const char *name, uint32_t dflt)
 {
     if (const char *e = getenv(name)) { const int v = atoi(e); if (v >= 1 && v <= 65536) return (uint32_t)v; }
@@ -875,7 +1425,7 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
                        const uint32_t *work, const CellBounds *bounds, const CellBounds *sub_bounds, const Centroid *cent,
                        uint32_t k, const float4 *lab_table, uint64_t *masks, void *cell_work, void *colour_labels,
                        uint16_t *sub_table, int64_t *sums, uint32_t n_rows, uint32_t flags, unsigned long long *stats,
-                       hipStream_t st, const CubeTail *tail)
+                       hipStream_t st, const CubeTail *tail, const float *sub_affine)
 {
     const CubeTail tl = (tail && hist && n_rows <= 1u) ? *tail : CubeTail();
     const uint32_t kpad = (k + 63u) & ~63u;
@@ -896,6 +1446,28 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
             return (size_t)v;
         }();
         if (lds_stage > lds_max || lds_scan > lds_max) return hipErrorInvalidValue;
+    }
+    // small centroid tables: the whole pass in one launch (k_cube_small) + the tail workgroup
+    static const bool small_on = !(getenv("KMG_CUBE_SMALL") && atoi(getenv("KMG_CUBE_SMALL")) == 0);
+    if (k <= kSmallMaxK && small_on) {
+        static const uint32_t g_small = env_grid("KMG_SMALL_GRID", kCells / kSmallCells);
+        const uint32_t kp = k <= 8u ? 8u : (k <= 16u ? 16u : 32u);
+        const size_t lds = sizeof(float4) * kp + (with_sums ? sizeof(unsigned long long) * (4ull * k + 4ull) * kSmallRepl : 0) +
+                           (size_t)kSmallCells * kCellColours + sizeof(uint32_t) * kSmallBlock * 2u + sizeof(uint32_t) * kSmallCells +
+                           sizeof(uint32_t) * 4u + sizeof(uint16_t) * (kSmallBlock + kSmallCells + kSmallTests) + kSmallBlock;
+        if (!n_rows) n_rows = 1u;
+#define KMG_SMALL(KP, S)                                                                                                    \
+        hipLaunchKernelGGL((k_cube_small<KP, S>), dim3(g_small), dim3(kSmallBlock), lds, st, hist, agg, sub_agg, occ_bits,   \
+                           work, bounds, sub_bounds, sub_affine, cent, k, lab_table, masks, (uint8_t *)colour_labels,        \
+                           sub_table,                                                                                         \
+                           sums, n_rows, flags, stats)
+        if (with_sums) { if (kp == 8u) KMG_SMALL(8, true); else if (kp == 16u) KMG_SMALL(16, true); else KMG_SMALL(32, true); }
+        else           { if (kp == 8u) KMG_SMALL(8, false); else if (kp == 16u) KMG_SMALL(16, false); else KMG_SMALL(32, false); }
+#undef KMG_SMALL
+        if (tl.acc_out)
+            hipLaunchKernelGGL((k_cube_pairs<uint8_t>), dim3(1), dim3(kBlock), 0, st, work, 1, occ_bits,
+                               (const uint8_t *)colour_labels, sub_table, flags | kCubeNoEntries, sums, k, tl);
+        return hipGetLastError();
     }
     // (the scan kernel's cells differ a lot in cost: finer hand-out, 2 cells per wave, measured 83 -> 75 us)
     // (stage: 1536 workgroups = one full round at its 6 waves per SIMD: 33 -> 30-31 us against 2048, round 3)

@@ -193,7 +193,13 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
                        const uint32_t *work, const CellBounds *bounds, const CellBounds *sub_bounds, const Centroid *cent,
                        uint32_t k, const float4 *lab_table, uint64_t *masks, void *cell_work, void *colour_labels,
                        uint16_t *sub_table, int64_t *sums, uint32_t n_rows, uint32_t flags, unsigned long long *stats,
-                       hipStream_t st, const CubeTail *tail = nullptr);
+                       hipStream_t st, const CubeTail *tail = nullptr, const float *sub_affine = nullptr);
+// k <= 32 takes the pass in ONE launch (k_cube_small, kmg_cube.hip).  sub_affine (optional, once per processor,
+// sub_affine_bytes() of them, image independent): per sub-cell affine models of the seven per-colour features the difference
+// of two keys is linear in, with exact residual ranges -- the dominance test that removes, from a sub-cell's candidates, those
+// another candidate beats on every colour of the sub-cell (3x fewer scanned sub-cells at k = 16).
+size_t sub_affine_bytes();
+hipError_t launch_sub_affine(const float4 *lab_table, float *affine, hipStream_t st);
 // pal == NULL: labels[i] = label; pal != NULL: labels[i] = pal[label] (RGBA8 output of replace mode).
 // reserve_cus: compute units left without a workgroup of the k <= 256 label pass (kmg_lloyd_reserve_cus)
 // hot: NULL, or the image's hot cells ([n_hot][cells ...], n_hot > 0 known to the host): k <= 256 keeps their labels in LDS
