@@ -8,9 +8,11 @@ like the reference's find_centroid dispatch) and the per-cluster sums of the new
 for N > 1 the RCCL all-reduce of the k x 4 int64 accumulators.
 
 N = 1: synthetic 8192x8192 RGBA (splitmix64 seed 0x5EED0003), k = 256.
-N > 1, --scaling weak (default): the image is 8192 x (8192*N), row-sharded so every rank owns one
-       8192x8192 band; the iteration is still ONE k-means problem (one all-reduce per iteration).
-N > 1, --scaling strong: the ONE 8192x8192 image is split into N row bands of 8192/N rows.
+N > 1 (default --scaling strong): the SAME 8192x8192 image over the N GPUs -- row bands of 8192/N rows for the label map and,
+       with the colour table, the cube pass sharded by cells (ShardedLloyd(cells=True): histogram all-reduce once, per iteration
+       the k x 4 all-reduce and an all-gather of the label tables).  The weak-scaling figure (one 8192-row band per GPU, one
+       k-means problem over the 8192 x 8192 N image) is measured right after and reported under `extra.weak_scaling_*`.
+N > 1, --scaling weak: only that.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
@@ -440,8 +442,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--k", type=int, default=K)
     ap.add_argument("--rows", type=int, default=None, help="rows per GPU (default 8192; --scaling strong: 8192 / gpus)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="weak: one 8192-row band per GPU; strong: ONE 8192x8192 image split into row bands")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="N > 1: strong (default) = the BASELINE 8192x8192 image split over the GPUs; weak = one 8192-row band "
+                         "per GPU (reported under `extra` by the default run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the untimed extra measurements (use under rocprofv3 to keep kernel averages clean)")
@@ -451,9 +454,13 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="(the default) kept for scripts")
     ap.add_argument("--cells", action="store_true",
                     help="N > 1: shard the cube pass by cells of the colour cube as well (ShardedLloyd(cells=True): histogram "
-                         "all-reduce once, all-gather of the label tables per iteration); default: row bands only")
+                         "all-reduce once, all-gather of the label tables per iteration); the default with --scaling strong")
+    ap.add_argument("--no-cells", action="store_true", help="N > 1: row bands only")
     ap.add_argument("--separate-update", action="store_true",
                     help="centroid update as a launch of its own (k_update + memset) instead of on the assign pass's last launch")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="N > 1 on a box with ONE GPU: every rank uses cuda:0 and the collectives go through gloo (RCCL refuses two "
+                         "ranks on a device) -- exercises the multi-rank code path, its timings mean nothing")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the all-reduce even with one rank (sanity check)")
     ap.add_argument("--only", choices=["cfg2"], default=None,
@@ -478,6 +485,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU path exists)")
+    if args.rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
@@ -485,9 +494,15 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     k = args.k
+    # N > 1 measures what BASELINE.json's north_star claims: the ONE 8192x8192 image over 1 / 2 / 4 / 8 GPUs (strong scaling;
+    # cell-sharded cube pass when the colour table is chosen); the weak-scaling figure goes to `extra`
+    args.scaling = args.scaling or ("strong" if world > 1 else "weak")
     if args.rows is not None:
         rows = args.rows
     elif args.scaling == "strong":
@@ -537,7 +552,8 @@ def main():
     first.close()
     lloyd, strategy, t_prep = prepared()
 
-    cells = bool(args.cells) and world > 1 and strategy == "table" and k <= 256
+    want_cells = bool(args.cells) or (args.scaling == "strong" and not args.no_cells)
+    cells = want_cells and world > 1 and strategy == "table" and k <= 256
     sh = ShardedLloyd(lloyd, k, rgba, labels, stream=stream, cells=cells)
     if cells:
         sh.bind_cells(n_local * world)        # once per image: band histograms all-reduced, this rank's share of the cube
@@ -589,6 +605,44 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # N > 1: the weak-scaling figure of the same loop (one 8192-row band per GPU, one k-means problem over the 8192 x 8192 N
+    # image, row bands + the k x 4 all-reduce behind the label pass) -- same bracket, MAX over the ranks; reported under `extra`
+    weak = None
+    if world > 1 and args.scaling == "strong" and args.rows is None and not args.no_extras:
+        n_w = WIDTH * ROWS_PER_GPU
+        rgba_w = synth.uniform_rgba_torch(seed, n_w, first=rank * n_w, device="cuda")
+        labels_w = torch.empty(n_w, dtype=torch.int32, device="cuda")
+        sel_w = synth.uniform_rgba_at(seed, np.arange(k, dtype=np.uint64) * np.uint64(n_w // k))
+        d_sel_w = torch.from_numpy(sel_w).cuda()
+        proc.rgb_to_lab(d_sel_w.data_ptr(), k, lab.data_ptr(), stream)
+        torch.cuda.synchronize()
+        cent_w = np.ones((k, 4), np.float32)
+        cent_w[:, :3] = lab.cpu().numpy()
+        lw = kg.Lloyd(proc, k)
+        lw.set_centroids(cent_w, stream)
+        how_w = lw.prepare(rgba_w.data_ptr(), n_w, True, stream)
+        shw = ShardedLloyd(lw, k, rgba_w, labels_w, stream=stream)
+        shw.split_labels = how_w == "table"
+        shw.prime()
+        for _ in range(args.warmup):
+            shw.iterate()
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t_w = time.perf_counter()
+        for _ in range(args.steps):
+            shw.iterate()
+        shw.flush()
+        torch.cuda.synchronize()
+        el_w = time.perf_counter() - t_w
+        dist.barrier()
+        tw = torch.tensor([el_w], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        el_w = float(tw.item())
+        weak = {"weak_scaling_value": n_w * world * args.steps / el_w, "weak_scaling_ms_per_step": el_w * 1e3 / args.steps,
+                "weak_scaling_workload": f"{WIDTH}x{ROWS_PER_GPU * world} (one {ROWS_PER_GPU}-row band per GPU), row bands",
+                "weak_scaling_strategy": how_w}
+        shw.close(); lw.close()
+        del rgba_w, labels_w
 
     # what a plain device-to-device copy of the same 2 x 4 B/px reaches on THIS box, for the "achievable" column
     copy_gbps = None
@@ -680,6 +734,8 @@ def main():
             c2 = cfg2_roofline(out["extra"], tj)
             if c2 is not None:
                 out["kernels_roofline"]["cfg2"] = c2
+        if weak is not None:
+            out.setdefault("extra", {}).update(weak)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(k, cent, seed)
         line = json.dumps(out)

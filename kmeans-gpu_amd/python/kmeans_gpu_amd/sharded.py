@@ -97,7 +97,7 @@ class ShardedLloyd:
     """
 
     def __init__(self, backend, k, rgba, labels=None, group=None, stream=0, collective=None, local_only=False,
-                 reserve_cus=RESERVED_CUS, cells=False, cell_hooks=None, rank=None):
+                 reserve_cus=RESERVED_CUS, cells=False, cell_hooks=None, rank=None, force_collectives=False):
         self.backend = backend
         self.k = int(k)
         self.rgba = rgba
@@ -134,7 +134,11 @@ class ShardedLloyd:
         # label map; the sums stay the k x 4 all-reduce.  Same labels and centroids as the unsharded loop, bit for bit.
         # Measured per-rank on one GPU (tools/strong_cells_per_rank.py): 1.70 / 2.54 / 3.71x at N = 2 / 4 / 8 against
         # 1.35 / 1.60 / 1.83x for row bands alone.
-        # cell_hooks (tests, one process): object with reduce_histogram(t), gather_tables(lab_t, ent_t), world, rank.
+        # cell_hooks (tests, one process): object with reduce_count(t), reduce_histogram(t), gather_tables(lab_t, ent_t),
+        # world, rank.
+        # force_collectives (tests): issue every collective even in a group of ONE rank, so that a single GPU drives the
+        # RCCL calls of this module -- on the tensors that alias the library's tables -- exactly as a multi-rank job does.
+        self.force_collectives = bool(force_collectives) and dist.is_initialized()
         self.cells = bool(cells)
         self.cell_hooks = cell_hooks
         self.rank = int(rank) if rank is not None else (dist.get_rank(group) if dist.is_initialized() else 0)
@@ -152,18 +156,27 @@ class ShardedLloyd:
         """once per image (cells=True): the band's histogram, all-reduced into the image's; this rank's share of the cube"""
         be = self.backend
         _require_current_stream(self.acc, self.stream)
-        be.bind_image(self.rgba.data_ptr(), self.n_local, self.stream)
+        collectives = self.world > 1 or self.force_collectives
+        if self.n_local:
+            be.bind_image(self.rgba.data_ptr(), self.n_local, self.stream)
+        else:
+            # a rank without rows still takes its share of the cube: the table of ONE dummy pixel, its count taken out again
+            if not hasattr(self, "_dummy"):
+                self._dummy = torch.zeros((1, 4), dtype=torch.uint8, device=self.acc.device)
+            be.bind_image(self._dummy.data_ptr(), 1, self.stream)
         hist = be.histogram_tensor()
+        if not self.n_local:
+            hist.zero_()
         if n_total is None:
             t = torch.tensor([self.n_local], dtype=torch.int64, device=self.acc.device)
             if self.cell_hooks is not None:
                 self.cell_hooks.reduce_count(t)
-            elif self.world > 1:
+            elif collectives:
                 dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
             n_total = int(t.item())
         if self.cell_hooks is not None:
             self.cell_hooks.reduce_histogram(hist)
-        elif self.world > 1:
+        elif collectives:
             dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=self.group)
         be.rebuild_from_histogram(n_total, self.stream)
         be.set_cell_share(self.rank, self.world, self.stream)
@@ -175,7 +188,7 @@ class ShardedLloyd:
         if self.cell_hooks is not None:
             self.cell_hooks.gather_tables(self._lab_t, self._ent_t)
             return
-        if self.world == 1:
+        if self.world == 1 and not self.force_collectives:
             return
         ranges = [cell_range(r, self.world) for r in range(self.world)]
         for t, per_cell in ((self._lab_t, CELL_COLOURS), (self._ent_t, 1)):
@@ -186,15 +199,28 @@ class ShardedLloyd:
                 for r, v in enumerate(views):
                     dist.broadcast(v, src=dist.get_global_rank(self.group, r) if self.group is not None else r, group=self.group)
 
+    def rebind(self, rgba=None, labels=None):
+        """new pixels (or a new buffer) for this loop: the cell-sharded binding and the aliased table tensors are stale"""
+        if rgba is not None:
+            self.rgba = rgba
+            self.n_local = int(rgba.shape[0]) if rgba.dim() == 2 else int(rgba.numel() // 4)
+        if labels is not None:
+            self.labels = labels
+        self._cells_bound = False
+        self._lab_t = self._ent_t = None
+
     def _pass_cells(self):
         lab_ptr = self.labels.data_ptr() if self.labels is not None else 0
         _require_current_stream(self.acc, self.stream)
         if not self._cells_bound:
             self.bind_cells()
-        self.backend.assign_accumulate(self.rgba.data_ptr(), self.n_local, 0, self.acc.data_ptr(), self.stream)
+        # (a rank without rows is bound to a dummy pixel: the pass walks its share of the image's colour table all the same)
+        bound_ptr = self.rgba.data_ptr() if self.n_local else self._dummy.data_ptr()
+        self.backend.assign_accumulate(bound_ptr, max(self.n_local, 1), 0, self.acc.data_ptr(), self.stream)
         work = self.exchange(async_op=True)
-        if lab_ptr:
+        if lab_ptr or self.world > 1 or self.force_collectives:
             self._gather_tables()
+        if lab_ptr and self.n_local:
             self.backend.labels_from_tables(self.rgba.data_ptr(), self.n_local, lab_ptr, self.stream)
         if work is not None:
             work.wait()
@@ -229,7 +255,7 @@ class ShardedLloyd:
         if self.collective is not None:
             self.collective(self.acc)
             return None
-        if self.world > 1:
+        if self.world > 1 or self.force_collectives:
             return dist.all_reduce(self.acc, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
         return None
 
@@ -240,7 +266,7 @@ class ShardedLloyd:
                 and hasattr(self.backend, "iterate"))
 
     def _fused(self):
-        return (self.fused and self.world == 1 and not self.cells and self.split_labels and self.labels is not None
+        return (self.fused and self.world == 1 and not self.force_collectives and not self.cells and self.split_labels and self.labels is not None
                 and self.n_local > 0 and hasattr(self.backend, "assign_update") and not self._pipelined())
 
     def _assign_then_update(self):
