@@ -48,7 +48,88 @@ def test_cfg3_full_pass_every_label_and_sum_vs_oracle(torch_cuda, oracle, monkey
         s.update(acc.data_ptr(), st)
         cent, _ = oracle.finalize(want_a, cent)
         assert np.array_equal(s.get_centroids(st).view(np.uint32), cent.view(np.uint32))
+    # a third pass through the call bench.py times: kmg_lloyd_assign_update(..., labels, acc, do_update = 1) -- the centroid
+    # update on the last launch of the assign pass (CubeTail): labels and sums of THIS assignment, centroids AFTER the update
+    labels.zero_(); acc.zero_()
+    s.assign_update(rgba.data_ptr(), n, labels.data_ptr(), acc.data_ptr(), True, st)
+    torch.cuda.synchronize()
+    want_l, want_a = oracle.assign_accumulate_rgba(host, cent)
+    got_l = labels.cpu().numpy().view(np.uint32)
+    assert np.array_equal(got_l, want_l), f"fused pass: {int((got_l != want_l).sum())} labels differ"
+    assert np.array_equal(acc.cpu().numpy(), want_a), "fused pass: accumulators differ"
+    cent, _ = oracle.finalize(want_a, cent)
+    assert np.array_equal(s.get_centroids(st).view(np.uint32), cent.view(np.uint32)), "fused pass: updated centroids differ"
     s.close()
+    p.close()
+
+
+def test_photograph_at_full_size_hot_cells_and_long_lists_vs_oracle(torch_cuda, oracle, monkeypatch):
+    """The tiled 8192 x 8192 photograph of bench.py (synthetic_image("photo")), k = 256: its pixels crowd into a few dark
+    cells, so the label pass keeps hot cells in LDS (k_labels_pairs<true>) and the cube pass bounds those cells' candidates
+    from long lists (long_list_stage) -- both asserted to have run -- and every label and every sum of one assign pass after
+    three Lloyd iterations equals the oracle's (find_centroid.wgsl:15-44, choose_centroid.wgsl:97-104)."""
+    import bench
+    import kmeans_gpu_amd as kg
+    torch = torch_cuda
+    monkeypatch.setenv("KMG_STRATEGY", "table")
+    st = _stream(torch)
+    n, k = 8192 * 8192, 256
+    rgba = bench.synthetic_image("photo", n, 0, k, 0x5EED0B10)
+    host = rgba.cpu().numpy()
+    sel = host[np.arange(k, dtype=np.int64) * (n // k)]
+    cent = oracle.centroids4(oracle.rgb_to_lab(sel))
+    p = kg.ImageProcessor(shrink_max_dim=0)
+    s = kg.Lloyd(p, k)
+    s.set_centroids(cent, st)
+    assert s.prepare(rgba.data_ptr(), n, True, st) == "table"
+    labels = torch.zeros(n, dtype=torch.int32, device="cuda")
+    acc = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
+    for _ in range(3):                                             # the centroids move into the crowded cells
+        s.assign_update(rgba.data_ptr(), n, 0, acc.data_ptr(), True, st)
+    cent = s.get_centroids(st)
+    s.assign_accumulate(rgba.data_ptr(), n, labels.data_ptr(), acc.data_ptr(), st)
+    torch.cuda.synchronize()
+    stats = s.debug_table_stats(st)
+    assert stats["max_candidates"] > 32 and stats["cells_unlisted"] > 0, stats       # long candidate lists were taken
+    mismatching, resolved, total = s.debug_check_pairs(st)
+    assert mismatching == 0 and total == n
+    want_l, want_a = oracle.assign_accumulate_rgba(host, cent)
+    got_l = labels.cpu().numpy().view(np.uint32)
+    assert np.array_equal(got_l, want_l), f"{int((got_l != want_l).sum())} labels differ"
+    assert np.array_equal(acc.cpu().numpy(), want_a), "accumulators differ"
+    assert resolved / total > 0.6, "the hot cells did not resolve the crowded pixels in LDS"
+    s.close()
+    p.close()
+
+
+@pytest.mark.parametrize("k", [300, 512])
+def test_two_list_dither_and_meld_rows_at_full_size_vs_oracle(torch_cuda, oracle, k):
+    """256 < k <= 512 on the 8192 x 8192 image of config 5: the dither pass over two byte lists per Lab cell
+    (k_dither_lists<2>) and the meld pass that merges the two halves' sorted triples (k_meld_lists<2>) -- the library's own
+    choice at this size -- against the oracle on three bands of 512 rows (mix_colors.wgsl:29-90)."""
+    import kmeans_gpu_amd as kg
+    from kmeans_gpu_amd import synth
+    torch = torch_cuda
+    st = _stream(torch)
+    w = h = 8192
+    n = w * h
+    rng = np.random.default_rng(1000 + k)
+    pal = np.full((k, 4), 255, np.uint8)
+    pal[:, :3] = rng.integers(0, 256, (k, 3))
+    pal = np.array(sorted(set(map(tuple, pal))), np.uint8)
+    assert pal.shape[0] > 256
+    cent = kg.palette_to_centroids(pal)
+    rgba = synth.uniform_rgba_torch(synth.SEED_CFG5, n, device="cuda")
+    p = kg.ImageProcessor()
+    out = torch.zeros((n, 4), dtype=torch.uint8, device="cuda")
+    for mode, omode in ((kg.ReduceMode.Dither, oracle.MODE_DITHER), (kg.ReduceMode.Meld, oracle.MODE_MELD)):
+        p.apply(rgba.data_ptr(), w, h, 0, cent, mode, out.data_ptr(), st)
+        torch.cuda.synchronize()
+        for r0, rows in ((0, 512), (4000, 512), (h - 512, 512)):     # r0 % 4 == 0: the oracle's Bayer rows line up
+            src = rgba[r0 * w:(r0 + rows) * w].cpu().numpy().reshape(rows, w, 4)
+            want = oracle.find(src, pal, omode)
+            got = out[r0 * w:(r0 + rows) * w].cpu().numpy().reshape(rows, w, 4)
+            assert np.array_equal(got, want), f"{mode.name} rows {r0}..{r0 + rows}: {int((got != want).any(-1).sum())} pixels differ"
     p.close()
 
 
