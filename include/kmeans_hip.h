@@ -76,6 +76,9 @@ KMG_API void kmg_processor_destroy(kmg_processor *p);
 /* Test support: out[0] = device blocks the processor has allocated with hipMalloc so far, out[1] = blocks it has handed out
  * again (colour tables, workspaces and output-pass scratch of finished objects are kept and reused).                 */
 KMG_API int kmg_debug_block_counts(kmg_processor *p, uint64_t out[2]);
+/* Test support: out[0] = blocks the processor holds idle right now, out[1] = their bytes.  The idle list is bounded (24 blocks,
+ * 3 GiB: the oldest go first) and is emptied when an allocation fails for lack of memory.                                  */
+KMG_API int kmg_debug_idle_blocks(kmg_processor *p, uint64_t out[2]);
 /* Test support: the meld pass turns a linear channel value into its sRGB8 byte with a 255-entry threshold table made on
  * the device by the encode of lab_to_rgb.wgsl:21-35 itself; *mismatches = the float values (every bit pattern, NaN aside)
  * for which table and encode give different bytes (0 = the table IS the encode).                                     */
@@ -209,12 +212,17 @@ KMG_API int kmg_lloyd_labels(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n_pix
 /* Cell-sharded cube pass, for ONE image sharded over `parts` ranks (strong scaling; no counterpart in the reference, which
  * is single-device: core/src/lib.rs:38-65).  Every rank binds the WHOLE image's colour histogram (its band's histogram,
  * all-reduced) and labels the colours of one share of the colour cube per iteration: after _set_cell_share(part, parts)
- * the assign passes of a bound image visit only the cells at positions [n part / parts, n (part + 1) / parts) of the
- * image's list of occupied cells -- the sums they return are those of the share's colours (the all-reduce of the k x 4
- * accumulators makes them the image's), and only the share's per-colour labels and cell entries are (re)written.  The
- * ranks then exchange their shares of the label tables (_table_buffers: the per-colour labels, cell-major, 512 per cell,
- * and the cell entries) and write their band's label map with _labels_from_tables, which applies the tables as they
- * stand to ANY pixels whose colours occur in the bound image.  parts = 1 restores the whole list.                    */
+ * the assign passes of a bound image visit only the occupied cells whose index lies in [32768 part / parts,
+ * 32768 (part + 1) / parts) -- equal RANGES of the colour cube (slabs of the red axis), so that the shares of the label tables
+ * are equal contiguous chunks an in-place all-gather can move; the WORK per share is equal only when the occupied cells are
+ * spread evenly (noise: yes; a photograph whose colours crowd into one slab: no -- unmeasured).  The sums such a pass returns
+ * are those of the share's colours (the all-reduce of the k x 4 accumulators makes them the image's), and only the share's
+ * per-colour labels and cell entries are (re)written.  The ranks then exchange their shares of the label tables
+ * (_table_buffers: the per-colour labels, cell-major, 512 per cell, and the cell entries) and write their band's label map
+ * with _labels_from_tables, which applies the tables as they stand to ANY pixels whose colours occur in the bound image.
+ * While a share is set, a pass that asks for a label map, a centroid update (kmg_lloyd_assign_update with do_update,
+ * kmg_lloyd_run, kmg_lloyd_iterate) or the two-step partial sums is refused with KMG_ERR_INVALID_ARGUMENT -- it would be that
+ * of a fraction of the image.  parts = 1 restores the whole list.                                                        */
 KMG_API int kmg_lloyd_set_cell_share(kmg_lloyd *s, uint32_t part, uint32_t parts, void *stream);
 /* The bound image's colour histogram (2^24 u32 counts in the library's cell-major colour order) for the all-reduce that
  * turns the band's histogram into the image's, and the call that re-derives everything a binding derives from it (cell

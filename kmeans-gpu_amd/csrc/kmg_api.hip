@@ -113,6 +113,12 @@ struct kmg_processor {
     hipMemPool_t pool;       // private stream-ordered pool for per-call scratch (never the device's default pool)
 };
 
+// The idle list is bounded: a block that would take it beyond kIdleMaxBlocks blocks or kIdleMaxBytes bytes pushes the OLDEST idle
+// blocks out (hipFree), so a processor that meets images of ever growing size, or ever larger k, does not keep every block
+// it once needed; and a hipMalloc that fails for lack of memory frees the whole list and tries once more.
+constexpr size_t kIdleMaxBlocks = 24;
+constexpr size_t kIdleMaxBytes = (size_t)3 << 30;
+
 // smallest idle block that is large enough, else a fresh one
 static hipError_t block_take(kmg_processor *p, size_t bytes, void **ptr, size_t *cap)
 {
@@ -134,7 +140,18 @@ static hipError_t block_take(kmg_processor *p, size_t bytes, void **ptr, size_t 
         }
         p->n_block_malloc += 1;
     }
-    const hipError_t e = hipMalloc(ptr, bytes);
+    hipError_t e = hipMalloc(ptr, bytes);
+    if (e == hipErrorOutOfMemory) {
+        // idle blocks may hold what this request needs: hand all of them back to the driver and try once more
+        std::vector<std::pair<void *, size_t>> victims;
+        {
+            std::lock_guard<std::mutex> lock(p->mu);
+            victims.swap(p->idle_arenas);
+        }
+        (void)hipGetLastError();
+        for (auto &v : victims) (void)hipFree(v.first);
+        if (!victims.empty()) e = hipMalloc(ptr, bytes);
+    }
     if (e == hipSuccess) *cap = bytes;
     return e;
 }
@@ -143,8 +160,19 @@ static hipError_t block_take(kmg_processor *p, size_t bytes, void **ptr, size_t 
 static void block_give(kmg_processor *p, void *ptr, size_t cap)
 {
     if (!ptr) return;
-    std::lock_guard<std::mutex> lock(p->mu);
-    p->idle_arenas.emplace_back(ptr, cap);
+    std::vector<void *> victims;
+    {
+        std::lock_guard<std::mutex> lock(p->mu);
+        p->idle_arenas.emplace_back(ptr, cap);
+        size_t total = 0;
+        for (auto &a : p->idle_arenas) total += a.second;
+        while (p->idle_arenas.size() > 1 && (p->idle_arenas.size() > kIdleMaxBlocks || total > kIdleMaxBytes)) {
+            total -= p->idle_arenas.front().second;
+            victims.push_back(p->idle_arenas.front().first);
+            p->idle_arenas.erase(p->idle_arenas.begin());
+        }
+    }
+    for (void *v : victims) (void)hipFree(v);                         // (outside the lock: hipFree synchronises the device)
 }
 
 static inline size_t pad256(size_t bytes) { return (bytes + 255u) & ~(size_t)255u; }
@@ -298,6 +326,16 @@ extern "C" int kmg_debug_block_counts(kmg_processor *p, uint64_t out[2])
     std::lock_guard<std::mutex> lock(p->mu);
     out[0] = p->n_block_malloc;
     out[1] = p->n_block_reuse;
+    return KMG_OK;
+}
+
+extern "C" int kmg_debug_idle_blocks(kmg_processor *p, uint64_t out[2])
+{
+    if (!p || !out) return fail(KMG_ERR_INVALID_ARGUMENT, "bad idle_blocks arguments");
+    std::lock_guard<std::mutex> lock(p->mu);
+    out[0] = p->idle_arenas.size();
+    out[1] = 0;
+    for (auto &a : p->idle_arenas) out[1] += a.second;
     return KMG_OK;
 }
 
@@ -1008,6 +1046,7 @@ static int debug_refresh(kmg_lloyd *s, hipStream_t st, unsigned long long stage[
 {
     ColourTable &t = s->tab;
     int rc_;
+    if (t.d_work_share) return fail(KMG_ERR_INVALID_ARGUMENT, "statistics / checks of a bound image need the whole cube: a cell share is set");
     if ((rc_ = side_flush(s, st)) != KMG_OK) return rc_;
     // d_partials is scratch here: the sums of this repeat pass and, behind them, the stage counters
     unsigned long long *d_stage = reinterpret_cast<unsigned long long *>(s->d_partials) + 4ull * s->k;
@@ -1055,6 +1094,12 @@ static int table_assign(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_
 {
     if (d_labels) defer_entries = false;
     ColourTable &t = s->tab;
+    // With a cell share set (kmg_lloyd_set_cell_share) a pass labels one share of the cube and returns ITS sums: the label
+    // tables are complete only after the caller's all-gather, the sums only after its all-reduce.  A label map, a centroid
+    // update or the two-step partial sums from such a pass would silently be those of a fraction of the image.
+    if (t.d_work_share && (d_labels || update_after || rows != 1u))
+        return fail(KMG_ERR_INVALID_ARGUMENT, "a cell share is set: this pass returns one share's sums only -- no label map, no "
+                    "update, no partial rows (all-reduce the sums, all-gather the tables, then kmg_lloyd_labels_from_tables)");
     t.bound_by_init = false;      // only a prepare() that directly follows the initialisation may reuse its binding
     int rc_;
     if ((rc_ = side_flush(s, st)) != KMG_OK) return rc_;
@@ -1085,7 +1130,9 @@ static int table_assign(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_
                                                    d_sums, rows, 0u, nullptr, st, nullptr, affine_for(s->p, s->k, st)));
         t.entries_valid = true;
     }
-    t.tables_valid = true;
+    // (a share's pass leaves the tables current for ITS cells only: kmg_lloyd_labels refuses them, _labels_from_tables -- after
+    // the caller's all-gather -- takes them as they stand)
+    t.tables_valid = t.d_work_share == nullptr;
     if (d_labels)
         PROF_LAUNCH(s, KMG_K_LABELS, st, launch_labels((const uint32_t *)d_rgba, n, t.d_colour_labels, t.d_sub, s->k, nullptr, d_labels, st, s->reserve_cus, t.n_hot ? t.d_work + kCells + 1 : nullptr));
     // (after an update the tables still describe the assignment just made, not the new centroids)
@@ -1266,8 +1313,9 @@ extern "C" int kmg_lloyd_init_centroids(kmg_lloyd *s, const uint8_t *d_rgba, uin
         if ((rc = init_over_colours(s, d_rgba, n, 0, &colours, stream)) != KMG_OK) return rc;
         if (!colours && s->dist_cap < n) {
             if (s->d_dist) {
+                // (too small for this image: freed, not parked -- a distance map serves nothing else)
                 HIP_TRY(hipStreamSynchronize(S(stream)));
-                block_give(s->p, s->d_dist, s->dist_blk_cap);
+                HIP_TRY(hipFree(s->d_dist));
                 s->d_dist = nullptr; s->dist_cap = 0; s->dist_blk_cap = 0;
             }
             HIP_TRY(block_take(s->p, sizeof(float) * n, (void **)&s->d_dist, &s->dist_blk_cap));
@@ -1319,7 +1367,7 @@ extern "C" int kmg_lloyd_init_step(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t
         if (j != 1) return fail(KMG_ERR_INVALID_ARGUMENT, "init_step: the distance map of this band was never started (j = 1)");
         if (s->d_dist) {
             HIP_TRY(hipStreamSynchronize(S(stream)));
-            block_give(s->p, s->d_dist, s->dist_blk_cap);
+            HIP_TRY(hipFree(s->d_dist));
             s->d_dist = nullptr; s->dist_cap = 0; s->dist_blk_cap = 0;
         }
         HIP_TRY(block_take(s->p, sizeof(float) * n_local, (void **)&s->d_dist, &s->dist_blk_cap));
@@ -1585,6 +1633,7 @@ extern "C" int kmg_lloyd_iterate(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n
     }
     hipStream_t st = S(stream);
     ColourTable &t = s->tab;
+    if (t.d_work_share) return fail(KMG_ERR_INVALID_ARGUMENT, "iterate: a cell share is set (kmg_lloyd_set_cell_share)");
     if (!s->side) {
         int least = 0, greatest = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
@@ -1660,6 +1709,8 @@ extern "C" int kmg_lloyd_run(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, ui
                              uint32_t *iterations, void *stream)
 {
     if (!s || !d_rgba || n == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad lloyd_run arguments");
+    if (s->tab.d_work_share && table_bound(s, d_rgba, n))
+        return fail(KMG_ERR_INVALID_ARGUMENT, "lloyd_run: a cell share is set (kmg_lloyd_set_cell_share): the loop would update from one share's sums");
     const kmg_options &o = s->p->opt;
     int rc;
     // large problems iterate over the image's colour table instead of its pixels (same results);

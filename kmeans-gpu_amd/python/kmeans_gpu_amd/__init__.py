@@ -82,7 +82,7 @@ SYMBOLS = [
     "kmg_lloyd_unbind_image", "kmg_lloyd_prepare", "kmg_debug_check_table", "kmg_debug_table_stats", "kmg_debug_check_pairs", "kmg_debug_check_dither_masks", "kmg_debug_check_meld_masks", "kmg_kernel_name",
     "kmg_lloyd_profile", "kmg_lloyd_profile_read",
     "kmg_lloyd_update", "kmg_lloyd_assign_update", "kmg_lloyd_set_cell_share", "kmg_lloyd_labels_from_tables",
-    "kmg_lloyd_table_buffers", "kmg_lloyd_histogram_buffer", "kmg_lloyd_rebuild_from_histogram", "kmg_debug_block_counts", "kmg_debug_encode_table_check", "kmg_debug_division_check", "kmg_lloyd_converged_count", "kmg_lloyd_iterate", "kmg_lloyd_flush", "kmg_lloyd_run", "kmg_dev_apply",
+    "kmg_lloyd_table_buffers", "kmg_lloyd_histogram_buffer", "kmg_lloyd_rebuild_from_histogram", "kmg_debug_block_counts", "kmg_debug_idle_blocks", "kmg_debug_encode_table_check", "kmg_debug_division_check", "kmg_lloyd_converged_count", "kmg_lloyd_iterate", "kmg_lloyd_flush", "kmg_lloyd_run", "kmg_dev_apply",
     "kmg_dither_threshold",
 ]
 
@@ -157,6 +157,7 @@ def lib():
     L.kmg_lloyd_set_cell_share.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
     L.kmg_lloyd_labels_from_tables.argtypes = [vp, u8p, C.c_uint64, u32p, vp]
     L.kmg_debug_block_counts.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.kmg_debug_idle_blocks.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.kmg_debug_encode_table_check.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.kmg_debug_division_check.argtypes = [vp, C.c_float, C.POINTER(C.c_uint64)]
     L.kmg_lloyd_histogram_buffer.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
@@ -312,6 +313,12 @@ class ImageProcessor:
         """(device blocks allocated with hipMalloc so far, blocks handed out again)"""
         out = (C.c_uint64 * 2)()
         _check(lib().kmg_debug_block_counts(self._h, out))
+        return int(out[0]), int(out[1])
+
+    def debug_idle_blocks(self):
+        """(blocks the processor holds idle right now, their bytes)"""
+        out = (C.c_uint64 * 2)()
+        _check(lib().kmg_debug_idle_blocks(self._h, out))
         return int(out[0]), int(out[1])
 
     def debug_encode_table_check(self):

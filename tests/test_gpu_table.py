@@ -1107,3 +1107,71 @@ def test_crowded_centroids_take_the_long_candidate_lists(torch_cuda, oracle, mon
         cent, _ = oracle.finalize(want_a, cent)
     s.close()
     p.close()
+
+
+def test_idle_blocks_stay_bounded_when_images_grow(torch_cuda, oracle, monkeypatch):
+    """The processor keeps the blocks of finished objects for the next image, but not without bound: binding images of
+    growing size (each needs blocks the earlier ones cannot serve) leaves at most 24 idle blocks / 3 GiB behind, and the
+    results stay those of the oracle."""
+    import kmeans_gpu_amd as kg
+    from kmeans_gpu_amd import synth
+    torch = torch_cuda
+    st = _stream(torch)
+    p = kg.ImageProcessor(shrink_max_dim=0)
+    k = 8
+    for i, n in enumerate([40_000 + 25_000 * j for j in range(40)]):
+        monkeypatch.setenv("KMG_STRATEGY", "table" if i % 2 else "brute")
+        img = synth.uniform_rgba_torch(900 + i, n, device="cuda")
+        s = kg.Lloyd(p, k + i)                                   # growing workspaces too
+        s.init_centroids(img.data_ptr(), n // 100, 100, st)      # growing distance maps (per-pixel init on the brute rounds)
+        labels = torch.zeros(n, dtype=torch.int32, device="cuda")
+        s.run(img.data_ptr(), n, labels.data_ptr(), st)
+        if i in (0, 17, 39):
+            host = img.cpu().numpy()
+            lab = oracle.rgb_to_lab(host)
+            want_c, want_l, _ = oracle.lloyd(lab, oracle.init_centroids(lab, n // 100, 100, k + i))
+            assert np.array_equal(labels.cpu().numpy().view(np.uint32), want_l)
+            assert np.array_equal(s.get_centroids(st).view(np.uint32), want_c.view(np.uint32))
+        s.close()
+        blocks, nbytes = p.debug_idle_blocks()
+        assert blocks <= 24 and nbytes <= 3 << 30, (i, blocks, nbytes)
+    mallocs, reuses = p.debug_block_counts()
+    assert reuses > 0
+    p.close()
+
+
+def test_cell_share_refuses_what_it_cannot_answer(torch_cuda, oracle, monkeypatch):
+    """With a cell share set a pass returns one share's sums: a label map, a fused update, the loop, the two-step partial
+    sums and the table statistics are refused instead of returning a fraction of the image's result."""
+    import kmeans_gpu_amd as kg
+    from kmeans_gpu_amd import synth
+    torch = torch_cuda
+    st = _stream(torch)
+    monkeypatch.setenv("KMG_STRATEGY", "table")
+    n, k = 300_000, 12
+    img = synth.uniform_rgba_torch(4711, n, device="cuda")
+    p = kg.ImageProcessor(shrink_max_dim=0)
+    s = kg.Lloyd(p, k)
+    s.set_centroids(oracle.centroids4(oracle.rgb_to_lab(img[:k].cpu().numpy())), st)
+    s.bind_image(img.data_ptr(), n, st)
+    labels = torch.zeros(n, dtype=torch.int32, device="cuda")
+    acc = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
+    s.set_cell_share(0, 2, st)
+    s.assign_accumulate(img.data_ptr(), n, 0, acc.data_ptr(), st)                 # the share's sums: fine
+    torch.cuda.synchronize()
+    assert 0 < int(acc[:, 3].sum()) < n
+    for call in (lambda: s.assign_accumulate(img.data_ptr(), n, labels.data_ptr(), acc.data_ptr(), st),
+                 lambda: s.assign_update(img.data_ptr(), n, 0, acc.data_ptr(), True, st),
+                 lambda: s.assign_partials(img.data_ptr(), n, 0, st),
+                 lambda: s.iterate(img.data_ptr(), n, labels.data_ptr(), acc.data_ptr(), True, st),
+                 lambda: s.run(img.data_ptr(), n, labels.data_ptr(), st),
+                 lambda: s.debug_table_stats(st)):
+        with pytest.raises(kg.KmgError):
+            call()
+    s.set_cell_share(0, 1, st)                                                      # the whole cube again
+    s.assign_accumulate(img.data_ptr(), n, labels.data_ptr(), acc.data_ptr(), st)
+    torch.cuda.synchronize()
+    want_l, want_a = oracle.assign_accumulate_rgba(img.cpu().numpy(), s.get_centroids(st))
+    assert np.array_equal(labels.cpu().numpy().view(np.uint32), want_l) and np.array_equal(acc.cpu().numpy(), want_a)
+    s.close()
+    p.close()
