@@ -291,6 +291,22 @@ def cfg2_timing(proc, stream, steps=20, strategies=("table", "scan"), profile_ke
     return out
 
 
+def attach_valu_roof(table, ms_of, tj):
+    """The roof that binds, per kernel of the line: `valu` = vector wave-instructions one launch executes (SQ_INSTS_VALU of
+    a rocprofv3 PMC pass of the same loop, profiles/traffic.json `valu_wave_instructions`) x 64 lanes over the kernel's time
+    and the fp32 vector issue peak (78.6 T lane-operations/s = 157.3 TF/s with an FMA as two); `bound` = the larger of the
+    two fractions -- "hbm" or "valu" -- and "requests" for the label pass, whose time goes to divergent gathers the vector
+    memory pipeline retires at ~1 lane per 2 clocks per CU (profiles/NOTES.md)."""
+    counts = tj.get("valu_wave_instructions", {})
+    for nm, row in table.items():
+        if not isinstance(row, dict) or "valu" in row or nm not in counts or nm not in ms_of or not ms_of[nm]:
+            continue
+        row["valu_wave_instructions"] = counts[nm]
+        row["valu"] = counts[nm] * 64 / (ms_of[nm] * 1e-3) / VALU_LANE_OPS_PEAK
+        row["bound"] = "requests" if nm == "k_labels" else ("valu" if row["valu"] > row.get("frac", 0.0) else "hbm")
+        row["valu_source"] = tj.get("valu_source", "profiles/traffic.json")
+
+
 def cfg2_roofline(extra, tj):
     """both roofs of SURVEY 8d for config 2: 8 B/px over the step against HBM, and the vector instructions the step's
     kernels execute (profiles/traffic.json `valu_wave_instructions`, rocprofv3 SQ_INSTS_VALU of the same loop) x 64 lanes
@@ -310,6 +326,7 @@ def cfg2_roofline(extra, tj):
     if valu:
         r["valu_wave_instructions"] = valu
         r["valu"] = valu * 64 / (ms * 1e-3) / VALU_LANE_OPS_PEAK
+        r["bound"] = "valu" if r["valu"] > r["frac"] else "hbm"
         r["traffic"] = tj.get("bytes_per_launch", {}).get("cfg2_step")
     return r
 
@@ -706,9 +723,12 @@ def main():
                          "achieved_iteration": step_gbps, "frac_iteration": step_gbps / HBM_PEAK_GBPS,
                          "frac_iteration_achievable": step_gbps / HBM_ACHIEVABLE_GBPS,
                          "frac_iteration_of_copy": (step_gbps / copy_gbps) if copy_gbps else None,
-                         # SURVEY 8d's second roof: flops of the literal per-pixel scan (17 k + 50 per pixel) over the
-                         # fp32 vector peak; > 1 means the colour table does not perform them
-                         "valu_fraction": flops / (ms_per_step * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
+                         # SURVEY 8d's second roof, for orientation only: the time the LITERAL per-pixel scan's flops
+                         # (17 k + 50 per pixel) would need at the fp32 vector peak, against the measured step -- a ratio, not a
+                         # utilisation (the colour table does not execute those flops).  What the kernels really issue is in
+                         # kernels_roofline.*.valu
+                         "literal_scan_valu_floor_ms": flops / (FP32_VECTOR_PEAK_TFLOPS * 1e12) * 1e3,
+                         "literal_scan_valu_floor_over_step": flops / (ms_per_step * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
                          "valu_peak_tflops": FP32_VECTOR_PEAK_TFLOPS},
             "kernels": kernels,
             # every timed kernel against the HBM roof, from its own algorithmic bytes (k_cube: 2^24 counts in, 2^24 labels out)
@@ -720,6 +740,7 @@ def main():
             "kernels_note": "HIP events on the launch stream; the dominant kernel inside the timed region, k_cube in a loop of "
                             "its own right after it (same state, same launches)",
         }
+        attach_valu_roof(out["kernels_roofline"], {nm: v["ms_per_launch"] for nm, v in kernels.items()}, tj)
         if world == 1 and rows == ROWS_PER_GPU and not args.no_extras:
             out["extra"] = output_pass_timing(proc, rgba, n_local, stream, sh)
             for name in ("find_dither_k64", "find_replace_k64"):          # the output passes of BASELINE config 5, same roof
@@ -734,6 +755,7 @@ def main():
             c2 = cfg2_roofline(out["extra"], tj)
             if c2 is not None:
                 out["kernels_roofline"]["cfg2"] = c2
+            attach_valu_roof(out["kernels_roofline"], {nm[:-3]: ms for nm, ms in out["extra"].items() if nm.endswith("_ms")}, tj)
         if weak is not None:
             out.setdefault("extra", {}).update(weak)
         if world == 1 and not args.no_cpu_baseline:

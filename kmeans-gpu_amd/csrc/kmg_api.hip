@@ -101,7 +101,7 @@ struct kmg_processor {
     CellBounds *d_sub_bounds;   // kSubCells static bounds of the 4x4x4 sub-cells
     float4 *d_lab_table;     // 2^24 x (L, a, b, C): Lab of every colour (256 MiB, built with d_bounds)
     float *d_sub_affine;     // sub_affine_bytes(): affine feature models per sub-cell (dominance test of k_cube_small), built on
-                             // the first colour-table pass with k <= 32
+                             // the first colour-table pass
     bool affine_failed;      // ... or not at all (allocation failed: the pass runs without the test)
     std::vector<hipStream_t> idle_streams;   // streams of finished host-buffer calls, reused by the next ones (mu)
     // Device blocks the processor keeps between uses (mu): output-pass scratch, colour tables and workspaces of finished
@@ -641,12 +641,12 @@ static int ensure_bounds(kmg_processor *p, hipStream_t st)
 // NULL when it cannot be had -- the pass is exact without it, only slower.
 static const float *affine_for(kmg_processor *p, uint32_t k, hipStream_t st)
 {
-    if (k > 32u) return nullptr;
+    if (k > 32u) return nullptr;                                     // (only k_cube_small makes the test)
     std::lock_guard<std::mutex> lock(p->mu);
     if (p->d_sub_affine || p->affine_failed || !p->d_lab_table) return p->d_sub_affine;
     float *a = nullptr;
     hipError_t e = hipMalloc((void **)&a, sub_affine_bytes());
-    if (e == hipSuccess) e = launch_sub_affine(p->d_lab_table, a, st);
+    if (e == hipSuccess) e = launch_sub_affine(p->d_lab_table, p->d_sub_bounds, a, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) {
         (void)hipGetLastError();

@@ -256,6 +256,50 @@ __device__ __forceinline__ uint2 long_list_stage(const float4 *s_cent, const uns
     return r;
 }
 
+
+constexpr uint32_t kAffineFloats = 48;                            // per sub-cell: 7 features x (alpha, 3 beta, Rmin, Rmax) = 42, then
+                                                                  // [42] = C1, [43] = wH1 of the sub-cell's bounds, 4 of padding
+
+// The dominance test (see k_cube_small's header for the derivation): true when, for every colour of the sub-cell whose model
+// is at `mdl` (kAffineFloats floats, LDS or registers), K_j - K_i >= 2^-11 U, U >= the float upper bound of key_i over the
+// sub-cell.  Binary32 throughout: the lower bound is accumulated together with `mag`, the sum of the magnitudes of everything
+// that enters it; the evaluation performs fewer than 40 roundings, each relative to a partial sum <= mag, and the inputs' own
+// errors -- differences of squares (w2, c0), N = a^2 + b^2 - C^2 -- are bounded by 3u times sums of squares that mag holds as
+// well (the features they multiply, wC and wH, are <= 1), so the computed value is within 64 u mag of the real one
+// (u = 2^-24) and subtracting that keeps the bound rigorous.  What the error term costs: mag ~ 3e4 for colours, 64 u mag ~ 0.1
+// in units of dE^2 -- against differences of tens for a box next to a boundary.
+template <typename Model>
+__device__ __forceinline__ bool dominated(const Model &mdl, const float4 cj, const float4 ci, float U)
+{
+    const float Lj2 = cj.x * cj.x, Li2 = ci.x * ci.x, Cj2 = cj.w * cj.w, Ci2 = ci.w * ci.w;
+    const float Aj = fmaf(cj.z, cj.z, cj.y * cj.y), Ai = fmaf(ci.z, ci.z, ci.y * ci.y);
+    const float dC = cj.w - ci.w;
+    const float w[7] = {-2.0f * (cj.x - ci.x), Cj2 - Ci2, -2.0f * dC, -2.0f * (cj.y - ci.y), -2.0f * (cj.z - ci.z), 2.0f * dC,
+                        (Aj - Cj2) - (Ai - Ci2)};
+    float d = Lj2 - Li2, gx = 0.0f, gy = 0.0f, gz = 0.0f, mx = 0.0f, my = 0.0f, mz = 0.0f;
+    float mag = (Lj2 + Li2) + (Cj2 + Ci2) + ((Aj + Cj2) + (Ai + Ci2));
+#pragma unroll
+    for (int m = 0; m < 7; ++m) {
+        const float t = w[m] * mdl[6 * m];
+        d += t;
+        mag += fabsf(t);
+        const float tx = w[m] * mdl[6 * m + 1], ty = w[m] * mdl[6 * m + 2], tz = w[m] * mdl[6 * m + 3];
+        gx += tx; gy += ty; gz += tz;
+        mx += fabsf(tx); my += fabsf(ty); mz += fabsf(tz);
+        const float r = fminf(w[m] * mdl[6 * m + 4], w[m] * mdl[6 * m + 5]);
+        d += r;
+        mag += fabsf(r);
+    }
+    d -= 1.5f * ((fabsf(gx) + fabsf(gy)) + fabsf(gz));
+    mag += 1.5f * ((mx + my) + mz);
+    const float cs = mdl[42] + ci.w;                              // C1 + Ci
+    const float delta = mdl[43] * (9.5367431640625e-07f * (cs * cs));   // wH1 2^-20 (C1 + Ci)^2
+    d -= delta;
+    mag += delta;
+    // 64 u = 2^-18; 2^-11 (1 + 2^-7)
+    return d - 3.814697265625e-06f * mag >= 0.000492095947265625f * U;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -887,7 +931,7 @@ __global__ __launch_bounds__(kBlock) void k_cube_pairs(const uint32_t *__restric
 // and feature, an affine model alpha + beta . (x - 1.5, y - 1.5, z - 1.5) over the 4 x 4 x 4 colours and the exact range
 // [Rmin, Rmax] of its residual (k_sub_affine), hence for every colour of the sub-cell
 //   K_j - K_i >= c0 + sum_m w_m alpha_m - 1.5 sum_d |sum_m w_m beta_md| + sum_m min(w_m Rmin_m, w_m Rmax_m) - wH1 delta.
-// Evaluated in binary64 (rounding ~1e-16 of the terms' magnitude, charged as 1e-9 of it).  A candidate j is dropped when this
+// Evaluated in binary32 with its rounding error charged explicitly (`dominated`).  A candidate j is dropped when this
 // lower bound is >= 2^-11 hi_i for the candidate i with the smallest upper bound hi_i: then K_j >= K_i (1 + 2^-11 (1 - 63u))
 // for every colour, and with |key - K| <= 560u K for the scan's keys (kmg_math.h) key_j > key_i (1 + 2^-12) -- j is neither
 // the arg-min nor within the tie threshold of it, exactly the property the interval test guarantees for what IT removes.
@@ -901,7 +945,6 @@ constexpr int kSmallBlock = 512;
 constexpr uint32_t kSmallWaves = kSmallBlock / 64;
 constexpr uint32_t kSmallCells = kSmallWaves * 8u;               // cells of a workgroup
 constexpr uint32_t kSmallTests = 2048;                           // dominance tests a workgroup lists per round
-constexpr uint32_t kAffineFloats = 48;                            // per sub-cell: 7 features x (alpha, 3 beta, Rmin, Rmax), padded
 
 __device__ __forceinline__ uint32_t group8_or(uint32_t v)
 {
@@ -936,7 +979,8 @@ __device__ __forceinline__ void affine_features(const float4 v, double F[7])
 }
 
 // once per processor: the affine models of the dominance test, one thread per sub-cell
-__global__ __launch_bounds__(kBlock) void k_sub_affine(const float4 *__restrict__ lab_table, float *__restrict__ affine)
+__global__ __launch_bounds__(kBlock) void k_sub_affine(const float4 *__restrict__ lab_table,
+                                                       const CellBounds *__restrict__ sub_bounds, float *__restrict__ affine)
 {
     const uint32_t sc = blockIdx.x * kBlock + threadIdx.x;
     if (sc >= kSubCells) return;
@@ -982,39 +1026,18 @@ __global__ __launch_bounds__(kBlock) void k_sub_affine(const float4 *__restrict_
         out[6 * m + 0] = al[m]; out[6 * m + 1] = bx[m]; out[6 * m + 2] = by[m]; out[6 * m + 3] = bz[m];
         out[6 * m + 4] = flo; out[6 * m + 5] = fhi;
     }
+    out[42] = sub_bounds[sc].C1;                                   // what the clamp correction of the test needs
+    out[43] = sub_bounds[sc].wH1;
 #pragma unroll
-    for (int m = 42; m < (int)kAffineFloats; ++m) out[m] = 0.0f;
+    for (int m = 44; m < (int)kAffineFloats; ++m) out[m] = 0.0f;
 }
 
 size_t sub_affine_bytes() { return sizeof(float) * (size_t)kAffineFloats * kSubCells; }
 
-hipError_t launch_sub_affine(const float4 *lab_table, float *affine, hipStream_t st)
+hipError_t launch_sub_affine(const float4 *lab_table, const CellBounds *sub_bounds, float *affine, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_sub_affine, dim3(kSubCells / kBlock), dim3(kBlock), 0, st, lab_table, affine);
+    hipLaunchKernelGGL(k_sub_affine, dim3(kSubCells / kBlock), dim3(kBlock), 0, st, lab_table, sub_bounds, affine);
     return hipGetLastError();
-}
-
-// lower bound of K_j - K_i over the sub-cell whose model is `mdl` (see above), and the magnitude of its terms
-__device__ __forceinline__ double dominance_lower_bound(const float (&mdl)[44], const float4 cj, const float4 ci, float C1, float wH1,
-                                                        double &mag)
-{
-    const double Lj = cj.x, aj = cj.y, bj = cj.z, Cj = cj.w, Li = ci.x, ai = ci.y, bi = ci.z, Ci = ci.w;
-    const double Nj = aj * aj + bj * bj - Cj * Cj, Ni = ai * ai + bi * bi - Ci * Ci;
-    const double w[7] = {-2.0 * (Lj - Li), Cj * Cj - Ci * Ci, -2.0 * (Cj - Ci), -2.0 * (aj - ai), -2.0 * (bj - bi), 2.0 * (Cj - Ci), Nj - Ni};
-    double d = Lj * Lj - Li * Li, gx = 0.0, gy = 0.0, gz = 0.0;
-    mag = fabs(Lj * Lj) + fabs(Li * Li);
-#pragma unroll
-    for (int m = 0; m < 7; ++m) {
-        const double t = w[m] * (double)mdl[6 * m];
-        d += t;
-        mag += fabs(t);
-        gx += w[m] * (double)mdl[6 * m + 1]; gy += w[m] * (double)mdl[6 * m + 2]; gz += w[m] * (double)mdl[6 * m + 3];
-        d += fmin(w[m] * (double)mdl[6 * m + 4], w[m] * (double)mdl[6 * m + 5]);
-    }
-    d -= 1.5 * (fabs(gx) + fabs(gy) + fabs(gz));
-    const double cs = (double)C1 + Ci;
-    d -= (double)wH1 * (9.5367431640625e-07 * (cs * cs));         // delta = 2^-20 (C1 + Ci)^2
-    return d;
 }
 
 template <int KP, bool SUMS>
@@ -1161,11 +1184,7 @@ __global__ __launch_bounds__(kSmallBlock) __attribute__((amdgpu_waves_per_eu(4, 
                     const float4 v = mp[q];
                     mdl[4 * q] = v.x; mdl[4 * q + 1] = v.y; mdl[4 * q + 2] = v.z; mdl[4 * q + 3] = v.w;
                 }
-                const CellBounds *tb = sub_bounds + tsc;
-                const float C1 = tb->C1, wH1 = tb->wH1;
-                double mag;
-                const double d = dominance_lower_bound(mdl, s_cent[j], s_cent[s_istar[e]], C1, wH1, mag);
-                if (d >= 0.00048828125 * (double)s_U[e] + 1.0e-9 * mag) atomicAnd(&s_mask[e], ~(1u << j));   // 2^-11 hi_i
+                if (dominated(mdl, s_cent[j], s_cent[s_istar[e]], s_U[e])) atomicAnd(&s_mask[e], ~(1u << j));
             }
             __syncthreads();
             mask = s_mask[threadIdx.x];

@@ -199,7 +199,7 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
 // of two keys is linear in, with exact residual ranges -- the dominance test that removes, from a sub-cell's candidates, those
 // another candidate beats on every colour of the sub-cell (3x fewer scanned sub-cells at k = 16).
 size_t sub_affine_bytes();
-hipError_t launch_sub_affine(const float4 *lab_table, float *affine, hipStream_t st);
+hipError_t launch_sub_affine(const float4 *lab_table, const CellBounds *sub_bounds, float *affine, hipStream_t st);
 // pal == NULL: labels[i] = label; pal != NULL: labels[i] = pal[label] (RGBA8 output of replace mode).
 // reserve_cus: compute units left without a workgroup of the k <= 256 label pass (kmg_lloyd_reserve_cus)
 // hot: NULL, or the image's hot cells ([n_hot][cells ...], n_hot > 0 known to the host): k <= 256 keeps their labels in LDS
