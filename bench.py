@@ -336,13 +336,23 @@ def reduce_end_to_end(proc, rgba, width, height, k):
     dither output pass, download -- PCIe included, never part of `value`.  The second call (warm processor: streams, blocks
     and pool memory are there) is the one reported."""
     import kmeans_gpu_amd as kg
+    import numpy as np
     host = rgba.cpu().numpy().reshape(height, width, 4)
     times = []
     for _ in range(3):
         t = time.perf_counter()
         proc.reduce(k, host, reduce_mode=kg.ReduceMode.Dither)
         times.append((time.perf_counter() - t) * 1e3)
-    return {"reduce_host_to_host_cold_ms": times[0], "reduce_host_to_host_warm_ms": min(times[1:])}
+    # the same call into a result buffer the caller keeps (what the C ABI does; the figures above include creating -- and, from
+    # the second call on, unmapping -- a fresh 256 MiB numpy array per call, as the reference's Vec-returning API would)
+    out = np.empty_like(host)
+    into = []
+    for _ in range(3):
+        t = time.perf_counter()
+        proc.reduce(k, host, reduce_mode=kg.ReduceMode.Dither, out=out)
+        into.append((time.perf_counter() - t) * 1e3)
+    return {"reduce_host_to_host_cold_ms": times[0], "reduce_host_to_host_warm_ms": min(times[1:]),
+            "reduce_host_to_host_into_callers_buffer_ms": min(into[1:])}
 
 
 def output_pass_timing(proc, rgba, n_pixels, stream, sh=None, steps=3):

@@ -13,7 +13,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <mutex>
+#include <thread>
 #include <new>
 #include <vector>
 
@@ -1945,23 +1947,56 @@ int extract_palette_kmeans(kmg_processor *p, const uint8_t *d_rgba, uint32_t w, 
 }
 
 // An image between a caller's (pageable) buffer and the device.  The calls that use this return when the work is done, so a large
-// image goes through the blocking hipMemcpy once `st` has drained: the runtime pipelines it through pinned staging at PCIe
+// image goes through a synchronous copy once `st` has drained: the runtime pipelines it through pinned staging at PCIe
 // rate (256 MiB: 4.7 ms each way on the MI355X box between touched buffers), where hipMemcpyAsync of pageable memory takes
 // 16-20 ms (tools/host_copy_probe.py, tools/reduce_host_probe.py).  A download into a result buffer whose pages do not exist yet
 // still takes 16-40 ms, the caller's page faults; asking for those pages ahead (MADV_POPULATE_WRITE on helper threads during
 // the GPU work) was measured and is not in: -6 ms per call in a fresh process, +8 ms in a long-running one.
-static hipError_t copy_host_image(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t st)
+// Round 4: the copy is ordered on the call's own stream (hipMemcpyWithStream), never on the legacy null stream -- that one
+// synchronises with every blocking stream of the host application and serialises the calls this API lets run concurrently on
+// one processor (examples/parallel.rs).  An image of 32 MiB or more is cut into kCopyParts row ranges copied by as many host
+// threads, each on a stream of its own from the processor's idle list: the staging copies and -- for a result buffer whose
+// pages do not exist yet -- the page faults of the ranges then proceed side by side (8192^2 download into fresh pages:
+// 26-40 ms as one copy).
+constexpr size_t kCopyParts = 4;
+
+static hipError_t copy_host_image(kmg_processor *p, void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t st)
 {
     if (bytes < ((size_t)1 << 20)) return hipMemcpyAsync(dst, src, bytes, kind, st);
-    const hipError_t e = hipStreamSynchronize(st);
-    return e != hipSuccess ? e : hipMemcpy(dst, src, bytes, kind);
+    hipError_t e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return e;
+    if (bytes < ((size_t)32 << 20)) return hipMemcpyWithStream(dst, src, bytes, kind, st);
+    StreamGuard extra[kCopyParts - 1];
+    hipStream_t streams[kCopyParts] = {st};
+    for (size_t i = 1; i < kCopyParts; ++i) {
+        if ((e = extra[i - 1].acquire(p)) != hipSuccess) return e;
+        streams[i] = extra[i - 1].st;
+    }
+    const size_t part = ((bytes / kCopyParts) + 4095u) & ~(size_t)4095u;
+    hipError_t results[kCopyParts];
+    std::thread workers[kCopyParts - 1];
+    const int device = p->device;
+    auto copy_part = [&](size_t i) {
+        const size_t off = i * part;
+        if (off >= bytes) { results[i] = hipSuccess; return; }
+        const size_t nb = std::min(part, bytes - off);
+        hipError_t r = i ? hipSetDevice(device) : hipSuccess;          // (a fresh thread has no current device)
+        if (r == hipSuccess) r = hipMemcpyWithStream((uint8_t *)dst + off, (const uint8_t *)src + off, nb, kind, streams[i]);
+        results[i] = r;
+    };
+    for (size_t i = 1; i < kCopyParts; ++i) workers[i - 1] = std::thread(copy_part, i);
+    copy_part(0);
+    for (size_t i = 1; i < kCopyParts; ++i) workers[i - 1].join();
+    for (size_t i = 0; i < kCopyParts; ++i)
+        if (results[i] != hipSuccess) return results[i];
+    return hipSuccess;
 }
 
 int upload_image(kmg_processor *p, const uint8_t *rgba, uint32_t w, uint32_t h, hipStream_t st, StreamBuf &buf)
 {
     const size_t bytes = (size_t)w * h * 4;
     HIP_TRY(buf.alloc(p, bytes, st));
-    HIP_TRY(copy_host_image(buf.ptr, rgba, bytes, hipMemcpyHostToDevice, st));   // structures.rs:31-65
+    HIP_TRY(copy_host_image(p, buf.ptr, rgba, bytes, hipMemcpyHostToDevice, st));   // structures.rs:31-65
     return KMG_OK;
 }
 
@@ -1974,7 +2009,7 @@ int apply_and_download(kmg_processor *p, const uint8_t *d_rgba, uint32_t w, uint
     const size_t bytes = (size_t)w * h * 4;
     HIP_TRY(out.alloc(p, bytes, st));
     if ((rc = kmg_dev_apply(p, d_rgba, w, h, 0, c4, k, mode, (uint8_t *)out.ptr, st)) != KMG_OK) return rc;
-    HIP_TRY(copy_host_image(out_rgba, out.ptr, bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(copy_host_image(p, out_rgba, out.ptr, bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return KMG_OK;
 }
@@ -2059,7 +2094,9 @@ extern "C" int kmg_reduce(kmg_processor *p, const uint8_t *rgba, uint32_t w, uin
     StreamGuard sg;
     HIP_TRY(sg.acquire(p));
     StreamBuf img;
+    const auto t0 = std::chrono::steady_clock::now();
     if ((rc = upload_image(p, rgba, w, h, sg.st, img)) != KMG_OK) return rc;
+    const auto t1 = std::chrono::steady_clock::now();
     if (algo == KMG_ALGO_OCTREE) {                                     // lib.rs:133-136
         std::vector<std::array<uint8_t, 4>> colors;
         if ((rc = octree_palette_of(p, (const uint8_t *)img.ptr, w, h, color_count, sg.st, colors)) != KMG_OK) return rc;
@@ -2069,7 +2106,16 @@ extern "C" int kmg_reduce(kmg_processor *p, const uint8_t *rgba, uint32_t w, uin
     }
     std::vector<float> c4(4 * (size_t)color_count);
     if ((rc = extract_palette_kmeans(p, (const uint8_t *)img.ptr, w, h, color_count, sg.st, c4.data())) != KMG_OK) return rc;
-    return apply_and_download(p, (const uint8_t *)img.ptr, w, h, c4.data(), color_count, mode, sg.st, out_rgba);
+    const auto t2 = std::chrono::steady_clock::now();
+    rc = apply_and_download(p, (const uint8_t *)img.ptr, w, h, c4.data(), color_count, mode, sg.st, out_rgba);
+    if (log_debug()) {
+        const auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+            return std::chrono::duration<double, std::milli>(b - a).count();
+        };
+        fprintf(stderr, "[kmeans_hip] reduce %ux%u k=%u: upload %.2f ms, palette %.2f ms, output pass + download %.2f ms\n", w, h,
+                color_count, ms(t0, t1), ms(t1, t2), ms(t2, std::chrono::steady_clock::now()));
+    }
+    return rc;
 }
 
 extern "C" int kmg_palette(kmg_processor *p, const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t color_count,

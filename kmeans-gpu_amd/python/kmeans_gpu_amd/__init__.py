@@ -234,6 +234,14 @@ def _image(image):
     return a
 
 
+def _result(img, out):
+    if out is None:
+        return np.empty_like(img)
+    if out.dtype != np.uint8 or out.shape != img.shape or not out.flags.c_contiguous:
+        raise ValueError("out must be a C-contiguous uint8 array of the image's shape")
+    return out
+
+
 class ImageProcessor:
     """Mirror of `kmeans_color_gpu::ImageProcessor` (core/src/lib.rs:24-165)."""
 
@@ -280,19 +288,21 @@ class ImageProcessor:
         return out[:cnt.value].copy()
 
     # lib.rs:79-114
-    def find(self, image, colors, reduce_mode=ReduceMode.Replace):
+    def find(self, image, colors, reduce_mode=ReduceMode.Replace, out=None):
+        """out: optional (height, width, 4) uint8 array that receives the result (the C ABI writes into the caller's buffer;
+        the reference returns a fresh Vec, which is what out=None does)"""
         img = _image(image)
         h, w = img.shape[:2]
         pal = np.ascontiguousarray(colors, np.uint8).reshape(-1, 4)
-        out = np.empty_like(img)
+        out = _result(img, out)
         _check(lib().kmg_find(self._h, _np_ptr(img), w, h, _np_ptr(pal), pal.shape[0], int(reduce_mode), _np_ptr(out)))
         return out
 
     # lib.rs:116-164
-    def reduce(self, color_count, image, algo=Algorithm.Kmeans, reduce_mode=ReduceMode.Replace):
+    def reduce(self, color_count, image, algo=Algorithm.Kmeans, reduce_mode=ReduceMode.Replace, out=None):
         img = _image(image)
         h, w = img.shape[:2]
-        out = np.empty_like(img)
+        out = _result(img, out)
         _check(lib().kmg_reduce(self._h, _np_ptr(img), w, h, int(color_count), int(algo), int(reduce_mode), _np_ptr(out)))
         return out
 
