@@ -957,7 +957,8 @@ constexpr size_t kLabelLdsPlain = sizeof(uint32_t) * (kCells + 256 + 128);
 constexpr size_t kLabelLdsHot = kLabelLdsPlain + (size_t)kHotMax * kCellColours + sizeof(uint32_t) * 64;
 
 // KNOCK (tools only, results wrong): 1 = gathers from a 64 KiB window of the table, 2 = from LDS instead, 3 = none,
-// 4 = plain non-temporal gathers, 5 = gathers from a table a quarter the size
+// 4 = plain non-temporal gathers, 5 = gathers from a table a quarter the size, 6 = the cheaper colour index of a
+// (cell, r & 7, g & 7, b & 7)-ordered table, 7 = three quarters of the pixel bytes read (round 4 probes, profiles/NOTES.md)
 template <bool HOT, int KNOCK = 0>
 __global__ __launch_bounds__(kLabelBlock) void k_labels_pairs(const uint32_t *__restrict__ rgba, uint64_t n,
                                                               const uint8_t *__restrict__ colour_labels,
@@ -1006,10 +1007,17 @@ __global__ __launch_bounds__(kLabelBlock) void k_labels_pairs(const uint32_t *__
         for (int g = 0; g < 2; ++g) {
             i0[g] = tile * TILE + (uint64_t)g * (kLabelBlock * 4) + (uint64_t)threadIdx.x * 4;
             uint32_t px[4];
-            load4_stream(rgba, i0[g], n, aligned != 0, px);
+            // (KNOCK 7: three quarters of the pixel bytes are read, aligned -- the bandwidth a packed 3-byte stream would save)
+            load4_stream(rgba, KNOCK == 7 ? ((i0[g] * 3u / 4u) & ~3ull) : i0[g], n, aligned != 0, px);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                ci[g * 4 + q] = colour_index(px[q]);
+                if (KNOCK == 6) {        // the index a (cell, r & 7, g & 7, b & 7)-ordered table would take: 11 operations instead of 18
+                    const uint32_t v = px[q];
+                    const uint32_t cell = ((v >> 3) & 31u) << 10 | ((v >> 11) & 31u) << 5 | ((v >> 19) & 31u);
+                    ci[g * 4 + q] = cell << 9 | (v & 7u) << 6 | ((v >> 8) & 7u) << 3 | ((v >> 16) & 7u);
+                } else {
+                    ci[g * 4 + q] = colour_index(px[q]);
+                }
                 xyz[g * 4 + q] = (px[q] & 0x00070707u) | 0x01000000u;   // (r & 7, g & 7, b & 7, 1)
             }
         }
@@ -1031,7 +1039,7 @@ __global__ __launch_bounds__(kLabelBlock) void k_labels_pairs(const uint32_t *__
 #pragma unroll
         for (int p = 0; p < 8; ++p)
             if (fine[p]) {
-                if (KNOCK == 0) lab[p] = (uint32_t)colour_labels[ci[p]];
+                if (KNOCK == 0 || KNOCK == 6 || KNOCK == 7) lab[p] = (uint32_t)colour_labels[ci[p]];
                 else if (KNOCK == 1) lab[p] = (uint32_t)colour_labels[ci[p] & 0xFFFFu];
                 else if (KNOCK == 2) lab[p] = (uint32_t)reinterpret_cast<const uint8_t *>(s_pair)[ci[p] & 0x1FFFFu];
                 else if (KNOCK == 4) lab[p] = (uint32_t)__builtin_nontemporal_load(colour_labels + ci[p]);
@@ -1072,7 +1080,7 @@ hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_la
 #define KMG_LK(K) hipLaunchKernelGGL((k_labels_pairs<false, K>), dim3(grid), dim3(kLabelBlock), kLabelLdsPlain, st, rgba, n, \
                                      (const uint8_t *)colour_labels, pairs, pal, k, labels, aligned, hot)
         if (knock == 1) KMG_LK(1); else if (knock == 2) KMG_LK(2); else if (knock == 3) KMG_LK(3); else if (knock == 4) KMG_LK(4);
-        else if (knock == 5) KMG_LK(5);
+        else if (knock == 5) KMG_LK(5); else if (knock == 6) KMG_LK(6); else if (knock == 7) KMG_LK(7);
 #undef KMG_LK
         else if (hot)
             hipLaunchKernelGGL(k_labels_pairs<true>, dim3(grid), dim3(kLabelBlock), kLabelLdsHot, st, rgba, n,
