@@ -944,6 +944,7 @@ constexpr uint32_t kSmallRepl = 16;
 constexpr int kSmallBlock = 512;
 constexpr uint32_t kSmallWaves = kSmallBlock / 64;
 constexpr uint32_t kSmallCells = kSmallWaves * 8u;               // cells of a workgroup
+constexpr uint32_t kSmallEmit = 0x100u;                           // k_cube_small: stage only, records for k_cube_scan / k_cube_pairs
 constexpr uint32_t kSmallTests = 2048;                           // dominance tests a workgroup lists per round
 
 __device__ __forceinline__ uint32_t group8_or(uint32_t v)
@@ -1051,6 +1052,7 @@ __global__ __launch_bounds__(kSmallBlock) __attribute__((amdgpu_waves_per_eu(4, 
                                                             const Centroid *__restrict__ cent, uint32_t k,
                                                             const float4 *__restrict__ lab_table,
                                                             uint64_t *__restrict__ masks_out,
+                                                            CellWork *__restrict__ cell_work,
                                                             uint8_t *__restrict__ colour_labels,
                                                             uint16_t *__restrict__ sub_table,
                                                             int64_t *__restrict__ sums, uint32_t n_rows, uint32_t flags,
@@ -1100,7 +1102,8 @@ __global__ __launch_bounds__(kSmallBlock) __attribute__((amdgpu_waves_per_eu(4, 
         const uint32_t task = base + wv;
         const uint32_t pos = task + ci * tasks;
         const bool valid = task < tasks && pos < n_work;
-        const uint32_t cell = valid ? (SUMS ? work[1u + pos] : pos) : 0u;
+        // (every cell occupied: the work list is the identity -- one round trip less)
+        const uint32_t cell = valid ? ((SUMS && n_work != kCells) ? work[1u + pos] : pos) : 0u;
         const uint32_t sc = cell * 8u + sub;
         const float4 *cbp = reinterpret_cast<const float4 *>(bounds + cell);
         const float4 cb0 = cbp[0], cb1 = cbp[1], cb2 = cbp[2];
@@ -1218,10 +1221,51 @@ __global__ __launch_bounds__(kSmallBlock) __attribute__((amdgpu_waves_per_eu(4, 
                     uint4 *dst = reinterpret_cast<uint4 *>(colour_labels + (uint64_t)cell * kCellColours + sub * 64u);
                     dst[0] = dst[1] = dst[2] = dst[3] = make_uint4(m4, m4, m4, m4);
                 }
-            } else if (valid) {
+            } else if (valid && !(flags & kSmallEmit)) {
                 uint4 *dst = reinterpret_cast<uint4 *>(s_lbl + slot * kCellColours + sub * 64u);
                 dst[0] = xv; dst[1] = xv; dst[2] = xv; dst[3] = xv;
+            } else if (valid && decided) {                          // (kSmallEmit: the scan and entries are other launches)
+                uint4 *dst = reinterpret_cast<uint4 *>(colour_labels + (uint64_t)cell * kCellColours + sub * 64u);
+                dst[0] = xv; dst[1] = xv; dst[2] = xv; dst[3] = xv;
             }
+        }
+        if (flags & kSmallEmit) {
+            // ---- stage only: the cell's record for k_cube_scan / k_cube_pairs (identity candidate list: position = centroid) ----
+            if (valid) {
+                CellWork *cw = cell_work + cell;
+                const uint32_t scan8 = group8_or(scan ? 1u << sub : 0u);
+                uint32_t lo_w[4], hi_w[4];
+#pragma unroll
+                for (uint32_t r = 0; r < 4u; ++r) {
+                    const uint32_t byte = (mask >> (8u * r)) & 0xFFu;
+                    lo_w[r] = group8_or(sub < 4u ? byte << (8u * sub) : 0u);
+                    hi_w[r] = group8_or(sub >= 4u ? byte << (8u * (sub - 4u)) : 0u);
+                }
+                if (sub < 4u) {
+                    const uint32_t l = sub == 0u ? lo_w[0] : (sub == 1u ? lo_w[1] : (sub == 2u ? lo_w[2] : lo_w[3]));
+                    const uint32_t h = sub == 0u ? hi_w[0] : (sub == 1u ? hi_w[1] : (sub == 2u ? hi_w[2] : hi_w[3]));
+                    cw->br[sub] = ((unsigned long long)h << 32) | l;
+                }
+                const uint32_t p0 = 4u * sub;
+                *reinterpret_cast<uint2 *>(cw->list + p0) = make_uint2(p0 | (p0 + 1u) << 16, (p0 + 2u) | (p0 + 3u) << 16);
+                if (sub == 0u) {
+                    cw->npop = uniform ? 1u : k;
+                    cw->scan_set = uniform ? 0u : (scan8 | 0x100u);
+                    if (!uniform) pair_entries[cell] = kPairPending;
+                }
+            }
+            if (stats) {
+                const unsigned long long scan_b = __ballot(scan);
+                st_single += (uint32_t)__builtin_popcountll(__ballot(valid && sub == 0u && __builtin_popcount(um) == 1));
+                st_multi += (uint32_t)__builtin_popcountll(__ballot(valid && sub == 0u && __builtin_popcount(um) != 1));
+                st_decided += (uint32_t)__builtin_popcountll(__ballot(decided && __builtin_popcount(um) != 1));
+                st_scanned += (uint32_t)__builtin_popcountll(scan_b);
+                st_cands += wave_add_u32(scan ? np : 0u);
+            }
+            __syncthreads();
+            if (threadIdx.x == 3u) s_count[3] = 0u;
+            __syncthreads();
+            continue;
         }
         {
             // the workgroup's lists: undecided sub-cells (thread ids), cells that need an entry (slots)
@@ -1475,14 +1519,31 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
                            (size_t)kSmallCells * kCellColours + sizeof(uint32_t) * kSmallBlock * 2u + sizeof(uint32_t) * kSmallCells +
                            sizeof(uint32_t) * 4u + sizeof(uint16_t) * (kSmallBlock + kSmallCells + kSmallTests) + kSmallBlock;
         if (!n_rows) n_rows = 1u;
+        // KMG_CUBE_SMALL=2: k_cube_small as the stage only, then the scan and entries launches of the general pass
+        static const bool split = getenv("KMG_CUBE_SMALL") && atoi(getenv("KMG_CUBE_SMALL")) == 2;
+        const uint32_t sflags = (flags & ~0x100u) | (split ? kSmallEmit : 0u);
 #define KMG_SMALL(KP, S)                                                                                                    \
         hipLaunchKernelGGL((k_cube_small<KP, S>), dim3(g_small), dim3(kSmallBlock), lds, st, hist, agg, sub_agg, occ_bits,   \
-                           work, bounds, sub_bounds, sub_affine, cent, k, lab_table, masks, (uint8_t *)colour_labels,        \
-                           sub_table,                                                                                         \
-                           sums, n_rows, flags, stats)
+                           work, bounds, sub_bounds, sub_affine, cent, k, lab_table, masks, (CellWork *)cell_work,            \
+                           (uint8_t *)colour_labels, sub_table, sums, n_rows, sflags, stats)
         if (with_sums) { if (kp == 8u) KMG_SMALL(8, true); else if (kp == 16u) KMG_SMALL(16, true); else KMG_SMALL(32, true); }
         else           { if (kp == 8u) KMG_SMALL(8, false); else if (kp == 16u) KMG_SMALL(16, false); else KMG_SMALL(32, false); }
 #undef KMG_SMALL
+        if (split) {
+            static const uint32_t g_scan2 = env_grid("KMG_SCAN_GRID", 2u * kCubeGrid), g_pairs2 = env_grid("KMG_PAIRS_GRID", kCubeGrid);
+            const uint32_t kpad2 = (k + 63u) & ~63u, repl2 = with_sums ? cube_replicas(k) : 1u;
+            const size_t lds_scan2 = sizeof(float4) * kpad2 + (with_sums ? sizeof(unsigned long long) * (4ull * k + 4ull) * repl2 : 0) +
+                                     sizeof(float4) * (kBlock / 64) * kMaxListed + (kBlock / 64) * kCellColours;
+            if (with_sums)
+                hipLaunchKernelGGL((k_cube_scan<uint8_t, true>), dim3(g_scan2), dim3(kBlock), lds_scan2, st, hist, sub_agg, work, cent, k,
+                                   lab_table, masks, (const CellWork *)cell_work, (uint8_t *)colour_labels, sub_table, sums, n_rows, repl2, flags);
+            else
+                hipLaunchKernelGGL((k_cube_scan<uint8_t, false>), dim3(g_scan2), dim3(kBlock), lds_scan2, st, hist, sub_agg, work, cent, k,
+                                   lab_table, masks, (const CellWork *)cell_work, (uint8_t *)colour_labels, sub_table, sums, n_rows, repl2, flags);
+            hipLaunchKernelGGL((k_cube_pairs<uint8_t>), dim3((flags & kCubeNoEntries) ? 1u : g_pairs2), dim3(kBlock), 0, st, work,
+                               with_sums ? 1 : 0, occ_bits, (const uint8_t *)colour_labels, sub_table, flags, sums, k, tl);
+            return hipGetLastError();
+        }
         if (tl.acc_out)
             hipLaunchKernelGGL((k_cube_pairs<uint8_t>), dim3(1), dim3(kBlock), 0, st, work, 1, occ_bits,
                                (const uint8_t *)colour_labels, sub_table, flags | kCubeNoEntries, sums, k, tl);
