@@ -1117,13 +1117,23 @@ static int table_assign(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_
         tail.convergence = s->p->opt.convergence;
         tail.cent = s->d_cent;
         tail.n_converged = s->d_nconv;
+        // (small centroid tables: the cube pass is one launch, and when a label pass follows, its tail rides on that one)
+        const bool tail_on_labels = d_labels != nullptr && s->k <= kCubeSmallMaxK;
         PROF_LAUNCH(s, KMG_K_CUBE, st, launch_cube(t.d_hist, t.d_agg, t.d_sub_agg, t.d_occ, t.d_work_share ? t.d_work_share : t.d_work,
                                                    s->p->d_bounds, s->p->d_sub_bounds,
                                                    s->d_cent, s->k, s->p->d_lab_table, t.d_masks, t.d_cell_work, t.d_colour_labels, t.d_sub,
-                                                   s->d_acc_int, 1u, defer_entries ? kCubeNoEntries : 0u, nullptr, st, &tail,
-                                                   affine_for(s->p, s->k, st)));
-        s->acc_int_dirty = false;
+                                                   s->d_acc_int, 1u, defer_entries ? kCubeNoEntries : 0u, nullptr, st,
+                                                   tail_on_labels ? nullptr : &tail, affine_for(s->p, s->k, st)));
         t.entries_valid = !defer_entries;
+        if (tail_on_labels) {
+            t.tables_valid = true;
+            PROF_LAUNCH(s, KMG_K_LABELS, st, launch_labels((const uint32_t *)d_rgba, n, t.d_colour_labels, t.d_sub, s->k, nullptr, d_labels, st,
+                                                           s->reserve_cus, t.n_hot ? t.d_work + kCells + 1 : nullptr, &tail, s->d_acc_int));
+            s->acc_int_dirty = false;
+            if (update_after) t.tables_valid = false;
+            return KMG_OK;
+        }
+        s->acc_int_dirty = false;
     } else {
         if (update_after) return fail(KMG_ERR_INVALID_ARGUMENT, "table_assign: update_after needs the final sums");
         HIP_TRY(hipMemsetAsync(d_sums, 0, sizeof(int64_t) * 4ull * s->k * rows, st));

@@ -939,7 +939,7 @@ __global__ __launch_bounds__(kBlock) void k_cube_pairs(const uint32_t *__restric
 // Honoured flags: bit 0 (labels of uniform cells too), kCubeNoEntries; knock-outs (tools, results WRONG): 9 no sums in the
 // scan, 10 no colour scan, 14 no entries phase, 15 no dominance test (that one is exact).
 // ------------------------------------------------------------------------------------------
-constexpr uint32_t kSmallMaxK = 32;
+constexpr uint32_t kSmallMaxK = kCubeSmallMaxK;
 constexpr uint32_t kSmallRepl = 16;
 constexpr int kSmallBlock = 512;
 constexpr uint32_t kSmallWaves = kSmallBlock / 64;

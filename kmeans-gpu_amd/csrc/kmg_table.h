@@ -177,6 +177,7 @@ size_t cube_work_bytes();
 // flags bit 16: the pass leaves the cells' pair entries / summaries (what the LABEL pass reads first) to a later
 // launch_cube_entries -- a loop that only needs the sums (kmg_lloyd_run) pays for them once, after its last iteration
 constexpr uint32_t kCubeNoEntries = 0x10000u;
+constexpr uint32_t kCubeSmallMaxK = 32;      // k up to which the cube pass is the one-launch k_cube_small
 hipError_t launch_cube_entries(const uint32_t *work, const uint8_t *occ_bits, const void *colour_labels, uint16_t *sub_table,
                                uint32_t k, hipStream_t st);
 // What the LAST launch of the cube pass does on top (one of its workgroups, once the sums are complete): hand the k x 4
@@ -203,9 +204,12 @@ hipError_t launch_sub_affine(const float4 *lab_table, const CellBounds *sub_boun
 // pal == NULL: labels[i] = label; pal != NULL: labels[i] = pal[label] (RGBA8 output of replace mode).
 // reserve_cus: compute units left without a workgroup of the k <= 256 label pass (kmg_lloyd_reserve_cus)
 // hot: NULL, or the image's hot cells ([n_hot][cells ...], n_hot > 0 known to the host): k <= 256 keeps their labels in LDS
+// tail + tail_sums (k <= 256): the cube pass's CubeTail performed by this launch's last workgroup instead of the cube pass's own
+// (the pass of small centroid tables, k <= kCubeSmallMaxK, is one launch and would need another for it)
 hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_labels,
                          const uint16_t *sub_table, uint32_t k, const uint32_t *pal, uint32_t *labels,
-                         hipStream_t st, uint32_t reserve_cus = 0, const uint32_t *hot = nullptr);
+                         hipStream_t st, uint32_t reserve_cus = 0, const uint32_t *hot = nullptr,
+                         const CubeTail *tail = nullptr, int64_t *tail_sums = nullptr);
 
 // ordered-dither output pass with candidate pruning: masks[(cell * 16 + Bayer index) * words + w] are the
 // centroids that can be the arg-min of Lab(colour) + threshold * (M[Bayer index] / 16 - 0.5) for any

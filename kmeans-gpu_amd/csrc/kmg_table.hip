@@ -965,9 +965,19 @@ __global__ __launch_bounds__(kLabelBlock) void k_labels_pairs(const uint32_t *__
                                                               const uint32_t *__restrict__ pair_table,
                                                               const uint32_t *__restrict__ pal, uint32_t k,
                                                               uint32_t *__restrict__ labels, int aligned,
-                                                              const uint32_t *__restrict__ hot)
+                                                              const uint32_t *__restrict__ hot, int64_t *__restrict__ tail_sums,
+                                                              CubeTail tail)
 {
     extern __shared__ uint32_t s_label_lds[];
+    // The cube pass's tail (kmg_table.h CubeTail) when that pass has no launch left to carry it (k_cube_small): the sums are
+    // final -- the cube pass is a launch of its own before this one -- and nothing in this pass reads them or the centroids.
+    if (tail.acc_out && blockIdx.x == gridDim.x - 1u) {
+        for (uint32_t i = threadIdx.x; i < 4u * k; i += kLabelBlock) tail.acc_out[i] = tail_sums[i];
+        if (tail.do_update) update_centroids(tail_sums, k, tail.convergence, tail.cent, tail.n_converged, s_label_lds, kLabelBlock);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < 4u * k; i += kLabelBlock) tail_sums[i] = 0;      // ready for the next pass
+        __syncthreads();
+    }
     uint32_t *s_pair = s_label_lds, *s_pal = s_label_lds + kCells, *s_dir = s_label_lds + kCells + 256;
     uint8_t *s_hot = reinterpret_cast<uint8_t *>(s_label_lds + kCells + 256 + 128);
     uint32_t *s_hcell = reinterpret_cast<uint32_t *>(s_hot + (size_t)kHotMax * kCellColours);
@@ -1064,8 +1074,10 @@ static uint32_t device_cus()
 }
 
 hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_labels, const uint16_t *sub_table,
-                         uint32_t k, const uint32_t *pal, uint32_t *labels, hipStream_t st, uint32_t reserve_cus, const uint32_t *hot)
+                         uint32_t k, const uint32_t *pal, uint32_t *labels, hipStream_t st, uint32_t reserve_cus, const uint32_t *hot,
+                         const CubeTail *tail, int64_t *tail_sums)
 {
+    const CubeTail tl = (tail && tail_sums && k <= 256) ? *tail : CubeTail();
     if (k <= 256) {
         const uint64_t tiles = (n + kLabelBlock * 8 - 1) / (kLabelBlock * 8);
         static const uint32_t all = device_cus();
@@ -1078,16 +1090,16 @@ hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_la
         const uint32_t *pairs = reinterpret_cast<const uint32_t *>(sub_table + kSubCells + kCells);
         static const int knock = getenv("KMG_LABEL_KNOCK") ? atoi(getenv("KMG_LABEL_KNOCK")) : 0;       // tools only
 #define KMG_LK(K) hipLaunchKernelGGL((k_labels_pairs<false, K>), dim3(grid), dim3(kLabelBlock), kLabelLdsPlain, st, rgba, n, \
-                                     (const uint8_t *)colour_labels, pairs, pal, k, labels, aligned, hot)
+                                     (const uint8_t *)colour_labels, pairs, pal, k, labels, aligned, hot, tail_sums, tl)
         if (knock == 1) KMG_LK(1); else if (knock == 2) KMG_LK(2); else if (knock == 3) KMG_LK(3); else if (knock == 4) KMG_LK(4);
         else if (knock == 5) KMG_LK(5); else if (knock == 6) KMG_LK(6); else if (knock == 7) KMG_LK(7);
 #undef KMG_LK
         else if (hot)
             hipLaunchKernelGGL(k_labels_pairs<true>, dim3(grid), dim3(kLabelBlock), kLabelLdsHot, st, rgba, n,
-                               (const uint8_t *)colour_labels, pairs, pal, k, labels, aligned, hot);
+                               (const uint8_t *)colour_labels, pairs, pal, k, labels, aligned, hot, tail_sums, tl);
         else
             hipLaunchKernelGGL(k_labels_pairs<false>, dim3(grid), dim3(kLabelBlock), kLabelLdsPlain, st, rgba, n,
-                               (const uint8_t *)colour_labels, pairs, pal, k, labels, aligned, hot);
+                               (const uint8_t *)colour_labels, pairs, pal, k, labels, aligned, hot, tail_sums, tl);
         return hipGetLastError();
     }
     const uint64_t tiles = (n + kLabelBlock * 8 - 1) / (kLabelBlock * 8);
