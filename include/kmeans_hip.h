@@ -73,6 +73,12 @@ KMG_API void kmg_default_options(kmg_options *opt);
 KMG_API int kmg_processor_create(kmg_processor **out);
 KMG_API int kmg_processor_create_ex(const kmg_options *opt, kmg_processor **out);
 KMG_API void kmg_processor_destroy(kmg_processor *p);
+/* Page-locked host memory for images that cross the boundary often (a frame loop): a result buffer from kmg_host_alloc has
+ * its pages resident and is copied to by DMA directly -- kmg_reduce of 8192 x 8192 into a fresh pageable buffer spends 30-50 ms
+ * in the caller's page faults, 10 ms into one of these.  Plain memory otherwise; release with kmg_host_free.  (No counterpart
+ * in the reference, whose results are fresh Vecs: structures.rs:441-470.)                                                    */
+KMG_API int kmg_host_alloc(size_t bytes, void **out);
+KMG_API void kmg_host_free(void *ptr);
 /* Test support: out[0] = device blocks the processor has allocated with hipMalloc so far, out[1] = blocks it has handed out
  * again (colour tables, workspaces and output-pass scratch of finished objects are kept and reused).                 */
 KMG_API int kmg_debug_block_counts(kmg_processor *p, uint64_t out[2]);

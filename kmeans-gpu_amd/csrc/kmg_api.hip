@@ -322,6 +322,19 @@ extern "C" int kmg_processor_create_ex(const kmg_options *opt, kmg_processor **o
     return KMG_OK;
 }
 
+extern "C" int kmg_host_alloc(size_t bytes, void **out)
+{
+    if (!out || bytes == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad host_alloc arguments");
+    *out = nullptr;
+    HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return KMG_OK;
+}
+
+extern "C" void kmg_host_free(void *ptr)
+{
+    if (ptr) (void)hipHostFree(ptr);
+}
+
 extern "C" int kmg_debug_block_counts(kmg_processor *p, uint64_t out[2])
 {
     if (!p || !out) return fail(KMG_ERR_INVALID_ARGUMENT, "bad block_counts arguments");

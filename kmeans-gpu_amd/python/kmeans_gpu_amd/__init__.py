@@ -71,7 +71,7 @@ _lib = None
 
 # every symbol include/kmeans_hip.h declares
 SYMBOLS = [
-    "kmg_last_error", "kmg_version", "kmg_default_options", "kmg_processor_create",
+    "kmg_last_error", "kmg_version", "kmg_host_alloc", "kmg_host_free", "kmg_default_options", "kmg_processor_create",
     "kmg_processor_create_ex", "kmg_processor_destroy", "kmg_palette", "kmg_find", "kmg_reduce",
     "kmg_palette_to_centroids", "kmg_centroids_to_palette", "kmg_octree_palette", "kmg_dev_rgb_to_lab",
     "kmg_resized_dims",
@@ -108,6 +108,9 @@ def lib():
     vp, u8p, u32p, f32p, i64p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
     L.kmg_last_error.restype = C.c_char_p
     L.kmg_version.restype = C.c_char_p
+    L.kmg_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    L.kmg_host_free.argtypes = [vp]
+    L.kmg_host_free.restype = None
     L.kmg_default_options.argtypes = [C.POINTER(Options)]
     L.kmg_default_options.restype = None
     L.kmg_processor_create.argtypes = [C.POINTER(vp)]
@@ -234,9 +237,47 @@ def _image(image):
     return a
 
 
+class _PinnedPool:
+    """Result arrays of large images in page-locked host memory (kmg_host_alloc): a fresh pageable array of 256 MiB costs the
+    call tens of milliseconds of page faults, a pinned block is copied to by DMA.  A block returns to the pool when the array
+    that wraps it is garbage collected and serves the next result of the same size; at most `limit` bytes are kept."""
+
+    def __init__(self, limit=1 << 30, threshold=16 << 20):
+        self.free, self.kept, self.limit, self.threshold = {}, 0, limit, threshold
+
+    def _give_back(self, ptr, nbytes):
+        if self.kept + nbytes <= self.limit:
+            self.free.setdefault(nbytes, []).append(ptr)
+            self.kept += nbytes
+        else:
+            lib().kmg_host_free(C.c_void_p(ptr))
+
+    def array(self, shape):
+        import weakref
+        nbytes = int(np.prod(shape))
+        if nbytes < self.threshold or os.environ.get("KMG_PINNED_RESULTS", "1") == "0":
+            return None
+        blocks = self.free.get(nbytes)
+        if blocks:
+            ptr = blocks.pop()
+            self.kept -= nbytes
+        else:
+            p = C.c_void_p()
+            if lib().kmg_host_alloc(nbytes, C.byref(p)) != 0 or not p.value:
+                return None
+            ptr = p.value
+        buf = (C.c_uint8 * nbytes).from_address(ptr)
+        weakref.finalize(buf, self._give_back, ptr, nbytes)      # (the numpy array keeps `buf` alive as its base)
+        return np.frombuffer(buf, dtype=np.uint8).reshape(shape)
+
+
+_pinned = _PinnedPool()
+
+
 def _result(img, out):
     if out is None:
-        return np.empty_like(img)
+        pinned = _pinned.array(img.shape)
+        return pinned if pinned is not None else np.empty_like(img)
     if out.dtype != np.uint8 or out.shape != img.shape or not out.flags.c_contiguous:
         raise ValueError("out must be a C-contiguous uint8 array of the image's shape")
     return out

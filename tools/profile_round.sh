@@ -4,6 +4,8 @@
 #   gpurun_out/<tag>_kernel_stats.csv       rocprofv3 --kernel-trace --stats of bench.py --no-cpu-baseline --no-extras
 #   gpurun_out/<tag>_pmc_fetch_write.csv    two separate passes: --pmc FETCH_SIZE / --pmc WRITE_SIZE (rows of our kernels)
 #   gpurun_out/<tag>_pmc_units.txt          TA / TCP / TCC / LDS / SQ counter groups, one pass each (tools/pmc_labels.sh)
+#   gpurun_out/<tag>_cfg2_bench.json, _cfg2_kernel_stats.csv, _cfg2_pmc.txt   BASELINE config 2 (4096^2, k = 16): bench.py --only cfg2,
+#                                           rocprofv3 --kernel-trace --stats and the counter groups of the same loop (tools/pmc_cfg2.sh)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-rXX}
 OUT=$ROOT/gpurun_out
@@ -28,3 +30,8 @@ with open(f"{out}/{tag}_pmc_fetch_write.csv", "w", newline="") as f:
 PY
 cd $ROOT && bash tools/pmc_labels.sh ${TAG}_pmc > $OUT/${TAG}_pmc.log 2>&1
 cp $OUT/${TAG}_pmc/summary.txt $OUT/${TAG}_pmc_units.txt
+cd $ROOT && bash tools/run_cfg2_profile.sh ${TAG}_cfg2run > $OUT/${TAG}_cfg2.log 2>&1
+cp $OUT/${TAG}_cfg2run/cfg2_bench.json $OUT/${TAG}_cfg2_bench.json
+cp $OUT/${TAG}_cfg2run/cfg2_kernel_stats.csv $OUT/${TAG}_cfg2_kernel_stats.csv
+bash tools/pmc_cfg2.sh ${TAG}_cfg2pmc >> $OUT/${TAG}_cfg2.log 2>&1
+cp $OUT/${TAG}_cfg2pmc/summary.txt $OUT/${TAG}_cfg2_pmc.txt

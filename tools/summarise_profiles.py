@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 for name in ("bench.json", "kernel_stats.csv", "pmc_fetch_write.csv", "pmc_units.txt", "init.txt", "table_stats.txt",
              "dither_knock.txt", "dither_stats.txt", "lab_rate.txt", "apply_kernel_stats.csv", "apply_pmc.txt", "apply_host.txt",
-             "strong_cells_per_rank.json"):
+             "strong_cells_per_rank.json", "cfg2_bench.json", "cfg2_kernel_stats.csv", "cfg2_pmc.txt"):
     src = os.path.join(G, f"{tag}_{name}")
     if os.path.exists(src):
         shutil.copy(src, os.path.join(P, f"{tag}_{name}"))
@@ -40,6 +40,43 @@ if cube:
 src = f"profiles/{tag}_pmc_fetch_write.csv via profiles/traffic.json (separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of tools/profile_round.sh, not the run that quotes them)"
 t["source"] = {"k_labels": src, "k_cube": src}
 t["rounds"][tag] = {"kernels": kernels, "note": note}
+
+
+def unit_counters(path):
+    """{kernel base name: {counter: mean per launch}} of a tools/pmc_*.sh summary"""
+    res, cur = {}, None
+    if not os.path.exists(path):
+        return res
+    for line in open(path):
+        if not line.startswith(" "):
+            cur = line.strip().replace("void ", "").replace("kmg::", "").split("<")[0]
+            res.setdefault(cur, {})
+        elif cur and "mean/launch" in line:
+            name, rest = line.split("mean/launch")
+            res[cur][name.strip()] = float(rest.split()[0])
+    return res
+
+
+# vector wave-instructions per launch (SQ_INSTS_VALU) of the kernels the bench line quotes: the VALU roof of kernels_roofline
+valu = t.setdefault("valu_wave_instructions", {})
+units = unit_counters(os.path.join(P, f"{tag}_pmc_units.txt"))
+if "k_labels_pairs" in units and "SQ_INSTS_VALU" in units["k_labels_pairs"]:
+    valu["k_labels"] = units["k_labels_pairs"]["SQ_INSTS_VALU"]
+cube_v = [v["SQ_INSTS_VALU"] for k, v in units.items() if k.startswith("k_cube") and "SQ_INSTS_VALU" in v]
+if cube_v:
+    valu["k_cube"] = sum(cube_v)
+app = unit_counters(os.path.join(P, f"{tag}_apply_pmc.txt"))
+if "k_dither_lists" in app and "SQ_INSTS_VALU" in app["k_dither_lists"]:
+    valu["find_dither_k64"] = app["k_dither_lists"]["SQ_INSTS_VALU"] + app.get("k_lab_candidates", {}).get("SQ_INSTS_VALU", 0.0)
+c2 = unit_counters(os.path.join(P, f"{tag}_cfg2_pmc.txt"))
+if c2:
+    step = [v for k, v in c2.items() if k.startswith(("k_cube", "k_labels"))]
+    if all("SQ_INSTS_VALU" in v for v in step) and step:
+        valu["cfg2_step"] = sum(v["SQ_INSTS_VALU"] for v in step)
+    if all("FETCH_SIZE" in v and "WRITE_SIZE" in v for v in step) and step:
+        # (pixel stream at 2 x FETCH_SIZE as for the headline; the small tables at face value would be lower: an upper figure)
+        t["bytes_per_launch"]["cfg2_step"] = sum(2 * v["FETCH_SIZE"] * 1024 + v["WRITE_SIZE"] * 1024 for v in step)
+t["valu_source"] = f"profiles/{tag}_pmc_units.txt, _apply_pmc.txt, _cfg2_pmc.txt (SQ_INSTS_VALU, mean per launch, separate rocprofv3 --pmc passes)"
 json.dump(t, open(os.path.join(P, "traffic.json"), "w"), indent=1)
 d = json.load(open(os.path.join(P, f"{tag}_bench.json")))
 print(d["value"], d["ms_per_step"], d["roofline"])
