@@ -51,3 +51,21 @@ def test_one_rank_rccl_group_runs_every_collective_of_the_sharded_loops(torch_cu
 @pytest.mark.parametrize("world", [2, 3])
 def test_ranks_sharing_one_gpu_over_gloo_equal_the_unsharded_loop(torch_cuda, world):
     _run("gloo", world)
+
+
+def test_bench_multi_gpu_path_rehearsed_on_one_gpu(torch_cuda):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one rank per process) with --rehearse: both ranks on
+    cuda:0, collectives through gloo.  The N > 1 code path of the benchmark -- strong scaling of the BASELINE image, cell-sharded
+    cube pass, weak-scaling extra -- must produce its JSON line (the timings of a rehearsal mean nothing)."""
+    import json
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("KMG_STRATEGY", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--rehearse"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["metric"].endswith("(8192x8192, k=256)")
+    assert "cube pass sharded by cells" in line["config"]["sharding"] and line["value"] > 0
+    assert line["extra"]["weak_scaling_value"] > 0
