@@ -64,6 +64,7 @@ typedef struct kmg_options {
 
 typedef struct kmg_processor kmg_processor;
 typedef struct kmg_lloyd kmg_lloyd;
+typedef struct kmg_apply_plan kmg_apply_plan;
 
 KMG_API const char *kmg_last_error(void);
 KMG_API const char *kmg_version(void);
@@ -312,6 +313,20 @@ KMG_API int kmg_lloyd_run(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n_pixels
 KMG_API int kmg_dev_apply(kmg_processor *p, const uint8_t *d_rgba, uint32_t width, uint32_t rows,
                           uint32_t row0, const float *centroids4, uint32_t k, int mode,
                           uint8_t *d_out_rgba, void *stream);
+
+/* The same output pass as a PLAN, for callers that process an image in row bands (a multi-GPU runtime, an image streamed
+ * through a pinned double buffer): _create builds everything that depends on the centroid table only -- the device copies of
+ * centroids and palette, the dither threshold, the candidate lists / masks or the label tables of the colour cube -- once,
+ * asynchronously on `stream`; n_pixels_hint = the pixels the plan is made for (it selects the route exactly as kmg_dev_apply
+ * does for a band of that size).  _run launches the per-pixel kernel of one band on any stream (it waits for the tables on the
+ * device, never on the host) and returns at once; any number of bands, any order.  _destroy returns the plan's scratch block:
+ * the caller has synchronised every stream that ran the plan, or passes synchronise != 0.  kmg_dev_apply = create + run +
+ * stream synchronisation + destroy.  (The reference runs the pass on whole textures only: operations.rs:99-155.)              */
+KMG_API int kmg_apply_plan_create(kmg_processor *p, const float *centroids4, uint32_t k, int mode, uint64_t n_pixels_hint,
+                                  void *stream, kmg_apply_plan **out);
+KMG_API int kmg_apply_plan_run(kmg_apply_plan *plan, const uint8_t *d_rgba, uint32_t width, uint32_t rows, uint32_t row0,
+                               uint8_t *d_out_rgba, void *stream);
+KMG_API void kmg_apply_plan_destroy(kmg_apply_plan *plan, int synchronise);
 
 /* mix_colors.wgsl:53-67: the dither threshold of a centroid table (host helper).             */
 KMG_API int kmg_dither_threshold(const float *centroids4, uint32_t k, float *threshold);

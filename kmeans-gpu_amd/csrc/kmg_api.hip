@@ -1792,17 +1792,41 @@ extern "C" int kmg_lloyd_run(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, ui
     return KMG_OK;
 }
 
-extern "C" int kmg_dev_apply(kmg_processor *p, const uint8_t *d_rgba, uint32_t w, uint32_t rows, uint32_t row0,
-                             const float *c4, uint32_t k, int mode, uint8_t *d_out, void *stream)
+// ---- the output pass as a PLAN: everything that depends on the centroid table only -- the device copy of centroids and palette,
+// the threshold, the candidate lists / masks or the label tables of the colour cube -- is built once (asynchronously on the
+// creating call's stream); kmg_apply_plan_run then launches the per-pixel kernel for any band of rows on any stream, without a
+// host synchronisation, so a caller that streams an image in bands (or runs bands on several streams) overlaps copies and
+// kernels.  kmg_dev_apply = create + run + synchronise + destroy.
+struct kmg_apply_plan {
+    kmg_processor *p = nullptr;
+    uint32_t k = 0;
+    int mode = 0;
+    bool dither = false;
+    float thr = 0.0f;
+    enum Route { kScan, kMeldScan, kMeldMasks, kMeldLists, kReplaceTable, kDitherLists, kDitherMasks } route = kScan;
+    ArenaGuard arena;
+    std::vector<uint8_t> staged;        // host copy of the tables: lives as long as the asynchronous upload may
+    Centroid *d_cent = nullptr;
+    uint32_t *d_pal = nullptr;
+    void *aux = nullptr;                // candidate lists / masks, or the per-colour labels (kReplaceTable)
+    uint16_t *sub = nullptr;            // kReplaceTable: the label pass's first-level tables
+    hipEvent_t ready = nullptr;         // the tables are built (recorded on the creating stream)
+    hipStream_t built_on = nullptr;
+};
+
+extern "C" int kmg_apply_plan_create(kmg_processor *p, const float *c4, uint32_t k, int mode, uint64_t n_pixels_hint, void *stream,
+                                     kmg_apply_plan **out)
 {
-    if (!p || !d_rgba || !d_out || !c4 || !w || !rows || k == 0)
-        return fail(KMG_ERR_INVALID_ARGUMENT, "bad apply arguments");
+    if (!p || !c4 || !out || k == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad apply_plan arguments");
+    *out = nullptr;
     if (k > KMG_MAX_K) return fail(KMG_ERR_UNSUPPORTED, "k = %u exceeds KMG_MAX_K = %u", k, KMG_MAX_K);
     if (mode != KMG_MODE_REPLACE && mode != KMG_MODE_DITHER && mode != KMG_MODE_MELD)
         return fail(KMG_ERR_INVALID_ARGUMENT, "unknown mode %d", mode);
-    // the output kernels keep the pixel index (and from it the Bayer coordinates) in 32 bits
-    if ((uint64_t)w * rows > 0xFFFFFFFFull) return fail(KMG_ERR_UNSUPPORTED, "band has more than 2^32-1 pixels");
     HIP_TRY(hipSetDevice(p->device));
+    kmg_apply_plan *pl = new (std::nothrow) kmg_apply_plan();
+    if (!pl) return fail(KMG_ERR_OUT_OF_MEMORY, "host allocation failed");
+    struct Undo { kmg_apply_plan *pl; ~Undo() { if (pl) { if (pl->ready) (void)hipEventDestroy(pl->ready); (void)hipStreamSynchronize(pl->built_on); delete pl; } } } undo{pl};
+    pl->p = p; pl->k = k; pl->mode = mode; pl->built_on = S(stream);
 
     // per-centroid work on the host: (L,a,b,C) table, RGBA8 palette (lab_to_rgb.wgsl), threshold
     std::vector<Centroid> hc(k);
@@ -1820,11 +1844,12 @@ extern "C" int kmg_dev_apply(kmg_processor *p, const uint8_t *d_rgba, uint32_t w
         shader_lab_to_rgba8(sentinel, px);
         memcpy(&pal[k], px, 4);
     }
-    bool dither = (mode == KMG_MODE_DITHER) && k > 1;                 // mix_colors.wgsl:104-108
-    float thr = dither ? dither_threshold(c4, k) : 0.0f;
+    const bool dither = (mode == KMG_MODE_DITHER) && k > 1;           // mix_colors.wgsl:104-108
+    const float thr = dither ? dither_threshold(c4, k) : 0.0f;
+    pl->dither = dither; pl->thr = thr;
 
-    // which route, and how much scratch it needs: one block per call (ArenaGuard)
-    const uint64_t n_px = (uint64_t)w * rows;
+    // which route (by the number of pixels the plan is made for), and how much scratch it needs: one block per plan
+    const uint64_t n_px = n_pixels_hint;
     const bool meld_masks_pay = mode == KMG_MODE_MELD && k >= 2 && meld_pruning_pays(n_px, k);
     const bool replace_table = mode != KMG_MODE_MELD && !dither && replace_table_pays(n_px, k);
     const bool dither_pruned = mode != KMG_MODE_MELD && dither && dither_pruning_pays(n_px, k);
@@ -1839,39 +1864,36 @@ extern "C" int kmg_dev_apply(kmg_processor *p, const uint8_t *d_rgba, uint32_t w
     if (dither_lists || meld_lists) need += ArenaGuard::padded(lab_list_bytes(k));
     if (replace_table) need += ArenaGuard::padded(labels_bytes) + ArenaGuard::padded(sub_bytes) + ArenaGuard::padded(cube_masks_bytes(k)) +
                                ArenaGuard::padded(cube_work_bytes());
-    ArenaGuard arena;
+    ArenaGuard &arena = pl->arena;
     hipError_t e = arena.acquire(p, need);
     // centroid table and palette travel in one block (one copy)
-    std::vector<uint8_t> staged(tables_bytes);
-    memcpy(staged.data(), hc.data(), sizeof(Centroid) * k);
-    memcpy(staged.data() + sizeof(Centroid) * k, pal.data(), sizeof(uint32_t) * (k + 1));
+    pl->staged.resize(tables_bytes);
+    memcpy(pl->staged.data(), hc.data(), sizeof(Centroid) * k);
+    memcpy(pl->staged.data() + sizeof(Centroid) * k, pal.data(), sizeof(uint32_t) * (k + 1));
     Centroid *d_cent = nullptr;
-    uint32_t *d_pal = nullptr;
     if (e == hipSuccess) {
         d_cent = (Centroid *)arena.take(tables_bytes);
-        d_pal = (uint32_t *)((uint8_t *)d_cent + sizeof(Centroid) * k);
-        e = hipMemcpyAsync(d_cent, staged.data(), staged.size(), hipMemcpyHostToDevice, S(stream));
+        pl->d_cent = d_cent;
+        pl->d_pal = (uint32_t *)((uint8_t *)d_cent + sizeof(Centroid) * k);
+        e = hipMemcpyAsync(d_cent, pl->staged.data(), pl->staged.size(), hipMemcpyHostToDevice, S(stream));
     }
     int rc = KMG_OK;
     if (e != hipSuccess) {
         // fall through to the error report
     } else if (mode == KMG_MODE_MELD) {
-        const uint64_t *meld_masks = nullptr;
+        pl->route = kmg_apply_plan::kMeldScan;
         if (meld_lists) {
             uint8_t *lst = (uint8_t *)arena.take(lab_list_bytes(k));
             e = launch_lab_candidates(d_cent, k, 0.0f, true, lst, S(stream));
-            if (e == hipSuccess)
-                e = launch_meld_lists((const uint32_t *)d_rgba, n_px, d_cent, k, p->d_lut, lst, (uint32_t *)d_out, S(stream));
+            pl->aux = lst; pl->route = kmg_apply_plan::kMeldLists;
         } else if (meld_masks_pay) {
             // large image: per colour cell, the centroids that can be one of a pixel's two closest
             if ((rc = ensure_bounds(p, S(stream))) == KMG_OK) {
                 uint64_t *m = (uint64_t *)arena.take(masks_bytes);
                 e = launch_meld_candidates(p->d_bounds, d_cent, k, m, S(stream));
-                meld_masks = m;
+                pl->aux = m; pl->route = kmg_apply_plan::kMeldMasks;
             }
         }
-        if (rc == KMG_OK && e == hipSuccess && !meld_lists)
-            e = launch_meld((const uint32_t *)d_rgba, n_px, d_cent, k, p->d_lut, meld_masks, (uint32_t *)d_out, S(stream));
     } else if (replace_table) {
         // replace mode on a large image: the label of a pixel depends on its colour only, so label the
         // colour cube once (candidate masks + cube pass without sums) and emit pal[label] through the
@@ -1883,32 +1905,93 @@ extern "C" int kmg_dev_apply(kmg_processor *p, const uint8_t *d_rgba, uint32_t w
             void *cwork = arena.take(cube_work_bytes());
             e = launch_cube(nullptr, nullptr, nullptr, nullptr, nullptr, p->d_bounds, p->d_sub_bounds, d_cent, k, p->d_lab_table,
                             m, cwork, colour_labels, sub, nullptr, 0, 0u, nullptr, S(stream), nullptr, affine_for(p, k, S(stream)));
-            if (e == hipSuccess)
-                e = launch_labels((const uint32_t *)d_rgba, n_px, colour_labels, sub, k, d_pal, (uint32_t *)d_out, S(stream));
+            pl->aux = colour_labels; pl->sub = sub; pl->route = kmg_apply_plan::kReplaceTable;
         }
     } else if (dither_pruned) {
-        // dither on a large image: candidate masks per (colour cell, Bayer index), then a scan of the
-        // pixel's candidates only
+        // dither on a large image: candidate lists per cell of a grid over Lab (mask words per (colour cell, Bayer index)
+        // above k = 512), then a scan of the pixel's candidates only
         if (dither_lists) {
             uint8_t *lst = (uint8_t *)arena.take(lab_list_bytes(k));
             e = launch_lab_candidates(d_cent, k, thr, false, lst, S(stream));
-            if (e == hipSuccess)
-                e = launch_dither_lists((const uint32_t *)d_rgba, w, rows, row0, d_cent, k, p->d_lut, d_pal, thr, lst,
-                                        (uint32_t *)d_out, S(stream));
+            pl->aux = lst; pl->route = kmg_apply_plan::kDitherLists;
         } else if ((rc = ensure_bounds(p, S(stream))) == KMG_OK) {
             uint64_t *m = (uint64_t *)arena.take(masks_bytes);
             e = launch_offset_candidates(p->d_bounds, d_cent, k, thr, m, S(stream));
-            if (e == hipSuccess)
-                e = launch_dither_pruned((const uint32_t *)d_rgba, w, rows, row0, d_cent, k, p->d_lut, d_pal, thr, m,
-                                         (uint32_t *)d_out, S(stream));
+            pl->aux = m; pl->route = kmg_apply_plan::kDitherMasks;
         }
-    } else {
-        e = launch_apply((const uint32_t *)d_rgba, w, rows, row0, d_cent, k, p->d_lut, d_pal, dither, thr,
-                         (uint32_t *)d_out, S(stream));
     }
-    const hipError_t e2 = hipStreamSynchronize(S(stream));
     if (rc != KMG_OK) return rc;
-    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? KMG_ERR_OUT_OF_MEMORY : KMG_ERR_HIP, "apply failed: %s", hipGetErrorString(e));
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&pl->ready, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(pl->ready, S(stream));
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? KMG_ERR_OUT_OF_MEMORY : KMG_ERR_HIP, "apply plan failed: %s", hipGetErrorString(e));
+    undo.pl = nullptr;
+    *out = pl;
+    return KMG_OK;
+}
+
+extern "C" int kmg_apply_plan_run(kmg_apply_plan *pl, const uint8_t *d_rgba, uint32_t w, uint32_t rows, uint32_t row0, uint8_t *d_out,
+                                  void *stream)
+{
+    if (!pl || !d_rgba || !d_out || !w || !rows) return fail(KMG_ERR_INVALID_ARGUMENT, "bad apply_plan_run arguments");
+    // the output kernels keep the pixel index (and from it the Bayer coordinates) in 32 bits
+    if ((uint64_t)w * rows > 0xFFFFFFFFull) return fail(KMG_ERR_UNSUPPORTED, "band has more than 2^32-1 pixels");
+    kmg_processor *p = pl->p;
+    HIP_TRY(hipSetDevice(p->device));
+    if (S(stream) != pl->built_on) HIP_TRY(hipStreamWaitEvent(S(stream), pl->ready, 0));      // (another stream: after the tables)
+    const uint64_t n_px = (uint64_t)w * rows;
+    const uint32_t k = pl->k;
+    hipError_t e = hipSuccess;
+    switch (pl->route) {
+    case kmg_apply_plan::kMeldLists:
+        e = launch_meld_lists((const uint32_t *)d_rgba, n_px, pl->d_cent, k, p->d_lut, (const uint8_t *)pl->aux, (uint32_t *)d_out, S(stream));
+        break;
+    case kmg_apply_plan::kMeldMasks:
+    case kmg_apply_plan::kMeldScan:
+        e = launch_meld((const uint32_t *)d_rgba, n_px, pl->d_cent, k, p->d_lut, (const uint64_t *)pl->aux, (uint32_t *)d_out, S(stream));
+        break;
+    case kmg_apply_plan::kReplaceTable:
+        e = launch_labels((const uint32_t *)d_rgba, n_px, pl->aux, pl->sub, k, pl->d_pal, (uint32_t *)d_out, S(stream));
+        break;
+    case kmg_apply_plan::kDitherLists:
+        e = launch_dither_lists((const uint32_t *)d_rgba, w, rows, row0, pl->d_cent, k, p->d_lut, pl->d_pal, pl->thr, (const uint8_t *)pl->aux,
+                                (uint32_t *)d_out, S(stream));
+        break;
+    case kmg_apply_plan::kDitherMasks:
+        e = launch_dither_pruned((const uint32_t *)d_rgba, w, rows, row0, pl->d_cent, k, p->d_lut, pl->d_pal, pl->thr, (const uint64_t *)pl->aux,
+                                 (uint32_t *)d_out, S(stream));
+        break;
+    default:
+        e = launch_apply((const uint32_t *)d_rgba, w, rows, row0, pl->d_cent, k, p->d_lut, pl->d_pal, pl->dither, pl->thr, (uint32_t *)d_out,
+                         S(stream));
+    }
+    if (e != hipSuccess) return fail(KMG_ERR_HIP, "apply failed: %s", hipGetErrorString(e));
+    return KMG_OK;
+}
+
+// The plan's scratch block goes back to the processor: every stream that ran the plan must have been synchronised by the caller,
+// or `synchronise` != 0 makes this call wait for the whole device first.
+extern "C" void kmg_apply_plan_destroy(kmg_apply_plan *pl, int synchronise)
+{
+    if (!pl) return;
+    (void)hipSetDevice(pl->p->device);
+    if (synchronise) (void)hipDeviceSynchronize();
+    if (pl->ready) (void)hipEventDestroy(pl->ready);
+    delete pl;                                                        // (~ArenaGuard returns the block)
+}
+
+extern "C" int kmg_dev_apply(kmg_processor *p, const uint8_t *d_rgba, uint32_t w, uint32_t rows, uint32_t row0,
+                             const float *c4, uint32_t k, int mode, uint8_t *d_out, void *stream)
+{
+    if (!p || !d_rgba || !d_out || !c4 || !w || !rows || k == 0)
+        return fail(KMG_ERR_INVALID_ARGUMENT, "bad apply arguments");
+    if ((uint64_t)w * rows > 0xFFFFFFFFull) return fail(KMG_ERR_UNSUPPORTED, "band has more than 2^32-1 pixels");
+    kmg_apply_plan *pl = nullptr;
+    int rc = kmg_apply_plan_create(p, c4, k, mode, (uint64_t)w * rows, stream, &pl);
+    if (rc != KMG_OK) return rc;
+    rc = kmg_apply_plan_run(pl, d_rgba, w, rows, row0, d_out, stream);
+    const hipError_t e2 = hipStreamSynchronize(S(stream));            // the call returns when the band is written; the block is idle again
+    kmg_apply_plan_destroy(pl, 0);
+    if (rc != KMG_OK) return rc;
     if (e2 != hipSuccess) return fail(KMG_ERR_HIP, "apply failed: %s", hipGetErrorString(e2));
     return KMG_OK;
 }

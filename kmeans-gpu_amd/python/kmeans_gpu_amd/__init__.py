@@ -21,7 +21,7 @@ import os
 
 import numpy as np
 
-__all__ = ["ImageProcessor", "Algorithm", "ReduceMode", "Lloyd", "KmgError", "lib", "library_path",
+__all__ = ["ImageProcessor", "Algorithm", "ReduceMode", "Lloyd", "ApplyPlan", "KmgError", "lib", "library_path",
            "resized_dims", "palette_to_centroids", "centroids_to_palette", "dither_threshold",
            "default_options", "Options"]
 
@@ -82,7 +82,7 @@ SYMBOLS = [
     "kmg_lloyd_unbind_image", "kmg_lloyd_prepare", "kmg_debug_check_table", "kmg_debug_table_stats", "kmg_debug_check_pairs", "kmg_debug_check_dither_masks", "kmg_debug_check_meld_masks", "kmg_kernel_name",
     "kmg_lloyd_profile", "kmg_lloyd_profile_read",
     "kmg_lloyd_update", "kmg_lloyd_assign_update", "kmg_lloyd_set_cell_share", "kmg_lloyd_labels_from_tables",
-    "kmg_lloyd_table_buffers", "kmg_lloyd_histogram_buffer", "kmg_lloyd_rebuild_from_histogram", "kmg_debug_block_counts", "kmg_debug_idle_blocks", "kmg_debug_encode_table_check", "kmg_debug_division_check", "kmg_lloyd_converged_count", "kmg_lloyd_iterate", "kmg_lloyd_flush", "kmg_lloyd_run", "kmg_dev_apply",
+    "kmg_lloyd_table_buffers", "kmg_lloyd_histogram_buffer", "kmg_lloyd_rebuild_from_histogram", "kmg_debug_block_counts", "kmg_debug_idle_blocks", "kmg_debug_encode_table_check", "kmg_debug_division_check", "kmg_lloyd_converged_count", "kmg_lloyd_iterate", "kmg_lloyd_flush", "kmg_lloyd_run", "kmg_dev_apply", "kmg_apply_plan_create", "kmg_apply_plan_run", "kmg_apply_plan_destroy",
     "kmg_dither_threshold",
 ]
 
@@ -171,6 +171,10 @@ def lib():
     L.kmg_lloyd_flush.argtypes = [vp, vp]
     L.kmg_lloyd_run.argtypes = [vp, u8p, C.c_uint64, u32p, C.POINTER(C.c_uint32), vp]
     L.kmg_dev_apply.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, C.c_uint32, f32p, C.c_uint32, C.c_int, u8p, vp]
+    L.kmg_apply_plan_create.argtypes = [vp, f32p, C.c_uint32, C.c_int, C.c_uint64, vp, C.POINTER(vp)]
+    L.kmg_apply_plan_run.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, C.c_uint32, u8p, vp]
+    L.kmg_apply_plan_destroy.argtypes = [vp, C.c_int]
+    L.kmg_apply_plan_destroy.restype = None
     L.kmg_dither_threshold.argtypes = [f32p, C.c_uint32, C.POINTER(C.c_float)]
     _lib = L
     return L
@@ -360,6 +364,10 @@ class ImageProcessor:
         _check(lib().kmg_dev_apply(self._h, C.c_void_p(d_rgba), width, rows, row0, _np_ptr(c), c.shape[0],
                                    int(mode), C.c_void_p(d_out), C.c_void_p(stream)))
 
+    def apply_plan(self, centroids4, mode, n_pixels_hint, stream=0):
+        """the output pass as a plan (kmg_apply_plan_*): tables built once, then `run` per row band, asynchronously"""
+        return ApplyPlan(self, centroids4, mode, n_pixels_hint, stream)
+
     def debug_block_counts(self):
         """(device blocks allocated with hipMalloc so far, blocks handed out again)"""
         out = (C.c_uint64 * 2)()
@@ -397,6 +405,30 @@ class ImageProcessor:
         v = C.c_uint64()
         _check(lib().kmg_debug_check_meld_masks(self._h, _np_ptr(c), c.shape[0], C.byref(v), C.c_void_p(stream)))
         return int(v.value)
+
+
+class ApplyPlan:
+    """kmg_apply_plan_*: the output pass for one centroid table, band by band, without host synchronisation"""
+
+    def __init__(self, processor, centroids4, mode, n_pixels_hint, stream=0):
+        c = np.ascontiguousarray(centroids4, np.float32).reshape(-1, 4)
+        self._h = C.c_void_p()
+        _check(lib().kmg_apply_plan_create(processor.handle, _np_ptr(c), c.shape[0], int(mode), int(n_pixels_hint), C.c_void_p(stream),
+                                           C.byref(self._h)))
+
+    def run(self, d_rgba, width, rows, row0, d_out, stream=0):
+        _check(lib().kmg_apply_plan_run(self._h, C.c_void_p(d_rgba), width, rows, row0, C.c_void_p(d_out), C.c_void_p(stream)))
+
+    def close(self, synchronise=True):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().kmg_apply_plan_destroy(self._h, int(bool(synchronise)))
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Lloyd:

@@ -341,3 +341,35 @@ def test_random_images_reduce_find_palette_match_oracle(processor, oracle, seed)
     colors = rng.integers(0, 256, (int(rng.integers(1, 20)), 4), dtype=np.uint8); colors[:, 3] = 255
     for mode, omode in ((kg.ReduceMode.Replace, oracle.MODE_REPLACE), (kg.ReduceMode.Dither, oracle.MODE_DITHER)):
         assert np.array_equal(processor.find(img, colors, mode), oracle.find(img, colors, omode)), (w, h, mode)
+
+
+@pytest.mark.parametrize("mode", ["Replace", "Dither", "Meld"])
+def test_apply_plan_in_bands_on_two_streams_equals_the_whole_pass(torch_cuda, processor, oracle, mode):
+    """kmg_apply_plan_*: tables built once, the image processed in uneven row bands alternating between two streams, no host
+    synchronisation in between -- the bytes equal kmg_dev_apply's on the whole image (and hence the oracle's: the Bayer index
+    uses image rows, find_centroid / mix_colors.wgsl)."""
+    import kmeans_gpu_amd as kg
+    from kmeans_gpu_amd import synth
+    torch = torch_cuda
+    w, h, k = 2048, 1536, 40
+    n = w * h
+    img = synth.uniform_rgba_torch(31337, n, device="cuda")
+    rng = np.random.default_rng(9)
+    pal = np.full((k, 4), 255, np.uint8); pal[:, :3] = rng.integers(0, 256, (k, 3))
+    cent = kg.palette_to_centroids(pal)
+    m = getattr(kg.ReduceMode, mode)
+    st = torch.cuda.current_stream().cuda_stream
+    whole = torch.zeros((n, 4), dtype=torch.uint8, device="cuda")
+    processor.apply(img.data_ptr(), w, h, 0, cent, m, whole.data_ptr(), st)
+    want = oracle.find(img.cpu().numpy().reshape(h, w, 4)[:64], pal, getattr(oracle, "MODE_" + mode.upper()))
+    assert np.array_equal(whole.cpu().numpy().reshape(h, w, 4)[:64], want)
+    out = torch.zeros((n, 4), dtype=torch.uint8, device="cuda")
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    plan = processor.apply_plan(cent, m, n, st)
+    bounds = [0, 100, 101, 640, 1203, h]
+    for i, (r0, r1) in enumerate(zip(bounds[:-1], bounds[1:])):
+        s = streams[i % 2]
+        plan.run(img[r0 * w:].data_ptr(), w, r1 - r0, r0, out[r0 * w:].data_ptr(), s.cuda_stream)
+    torch.cuda.synchronize()
+    plan.close()
+    assert torch.equal(out, whole)
