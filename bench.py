@@ -291,11 +291,19 @@ def cfg2_timing(proc, stream, steps=20, strategies=("table", "scan"), profile_ke
     return out
 
 
+def _bound(hbm_frac, valu_frac):
+    """the roof a kernel sits under: the larger of its two fractions -- unless both are low: then neither bytes nor vector issue
+    is what it waits for but chains of dependent instructions / memory round trips at the wave counts its registers allow"""
+    if max(hbm_frac, valu_frac) < 0.35:
+        return "issue"
+    return "valu" if valu_frac > hbm_frac else "hbm"
+
+
 def attach_valu_roof(table, ms_of, tj):
     """The roof that binds, per kernel of the line: `valu` = vector wave-instructions one launch executes (SQ_INSTS_VALU of
     a rocprofv3 PMC pass of the same loop, profiles/traffic.json `valu_wave_instructions`) x 64 lanes over the kernel's time
     and the fp32 vector issue peak (78.6 T lane-operations/s = 157.3 TF/s with an FMA as two); `bound` = the larger of the
-    two fractions -- "hbm" or "valu" -- and "requests" for the label pass, whose time goes to divergent gathers the vector
+    two fractions -- "hbm" or "valu"; "issue" when both are below 0.35 -- and "requests" for the label pass, whose time goes to divergent gathers the vector
     memory pipeline retires at ~1 lane per 2 clocks per CU (profiles/NOTES.md)."""
     counts = tj.get("valu_wave_instructions", {})
     for nm, row in table.items():
@@ -303,7 +311,7 @@ def attach_valu_roof(table, ms_of, tj):
             continue
         row["valu_wave_instructions"] = counts[nm]
         row["valu"] = counts[nm] * 64 / (ms_of[nm] * 1e-3) / VALU_LANE_OPS_PEAK
-        row["bound"] = "requests" if nm == "k_labels" else ("valu" if row["valu"] > row.get("frac", 0.0) else "hbm")
+        row["bound"] = "requests" if nm == "k_labels" else _bound(row.get("frac", 0.0), row["valu"])
         row["valu_source"] = tj.get("valu_source", "profiles/traffic.json")
 
 
@@ -326,7 +334,7 @@ def cfg2_roofline(extra, tj):
     if valu:
         r["valu_wave_instructions"] = valu
         r["valu"] = valu * 64 / (ms * 1e-3) / VALU_LANE_OPS_PEAK
-        r["bound"] = "valu" if r["valu"] > r["frac"] else "hbm"
+        r["bound"] = _bound(r["frac"], r["valu"])
         r["traffic"] = tj.get("bytes_per_launch", {}).get("cfg2_step")
     return r
 
