@@ -16,3 +16,15 @@ def test_random_problems_agree_across_strategies(seed):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "40 cases, 0 mismatching" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["0", "2"])
+def test_alternative_cube_passes_of_small_centroid_tables(mode):
+    """KMG_CUBE_SMALL = 0 (the general three-launch pass for k <= 32 too) and 2 (k_cube_small as the stage only, then the general
+    scan and entries launches): the A/B switches of round 4 stay exact -- same random problems, fresh process (the switch is read once)."""
+    env = dict(os.environ, KMG_CUBE_SMALL=mode)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "24", "21"], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "24 cases, 0 mismatching" in r.stdout

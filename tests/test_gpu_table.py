@@ -101,10 +101,13 @@ def test_table_pass_equals_pixel_scan(torch_cuda, processor, oracle, tokyo, kind
     assert np.array_equal(table[0][0].view(np.uint32), wl) and np.array_equal(table[0][1], wa)
 
 
-def test_table_sums_only_and_labels_only(torch_cuda, processor, oracle):
+@pytest.mark.parametrize("k", [33, 12])
+def test_table_sums_only_and_labels_only(torch_cuda, processor, oracle, k):
+    """(k = 12: the one-launch cube pass of small centroid tables -- sums only, labels only through the partial rows, and
+    the two-step partial sums)"""
     import kmeans_gpu_amd as kg
     torch = torch_cuda
-    n, k = 400_000, 33
+    n = 400_000
     rgba = oracle.synth_uniform(99, n)
     cent = oracle.centroids4(oracle.rgb_to_lab(rgba[:k]))
     wl, wa = oracle.assign_accumulate_rgba(rgba, cent)
@@ -117,6 +120,13 @@ def test_table_sums_only_and_labels_only(torch_cuda, processor, oracle):
     labels = torch.zeros(n, dtype=torch.int32, device="cuda")
     s.assign_accumulate(d.data_ptr(), n, 0, acc.data_ptr(), st)
     s.assign_accumulate(d.data_ptr(), n, labels.data_ptr(), 0, st)
+    torch.cuda.synchronize()
+    assert np.array_equal(acc.cpu().numpy(), wa)
+    assert np.array_equal(labels.cpu().numpy().view(np.uint32), wl)
+    # the two-step entry points (partial rows, then their reduction) through the table
+    acc.zero_(); labels.zero_()
+    s.assign_partials(d.data_ptr(), n, labels.data_ptr(), st)
+    s.reduce_partials(n, acc.data_ptr(), st)
     torch.cuda.synchronize()
     assert np.array_equal(acc.cpu().numpy(), wa)
     assert np.array_equal(labels.cpu().numpy().view(np.uint32), wl)
