@@ -51,7 +51,10 @@ def test_bounds_and_masks_conservative_for_all_colours(torch_cuda, processor, or
 
 
 @pytest.mark.parametrize("kind,n,k", [("uniform", 300_001, 16), ("uniform", 1_000_003, 256), ("uniform", 65_536, 300),
-                                      ("blobs", 700_000, 64), ("flat", 100_000, 5), ("tokyo", 0, 8), ("tokyo", 0, 46)])
+                                      ("blobs", 700_000, 64), ("flat", 100_000, 5), ("tokyo", 0, 8), ("tokyo", 0, 46),
+                                      # the edges of the one-launch pass of small centroid tables (k <= 32: KP = 8 / 16 / 32)
+                                      ("uniform", 500_000, 1), ("uniform", 500_000, 2), ("uniform", 2_500_000, 9),
+                                      ("blobs", 600_000, 32), ("uniform", 600_000, 33)])
 def test_table_pass_equals_pixel_scan(torch_cuda, processor, oracle, tokyo, kind, n, k):
     import kmeans_gpu_amd as kg
     torch = torch_cuda
