@@ -260,7 +260,7 @@ KMG_API int kmg_lloyd_reduce_partials(kmg_lloyd *s, uint64_t n_pixels, int64_t *
  * (-1 = all, 0 = stop); _profile_read synchronises the recorded events, returns the summed duration
  * and launch count per kernel id and resets.  Every timed launch adds two event records to the
  * stream, so time only what is needed inside a throughput measurement.
- * KMG_K_CUBE covers the three launches of the cube pass (k_cube_stage, k_cube_scan, k_cube_pairs) as one interval;
+ * KMG_K_CUBE covers the launches of the cube pass (k_cube_stage, k_cube_scan, k_cube_pairs; k <= 32: k_cube_small) as one interval;
  * KMG_K_CANDIDATES is the candidate kernel of the first release, now the first phase of k_cube_stage: the id is
  * kept so that the others do not move, nothing is reported under it.                                             */
 typedef enum kmg_kernel_id {
