@@ -34,6 +34,11 @@ def _centroid_sets(oracle, rng):
     sets["duplicates"] = np.concatenate([lab[:8], lab[:8], lab[3:4]])
     sets["tight"] = (lab[5] + rng.normal(0, 0.5, (40, 3))).astype(np.float32)
     sets["outside"] = np.array([[150, 0, 0], [-50, 0, 0], [50, 300, -300], [50, 0.001, -0.001]], np.float32)
+    # small tables take the dominance test (kmg_cube.hip `dominated`): it is skipped when a component is above 1024 in
+    # magnitude ("far"), and must stay conservative right below that ("edge1024")
+    sets["far"] = np.array([[5000, 0, 0], [50, 2000, -2000], [1e6, 1e6, 1e6], [50, 0, 0], [60, 10, 10]], np.float32)
+    sets["edge1024"] = np.array([[1000, 1000, -1000], [50, 5, 5], [52, 5, 5], [-1000, -1000, 1000], [50, 1023, 0],
+                                 [51, -3, 4], [1023, 0, 0]], np.float32)
     sets["k512"] = oracle.rgb_to_lab(rng.integers(0, 256, (512, 4), dtype=np.uint8))                                   # two byte lists per cell
     sets["crowded_high"] = np.concatenate([lab[:260], (lab[9] + rng.normal(0, 0.3, (90, 3))).astype(np.float32)])        # > 63 in the second
     sets["crowded100"] = np.concatenate([(lab[7] + rng.normal(0, 0.3, (100, 3))).astype(np.float32), lab[100:256]])   # > 63 candidates
@@ -102,6 +107,35 @@ def test_table_pass_equals_pixel_scan(torch_cuda, processor, oracle, tokyo, kind
     # and the first pass against the oracle itself
     wl, wa = oracle.assign_accumulate_rgba(rgba, cent)
     assert np.array_equal(table[0][0].view(np.uint32), wl) and np.array_equal(table[0][1], wa)
+
+
+@pytest.mark.parametrize("name", ["far", "edge1024", "outside", "duplicates"])
+def test_table_pass_with_centroids_far_outside_the_gamut(torch_cuda, processor, oracle, name):
+    """small tables (the one-launch cube pass with its dominance test) with centroids no image produces: labels and sums of
+    the table pass == the per-pixel scan == the oracle (find_centroid.wgsl:29-41: first minimum, strict <)"""
+    import kmeans_gpu_amd as kg
+    torch = torch_cuda
+    cent = _centroid_sets(oracle, np.random.default_rng(11))[name]
+    k, n = cent.shape[0], 700_000
+    rgba = oracle.synth_uniform(4242 + k, n)
+    wl, wa = oracle.assign_accumulate_rgba(rgba, cent)
+    d = _dev(torch, rgba)
+    st = _stream(torch)
+    for strategy in ("scan", "table"):
+        s = kg.Lloyd(processor, k)
+        s.set_centroids(cent)
+        if strategy == "table":
+            s.bind_image(d.data_ptr(), n, st)                     # (an explicit binding: the table whatever the cost model says)
+        labels = torch.zeros(n, dtype=torch.int32, device="cuda")
+        acc = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
+        s.assign_accumulate(d.data_ptr(), n, labels.data_ptr(), acc.data_ptr(), st)
+        torch.cuda.synchronize()
+        assert np.array_equal(labels.cpu().numpy().view(np.uint32), wl), (name, strategy)
+        assert np.array_equal(acc.cpu().numpy(), wa), (name, strategy)
+        if strategy == "table":
+            bad, resolved, total = s.debug_check_pairs(st)
+            assert bad == 0 and total == n
+        s.close()
 
 
 @pytest.mark.parametrize("k", [33, 12])
