@@ -78,12 +78,14 @@ __device__ __forceinline__ long long wave_sum(long long v)
     return v;
 }
 
-// DPP cross-lane moves (no LDS traffic): src of lane i = lane perm(i) within its row of 16
+// DPP cross-lane moves (no LDS traffic): src of lane i = lane perm(i) within its row of 16.  For the permutations used
+// through these two helpers (quad_perm, row_mirror, row_half_mirror) every lane has a source, so `old` is never taken: old = 0
+// with bound_ctrl lets the compiler fold the move into the operation that consumes it (v_min_f32_dpp, v_add_u32_dpp ...:
+// one instruction per reduction step instead of copy + v_mov_b32_dpp + operation)
 template <int CTRL>
 __device__ __forceinline__ float dpp_f32(float v)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v),
-                                                                 CTRL, 0xF, 0xF, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
 constexpr int kDppXor1 = 0xB1;          // quad_perm [1,0,3,2]
 constexpr int kDppXor2 = 0x4E;          // quad_perm [2,3,0,1]
@@ -113,7 +115,7 @@ __device__ __forceinline__ float wave_min(float v)
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_u32(uint32_t v)
 {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
 }
 
 // sum over the wave of a per-lane u32 whose wave total cannot overflow (e.g. three packed 10-bit counters of
