@@ -958,7 +958,8 @@ constexpr size_t kLabelLdsHot = kLabelLdsPlain + (size_t)kHotMax * kCellColours 
 
 // KNOCK (tools only, results wrong): 1 = gathers from a 64 KiB window of the table, 2 = from LDS instead, 3 = none,
 // 4 = plain non-temporal gathers, 5 = gathers from a table a quarter the size, 6 = the cheaper colour index of a
-// (cell, r & 7, g & 7, b & 7)-ordered table, 7 = three quarters of the pixel bytes read (round 4 probes, profiles/NOTES.md)
+// (cell, r & 7, g & 7, b & 7)-ordered table, 7 = three quarters of the pixel bytes read, 8 = half the pair
+// table in LDS and two workgroups per CU (round 4 probes, profiles/NOTES.md)
 template <bool HOT, int KNOCK = 0>
 __global__ __launch_bounds__(kLabelBlock) void k_labels_pairs(const uint32_t *__restrict__ rgba, uint64_t n,
                                                               const uint8_t *__restrict__ colour_labels,
@@ -978,15 +979,17 @@ __global__ __launch_bounds__(kLabelBlock) void k_labels_pairs(const uint32_t *__
         for (uint32_t i = threadIdx.x; i < 4u * k; i += kLabelBlock) tail_sums[i] = 0;      // ready for the next pass
         __syncthreads();
     }
-    uint32_t *s_pair = s_label_lds, *s_pal = s_label_lds + kCells, *s_dir = s_label_lds + kCells + 256;
-    uint8_t *s_hot = reinterpret_cast<uint8_t *>(s_label_lds + kCells + 256 + 128);
+    // (KNOCK 8: half the pair table -- 64 KiB, two workgroups per CU; cells share entries, i.e. wrong results)
+    constexpr uint32_t kPairWords = KNOCK == 8 ? kCells / 2u : kCells;
+    uint32_t *s_pair = s_label_lds, *s_pal = s_label_lds + kPairWords, *s_dir = s_label_lds + kPairWords + 256;
+    uint8_t *s_hot = reinterpret_cast<uint8_t *>(s_label_lds + kPairWords + 256 + 128);
     uint32_t *s_hcell = reinterpret_cast<uint32_t *>(s_hot + (size_t)kHotMax * kCellColours);
     if (pal && threadIdx.x < k) s_pal[threadIdx.x] = pal[threadIdx.x];
     if (threadIdx.x < 128) s_dir[threadIdx.x] = threadIdx.x < kPairDirs ? pair_dir_word(threadIdx.x) : 0u;
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(pair_table);
         uint4 *dst = reinterpret_cast<uint4 *>(s_pair);
-        for (uint32_t i = threadIdx.x; i < kCells / 4; i += kLabelBlock) dst[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < kPairWords / 4; i += kLabelBlock) dst[i] = src[i];
     }
     __syncthreads();
     if (HOT) {
@@ -1035,7 +1038,7 @@ __global__ __launch_bounds__(kLabelBlock) void k_labels_pairs(const uint32_t *__
         bool fine[8];
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
-            const uint32_t e = s_pair[ci[p] >> 9];
+            const uint32_t e = s_pair[(ci[p] >> 9) & (kPairWords - 1u)];
             const uint32_t code = (e >> 16) & 127u;
             const int proj = __builtin_amdgcn_sdot4((int)xyz[p], (int)s_dir[code], 0, false);
             const int tlo = (int)((e >> 23) & 63u), w = (int)(e >> 29);
@@ -1049,7 +1052,7 @@ __global__ __launch_bounds__(kLabelBlock) void k_labels_pairs(const uint32_t *__
 #pragma unroll
         for (int p = 0; p < 8; ++p)
             if (fine[p]) {
-                if (KNOCK == 0 || KNOCK == 6 || KNOCK == 7) lab[p] = (uint32_t)colour_labels[ci[p]];
+                if (KNOCK == 0 || KNOCK == 6 || KNOCK == 7 || KNOCK == 8) lab[p] = (uint32_t)colour_labels[ci[p]];
                 else if (KNOCK == 1) lab[p] = (uint32_t)colour_labels[ci[p] & 0xFFFFu];
                 else if (KNOCK == 2) lab[p] = (uint32_t)reinterpret_cast<const uint8_t *>(s_pair)[ci[p] & 0x1FFFFu];
                 else if (KNOCK == 4) lab[p] = (uint32_t)__builtin_nontemporal_load(colour_labels + ci[p]);
@@ -1093,6 +1096,9 @@ hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_la
                                      (const uint8_t *)colour_labels, pairs, pal, k, labels, aligned, hot, tail_sums, tl)
         if (knock == 1) KMG_LK(1); else if (knock == 2) KMG_LK(2); else if (knock == 3) KMG_LK(3); else if (knock == 4) KMG_LK(4);
         else if (knock == 5) KMG_LK(5); else if (knock == 6) KMG_LK(6); else if (knock == 7) KMG_LK(7);
+        else if (knock == 8)
+            hipLaunchKernelGGL((k_labels_pairs<false, 8>), dim3(2u * grid), dim3(kLabelBlock), kLabelLdsPlain - sizeof(uint32_t) * kCells / 2u,
+                               st, rgba, n, (const uint8_t *)colour_labels, pairs, pal, k, labels, aligned, hot, tail_sums, tl);
 #undef KMG_LK
         else if (hot)
             hipLaunchKernelGGL(k_labels_pairs<true>, dim3(grid), dim3(kLabelBlock), kLabelLdsHot, st, rgba, n,
