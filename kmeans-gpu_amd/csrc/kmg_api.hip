@@ -227,7 +227,7 @@ struct kmg_lloyd {
                                  // over and clears it, kmg_table.h CubeTail) -- no memset launch per pass
     bool acc_int_dirty;          // a pass was interrupted: clear d_acc_int before the next one
     uint32_t *d_nconv;           // 1
-    unsigned long long *d_key;   // 1 (init arg-max)
+    unsigned long long *d_key;   // 3 (init arg-max keys, in rotation: kmg_kernels.h launch_init_pass)
     float *d_dist;               // init distance map, grown on demand (a block of its own)
     uint64_t dist_cap;
     size_t dist_blk_cap;
@@ -1187,7 +1187,7 @@ static int lloyd_create_impl(kmg_processor *p, uint32_t k, kmg_lloyd **out, hipS
     s->ws = nullptr; s->ws_cap = 0; s->dist_blk_cap = 0;
     // one block from the processor's idle blocks (a warm processor creates a kmg_lloyd without a hipMalloc)
     const size_t sizes[6] = {sizeof(Centroid) * k, sizeof(int64_t) * 4ull * k * 2048ull, sizeof(int64_t) * 4ull * k, sizeof(uint32_t),
-                             sizeof(unsigned long long), sizeof(int64_t) * 4ull * k};
+                             3u * sizeof(unsigned long long), sizeof(int64_t) * 4ull * k};
     size_t need = 0;
     for (size_t b : sizes) need += pad256(b);
     hipError_t e = block_take(p, need, &s->ws, &s->ws_cap);
@@ -1353,10 +1353,12 @@ extern "C" int kmg_lloyd_init_centroids(kmg_lloyd *s, const uint8_t *d_rgba, uin
                                                j < s->k ? 1 : 0, s->tab.d_cdist, s->tab.d_init_cells, nullptr, rgba, s->p->d_lut,
                                                S(stream)));
             } else {
-                HIP_TRY(launch_init_pass(rgba, n, s->p->d_lut, s->d_cent, j, s->d_dist, s->d_key, 0, S(stream)));
-                HIP_TRY(launch_init_pick(rgba, s->p->d_lut, s->d_key, s->d_cent, j, S(stream)));
+                // launch j picks centroid j - 1 (j >= 2) and runs pass j; three keys in rotation (kmg_kernels.h)
+                HIP_TRY(launch_init_pass(rgba, n, s->p->d_lut, s->d_cent, j, s->d_dist, s->d_key, 0, S(stream), true));
             }
         }
+        if (!colours)       // the last centroid, from the last pass's key (which it leaves zero)
+            HIP_TRY(launch_init_pick(rgba, s->p->d_lut, s->d_key + (s->k - 1u) % 3u, s->d_cent, s->k - 1u, S(stream)));
     }
     return KMG_OK;
 }

@@ -36,9 +36,11 @@ hipError_t launch_update(const int64_t *acc, uint32_t k, float convergence, Cent
 // farthest-point init
 hipError_t launch_init_first(const uint32_t *rgba, uint64_t index, const float *lut,
                              Centroid *cent, unsigned long long *key, hipStream_t st);
+// pick = false: pass j into *key.  pick = true (whole image, one device): key[3] in rotation, the launch first picks
+// centroid j - 1 from key[(j - 1) % 3] (j >= 2), runs pass j into key[j % 3] and clears key[(j + 1) % 3]
 hipError_t launch_init_pass(const uint32_t *rgba, uint64_t n, const float *lut,
-                            const Centroid *cent, uint32_t j, float *dist,
-                            unsigned long long *key, uint64_t first_index, hipStream_t st);
+                            Centroid *cent, uint32_t j, float *dist,
+                            unsigned long long *key, uint64_t first_index, hipStream_t st, bool pick = false);
 hipError_t launch_init_pick(const uint32_t *rgba, const float *lut, unsigned long long *key,
                             Centroid *cent, uint32_t j, hipStream_t st);
 // sharded init (row bands): publish the colour of the pixel named by an all-reduced key; set one centroid

@@ -12,7 +12,10 @@
 // Compile with -ffp-contract=off: arithmetic must match kmg_math.h operation for operation.
 
 #include "kmg_kernels.h"
+
+#include <stdlib.h>
 #include "kmg_device.h"
+#include "kmg_table_dev.h"       // lane_value, wave_min, wave_max_u32_dpp
 
 namespace kmg {
 
@@ -136,25 +139,41 @@ __device__ __forceinline__ void argmin_scan(const PixelTerms (&pt)[PPT], float (
             near_any = near_any || second[p] <= thr[p];
         }
         if (__ballot(near_any)) {
-            float lb[PPT];
-            uint32_t li[PPT];
+            // One near-tie pixel at a time, the WAVE working on it: the pixel's terms go to every lane, lane l takes the
+            // centroids l, l + 64, ... -- the literal distance where the key is inside the threshold, smallest index first --
+            // and the wave reduces to (smallest distance, lowest index among equals) = what the reference's ordered scan with
+            // strict `<` returns.  The cost follows the number of such pixels (a few per thousand): the loop this replaces
+            // walked the whole table with all lanes for every wave that held one -- 40 % of the vector work of the kernel at
+            // 4096^2, k = 16 (512 pixels per wave: nearly every wave), and on a small image the launch's duration (46 us at
+            // k = 256 for the wave that met one; profiles/NOTES.md, round 4).
+            const uint32_t lane = threadIdx.x & 63u;
 #pragma unroll
             for (int p = 0; p < PPT; ++p) {
-                lb[p] = SENTINEL ? cie94_c(pt[p].L, pt[p].a, pt[p].b, pt[p].C, 10000.0f, 10000.0f, 10000.0f, chroma(10000.0f, 10000.0f)) : 100000.0f;
-                li[p] = SENTINEL ? k : 0u;
-            }
-            for (uint32_t j = 0; j < k; ++j) {
-                const float4 c = s_cent[j];
-#pragma unroll
-                for (int p = 0; p < PPT; ++p) {
-                    if (second[p] <= thr[p] && cie94_key(pt[p], c.x, c.y, c.z, c.w) <= thr[p]) {
-                        const float d = cie94_c(pt[p].L, pt[p].a, pt[p].b, pt[p].C, c.x, c.y, c.z, c.w);
-                        if (d < lb[p]) { lb[p] = d; li[p] = j; }
+                unsigned long long todo = __ballot(second[p] <= thr[p]);
+                while (todo) {
+                    const uint32_t src = (uint32_t)__builtin_ctzll(todo);
+                    todo &= todo - 1ull;
+                    PixelTerms q;
+                    q.L = lane_value(pt[p].L, src); q.a = lane_value(pt[p].a, src); q.b = lane_value(pt[p].b, src);
+                    q.C = lane_value(pt[p].C, src); q.wC = lane_value(pt[p].wC, src); q.wH = lane_value(pt[p].wH, src);
+                    const float t = lane_value(thr[p], src);
+                    float my_d = 3.0e38f;
+                    uint32_t my_j = 0xFFFFFFFFu;
+                    for (uint32_t j = lane; j < k; j += 64u) {
+                        const float4 c = s_cent[j];
+                        if (cie94_key(q, c.x, c.y, c.z, c.w) <= t) {
+                            const float d = cie94_c(q.L, q.a, q.b, q.C, c.x, c.y, c.z, c.w);
+                            if (d < my_d) { my_d = d; my_j = j; }
+                        }
                     }
+                    const float wd = wave_min(my_d);
+                    const uint32_t wj = ~wave_max_u32_dpp(~(my_d == wd ? my_j : 0xFFFFFFFFu));
+                    // (find_centroid.wgsl:29-30 / mix_colors.wgsl:73-75: what the scan starts from)
+                    const float start = SENTINEL ? cie94_c(q.L, q.a, q.b, q.C, 10000.0f, 10000.0f, 10000.0f, chroma(10000.0f, 10000.0f)) : 100000.0f;
+                    const uint32_t res = wd < start ? wj : (SENTINEL ? k : 0u);
+                    if (lane == src) idx[p] = res;
                 }
             }
-#pragma unroll
-            for (int p = 0; p < PPT; ++p) idx[p] = second[p] <= thr[p] ? li[p] : idx[p];
         }
     }
 }
@@ -165,6 +184,9 @@ __device__ __forceinline__ void argmin_scan(const PixelTerms (&pt)[PPT], float (
 // 4 consecutive pixels = one 16-byte load, the groups of a tile interleaved so every load
 // instruction is fully coalesced).  Sums go to per-workgroup int64 bins in LDS (ds_add_u64),
 // flushed once per workgroup into the partial-sum slab.
+// PPT = 8 on large images; 4 / 2 / 1 (groups of PPT consecutive pixels) on small ones (assign_ppt): the reference's default
+// call shrinks every image to <= 256 x 256 (structures.rs:67-89), and 65 536 pixels at 8 per thread are 32 workgroups for 256
+// CUs -- k_assign took 97 us per Lloyd iteration of such an image at k = 256, 18 x that per default call.
 // LDS: [centroids kpad x 16 B][bins k x 32 B (ACCUM)][sRGB table 1 KiB]
 // ------------------------------------------------------------------------------------------
 template <int PPT, bool ACCUM, bool CHUNKED>
@@ -186,7 +208,8 @@ __global__ __launch_bounds__(kBlock) void k_assign(const uint32_t *__restrict__ 
         for (uint32_t i = threadIdx.x; i < 4 * k; i += kBlock) bins[i] = 0ull;
     __syncthreads();
 
-    constexpr int GROUPS = PPT / 4;
+    constexpr int G = PPT < 4 ? PPT : 4;                   // consecutive pixels per group
+    constexpr int GROUPS = PPT / G;
     constexpr uint64_t TILE = (uint64_t)kBlock * PPT;
     const uint64_t tiles = (n + TILE - 1) / TILE;
     for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
@@ -195,12 +218,17 @@ __global__ __launch_bounds__(kBlock) void k_assign(const uint32_t *__restrict__ 
         PixelTerms pt[PPT];
 #pragma unroll
         for (int g = 0; g < GROUPS; ++g) {
-            i0[g] = tile * TILE + (uint64_t)g * (kBlock * 4) + (uint64_t)threadIdx.x * 4;
+            i0[g] = tile * TILE + (uint64_t)g * (kBlock * G) + (uint64_t)threadIdx.x * G;
             uint32_t px[4];
-            load4(rgba, i0[g], n, aligned != 0, px);
+            if (G == 4) {
+                load4(rgba, i0[g], n, aligned != 0, px);
+            } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int p = g * 4 + q;
+                for (int q = 0; q < G; ++q) px[q] = (i0[g] + q < n) ? rgba[i0[g] + q] : 0u;
+            }
+#pragma unroll
+            for (int q = 0; q < G; ++q) {
+                const int p = g * G + q;
                 px_to_lab(s_lut, px[q], L[p], A[p], B[p]);
                 pt[p] = pixel_terms(L[p], A[p], B[p]);
             }
@@ -217,17 +245,23 @@ __global__ __launch_bounds__(kBlock) void k_assign(const uint32_t *__restrict__ 
 #pragma unroll
         for (int g = 0; g < GROUPS; ++g) {
             if (labels) {
-                uint32_t v[4] = {idx[g * 4], idx[g * 4 + 1], idx[g * 4 + 2], idx[g * 4 + 3]};
-                store4(labels, i0[g], n, aligned != 0, v);
+                if (G == 4) {
+                    uint32_t v[4] = {idx[g * 4], idx[g * 4 + 1], idx[g * 4 + 2], idx[g * 4 + 3]};
+                    store4(labels, i0[g], n, aligned != 0, v);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < G; ++q)
+                        if (i0[g] + q < n) labels[i0[g] + q] = idx[g * G + q];
+                }
             }
             if (ACCUM) {
-                // the 4 consecutive pixels of a group often share a label (always, in flat regions of a
+                // the consecutive pixels of a group often share a label (always, in flat regions of a
                 // real image): merge such runs in registers and touch the LDS bins once per run
                 long long rs[4] = {0, 0, 0, 0};
                 uint32_t cur = 0xFFFFFFFFu;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int p = g * 4 + q;
+                for (int q = 0; q < G; ++q) {
+                    const int p = g * G + q;
                     if (i0[g] + q < n) {
                         if (idx[p] != cur) {
                             if (cur != 0xFFFFFFFFu) {
@@ -259,11 +293,20 @@ __global__ __launch_bounds__(kBlock) void k_assign(const uint32_t *__restrict__ 
     }
 }
 
-constexpr int kAssignPPT = 8;   // pixels per thread of the assign kernel
+constexpr int kAssignPPT = 8;   // pixels per thread of the assign / output kernels on large images
+
+// pixels per thread of k_assign: 8 once the image fills the device at that (4 waves per SIMD = 2^21 pixels), fewer below
+// (measured, MI355X, k = 256: tools/default_reduce_probe.py and profiles/NOTES.md round 4)
+static int assign_ppt(uint64_t n)
+{
+    static const int forced = getenv("KMG_ASSIGN_PPT") ? atoi(getenv("KMG_ASSIGN_PPT")) : 0;      // tools only
+    if (forced == 1 || forced == 2 || forced == 4 || forced == 8) return forced;
+    return n >= (1ull << 21) ? 8 : (n >= (1ull << 20) ? 4 : (n >= (1ull << 19) ? 2 : 1));
+}
 
 uint32_t assign_grid(uint64_t n)
 {
-    const uint64_t tile = (uint64_t)kBlock * kAssignPPT;
+    const uint64_t tile = (uint64_t)kBlock * (uint64_t)assign_ppt(n);
     uint64_t tiles = (n + tile - 1) / tile;
     if (tiles < 1) tiles = 1;
     return (uint32_t)(tiles < 2048 ? tiles : 2048);
@@ -279,22 +322,22 @@ hipError_t launch_assign(const uint32_t *rgba, uint64_t n, const Centroid *cent,
                             ? 1 : 0;
     const bool chunked = k >= 32;   // the recovery step costs ~4 extra pairs per pixel
     size_t lds = sizeof(float4) * kpad + 256 * sizeof(float);
-    if (partials) {
-        lds += sizeof(unsigned long long) * 4ull * k;
-        if (chunked)
-            hipLaunchKernelGGL((k_assign<kAssignPPT, true, true>), dim3(grid), dim3(kBlock), lds, st,
-                               rgba, n, cent, k, lut, labels, partials, aligned);
-        else
-            hipLaunchKernelGGL((k_assign<kAssignPPT, true, false>), dim3(grid), dim3(kBlock), lds, st,
-                               rgba, n, cent, k, lut, labels, partials, aligned);
-    } else {
-        if (chunked)
-            hipLaunchKernelGGL((k_assign<kAssignPPT, false, true>), dim3(grid), dim3(kBlock), lds, st,
-                               rgba, n, cent, k, lut, labels, partials, aligned);
-        else
-            hipLaunchKernelGGL((k_assign<kAssignPPT, false, false>), dim3(grid), dim3(kBlock), lds, st,
-                               rgba, n, cent, k, lut, labels, partials, aligned);
+    if (partials) lds += sizeof(unsigned long long) * 4ull * k;
+#define KMG_ASSIGN(P, A, C)                                                                                    \
+    hipLaunchKernelGGL((k_assign<P, A, C>), dim3(grid), dim3(kBlock), lds, st, rgba, n, cent, k, lut, labels, partials, aligned)
+#define KMG_ASSIGN_P(P)                                                                                        \
+    do {                                                                                                       \
+        if (partials) { if (chunked) KMG_ASSIGN(P, true, true); else KMG_ASSIGN(P, true, false); }             \
+        else          { if (chunked) KMG_ASSIGN(P, false, true); else KMG_ASSIGN(P, false, false); }           \
+    } while (0)
+    switch (assign_ppt(n)) {
+    case 1: KMG_ASSIGN_P(1); break;
+    case 2: KMG_ASSIGN_P(2); break;
+    case 4: KMG_ASSIGN_P(4); break;
+    default: KMG_ASSIGN_P(kAssignPPT); break;
     }
+#undef KMG_ASSIGN_P
+#undef KMG_ASSIGN
     return hipGetLastError();
 }
 
@@ -370,7 +413,7 @@ __global__ void k_init_first(const uint32_t *__restrict__ rgba, uint64_t index,
         linear100_to_lab(lut[px & 255u], lut[(px >> 8) & 255u], lut[(px >> 16) & 255u], L, a, b);
         Centroid c; c.L = L; c.a = a; c.b = b; c.C = chroma(a, b);
         cent[0] = c;
-        *key = 0ull;
+        key[0] = key[1] = key[2] = 0ull;                  // (three keys in rotation: k_init_pass PICK)
     }
 }
 
@@ -381,9 +424,15 @@ hipError_t launch_init_first(const uint32_t *rgba, uint64_t index, const float *
     return hipGetLastError();
 }
 
+// PICK (a whole image on one device): `key` holds three keys in rotation and launch j first picks centroid j - 1 from
+// key[(j - 1) % 3] -- plus_plus_init.wgsl:172-181 `pick`, by one thread of EVERY workgroup, the same arithmetic on the same
+// pixel -- then runs pass j into key[j % 3] and clears key[(j + 1) % 3] for the next launch: one launch per pass instead of
+// two (the reference's default call initialises on a <= 256 x 256 image: 255 passes of ~5 us at k = 256, each followed by a
+// 2 us pick launch).  The last centroid is picked by k_init_pick from key[(k - 1) % 3].
+template <bool PICK>
 __global__ __launch_bounds__(kBlock) void k_init_pass(const uint32_t *__restrict__ rgba, uint64_t n,
                                                       const float *__restrict__ lut,
-                                                      const Centroid *__restrict__ cent, uint32_t j,
+                                                      Centroid *__restrict__ cent, uint32_t j,
                                                       float *__restrict__ dist,
                                                       unsigned long long *__restrict__ key,
                                                       uint64_t first_index)
@@ -392,9 +441,26 @@ __global__ __launch_bounds__(kBlock) void k_init_pass(const uint32_t *__restrict
     // tie rule of the key is the image's, not the band's
     __shared__ float s_lut[256];
     __shared__ unsigned long long s_key[kBlock / 64];
+    __shared__ Centroid s_c;
     s_lut[threadIdx.x] = lut[threadIdx.x];
+    if (PICK && j >= 2u && threadIdx.x == 0) {
+        const unsigned long long kk = key[(j - 1u) % 3u];
+        uint32_t index = 0;                                   // Candidate(0, 0.0) when every distance is 0
+        if ((kk >> 32) != 0ull) {
+            const uint32_t low = (uint32_t)kk;
+            index = (low & ~15u) | (15u - (low & 15u));
+        }
+        const uint32_t px = rgba[index];
+        float L, a, b;
+        linear100_to_lab(lut[px & 255u], lut[(px >> 8) & 255u], lut[(px >> 16) & 255u], L, a, b);
+        Centroid o; o.L = L; o.a = a; o.b = b; o.C = chroma(a, b);
+        s_c = o;
+        if (blockIdx.x == 0) cent[j - 1u] = o;
+    }
+    if (PICK && blockIdx.x == 0 && threadIdx.x == 0) key[(j + 1u) % 3u] = 0ull;
     __syncthreads();
-    const Centroid c = cent[j - 1];
+    const Centroid c = (PICK && j >= 2u) ? s_c : cent[j - 1];
+    if (PICK) key += j % 3u;
     unsigned long long best = 0ull;
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
@@ -421,12 +487,13 @@ __global__ __launch_bounds__(kBlock) void k_init_pass(const uint32_t *__restrict
     }
 }
 
-hipError_t launch_init_pass(const uint32_t *rgba, uint64_t n, const float *lut, const Centroid *cent,
-                            uint32_t j, float *dist, unsigned long long *key, uint64_t first_index, hipStream_t st)
+hipError_t launch_init_pass(const uint32_t *rgba, uint64_t n, const float *lut, Centroid *cent,
+                            uint32_t j, float *dist, unsigned long long *key, uint64_t first_index, hipStream_t st, bool pick)
 {
     uint64_t blocks = (n + kBlock - 1) / kBlock;
     uint32_t grid = (uint32_t)(blocks < 2048 ? (blocks ? blocks : 1) : 2048);
-    hipLaunchKernelGGL(k_init_pass, dim3(grid), dim3(kBlock), 0, st, rgba, n, lut, cent, j, dist, key, first_index);
+    if (pick) hipLaunchKernelGGL(k_init_pass<true>, dim3(grid), dim3(kBlock), 0, st, rgba, n, lut, cent, j, dist, key, first_index);
+    else hipLaunchKernelGGL(k_init_pass<false>, dim3(grid), dim3(kBlock), 0, st, rgba, n, lut, cent, j, dist, key, first_index);
     return hipGetLastError();
 }
 
@@ -642,7 +709,8 @@ hipError_t launch_apply(const uint32_t *rgba, uint32_t w, uint32_t rows, uint32_
                         bool dither, float threshold, uint32_t *out, hipStream_t st)
 {
     const uint64_t n = (uint64_t)w * rows;
-    const uint32_t grid = assign_grid(n);
+    const uint64_t tiles = (n + (uint64_t)kBlock * kAssignPPT - 1) / ((uint64_t)kBlock * kAssignPPT);
+    const uint32_t grid = (uint32_t)(tiles < 2048 ? (tiles ? tiles : 1) : 2048);
     const uint32_t kpad = (k + 3u) & ~3u;
     const int aligned = ((reinterpret_cast<uintptr_t>(rgba) & 15u) == 0 &&
                          (reinterpret_cast<uintptr_t>(out) & 15u) == 0) ? 1 : 0;
