@@ -363,6 +363,29 @@ def reduce_end_to_end(proc, rgba, width, height, k):
             "reduce_host_to_host_into_callers_buffer_ms": min(into[1:])}
 
 
+def default_call_timing():
+    """BASELINE config 1 and the reference's DEFAULT call (lib.rs:116-164 with structures.rs:67-89: shrink to <= 256, init, Lloyd
+    loop, output pass) from and to host buffers on the reference's own test image: wall time per warm call.  Launch-bound --
+    a 256 x 171 working image -- and never part of `value`."""
+    import numpy as np
+    import kmeans_gpu_amd as kg
+    from PIL import Image
+    tokyo = np.array(Image.open(os.path.join(ROOT, "tests", "golden", "tokyo.png")).convert("RGBA"))
+    p = kg.ImageProcessor()                   # the reference's defaults
+    out = {}
+
+    def warm(fn, reps=5):
+        ts = []
+        for _ in range(reps):
+            t = time.perf_counter(); fn(); ts.append((time.perf_counter() - t) * 1e3)
+        return min(ts[1:])
+    out["cfg1_reduce_tokyo_k8_replace_ms"] = warm(lambda: p.reduce(8, tokyo, reduce_mode=kg.ReduceMode.Replace))
+    out["default_palette_tokyo_k256_ms"] = warm(lambda: p.palette(256, tokyo))
+    out["default_reduce_tokyo_k256_dither_ms"] = warm(lambda: p.reduce(256, tokyo, reduce_mode=kg.ReduceMode.Dither))
+    p.close()
+    return out
+
+
 def output_pass_timing(proc, rgba, n_pixels, stream, sh=None, steps=3):
     """Not part of `value`: the other kernel family of the path, BASELINE config 5 -- find + ordered
     dither with the 64-entry resurrect_64 palette on the same 8192x8192 pixels (8 B/px algorithmic:
@@ -435,6 +458,7 @@ def output_pass_timing(proc, rgba, n_pixels, stream, sh=None, steps=3):
         extra.update(cfg4_tiled_rank_share(proc, k3, WIDTH, n_pixels // WIDTH, stream, steps=steps))
         extra.update(reduce_end_to_end(proc, rgba, WIDTH, n_pixels // WIDTH, k3))
         extra.update(cfg2_timing(proc, stream, steps=max(steps, 2) * 5))
+        extra.update(default_call_timing())
     except Exception as e:      # the extras must never break the benchmark line (tests/test_gpu_bench.py fails on it instead)
         import traceback
         extra["error"] = repr(e) + " | " + traceback.format_exc().strip().splitlines()[-3].strip()

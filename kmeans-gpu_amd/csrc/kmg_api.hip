@@ -1631,7 +1631,15 @@ static int assign_update_impl(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, u
     HIP_TRY(hipSetDevice(s->p->device));
     if (table_bound(s, d_rgba, n)) return table_assign(s, d_rgba, n, d_labels, d_acc4, 1u, S(stream), do_update != 0, defer_entries);
     int rc;
-    if ((rc = kmg_lloyd_assign_accumulate(s, d_rgba, n, d_labels, d_acc4, stream)) != KMG_OK) return rc;
+    // (a small slab of partial sums: reduction and update are one launch -- kmg_kernels.h reduce_update_fits)
+    if ((rc = assign_pass(s, d_rgba, n, d_labels, true, S(stream))) != KMG_OK) return rc;
+    if (reduce_update_fits(s->last_rows, s->k)) {
+        if (do_update) s->tab.tables_valid = false;
+        PROF_LAUNCH(s, KMG_K_REDUCE, S(stream), launch_reduce_update(s->d_partials, s->last_rows, s->k, d_acc4, do_update, s->p->opt.convergence,
+                                                                    s->d_cent, s->d_nconv, S(stream)));
+        return KMG_OK;
+    }
+    PROF_LAUNCH(s, KMG_K_REDUCE, S(stream), launch_reduce_partials(s->d_partials, s->last_rows, s->k, d_acc4, S(stream)));
     return do_update ? kmg_lloyd_update(s, d_acc4, stream) : KMG_OK;
 }
 

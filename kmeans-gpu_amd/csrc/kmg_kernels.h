@@ -30,6 +30,10 @@ hipError_t launch_reduce_partials(const int64_t *partials, uint32_t rows, uint32
                                   int64_t *acc, hipStream_t st);
 
 // choose_centroid.wgsl `pick` for all k
+// rows x k x 4 values small enough (reduce_update_fits): reduction and -- do_update -- the update in one launch of one workgroup
+bool reduce_update_fits(uint32_t rows, uint32_t k);
+hipError_t launch_reduce_update(const int64_t *partials, uint32_t rows, uint32_t k, int64_t *acc, int do_update, float convergence,
+                                Centroid *cent, uint32_t *n_converged, hipStream_t st);
 hipError_t launch_update(const int64_t *acc, uint32_t k, float convergence, Centroid *cent,
                          uint32_t *n_converged, hipStream_t st);
 

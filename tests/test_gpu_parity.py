@@ -39,7 +39,9 @@ def test_lab_all_16m_colours(torch_cuda, processor, oracle):
 
 
 @pytest.mark.parametrize("n,k,seed", [(1, 1, 1), (5, 3, 2), (1023, 16, 3), (1024, 16, 4), (4099, 7, 5),
-                                      (300_000, 16, 0x5EED0002), (200_003, 256, 0x5EED0003)])
+                                      (300_000, 16, 0x5EED0002), (200_003, 256, 0x5EED0003),
+                                      # k_assign's pixels per thread follow the image size: 1 below 2^19 pixels (above), 2, 4, 8
+                                      (600_001, 12, 6), (1_300_003, 33, 7), (2_200_001, 5, 8)])
 def test_assign_accumulate_matches_oracle(torch_cuda, processor, oracle, n, k, seed):
     """S2 + S4: labels bit-exact, int64 accumulators bit-exact, incl. ragged tails."""
     import kmeans_gpu_amd as kg
@@ -66,6 +68,35 @@ def test_assign_accumulate_matches_oracle(torch_cuda, processor, oracle, n, k, s
     torch.cuda.synchronize()
     assert torch.equal(labels, labels2) and torch.equal(acc, acc2)
     s.close()
+
+
+@pytest.mark.parametrize("n", [3_000, 70_000, 600_000, 1_100_000])
+def test_assign_near_ties_are_decided_by_the_literal_distance(torch_cuda, processor, oracle, n):
+    """centroid tables full of (near-)duplicates: the ordering key cannot separate them, the literal CIE94 distance with the
+    reference's strict `<` (find_centroid.wgsl:32-41: first minimum wins) must -- the repair of k_assign's scan, for every
+    pixels-per-thread variant (1, 1, 2, 4 by image size) and for both the plain (k < 32) and the chunked scan"""
+    import kmeans_gpu_amd as kg
+    torch = torch_cuda
+    rng = np.random.default_rng(n)
+    rgba = oracle.synth_uniform(900 + n, n)
+    base = oracle.rgb_to_lab(rgba[:12])
+    for k in (24, 40):
+        lab = np.tile(base, (4, 1))[:k].astype(np.float32)
+        # a few entries one or two ulps off their twin: near-ties that are NOT exact duplicates
+        bump = lab[12:16].view(np.uint32) + np.array([1, 2, 1, 3], np.uint32)[:, None]
+        lab[12:16] = bump.view(np.float32)
+        cent = oracle.centroids4(lab)
+        want_labels, want_acc = oracle.assign_accumulate_rgba(rgba, cent)
+        d = _dev(torch, rgba)
+        labels = torch.zeros(n, dtype=torch.int32, device="cuda")
+        acc = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
+        s = kg.Lloyd(processor, k)
+        s.set_centroids(cent)
+        s.assign_accumulate(d.data_ptr(), n, labels.data_ptr(), acc.data_ptr(), _stream(torch))
+        torch.cuda.synchronize()
+        assert np.array_equal(labels.cpu().numpy().view(np.uint32), want_labels), k
+        assert np.array_equal(acc.cpu().numpy(), want_acc), k
+        s.close()
 
 
 def test_assign_unaligned_band(torch_cuda, processor, oracle):
@@ -113,7 +144,7 @@ def test_update_and_lloyd_loop(torch_cuda, processor, oracle, tokyo):
     s.close()
 
 
-@pytest.mark.parametrize("k", [1, 2, 8, 33])
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 8, 33, 256])     # (the keys of the passes rotate through three slots)
 def test_init_centroids(torch_cuda, processor, oracle, tokyo, k):
     """S12 farthest-point init incl. its arg-max tie rule"""
     import kmeans_gpu_amd as kg
