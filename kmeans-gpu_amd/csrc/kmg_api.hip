@@ -227,7 +227,7 @@ struct kmg_lloyd {
                                  // over and clears it, kmg_table.h CubeTail) -- no memset launch per pass
     bool acc_int_dirty;          // a pass was interrupted: clear d_acc_int before the next one
     uint32_t *d_nconv;           // 1
-    unsigned long long *d_key;   // 3 (init arg-max keys, in rotation: kmg_kernels.h launch_init_pass)
+    unsigned long long *d_key;   // 1 (init arg-max of a sharded image)
     float *d_dist;               // init distance map, grown on demand (a block of its own)
     uint64_t dist_cap;
     size_t dist_blk_cap;
@@ -1187,7 +1187,7 @@ static int lloyd_create_impl(kmg_processor *p, uint32_t k, kmg_lloyd **out, hipS
     s->ws = nullptr; s->ws_cap = 0; s->dist_blk_cap = 0;
     // one block from the processor's idle blocks (a warm processor creates a kmg_lloyd without a hipMalloc)
     const size_t sizes[6] = {sizeof(Centroid) * k, sizeof(int64_t) * 4ull * k * 2048ull, sizeof(int64_t) * 4ull * k, sizeof(uint32_t),
-                             3u * sizeof(unsigned long long), sizeof(int64_t) * 4ull * k};
+                             sizeof(unsigned long long), sizeof(int64_t) * 4ull * k};
     size_t need = 0;
     for (size_t b : sizes) need += pad256(b);
     hipError_t e = block_take(p, need, &s->ws, &s->ws_cap);
@@ -1353,12 +1353,13 @@ extern "C" int kmg_lloyd_init_centroids(kmg_lloyd *s, const uint8_t *d_rgba, uin
                                                j < s->k ? 1 : 0, s->tab.d_cdist, s->tab.d_init_cells, nullptr, rgba, s->p->d_lut,
                                                S(stream)));
             } else {
-                // launch j picks centroid j - 1 (j >= 2) and runs pass j; three keys in rotation (kmg_kernels.h)
-                HIP_TRY(launch_init_pass(rgba, n, s->p->d_lut, s->d_cent, j, s->d_dist, s->d_key, 0, S(stream), true));
+                // launch j picks centroid j - 1 (j >= 2) and runs pass j; the workgroups' keys travel through two slot sets
+                // in the partial-sum slab, which nothing else uses during the initialisation (kmg_kernels.h)
+                HIP_TRY(launch_init_pass(rgba, n, s->p->d_lut, s->d_cent, j, s->d_dist, (unsigned long long *)s->d_partials, 0, S(stream), true));
             }
         }
-        if (!colours)       // the last centroid, from the last pass's key (which it leaves zero)
-            HIP_TRY(launch_init_pick(rgba, s->p->d_lut, s->d_key + (s->k - 1u) % 3u, s->d_cent, s->k - 1u, S(stream)));
+        if (!colours)       // the last centroid, from the last pass's slots
+            HIP_TRY(launch_init_pick_slots(rgba, n, s->p->d_lut, (const unsigned long long *)s->d_partials, s->d_cent, s->k - 1u, S(stream)));
     }
     return KMG_OK;
 }
@@ -1766,6 +1767,39 @@ extern "C" int kmg_lloyd_run(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, ui
     // in between -- i.e. unless that pass is the one a convergence check follows: after the last update nothing but the
     // re-assignment may happen.
     auto checked = [&](uint32_t it) { return it > 0 && it % o.check_period == 0; };
+    if (!table && assign_loop_fits(n) && assign_loop_scratch_bytes(s->k) <= sizeof(int64_t) * 4ull * s->k * 2048ull) {
+        // Small image (the reference's default working size): one launch per iteration (kmg_kernels.h launch_assign_loop).
+        // The partial-sum slab, unused by this loop, holds its three sum buffers and the second centroid buffer.
+        hipStream_t st = S(stream);
+        if ((rc = side_flush(s, st)) != KMG_OK) return rc;
+        int64_t *acc3[3] = {s->d_partials, s->d_partials + 4ull * s->k, s->d_partials + 8ull * s->k};
+        Centroid *cur = s->d_cent, *alt = reinterpret_cast<Centroid *>(s->d_partials + 12ull * s->k);
+        HIP_TRY(hipMemsetAsync(s->d_partials, 0, sizeof(int64_t) * 12ull * s->k, st));
+        const uint32_t *px = (const uint32_t *)d_rgba;
+        s->tab.tables_valid = false;
+        // operations.rs:75-83: the initial assignment
+        PROF_LAUNCH(s, KMG_K_ASSIGN, st, launch_assign_loop(px, n, cur, alt, s->k, s->p->d_lut, d_labels, nullptr, acc3[0], acc3[1], 0,
+                                                          o.convergence, s->d_nconv, st));
+        uint32_t it = 0;
+        for (it = 0; it < o.max_iterations; ++it) {                   // modules.rs:769: update (:773-788), re-assign (:793-800)
+            const uint32_t l = it + 1u;
+            PROF_LAUNCH(s, KMG_K_ASSIGN, st, launch_assign_loop(px, n, cur, alt, s->k, s->p->d_lut, d_labels, acc3[(l + 2u) % 3u], acc3[l % 3u],
+                                                              acc3[(l + 1u) % 3u], 1, o.convergence, s->d_nconv, st));
+            std::swap(cur, alt);
+            if (checked(it)) {                                       // :802
+                uint32_t conv = 0;
+                if ((rc = kmg_lloyd_converged_count(s, &conv, stream)) != KMG_OK) return rc;
+                if (conv >= s->k) {                                  // :826-831
+                    if (log_debug()) fprintf(stderr, "[kmeans_hip] We have convergence, checked at iteration %u\n", it);
+                    break;
+                }
+            }
+        }
+        if (cur != s->d_cent) HIP_TRY(hipMemcpyAsync(s->d_cent, cur, sizeof(Centroid) * s->k, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (iterations) *iterations = it < o.max_iterations ? it : o.max_iterations - 1;
+        return KMG_OK;
+    }
     // pass(it) = the assign pass of iteration it (it = -1: the initial one); its update-after is iteration it + 1's update
     auto pass = [&](long it) -> int {
         const bool may_stop_here = it >= 0 && checked((uint32_t)it);          // a check follows this pass

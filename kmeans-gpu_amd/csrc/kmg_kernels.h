@@ -30,6 +30,15 @@ hipError_t launch_reduce_partials(const int64_t *partials, uint32_t rows, uint32
                                   int64_t *acc, hipStream_t st);
 
 // choose_centroid.wgsl `pick` for all k
+// Small images (assign_loop_fits): one launch per Lloyd iteration -- every workgroup updates its own copy of the centroids from
+// acc_in (do_update; workgroup 0 writes them to cent_out and the convergence count to n_converged), assigns, adds its sums to
+// acc_out (zero on entry) and workgroup 0 clears acc_clear.  The caller rotates three k x 4 sum buffers and two centroid
+// buffers (assign_loop_scratch_bytes(k) bytes hold the three sum buffers and the second centroid buffer).
+bool assign_loop_fits(uint64_t n_pixels);
+size_t assign_loop_scratch_bytes(uint32_t k);
+hipError_t launch_assign_loop(const uint32_t *rgba, uint64_t n, const Centroid *cent, Centroid *cent_out, uint32_t k, const float *lut,
+                              uint32_t *labels, const int64_t *acc_in, int64_t *acc_out, int64_t *acc_clear, int do_update,
+                              float convergence, uint32_t *n_converged, hipStream_t st);
 // rows x k x 4 values small enough (reduce_update_fits): reduction and -- do_update -- the update in one launch of one workgroup
 bool reduce_update_fits(uint32_t rows, uint32_t k);
 hipError_t launch_reduce_update(const int64_t *partials, uint32_t rows, uint32_t k, int64_t *acc, int do_update, float convergence,
@@ -40,11 +49,15 @@ hipError_t launch_update(const int64_t *acc, uint32_t k, float convergence, Cent
 // farthest-point init
 hipError_t launch_init_first(const uint32_t *rgba, uint64_t index, const float *lut,
                              Centroid *cent, unsigned long long *key, hipStream_t st);
-// pick = false: pass j into *key.  pick = true (whole image, one device): key[3] in rotation, the launch first picks
-// centroid j - 1 from key[(j - 1) % 3] (j >= 2), runs pass j into key[j % 3] and clears key[(j + 1) % 3]
+// pick = false: pass j into *key (atomicMax).  pick = true (whole image, one device): `key` = init_slots_bytes() of slots; the
+// launch first picks centroid j - 1 from the slots of launch j - 1 (j >= 2), runs pass j and leaves its keys in the other slot
+// set; launch_init_pick_slots picks the last centroid (j = k - 1) from the slots of the last pass
 hipError_t launch_init_pass(const uint32_t *rgba, uint64_t n, const float *lut,
                             Centroid *cent, uint32_t j, float *dist,
                             unsigned long long *key, uint64_t first_index, hipStream_t st, bool pick = false);
+size_t init_slots_bytes();
+hipError_t launch_init_pick_slots(const uint32_t *rgba, uint64_t n, const float *lut, const unsigned long long *slots, Centroid *cent,
+                                  uint32_t j, hipStream_t st);
 hipError_t launch_init_pick(const uint32_t *rgba, const float *lut, unsigned long long *key,
                             Centroid *cent, uint32_t j, hipStream_t st);
 // sharded init (row bands): publish the colour of the pixel named by an all-reduced key; set one centroid

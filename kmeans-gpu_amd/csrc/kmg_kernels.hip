@@ -189,12 +189,28 @@ __device__ __forceinline__ void argmin_scan(const PixelTerms (&pt)[PPT], float (
 // CUs -- k_assign took 97 us per Lloyd iteration of such an image at k = 256, 18 x that per default call.
 // LDS: [centroids kpad x 16 B][bins k x 32 B (ACCUM)][sRGB table 1 KiB]
 // ------------------------------------------------------------------------------------------
-template <int PPT, bool ACCUM, bool CHUNKED>
+// LOOP (small images, kmg_lloyd_run): ONE launch per Lloyd iteration (modules.rs:769-800: update, then re-assign).  Every
+// workgroup first does the update itself -- choose_centroid.wgsl:180-206 `pick` for all clusters, from the previous launch's sums
+// in loop.acc_in, on its LDS copy of the centroids (workgroup 0 also writes them to loop.cent_out and the convergence count to
+// loop.n_converged) -- then assigns, and adds its bins to loop.acc_out with atomics (integers: any order); workgroup 0 clears
+// loop.acc_clear for the launch after.  Three sum buffers and two centroid buffers in rotation, so that no launch reads what
+// it or a concurrent workgroup writes: the launch boundary is the only synchronisation.
+struct AssignLoop {
+    const int64_t *acc_in = nullptr;     // sums of the previous launch's assignment (do_update)
+    int64_t *acc_out = nullptr;          // zero on entry
+    int64_t *acc_clear = nullptr;        // cleared for the next launch
+    Centroid *cent_out = nullptr;        // the updated centroids (do_update); the launch reads `cent`
+    uint32_t *n_converged = nullptr;
+    float convergence = 0.0f;
+    int do_update = 0;
+};
+
+template <int PPT, bool ACCUM, bool CHUNKED, bool LOOP = false>
 __global__ __launch_bounds__(kBlock) void k_assign(const uint32_t *__restrict__ rgba, uint64_t n,
                                                    const Centroid *__restrict__ cent, uint32_t k,
                                                    const float *__restrict__ lut,
                                                    uint32_t *__restrict__ labels,
-                                                   int64_t *__restrict__ partials, int aligned)
+                                                   int64_t *__restrict__ partials, int aligned, AssignLoop loop)
 {
     extern __shared__ float4 smem4[];
     const uint32_t kpad = (k + 3u) & ~3u;
@@ -204,6 +220,37 @@ __global__ __launch_bounds__(kBlock) void k_assign(const uint32_t *__restrict__ 
 
     s_lut[threadIdx.x] = lut[threadIdx.x];
     stage_centroids(s_cent, cent, k, kpad);
+    if (LOOP && loop.do_update) {
+        __shared__ uint32_t s_conv;
+        const long long *sums = reinterpret_cast<const long long *>(bins);
+        for (uint32_t i = threadIdx.x; i < 4 * k; i += kBlock) bins[i] = (unsigned long long)loop.acc_in[i];
+        if (threadIdx.x == 0) s_conv = 0u;
+        __syncthreads();
+        // (update_centroids of kmg_device.h, operation for operation, on the LDS copy)
+        uint32_t mine = 0;
+        for (uint32_t c = threadIdx.x; c < k; c += kBlock) {
+            const float4 prev = s_cent[c];
+            float4 now = prev;
+            const long long count = sums[4ull * c + 3];
+            if (count > 0) {                                         // choose_centroid.wgsl:185
+                float nw[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    double mean = ((double)sums[4ull * c + j] / (double)count) * (1.0 / 1048576.0);
+                    nw[j] = (float)mean;                             // :186
+                }
+                now = make_float4(nw[0], nw[1], nw[2], chroma(nw[1], nw[2]));
+                if (cie94(nw[0], nw[1], nw[2], prev.x, prev.y, prev.z) < loop.convergence) mine += 1;   // :191
+            }                                                        // :192-194 empty: unchanged, 0
+            s_cent[c] = now;
+            if (blockIdx.x == 0) { Centroid o; o.L = now.x; o.a = now.y; o.b = now.z; o.C = now.w; loop.cent_out[c] = o; }
+        }
+        if (mine) atomicAdd(&s_conv, mine);
+        __syncthreads();
+        if (blockIdx.x == 0 && threadIdx.x == 0) *loop.n_converged = s_conv;   // :196-202
+    }
+    if (LOOP && blockIdx.x == 0)
+        for (uint32_t i = threadIdx.x; i < 4 * k; i += kBlock) loop.acc_clear[i] = 0;
     if (ACCUM)
         for (uint32_t i = threadIdx.x; i < 4 * k; i += kBlock) bins[i] = 0ull;
     __syncthreads();
@@ -285,7 +332,14 @@ __global__ __launch_bounds__(kBlock) void k_assign(const uint32_t *__restrict__ 
         }
     }
 
-    if (ACCUM) {
+    if (ACCUM && LOOP) {
+        __syncthreads();
+        unsigned long long *to = reinterpret_cast<unsigned long long *>(loop.acc_out);
+        for (uint32_t i = threadIdx.x; i < 4 * k; i += kBlock) {
+            const unsigned long long v = bins[i];
+            if (v) atomicAdd(to + i, v);                             // (only the clusters this workgroup met)
+        }
+    } else if (ACCUM) {
         __syncthreads();
         unsigned long long *row = reinterpret_cast<unsigned long long *>(partials) +
                                   (uint64_t)blockIdx.x * 4ull * k;
@@ -324,7 +378,7 @@ hipError_t launch_assign(const uint32_t *rgba, uint64_t n, const Centroid *cent,
     size_t lds = sizeof(float4) * kpad + 256 * sizeof(float);
     if (partials) lds += sizeof(unsigned long long) * 4ull * k;
 #define KMG_ASSIGN(P, A, C)                                                                                    \
-    hipLaunchKernelGGL((k_assign<P, A, C>), dim3(grid), dim3(kBlock), lds, st, rgba, n, cent, k, lut, labels, partials, aligned)
+    hipLaunchKernelGGL((k_assign<P, A, C>), dim3(grid), dim3(kBlock), lds, st, rgba, n, cent, k, lut, labels, partials, aligned, AssignLoop())
 #define KMG_ASSIGN_P(P)                                                                                        \
     do {                                                                                                       \
         if (partials) { if (chunked) KMG_ASSIGN(P, true, true); else KMG_ASSIGN(P, true, false); }             \
@@ -338,6 +392,30 @@ hipError_t launch_assign(const uint32_t *rgba, uint64_t n, const Centroid *cent,
     }
 #undef KMG_ASSIGN_P
 #undef KMG_ASSIGN
+    return hipGetLastError();
+}
+
+bool assign_loop_fits(uint64_t n) { return assign_ppt(n) == 1; }
+
+size_t assign_loop_scratch_bytes(uint32_t k) { return sizeof(int64_t) * 12ull * k + sizeof(Centroid) * k; }
+
+hipError_t launch_assign_loop(const uint32_t *rgba, uint64_t n, const Centroid *cent, Centroid *cent_out, uint32_t k, const float *lut,
+                              uint32_t *labels, const int64_t *acc_in, int64_t *acc_out, int64_t *acc_clear, int do_update,
+                              float convergence, uint32_t *n_converged, hipStream_t st)
+{
+    const uint64_t tiles = (n + kBlock - 1) / kBlock;
+    const uint32_t grid = (uint32_t)(tiles < 2048 ? (tiles ? tiles : 1) : 2048);
+    const uint32_t kpad = (k + 3u) & ~3u;
+    const int aligned = 0;                                  // (one pixel per thread: scalar loads and stores)
+    const size_t lds = sizeof(float4) * kpad + 256 * sizeof(float) + sizeof(unsigned long long) * 4ull * k;
+    AssignLoop loop;
+    loop.acc_in = acc_in; loop.acc_out = acc_out; loop.acc_clear = acc_clear; loop.cent_out = cent_out;
+    loop.n_converged = n_converged; loop.convergence = convergence; loop.do_update = do_update;
+    int64_t *no_partials = nullptr;
+    if (k >= 32)
+        hipLaunchKernelGGL((k_assign<1, true, true, true>), dim3(grid), dim3(kBlock), lds, st, rgba, n, cent, k, lut, labels, no_partials, aligned, loop);
+    else
+        hipLaunchKernelGGL((k_assign<1, true, false, true>), dim3(grid), dim3(kBlock), lds, st, rgba, n, cent, k, lut, labels, no_partials, aligned, loop);
     return hipGetLastError();
 }
 
@@ -456,7 +534,7 @@ __global__ void k_init_first(const uint32_t *__restrict__ rgba, uint64_t index,
         linear100_to_lab(lut[px & 255u], lut[(px >> 8) & 255u], lut[(px >> 16) & 255u], L, a, b);
         Centroid c; c.L = L; c.a = a; c.b = b; c.C = chroma(a, b);
         cent[0] = c;
-        key[0] = key[1] = key[2] = 0ull;                  // (three keys in rotation: k_init_pass PICK)
+        *key = 0ull;
     }
 }
 
@@ -467,11 +545,41 @@ hipError_t launch_init_first(const uint32_t *rgba, uint64_t index, const float *
     return hipGetLastError();
 }
 
-// PICK (a whole image on one device): `key` holds three keys in rotation and launch j first picks centroid j - 1 from
-// key[(j - 1) % 3] -- plus_plus_init.wgsl:172-181 `pick`, by one thread of EVERY workgroup, the same arithmetic on the same
-// pixel -- then runs pass j into key[j % 3] and clears key[(j + 1) % 3] for the next launch: one launch per pass instead of
-// two (the reference's default call initialises on a <= 256 x 256 image: 255 passes of ~5 us at k = 256, each followed by a
-// 2 us pick launch).  The last centroid is picked by k_init_pick from key[(k - 1) % 3].
+// PICK (a whole image on one device): one launch per pass, no atomics.  `key` is then an array of 2 x kInitSlots slots: launch j
+// first picks centroid j - 1 = the pixel named by the largest slot of launch j - 1 -- plus_plus_init.wgsl:172-181 `pick`, by
+// EVERY workgroup, the same arithmetic on the same pixel -- then runs pass j and leaves its workgroups' keys in the other slot
+// set.  (The reference's default call initialises on a <= 256 x 256 image: 255 passes at k = 256, each 4.9 us + a 2 us pick
+// launch; 171 workgroups' atomicMax on one address retire at ~13 ns each, 2 us at the end of every pass.)
+// The last centroid is picked by k_init_pick_slots.
+constexpr uint32_t kInitSlots = 2048;          // >= the grid of k_init_pass
+
+__device__ __forceinline__ uint32_t init_key_index(unsigned long long kk)
+{
+    uint32_t index = 0;                                       // Candidate(0, 0.0) when every distance is 0
+    if ((kk >> 32) != 0ull) {
+        const uint32_t low = (uint32_t)kk;
+        index = (low & ~15u) | (15u - (low & 15u));
+    }
+    return index;
+}
+
+// largest of n_slots keys, in thread 0 (s_key: kBlock / 64 words of LDS; ends with a barrier)
+__device__ __forceinline__ unsigned long long init_max_slot(const unsigned long long *__restrict__ slots, uint32_t n_slots,
+                                                            unsigned long long *s_key)
+{
+    unsigned long long m = 0ull;
+    for (uint32_t q = threadIdx.x; q < n_slots; q += kBlock) { const unsigned long long v = slots[q]; m = v > m ? v : m; }
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_down(m, off, 64);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0) s_key[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int w = 1; w < kBlock / 64; ++w) m = s_key[w] > m ? s_key[w] : m;
+    return m;
+}
+
 template <bool PICK>
 __global__ __launch_bounds__(kBlock) void k_init_pass(const uint32_t *__restrict__ rgba, uint64_t n,
                                                       const float *__restrict__ lut,
@@ -486,24 +594,19 @@ __global__ __launch_bounds__(kBlock) void k_init_pass(const uint32_t *__restrict
     __shared__ unsigned long long s_key[kBlock / 64];
     __shared__ Centroid s_c;
     s_lut[threadIdx.x] = lut[threadIdx.x];
-    if (PICK && j >= 2u && threadIdx.x == 0) {
-        const unsigned long long kk = key[(j - 1u) % 3u];
-        uint32_t index = 0;                                   // Candidate(0, 0.0) when every distance is 0
-        if ((kk >> 32) != 0ull) {
-            const uint32_t low = (uint32_t)kk;
-            index = (low & ~15u) | (15u - (low & 15u));
+    if (PICK && j >= 2u) {
+        const unsigned long long kk = init_max_slot(key + ((j - 1u) & 1u) * kInitSlots, gridDim.x, s_key);
+        if (threadIdx.x == 0) {
+            const uint32_t px = rgba[init_key_index(kk)];
+            float L, a, b;
+            linear100_to_lab(lut[px & 255u], lut[(px >> 8) & 255u], lut[(px >> 16) & 255u], L, a, b);
+            Centroid o; o.L = L; o.a = a; o.b = b; o.C = chroma(a, b);
+            s_c = o;
+            if (blockIdx.x == 0) cent[j - 1u] = o;
         }
-        const uint32_t px = rgba[index];
-        float L, a, b;
-        linear100_to_lab(lut[px & 255u], lut[(px >> 8) & 255u], lut[(px >> 16) & 255u], L, a, b);
-        Centroid o; o.L = L; o.a = a; o.b = b; o.C = chroma(a, b);
-        s_c = o;
-        if (blockIdx.x == 0) cent[j - 1u] = o;
     }
-    if (PICK && blockIdx.x == 0 && threadIdx.x == 0) key[(j + 1u) % 3u] = 0ull;
     __syncthreads();
     const Centroid c = (PICK && j >= 2u) ? s_c : cent[j - 1];
-    if (PICK) key += j % 3u;
     unsigned long long best = 0ull;
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
@@ -526,15 +629,46 @@ __global__ __launch_bounds__(kBlock) void k_init_pass(const uint32_t *__restrict
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < kBlock / 64; ++w) best = s_key[w] > best ? s_key[w] : best;
-        atomicMax(key, best);
+        if (PICK) key[(j & 1u) * kInitSlots + blockIdx.x] = best;
+        else atomicMax(key, best);
     }
+}
+
+// the last centroid of a PICK initialisation: from the slots of pass j
+__global__ __launch_bounds__(kBlock) void k_init_pick_slots(const uint32_t *__restrict__ rgba, const float *__restrict__ lut,
+                                                            const unsigned long long *__restrict__ slots, uint32_t n_slots,
+                                                            Centroid *__restrict__ cent, uint32_t j)
+{
+    __shared__ unsigned long long s_key[kBlock / 64];
+    const unsigned long long kk = init_max_slot(slots + (j & 1u) * kInitSlots, n_slots, s_key);
+    if (threadIdx.x == 0) {
+        const uint32_t px = rgba[init_key_index(kk)];
+        float L, a, b;
+        linear100_to_lab(lut[px & 255u], lut[(px >> 8) & 255u], lut[(px >> 16) & 255u], L, a, b);
+        Centroid o; o.L = L; o.a = a; o.b = b; o.C = chroma(a, b);
+        cent[j] = o;
+    }
+}
+
+static uint32_t init_pass_grid(uint64_t n)
+{
+    const uint64_t blocks = (n + kBlock - 1) / kBlock;
+    return (uint32_t)(blocks < kInitSlots ? (blocks ? blocks : 1) : kInitSlots);
+}
+
+size_t init_slots_bytes() { return sizeof(unsigned long long) * 2u * kInitSlots; }
+
+hipError_t launch_init_pick_slots(const uint32_t *rgba, uint64_t n, const float *lut, const unsigned long long *slots, Centroid *cent,
+                                  uint32_t j, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_init_pick_slots, dim3(1), dim3(kBlock), 0, st, rgba, lut, slots, init_pass_grid(n), cent, j);
+    return hipGetLastError();
 }
 
 hipError_t launch_init_pass(const uint32_t *rgba, uint64_t n, const float *lut, Centroid *cent,
                             uint32_t j, float *dist, unsigned long long *key, uint64_t first_index, hipStream_t st, bool pick)
 {
-    uint64_t blocks = (n + kBlock - 1) / kBlock;
-    uint32_t grid = (uint32_t)(blocks < 2048 ? (blocks ? blocks : 1) : 2048);
+    const uint32_t grid = init_pass_grid(n);
     if (pick) hipLaunchKernelGGL(k_init_pass<true>, dim3(grid), dim3(kBlock), 0, st, rgba, n, lut, cent, j, dist, key, first_index);
     else hipLaunchKernelGGL(k_init_pass<false>, dim3(grid), dim3(kBlock), 0, st, rgba, n, lut, cent, j, dist, key, first_index);
     return hipGetLastError();
