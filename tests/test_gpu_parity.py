@@ -144,7 +144,43 @@ def test_update_and_lloyd_loop(torch_cuda, processor, oracle, tokyo):
     s.close()
 
 
-@pytest.mark.parametrize("k", [1, 2, 3, 4, 8, 33, 256])     # (the keys of the passes rotate through three slots)
+@pytest.mark.parametrize("k,max_it,period,conv", [(1, 128, 8, 1.0), (5, 128, 8, 1.0), (33, 128, 8, 1.0), (64, 128, 8, 1.0),
+                                                  (12, 5, 8, 1.0), (12, 9, 8, 1.0), (12, 128, 3, 1.0), (40, 128, 1, 0.05),
+                                                  (7, 1, 8, 1.0), (300, 20, 4, 1.0)])
+def test_lloyd_loop_on_a_small_image_one_launch_per_iteration(torch_cuda, oracle, k, max_it, period, conv):
+    """modules.rs:763-840 on the reference's working size (an image of <= 65 536 pixels): kmg_lloyd_run takes one launch per
+    iteration there (update in every workgroup's prologue, sums through rotating buffers).  Iteration count, centroids and
+    labels equal the oracle's for iteration caps and check periods that end the loop in every position of the rotation."""
+    import kmeans_gpu_amd as kg
+    torch = torch_cuda
+    rng = np.random.default_rng(k * 1000 + max_it)
+    w, h = 211, 157
+    c = rng.integers(0, 256, (9, 3))
+    px = c[rng.integers(0, 9, w * h)] + rng.normal(0, 14.0, (w * h, 3))
+    rgba = np.full((w * h, 4), 255, np.uint8)
+    rgba[:, :3] = np.clip(np.rint(px), 0, 255).astype(np.uint8)
+    lab = oracle.rgb_to_lab(rgba)
+    init = oracle.init_centroids(lab, w, h, k)
+    want_c, want_labels, want_it = oracle.lloyd(lab, init, max_iterations=max_it, check_period=period, convergence=conv)
+    p = kg.ImageProcessor(max_iterations=max_it, check_period=period, convergence=conv)
+    d = _dev(torch, rgba)
+    labels = torch.zeros(w * h, dtype=torch.int32, device="cuda")
+    s = kg.Lloyd(p, k)
+    s.set_centroids(init)
+    it = s.run(d.data_ptr(), w * h, labels.data_ptr(), _stream(torch))
+    assert it == want_it
+    assert np.array_equal(s.get_centroids().view(np.uint32), want_c.view(np.uint32))
+    assert np.array_equal(labels.cpu().numpy().view(np.uint32), want_labels)
+    # a second run on the same object starts from the centroids the first one left (and from clean sum buffers)
+    want_c2, want_labels2, want_it2 = oracle.lloyd(lab, want_c, max_iterations=max_it, check_period=period, convergence=conv)
+    it2 = s.run(d.data_ptr(), w * h, labels.data_ptr(), _stream(torch))
+    assert it2 == want_it2
+    assert np.array_equal(s.get_centroids().view(np.uint32), want_c2.view(np.uint32))
+    assert np.array_equal(labels.cpu().numpy().view(np.uint32), want_labels2)
+    s.close(); p.close()
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 8, 33, 256])     # (the workgroups' keys travel through two slot sets)
 def test_init_centroids(torch_cuda, processor, oracle, tokyo, k):
     """S12 farthest-point init incl. its arg-max tie rule"""
     import kmeans_gpu_amd as kg
