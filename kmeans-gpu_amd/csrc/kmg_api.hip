@@ -580,7 +580,9 @@ static bool table_pays(uint64_t n, uint32_t k, bool labels)
         if (!strcmp(e, "table")) return true;
     }
     const double N = (double)n;
-    const double brute = 1.4e-5 + 3.3e-7 * k + N * (6.8e-12 + 2.45e-13 * k);
+    // (per-pixel scan: assign + reduce + update launches 11 us + 0.09 us per cluster, then 7.5 + 0.245 k ps per pixel --
+    // round 4, after k_assign's pixels per thread followed the image size: tools/strategy_sweep.py, profiles/r04_strategy_sweep.txt)
+    const double brute = 1.1e-5 + 9.3e-8 * k + N * (7.5e-12 + 2.45e-13 * k);
     const double label_pass = labels ? N * (k <= 256 ? 1.8e-12 + 2.0e-15 * k : 6.7e-12) : 0.0;
     // (k <= 32: the one-launch cube pass of small centroid tables, k_cube_small -- 58 us at k = 16, round 4)
     const double cube = k <= 32u ? 5.6e-5 + 2.0e-7 * k : 8.6e-5 + 1.85e-7 * k;
