@@ -594,8 +594,19 @@ __global__ __launch_bounds__(kBlock) void k_init_pass(const uint32_t *__restrict
     __shared__ unsigned long long s_key[kBlock / 64];
     __shared__ Centroid s_c;
     s_lut[threadIdx.x] = lut[threadIdx.x];
+    // (this thread's first pixel and its running distance do not depend on the new centroid: requested before the pick, whose
+    // chain of two dependent loads and a Lab conversion they then overlap -- a pass is a chain of round trips, 4.6 -> ~4 us)
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    const uint64_t i_first = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    uint32_t px_first = 0u;
+    float d_first = 1000000.0f;
+    if (PICK && i_first < n) {
+        px_first = rgba[i_first];
+        if (j != 1) d_first = dist[i_first];
+    }
+    float L_first = 0.0f, a_first = 0.0f, b_first = 0.0f;
     if (PICK && j >= 2u) {
-        const unsigned long long kk = init_max_slot(key + ((j - 1u) & 1u) * kInitSlots, gridDim.x, s_key);
+        const unsigned long long kk = init_max_slot(key + ((j - 1u) & 1u) * kInitSlots, gridDim.x, s_key);   // (a barrier inside: s_lut is there)
         if (threadIdx.x == 0) {
             const uint32_t px = rgba[init_key_index(kk)];
             float L, a, b;
@@ -604,17 +615,23 @@ __global__ __launch_bounds__(kBlock) void k_init_pass(const uint32_t *__restrict
             s_c = o;
             if (blockIdx.x == 0) cent[j - 1u] = o;
         }
+        px_to_lab(s_lut, px_first, L_first, a_first, b_first);
     }
     __syncthreads();
+    if (PICK && j < 2u) px_to_lab(s_lut, px_first, L_first, a_first, b_first);
     const Centroid c = (PICK && j >= 2u) ? s_c : cent[j - 1];
     unsigned long long best = 0ull;
-    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-        float L, a, b;
-        px_to_lab(s_lut, rgba[i], L, a, b);
+    for (uint64_t i = i_first; i < n; i += stride) {
+        float L, a, b, before;
+        if (PICK && i == i_first) {
+            L = L_first; a = a_first; b = b_first; before = d_first;
+        } else {
+            px_to_lab(s_lut, rgba[i], L, a, b);
+            before = j == 1 ? 1000000.0f : dist[i];
+        }
         // kmeans++_calc_diff.wgsl:26-30; the running minimum equals the recomputed one
         float d = cie94(L, a, b, c.L, c.a, c.b);
-        float m = fminf(j == 1 ? 1000000.0f : dist[i], d);
+        float m = fminf(before, d);
         dist[i] = m;
         const uint64_t gi = first_index + i;
         unsigned long long kk = ((unsigned long long)float_to_bits(m) << 32) |
