@@ -35,6 +35,12 @@ __global__ __launch_bounds__(1024) void k_gather(const uint32_t *__restrict__ id
 #pragma unroll
             for (int p = 0; p < 8; ++p)
                 if ((fm >> p) & 1u) r[p] = tab[v[p] & mask];
+        } else if (MODE == 2) {
+            // the aligned dword that holds the byte, then a shift: is a sub-dword load dearer than a dword load?
+            const uint32_t *tab32 = reinterpret_cast<const uint32_t *>(tab);
+#pragma unroll
+            for (int p = 0; p < 8; ++p)
+                if ((fm >> p) & 1u) { const uint32_t a = v[p] & mask; r[p] = (tab32[a >> 2] >> ((a & 3u) * 8u)) & 255u; }
         } else if (MODE == 1) {
             while (__ballot(fm != 0u)) {
                 const uint32_t p = fm ? (uint32_t)__builtin_ctz(fm) : 8u;
@@ -84,7 +90,8 @@ int main()
             // (dynamic LDS of 128 KiB: one workgroup per CU, as the label pass)
             float a = time([&] { hipLaunchKernelGGL((k_gather<0>), dim3(256), dim3(1024), 128 << 10, 0, idx, n, tab, mask, pct, out); });
             float b = time([&] { hipLaunchKernelGGL((k_gather<1>), dim3(256), dim3(1024), 128 << 10, 0, idx, n, tab, mask, pct, out); });
-            printf("table 2^%-2u B  active %3u %%   masked x8 %.1f us   compacted %.1f us\n", bits, pct, a * 1e3, b * 1e3);
+            float c = time([&] { hipLaunchKernelGGL((k_gather<2>), dim3(256), dim3(1024), 128 << 10, 0, idx, n, tab, mask, pct, out); });
+            printf("table 2^%-2u B  active %3u %%   masked x8 %.1f us   compacted %.1f us   dword loads %.1f us\n", bits, pct, a * 1e3, b * 1e3, c * 1e3);
         }
     return 0;
 }
