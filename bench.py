@@ -611,19 +611,53 @@ def main():
     first.close()
     lloyd, strategy, t_prep = prepared()
 
-    want_cells = bool(args.cells) or (args.scaling == "strong" and not args.no_cells)
-    cells = want_cells and world > 1 and strategy == "table" and k <= 256
-    sh = ShardedLloyd(lloyd, k, rgba, labels, stream=stream, cells=cells)
-    if cells:
-        sh.bind_cells(n_local * world)        # once per image: band histograms all-reduced, this rank's share of the cube
-    sh.split_labels = strategy == "table"     # the all-reduce overlaps the label-gather pass
-    sh.pipeline = bool(args.overlap) and not args.no_overlap
-    sh.fused = not args.separate_update       # one rank + colour table: the update rides on the assign pass's last launch
-    if args.force_dist:
-        sh.world = 2          # take the collective path even though the group has one rank
-    sh.prime()
-    for _ in range(args.warmup):
-        sh.iterate()
+    def make_loop(lloyd_, cells_):
+        sh_ = ShardedLloyd(lloyd_, k, rgba, labels, stream=stream, cells=cells_)
+        if cells_:
+            sh_.bind_cells(n_local * world)   # once per image: band histograms all-reduced, this rank's share of the cube
+        sh_.split_labels = strategy == "table"     # the all-reduce overlaps the label-gather pass
+        sh_.pipeline = bool(args.overlap) and not args.no_overlap
+        sh_.fused = not args.separate_update       # one rank + colour table: the update rides on the assign pass's last launch
+        if args.force_dist:
+            sh_.world = 2         # take the collective path even though the group has one rank
+        sh_.prime()
+        for _ in range(args.warmup):
+            sh_.iterate()
+        return sh_
+
+    cells_possible = world > 1 and strategy == "table" and k <= 256
+    picked = None
+    if cells_possible and args.scaling == "strong" and not args.cells and not args.no_cells:
+        # One image over N GPUs has two shapes: row bands with a cell-sharded cube pass (the cube pass shrinks with N, the label
+        # tables are all-gathered every iteration: 16 MiB / N per rank at k <= 256) or row bands alone (every rank labels the whole
+        # cube for its band, one k x 4 all-reduce).  Which one wins depends on what an all-gather of 16 MiB costs on the node's
+        # fabric, which no run of this project has met yet -- so both are timed here, outside the timed region (a few iterations
+        # each, MAX over the ranks), and the faster one is the loop that is measured.  Reported in config.sharding_choice.
+        trial = {}
+        loops = {}
+        for name, cells_ in (("cells", True), ("bands", False)):
+            l_ = lloyd if name == "cells" else prepared()[0]
+            sh_ = make_loop(l_, cells_)
+            sh_.flush(); torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            t_ = time.perf_counter()
+            for _ in range(5):
+                sh_.iterate()
+            sh_.flush(); torch.cuda.synchronize()
+            tt = torch.tensor([time.perf_counter() - t_], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            trial[name] = float(tt.item()) / 5 * 1e3
+            loops[name] = (l_, sh_)
+        best = min(trial, key=trial.get)             # (the same on every rank: the times were all-reduced)
+        for name, (l_, sh_) in loops.items():
+            if name != best:
+                sh_.close(); l_.close()
+        lloyd, sh = loops[best]
+        cells = best == "cells"
+        picked = {"picked": best, "cells_ms_per_step": trial["cells"], "bands_ms_per_step": trial["bands"]}
+    else:
+        want_cells = bool(args.cells) or (args.scaling == "strong" and not args.no_cells)
+        cells = want_cells and cells_possible
+        sh = make_loop(lloyd, cells)
 
     def fence():
         sh.flush()
@@ -753,7 +787,8 @@ def main():
                        "strategy": strategy, "prepare_ms": t_prep * 1e3, "prepare_cold_ms": t_prep_cold * 1e3,
                        "label_pass": "beside the next iteration's cube pass" if sh.pipeline else "before the next iteration",
                        "update": "by the last launch of the assign pass (kmg_lloyd_assign_update)" if sh._fused()
-                                 else "k_update launch"},
+                                 else "k_update launch",
+                       **({"sharding_choice": picked} if picked else {})},
             "roofline": {"bound": "hbm", "kernel": dominant,
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS,

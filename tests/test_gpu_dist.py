@@ -67,5 +67,15 @@ def test_bench_multi_gpu_path_rehearsed_on_one_gpu(torch_cuda):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["metric"].endswith("(8192x8192, k=256)")
-    assert "cube pass sharded by cells" in line["config"]["sharding"] and line["value"] > 0
+    # both shapes of "one image over N GPUs" were tried and the faster one measured
+    choice = line["config"]["sharding_choice"]
+    assert choice["cells_ms_per_step"] > 0 and choice["bands_ms_per_step"] > 0 and choice["picked"] in ("cells", "bands")
+    assert ("cube pass sharded by cells" in line["config"]["sharding"]) == (choice["picked"] == "cells") and line["value"] > 0
     assert line["extra"]["weak_scaling_value"] > 0
+    # and the cell-sharded loop when asked for
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--rehearse", "--cells", "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert "cube pass sharded by cells" in line["config"]["sharding"] and "sharding_choice" not in line["config"] and line["value"] > 0
