@@ -681,8 +681,10 @@ __global__ __launch_bounds__(kBlock) void k_cube_scan(const uint32_t *__restrict
             scan_set &= scan_set - 1u;                                                                           \
             const uint32_t c0_ = cell * kCellColours + (X##_s0 & 7u) * 64u + lane;                               \
             const uint32_t c1_ = cell * kCellColours + (X##_s1 & 7u) * 64u + lane;                               \
-            X##_v0 = lab_table[c0_];                                                                             \
-            X##_v1 = lab_table[c1_];                                /* s1 == 8: sub-cell 0 again, unused */      \
+            /* (knock-out, tools only, results wrong: flag bit 20 = the Lab rows from a cache-resident 64 KiB window) */ \
+            const uint32_t km_ = (flags & 0x100000u) ? 0xFFFu : 0xFFFFFFFFu;                                     \
+            X##_v0 = lab_table[c0_ & km_];                                                                       \
+            X##_v1 = lab_table[c1_ & km_];                          /* s1 == 8: sub-cell 0 again, unused */      \
             if (SUMS) { X##_c0 = hist[c0_]; X##_c1 = hist[c1_]; }                                                \
         } while (0)
         KMG_REQUEST_COLOURS(A);
@@ -1494,7 +1496,7 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
     const uint32_t kpad = (k + 63u) & ~63u;
     const bool with_sums = hist != nullptr;
     const uint32_t repl = with_sums ? cube_replicas(k) : 1u;
-    if (const char *e = getenv("KMG_CUBE_FLAGS")) flags |= (uint32_t)strtoul(e, nullptr, 0) & 0xFF00u;
+    if (const char *e = getenv("KMG_CUBE_FLAGS")) flags |= (uint32_t)strtoul(e, nullptr, 0) & 0x10FF00u;
     const size_t lds_stage = sizeof(float4) * kpad + (with_sums ? sizeof(unsigned long long) * 4ull * k : 0) +
                              sizeof(uint32_t) * (kBlock / 64) * kMaxListed + sizeof(unsigned long long) * (kBlock / 64) * (kpad / 64u) +
                              (k <= 256 ? (kBlock / 64) * (32u * sizeof(unsigned long long) + kMaxLong * sizeof(uint16_t)) : 0u);
