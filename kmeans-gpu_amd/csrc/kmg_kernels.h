@@ -58,8 +58,6 @@ hipError_t launch_init_pass(const uint32_t *rgba, uint64_t n, const float *lut,
 size_t init_slots_bytes();
 hipError_t launch_init_pick_slots(const uint32_t *rgba, uint64_t n, const float *lut, const unsigned long long *slots, Centroid *cent,
                                   uint32_t j, hipStream_t st);
-hipError_t launch_init_pick(const uint32_t *rgba, const float *lut, unsigned long long *key,
-                            Centroid *cent, uint32_t j, hipStream_t st);
 // sharded init (row bands): publish the colour of the pixel named by an all-reduced key; set one centroid
 hipError_t launch_init_pick_band(const uint32_t *rgba, uint64_t n, uint64_t first_index,
                                  const unsigned long long *key, uint32_t *colour2, hipStream_t st);

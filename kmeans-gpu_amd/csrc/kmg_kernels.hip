@@ -736,34 +736,6 @@ hipError_t launch_set_centroid_rgba(const uint32_t *colour, const float *lut, Ce
     return hipGetLastError();
 }
 
-__global__ void k_init_pick(const uint32_t *__restrict__ rgba, const float *__restrict__ lut,
-                            unsigned long long *__restrict__ key, Centroid *__restrict__ cent,
-                            uint32_t j)
-{
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        // plus_plus_init.wgsl:172-181 `pick`
-        const unsigned long long kk = *key;
-        uint32_t index = 0;
-        if ((kk >> 32) != 0ull) {
-            uint32_t low = (uint32_t)kk;
-            index = (low & ~15u) | (15u - (low & 15u));
-        }
-        uint32_t px = rgba[index];
-        float L, a, b;
-        linear100_to_lab(lut[px & 255u], lut[(px >> 8) & 255u], lut[(px >> 16) & 255u], L, a, b);
-        Centroid c; c.L = L; c.a = a; c.b = b; c.C = chroma(a, b);
-        cent[j] = c;
-        *key = 0ull;
-    }
-}
-
-hipError_t launch_init_pick(const uint32_t *rgba, const float *lut, unsigned long long *key,
-                            Centroid *cent, uint32_t j, hipStream_t st)
-{
-    hipLaunchKernelGGL(k_init_pick, dim3(1), dim3(64), 0, st, rgba, lut, key, cent, j);
-    return hipGetLastError();
-}
-
 // ------------------------------------------------------------------------------------------
 // Bilinear shrink (resize.wgsl:7-18 + the sampler of structures.rs:121-131): uv = gid / dims,
 // clamp-to-edge, linear filter with exact f32 weights, x first then y, rgba8unorm store.
