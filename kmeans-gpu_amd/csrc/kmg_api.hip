@@ -221,7 +221,8 @@ struct kmg_lloyd {
     kmg_processor *p;
     uint32_t k;
     Centroid *d_cent;            // k
-    int64_t *d_partials;         // 2048 x k x 4
+    int64_t *d_partials;         // 2048 x k x 4: partial sums of the per-pixel scan; between passes also scratch of whoever runs --
+                                 // the key slots of a per-pixel initialisation, the sum / centroid rotation of the small-image loop
     int64_t *d_acc;              // k x 4 (used by kmg_lloyd_run)
     int64_t *d_acc_int;          // k x 4: where the cube pass accumulates; ZERO between passes (its last launch hands the sums
                                  // over and clears it, kmg_table.h CubeTail) -- no memset launch per pass
