@@ -31,7 +31,8 @@ def test_bench_extras_run_without_error(torch_cuda, oracle):
     assert "error" not in extra, extra["error"]
     for key in ("find_dither_k64_ms", "find_replace_k64_ms", "iteration_without_label_map_ms", "cfg3_init_ms",
                 "cfg3_lloyd_and_labels_ms", "cfg3_dither_ms", "blobs_ms_per_step", "photo_ms_per_step",
-                "cfg4_rank_share_ms_per_iteration", "cfg4_tiled_rank_share_ms_per_iteration", "reduce_host_to_host_warm_ms"):
+                "cfg4_rank_share_ms_per_iteration", "cfg4_tiled_rank_share_ms_per_iteration", "reduce_host_to_host_warm_ms",
+                "cfg2_ms_per_step", "cfg1_reduce_tokyo_k8_replace_ms", "default_palette_tokyo_k256_ms"):
         assert key in extra and extra[key] > 0, key
     lloyd.close()
     proc.close()
