@@ -180,6 +180,33 @@ def test_lloyd_loop_on_a_small_image_one_launch_per_iteration(torch_cuda, oracle
     s.close(); p.close()
 
 
+@pytest.mark.parametrize("w,h,k", [(1000, 650, 6), (1400, 900, 33)])
+def test_lloyd_loop_per_pixel_scan_on_mid_size_images(torch_cuda, oracle, monkeypatch, w, h, k):
+    """kmg_lloyd_run with the per-pixel scan on images of 2^19 ... 2^21 pixels (2 and 4 pixels per thread, the partial-sum slab and the
+    separate reduce / update launches): iteration count, centroids and labels equal the oracle's"""
+    import kmeans_gpu_amd as kg
+    torch = torch_cuda
+    monkeypatch.setenv("KMG_STRATEGY", "brute")
+    rng = np.random.default_rng(w + k)
+    c = rng.integers(0, 256, (11, 3))
+    px = c[rng.integers(0, 11, w * h)] + rng.normal(0, 20.0, (w * h, 3))
+    rgba = np.full((w * h, 4), 255, np.uint8)
+    rgba[:, :3] = np.clip(np.rint(px), 0, 255).astype(np.uint8)
+    lab = oracle.rgb_to_lab(rgba)
+    init = oracle.centroids4(lab[rng.choice(w * h, k, replace=False)])
+    want_c, want_labels, want_it = oracle.lloyd(lab, init, max_iterations=10, check_period=4)
+    p = kg.ImageProcessor(shrink_max_dim=0, max_iterations=10, check_period=4)
+    d = _dev(torch, rgba)
+    labels = torch.zeros(w * h, dtype=torch.int32, device="cuda")
+    s = kg.Lloyd(p, k)
+    s.set_centroids(init)
+    it = s.run(d.data_ptr(), w * h, labels.data_ptr(), _stream(torch))
+    assert it == want_it
+    assert np.array_equal(s.get_centroids().view(np.uint32), want_c.view(np.uint32))
+    assert np.array_equal(labels.cpu().numpy().view(np.uint32), want_labels)
+    s.close(); p.close()
+
+
 @pytest.mark.parametrize("k", [1, 2, 3, 4, 8, 33, 256])     # (the workgroups' keys travel through two slot sets)
 def test_init_centroids(torch_cuda, processor, oracle, tokyo, k):
     """S12 farthest-point init incl. its arg-max tie rule"""
