@@ -81,7 +81,8 @@ __device__ __forceinline__ long long wave_sum(long long v)
 // DPP cross-lane moves (no LDS traffic): src of lane i = lane perm(i) within its row of 16.  For the permutations used
 // through these two helpers (quad_perm, row_mirror, row_half_mirror) every lane has a source, so `old` is never taken: old = 0
 // with bound_ctrl lets the compiler fold the move into the operation that consumes it (v_min_f32_dpp, v_add_u32_dpp ...:
-// one instruction per reduction step instead of copy + v_mov_b32_dpp + operation)
+// one instruction per reduction step instead of copy + v_mov_b32_dpp + operation).  Call them with every lane of the wave
+// active: a lane switched off reads as 0, which is the identity of sum, or and unsigned max but not of a minimum.
 template <int CTRL>
 __device__ __forceinline__ float dpp_f32(float v)
 {
