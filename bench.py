@@ -556,7 +556,20 @@ def main():
         if args.rehearse:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            # RCCL prints a version banner on STDOUT when its communicator is created: that happens here (device_id = eager
+            # creation) or at the first collective -- both with stdout pointed at stderr, so that the JSON line is all stdout carries
+            sys.stdout.flush()
+            saved_stdout = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                warm = torch.zeros(1, device="cuda")
+                dist.all_reduce(warm)
+                torch.cuda.synchronize()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved_stdout, 1)
+                os.close(saved_stdout)
 
     k = args.k
     # N > 1 measures what BASELINE.json's north_star claims: the ONE 8192x8192 image over 1 / 2 / 4 / 8 GPUs (strong scaling;
