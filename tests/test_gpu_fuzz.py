@@ -28,3 +28,14 @@ def test_alternative_cube_passes_of_small_centroid_tables(mode):
                        timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "24 cases, 0 mismatching" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [3, 4])
+def test_random_default_calls_equal_the_oracle(seed):
+    """tools/fuzz_default_call.py: kmg_reduce / kmg_palette at the reference's defaults (shrink to <= 256, init, Lloyd loop, output
+    pass -- lib.rs:116-164) of random images, k and modes against oracle.reduce / oracle.palette, byte for byte"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_default_call.py"), "30", str(seed)],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "30 cases, 0 mismatching" in r.stdout
