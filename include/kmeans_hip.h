@@ -331,6 +331,107 @@ KMG_API void kmg_apply_plan_destroy(kmg_apply_plan *plan, int synchronise);
 /* mix_colors.wgsl:53-67: the dither threshold of a centroid table (host helper).             */
 KMG_API int kmg_dither_threshold(const float *centroids4, uint32_t k, float *threshold);
 
+/* ======================= several GPUs: a group of devices ================================
+ * ImageProcessor::new (core/src/lib.rs:38-65) picks ONE adapter; the reference has no multi-device path.  A kmg_group is the
+ * same constructor over a device LIST: one kmg_processor, one compute stream and one RCCL communicator rank per device.
+ * RCCL is loaded at run time (dlopen of librccl.so.1 -- the copy a host process already maps, e.g. PyTorch's, is reused),
+ * so a single-GPU host needs no RCCL at all.  The path's one exchange step is ncclAllReduce(sum) of the
+ * k x 4 int64 accumulators over xGMI between the assign pass and the centroid update; because the sums are exact integers,
+ * centroids and labels are bit-identical for any number of devices.
+ *
+ *   one process, n devices   kmg_group_create: ncclCommInitAll, one worker thread per device inside the library; the
+ *                            host-buffer calls kmg_group_{palette, find, reduce} tile one image in row bands (device g of G
+ *                            owns rows [g H / G, (g + 1) H / G)), kmg_group_reduce_batch places whole images (BASELINE
+ *                            config 4: no collective at all).
+ *   one process per GPU      rank 0 calls kmg_group_unique_id, the host runtime hands the 128 bytes to every process (MPI,
+ *                            a file, torch.distributed ...), each calls kmg_group_create_rank(first_rank = its rank): the
+ *                            kmg_group_lloyd_* calls then drive THIS process's band(s) of the sharded image.
+ * Ranks are numbered first_rank + i for the group's local device i; `world` = ranks over all processes.                  */
+#define KMG_MAX_DEVICES 16
+#define KMG_UNIQUE_ID_BYTES 128
+/* kmg_group_options.flags */
+#define KMG_GROUP_FORCE_COLLECTIVES 1u /* issue every collective even in a world of ONE rank (a one-GPU box then drives the
+                                          RCCL calls exactly as a multi-rank job does: tests)                              */
+#define KMG_GROUP_LOOPBACK          2u /* exchange through this process's device memory instead of RCCL; the device list may
+                                          then name a device more than once (RCCL refuses two ranks on one device) -- the
+                                          multi-rank code path on a one-GPU box (tests); one process only                  */
+typedef struct kmg_group_options {
+    uint32_t struct_size;               /* sizeof(kmg_group_options)                                                    */
+    uint32_t n_devices;                 /* 0 = every visible HIP device, in ordinal order                               */
+    int32_t  devices[KMG_MAX_DEVICES];  /* HIP device ordinals of the n_devices local ranks                             */
+    uint32_t flags;                     /* KMG_GROUP_*                                                                  */
+    kmg_options processor;              /* options of every member processor (its `device` field is ignored)            */
+} kmg_group_options;
+
+typedef struct kmg_group kmg_group;
+typedef struct kmg_group_lloyd kmg_group_lloyd;
+
+KMG_API void kmg_default_group_options(kmg_group_options *opt);
+KMG_API int kmg_group_create(const kmg_group_options *opt, kmg_group **out);
+KMG_API int kmg_group_unique_id(uint8_t id[KMG_UNIQUE_ID_BYTES]);
+KMG_API int kmg_group_create_rank(const kmg_group_options *opt, const uint8_t id[KMG_UNIQUE_ID_BYTES], uint32_t first_rank,
+                                  uint32_t world, kmg_group **out);
+KMG_API void kmg_group_destroy(kmg_group *g);
+/* n_local = devices of this process, first_rank / world as above, rccl_version = ncclGetVersion() or 0 when RCCL was not
+ * needed (one rank without KMG_GROUP_FORCE_COLLECTIVES, or KMG_GROUP_LOOPBACK).  Any out pointer may be NULL.            */
+KMG_API int kmg_group_info(kmg_group *g, uint32_t *n_local, uint32_t *first_rank, uint32_t *world, int *rccl_version);
+/* local device i's processor / compute stream (hipStream_t): everything the group enqueues for that device runs on it   */
+KMG_API kmg_processor *kmg_group_processor(kmg_group *g, uint32_t i);
+KMG_API void *kmg_group_stream(kmg_group *g, uint32_t i);
+
+/* ---- ImageProcessor::{palette, find, reduce} (core/src/lib.rs:67-164) on a one-process group: same arguments and results
+ * as kmg_palette / kmg_find / kmg_reduce, byte for byte.  Every device uploads its band (and one halo row for the bilinear
+ * shrink), shrinks its share of the <= 256-pixel working image (structures.rs:67-182), device 0 runs the k-means of that tiny
+ * image (launch-bound: nothing to shard), and every device runs the output pass of its band -- the step that touches every
+ * pixel -- and downloads it.  With shrink_max_dim = 0 and an image of at least 2^20 pixels the k-means itself runs sharded
+ * (kmg_group_lloyd_*: initialisation, loop and the RCCL all-reduce per iteration).                                        */
+KMG_API int kmg_group_palette(kmg_group *g, const uint8_t *rgba, uint32_t width, uint32_t height, uint32_t color_count, int algo,
+                              uint8_t *out_rgba, uint32_t *out_count);
+KMG_API int kmg_group_find(kmg_group *g, const uint8_t *rgba, uint32_t width, uint32_t height, const uint8_t *palette_rgba,
+                           uint32_t n_colors, int mode, uint8_t *out_rgba);
+KMG_API int kmg_group_reduce(kmg_group *g, const uint8_t *rgba, uint32_t width, uint32_t height, uint32_t color_count, int algo,
+                             int mode, uint8_t *out_rgba);
+/* A batch of images, WHOLE images per device (image i on local device i % n_local), no collective: kmg_reduce of every image
+ * on its device's processor, the devices side by side (BASELINE config 4 as this build places it).  Returns the first failure.  */
+KMG_API int kmg_group_reduce_batch(kmg_group *g, uint32_t n_images, const uint8_t *const *rgba, const uint32_t *widths,
+                                   const uint32_t *heights, uint32_t color_count, int algo, int mode, uint8_t *const *out_rgba);
+
+/* ---- ChooseCentroidModule::compute (core/src/modules.rs:763-840) over row bands that are resident on the group's devices.
+ * d_rgba[i] (device memory of local device i) holds image rows [row0[i], row0[i] + rows[i]) of a width x height image,
+ * d_labels[i] (optional, may be NULL as a whole) receives that band's u32 label map; rows[i] may be 0.  The bands of all
+ * ranks of the world tile the image.  _bind only records the bands (it may be called again for a new image); the calls below
+ * enqueue on the devices' compute streams and return -- only _run, _sync and _get_centroids synchronise.
+ *   _init       PlusPlusInitModule::compute (modules.rs:946-1246) sharded: per centroid a MAX all-reduce of the 64-bit
+ *               arg-max key and a SUM all-reduce of {colour, 1} (kmg_lloyd_init_step / _init_pick_band)
+ *   _prime      the initial assignment (operations.rs:75-83) with its sums, all-reduced
+ *   _step       one iteration (modules.rs:769-800): centroid update from the global sums, labels + sums of the new
+ *               assignment, all-reduce of the sums
+ *   _run        _prime, then _step until the convergence count read every check_period-th iteration reaches k or
+ *               max_iterations (kmg_options of the group's processors); *iterations as kmg_lloyd_run
+ * flags (kmg_group_lloyd_bind):                                                                                            */
+#define KMG_GROUP_CELLS   1u /* strong scaling of ONE image (colour table, k <= 256): the cube pass is sharded by cells of the
+                                colour cube as well -- band histograms all-reduced once per image, per iteration the k x 4
+                                all-reduce and an in-place all-gather of the label tables (kmg_lloyd_set_cell_share)        */
+#define KMG_GROUP_OVERLAP 2u /* the all-reduce of the sums runs on a second stream beside the label pass (two cross-stream
+                                dependencies per iteration) instead of in line on the compute stream                       */
+#define KMG_GROUP_FUSED_UPDATE 4u /* a world of ONE rank without collectives: _prime and _step are kmg_lloyd_assign_update (assign,
+                                     then the update on the assign pass's last launch) -- per call still one assignment with its
+                                     label map and one update, shifted by half a step; refused by _run, which reads the
+                                     convergence count between update and re-assignment                                        */
+KMG_API int kmg_group_lloyd_create(kmg_group *g, uint32_t k, kmg_group_lloyd **out);
+KMG_API void kmg_group_lloyd_destroy(kmg_group_lloyd *gl);
+KMG_API int kmg_group_lloyd_bind(kmg_group_lloyd *gl, const uint8_t *const *d_rgba, const uint32_t *row0, const uint32_t *rows,
+                                 uint32_t width, uint32_t height, uint32_t *const *d_labels, uint32_t flags);
+KMG_API int kmg_group_lloyd_set_centroids(kmg_group_lloyd *gl, const float *centroids4);
+KMG_API int kmg_group_lloyd_get_centroids(kmg_group_lloyd *gl, float *centroids4);
+KMG_API int kmg_group_lloyd_init(kmg_group_lloyd *gl);
+KMG_API int kmg_group_lloyd_prime(kmg_group_lloyd *gl);
+KMG_API int kmg_group_lloyd_step(kmg_group_lloyd *gl);
+KMG_API int kmg_group_lloyd_sync(kmg_group_lloyd *gl);
+KMG_API int kmg_group_lloyd_run(kmg_group_lloyd *gl, uint32_t *iterations);
+/* local device i's kmg_lloyd (profiling, statistics) and "table" (1) / "scan" (0) strategy of its band, once primed          */
+KMG_API kmg_lloyd *kmg_group_lloyd_member(kmg_group_lloyd *gl, uint32_t i, int *strategy);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "kmg_color.h"
+#include "kmg_internal.h"
 #include "kmg_kernels.h"
 #include "kmg_octree.h"
 #include "kmg_table.h"
@@ -31,7 +32,7 @@ using namespace kmg;
 // ---------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
 
-static int fail(int code, const char *fmt, ...)
+int kmg::fail(int code, const char *fmt, ...)
 {
     va_list ap;
     va_start(ap, fmt);
@@ -71,7 +72,7 @@ static int fail(int code, const char *fmt, ...)
         }                                                                                      \
     } while (0)
 
-static bool log_debug()
+bool kmg::log_debug()
 {
     const char *lv = getenv("KMG_LOG");
     return lv && !strcmp(lv, "debug");
@@ -2154,7 +2155,9 @@ int extract_palette_kmeans(kmg_processor *p, const uint8_t *d_rgba, uint32_t w, 
 // 26-40 ms as one copy).
 constexpr size_t kCopyParts = 4;
 
-static hipError_t copy_host_image(kmg_processor *p, void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t st)
+}  // namespace
+
+hipError_t kmg::copy_host_image(kmg_processor *p, void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t st)
 {
     if (bytes < ((size_t)1 << 20)) return hipMemcpyAsync(dst, src, bytes, kind, st);
     hipError_t e = hipStreamSynchronize(st);
@@ -2185,6 +2188,8 @@ static hipError_t copy_host_image(kmg_processor *p, void *dst, const void *src, 
         if (results[i] != hipSuccess) return results[i];
     return hipSuccess;
 }
+
+namespace {
 
 int upload_image(kmg_processor *p, const uint8_t *rgba, uint32_t w, uint32_t h, hipStream_t st, StreamBuf &buf)
 {
@@ -2227,7 +2232,15 @@ int octree_palette_of(kmg_processor *p, const uint8_t *d_rgba, uint32_t w, uint3
     std::vector<uint8_t> host((size_t)sw * sh * 4);
     HIP_TRY(hipMemcpyAsync(host.data(), src, host.size(), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    colors = octree_palette(host.data(), (uint64_t)sw * sh, color_count);   // operations.rs:90-97
+    colors = octree_sorted_palette(host.data(), (uint64_t)sw * sh, color_count);
+    return KMG_OK;
+}
+
+}  // namespace
+
+std::vector<std::array<uint8_t, 4>> kmg::octree_sorted_palette(const uint8_t *host_rgba, uint64_t n_pixels, uint32_t color_count)
+{
+    std::vector<std::array<uint8_t, 4>> colors = octree_palette(host_rgba, n_pixels, color_count);   // operations.rs:90-97
     std::vector<float> L(colors.size());
     for (size_t i = 0; i < colors.size(); ++i) {
         float lab[3];
@@ -2239,11 +2252,25 @@ int octree_palette_of(kmg_processor *p, const uint8_t *d_rgba, uint32_t w, uint3
     std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return L[a] < L[b]; });   // lib.rs:320-328
     std::vector<std::array<uint8_t, 4>> sorted(colors.size());
     for (size_t i = 0; i < order.size(); ++i) sorted[i] = colors[order[i]];
-    colors.swap(sorted);
-    return KMG_OK;
+    return sorted;
 }
 
-}  // namespace
+// lib.rs:255-286: pull_values (palette-crate Lab -> sRGB8) then sort ascending by Lab L
+void kmg::sorted_palette_of(const float *c4, uint32_t color_count, uint8_t *out_rgba)
+{
+    struct Entry { float L; uint8_t px[4]; };
+    std::vector<Entry> e(color_count);
+    for (uint32_t i = 0; i < color_count; ++i) {
+        uint8_t rgb[3];
+        float lab[3];
+        crate_lab_to_srgb8(&c4[4 * i], rgb);
+        e[i].px[0] = rgb[0]; e[i].px[1] = rgb[1]; e[i].px[2] = rgb[2]; e[i].px[3] = 255;
+        crate_srgb8_to_lab(rgb, lab);
+        e[i].L = lab[0];
+    }
+    std::stable_sort(e.begin(), e.end(), [](const Entry &a, const Entry &b) { return a.L < b.L; });
+    for (uint32_t i = 0; i < color_count; ++i) memcpy(out_rgba + 4 * i, e[i].px, 4);
+}
 
 // ColorTree::{add_color, reduce} (core/src/octree.rs): host helper, needs no device
 extern "C" int kmg_octree_palette(const uint8_t *rgba, uint64_t n_pixels, uint32_t color_count, uint8_t *out_rgba,
@@ -2336,19 +2363,7 @@ extern "C" int kmg_palette(kmg_processor *p, const uint8_t *rgba, uint32_t w, ui
     }
     std::vector<float> c4(4 * (size_t)color_count);
     if ((rc = extract_palette_kmeans(p, (const uint8_t *)img.ptr, w, h, color_count, sg.st, c4.data())) != KMG_OK) return rc;
-    // lib.rs:255-286: pull_values (palette-crate Lab -> sRGB8) then sort ascending by Lab L
-    struct Entry { float L; uint8_t px[4]; };
-    std::vector<Entry> e(color_count);
-    for (uint32_t i = 0; i < color_count; ++i) {
-        uint8_t rgb[3];
-        float lab[3];
-        crate_lab_to_srgb8(&c4[4 * i], rgb);
-        e[i].px[0] = rgb[0]; e[i].px[1] = rgb[1]; e[i].px[2] = rgb[2]; e[i].px[3] = 255;
-        crate_srgb8_to_lab(rgb, lab);
-        e[i].L = lab[0];
-    }
-    std::stable_sort(e.begin(), e.end(), [](const Entry &a, const Entry &b) { return a.L < b.L; });
-    for (uint32_t i = 0; i < color_count; ++i) memcpy(out_rgba + 4 * i, e[i].px, 4);
+    sorted_palette_of(c4.data(), color_count, out_rgba);
     *out_count = color_count;
     return KMG_OK;
 }

@@ -1,0 +1,30 @@
+// kmg_internal.h -- what the translation units of libkmeans_hip share besides the kernels' launchers: the error
+// channel of the C ABI and the few host helpers of kmg_api.hip that the multi-device layer (kmg_group.hip) reuses.
+// Nothing here is exported (-fvisibility=hidden).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <array>
+#include <vector>
+
+#include "../../include/kmeans_hip.h"
+
+namespace kmg {
+
+// sets the calling thread's kmg_last_error() message and returns `code`
+int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+bool log_debug();
+
+// lib.rs:255-286 kmeans_palette: CentroidsBuffer::pull_values (palette-crate Lab -> sRGB8) of a k-means centroid table, then
+// sorted ascending by the palette-crate Lab L of the 8-bit colour.  out_rgba: k x 4 bytes.
+void sorted_palette_of(const float *centroids4, uint32_t k, uint8_t *out_rgba);
+// lib.rs:288-331 octree_palette on a host image already shrunk to <= 128: the reference's CPU octree, sorted by L
+std::vector<std::array<uint8_t, 4>> octree_sorted_palette(const uint8_t *host_rgba, uint64_t n_pixels, uint32_t color_count);
+
+// An image between a caller's (pageable) buffer and the device, ordered on `st` (kmg_api.hip): small images asynchronously,
+// large ones as synchronous row-range copies on several streams of the processor.
+hipError_t copy_host_image(kmg_processor *p, void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t st);
+
+}  // namespace kmg

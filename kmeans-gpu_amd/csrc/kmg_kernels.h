@@ -66,6 +66,12 @@ hipError_t launch_set_centroid_rgba(const uint32_t *colour, const float *lut, Ce
 
 hipError_t launch_resize(const uint32_t *rgba, uint32_t w, uint32_t h, uint32_t nw, uint32_t nh,
                          uint32_t *out, hipStream_t st);
+// The same resize for a row band of a sharded image: `band` holds the image rows from src_row0 on (at least every source row
+// the requested output rows sample: resize_source_row(gy) and the row below it), `out` receives output rows
+// [out_row0, out_row0 + out_rows).  Same values as launch_resize of the whole image, row for row.
+hipError_t launch_resize_band(const uint32_t *band, uint32_t w, uint32_t h, uint32_t src_row0, uint32_t nw, uint32_t nh,
+                              uint32_t out_row0, uint32_t out_rows, uint32_t *out, hipStream_t st);
+uint32_t resize_source_row(uint32_t gy, uint32_t h, uint32_t nh);
 
 // replace / dither output pass.  pal: k+1 RGBA8 words (entry k = the converted sentinel).
 hipError_t launch_apply(const uint32_t *rgba, uint32_t w, uint32_t rows, uint32_t row0,

@@ -743,12 +743,15 @@ hipError_t launch_set_centroid_rgba(const uint32_t *colour, const float *lut, Ce
 
 __global__ __launch_bounds__(kBlock) void k_resize(const uint32_t *__restrict__ rgba, uint32_t w,
                                                    uint32_t h, uint32_t nw, uint32_t nh,
-                                                   uint32_t *__restrict__ out)
+                                                   uint32_t *__restrict__ out, uint32_t src_row0,
+                                                   uint32_t out_row0, uint32_t out_rows)
 {
-    const uint64_t total = (uint64_t)nw * nh;
+    // `rgba` starts at image row src_row0 and `out` at output row out_row0 (a row band of a sharded image, launch_resize_band);
+    // the whole image: 0, 0, nh
+    const uint64_t total = (uint64_t)nw * out_rows;
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += stride) {
-        const uint32_t gx = (uint32_t)(i % nw), gy = (uint32_t)(i / nw);
+        const uint32_t gx = (uint32_t)(i % nw), gy = (uint32_t)(i / nw) + out_row0;
         const float u = (float)gx / (float)nw, v = (float)gy / (float)nh;
         const float tx = u * (float)w - 0.5f, ty = v * (float)h - 0.5f;
         const float fx0 = floorf(tx), fy0 = floorf(ty);
@@ -759,6 +762,7 @@ __global__ __launch_bounds__(kBlock) void k_resize(const uint32_t *__restrict__ 
         x1 = x1 < 0 ? 0 : (x1 > (long long)w - 1 ? (long long)w - 1 : x1);
         y0 = y0 < 0 ? 0 : (y0 > (long long)h - 1 ? (long long)h - 1 : y0);
         y1 = y1 < 0 ? 0 : (y1 > (long long)h - 1 ? (long long)h - 1 : y1);
+        y0 -= src_row0; y1 -= src_row0;
         const uint32_t p00 = rgba[(uint64_t)y0 * w + x0], p10 = rgba[(uint64_t)y0 * w + x1];
         const uint32_t p01 = rgba[(uint64_t)y1 * w + x0], p11 = rgba[(uint64_t)y1 * w + x1];
         uint32_t o = 0;
@@ -779,9 +783,27 @@ __global__ __launch_bounds__(kBlock) void k_resize(const uint32_t *__restrict__ 
 hipError_t launch_resize(const uint32_t *rgba, uint32_t w, uint32_t h, uint32_t nw, uint32_t nh,
                          uint32_t *out, hipStream_t st)
 {
-    uint64_t blocks = ((uint64_t)nw * nh + kBlock - 1) / kBlock;
+    return launch_resize_band(rgba, w, h, 0, nw, nh, 0, nh, out, st);
+}
+
+// source row of the first sample of output row gy (resize.wgsl:15-16 with clamp-to-edge): the same binary32 operations as the
+// kernel, so that a host can tell which band of a sharded image an output row belongs to
+uint32_t resize_source_row(uint32_t gy, uint32_t h, uint32_t nh)
+{
+    const float v = (float)gy / (float)nh;
+    const float ty = v * (float)h - 0.5f;
+    long long y0 = (long long)floorf(ty);
+    y0 = y0 < 0 ? 0 : (y0 > (long long)h - 1 ? (long long)h - 1 : y0);
+    return (uint32_t)y0;
+}
+
+hipError_t launch_resize_band(const uint32_t *band, uint32_t w, uint32_t h, uint32_t src_row0, uint32_t nw, uint32_t nh,
+                              uint32_t out_row0, uint32_t out_rows, uint32_t *out, hipStream_t st)
+{
+    if (out_rows == 0) return hipSuccess;
+    uint64_t blocks = ((uint64_t)nw * out_rows + kBlock - 1) / kBlock;
     uint32_t grid = (uint32_t)(blocks < 4096 ? (blocks ? blocks : 1) : 4096);
-    hipLaunchKernelGGL(k_resize, dim3(grid), dim3(kBlock), 0, st, rgba, w, h, nw, nh, out);
+    hipLaunchKernelGGL(k_resize, dim3(grid), dim3(kBlock), 0, st, band, w, h, nw, nh, out, src_row0, out_row0, out_rows);
     return hipGetLastError();
 }
 

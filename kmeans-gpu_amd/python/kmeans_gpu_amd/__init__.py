@@ -21,7 +21,8 @@ import os
 
 import numpy as np
 
-__all__ = ["ImageProcessor", "Algorithm", "ReduceMode", "Lloyd", "ApplyPlan", "KmgError", "lib", "library_path",
+__all__ = ["ImageProcessor", "Algorithm", "ReduceMode", "Lloyd", "ApplyPlan", "Group", "GroupLloyd", "GroupOptions", "KmgError", "lib",
+           "library_path", "GROUP_FORCE_COLLECTIVES", "GROUP_LOOPBACK", "GROUP_CELLS", "GROUP_OVERLAP", "GROUP_FUSED_UPDATE",
            "resized_dims", "palette_to_centroids", "centroids_to_palette", "dither_threshold",
            "default_options", "Options"]
 
@@ -63,6 +64,17 @@ class Options(C.Structure):             # include/kmeans_hip.h kmg_options
                 ("max_iterations", C.c_uint32), ("check_period", C.c_uint32), ("convergence", C.c_float)]
 
 
+MAX_DEVICES = 16                        # KMG_MAX_DEVICES
+UNIQUE_ID_BYTES = 128                   # KMG_UNIQUE_ID_BYTES
+GROUP_FORCE_COLLECTIVES, GROUP_LOOPBACK = 1, 2                  # kmg_group_options.flags
+GROUP_CELLS, GROUP_OVERLAP, GROUP_FUSED_UPDATE = 1, 2, 4        # kmg_group_lloyd_bind flags
+
+
+class GroupOptions(C.Structure):        # include/kmeans_hip.h kmg_group_options
+    _fields_ = [("struct_size", C.c_uint32), ("n_devices", C.c_uint32), ("devices", C.c_int32 * MAX_DEVICES),
+                ("flags", C.c_uint32), ("processor", Options)]
+
+
 def library_path():
     return _LIB_PATH
 
@@ -84,6 +96,11 @@ SYMBOLS = [
     "kmg_lloyd_update", "kmg_lloyd_assign_update", "kmg_lloyd_set_cell_share", "kmg_lloyd_labels_from_tables",
     "kmg_lloyd_table_buffers", "kmg_lloyd_histogram_buffer", "kmg_lloyd_rebuild_from_histogram", "kmg_debug_block_counts", "kmg_debug_idle_blocks", "kmg_debug_encode_table_check", "kmg_debug_division_check", "kmg_lloyd_converged_count", "kmg_lloyd_iterate", "kmg_lloyd_flush", "kmg_lloyd_run", "kmg_dev_apply", "kmg_apply_plan_create", "kmg_apply_plan_run", "kmg_apply_plan_destroy",
     "kmg_dither_threshold",
+    "kmg_default_group_options", "kmg_group_create", "kmg_group_unique_id", "kmg_group_create_rank", "kmg_group_destroy",
+    "kmg_group_info", "kmg_group_processor", "kmg_group_stream", "kmg_group_palette", "kmg_group_find", "kmg_group_reduce",
+    "kmg_group_reduce_batch", "kmg_group_lloyd_create", "kmg_group_lloyd_destroy", "kmg_group_lloyd_bind",
+    "kmg_group_lloyd_set_centroids", "kmg_group_lloyd_get_centroids", "kmg_group_lloyd_init", "kmg_group_lloyd_prime",
+    "kmg_group_lloyd_step", "kmg_group_lloyd_sync", "kmg_group_lloyd_run", "kmg_group_lloyd_member",
 ]
 
 
@@ -176,6 +193,35 @@ def lib():
     L.kmg_apply_plan_destroy.argtypes = [vp, C.c_int]
     L.kmg_apply_plan_destroy.restype = None
     L.kmg_dither_threshold.argtypes = [f32p, C.c_uint32, C.POINTER(C.c_float)]
+    L.kmg_default_group_options.argtypes = [C.POINTER(GroupOptions)]
+    L.kmg_default_group_options.restype = None
+    L.kmg_group_create.argtypes = [C.POINTER(GroupOptions), C.POINTER(vp)]
+    L.kmg_group_unique_id.argtypes = [vp]
+    L.kmg_group_create_rank.argtypes = [C.POINTER(GroupOptions), vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+    L.kmg_group_destroy.argtypes = [vp]
+    L.kmg_group_destroy.restype = None
+    L.kmg_group_info.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
+    L.kmg_group_processor.argtypes = [vp, C.c_uint32]
+    L.kmg_group_processor.restype = vp
+    L.kmg_group_stream.argtypes = [vp, C.c_uint32]
+    L.kmg_group_stream.restype = vp
+    L.kmg_group_palette.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, u8p, C.POINTER(C.c_uint32)]
+    L.kmg_group_find.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, u8p, C.c_uint32, C.c_int, u8p]
+    L.kmg_group_reduce.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, u8p]
+    L.kmg_group_reduce_batch.argtypes = [vp, C.c_uint32, C.POINTER(vp), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32,
+                                         C.c_int, C.c_int, C.POINTER(vp)]
+    L.kmg_group_lloyd_create.argtypes = [vp, C.c_uint32, C.POINTER(vp)]
+    L.kmg_group_lloyd_destroy.argtypes = [vp]
+    L.kmg_group_lloyd_destroy.restype = None
+    L.kmg_group_lloyd_bind.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32,
+                                       C.POINTER(vp), C.c_uint32]
+    L.kmg_group_lloyd_set_centroids.argtypes = [vp, f32p]
+    L.kmg_group_lloyd_get_centroids.argtypes = [vp, f32p]
+    for name in ("init", "prime", "step", "sync"):
+        getattr(L, "kmg_group_lloyd_" + name).argtypes = [vp]
+    L.kmg_group_lloyd_run.argtypes = [vp, C.POINTER(C.c_uint32)]
+    L.kmg_group_lloyd_member.argtypes = [vp, C.c_uint32, C.POINTER(C.c_int)]
+    L.kmg_group_lloyd_member.restype = vp
     _lib = L
     return L
 
@@ -625,3 +671,192 @@ class Lloyd:
         _check(lib().kmg_lloyd_run(self._h, C.c_void_p(d_rgba), n_pixels, C.c_void_p(d_labels or None),
                                    C.byref(it), C.c_void_p(stream)))
         return it.value
+
+
+class _BorrowedProcessor(ImageProcessor):
+    """a member processor of a Group: the group owns it"""
+
+    def __init__(self, handle):                      # pylint: disable=super-init-not-called
+        self._h = C.c_void_p(handle)
+
+    def close(self):
+        self._h = C.c_void_p()
+
+
+class _BorrowedLloyd(Lloyd):
+    """a member kmg_lloyd of a GroupLloyd (profiling, statistics): the group owns it"""
+
+    def __init__(self, handle, k):                   # pylint: disable=super-init-not-called
+        self._h = C.c_void_p(handle)
+        self.k = int(k)
+
+    def close(self):
+        self._h = C.c_void_p()
+
+
+class Group:
+    """kmg_group_*: ImageProcessor::new (core/src/lib.rs:38-65) over a device LIST -- one processor, compute stream and RCCL
+    rank per device.  `devices` = HIP ordinals of this process's ranks (None = every visible device).  One process per GPU:
+    rank 0 makes `unique_id()`, the host runtime hands it to every process, each passes it with its `first_rank` and `world`.
+    palette / find / reduce mirror ImageProcessor's and give the same bytes."""
+
+    def __init__(self, devices=None, flags=0, unique_id=None, first_rank=0, world=None, shrink_max_dim=256, max_iterations=128,
+                 check_period=8, convergence=1.0):
+        o = GroupOptions()
+        lib().kmg_default_group_options(C.byref(o))
+        if devices is not None:
+            devices = [int(d) for d in devices]
+            if len(devices) > MAX_DEVICES:
+                raise ValueError("too many devices")
+            o.n_devices = len(devices)
+            for i, d in enumerate(devices):
+                o.devices[i] = d
+        o.flags = int(flags)
+        o.processor.shrink_max_dim = shrink_max_dim
+        o.processor.max_iterations = max_iterations
+        o.processor.check_period = check_period
+        o.processor.convergence = convergence
+        self._h = C.c_void_p()
+        if unique_id is None:
+            _check(lib().kmg_group_create(C.byref(o), C.byref(self._h)))
+        else:
+            uid = (C.c_uint8 * UNIQUE_ID_BYTES).from_buffer_copy(bytes(unique_id))
+            _check(lib().kmg_group_create_rank(C.byref(o), uid, int(first_rank), int(world), C.byref(self._h)))
+        a, b, c, v = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_int()
+        _check(lib().kmg_group_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(v)))
+        self.n_local, self.first_rank, self.world, self.rccl_version = a.value, b.value, c.value, v.value
+        self.options = o
+
+    @staticmethod
+    def unique_id():
+        """ncclGetUniqueId through the library (loads RCCL): 128 bytes for every process of the job"""
+        buf = (C.c_uint8 * UNIQUE_ID_BYTES)()
+        _check(lib().kmg_group_unique_id(buf))
+        return bytes(buf)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().kmg_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def handle(self):
+        return self._h
+
+    def processor(self, i=0):
+        return _BorrowedProcessor(lib().kmg_group_processor(self._h, int(i)))
+
+    def stream(self, i=0):
+        """local device i's compute stream (hipStream_t as an integer): everything the group enqueues there runs on it"""
+        return int(lib().kmg_group_stream(self._h, int(i)) or 0)
+
+    def palette(self, color_count, image, algo=Algorithm.Kmeans):
+        img = _image(image)
+        h, w = img.shape[:2]
+        out = np.empty((max(int(color_count), 1), 4), np.uint8)
+        cnt = C.c_uint32()
+        _check(lib().kmg_group_palette(self._h, _np_ptr(img), w, h, int(color_count), int(algo), _np_ptr(out), C.byref(cnt)))
+        return out[:cnt.value].copy()
+
+    def find(self, image, colors, reduce_mode=ReduceMode.Replace, out=None):
+        img = _image(image)
+        h, w = img.shape[:2]
+        pal = np.ascontiguousarray(colors, np.uint8).reshape(-1, 4)
+        out = _result(img, out)
+        _check(lib().kmg_group_find(self._h, _np_ptr(img), w, h, _np_ptr(pal), pal.shape[0], int(reduce_mode), _np_ptr(out)))
+        return out
+
+    def reduce(self, color_count, image, algo=Algorithm.Kmeans, reduce_mode=ReduceMode.Replace, out=None):
+        img = _image(image)
+        h, w = img.shape[:2]
+        out = _result(img, out)
+        _check(lib().kmg_group_reduce(self._h, _np_ptr(img), w, h, int(color_count), int(algo), int(reduce_mode), _np_ptr(out)))
+        return out
+
+    def reduce_batch(self, color_count, images, algo=Algorithm.Kmeans, reduce_mode=ReduceMode.Replace):
+        """whole images per device, no collective (BASELINE config 4 as placed); returns the list of results"""
+        imgs = [_image(im) for im in images]
+        outs = [np.empty_like(im) for im in imgs]
+        n = len(imgs)
+        src = (C.c_void_p * n)(*[im.ctypes.data for im in imgs])
+        dst = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        ws = (C.c_uint32 * n)(*[im.shape[1] for im in imgs])
+        hs = (C.c_uint32 * n)(*[im.shape[0] for im in imgs])
+        _check(lib().kmg_group_reduce_batch(self._h, n, src, ws, hs, int(color_count), int(algo), int(reduce_mode), dst))
+        return outs
+
+
+class GroupLloyd:
+    """kmg_group_lloyd_*: one Lloyd problem over row bands resident on the group's devices (modules.rs:763-840 + the RCCL
+    all-reduce of the k x 4 int64 sums).  Pointers are raw device addresses, one per local device."""
+
+    def __init__(self, group, k):
+        self._g = group
+        self.k = int(k)
+        self._h = C.c_void_p()
+        _check(lib().kmg_group_lloyd_create(group.handle, self.k, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().kmg_group_lloyd_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def bind(self, d_rgba, row0, rows, width, height, d_labels=None, flags=0):
+        n = self._g.n_local
+        if not (len(d_rgba) == len(row0) == len(rows) == n):
+            raise ValueError("one band per local device")
+        px = (C.c_void_p * n)(*[int(p) or None for p in d_rgba])
+        r0 = (C.c_uint32 * n)(*[int(v) for v in row0])
+        rs = (C.c_uint32 * n)(*[int(v) for v in rows])
+        lab = (C.c_void_p * n)(*[int(p) or None for p in d_labels]) if d_labels is not None else None
+        _check(lib().kmg_group_lloyd_bind(self._h, px, r0, rs, int(width), int(height), lab, int(flags)))
+
+    def set_centroids(self, centroids4):
+        c = np.ascontiguousarray(centroids4, np.float32).reshape(self.k, 4)
+        _check(lib().kmg_group_lloyd_set_centroids(self._h, _np_ptr(c)))
+
+    def get_centroids(self):
+        out = np.empty((self.k, 4), np.float32)
+        _check(lib().kmg_group_lloyd_get_centroids(self._h, _np_ptr(out)))
+        return out
+
+    def init(self):
+        _check(lib().kmg_group_lloyd_init(self._h))
+
+    def prime(self):
+        _check(lib().kmg_group_lloyd_prime(self._h))
+
+    def step(self):
+        _check(lib().kmg_group_lloyd_step(self._h))
+
+    def sync(self):
+        _check(lib().kmg_group_lloyd_sync(self._h))
+
+    def run(self):
+        it = C.c_uint32()
+        _check(lib().kmg_group_lloyd_run(self._h, C.byref(it)))
+        return it.value
+
+    def member(self, i=0):
+        """(Lloyd of local device i, "table" | "scan")"""
+        st = C.c_int()
+        h = lib().kmg_group_lloyd_member(self._h, int(i), C.byref(st))
+        return _BorrowedLloyd(h, self.k), ("table" if st.value == 1 else "scan")
