@@ -10,7 +10,6 @@ def test_bench_extras_run_without_error(torch_cuda, oracle):
     import bench
     import kmeans_gpu_amd as kg
     from kmeans_gpu_amd import synth
-    from kmeans_gpu_amd.sharded import ShardedLloyd
     torch = torch_cuda
     st = torch.cuda.current_stream().cuda_stream
     rows, k = 512, 256
@@ -23,11 +22,10 @@ def test_bench_extras_run_without_error(torch_cuda, oracle):
     lloyd = kg.Lloyd(proc, k)
     lloyd.set_centroids(cent, st)
     strategy = lloyd.prepare(rgba.data_ptr(), n, True, st)
-    sh = ShardedLloyd(lloyd, k, rgba, labels, stream=st)
-    sh.split_labels = strategy == "table"
-    sh.prime()
-    sh.iterate()
-    extra = bench.output_pass_timing(proc, rgba, n, st, sh, steps=1)
+    acc = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
+    lloyd.assign_update(rgba.data_ptr(), n, labels.data_ptr(), acc.data_ptr(), True, st)
+    lloyd.assign_update(rgba.data_ptr(), n, labels.data_ptr(), acc.data_ptr(), True, st)
+    extra = bench.output_pass_timing(proc, rgba, n, st, bench._Loop(lloyd, acc, strategy == "table", k), steps=1)
     assert "error" not in extra, extra["error"]
     for key in ("find_dither_k64_ms", "find_replace_k64_ms", "iteration_without_label_map_ms", "cfg3_init_ms",
                 "cfg3_lloyd_and_labels_ms", "cfg3_dither_ms", "blobs_ms_per_step", "photo_ms_per_step",

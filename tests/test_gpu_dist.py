@@ -54,28 +54,50 @@ def test_ranks_sharing_one_gpu_over_gloo_equal_the_unsharded_loop(torch_cuda, wo
 
 
 def test_bench_multi_gpu_path_rehearsed_on_one_gpu(torch_cuda):
-    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one rank per process) with --rehearse: both ranks on
-    cuda:0, collectives through gloo.  The N > 1 code path of the benchmark -- strong scaling of the BASELINE image, cell-sharded
-    cube pass, weak-scaling extra -- must produce its JSON line (the timings of a rehearsal mean nothing)."""
+    """`python bench.py --gpus 2 --rehearse` WITHOUT a launcher: bench.py starts its two ranks itself (a fresh
+    torch.distributed.run child, before any HIP call) and relays rank 0's JSON line.  --rehearse: the box has one GPU and RCCL
+    takes one rank per device, so rank 0 hosts both ranks of the kmg_group on cuda:0 (loopback exchange).  The N > 1 code path of
+    the benchmark -- strong scaling of the BASELINE image through kmg_group_lloyd_*, the shapes tried before the timed region,
+    weak-scaling and one-GPU extras -- must produce its line (the timings of a rehearsal mean nothing)."""
     import json
     root = os.path.dirname(HERE)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    env.pop("KMG_STRATEGY", None)
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                        "--rehearse"], env=env, capture_output=True, text=True, timeout=600)
+    for name in ("KMG_STRATEGY", "WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(name, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--rehearse"],
+                       env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert r.stdout.count("\n") == 1 and r.stdout.startswith("{"), r.stdout[:300]      # stdout carries the JSON line only
+    line = json.loads(r.stdout)
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["metric"].endswith("(8192x8192, k=256)")
-    # both shapes of "one image over N GPUs" were tried and the faster one measured
-    choice = line["config"]["sharding_choice"]
-    assert choice["cells_ms_per_step"] > 0 and choice["bands_ms_per_step"] > 0 and choice["picked"] in ("cells", "bands")
-    assert ("cube pass sharded by cells" in line["config"]["sharding"]) == (choice["picked"] == "cells") and line["value"] > 0
+    cfg = line["config"]
+    assert cfg["collective_ranks"] == 2 and "loopback" in cfg["collective_backend"] and "kmg_group_lloyd" in cfg["driver"]
+    # the shapes of "one image over N GPUs" were tried and the fastest one measured
+    choice = cfg["sharding_choice"]
+    assert choice["cells_ms_per_step"] > 0 and choice["bands_ms_per_step"] > 0 and (choice["picked"] + "_ms_per_step") in choice
+    assert ("cube pass sharded by cells" in cfg["sharding"]) == (choice["picked"] == "cells") and line["value"] > 0
+    assert cfg["expected_speedup"] in (1.70, 1.35) and cfg["measured_speedup"] > 0 and cfg["one_gpu_ms_per_step_same_run"] > 0
     assert line["extra"]["weak_scaling_value"] > 0
-    # and the cell-sharded loop when asked for
+    # and the cell-sharded loop when asked for, started the way the driver starts N > 1
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                         "--rehearse", "--cells", "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert "cube pass sharded by cells" in line["config"]["sharding"] and "sharding_choice" not in line["config"] and line["value"] > 0
+
+
+def test_bench_one_rank_under_the_launcher_with_real_rccl(torch_cuda):
+    """the driver's N > 1 start (torch.distributed.run, RANK / WORLD_SIZE from the environment) with ONE rank and --force-dist:
+    the unique id made by rank 0, kmg_group_create_rank, and every per-iteration ncclAllReduce really issued by the library"""
+    import json
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("KMG_STRATEGY", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--force-dist", "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["config"]["collective_backend"].startswith("RCCL 2") and line["config"]["collective_ranks"] == 1 and line["value"] > 0
+    assert line["config"]["update"] == "k_update launch"
