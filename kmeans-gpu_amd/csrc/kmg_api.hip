@@ -719,7 +719,7 @@ static int tables_from_histogram(kmg_lloyd *s, uint64_t n_pixels, hipStream_t st
     HIP_TRY(launch_work_list(t.d_agg, t.d_work, s->k <= 256 ? n_pixels : 0, st));
     HIP_TRY(hipMemcpyAsync(&t.n_hot, t.d_work + kCells + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (const char *e = getenv("KMG_HOT_CELLS")) { if (e[0] == '0') t.n_hot = 0; }      // probes
+    if (const char *e = KMG_TOOLS_ENV("KMG_HOT_CELLS")) { if (e[0] == '0') t.n_hot = 0; }      // (tools build only)
     t.d_work_share = nullptr;
     return KMG_OK;
 }
@@ -923,7 +923,7 @@ extern "C" int kmg_debug_check_dither_masks(kmg_processor *p, const float *c4, u
     HIP_TRY(hipMemcpyAsync(&h, viol.ptr, sizeof h, hipMemcpyDeviceToHost, S(stream)));
     HIP_TRY(hipStreamSynchronize(S(stream)));
     *violations = h;
-    if (getenv("KMG_DITHER_STATS")) {
+    if (KMG_TOOLS_ENV("KMG_DITHER_STATS")) {
         // distribution of the candidate counts: per (cell, Bayer index) slot, and per cell over its 16 slots together
         const uint32_t words = mask_words(k);
         std::vector<uint64_t> hm((size_t)kCells * 16u * words);

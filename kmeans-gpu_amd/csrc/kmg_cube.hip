@@ -21,6 +21,7 @@
 // integers.  tests/test_gpu_table.py compares every label / sum with the per-pixel scan and the oracle.
 // Compile with -ffp-contract=off.
 
+#include "kmg_internal.h"
 #include "kmg_table_dev.h"
 
 #include <stdlib.h>
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
             }
         }
 
-        if (npop == 1u || (flags & 0x800u)) {
+        if (npop == 1u || KMG_KNOCK(flags, 0x800u)) {
             // the whole cell belongs to `first`: sums from the cell table, no per-colour traffic
             if (sizeof(LabelT) == 1) {
                 if (lane == 0u) *pair_entry_ptr = pair_entry(first, first, 0u, 0u, 0u);
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         st_multi += 1;
 
         // ---- 2. sub-cell stage: list the candidates, bound each over each sub-cell ----
-        const bool listed = npop <= kMaxListed && !(flags & 0x1000u);
+        const bool listed = npop <= kMaxListed && !KMG_KNOCK(flags, 0x1000u);
         uint32_t my_cand = 0;                                       // lane p < npop: the p-th candidate
         unsigned long long br[4] = {0ull, 0ull, 0ull, 0ull};       // round r: bit 8 s + c = sub-cell s keeps candidate 8 r + c
         bool long_cell = false;
@@ -527,7 +528,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
             for (uint32_t r = 0; r < 4u; ++r)
                 if (r < rounds) br[r] = __ballot(lo[r] <= Us);
             if (lane < 4u) cw->br[lane] = lane == 0u ? br[0] : (lane == 1u ? br[1] : (lane == 2u ? br[2] : br[3]));
-        } else if (words <= 4u && npop <= kMaxLong && !(flags & 0x1000u)) {
+        } else if (words <= 4u && npop <= kMaxLong && !KMG_KNOCK(flags, 0x1000u)) {
             // long list (rare on noise, the heavy cells of a photograph): long_list_stage
             long_cell = true;
 #pragma unroll
@@ -552,7 +553,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         const bool occupied_v = lane < 8u && (SUMS ? scnt != 0 : true);
         const bool decided_v = occupied_v && ((listed && __builtin_popcount(sm_v) == 1) || (long_cell && long_cnt == 1u));
         const uint32_t decided_set = (uint32_t)__ballot(decided_v);
-        const uint32_t scan_set = (flags & 0x400u) ? 0u : (uint32_t)__ballot(occupied_v && !decided_v);
+        const uint32_t scan_set = KMG_KNOCK(flags, 0x400u) ? 0u : (uint32_t)__ballot(occupied_v && !decided_v);
         // label of a decided sub-cell, at lane s
         uint32_t X_v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((sm_v ? (uint32_t)__builtin_ctz(sm_v) : 0u)) << 2), (int)my_cand);
         if (long_cell) X_v = long_one;
@@ -570,7 +571,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
             }
             // its sums: lane 4 s + j holds sum j of sub-cell s
             const uint32_t Xs = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane >> 2) & 7u) << 2), (int)X_v);
-            if (SUMS && !(flags & 0x200u) && lane < 32u && ((decided_set >> (lane >> 2)) & 1u))
+            if (SUMS && !KMG_KNOCK(flags, 0x200u) && lane < 32u && ((decided_set >> (lane >> 2)) & 1u))
                 atomicAdd(bins + 4ull * Xs + (lane & 3u), (unsigned long long)sagg);
         }
         if (sizeof(LabelT) != 1) {
@@ -682,7 +683,7 @@ __global__ __launch_bounds__(kBlock) void k_cube_scan(const uint32_t *__restrict
             const uint32_t c0_ = cell * kCellColours + (X##_s0 & 7u) * 64u + lane;                               \
             const uint32_t c1_ = cell * kCellColours + (X##_s1 & 7u) * 64u + lane;                               \
             /* (knock-out, tools only, results wrong: flag bit 20 = the Lab rows from a cache-resident 64 KiB window) */ \
-            const uint32_t km_ = (flags & 0x100000u) ? 0xFFFu : 0xFFFFFFFFu;                                     \
+            const uint32_t km_ = KMG_KNOCK(flags, 0x100000u) ? 0xFFFu : 0xFFFFFFFFu;                                     \
             X##_v0 = lab_table[c0_ & km_];                                                                       \
             X##_v1 = lab_table[c1_ & km_];                          /* s1 == 8: sub-cell 0 again, unused */      \
             if (SUMS) { X##_c0 = hist[c0_]; X##_c1 = hist[c1_]; }                                                \
@@ -811,7 +812,7 @@ __global__ __launch_bounds__(kBlock) void k_cube_scan(const uint32_t *__restrict
                         if (__builtin_popcountll(__ballot(counts && ix == X1)) > __builtin_popcountll(occm & ~other)) R = X1;
                     }
                     st = other ? (uint32_t)kSubMixed : X0;
-                    if (SUMS && !(flags & 0x200u)) {
+                    if (SUMS && !KMG_KNOCK(flags, 0x200u)) {
                         if ((lane >> 2) == s) atomicAdd(bins + 4ull * R + (lane & 3u), (unsigned long long)sagg);
                         if (other && counts && ix != R) {
                             const long long m = (long long)cnt;
@@ -840,7 +841,7 @@ __global__ __launch_bounds__(kBlock) void k_cube_scan(const uint32_t *__restrict
 #undef KMG_REQUEST_COLOURS
         // the labels of the scanned sub-cells: lane l owns the colours 8 l .. 8 l + 7 (sub-cell l >> 3), one store
         __builtin_amdgcn_wave_barrier();
-        if (!(flags & 0x2000u) && ((label_set >> (lane >> 3)) & 1u)) {
+        if (!KMG_KNOCK(flags, 0x2000u) && ((label_set >> (lane >> 3)) & 1u)) {
             if (sizeof(LabelT) == 1)
                 *reinterpret_cast<uint2 *>(cell_labels + lane * 8u) = *reinterpret_cast<const uint2 *>(s_lbl + lane * 8u);
             else
@@ -886,7 +887,7 @@ __global__ __launch_bounds__(kBlock) void k_cube_pairs(const uint32_t *__restric
             uint32_t idx[8];
 #pragma unroll
             for (uint32_t q = 0; q < 4u; ++q) { idx[q] = (lv.x >> (8u * q)) & 0xFFu; idx[4u + q] = (lv.y >> (8u * q)) & 0xFFu; }
-            const uint32_t e = (flags & 0x100u) ? pair_entry(idx[0], idx[0], 0u, 0u, 0u) : cell_pair_entry(idx, occ, lane);
+            const uint32_t e = KMG_KNOCK(flags, 0x100u) ? pair_entry(idx[0], idx[0], 0u, 0u, 0u) : cell_pair_entry(idx, occ, lane);
             if (lane == 0u) *pair_entry_ptr = e;
         } else {
             // cell summary = merge of the eight sub-cell summaries (k_cube_stage wrote the decided / empty ones,
@@ -1089,7 +1090,7 @@ __global__ __launch_bounds__(kSmallBlock) __attribute__((amdgpu_waves_per_eu(4, 
         if (!(fabsf(c.x) <= 1024.0f && fabsf(c.y) <= 1024.0f && fabsf(c.z) <= 1024.0f)) s_count[2] = 1u;
     }
     __syncthreads();
-    const bool dominance = sub_affine != nullptr && s_count[2] == 0u && !(flags & 0x8000u);
+    const bool dominance = sub_affine != nullptr && s_count[2] == 0u && !KMG_KNOCK(flags, 0x8000u);
 
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     unsigned long long *my_bins = bins + (uint64_t)(lane & (kSmallRepl - 1u)) * bin_stride;
@@ -1294,8 +1295,8 @@ __global__ __launch_bounds__(kSmallBlock) __attribute__((amdgpu_waves_per_eu(4, 
             }
         }
         __syncthreads();
-        const uint32_t n_ent = (flags & 0x400u) ? 0u : s_count[0];
-        const uint32_t n_pend = (flags & 0x4000u) ? 0u : s_count[1];
+        const uint32_t n_ent = KMG_KNOCK(flags, 0x400u) ? 0u : s_count[0];
+        const uint32_t n_pend = KMG_KNOCK(flags, 0x4000u) ? 0u : s_count[1];
 
         // ---- 2. scan: the undecided sub-cells of the workgroup, pair p to wave p % 8, one colour per lane ----
         // (its occupancy bytes for phase 3 are requested now: the scan hides their latency)
@@ -1386,7 +1387,7 @@ __global__ __launch_bounds__(kSmallBlock) __attribute__((amdgpu_waves_per_eu(4, 
                 // label R, a colour with another label moves its own contribution from R to that label
                 auto finish = [&](uint32_t e, uint32_t ix, uint32_t cnt, long long g, float vL, float va, float vb) {
                     s_lbl[(e >> 3) * kCellColours + (e & 7u) * 64u + lane] = (uint8_t)ix;
-                    if (!SUMS || (flags & 0x200u)) return;
+                    if (!SUMS || KMG_KNOCK(flags, 0x200u)) return;
                     const bool counts = cnt != 0u;
                     const unsigned long long occm = __ballot(counts);
                     if (!occm) return;
@@ -1468,18 +1469,19 @@ __global__ __launch_bounds__(kSmallBlock) __attribute__((amdgpu_waves_per_eu(4, 
     }
 }
 
-static uint32_t env_grid(const char *name, uint32_t dflt)
+static uint32_t grid_or(const char *e, uint32_t dflt)
 {
-    if (const char *e = getenv(name)) { const int v = atoi(e); if (v >= 1 && v <= 65536) return (uint32_t)v; }
+    if (e) { const int v = atoi(e); if (v >= 1 && v <= 65536) return (uint32_t)v; }
     return dflt;
 }
+#define env_grid(name, dflt) grid_or(KMG_TOOLS_ENV(name), (dflt))
 
 uint32_t cube_replicas(uint32_t k)
 {
     // copies of the scan kernel's LDS bins (lanes spread their atomic adds over them).  Measured at k = 256 (round 3,
     // profiles/r03_*): 1 copy 73.4 us, 2 copies 69.5 us, 4 copies 97.6 us (the bins then take the LDS of a workgroup per CU)
     uint32_t r = 2;
-    if (const char *e = getenv("KMG_CUBE_REPL")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) r = (uint32_t)v; }
+    if (const char *e = KMG_TOOLS_ENV("KMG_CUBE_REPL")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) r = (uint32_t)v; }
     while (r > 1u && (uint64_t)r * (k * 32ull + 32ull) > 33024ull) r >>= 1;
     return r;
 }
@@ -1496,7 +1498,7 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
     const uint32_t kpad = (k + 63u) & ~63u;
     const bool with_sums = hist != nullptr;
     const uint32_t repl = with_sums ? cube_replicas(k) : 1u;
-    if (const char *e = getenv("KMG_CUBE_FLAGS")) flags |= (uint32_t)strtoul(e, nullptr, 0) & 0x10FF00u;
+    if (const char *e = KMG_TOOLS_ENV("KMG_CUBE_FLAGS")) flags |= (uint32_t)strtoul(e, nullptr, 0) & 0x10FF00u;   // (tools build only)
     const size_t lds_stage = sizeof(float4) * kpad + (with_sums ? sizeof(unsigned long long) * 4ull * k : 0) +
                              sizeof(uint32_t) * (kBlock / 64) * kMaxListed + sizeof(unsigned long long) * (kBlock / 64) * (kpad / 64u) +
                              (k <= 256 ? (kBlock / 64) * (32u * sizeof(unsigned long long) + kMaxLong * sizeof(uint16_t)) : 0u);
@@ -1513,7 +1515,7 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
         if (lds_stage > lds_max || lds_scan > lds_max) return hipErrorInvalidValue;
     }
     // small centroid tables: the whole pass in one launch (k_cube_small) + the tail workgroup
-    static const bool small_on = !(getenv("KMG_CUBE_SMALL") && atoi(getenv("KMG_CUBE_SMALL")) == 0);
+    static const bool small_on = !(KMG_TOOLS_ENV("KMG_CUBE_SMALL") && atoi(KMG_TOOLS_ENV("KMG_CUBE_SMALL")) == 0);
     if (k <= kSmallMaxK && small_on) {
         static const uint32_t g_small = env_grid("KMG_SMALL_GRID", kCells / kSmallCells);
         const uint32_t kp = k <= 8u ? 8u : (k <= 16u ? 16u : 32u);
@@ -1522,7 +1524,7 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
                            sizeof(uint32_t) * 4u + sizeof(uint16_t) * (kSmallBlock + kSmallCells + kSmallTests) + kSmallBlock;
         if (!n_rows) n_rows = 1u;
         // KMG_CUBE_SMALL=2: k_cube_small as the stage only, then the scan and entries launches of the general pass
-        static const bool split = getenv("KMG_CUBE_SMALL") && atoi(getenv("KMG_CUBE_SMALL")) == 2;
+        static const bool split = KMG_TOOLS_ENV("KMG_CUBE_SMALL") && atoi(KMG_TOOLS_ENV("KMG_CUBE_SMALL")) == 2;
         const uint32_t sflags = (flags & ~0x100u) | (split ? kSmallEmit : 0u);
 #define KMG_SMALL(KP, S)                                                                                                    \
         hipLaunchKernelGGL((k_cube_small<KP, S>), dim3(g_small), dim3(kSmallBlock), lds, st, hist, agg, sub_agg, occ_bits,   \
@@ -1561,7 +1563,7 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
     do {                                                                                                                    \
         hipLaunchKernelGGL((k_cube_stage<T, S>), dim3(g_stage), dim3(kBlock), lds_stage, st, agg, sub_agg, work, bounds,    \
                            sub_bounds, cent, k, masks, cw, (T *)colour_labels, sub_table, sums, n_rows, flags, stats);      \
-        if (!(flags & 0xC00u))                                                                                              \
+        if (!KMG_KNOCK(flags, 0xC00u))                                                                                      \
             hipLaunchKernelGGL((k_cube_scan<T, S>), dim3(g_scan), dim3(kBlock), lds_scan, st, hist, sub_agg, work, cent, k, \
                                lab_table, masks, cw, (T *)colour_labels, sub_table, sums, n_rows, repl, flags);             \
         hipLaunchKernelGGL((k_cube_pairs<T>), dim3((flags & kCubeNoEntries) ? 1u : g_pairs), dim3(kBlock), 0, st, work,   \

@@ -11,6 +11,19 @@
 
 #include "../../include/kmeans_hip.h"
 
+// Tuning switches and knock-outs (kernel variants that skip work and return WRONG results, for measurements) exist only in the
+// tools build (make tools: -DKMG_TOOLS, lib/libkmeans_hip_tools.so, loaded by tools/ through KMG_LIBRARY).  In the product
+// library the environment is not even consulted for them: KMG_TOOLS_ENV is a macro so that the variable's name is not in the
+// binary, and KMG_KNOCK(flags, bit) is a constant so that the knocked-out paths are not compiled.
+#ifdef KMG_TOOLS
+#include <stdlib.h>
+#define KMG_TOOLS_ENV(name) getenv(name)
+#define KMG_KNOCK(flags, bit) (((flags) & (bit)) != 0u)
+#else
+#define KMG_TOOLS_ENV(name) (static_cast<const char *>(nullptr))
+#define KMG_KNOCK(flags, bit) (false)
+#endif
+
 namespace kmg {
 
 // sets the calling thread's kmg_last_error() message and returns `code`

@@ -10,6 +10,7 @@
 //  * sums are exact integers: sum over colours of count * q equals the per-pixel sum of q.
 // Compile with -ffp-contract=off.
 
+#include "kmg_internal.h"
 #include "kmg_table_dev.h"
 
 namespace kmg {
@@ -1091,7 +1092,8 @@ hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_la
         const int aligned = ((reinterpret_cast<uintptr_t>(rgba) & 15u) == 0 &&
                              (reinterpret_cast<uintptr_t>(labels) & 15u) == 0) ? 1 : 0;
         const uint32_t *pairs = reinterpret_cast<const uint32_t *>(sub_table + kSubCells + kCells);
-        static const int knock = getenv("KMG_LABEL_KNOCK") ? atoi(getenv("KMG_LABEL_KNOCK")) : 0;       // tools only
+#ifdef KMG_TOOLS
+        static const int knock = getenv("KMG_LABEL_KNOCK") ? atoi(getenv("KMG_LABEL_KNOCK")) : 0;       // tools build only
 #define KMG_LK(K) hipLaunchKernelGGL((k_labels_pairs<false, K>), dim3(grid), dim3(kLabelBlock), kLabelLdsPlain, st, rgba, n, \
                                      (const uint8_t *)colour_labels, pairs, pal, k, labels, aligned, hot, tail_sums, tl)
         if (knock == 1) KMG_LK(1); else if (knock == 2) KMG_LK(2); else if (knock == 3) KMG_LK(3); else if (knock == 4) KMG_LK(4);
@@ -1099,8 +1101,10 @@ hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_la
         else if (knock == 8)
             hipLaunchKernelGGL((k_labels_pairs<false, 8>), dim3(2u * grid), dim3(kLabelBlock), kLabelLdsPlain - sizeof(uint32_t) * kCells / 2u,
                                st, rgba, n, (const uint8_t *)colour_labels, pairs, pal, k, labels, aligned, hot, tail_sums, tl);
+        else
 #undef KMG_LK
-        else if (hot)
+#endif
+        if (hot)
             hipLaunchKernelGGL(k_labels_pairs<true>, dim3(grid), dim3(kLabelBlock), kLabelLdsHot, st, rgba, n,
                                (const uint8_t *)colour_labels, pairs, pal, k, labels, aligned, hot, tail_sums, tl);
         else
@@ -1353,7 +1357,7 @@ __global__ __launch_bounds__(kBlock) void k_dither_pruned(const uint32_t *__rest
             const uint32_t cell = (((px[q] >> 3) & 31u) << 10) | (((px[q] >> 11) & 31u) << 5) | ((px[q] >> 19) & 31u);
             slot[q] = cell * 16u + bi;
 #pragma unroll
-            for (int u = 0; u < UP; ++u) m0[q][u] = (knock & 1u) ? (0x0000100000100001ull << (px[q] & 7u)) : masks[(uint64_t)slot[q] * words + u];   // gathers in flight during the Lab conversion
+            for (int u = 0; u < UP; ++u) m0[q][u] = KMG_KNOCK(knock, 1u) ? (0x0000100000100001ull << (px[q] & 7u)) : masks[(uint64_t)slot[q] * words + u];   // gathers in flight during the Lab conversion
             gx += 1;
             if (gx == w) { gx = 0; gy += 1; }
         }
@@ -1361,7 +1365,7 @@ __global__ __launch_bounds__(kBlock) void k_dither_pruned(const uint32_t *__rest
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float L, a, b;
-            if (knock & 4u) { L = s_lut[px[q] & 255u]; a = s_lut[(px[q] >> 8) & 255u]; b = s_lut[(px[q] >> 16) & 255u]; }
+            if KMG_KNOCK(knock, 4u) { L = s_lut[px[q] & 255u]; a = s_lut[(px[q] >> 8) & 255u]; b = s_lut[(px[q] >> 16) & 255u]; }
             else px_to_lab(s_lut, px[q], L, a, b);
             const float off = s_off[slot[q] & 15u];
             L = L + off; a = a + off; b = b + off;                   // mix_colors.wgsl:72
@@ -1380,7 +1384,7 @@ __global__ __launch_bounds__(kBlock) void k_dither_pruned(const uint32_t *__rest
                 }
             };
 #pragma unroll
-            for (int u = 0; u < UP; ++u) scan_word((knock & 2u) ? 0ull : m0[q][u], (uint32_t)u);
+            for (int u = 0; u < UP; ++u) scan_word(KMG_KNOCK(knock, 2u) ? 0ull : m0[q][u], (uint32_t)u);
             if (WORDS == 0)
                 for (uint32_t wd = 1; wd < words; ++wd) scan_word(masks[(uint64_t)slot[q] * words + wd], wd);
             if (kLiteralArgmin && second <= tie_threshold(best)) {
@@ -1405,7 +1409,7 @@ __global__ __launch_bounds__(kBlock) void k_dither_pruned(const uint32_t *__rest
                     for (uint32_t wd = 1; wd < words; ++wd) rescan_word(masks[(uint64_t)slot[q] * words + wd], wd);
                 idx = li;
             }
-            res[q] = (knock & 8u) ? idx : pal[idx];
+            res[q] = KMG_KNOCK(knock, 8u) ? idx : pal[idx];
         }
         store4_stream(out, i0, n, aligned != 0, res);
     }
@@ -1597,11 +1601,11 @@ hipError_t launch_dither_pruned(const uint32_t *rgba, uint32_t w, uint32_t rows,
     const int aligned = ((reinterpret_cast<uintptr_t>(rgba) & 15u) == 0 &&
                          (reinterpret_cast<uintptr_t>(out) & 15u) == 0) ? 1 : 0;
     uint32_t knock = 0;
-    if (const char *e = getenv("KMG_DITHER_KNOCK")) knock = (uint32_t)atoi(e);
+    if (const char *e = KMG_TOOLS_ENV("KMG_DITHER_KNOCK")) knock = (uint32_t)atoi(e);      // (tools build only)
 #define KMG_DP(W) hipLaunchKernelGGL(k_dither_pruned<W>, dim3(grid), dim3(kBlock), lds, st, rgba, w, n, row0, cent, k, lut, \
                                      pal, threshold, masks, out, aligned, knock)
     const uint32_t n_words = (k + 63u) / 64u;
-    static const bool sorted = !(getenv("KMG_DITHER_SORT") && atoi(getenv("KMG_DITHER_SORT")) == 0);
+    static const bool sorted = !(KMG_TOOLS_ENV("KMG_DITHER_SORT") && atoi(KMG_TOOLS_ENV("KMG_DITHER_SORT")) == 0);
     if (sorted && !knock && n_words == 1u) {
         // the pixels of a tile sorted by candidate-list length (k_dither_sorted): 8192^2, 64-entry palette 0.95 -> 0.88 ms.
         // With more mask words the records outgrow the LDS a well-occupied CU can give them (k = 256, 2 pixels per

@@ -28,7 +28,9 @@ __all__ = ["ImageProcessor", "Algorithm", "ReduceMode", "Lloyd", "ApplyPlan", "G
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _PKG_ROOT = os.path.dirname(os.path.dirname(_HERE))          # .../kmeans-gpu_amd
-_LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libkmeans_hip.so")
+# KMG_LIBRARY: another build of the same ABI -- tools/ loads lib/libkmeans_hip_tools.so (make tools: tuning switches and
+# knock-outs compiled in) through it; the product library reads none of those switches
+_LIB_PATH = os.environ.get("KMG_LIBRARY") or os.path.join(_PKG_ROOT, "lib", "libkmeans_hip.so")
 
 
 class _RawDeviceArray:

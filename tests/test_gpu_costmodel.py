@@ -1,0 +1,78 @@
+"""The strategy choice of kmg_lloyd_prepare (csrc/kmg_api.hip table_pays) on a PHOTOGRAPH near its crossover (-m gpu): the cost
+model was fitted on uniform noise (tools/strategy_sweep.py); a photograph has fewer occupied cells (a cheaper cube pass) and
+crowded ones (more candidates per colour).  Both strategies are timed on the tiled test photograph at 1, 2 and 4 Mpx for
+k = 16 and k = 256; the test fails when the library's own choice is more than 15 % slower than the other strategy."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _time_strategy(torch, kg, proc, rgba, n, k, cent, strategy, monkeypatch, iters=30, repeats=3):
+    st = torch.cuda.current_stream().cuda_stream
+    monkeypatch.setenv("KMG_STRATEGY", {"scan": "brute", "table": "table"}[strategy])
+    labels = torch.empty(n, dtype=torch.int32, device="cuda")
+    acc = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
+    s = kg.Lloyd(proc, k)
+    s.set_centroids(cent, st)
+    s.prepare(rgba.data_ptr(), n, True, st)              # (first binding: blocks, static tables)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    assert s.prepare(rgba.data_ptr(), n, True, st) == strategy
+    torch.cuda.synchronize()
+    prep = time.perf_counter() - t
+    best = None
+    for _ in range(repeats):
+        s.set_centroids(cent, st)
+        for _ in range(3):
+            s.assign_update(rgba.data_ptr(), n, labels.data_ptr(), acc.data_ptr(), True, st)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(iters):
+            s.assign_update(rgba.data_ptr(), n, labels.data_ptr(), acc.data_ptr(), True, st)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t) / iters
+        best = dt if best is None else min(best, dt)
+    s.close()
+    # the model spreads the one-off binding over ~16 passes (kmg_api.hip bind_seconds)
+    return best + (prep / 16.0 if strategy == "table" else 0.0)
+
+
+def test_prepare_picks_the_faster_strategy_on_a_photograph_near_the_crossover(torch_cuda, monkeypatch):
+    import bench
+    import kmeans_gpu_amd as kg
+    torch = torch_cuda
+    st = torch.cuda.current_stream().cuda_stream
+    proc = kg.ImageProcessor(shrink_max_dim=0)
+    rows = []
+    failures = []
+    for mpx in (1, 2, 4):
+        n = mpx << 20
+        rgba = bench.synthetic_image("photo", n, 0, 0, 1)
+        for k in (16, 256):
+            sel = rgba[(torch.arange(k, device="cuda") * (n // k))].contiguous()
+            lab = torch.empty((k, 3), dtype=torch.float32, device="cuda")
+            proc.rgb_to_lab(sel.data_ptr(), k, lab.data_ptr(), st)
+            torch.cuda.synchronize()
+            cent = np.ones((k, 4), np.float32)
+            cent[:, :3] = lab.cpu().numpy()
+            monkeypatch.delenv("KMG_STRATEGY", raising=False)
+            s = kg.Lloyd(proc, k)
+            s.set_centroids(cent, st)
+            auto = s.prepare(rgba.data_ptr(), n, True, st)
+            s.close()
+            t = {name: _time_strategy(torch, kg, proc, rgba, n, k, cent, name, monkeypatch) for name in ("scan", "table")}
+            other = "table" if auto == "scan" else "scan"
+            rows.append(f"{mpx} Mpx k={k}: auto={auto} scan {t['scan'] * 1e6:.1f} us table {t['table'] * 1e6:.1f} us")
+            if t[auto] > 1.15 * t[other]:
+                failures.append(rows[-1])
+    print("\n".join(rows))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "costmodel_photo.txt"), "w") as f:
+            f.write("\n".join(rows) + "\n")
+    proc.close()
+    assert not failures, "kmg_lloyd_prepare's choice is > 15 % slower than the other strategy:\n" + "\n".join(failures)

@@ -18,16 +18,37 @@ def test_random_problems_agree_across_strategies(seed):
     assert "40 cases, 0 mismatching" in r.stdout
 
 
+# every switch the TOOLS build of the library reads (kmg_internal.h KMG_TOOLS_ENV / KMG_KNOCK), set to a value that changes a
+# launch shape or -- the knock-outs -- skips work and returns wrong results there
+TOOLS_SWITCHES = {"KMG_LABEL_KNOCK": "3", "KMG_CUBE_FLAGS": "0x2700", "KMG_DITHER_KNOCK": "15", "KMG_ASSIGN_PPT": "1", "KMG_HOT_CELLS": "0",
+                  "KMG_CUBE_REPL": "1", "KMG_CUBE_SMALL": "0", "KMG_DITHER_SORT": "0", "KMG_CUBE_GRID": "7", "KMG_SCAN_GRID": "5",
+                  "KMG_PAIRS_GRID": "3", "KMG_SMALL_GRID": "9", "KMG_DITHER_STATS": "1"}
+
+
+def test_product_library_does_not_contain_the_tools_switches():
+    """`strings lib/libkmeans_hip.so | grep -c KNOCK` is 0: the knock-outs (kernel variants that return WRONG results) and the
+    tuning switches are compiled into lib/libkmeans_hip_tools.so only (make tools, -DKMG_TOOLS)"""
+    blob = open(os.path.join(ROOT, "kmeans-gpu_amd", "lib", "libkmeans_hip.so"), "rb").read()
+    assert b"KNOCK" not in blob
+    for name in TOOLS_SWITCHES:
+        assert name.encode() not in blob, name
+    for name in (b"KMG_STRATEGY", b"KMG_LOG", b"KMG_RCCL_LIBRARY"):          # what the product does read
+        assert name in blob
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["0", "2"])
-def test_alternative_cube_passes_of_small_centroid_tables(mode):
-    """KMG_CUBE_SMALL = 0 (the general three-launch pass for k <= 32 too) and 2 (k_cube_small as the stage only, then the general
-    scan and entries launches): the A/B switches of round 4 stay exact -- same random problems, fresh process (the switch is read once)."""
-    env = dict(os.environ, KMG_CUBE_SMALL=mode)
+def test_product_library_ignores_every_tools_switch():
+    """with all of them set, the product library still returns what the per-pixel scans return (and the oracle: the next test)"""
+    env = dict(os.environ, **TOOLS_SWITCHES)
+    env.pop("KMG_LIBRARY", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "24", "21"], capture_output=True, text=True,
                        timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "24 cases, 0 mismatching" in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_default_call.py"), "12", "5"], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "12 cases, 0 mismatching" in r.stdout
 
 
 @pytest.mark.gpu

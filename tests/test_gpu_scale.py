@@ -443,3 +443,52 @@ def test_cfg4_one_ranks_share_of_the_batch(torch_cuda, oracle):
     for s in backends + helpers:
         s.close()
     p.close()
+
+
+def test_band_with_random_alpha_equals_the_oracle_and_the_opaque_band(torch_cuda, oracle, monkeypatch):
+    """Alpha is ignored on input (rgb_to_lab.wgsl:78) and forced to 255 on output (lab_to_rgb.wgsl:37): a 1024-row band of the
+    8192-wide benchmark image with RANDOM alpha bytes gives the labels, sums and dither / meld / replace bytes of the same band
+    with alpha 255 -- and those of the oracle -- through both strategies (the colour table masks alpha when it builds colour
+    indices, kmg_table.h colour_index; the per-pixel kernels never read it)."""
+    import kmeans_gpu_amd as kg
+    from kmeans_gpu_amd import synth
+    torch = torch_cuda
+    st = _stream(torch)
+    w, rows, k = 8192, 1024, 64
+    n = w * rows
+    opaque = synth.uniform_rgba_torch(synth.SEED_CFG3, n, device="cuda")
+    g = torch.Generator(device="cuda"); g.manual_seed(77)
+    rgba = opaque.clone()
+    rgba[:, 3] = torch.randint(0, 256, (n,), generator=g, device="cuda", dtype=torch.int32).to(torch.uint8)
+    assert int((rgba[:, 3] != 255).sum()) > n // 2
+    cent = _cfg3_centroids(oracle, synth, n, k)
+    host = rgba.cpu().numpy()
+    want_l, want_a = oracle.assign_accumulate_rgba(host[:w * 64], cent)            # (the oracle on the first 64 rows)
+    p = kg.ImageProcessor(shrink_max_dim=0)
+    results = {}
+    for strategy in ("table", "brute"):
+        monkeypatch.setenv("KMG_STRATEGY", strategy)
+        for name, src in (("alpha", rgba), ("opaque", opaque)):
+            s = kg.Lloyd(p, k)
+            s.set_centroids(cent, st)
+            s.prepare(src.data_ptr(), n, True, st)
+            labels = torch.zeros(n, dtype=torch.int32, device="cuda")
+            acc = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
+            s.assign_accumulate(src.data_ptr(), n, labels.data_ptr(), acc.data_ptr(), st)
+            outs = []
+            for mode in (kg.ReduceMode.Replace, kg.ReduceMode.Dither, kg.ReduceMode.Meld):
+                out = torch.zeros((n, 4), dtype=torch.uint8, device="cuda")
+                p.apply(src.data_ptr(), w, rows, 0, cent, mode, out.data_ptr(), st)
+                outs.append(out)
+            torch.cuda.synchronize()
+            results[(strategy, name)] = (labels, acc, *outs)
+            s.close()
+    ref = results[("table", "opaque")]
+    for key, got in results.items():
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b), key
+    assert np.array_equal(ref[0][:w * 64].cpu().numpy().view(np.uint32), want_l)
+    assert int((ref[3][:, 3] != 255).sum()) == 0
+    band = host[:w * 64].reshape(64, w, 4)
+    assert np.array_equal(results[("table", "alpha")][3][:w * 64].cpu().numpy().reshape(64, w, 4), oracle.apply(band, cent, oracle.MODE_DITHER))
+    p.close()

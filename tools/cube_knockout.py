@@ -11,6 +11,7 @@ cases = [("baseline", 0), ("no pair entry", 0x100), ("no sums", 0x200), ("no col
 extra = sys.argv[1:]
 for name, fl in cases:
     env = dict(os.environ, KMG_CUBE_FLAGS=hex(fl))
+    use_tools_library(env)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-extras", "--steps", "10"] + extra,
                          env=env, capture_output=True, text=True).stdout.strip().splitlines()
     try:

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Knock-out timing of the cfg5 output pass (k_dither_pruned), run on the GPU box; results of knocked-out runs are wrong by design."""
-import os, subprocess, sys
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _toolslib import use_tools_library, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, os.path.join(ROOT, "kmeans-gpu_amd", "python"))
@@ -27,5 +30,6 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
 for name, kn in (("baseline", 0), ("no mask gather", 1), ("no candidates", 2), ("no Lab conversion", 4), ("no palette gather", 8),
                  ("no gather, no candidates", 3), ("none of the four", 15)):
     env = dict(os.environ, KMG_DITHER_KNOCK=str(kn))
+    use_tools_library(env)
     r = subprocess.run([sys.executable, __file__, "child"], env=env, capture_output=True, text=True)
     print(f"{name:30s} {r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-300:]}", flush=True)

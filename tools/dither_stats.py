@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Candidate counts of the dither output pass per (cell, Bayer index) slot and per cell (KMG_DITHER_STATS makes
 kmg_debug_check_dither_masks print both distributions to stderr); run on the GPU box."""
-import os, sys
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _toolslib import use_tools_library
+use_tools_library(), sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "kmeans-gpu_amd", "python"))
 os.environ["KMG_DITHER_STATS"] = "1"

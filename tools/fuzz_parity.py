@@ -28,7 +28,8 @@ def image(kind, w, h):
     else:  # gradient
         i = np.arange(n)
         a = np.stack([(i % w) * 255 // max(w - 1, 1), (i // w) * 255 // max(h - 1, 1), (i * 7) % 256, i % 256], 1).astype(np.uint8)
-    a[:, 3] = 255
+    # alpha is ignored on input (rgb_to_lab.wgsl:78) and 255 on output (lab_to_rgb.wgsl:37): every image carries random alpha
+    a[:, 3] = rng.integers(0, 256, n, dtype=np.uint8)
     return a
 
 

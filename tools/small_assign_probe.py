@@ -2,7 +2,11 @@
 """k_assign on the reference's default working size (an image shrunk to <= 256 x 256): time per launch by pixels per thread
 (KMG_ASSIGN_PPT, set per run), labels only / sums only / both, k = 8, 64, 256.
     for P in 1 2 4 8; do KMG_ASSIGN_PPT=$P python tools/small_assign_probe.py; done"""
-import os, sys, time
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _toolslib import use_tools_library
+use_tools_library(), sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "kmeans-gpu_amd", "python"))
 import numpy as np, torch
