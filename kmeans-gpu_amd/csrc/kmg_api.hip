@@ -1385,6 +1385,27 @@ extern "C" int kmg_lloyd_init_centroids(kmg_lloyd *s, const uint8_t *d_rgba, uin
             HIP_TRY(block_take(s->p, sizeof(float) * n, (void **)&s->d_dist, &s->dist_blk_cap));
             s->dist_cap = n;
         }
+        // Per-pixel passes of a whole image, k >= 32: several centroids per launch (kmg_kernels.h
+        // launch_init_multi).  Launches go out in chunks -- the reference submits its passes 32 at a time and polls,
+        // modules.rs:949,1211-1246 -- and the number of centroids chosen so far comes back in between (a launch picks one to
+        // four; one that finds the table complete does nothing).
+        if (!colours && s->k >= 32u && init_multi_bytes(n) <= sizeof(int64_t) * 4ull * s->k * 2048ull) {
+            uint32_t have = 1u, launch = 1u, launches = 0u;
+            while (have < s->k) {
+                // (launch 1 only sweeps; early launches pick ~1.3 centroids each, late ones ~3: a third of what is missing, then look)
+                const uint32_t chunk = (launch == 1u ? 1u : 0u) + (s->k - have + 2u) / 3u;
+                for (uint32_t q = 0; q < chunk; ++q, ++launch)
+                    HIP_TRY(launch_init_multi(rgba, n, s->p->d_lut, s->d_cent, s->k, launch, s->d_dist, s->d_partials, S(stream)));
+                launches += chunk;
+                uint32_t *h = s->h_slot ? static_cast<uint32_t *>(s->h_slot) : &have;
+                HIP_TRY(hipMemcpyAsync(h, init_multi_count(s->d_partials, n, launch - 1u), sizeof(uint32_t), hipMemcpyDeviceToHost, S(stream)));
+                HIP_TRY(hipStreamSynchronize(S(stream)));
+                have = *static_cast<volatile uint32_t *>(h);
+                if (have == 0u || have > s->k) return fail(KMG_ERR_HIP, "initialisation: centroid count %u out of range", have);
+            }
+            if (log_debug()) fprintf(stderr, "[kmeans_hip] initialisation: %u centroids in %u launches\n", s->k, launches);
+            return KMG_OK;
+        }
         for (uint32_t j = 1; j < s->k + (colours ? 1u : 0u); ++j) {   // modules.rs:1211-1246
             if (colours) {
                 // launch j picks centroid j - 1 and runs pass j; launch k only picks

@@ -56,6 +56,14 @@ hipError_t launch_init_pass(const uint32_t *rgba, uint64_t n, const float *lut,
                             Centroid *cent, uint32_t j, float *dist,
                             unsigned long long *key, uint64_t first_index, hipStream_t st, bool pick = false);
 size_t init_slots_bytes();
+// Whole image on one device, SEVERAL centroids per launch (kmg_kernels.hip k_init_multi): launch L = 1, 2, ... picks up to four
+// centroids from what launch L - 1 left in `scratch` (init_multi_bytes(n); centroid 0 is there: launch_init_first) and sweeps the
+// running distances against all of them; a launch that finds the table complete does nothing.  *init_multi_count(scratch, n, L)
+// (device memory) = centroids chosen after launch L: the host enqueues launches in chunks and reads it in between.
+size_t init_multi_bytes(uint64_t n);
+hipError_t launch_init_multi(const uint32_t *rgba, uint64_t n, const float *lut, Centroid *cent, uint32_t k, uint32_t launch,
+                             float *dist, void *scratch, hipStream_t st);
+const uint32_t *init_multi_count(const void *scratch, uint64_t n, uint32_t launch);
 hipError_t launch_init_pick_slots(const uint32_t *rgba, uint64_t n, const float *lut, const unsigned long long *slots, Centroid *cent,
                                   uint32_t j, hipStream_t st);
 // sharded init (row bands): publish the colour of the pixel named by an all-reduced key; set one centroid

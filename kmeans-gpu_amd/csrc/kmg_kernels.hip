@@ -668,6 +668,216 @@ __global__ __launch_bounds__(kBlock) void k_init_pick_slots(const uint32_t *__re
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Several centroids per launch, exactly (whole image on one device; round 5).
+//
+// A pass only LOWERS running distances, so every pixel's key can only decrease.  Let k1 > k2 > ... be the largest keys after
+// the sweep that applied centroids c_0 .. c_{t-1}; c_t = pixel(k1) (plus_plus_init.wgsl:172-181).  If cie94(pixel(k2), c_t) >=
+// dist(k2), the sweep against c_t leaves k2 untouched while every other key stays below it or drops: pixel(k2) IS c_{t+1} --
+// without that sweep.  Likewise pixel(k3) against c_t and c_{t+1}, and so on until the first failure.  (A key whose distance
+// is 0 is never accepted this way: that case is Candidate(0, 0.0) = pixel 0, init_key_index.)  One launch therefore
+//   [picks up to kInitMulti centroids from the top keys the previous launch left] -> [one sweep: dist = min(dist, all of them)]
+// Farthest points are far from each other: the reference's default call (<= 256 x 256 pixels, k = 256) takes ~90 launches
+// instead of 255 (measured acceptance: profiles/NOTES.md round 5), each a chain of round trips whatever it computes.
+// slots: [2][grid][kInitMulti] candidates (key + Lab of its pixel), one row per WORKGROUP of launch parity L & 1 (sorted,
+// largest first; key 0 = none);
+// count[2]: centroids chosen after launch parity L & 1.  The host enqueues launches in chunks and reads count between them.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kInitMulti = 4;
+
+// a candidate: its key and the Lab of its pixel (travels with the key, so that a pick fetches no pixel)
+struct alignas(16) InitCand { unsigned long long key; float L, a, b; uint32_t pad; };
+static_assert(sizeof(InitCand) == 32, "InitCand layout");
+
+struct TopList {
+    unsigned long long key[kInitMulti];
+    float L[kInitMulti], a[kInitMulti], b[kInitMulti];
+};
+
+__device__ __forceinline__ void top_clear(TopList &t)
+{
+#pragma unroll
+    for (uint32_t i = 0; i < kInitMulti; ++i) { t.key[i] = 0ull; t.L[i] = 0.0f; t.a[i] = 0.0f; t.b[i] = 0.0f; }
+}
+
+__device__ __forceinline__ void top_insert(TopList &t, unsigned long long x, float L, float a, float b)
+{
+    if (x > t.key[kInitMulti - 1]) {
+        t.key[kInitMulti - 1] = x; t.L[kInitMulti - 1] = L; t.a[kInitMulti - 1] = a; t.b[kInitMulti - 1] = b;
+#pragma unroll
+        for (int i = (int)kInitMulti - 1; i > 0; --i)
+            if (t.key[i] > t.key[i - 1]) {
+                const unsigned long long u = t.key[i]; t.key[i] = t.key[i - 1]; t.key[i - 1] = u;
+                float f;
+                f = t.L[i]; t.L[i] = t.L[i - 1]; t.L[i - 1] = f;
+                f = t.a[i]; t.a[i] = t.a[i - 1]; t.a[i - 1] = f;
+                f = t.b[i]; t.b[i] = t.b[i - 1]; t.b[i - 1] = f;
+            }
+    }
+}
+
+// the largest head of the lanes' sorted lists: every lane gets the key, the lane that holds it writes the candidate to
+// *out and drops it from its list (keys are distinct or 0; key 0: lane 0 writes an empty candidate)
+__device__ __forceinline__ void wave_pop_max(TopList &t, InitCand *out, uint32_t lane)
+{
+    const uint32_t hi = (uint32_t)(t.key[0] >> 32), lo = (uint32_t)t.key[0];
+    const uint32_t mhi = wave_max_u32_dpp(hi);
+    const uint32_t mlo = wave_max_u32_dpp(hi == mhi ? lo : 0u);
+    const unsigned long long g = ((unsigned long long)mhi << 32) | mlo;
+    if (g == 0ull) {
+        if (lane == 0u) { InitCand o; o.key = 0ull; o.L = 0.0f; o.a = 0.0f; o.b = 0.0f; o.pad = 0u; *out = o; }
+    } else if (t.key[0] == g) {
+        InitCand o; o.key = g; o.L = t.L[0]; o.a = t.a[0]; o.b = t.b[0]; o.pad = 0u;
+        *out = o;
+#pragma unroll
+        for (uint32_t i = 0; i + 1 < kInitMulti; ++i) { t.key[i] = t.key[i + 1]; t.L[i] = t.L[i + 1]; t.a[i] = t.a[i + 1]; t.b[i] = t.b[i + 1]; }
+        t.key[kInitMulti - 1] = 0ull;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_init_multi(const uint32_t *__restrict__ rgba, uint64_t n, const float *__restrict__ lut,
+                                                       Centroid *__restrict__ cent, uint32_t k, uint32_t launch, float *__restrict__ dist,
+                                                       InitCand *__restrict__ slots, uint32_t *__restrict__ count)
+{
+    constexpr uint32_t kWaves = kBlock / 64;
+    __shared__ float s_lut[256];
+    __shared__ InitCand s_top[kWaves * kInitMulti];
+    __shared__ InitCand s_best[kInitMulti];
+    __shared__ uint32_t s_fail;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t n_rows = gridDim.x;                              // rows of a slot set: one per workgroup of a launch
+    s_lut[threadIdx.x] = lut[threadIdx.x];
+    if (threadIdx.x == 0) s_fail = 0u;
+    // (this thread's first pixel and its running distance do not depend on the picks: requested before them)
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    const uint64_t i_first = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    uint32_t px_first = 0u;
+    float d_first = 1000000.0f;                                     // kmeans++_calc_diff.wgsl:26-30
+    if (i_first < n) {
+        px_first = rgba[i_first];
+        if (launch != 1u) d_first = dist[i_first];
+    }
+    uint32_t n_new = 1u;                                            // centroids this launch sweeps against
+    float L_first = 0.0f, a_first = 0.0f, b_first = 0.0f;
+    if (launch == 1u) {
+        // centroid 0 is there (k_init_first): nothing to pick
+        if (threadIdx.x == 0) {
+            const Centroid c0 = cent[0];
+            InitCand o; o.key = 0ull; o.L = c0.L; o.a = c0.a; o.b = c0.b; o.pad = 0u;
+            s_best[0] = o;
+            if (blockIdx.x == 0) count[1] = 1u;
+        }
+        __syncthreads();
+        px_to_lab(s_lut, px_first, L_first, a_first, b_first);
+    } else {
+        // the kInitMulti largest candidates of the previous launch: every thread merges its share of the rows, every wave
+        // its threads', thread 0..15 ranks the waves' 16.  The first rows of a thread are requested whole and together with
+        // the count -- one round trip; a row is sorted, so further rows (large grids) are read only when their head counts.
+        const InitCand *prev = slots + (uint64_t)((launch - 1u) & 1u) * n_rows * kInitMulti;
+        TopList t;
+        top_clear(t);
+        {
+            // thread r takes row r (sorted: it IS the thread's list) -- requested together with the count: one round trip
+            InitCand row[kInitMulti];
+#pragma unroll
+            for (uint32_t e = 0; e < kInitMulti; ++e) {
+                row[e].key = 0ull; row[e].L = 0.0f; row[e].a = 0.0f; row[e].b = 0.0f;
+                if (threadIdx.x < n_rows) row[e] = prev[(uint64_t)threadIdx.x * kInitMulti + e];
+            }
+            const uint32_t have_ = count[(launch - 1u) & 1u];
+            if (have_ >= k) {                                       // the table is complete: an empty launch of a chunk
+                if (blockIdx.x == 0 && threadIdx.x == 0) count[launch & 1u] = have_;
+                return;
+            }
+#pragma unroll
+            for (uint32_t e = 0; e < kInitMulti; ++e) { t.key[e] = row[e].key; t.L[e] = row[e].L; t.a[e] = row[e].a; t.b[e] = row[e].b; }
+        }
+        const uint32_t have = count[(launch - 1u) & 1u];
+        // (more workgroups than threads -- images beyond 65 536 pixels: further rows are read only when their head counts)
+        for (uint32_t r = threadIdx.x + kBlock; r < n_rows; r += kBlock) {
+            const InitCand *rp = prev + (uint64_t)r * kInitMulti;
+            if (rp[0].key > t.key[kInitMulti - 1])
+                for (uint32_t e = 0; e < kInitMulti; ++e) { const InitCand cnd = rp[e]; top_insert(t, cnd.key, cnd.L, cnd.a, cnd.b); }
+        }
+#pragma unroll
+        for (uint32_t r = 0; r < kInitMulti; ++r) wave_pop_max(t, &s_top[wv * kInitMulti + r], lane);
+        __syncthreads();
+        px_to_lab(s_lut, px_first, L_first, a_first, b_first);      // (own pixel: independent of the picks)
+        if (threadIdx.x < kWaves * kInitMulti) {
+            const InitCand mine = s_top[threadIdx.x];
+            uint32_t rank = 0;
+            for (uint32_t q = 0; q < kWaves * kInitMulti; ++q) {
+                const unsigned long long o = s_top[q].key;
+                rank += (o > mine.key || (o == mine.key && q < threadIdx.x)) ? 1u : 0u;
+            }
+            if (rank < kInitMulti) {
+                InitCand o = mine;
+                if ((uint32_t)(o.key >> 32) == 0u && rank == 0u) {
+                    // every distance is 0: Candidate(0, 0.0) = pixel 0 (plus_plus_init.wgsl:62-68, 172-181)
+                    px_to_lab(s_lut, rgba[0], o.L, o.a, o.b);
+                }
+                s_best[rank] = o;
+            }
+        }
+        __syncthreads();
+        // the tests: thread (a, b), b < a -- does the sweep against candidate b leave candidate a's distance alone?
+        if (threadIdx.x < kInitMulti * kInitMulti) {
+            const uint32_t a = threadIdx.x / kInitMulti, b = threadIdx.x % kInitMulti;
+            if (b < a) {
+                const InitCand pa = s_best[a], cb = s_best[b];
+                const float have_d = bits_to_float((uint32_t)(pa.key >> 32));
+                if (!(cie94(pa.L, pa.a, pa.b, cb.L, cb.a, cb.b) >= have_d)) atomicOr(&s_fail, 1u << a);
+            }
+        }
+        __syncthreads();
+        const uint32_t fail = s_fail;
+        if ((uint32_t)(s_best[0].key >> 32) != 0u) {                // (all distances zero: one pick)
+            while (n_new < kInitMulti && have + n_new < k && (uint32_t)(s_best[n_new].key >> 32) != 0u && !((fail >> n_new) & 1u)) ++n_new;
+        }
+        if (blockIdx.x == 0 && threadIdx.x < n_new) {
+            const InitCand o = s_best[threadIdx.x];
+            Centroid c; c.L = o.L; c.a = o.a; c.b = o.b; c.C = chroma(o.a, o.b);
+            cent[have + threadIdx.x] = c;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) count[launch & 1u] = have + n_new;
+        if (have + n_new >= k) return;                              // the last centroids: no distances are needed any more
+    }
+    float cL[kInitMulti], ca[kInitMulti], cb_[kInitMulti];
+#pragma unroll
+    for (uint32_t q = 0; q < kInitMulti; ++q) { const InitCand o = s_best[q < n_new ? q : 0u]; cL[q] = o.L; ca[q] = o.a; cb_[q] = o.b; }
+    TopList t;
+    top_clear(t);
+    for (uint64_t i = i_first; i < n; i += stride) {
+        float L, a, b, before;
+        if (i == i_first) { L = L_first; a = a_first; b = b_first; before = d_first; }
+        else { px_to_lab(s_lut, rgba[i], L, a, b); before = launch == 1u ? 1000000.0f : dist[i]; }
+        // (all kInitMulti distances, unconditionally -- entries beyond n_new repeat the first: four independent chains that
+        // the scheduler interleaves cost little more than one, a branch per centroid serialises them)
+        float d4[kInitMulti];
+#pragma unroll
+        for (uint32_t q = 0; q < kInitMulti; ++q) d4[q] = cie94(L, a, b, cL[q], ca[q], cb_[q]);
+        const float m = fminf(fminf(before, d4[0]), fminf(fminf(d4[1], d4[2]), d4[3]));
+        dist[i] = m;
+        const unsigned long long kk = ((unsigned long long)float_to_bits(m) << 32) |
+                                      (unsigned long long)(((uint32_t)(i >> 4) << 4) | (15u - (uint32_t)(i & 15u)));
+        top_insert(t, kk, L, a, b);
+    }
+    // the workgroup's row: its waves' top candidates, ranked by 16 threads
+    __syncthreads();                                                // (s_top / s_best of the picks are read no more)
+#pragma unroll
+    for (uint32_t r = 0; r < kInitMulti; ++r) wave_pop_max(t, &s_top[wv * kInitMulti + r], lane);
+    __syncthreads();
+    if (threadIdx.x < kWaves * kInitMulti) {
+        const InitCand mine = s_top[threadIdx.x];
+        uint32_t rank = 0;
+        for (uint32_t q = 0; q < kWaves * kInitMulti; ++q) {
+            const unsigned long long o = s_top[q].key;
+            rank += (o > mine.key || (o == mine.key && q < threadIdx.x)) ? 1u : 0u;
+        }
+        if (rank < kInitMulti) slots[((uint64_t)(launch & 1u) * n_rows + blockIdx.x) * kInitMulti + rank] = mine;
+    }
+}
+
 static uint32_t init_pass_grid(uint64_t n)
 {
     const uint64_t blocks = (n + kBlock - 1) / kBlock;
@@ -675,6 +885,25 @@ static uint32_t init_pass_grid(uint64_t n)
 }
 
 size_t init_slots_bytes() { return sizeof(unsigned long long) * 2u * kInitSlots; }
+
+static size_t init_multi_cands(uint64_t n) { return 2ull * init_pass_grid(n) * kInitMulti; }
+
+size_t init_multi_bytes(uint64_t n) { return sizeof(InitCand) * init_multi_cands(n) + 2u * sizeof(uint32_t); }
+
+hipError_t launch_init_multi(const uint32_t *rgba, uint64_t n, const float *lut, Centroid *cent, uint32_t k, uint32_t launch,
+                             float *dist, void *scratch, hipStream_t st)
+{
+    InitCand *slots = static_cast<InitCand *>(scratch);
+    uint32_t *count = reinterpret_cast<uint32_t *>(slots + init_multi_cands(n));
+    hipLaunchKernelGGL(k_init_multi, dim3(init_pass_grid(n)), dim3(kBlock), 0, st, rgba, n, lut, cent, k, launch, dist, slots, count);
+    return hipGetLastError();
+}
+
+const uint32_t *init_multi_count(const void *scratch, uint64_t n, uint32_t launch)
+{
+    const InitCand *slots = static_cast<const InitCand *>(scratch);
+    return reinterpret_cast<const uint32_t *>(slots + init_multi_cands(n)) + (launch & 1u);
+}
 
 hipError_t launch_init_pick_slots(const uint32_t *rgba, uint64_t n, const float *lut, const unsigned long long *slots, Centroid *cent,
                                   uint32_t j, hipStream_t st)

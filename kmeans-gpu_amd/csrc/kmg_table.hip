@@ -1041,7 +1041,18 @@ __global__ __launch_bounds__(kLabelBlock) void k_labels_pairs(const uint32_t *__
         for (int p = 0; p < 8; ++p) {
             const uint32_t e = s_pair[(ci[p] >> 9) & (kPairWords - 1u)];
             const uint32_t code = (e >> 16) & 127u;
-            const int proj = __builtin_amdgcn_sdot4((int)xyz[p], (int)s_dir[code], 0, false);
+            uint32_t dirw;
+            if (KNOCK == 10) {
+                // probe (round 5, results RIGHT): the direction word computed from its code instead of read from LDS
+                const uint32_t qx = (code * 41u) >> 10, rem = code - 25u * qx;      // code / 25, code < 128
+                const uint32_t qy = (rem * 13u) >> 6, qz = rem - 5u * qy;           // rem / 5, rem < 28
+                const int nx = (int)qx - 2, ny = (int)qy - 2, nz = (int)qz - 2;
+                const int bias = 7 * (max(-nx, 0) + max(-ny, 0) + max(-nz, 0));
+                dirw = ((uint32_t)nx & 255u) | (((uint32_t)ny & 255u) << 8) | (((uint32_t)nz & 255u) << 16) | ((uint32_t)bias << 24);
+            } else {
+                dirw = s_dir[code];
+            }
+            const int proj = __builtin_amdgcn_sdot4((int)xyz[p], (int)dirw, 0, false);
             const int tlo = (int)((e >> 23) & 63u), w = (int)(e >> 29);
             const bool inA = proj < tlo, inB = proj >= tlo + w + (w == 7 ? 64 : 0);
             lab[p] = inA ? (e & 0xFFu) : ((e >> 8) & 0xFFu);
@@ -1050,10 +1061,41 @@ __global__ __launch_bounds__(kLabelBlock) void k_labels_pairs(const uint32_t *__
                 lab[p] = (uint32_t)s_hot[(e & 0xFFu) * kCellColours + (ci[p] & (kCellColours - 1u))];
             }
         }
+        if (KNOCK == 11) {
+            // probe (round 5): what ONE more random LDS read per pixel costs (the label is xor-ed with a bit that is always 0)
+#pragma unroll
+            for (int p = 0; p < 8; ++p) lab[p] ^= s_pair[(ci[p] >> 7) & (kPairWords - 1u)] >> 31 & (lab[p] >> 30);
+        }
+        if (KNOCK == 9) {
+            // probe (round 5, results wrong): the COST of a second-plane extension entry -- bitmap word, prefix count, rank, the
+            // entry and its plane test, all from LDS, for the pixels the first entry leaves to the gather -- and the GAIN it is
+            // simulated to have on the benchmark image (tools/pair_schemes.py: 2.9 of the 15.8 points of gathering pixels)
+            // (branch-free: every slot's chain of four dependent LDS reads is in flight beside the others'; as eight
+            // divergent branches the pass went from 158 to 237 us)
+            uint32_t word[8], pre[8], e2[8], d2[8];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) { const uint32_t cell = ci[p] >> 9; word[p] = s_pair[(cell >> 5) & 1023u]; pre[p] = s_pair[1024u + ((cell >> 6) & 511u)]; }
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const uint32_t cell = ci[p] >> 9;
+                const uint32_t rank = (pre[p] & 0x1FFFu) + (uint32_t)__builtin_popcount(word[p] & ((1u << (cell & 31u)) - 1u));
+                e2[p] = s_pair[2048u + (rank & 8191u)];
+            }
+#pragma unroll
+            for (int p = 0; p < 8; ++p) d2[p] = s_dir[(e2[p] >> 16) & 127u];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int proj2 = __builtin_amdgcn_sdot4((int)xyz[p], (int)d2[p], 0, false);
+                const int tlo2 = (int)((e2[p] >> 23) & 63u), w2 = (int)(e2[p] >> 29);
+                const bool resolved = fine[p] && (proj2 < tlo2 || proj2 >= tlo2 + w2) && ((ci[p] * 2654435761u) >> 25) < 24u;    // 24 / 128 = 18.75 %
+                lab[p] = resolved ? (proj2 < tlo2 ? (e2[p] & 0xFFu) : ((e2[p] >> 8) & 0xFFu)) : lab[p];
+                fine[p] = fine[p] && !resolved;
+            }
+        }
 #pragma unroll
         for (int p = 0; p < 8; ++p)
             if (fine[p]) {
-                if (KNOCK == 0 || KNOCK == 6 || KNOCK == 7 || KNOCK == 8) lab[p] = (uint32_t)colour_labels[ci[p]];
+                if (KNOCK == 0 || KNOCK >= 6) lab[p] = (uint32_t)colour_labels[ci[p]];
                 else if (KNOCK == 1) lab[p] = (uint32_t)colour_labels[ci[p] & 0xFFFFu];
                 else if (KNOCK == 2) lab[p] = (uint32_t)reinterpret_cast<const uint8_t *>(s_pair)[ci[p] & 0x1FFFFu];
                 else if (KNOCK == 4) lab[p] = (uint32_t)__builtin_nontemporal_load(colour_labels + ci[p]);
@@ -1097,7 +1139,7 @@ hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_la
 #define KMG_LK(K) hipLaunchKernelGGL((k_labels_pairs<false, K>), dim3(grid), dim3(kLabelBlock), kLabelLdsPlain, st, rgba, n, \
                                      (const uint8_t *)colour_labels, pairs, pal, k, labels, aligned, hot, tail_sums, tl)
         if (knock == 1) KMG_LK(1); else if (knock == 2) KMG_LK(2); else if (knock == 3) KMG_LK(3); else if (knock == 4) KMG_LK(4);
-        else if (knock == 5) KMG_LK(5); else if (knock == 6) KMG_LK(6); else if (knock == 7) KMG_LK(7);
+        else if (knock == 5) KMG_LK(5); else if (knock == 6) KMG_LK(6); else if (knock == 7) KMG_LK(7); else if (knock == 9) KMG_LK(9); else if (knock == 10) KMG_LK(10); else if (knock == 11) KMG_LK(11);
         else if (knock == 8)
             hipLaunchKernelGGL((k_labels_pairs<false, 8>), dim3(2u * grid), dim3(kLabelBlock), kLabelLdsPlain - sizeof(uint32_t) * kCells / 2u,
                                st, rgba, n, (const uint8_t *)colour_labels, pairs, pal, k, labels, aligned, hot, tail_sums, tl);
