@@ -6,6 +6,10 @@
 //   processor.palette(color_count, &image, algo)           -> std::vector<RGBA8>
 //   processor.find(&image, &colors, &reduce_mode)          -> Image
 //   processor.reduce(color_count, &image, &algo, &mode)    -> Image
+// and, with no counterpart in the single-device reference (lib.rs:38-65 picks one adapter):
+//   ImageProcessor::create_on({0, 1, ..})      -> the same object over a device LIST (kmg_group_*: one processor + RCCL rank per
+//                                                 device; palette / find / reduce tile the image in row bands, same bytes)
+//   processor.reduce_batch(color_count, images, algo, mode) -> whole images per device, side by side
 // `anyhow::Result` errors become kmeans_color_gpu::Error exceptions carrying the kmg_status and the
 // library's message.  Header only; link with -lkmeans_hip.
 #pragma once
@@ -68,24 +72,39 @@ public:
     // lib.rs:38-65
     static ImageProcessor create() { return ImageProcessor(nullptr); }
     static ImageProcessor create(const kmg_options &opt) { return ImageProcessor(&opt); }
+    // the same constructor over several devices of the node (HIP ordinals; empty = every visible device)
+    static ImageProcessor create_on(const std::vector<int> &devices, const kmg_options *opt = nullptr, uint32_t flags = 0)
+    {
+        kmg_group_options go;
+        kmg_default_group_options(&go);
+        if (devices.size() > KMG_MAX_DEVICES) throw Error(KMG_ERR_INVALID_ARGUMENT, "too many devices");
+        go.n_devices = (uint32_t)devices.size();
+        for (size_t i = 0; i < devices.size(); ++i) go.devices[i] = devices[i];
+        go.flags = flags;
+        if (opt) go.processor = *opt;
+        ImageProcessor p;
+        check(kmg_group_create(&go, &p.g_));
+        return p;
+    }
 
-    ImageProcessor(ImageProcessor &&o) noexcept : p_(o.p_) { o.p_ = nullptr; }
+    ImageProcessor(ImageProcessor &&o) noexcept : p_(o.p_), g_(o.g_) { o.p_ = nullptr; o.g_ = nullptr; }
     ImageProcessor &operator=(ImageProcessor &&o) noexcept
     {
-        if (this != &o) { kmg_processor_destroy(p_); p_ = o.p_; o.p_ = nullptr; }
+        if (this != &o) { release(); p_ = o.p_; g_ = o.g_; o.p_ = nullptr; o.g_ = nullptr; }
         return *this;
     }
     ImageProcessor(const ImageProcessor &) = delete;
     ImageProcessor &operator=(const ImageProcessor &) = delete;
-    ~ImageProcessor() { kmg_processor_destroy(p_); }
+    ~ImageProcessor() { release(); }
 
     // lib.rs:67-77
     std::vector<RGBA8> palette(uint32_t color_count, const Image &image, Algorithm algo) const
     {
         std::vector<RGBA8> out(color_count ? color_count : 1);
         uint32_t n = 0;
-        check(kmg_palette(p_, bytes(image), image.dims.first, image.dims.second, color_count, (int)algo,
-                          reinterpret_cast<uint8_t *>(out.data()), &n));
+        uint8_t *dst = reinterpret_cast<uint8_t *>(out.data());
+        check(g_ ? kmg_group_palette(g_, bytes(image), image.dims.first, image.dims.second, color_count, (int)algo, dst, &n)
+                 : kmg_palette(p_, bytes(image), image.dims.first, image.dims.second, color_count, (int)algo, dst, &n));
         out.resize(n);
         return out;
     }
@@ -94,9 +113,10 @@ public:
     Image find(const Image &image, const std::vector<RGBA8> &colors, ReduceMode reduce_mode) const
     {
         Image out(image.dims, std::vector<RGBA8>(image.rgba.size()));
-        check(kmg_find(p_, bytes(image), image.dims.first, image.dims.second,
-                       reinterpret_cast<const uint8_t *>(colors.data()), (uint32_t)colors.size(), (int)reduce_mode,
-                       reinterpret_cast<uint8_t *>(out.rgba.data())));
+        const uint8_t *pal = reinterpret_cast<const uint8_t *>(colors.data());
+        uint8_t *dst = reinterpret_cast<uint8_t *>(out.rgba.data());
+        check(g_ ? kmg_group_find(g_, bytes(image), image.dims.first, image.dims.second, pal, (uint32_t)colors.size(), (int)reduce_mode, dst)
+                 : kmg_find(p_, bytes(image), image.dims.first, image.dims.second, pal, (uint32_t)colors.size(), (int)reduce_mode, dst));
         return out;
     }
 
@@ -104,17 +124,47 @@ public:
     Image reduce(uint32_t color_count, const Image &image, Algorithm algo, ReduceMode reduce_mode) const
     {
         Image out(image.dims, std::vector<RGBA8>(image.rgba.size()));
-        check(kmg_reduce(p_, bytes(image), image.dims.first, image.dims.second, color_count, (int)algo,
-                         (int)reduce_mode, reinterpret_cast<uint8_t *>(out.rgba.data())));
+        uint8_t *dst = reinterpret_cast<uint8_t *>(out.rgba.data());
+        check(g_ ? kmg_group_reduce(g_, bytes(image), image.dims.first, image.dims.second, color_count, (int)algo, (int)reduce_mode, dst)
+                 : kmg_reduce(p_, bytes(image), image.dims.first, image.dims.second, color_count, (int)algo, (int)reduce_mode, dst));
         return out;
     }
 
-    kmg_processor *handle() const { return p_; }
+    // a batch: whole images per device (a single-device processor takes them one after the other)
+    std::vector<Image> reduce_batch(uint32_t color_count, const std::vector<Image> &images, Algorithm algo, ReduceMode reduce_mode) const
+    {
+        std::vector<Image> out;
+        for (const Image &im : images) out.emplace_back(im.dims, std::vector<RGBA8>(im.rgba.size()));
+        if (!g_) {
+            for (size_t i = 0; i < images.size(); ++i) out[i] = reduce(color_count, images[i], algo, reduce_mode);
+            return out;
+        }
+        std::vector<const uint8_t *> src;
+        std::vector<uint8_t *> dst;
+        std::vector<uint32_t> ws, hs;
+        for (size_t i = 0; i < images.size(); ++i) {
+            src.push_back(bytes(images[i])); dst.push_back(reinterpret_cast<uint8_t *>(out[i].rgba.data()));
+            ws.push_back(images[i].dims.first); hs.push_back(images[i].dims.second);
+        }
+        check(kmg_group_reduce_batch(g_, (uint32_t)images.size(), src.data(), ws.data(), hs.data(), color_count, (int)algo, (int)reduce_mode,
+                                     dst.data()));
+        return out;
+    }
+
+    kmg_processor *handle() const { return g_ ? kmg_group_processor(g_, 0) : p_; }
+    kmg_group *group() const { return g_; }
 
 private:
-    explicit ImageProcessor(const kmg_options *opt) : p_(nullptr)
+    ImageProcessor() : p_(nullptr), g_(nullptr) {}
+    explicit ImageProcessor(const kmg_options *opt) : p_(nullptr), g_(nullptr)
     {
         check(opt ? kmg_processor_create_ex(opt, &p_) : kmg_processor_create(&p_));
+    }
+    void release()
+    {
+        if (g_) kmg_group_destroy(g_);
+        kmg_processor_destroy(p_);
+        g_ = nullptr; p_ = nullptr;
     }
     static const uint8_t *bytes(const Image &im) { return reinterpret_cast<const uint8_t *>(im.rgba.data()); }
     static void check(int rc)
@@ -122,6 +172,7 @@ private:
         if (rc != KMG_OK) throw Error(rc, kmg_last_error());
     }
     kmg_processor *p_;
+    kmg_group *g_;
 };
 
 }  // namespace kmeans_color_gpu

@@ -24,6 +24,25 @@ pub struct kmg_options {
     pub convergence: f32,
 }
 
+/// Opaque `kmg_group`: a processor + RCCL rank per device of a list (include/kmeans_hip.h, "a group of devices").
+#[repr(C)]
+pub struct kmg_group {
+    _private: [u8; 0],
+}
+
+pub const KMG_MAX_DEVICES: usize = 16;
+
+/// `kmg_group_options` (include/kmeans_hip.h); `kmg_default_group_options` fills it in.
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct kmg_group_options {
+    pub struct_size: u32,
+    pub n_devices: u32,
+    pub devices: [i32; KMG_MAX_DEVICES],
+    pub flags: u32,
+    pub processor: kmg_options,
+}
+
 pub const KMG_OK: c_int = 0;
 pub const KMG_ALGO_KMEANS: c_int = 0;
 pub const KMG_ALGO_OCTREE: c_int = 1;
@@ -64,6 +83,41 @@ extern "C" {
     // ImageProcessor::reduce -- lib.rs:116-164
     pub fn kmg_reduce(
         p: *mut kmg_processor,
+        rgba: *const u8,
+        width: u32,
+        height: u32,
+        color_count: u32,
+        algo: c_int,
+        mode: c_int,
+        out_rgba: *mut u8,
+    ) -> c_int;
+    // ImageProcessor::new over a device list (the reference is single-device: lib.rs:38-65) and the same three calls, the image
+    // tiled in row bands over the devices, the k x 4 sums of a sharded Lloyd loop all-reduced by RCCL inside the library
+    pub fn kmg_default_group_options(opt: *mut kmg_group_options);
+    pub fn kmg_group_create(opt: *const kmg_group_options, out: *mut *mut kmg_group) -> c_int;
+    pub fn kmg_group_destroy(g: *mut kmg_group);
+    pub fn kmg_group_palette(
+        g: *mut kmg_group,
+        rgba: *const u8,
+        width: u32,
+        height: u32,
+        color_count: u32,
+        algo: c_int,
+        out_rgba: *mut u8,
+        out_count: *mut u32,
+    ) -> c_int;
+    pub fn kmg_group_find(
+        g: *mut kmg_group,
+        rgba: *const u8,
+        width: u32,
+        height: u32,
+        palette_rgba: *const u8,
+        n_colors: u32,
+        mode: c_int,
+        out_rgba: *mut u8,
+    ) -> c_int;
+    pub fn kmg_group_reduce(
+        g: *mut kmg_group,
         rgba: *const u8,
         width: u32,
         height: u32,

@@ -20,6 +20,8 @@ pub mod image;
 
 pub struct ImageProcessor {
     raw: *mut ffi::kmg_processor,
+    /// non-null: the processor spans several devices (`with_devices`); the calls go through `kmg_group_*`
+    group: *mut ffi::kmg_group,
 }
 
 // every entry point of libkmeans_hip is re-entrant on one processor (per-call stream and workspace)
@@ -41,7 +43,23 @@ impl ImageProcessor {
         let mut raw = std::ptr::null_mut();
         check(unsafe { ffi::kmg_processor_create(&mut raw) })?;
         log::debug!("{}", unsafe { CStr::from_ptr(ffi::kmg_version()) }.to_string_lossy());
-        Ok(ImageProcessor { raw })
+        Ok(ImageProcessor { raw, group: std::ptr::null_mut() })
+    }
+
+    /// The same constructor over several GPUs of the node (HIP ordinals; empty = every visible device).  No counterpart in
+    /// the reference, which picks one adapter (lib.rs:38-65): `palette`, `find` and `reduce` then tile the image in row bands
+    /// over the devices and return the same bytes; a sharded Lloyd loop all-reduces its k x 4 integer sums with RCCL.
+    pub async fn with_devices(devices: &[i32]) -> Result<Self> {
+        let mut opt: ffi::kmg_group_options = unsafe { std::mem::zeroed() };
+        unsafe { ffi::kmg_default_group_options(&mut opt) };
+        if devices.len() > ffi::KMG_MAX_DEVICES {
+            return Err(anyhow!("at most {} devices", ffi::KMG_MAX_DEVICES));
+        }
+        opt.n_devices = devices.len() as u32;
+        opt.devices[..devices.len()].copy_from_slice(devices);
+        let mut group = std::ptr::null_mut();
+        check(unsafe { ffi::kmg_group_create(&opt, &mut group) })?;
+        Ok(ImageProcessor { raw: std::ptr::null_mut(), group })
     }
 
     /// lib.rs:67-77: `color_count` dominant colours, sorted by Lab lightness (k-means: exactly
@@ -55,17 +73,13 @@ impl ImageProcessor {
         let (width, height) = image.dimensions();
         let mut out = vec![RGBA8::default(); color_count.max(1) as usize];
         let mut count = 0u32;
+        let (px, dst) = (image.as_bytes().as_ptr(), out.as_mut_ptr() as *mut u8);
         check(unsafe {
-            ffi::kmg_palette(
-                self.raw,
-                image.as_bytes().as_ptr(),
-                width,
-                height,
-                color_count,
-                algo.as_c(),
-                out.as_mut_ptr() as *mut u8,
-                &mut count,
-            )
+            if self.group.is_null() {
+                ffi::kmg_palette(self.raw, px, width, height, color_count, algo.as_c(), dst, &mut count)
+            } else {
+                ffi::kmg_group_palette(self.group, px, width, height, color_count, algo.as_c(), dst, &mut count)
+            }
         })?;
         out.truncate(count as usize);
         Ok(out)
@@ -80,17 +94,13 @@ impl ImageProcessor {
     ) -> Result<Image<Vec<RGBA8>>> {
         let (width, height) = image.dimensions();
         let mut out = vec![RGBA8::default(); width as usize * height as usize];
+        let (px, pal, dst) = (image.as_bytes().as_ptr(), colors.as_ptr() as *const u8, out.as_mut_ptr() as *mut u8);
         check(unsafe {
-            ffi::kmg_find(
-                self.raw,
-                image.as_bytes().as_ptr(),
-                width,
-                height,
-                colors.as_ptr() as *const u8,
-                colors.len() as u32,
-                reduce_mode.as_c(),
-                out.as_mut_ptr() as *mut u8,
-            )
+            if self.group.is_null() {
+                ffi::kmg_find(self.raw, px, width, height, pal, colors.len() as u32, reduce_mode.as_c(), dst)
+            } else {
+                ffi::kmg_group_find(self.group, px, width, height, pal, colors.len() as u32, reduce_mode.as_c(), dst)
+            }
         })?;
         Ok(Image::new((width, height), out))
     }
@@ -105,17 +115,13 @@ impl ImageProcessor {
     ) -> Result<Image<Vec<RGBA8>>> {
         let (width, height) = image.dimensions();
         let mut out = vec![RGBA8::default(); width as usize * height as usize];
+        let (px, dst) = (image.as_bytes().as_ptr(), out.as_mut_ptr() as *mut u8);
         check(unsafe {
-            ffi::kmg_reduce(
-                self.raw,
-                image.as_bytes().as_ptr(),
-                width,
-                height,
-                color_count,
-                algo.as_c(),
-                reduce_mode.as_c(),
-                out.as_mut_ptr() as *mut u8,
-            )
+            if self.group.is_null() {
+                ffi::kmg_reduce(self.raw, px, width, height, color_count, algo.as_c(), reduce_mode.as_c(), dst)
+            } else {
+                ffi::kmg_group_reduce(self.group, px, width, height, color_count, algo.as_c(), reduce_mode.as_c(), dst)
+            }
         })?;
         Ok(Image::new((width, height), out))
     }
@@ -123,7 +129,12 @@ impl ImageProcessor {
 
 impl Drop for ImageProcessor {
     fn drop(&mut self) {
-        unsafe { ffi::kmg_processor_destroy(self.raw) }
+        unsafe {
+            if !self.group.is_null() {
+                ffi::kmg_group_destroy(self.group)
+            }
+            ffi::kmg_processor_destroy(self.raw)
+        }
     }
 }
 

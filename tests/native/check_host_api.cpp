@@ -57,6 +57,17 @@ int main(int argc, char **argv)
         const Image o = processor.reduce(8, image, Algorithm::Octree, ReduceMode::Replace);
         put(out, o.rgba.data(), o.rgba.size() * 4);
     }
+    // the same object over a device list (kmg_group_*; two ranks sharing device 0 through the loopback exchange): same bytes
+    {
+        ImageProcessor many = ImageProcessor::create_on({0, 0}, nullptr, KMG_GROUP_LOOPBACK);
+        const Image one = processor.reduce(8, image, Algorithm::Kmeans, ReduceMode::Dither);
+        const Image two = many.reduce(8, image, Algorithm::Kmeans, ReduceMode::Dither);
+        if (!(one.rgba == two.rgba) || !(processor.palette(8, image, Algorithm::Kmeans) == many.palette(8, image, Algorithm::Kmeans))) return 5;
+        const std::vector<Image> batch = many.reduce_batch(5, {image, image}, Algorithm::Kmeans, ReduceMode::Replace);
+        if (batch.size() != 2 || !(batch[0].rgba == processor.reduce(5, image, Algorithm::Kmeans, ReduceMode::Replace).rgba) ||
+            !(batch[0].rgba == batch[1].rgba)) return 6;
+        std::cout << "device list ok\n";
+    }
     // error behaviour: anyhow::Err -> exception with the library's message
     int errors = 0;
     try { processor.reduce(0, image, Algorithm::Kmeans, ReduceMode::Replace); } catch (const Error &e) { errors += e.status == KMG_ERR_INVALID_ARGUMENT; }

@@ -39,7 +39,7 @@ def test_cpp_mirror_matches_binding_and_oracle(tmp_path, processor, oracle, toky
     out = tmp_path / "out.bin"
     r = subprocess.run([exe, "run", str(raw), str(w), str(h), str(out)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "errors 3" in r.stdout and "octree meld" in r.stdout
+    assert "errors 3" in r.stdout and "octree meld" in r.stdout and "device list ok" in r.stdout
     data = np.fromfile(out, np.uint8)
     pos = 0
 
