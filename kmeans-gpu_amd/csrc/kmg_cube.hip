@@ -1515,7 +1515,7 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
         if (lds_stage > lds_max || lds_scan > lds_max) return hipErrorInvalidValue;
     }
     // small centroid tables: the whole pass in one launch (k_cube_small) + the tail workgroup
-    static const bool small_on = !(KMG_TOOLS_ENV("KMG_CUBE_SMALL") && atoi(KMG_TOOLS_ENV("KMG_CUBE_SMALL")) == 0);
+    static const bool small_on = tools_env_int(KMG_TOOLS_ENV("KMG_CUBE_SMALL"), 1) != 0;
     if (k <= kSmallMaxK && small_on) {
         static const uint32_t g_small = env_grid("KMG_SMALL_GRID", kCells / kSmallCells);
         const uint32_t kp = k <= 8u ? 8u : (k <= 16u ? 16u : 32u);
@@ -1524,7 +1524,7 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
                            sizeof(uint32_t) * 4u + sizeof(uint16_t) * (kSmallBlock + kSmallCells + kSmallTests) + kSmallBlock;
         if (!n_rows) n_rows = 1u;
         // KMG_CUBE_SMALL=2: k_cube_small as the stage only, then the scan and entries launches of the general pass
-        static const bool split = KMG_TOOLS_ENV("KMG_CUBE_SMALL") && atoi(KMG_TOOLS_ENV("KMG_CUBE_SMALL")) == 2;
+        static const bool split = tools_env_int(KMG_TOOLS_ENV("KMG_CUBE_SMALL"), 1) == 2;
         const uint32_t sflags = (flags & ~0x100u) | (split ? kSmallEmit : 0u);
 #define KMG_SMALL(KP, S)                                                                                                    \
         hipLaunchKernelGGL((k_cube_small<KP, S>), dim3(g_small), dim3(kSmallBlock), lds, st, hist, agg, sub_agg, occ_bits,   \

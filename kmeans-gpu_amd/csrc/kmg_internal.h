@@ -24,6 +24,9 @@
 #define KMG_KNOCK(flags, bit) (false)
 #endif
 
+#include <stdlib.h>
+static inline int tools_env_int(const char *e, int dflt) { return e ? atoi(e) : dflt; }
+
 namespace kmg {
 
 // sets the calling thread's kmg_last_error() message and returns `code`

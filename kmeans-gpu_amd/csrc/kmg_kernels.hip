@@ -354,7 +354,7 @@ constexpr int kAssignPPT = 8;   // pixels per thread of the assign / output kern
 // (measured, MI355X, k = 256: tools/default_reduce_probe.py and profiles/NOTES.md round 4)
 static int assign_ppt(uint64_t n)
 {
-    static const int forced = KMG_TOOLS_ENV("KMG_ASSIGN_PPT") ? atoi(KMG_TOOLS_ENV("KMG_ASSIGN_PPT")) : 0;      // tools build only
+    static const int forced = tools_env_int(KMG_TOOLS_ENV("KMG_ASSIGN_PPT"), 0);      // tools build only
     if (forced == 1 || forced == 2 || forced == 4 || forced == 8) return forced;
     return n >= (1ull << 21) ? 8 : (n >= (1ull << 20) ? 4 : (n >= (1ull << 19) ? 2 : 1));
 }

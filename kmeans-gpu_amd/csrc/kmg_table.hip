@@ -1647,7 +1647,7 @@ hipError_t launch_dither_pruned(const uint32_t *rgba, uint32_t w, uint32_t rows,
 #define KMG_DP(W) hipLaunchKernelGGL(k_dither_pruned<W>, dim3(grid), dim3(kBlock), lds, st, rgba, w, n, row0, cent, k, lut, \
                                      pal, threshold, masks, out, aligned, knock)
     const uint32_t n_words = (k + 63u) / 64u;
-    static const bool sorted = !(KMG_TOOLS_ENV("KMG_DITHER_SORT") && atoi(KMG_TOOLS_ENV("KMG_DITHER_SORT")) == 0);
+    static const bool sorted = tools_env_int(KMG_TOOLS_ENV("KMG_DITHER_SORT"), 1) != 0;
     if (sorted && !knock && n_words == 1u) {
         // the pixels of a tile sorted by candidate-list length (k_dither_sorted): 8192^2, 64-entry palette 0.95 -> 0.88 ms.
         // With more mask words the records outgrow the LDS a well-occupied CU can give them (k = 256, 2 pixels per
