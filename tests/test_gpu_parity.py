@@ -51,8 +51,7 @@ def test_assign_accumulate_matches_oracle(torch_cuda, processor, oracle, n, k, s
     cent = oracle.centroids4(lab[(np.arange(k) * (n // k)) % n])
     want_labels, want_acc = oracle.assign_accumulate_rgba(rgba, cent)
     d = _dev(torch, rgba)
-    labels = torch.full((n,), 0xFFFFFFFF, dtype=torch.int64, device="cuda").to(torch.int32)
-    labels = torch.zeros(n, dtype=torch.int32, device="cuda")
+    labels = torch.full((n,), -1, dtype=torch.int32, device="cuda")        # (0xFFFFFFFF: no pixel may keep it)
     acc = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
     s = kg.Lloyd(processor, k)
     s.set_centroids(cent)
