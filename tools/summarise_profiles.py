@@ -76,6 +76,11 @@ if c2:
     if all("FETCH_SIZE" in v and "WRITE_SIZE" in v for v in step) and step:
         # (pixel stream at 2 x FETCH_SIZE as for the headline; the small tables at face value would be lower: an upper figure)
         t["bytes_per_launch"]["cfg2_step"] = sum(2 * v["FETCH_SIZE"] * 1024 + v["WRITE_SIZE"] * 1024 for v in step)
+# the commit the counters belong to (the newest one that touches the kernels at the time of the profile run): bench.py quotes it as
+# roofline.traffic_age, tests/test_profiles_fresh.py fails when the kernels have changed since
+import subprocess
+t["commit"] = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip()
+t["profile_tag"] = tag
 t["valu_source"] = f"profiles/{tag}_pmc_units.txt, _apply_pmc.txt, _cfg2_pmc.txt (SQ_INSTS_VALU, mean per launch, separate rocprofv3 --pmc passes)"
 json.dump(t, open(os.path.join(P, "traffic.json"), "w"), indent=1)
 d = json.load(open(os.path.join(P, f"{tag}_bench.json")))
