@@ -1,5 +1,5 @@
 // kmg_internal.h -- what the translation units of libkmeans_hip share besides the kernels' launchers: the error
-// channel of the C ABI and the few host helpers of kmg_api.hip that the multi-device layer (kmg_group.hip) reuses.
+// channel of the C ABI and the few host helpers of kmg_api.hip / kmg_processor.hip that the multi-device layer (kmg_group.hip) reuses.
 // Nothing here is exported (-fvisibility=hidden).
 #pragma once
 

@@ -1,4 +1,4 @@
-"""The strategy choice of kmg_lloyd_prepare (csrc/kmg_api.hip table_pays) on a PHOTOGRAPH near its crossover (-m gpu): the cost
+"""The strategy choice of kmg_lloyd_prepare (csrc/kmg_lloyd.hip table_pays) on a PHOTOGRAPH near its crossover (-m gpu): the cost
 model was fitted on uniform noise (tools/strategy_sweep.py); a photograph has fewer occupied cells (a cheaper cube pass) and
 crowded ones (more candidates per colour).  Both strategies are timed on the tiled test photograph at 1, 2 and 4 Mpx for
 k = 16 and k = 256; the test fails when the library's own choice is more than 15 % slower than the other strategy."""
@@ -37,7 +37,7 @@ def _time_strategy(torch, kg, proc, rgba, n, k, cent, strategy, monkeypatch, ite
         dt = (time.perf_counter() - t) / iters
         best = dt if best is None else min(best, dt)
     s.close()
-    # the model spreads the one-off binding over ~16 passes (kmg_api.hip bind_seconds)
+    # the model spreads the one-off binding over ~16 passes (kmg_lloyd.hip bind_seconds)
     return best + (prep / 16.0 if strategy == "table" else 0.0)
 
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Ordered-dither output pass: scan of all centroids (k_apply) against the pruned pass (lists over Lab cells for k <= 256, mask
-words above) over a grid of (pixels, k) on noise -- the data behind dither_pruning_pays() in csrc/kmg_api.hip.
+words above) over a grid of (pixels, k) on noise -- the data behind dither_pruning_pays() in csrc/kmg_apply.hip.
 python tools/dither_crossover.py > gpurun_out/dither_crossover.txt"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times one Lloyd iteration (update + assign/accumulate, labels written) with the per-pixel scan and
-with the colour table over a grid of (pixels, k): the data behind table_pays() in csrc/kmg_api.hip."""
+with the colour table over a grid of (pixels, k): the data behind table_pays() in csrc/kmg_lloyd.hip."""
 import os, sys, time, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "kmeans-gpu_amd", "python"))
