@@ -132,6 +132,33 @@ int main(int argc, char **argv)
             CHECK(kmg_group_reduce_batch(g, 3, src, bw, bh, k, KMG_ALGO_KMEANS, KMG_MODE_DITHER, dst));
             for (int i = 0; i < 3; ++i) EXPECT(out[i] == want[i]);
         }
+        // argument errors of the group layer: refused before any rank starts, the group stays usable
+        if (shrink == 0) {
+            kmg_group_options bad = go;
+            if (ranks == 1) {
+                bad.n_devices = 2; bad.devices[0] = 0; bad.devices[1] = 0; bad.flags = 0;      // one device twice without the loopback exchange
+                kmg_group *gb = nullptr;
+                EXPECT(kmg_group_create(&bad, &gb) == KMG_ERR_INVALID_ARGUMENT && gb == nullptr && strstr(kmg_last_error(), "twice"));
+            }
+            bad = go; bad.devices[0] = 4096;
+            kmg_group *gb = nullptr;
+            EXPECT(kmg_group_create(&bad, &gb) == KMG_ERR_NO_DEVICE && gb == nullptr);
+            kmg_group_lloyd *gl = nullptr;
+            CHECK(kmg_group_lloyd_create(g, k, &gl));
+            uint32_t it = 0;
+            EXPECT(kmg_group_lloyd_run(gl, &it) == KMG_ERR_INVALID_ARGUMENT);                    // no bands yet
+            EXPECT(kmg_group_lloyd_step(gl) == KMG_ERR_INVALID_ARGUMENT);
+            std::vector<const uint8_t *> nb(ranks, nullptr);
+            std::vector<uint32_t> r0(ranks, 0u), rs(ranks, 0u);
+            rs[0] = h + 1;                                                                       // a band that leaves the image
+            nb[0] = img.data();
+            EXPECT(kmg_group_lloyd_bind(gl, nb.data(), r0.data(), rs.data(), w, h, nullptr, 0u) == KMG_ERR_INVALID_ARGUMENT);
+            rs[0] = 1; nb[0] = nullptr;                                                          // rows without pixels
+            EXPECT(kmg_group_lloyd_bind(gl, nb.data(), r0.data(), rs.data(), w, h, nullptr, 0u) == KMG_ERR_INVALID_ARGUMENT);
+            kmg_group_lloyd_destroy(gl);
+            EXPECT(kmg_group_lloyd_create(g, 0, &gl) == KMG_ERR_INVALID_ARGUMENT);
+            EXPECT(kmg_group_processor(g, ranks) == nullptr && kmg_group_processor(g, 0) != nullptr && kmg_group_stream(g, 0) != nullptr);
+        }
         // errors reach the caller with a message
         EXPECT(kmg_group_reduce(g, img.data(), w, h, 0, KMG_ALGO_KMEANS, KMG_MODE_REPLACE, b.data()) == KMG_ERR_INVALID_ARGUMENT);
         EXPECT(kmg_group_find(g, img.data(), 0, h, pa.data(), ca, KMG_MODE_REPLACE, b.data()) == KMG_ERR_INVALID_ARGUMENT && strlen(kmg_last_error()) > 0);
@@ -189,6 +216,12 @@ int main(int argc, char **argv)
                 EXPECT(!memcmp(c_one.data(), c_group.data(), sizeof(float) * 4 * k));
                 HIPCHECK(hipMemcpy(lab_group.data(), d_lab_group, n * 4, hipMemcpyDeviceToHost));
                 EXPECT(lab_one == lab_group);
+                if (flags == 0u) {
+                    // the loop reads the convergence count between update and re-assignment: the fused form is for _prime / _step
+                    CHECK(kmg_group_lloyd_bind(gl, bands.data(), row0.data(), rows.data(), w, h, labs.data(), KMG_GROUP_FUSED_UPDATE));
+                    EXPECT(kmg_group_lloyd_run(gl, &it_group) == KMG_ERR_INVALID_ARGUMENT && strstr(kmg_last_error(), "FUSED"));
+                    CHECK(kmg_group_lloyd_bind(gl, bands.data(), row0.data(), rows.data(), w, h, labs.data(), flags));
+                }
                 int strategy = -1;
                 EXPECT(kmg_group_lloyd_member(gl, 0, &strategy) != nullptr);
                 printf("flags %u: %u iterations, strategy of rank 0: %s\n", flags, it_group, strategy ? "table" : "scan");
