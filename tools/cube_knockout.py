@@ -2,6 +2,8 @@
 """Knock-out timing of k_cube (run on the GPU box): python tools/cube_knockout.py > gpurun_out/knock.txt
 Each line = one bench.py run with a KMG_CUBE_FLAGS knock-out (results of those runs are wrong by design)."""
 import json, os, subprocess, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _toolslib import use_tools_library
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 cases = [("baseline", 0), ("no pair entry", 0x100), ("no sums", 0x200), ("no colour scan", 0x400),
          ("all cells single (candidates only)", 0x800), ("no sub-cell stage", 0x1000), ("no label stores", 0x2000),

@@ -3,7 +3,8 @@
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from _toolslib import use_tools_library, subprocess, sys
+from _toolslib import use_tools_library
+import subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, os.path.join(ROOT, "kmeans-gpu_amd", "python"))

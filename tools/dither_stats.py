@@ -5,7 +5,7 @@ import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from _toolslib import use_tools_library
-use_tools_library(), sys
+use_tools_library()
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "kmeans-gpu_amd", "python"))
 os.environ["KMG_DITHER_STATS"] = "1"

@@ -6,7 +6,8 @@ import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from _toolslib import use_tools_library
-use_tools_library(), sys, time
+use_tools_library()
+import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "kmeans-gpu_amd", "python"))
 import numpy as np, torch
