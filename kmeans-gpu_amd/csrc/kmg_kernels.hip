@@ -886,7 +886,16 @@ static uint32_t init_pass_grid(uint64_t n)
 
 size_t init_slots_bytes() { return sizeof(unsigned long long) * 2u * kInitSlots; }
 
-static size_t init_multi_cands(uint64_t n) { return 2ull * init_pass_grid(n) * kInitMulti; }
+// Every workgroup of a launch merges ALL rows of the previous one (no device-wide step in between), so the grid stays small: at
+// most one row per thread of the merge -- 256 workgroups, the image's pixels strided over their 65 536 threads.  (With the 2048
+// workgroups of the single-pick pass the merge alone moved 2048^2 x 128 B = 537 MB per launch: 92 us at 524 288 pixels.)
+static uint32_t init_multi_grid(uint64_t n)
+{
+    const uint64_t blocks = (n + kBlock - 1) / kBlock;
+    return (uint32_t)(blocks < (uint64_t)kBlock ? (blocks ? blocks : 1) : (uint64_t)kBlock);
+}
+
+static size_t init_multi_cands(uint64_t n) { return 2ull * init_multi_grid(n) * kInitMulti; }
 
 size_t init_multi_bytes(uint64_t n) { return sizeof(InitCand) * init_multi_cands(n) + 2u * sizeof(uint32_t); }
 
@@ -895,7 +904,7 @@ hipError_t launch_init_multi(const uint32_t *rgba, uint64_t n, const float *lut,
 {
     InitCand *slots = static_cast<InitCand *>(scratch);
     uint32_t *count = reinterpret_cast<uint32_t *>(slots + init_multi_cands(n));
-    hipLaunchKernelGGL(k_init_multi, dim3(init_pass_grid(n)), dim3(kBlock), 0, st, rgba, n, lut, cent, k, launch, dist, slots, count);
+    hipLaunchKernelGGL(k_init_multi, dim3(init_multi_grid(n)), dim3(kBlock), 0, st, rgba, n, lut, cent, k, launch, dist, slots, count);
     return hipGetLastError();
 }
 

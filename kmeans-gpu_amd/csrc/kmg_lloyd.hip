@@ -609,7 +609,10 @@ static bool init_table_pays(uint64_t n, uint32_t k)
         if (!strcmp(e, "table")) return true;
     }
     const double N = (double)n, passes = (double)(k - 1);
-    const double pixels = passes * (8.0e-6 + N * 7.0e-12);
+    // (k >= 32: k_init_multi picks up to four centroids per launch -- ~0.3 k + 18 launches -- on a grid of at most 256
+    // workgroups, four literal distances per pixel and launch: 9 us + 30 ps per pixel; tools/init_crossover.py,
+    // profiles/r05_init_crossover.txt)
+    const double pixels = k >= 32u ? (0.3 * k + 18.0) * (9.0e-6 + N * 30.0e-12) : passes * (8.0e-6 + N * 7.0e-12);
     const double colours = passes * 1.05e-5 + (passes < 16.0 ? passes : 16.0) * 3.0e-5 + 1.5 * bind_seconds(n) +
                            (n >= (1ull << 21) ? 0.0 : 1.0e-4 + N * 3.7e-11);
     return colours < pixels;
