@@ -602,6 +602,9 @@ def main():
         # host; the data path's collectives are RCCL calls inside libkmeans_hip (kmg_group_*)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        # one node: RCCL's bootstrap sockets (the unique id carries an address) stay on the loopback interface -- the container's
+        # hostname may not resolve and no other interface is needed; the data path is xGMI / shared memory either way
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         dist.init_process_group("gloo")
     if args.rehearse and rank != 0:
         dist.barrier()                                        # rank 0 hosts every rank of the rehearsal
