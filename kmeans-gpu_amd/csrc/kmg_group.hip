@@ -195,6 +195,7 @@ struct kmg_group {
     Barrier barrier;                 // the local ranks' host rendezvous (loopback exchange, host-buffer calls)
     std::vector<const void *> lb_ptrs;
     std::mutex call_mu;              // one group operation at a time: the ranks' collectives must pair up
+    std::mutex abort_mu;
     bool broken = false;
 };
 
@@ -230,6 +231,7 @@ void worker_main(GroupRank *r)
 // a rank that fails leaves the others waiting in a collective or at the barrier: release them, the group is finished
 void group_abort(kmg_group *g)
 {
+    std::lock_guard<std::mutex> lock(g->abort_mu);                  // (two ranks may fail at once)
     g->barrier.abort();
     if (g->rccl)
         for (GroupRank &r : g->ranks)
