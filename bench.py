@@ -166,6 +166,26 @@ def cfg4_rank_share(proc, k, n_pixels, stream, steps=5):
             "cfg4_collectives_per_iteration": 0}
 
 
+def cfg4_native_batch(k, width, height, images=2):
+    """BASELINE config 4 through the C ABI's own batch call: kmg_group_reduce_batch of one rank's share (two whole 8192 x 8192
+    images on this GPU: upload, initialisation and Lloyd loop at FULL resolution, dither output pass, download) -- host buffers
+    in and out, PCIe included, never part of `value`.  On a node the group spans the 8 devices and takes 16 images in the same
+    call, the devices side by side."""
+    import numpy as np
+    import kmeans_gpu_amd as kg
+    from kmeans_gpu_amd import synth
+    imgs = [synth.uniform_rgba_numpy(0x5EED0400 + i, width * height).reshape(height, width, 4) for i in range(images)]
+    with kg.Group(devices=[0], shrink_max_dim=0) as g:
+        times = []
+        for _ in range(3):
+            t = time.perf_counter()
+            outs = g.reduce_batch(k, imgs, reduce_mode=kg.ReduceMode.Dither)
+            times.append((time.perf_counter() - t) * 1e3)
+        assert all(int(o[..., 3].min()) == 255 for o in outs)
+    return {"cfg4_native_batch_images": images, "cfg4_native_batch_host_to_host_cold_ms": times[0],
+            "cfg4_native_batch_host_to_host_warm_ms": min(times[1:])}
+
+
 def cfg4_tiled_rank_share(proc, k, width, height, stream, steps=3, images=16, world=8, rank=3):
     """BASELINE config 4 split the way north_star words it: every image tiled over the 8 GPUs in row bands, one all-reduce
     of images x k x 4 int64 per iteration (sharded.ShardedBatch) -- exactly the configuration of
@@ -456,6 +476,8 @@ def output_pass_timing(proc, rgba, n_pixels, stream, sh=None, steps=3):
         extra.update(other_distributions(proc, k3, n_pixels, stream, steps=max(steps, 2) * 3))
         extra.update(cfg4_rank_share(proc, k3, n_pixels, stream, steps=steps))
         extra.update(cfg4_tiled_rank_share(proc, k3, WIDTH, n_pixels // WIDTH, stream, steps=steps))
+        if n_pixels == WIDTH * ROWS_PER_GPU:
+            extra.update(cfg4_native_batch(k3, WIDTH, n_pixels // WIDTH))
         extra.update(reduce_end_to_end(proc, rgba, WIDTH, n_pixels // WIDTH, k3))
         extra.update(cfg2_timing(proc, stream, steps=max(steps, 2) * 5))
         extra.update(default_call_timing())

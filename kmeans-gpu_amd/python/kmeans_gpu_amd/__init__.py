@@ -790,7 +790,7 @@ class Group:
     def reduce_batch(self, color_count, images, algo=Algorithm.Kmeans, reduce_mode=ReduceMode.Replace):
         """whole images per device, no collective (BASELINE config 4 as placed); returns the list of results"""
         imgs = [_image(im) for im in images]
-        outs = [np.empty_like(im) for im in imgs]
+        outs = [_result(im, None) for im in imgs]          # (large results from the pool of page-locked blocks, as reduce() does)
         n = len(imgs)
         src = (C.c_void_p * n)(*[im.ctypes.data for im in imgs])
         dst = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
