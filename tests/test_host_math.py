@@ -34,3 +34,15 @@ def test_oracle_cbrt_is_correctly_rounded_vs_long_double(oracle):
     got = np.array([oracle.cbrt(float(x)) for x in xs[::37]], np.float32)
     want = np.cbrt(xs[::37].astype(np.longdouble)).astype(np.float32)
     assert np.array_equal(got, want)
+
+
+def test_colour_index_equals_its_plain_form_for_every_colour(tmp_path):
+    """kmg_table.h colour_index gathers the bits of a pixel with two 24-bit multiplies (five vector instructions fewer per pixel in
+    the label pass): equal to the bit-by-bit form, alpha ignored, and inverted by index_to_rgb -- all 2^24 colours
+    (tests/native/check_colour_index.cpp, host build of the same header)."""
+    exe = str(tmp_path / "check_colour_index")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include",
+                    "-I", os.path.join(ROOT, "kmeans-gpu_amd", "csrc"),
+                    os.path.join(ROOT, "tests", "native", "check_colour_index.cpp"), "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "colour_index_mismatches 0" in r.stdout and "inverse_mismatches 0" in r.stdout, r.stdout
