@@ -8,7 +8,8 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL_SOURCES = ["kmeans-gpu_amd/csrc/kmg_table.hip", "kmeans-gpu_amd/csrc/kmg_cube.hip"]
+KERNEL_SOURCES = ["kmeans-gpu_amd/csrc/kmg_table.hip", "kmeans-gpu_amd/csrc/kmg_cube.hip", "kmeans-gpu_amd/csrc/kmg_table.h",
+                  "kmeans-gpu_amd/csrc/kmg_table_dev.h"]
 
 
 def _git(*args):
