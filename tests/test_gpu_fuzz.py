@@ -60,3 +60,16 @@ def test_random_default_calls_equal_the_oracle(seed):
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "30 cases, 0 mismatching" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [7])
+def test_random_group_calls_equal_the_single_processor(seed):
+    """tools/fuzz_group.py: palette / find / reduce through kmg_group_* (one rank with forced RCCL collectives, two to five ranks
+    sharing the GPU through the loopback exchange; the reference's shrink and full resolution) against the single processor"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("KMG_STRATEGY", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_group.py"), "24", str(seed)], capture_output=True, text=True,
+                       timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "24 cases, 0 mismatching" in r.stdout
