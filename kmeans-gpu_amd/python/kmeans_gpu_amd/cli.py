@@ -5,7 +5,9 @@
     python -m kmeans_gpu_amd.cli find    -i img.png -p "#050505,#ffffff,#ff0000"|palette.png [-m ...] [-o out.png]
     python -m kmeans_gpu_amd.cli palette -i img.png -c 8 [-a ...] [-s 40] [-o out.png]
 
-Image decoding/encoding (the `image` crate in the reference) is done with Pillow.
+Image decoding/encoding (the `image` crate in the reference) is done with Pillow.  One flag the reference does not have:
+`--devices 0,1,...` (before the sub-command) runs the same operation over several GPUs of the node (kmg_group_*: the image
+tiled in row bands, same bytes).
 """
 import argparse
 import os
@@ -15,7 +17,7 @@ import time
 
 import numpy as np
 
-from . import Algorithm, ImageProcessor, ReduceMode
+from . import Algorithm, Group, ImageProcessor, ReduceMode
 
 _PALETTE_RE = re.compile(r"^#[0-9a-fA-F]{6}(?:,#[0-9a-fA-F]{6})*$")     # args.rs:184
 _MODES = {"replace": ReduceMode.Replace, "dither": ReduceMode.Dither, "meld": ReduceMode.Meld}
@@ -103,8 +105,20 @@ def validate_size(s):                                       # args.rs:36-38 valu
     return v
 
 
+def validate_devices(s):
+    try:
+        devices = [int(v) for v in s.split(",")]
+    except ValueError:
+        devices = []
+    if not devices or min(devices) < 0:
+        raise argparse.ArgumentTypeError("--devices takes a comma separated list of device ordinals, e.g. 0,1")
+    return devices
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="kmeans-hip", description="k-means colour quantisation on MI355X")
+    ap.add_argument("--devices", type=validate_devices, default=None,
+                    help="HIP device ordinals, e.g. 0,1,2,3: tile the image over several GPUs (no counterpart in the reference)")
     sub = ap.add_subparsers(dest="command", required=True)
     p = sub.add_parser("palette", help="Create an image with the dominant colors of the input")
     p.add_argument("-c", "--colorcount", type=validate_k, required=True)
@@ -126,7 +140,7 @@ def main(argv=None):
     args = ap.parse_args(argv)
 
     image = _load(args.input)
-    with ImageProcessor() as proc:
+    with (Group(devices=args.devices) if args.devices else ImageProcessor()) as proc:
         if args.command == "palette":                    # main.rs:46-72
             colors = proc.palette(args.colorcount, image, _ALGOS[args.algo])
             out = np.repeat(np.repeat(colors[None, :, :], args.size, axis=0), args.size, axis=1)   # main.rs:221-239

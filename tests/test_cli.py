@@ -60,6 +60,9 @@ def test_cli_reproduces_samples(tmp_path, capsys):
     assert np.array_equal(load_rgba(out), load_rgba("tokyo-find-replace-dark-white-red.png"))
     assert cli.main(["find", "-i", src, "-p", os.path.join(GOLDEN, "apollo-1x.png"), "-m", "dither", "-o", out]) == 0
     assert np.array_equal(load_rgba(out), load_rgba("tokyo-find-dither-apollo.png"))
+    # the same through the device-list constructor (kmg_group_*)
+    assert cli.main(["--devices", "0", "find", "-i", src, "-p", os.path.join(GOLDEN, "apollo-1x.png"), "-m", "dither", "-o", out]) == 0
+    assert np.array_equal(load_rgba(out), load_rgba("tokyo-find-dither-apollo.png"))
     assert cli.main(["reduce", "-i", src, "-c", "8"]) == 0
     got = load_rgba(str(tmp_path / "tokyo-reduce-c8-kmeans-replace.png"))
     gold = load_rgba("tokyo-reduce-c8-kmeans-replace.png")
@@ -69,3 +72,12 @@ def test_cli_reproduces_samples(tmp_path, capsys):
     assert "Palette: #" in capsys.readouterr().out
     pal = load_rgba(str(tmp_path / "tokyo-palette-c8-kmeans-s40.png"))
     assert pal.shape == (40, 320, 4)
+
+
+def test_devices_flag_is_validated():
+    """--devices (no counterpart in the reference): a comma separated list of ordinals"""
+    from kmeans_gpu_amd import cli
+    assert cli.validate_devices("0,1,3") == [0, 1, 3]
+    for bad in ("", "a", "0,-1", "1;2"):
+        with pytest.raises(Exception):
+            cli.validate_devices(bad)
