@@ -431,20 +431,18 @@ static_assert(sizeof(InitSlot) == 32 && sizeof(InitRecord) == 32 + sizeof(CellBo
 
 size_t init_scratch_bytes() { return sizeof(InitRecord) * (size_t)kCells + sizeof(InitSlot) * 2u * kInitGrid; }
 
+// wave-wide maxima through DPP row operations (kmg_table_dev.h): a 64-bit maximum is the maximum of the high words, then of the
+// low words of the lanes that hold it.  (Rounds 2-4 used six shuffle steps -- twelve ds_bpermute round trips for 64 bits -- in
+// kernels that are chains of dependent steps: cfg3's initialisation 3.85 -> 3.63 ms.)
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 {
-    for (int off = 32; off > 0; off >>= 1) {
-        const unsigned long long o = __shfl_xor(v, off, 64);
-        v = o > v ? o : v;
-    }
-    return v;
+    const uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
+    const uint32_t mhi = wave_max_u32_dpp(hi);
+    const uint32_t mlo = wave_max_u32_dpp(hi == mhi ? lo : 0u);
+    return ((unsigned long long)mhi << 32) | mlo;
 }
 
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
-{
-    for (int off = 32; off > 0; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off, 64));
-    return v;
-}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { return wave_max_u32_dpp(v); }
 
 // test slot q (0..127) of workgroup g (0..255) -> index into the work list: with every cell occupied the index
 // is the cell [r:5][g:5][b:5], and g = [r1 r0][g2 g1 g0][b2 b1 b0], q = [r4 r3 r2][g4 g3][b4 b3]
@@ -573,8 +571,11 @@ __global__ __launch_bounds__(kInitBlock) void k_init_fused(const uint32_t *__res
         }
         __syncthreads();
         if (threadIdx.x == 0) {
-            uint32_t w = 0;
-            for (uint32_t q = 1; q < kInitGrid / 64u; ++q) if (s_key[q] > s_key[w]) w = q;
+            // (the four entries requested together, not one dependent LDS round trip per comparison)
+            const unsigned long long k0 = s_key[0], k1 = s_key[1], k2 = s_key[2], k3 = s_key[3];
+            static_assert(kInitGrid / 64u == 4u, "four slot waves");
+            const uint32_t wa = k1 > k0 ? 1u : 0u, wb = k3 > k2 ? 3u : 2u;
+            const uint32_t w = (wb == 3u ? k3 : k2) > (wa == 1u ? k1 : k0) ? wb : wa;
             float4 v = s_lab[w];
             if ((s_key[w] >> 32) == 0ull) {
                 // Candidate(0, 0.0): every distance is 0 -> pixel 0
@@ -696,11 +697,16 @@ __global__ __launch_bounds__(kInitBlock) void k_init_fused(const uint32_t *__res
         const unsigned long long wbest = wave_max_u64(run_key);
         if (lane == (uint32_t)__builtin_ctzll(__ballot(run_key == wbest))) { s_key[wv] = wbest; s_lab[wv] = run_lab; }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t w = 0;
-            for (uint32_t q = 1; q < kInitBlock / 64u; ++q) if (s_key[q] > s_key[w]) w = q;
-            InitSlot o; o.key = s_key[w]; o.pad[0] = 0u; o.pad[1] = 0u; o.lab = s_lab[w];
-            slots[(j & 1u) * kInitGrid + blockIdx.x] = o;
+        if (wv == 0u) {
+            // the largest of the 16 waves' entries: lane l holds entry l, one more wave maximum (a serial scan by thread 0 was
+            // 16 dependent LDS round trips at the end of every launch)
+            const unsigned long long e = lane < kInitBlock / 64u ? s_key[lane] : 0ull;
+            const float4 el = s_lab[lane < kInitBlock / 64u ? lane : 0u];
+            const unsigned long long best = wave_max_u64(e);
+            if (lane == (uint32_t)__builtin_ctzll(__ballot(e == best))) {
+                InitSlot o; o.key = best; o.pad[0] = 0u; o.pad[1] = 0u; o.lab = el;
+                slots[(j & 1u) * kInitGrid + blockIdx.x] = o;
+            }
         }
     }
 }
