@@ -634,6 +634,10 @@ def main():
         return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU path exists)")
+    if world > torch.cuda.device_count() and not args.rehearse:
+        # (every rank sees this before any communicator is created: nobody is left waiting in ncclCommInitRank)
+        raise SystemExit(f"--gpus {world} needs {world} devices, this node shows {torch.cuda.device_count()} "
+                         "(RCCL takes one rank per device; --rehearse runs the N-rank path on one GPU)")
     if args.rehearse:
         local_rank = 0
     torch.cuda.set_device(local_rank)
