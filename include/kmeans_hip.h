@@ -222,7 +222,8 @@ KMG_API int kmg_lloyd_labels(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n_pix
  * the assign passes of a bound image visit only the occupied cells whose index lies in [32768 part / parts,
  * 32768 (part + 1) / parts) -- equal RANGES of the colour cube (slabs of the red axis), so that the shares of the label tables
  * are equal contiguous chunks an in-place all-gather can move; the WORK per share is equal only when the occupied cells are
- * spread evenly (noise: yes; a photograph whose colours crowd into one slab: no -- unmeasured).  The sums such a pass returns
+ * spread evenly (noise: yes; the test photograph: the fullest of 2 / 4 / 8 shares holds 1.20 / 1.25 / 1.31 x the mean number of
+ * occupied cells -- counted, not timed; its crowded dark cells carry more candidates each).  The sums such a pass returns
  * are those of the share's colours (the all-reduce of the k x 4 accumulators makes them the image's), and only the share's
  * per-colour labels and cell entries are (re)written.  The ranks then exchange their shares of the label tables
  * (_table_buffers: the per-colour labels, cell-major, 512 per cell, and the cell entries) and write their band's label map
