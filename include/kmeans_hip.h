@@ -196,8 +196,9 @@ KMG_API int kmg_debug_check_table(kmg_lloyd *s, uint64_t out[3], void *stream);
  * out = {occupied cells, sum of candidate counts, cells with one candidate, max candidates,
  *        cells with one label, occupied sub-cells, sub-cells with one label, distinct colours,
  *        sub-cells decided from their bounds, sub-cells scanned, candidates over the scanned sub-cells,
- *        cells with too many candidates for the sub-cell stage}.                                 */
-KMG_API int kmg_debug_table_stats(kmg_lloyd *s, uint64_t out[12], void *stream);
+ *        cells with too many candidates for the sub-cell stage, candidates the dominance phase removed from
+ *        scanned sub-cells, scanned sub-cells it left with one candidate}.                      */
+KMG_API int kmg_debug_table_stats(kmg_lloyd *s, uint64_t out[14], void *stream);
 /* Test support (k <= 256): checks the per-cell pair entries the label pass keeps in LDS against the
  * per-colour label table of the last colour-table pass (synchronises).  out[0] = occupied colours
  * whose entry disagrees (must be 0), out[1] = pixels resolved by the entries alone, out[2] = pixels. */

@@ -55,6 +55,31 @@ __device__ __forceinline__ int round_dir(int g, int m)           // rint(2 g / m
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
+__device__ __forceinline__ uint32_t group8_or(uint32_t v)
+{
+    v |= dpp_u32<kDppXor1>(v);
+    v |= dpp_u32<kDppXor2>(v);
+    v |= dpp_u32<kDppHalfMirror>(v);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t group8_min_u32(uint32_t v)
+{
+    v = min(v, dpp_u32<kDppXor1>(v));
+    v = min(v, dpp_u32<kDppXor2>(v));
+    v = min(v, dpp_u32<kDppHalfMirror>(v));
+    return v;
+}
+
+__device__ __forceinline__ uint32_t group8_max_u32(uint32_t v)
+{
+    v = max(v, dpp_u32<kDppXor1>(v));
+    v = max(v, dpp_u32<kDppXor2>(v));
+    v = max(v, dpp_u32<kDppHalfMirror>(v));
+    return v;
+}
+
+
 
 // ------------------------------------------------------------------------------------------
 // pair entry of one cell (kmg_table.h).  Lane l holds the colours 8 l .. 8 l + 7 of the cell
@@ -182,12 +207,32 @@ struct alignas(16) CellWork {
     uint16_t list[kMaxListed];     // the cell's candidates in index order (listed cells)
     unsigned long long br[4];      // round r: bit 8 s + c = sub-cell s keeps candidate 8 r + c of the list
     uint32_t npop;                 // number of candidates of the cell
-    uint32_t scan_set;             // bits 0..7: sub-cells whose colours are scanned; bit 8: the cell is listed
-    uint32_t pad[6];
+    uint32_t scan_set;             // bits 0..7: sub-cells whose colours are scanned; bit 8: the cell is listed; bit 9: long list;
+                                   // bits 16..23: sub-cells the stage decided as a whole (one candidate)
+    // (listed cells) per sub-cell, for k_cube_prune: the candidate with the smallest upper bound of its key over the sub-cell
+    // (list position) and that bound, rounded UP to the 16 high bits of its binary32 pattern
+    uint16_t U16[8];
+    uint8_t istar[8];
 };
 static_assert(sizeof(CellWork) == 128, "CellWork layout");
 
 constexpr uint32_t kPairPending = 0xFFFFFFFEu;   // pair entry of a cell k_cube_pairs still has to derive
+
+// What k_cube_prune leaves for k_cube_scan / k_cube_pairs, behind the cells' work records (u32 words):
+//   [2 s, 2 s + 1], s < kListSegs: one u64 counter per segment = items | whole cells << 21 | entry cells << 42 (one atomic of a
+//                   wave of k_cube_prune -- 8 cells -- reserves its places in all three; same-address atomics retire one by
+//                   one, 12-15 ns each: 64 per segment)
+//   [kListFar]      a centroid is outside the dominance test's error budget (set by the stage kernel)
+//   kListsHead ...  items   [kListSegs][kItemSegCap] x 16 B: TWO sub-cells of one cell to scan and the union of their candidate
+//                           sets -- {cell | s0 << 15 | s1 << 18 (8: none) | n << 22, 12 centroids (u8, ascending)}: the scan
+//                           kernel needs nothing else, one wave per item
+//                   whole   [kListSegs][kListSegCap] cells scanned from their work records as before (unlisted / long cells, unions
+//                           of more than kItemCands candidates)
+//                   entries [kListSegs][kListSegCap] cells that need a pair entry derived from their labels
+constexpr uint32_t kListSegs = 64, kListSegCap = kCells / kListSegs, kItemSegCap = 4u * kListSegCap, kItemCands = 12;
+constexpr uint32_t kListFar = 2 * kListSegs, kListsHead = 2 * kListSegs + 64;
+constexpr uint32_t kListItems = kListsHead, kListWhole = kListItems + 4u * kListSegs * kItemSegCap, kListEntries = kListWhole + kCells;
+constexpr size_t kListsWords = kListEntries + kCells;
 
 // LDS bins: repl copies of k x 4 u64, consecutive copies 32 B further along the bank row
 __device__ __forceinline__ void flush_bins(const unsigned long long *bins, uint32_t k, uint32_t repl, uint32_t bin_stride,
@@ -349,6 +394,19 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
     }
     for (uint32_t i = threadIdx.x; i < n_bins; i += kBlock) bins[i] = 0ull;
     __syncthreads();
+    if ((flags & kCubePruned) && blockIdx.x == 0u) {
+        // the head of k_cube_prune's lists: counters zero, and whether its test applies to this centroid table at all
+        uint32_t *lists = reinterpret_cast<uint32_t *>(cell_work + kCells);
+        bool far = false;
+        for (uint32_t i = threadIdx.x; i < k; i += kBlock) {
+            const float4 c = s_cent[i];
+            far = far || !(fabsf(c.x) <= 1024.0f && fabsf(c.y) <= 1024.0f && fabsf(c.z) <= 1024.0f);
+        }
+        const unsigned long long any_far = __ballot(far);
+        if (threadIdx.x < kListsHead) lists[threadIdx.x] = 0u;
+        __syncthreads();
+        if (any_far && (threadIdx.x & 63u) == 0u) lists[kListFar] = 1u;
+    }
 
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wv = threadIdx.x >> 6;
@@ -508,7 +566,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
             sb.b0 = sb1.x; sb.b1 = sb1.y; sb.C0 = sb1.z; sb.C1 = sb1.w;
             sb.wC0 = sb2.x; sb.wC1 = sb2.y; sb.wH0 = sb2.z; sb.wH1 = sb2.w;
             const uint32_t rounds = (npop + 7u) >> 3;
-            float Usub = 3.0e38f, lo[4];
+            // the smallest upper bound AND the candidate that has it: the bound's bit pattern (a non-negative float: patterns
+            // order like values) rounded up to a multiple of 32 ulps, the list position in the 5 bits that frees.  The threshold
+            // is taken from the rounded bound -- a little above the exact one, which only keeps candidates.
+            uint32_t Ubest = 0x7F7FFFE0u;
+            float lo[4];
 #pragma unroll
             for (uint32_t r = 0; r < 4u; ++r) {
                 lo[r] = 3.0e38f;
@@ -519,15 +581,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
                         const float4 c = s_cent[j];
                         const KeyRange kr = key_range(sb, c.x, c.y, c.z, c.w);
                         lo[r] = kr.lo;
-                        Usub = fminf(Usub, kr.hi);
+                        Ubest = min(Ubest, ((float_to_bits(kr.hi) + 31u) & ~31u) | pos);
                     }
                 }
             }
-            const float Us = mask_threshold(group8_min(Usub));
+            Ubest = group8_min_u32(Ubest);
+            const float Us = mask_threshold(bits_to_float(Ubest & ~31u));
 #pragma unroll
             for (uint32_t r = 0; r < 4u; ++r)
                 if (r < rounds) br[r] = __ballot(lo[r] <= Us);
             if (lane < 4u) cw->br[lane] = lane == 0u ? br[0] : (lane == 1u ? br[1] : (lane == 2u ? br[2] : br[3]));
+            if (cand_of_lane == 0u) {
+                cw->U16[sub_of_lane] = (uint16_t)((Ubest + 0xFFFFu) >> 16);
+                cw->istar[sub_of_lane] = (uint8_t)(Ubest & 31u);
+            }
         } else if (words <= 4u && npop <= kMaxLong && !KMG_KNOCK(flags, 0x1000u)) {
             // long list (rare on noise, the heavy cells of a photograph): long_list_stage
             long_cell = true;
@@ -586,7 +653,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         }
         if (lane == 0u) {
             cw->npop = npop;
-            cw->scan_set = scan_set | (listed ? 0x100u : 0u) | (long_cell ? kLongFlag : 0u);
+            cw->scan_set = scan_set | (listed ? 0x100u : 0u) | (long_cell ? kLongFlag : 0u) | (decided_set << 16);
             if (sizeof(LabelT) == 1) *pair_entry_ptr = kPairPending;
         }
     }
@@ -597,6 +664,194 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         atomicAdd(stats + 3, st_scanned); atomicAdd(stats + 4, st_cands); atomicAdd(stats + 5, st_unlisted);
     }
     if (SUMS) flush_bins(bins, k, 1u, 4u * k, sums, n_rows);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_cube_prune (32 < k <= 256, between k_cube_stage and k_cube_scan): the DOMINANCE test of k_cube_small's header for the
+// listed cells of the general pass, as a phase of its own, and the compact work of the two launches that follow.
+// A workgroup takes kPruneCells cells of the work list, one sub-cell per thread:
+//   1. every (sub-cell to scan, candidate other than the one with the smallest upper bound) goes into ONE compact list in
+//      LDS, one test per lane; a candidate another candidate beats on every colour of the sub-cell leaves the sub-cell's set
+//      (exact: what the test removes is neither the arg-min nor within the tie threshold of it for any colour of the
+//      sub-cell -- `dominated`; a list that overflows drops tests, i.e. keeps candidates);
+//   2. a sub-cell left with ONE candidate is decided here as the stage kernel decides its own: 64 labels, the sums of the
+//      sub-cell table; a cell whose occupied sub-cells all went to one centroid gets its pair entry at once;
+//   3. what is still to scan leaves as ITEMS (two sub-cells of a cell and the union of their candidates, 16 bytes: all the
+//      scan kernel reads), the cells that need a pair entry derived from their labels as a list of cells (the layout above);
+//      one 64-bit atomic per wave reserves the places of its 8 cells.
+// sub_affine == NULL or a centroid outside the test's error budget (lists[kListFar], set by the stage kernel): no tests,
+// the items and lists all the same.
+// stats (optional): [6] candidates removed, [7] sub-cells left with one candidate.
+// flags (tools build, results WRONG): bit 21 no tests, 22 no decisions, 23 no reservation.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kPruneCells = kBlock / 8;                      // 32 cells of a workgroup
+constexpr uint32_t kPruneTests = 2048;
+
+template <bool SUMS>
+__global__ __launch_bounds__(kBlock) void k_cube_prune(const uint32_t *__restrict__ work, const int64_t *__restrict__ sub_agg,
+                                                       const Centroid *__restrict__ cent, uint32_t k,
+                                                       const float *__restrict__ sub_affine, CellWork *__restrict__ cell_work,
+                                                       uint8_t *__restrict__ colour_labels, uint16_t *__restrict__ sub_table,
+                                                       uint32_t *__restrict__ lists, int64_t *__restrict__ sums, uint32_t n_rows,
+                                                       uint32_t flags, unsigned long long *__restrict__ stats)
+{
+    __shared__ uint32_t s_mask[kBlock];                            // [sub-cell]: candidates (list positions)
+    __shared__ uint32_t s_ref[kBlock];                             // [sub-cell]: upper bound (16 high bits) | position of the reference candidate
+    __shared__ uint16_t s_list[kPruneCells * kMaxListed];          // [cell][position]: centroid
+    __shared__ uint32_t s_cell[kPruneCells];
+    __shared__ uint16_t s_test[kPruneTests];                       // (sub-cell << 5) | position
+    __shared__ uint32_t s_count;                                   // tests
+    extern __shared__ unsigned long long bins[];                   // k x 4 u64 (SUMS): sums of the sub-cells decided here
+    const uint32_t vz = opaque_vgpr_zero();
+    const uint32_t n_work_v = SUMS ? work[vz] : kCells;
+    const uint32_t far_v = lists[kListFar + vz];
+    const uint32_t slot = threadIdx.x >> 3, sub = threadIdx.x & 7u, lane = threadIdx.x & 63u;
+    // (the first batch's cells are requested with the list's length, not after it: entries beyond it are readable)
+    const uint32_t cell_first = SUMS ? work[1u + blockIdx.x * kPruneCells + slot] : blockIdx.x * kPruneCells + slot;
+    if (threadIdx.x == 0u) s_count = 0u;
+    // (straight global atomics instead of LDS bins were measured: 420 K of them per pass, the kernel 25 -> 137 us)
+    if (SUMS) for (uint32_t i = threadIdx.x; i < 4u * k; i += kBlock) bins[i] = 0ull;
+    __syncthreads();
+    const uint32_t n_work = __builtin_amdgcn_readfirstlane(n_work_v);
+    const bool dominance = sub_affine != nullptr && __builtin_amdgcn_readfirstlane(far_v) == 0u && !KMG_KNOCK(flags, 0x200000u);
+    uint32_t *pair_entries = reinterpret_cast<uint32_t *>(sub_table + kSubCells + kCells);
+    unsigned long long st_removed = 0, st_single = 0;
+    // (one batch per workgroup: the grid is kCells / kPruneCells whatever the list's length)
+    const uint32_t base = blockIdx.x * kPruneCells;
+    if (base >= n_work) return;
+    {
+        const uint32_t wi = base + slot;
+        const bool valid = wi < n_work;
+        const uint32_t cell = valid ? cell_first : 0u;
+        CellWork *cw = cell_work + cell;
+        const uint32_t ss = valid ? cw->scan_set : 0u;
+        const uint32_t npop = valid ? cw->npop : 1u;
+        const bool listed = (ss & 0x100u) != 0u;
+        const bool mine = listed && ((ss >> sub) & 1u) != 0u;       // a sub-cell the stage kernel left to the scan
+        uint32_t sm = 0u, istar = 0u, u16 = 0u;
+        longlong2 g01 = {0, 0}, g23 = {0, 0};
+        if (listed) {
+            const unsigned long long b0 = cw->br[0], b1 = cw->br[1], b2 = cw->br[2], b3 = cw->br[3];
+            sm = ((uint32_t)(b0 >> (8u * sub)) & 0xFFu) | (((uint32_t)(b1 >> (8u * sub)) & 0xFFu) << 8) |
+                 (((uint32_t)(b2 >> (8u * sub)) & 0xFFu) << 16) | (((uint32_t)(b3 >> (8u * sub)) & 0xFFu) << 24);
+            *reinterpret_cast<uint2 *>(s_list + slot * kMaxListed + 4u * sub) = *reinterpret_cast<const uint2 *>(cw->list + 4u * sub);
+            istar = (uint32_t)cw->istar[sub];
+            u16 = (uint32_t)cw->U16[sub];
+            if (SUMS && mine) {                                     // (what a sub-cell decided here hands over)
+                const longlong2 *sp = reinterpret_cast<const longlong2 *>(sub_agg + ((uint64_t)cell * 8u + sub) * 4u);
+                g01 = sp[0]; g23 = sp[1];
+            }
+        }
+        s_mask[threadIdx.x] = sm;
+        if (sub == 0u) s_cell[slot] = cell;
+        const uint32_t others = (mine && dominance) ? sm & ~(1u << istar) : 0u;
+        if (others) {
+            s_ref[threadIdx.x] = (u16 << 16) | istar;
+            const uint32_t nt = (uint32_t)__builtin_popcount(others);
+            uint32_t at = atomicAdd(&s_count, nt);
+            for (uint32_t m = others; m && at < kPruneTests; m &= m - 1u, ++at)
+                s_test[at] = (uint16_t)((threadIdx.x << 5) | (uint32_t)__builtin_ctz(m));
+        }
+        __syncthreads();
+        const uint32_t n_tests = min(s_count, kPruneTests);
+        for (uint32_t t = threadIdx.x; t < n_tests; t += kBlock) {
+            const uint32_t e = (uint32_t)s_test[t] >> 5, pos = (uint32_t)s_test[t] & 31u;
+            const uint32_t tsc = s_cell[e >> 3] * 8u + (e & 7u);
+            const float4 *mp = reinterpret_cast<const float4 *>(sub_affine + (uint64_t)tsc * kAffineFloats);
+            const uint32_t r = s_ref[e];
+            const Centroid cj = cent[s_list[(e >> 3) * kMaxListed + pos]], ci = cent[s_list[(e >> 3) * kMaxListed + (r & 31u)]];
+            float mdl[44];
+#pragma unroll
+            for (int q = 0; q < 11; ++q) {
+                const float4 v = mp[q];
+                mdl[4 * q] = v.x; mdl[4 * q + 1] = v.y; mdl[4 * q + 2] = v.z; mdl[4 * q + 3] = v.w;
+            }
+            if (dominated(mdl, make_float4(cj.L, cj.a, cj.b, cj.C), make_float4(ci.L, ci.a, ci.b, ci.C), bits_to_float(r & 0xFFFF0000u)))
+                atomicAnd(&s_mask[e], ~(1u << pos));
+        }
+        __syncthreads();
+        // ---- what is left of every sub-cell's set ----
+        const uint32_t nm = s_mask[threadIdx.x];
+        const uint32_t np = (uint32_t)__builtin_popcount(nm);
+        const bool one = mine && np == 1u, still = mine && np > 1u;
+        const bool was_decided = listed && ((ss >> (16u + sub)) & 1u) != 0u;            // (by the stage kernel: its set has one member)
+        const uint32_t X = (uint32_t)s_list[slot * kMaxListed + (nm ? (uint32_t)__builtin_ctz(nm) : 0u)];
+        const uint32_t scan8 = group8_or(still ? 1u << sub : 0u);
+        const bool settled = one || was_decided;
+        const uint32_t xmin = group8_min_u32(settled ? X : 255u), xmax = group8_max_u32(settled ? X : 0u);
+        const bool uniform = listed && scan8 == 0u && xmin == xmax;   // every occupied sub-cell of the cell went to centroid xmin
+        // ---- what the scan and the entries launches get: one 64-bit atomic per wave reserves the places of its cells ----
+        // items: the sub-cells still to scan, two per item in ascending order; a lane that heads a pair builds the item
+        const uint32_t rank = (uint32_t)__builtin_popcount(scan8 & ((1u << sub) - 1u));
+        const bool head = still && (rank & 1u) == 0u;
+        const uint32_t after = scan8 & ~((2u << sub) - 1u);
+        const uint32_t s1 = after ? (uint32_t)__builtin_ctz(after) : 8u;
+        const uint32_t un = nm | ((head && s1 < 8u) ? s_mask[threadIdx.x - sub + s1] : 0u);
+        const uint32_t n_un = (uint32_t)__builtin_popcount(un);
+        const bool as_items = listed && group8_or((head && n_un > kItemCands) ? 1u : 0u) == 0u;
+        const bool emit = head && as_items && !KMG_KNOCK(flags, 0x400u);
+        const bool need_whole = valid && sub == 0u && !KMG_KNOCK(flags, 0x400u) && (listed ? (scan8 != 0u && !as_items) : (ss & 0xFFu) != 0u);
+        const bool need_entry = valid && sub == 0u && npop != 1u && !uniform;
+        const unsigned long long item_b = __ballot(emit), whole_b = __ballot(need_whole), ent_b = __ballot(need_entry);
+        const uint32_t seg = (base / 8u + (threadIdx.x >> 6)) & (kListSegs - 1u);
+        unsigned long long at64 = 0ull;
+        if (lane == 0u && (item_b | whole_b | ent_b) && !KMG_KNOCK(flags, 0x800000u))
+            at64 = atomicAdd(reinterpret_cast<unsigned long long *>(lists) + seg,
+                             (unsigned long long)__builtin_popcountll(item_b) | ((unsigned long long)__builtin_popcountll(whole_b) << 21) |
+                                 ((unsigned long long)__builtin_popcountll(ent_b) << 42));
+        uint32_t iw0 = 0u, iw1 = 0u, iw2 = 0u;
+        if (emit) {
+            uint32_t q = 0u;
+            for (uint32_t m = un; m; m &= m - 1u, ++q) {
+                const uint32_t c = (uint32_t)s_list[slot * kMaxListed + (uint32_t)__builtin_ctz(m)] << (8u * (q & 3u));
+                iw0 |= q < 4u ? c : 0u; iw1 |= (q >= 4u && q < 8u) ? c : 0u; iw2 |= q >= 8u ? c : 0u;
+            }
+        }
+        if (one && !KMG_KNOCK(flags, 0x400000u)) {
+            const uint32_t x4 = X * 0x01010101u;
+            uint4 *dst = reinterpret_cast<uint4 *>(colour_labels + (uint64_t)cell * kCellColours + sub * 64u);
+            dst[0] = dst[1] = dst[2] = dst[3] = make_uint4(x4, x4, x4, x4);
+            if (SUMS && !KMG_KNOCK(flags, 0x200u)) {
+                unsigned long long *to = bins + 4ull * X;
+                atomicAdd(to + 0, (unsigned long long)g01.x); atomicAdd(to + 1, (unsigned long long)g01.y);
+                atomicAdd(to + 2, (unsigned long long)g23.x); atomicAdd(to + 3, (unsigned long long)g23.y);
+            }
+        }
+        if (listed && scan8 != 0u && !as_items && group8_or(nm != sm ? 1u : 0u)) {
+            // a cell that is scanned from its record after all: the sub-cells' sets back into it (round r: bit 8 s + c = sub-cell s
+            // keeps candidate 8 r + c)
+            uint32_t lo_w[4], hi_w[4];
+#pragma unroll
+            for (uint32_t r = 0; r < 4u; ++r) {
+                const uint32_t byte = (nm >> (8u * r)) & 0xFFu;
+                lo_w[r] = group8_or(sub < 4u ? byte << (8u * sub) : 0u);
+                hi_w[r] = group8_or(sub >= 4u ? byte << (8u * (sub - 4u)) : 0u);
+            }
+            if (sub < 4u) {
+                const uint32_t l = sub == 0u ? lo_w[0] : (sub == 1u ? lo_w[1] : (sub == 2u ? lo_w[2] : lo_w[3]));
+                const uint32_t h = sub == 0u ? hi_w[0] : (sub == 1u ? hi_w[1] : (sub == 2u ? hi_w[2] : hi_w[3]));
+                cw->br[sub] = ((unsigned long long)h << 32) | l;
+            }
+            if (sub == 0u) cw->scan_set = (ss & ~0xFFu) | scan8;
+        }
+        if (uniform && sub == 0u) pair_entries[cell] = pair_entry(xmin, xmin, 0u, 0u, 0u);
+        if (stats) {
+            st_removed += wave_add_u32((uint32_t)__builtin_popcount(sm & ~nm));
+            st_single += (uint32_t)__builtin_popcountll(__ballot(one));
+        }
+        // (the sums leave while the reservation is on its way)
+        if (SUMS) flush_bins(bins, k, 1u, 4u * k, sums, n_rows);
+        {
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)at64), hi = __builtin_amdgcn_readfirstlane((uint32_t)(at64 >> 32));
+            const uint32_t a_item = lo & 0x1FFFFFu, a_whole = ((lo >> 21) | (hi << 11)) & 0x1FFFFFu, a_ent = hi >> 10;
+            if (emit)
+                reinterpret_cast<uint4 *>(lists + kListItems)[seg * kItemSegCap + a_item + bits_below_lane(item_b)] =
+                    make_uint4(cell | (sub << 15) | (s1 << 18) | (n_un << 22), iw0, iw1, iw2);
+            if (need_whole) lists[kListWhole + seg * kListSegCap + a_whole + bits_below_lane(whole_b)] = cell;
+            if (need_entry) lists[kListEntries + seg * kListSegCap + a_ent + bits_below_lane(ent_b)] = cell;
+        }
+    }
+    if (stats && lane == 0u) { atomicAdd(stats + 6, st_removed); atomicAdd(stats + 7, st_single); }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -641,11 +896,25 @@ __global__ __launch_bounds__(kBlock) void k_cube_scan(const uint32_t *__restrict
     float4 *s_cc = s_cc_all + wv * kMaxListed;
     LabelT *s_lbl = s_lbl_all + wv * kCellColours;
 
-    const uint32_t n_work = SUMS ? __builtin_amdgcn_readfirstlane(work[0]) : kCells;
+    // kCubePruned: what k_cube_prune left -- segment wave % kListSegs of its lists, every (n_waves / kListSegs)-th entry: first
+    // the ITEMS (two sub-cells and their candidates each: nothing else is read), then the cells that are scanned from their
+    // work records; otherwise the whole work list
+    const bool from_list = (flags & kCubePruned) != 0u;
+    const uint32_t *lists = reinterpret_cast<const uint32_t *>(cell_work + kCells);
+    const uint32_t seg = wave & (kListSegs - 1u);
+    uint32_t n_whole = 0u, n_items = 0u;
+    if (from_list) {
+        const uint32_t cnt_lo = __builtin_amdgcn_readfirstlane(lists[2u * seg]), cnt_hi = __builtin_amdgcn_readfirstlane(lists[2u * seg + 1u]);
+        n_items = cnt_lo & 0x1FFFFFu;
+        n_whole = ((cnt_lo >> 21) | (cnt_hi << 11)) & 0x1FFFFFu;
+    }
+    const uint32_t n_work = from_list ? n_whole : (SUMS ? __builtin_amdgcn_readfirstlane(work[0]) : kCells);
+    const uint32_t *cells = from_list ? lists + kListWhole + seg * kListSegCap : (SUMS ? work + 1 : nullptr);
+    const uint32_t wi_step = from_list ? n_waves / kListSegs : n_waves;
     // (Requesting the NEXT cell's work record ahead -- one vector load, lane i = dword i -- was measured: the 8 registers
     // it holds cost a wave per SIMD, 73.6 -> 76.6 us.)
-    for (uint32_t wi = wave; wi < n_work; wi += n_waves) {
-        const uint32_t cell = SUMS ? __builtin_amdgcn_readfirstlane(work[1u + wi]) : wi;
+    for (uint32_t wi = from_list ? wave / kListSegs : wave; wi < n_work; wi += wi_step) {
+        const uint32_t cell = cells ? __builtin_amdgcn_readfirstlane(cells[wi]) : wi;
         const CellWork *cw = cell_work + cell;
         uint32_t scan_set = __builtin_amdgcn_readfirstlane(cw->scan_set);
         if ((scan_set & 0xFFu) == 0u) continue;                     // one candidate, or every sub-cell decided
@@ -849,6 +1118,125 @@ __global__ __launch_bounds__(kBlock) void k_cube_scan(const uint32_t *__restrict
         }
         __builtin_amdgcn_wave_barrier();
     }
+    // ---- the items (after the whole cells: those are the heavy ones -- the long lists of a photograph -- and start first) ----
+    if (from_list) {
+        const uint4 *items = reinterpret_cast<const uint4 *>(lists + kListItems) + seg * kItemSegCap;
+        const uint32_t vz = opaque_vgpr_zero();
+        const uint32_t step = n_waves / kListSegs;
+        uint32_t it = wave / kListSegs;
+        uint4 item_n = items[(it < n_items ? it : 0u) + vz];        // (vector loads: see k_cube_stage)
+        // two register sets A / B, the loop body once per set (see the cells' loop below): the colours of the NEXT item are in
+        // flight while the current one is scanned, the header of the one after that is requested behind them
+        uint32_t A_h = 0u, A_w0 = 0u, A_w1 = 0u, A_w2 = 0u, B_h = 0u, B_w0 = 0u, B_w1 = 0u, B_w2 = 0u;
+        float4 A_v0, A_v1, B_v0, B_v1;
+        uint32_t A_c0 = 1u, A_c1 = 1u, B_c0 = 1u, B_c1 = 1u;
+        long long A_g = 0, B_g = 0;
+        uint32_t it_req = it;                                       // the item whose header item_n holds
+#define KMG_REQUEST_ITEM(X)                                                                                      \
+        do {                                                                                                     \
+            X##_h = __builtin_amdgcn_readfirstlane(item_n.x); X##_w0 = __builtin_amdgcn_readfirstlane(item_n.y); \
+            X##_w1 = __builtin_amdgcn_readfirstlane(item_n.z); X##_w2 = __builtin_amdgcn_readfirstlane(item_n.w); \
+            const uint32_t cell_ = X##_h & 0x7FFFu;                                                              \
+            const uint32_t c0_ = cell_ * kCellColours + ((X##_h >> 15) & 7u) * 64u + lane;                       \
+            const uint32_t c1_ = cell_ * kCellColours + ((X##_h >> 18) & 7u) * 64u + lane;   /* s1 == 8: sub-cell 0, unused */ \
+            X##_v0 = lab_table[c0_]; X##_v1 = lab_table[c1_];                                                    \
+            if (SUMS) { X##_c0 = hist[c0_]; X##_c1 = hist[c1_]; X##_g = sub_agg[(uint64_t)cell_ * 32u + (lane & 31u)]; } \
+            it_req += step;                                                                                      \
+            item_n = items[(it_req < n_items ? it_req : 0u) + vz];  /* past the end: a harmless repeat */        \
+        } while (0)
+        auto scan_item = [&](const uint32_t hdr, const uint32_t w0, const uint32_t w1, const uint32_t w2, const float4 v0, const float4 v1,
+                             const uint32_t cnt0, const uint32_t cnt1, const long long sagg) {
+            const uint32_t cell = hdr & 0x7FFFu, s0 = (hdr >> 15) & 7u, s1 = (hdr >> 18) & 15u, n = hdr >> 22;
+            // lane p < n: the p-th candidate
+            const uint32_t my_cand = ((lane < 4u ? w0 : (lane < 8u ? w1 : w2)) >> (8u * (lane & 3u))) & 0xFFu;
+            const PixelTerms pt0 = pixel_terms_fast(v0.x, v0.y, v0.z, v0.w), pt1 = pixel_terms_fast(v1.x, v1.y, v1.z, v1.w);
+            uint32_t b0 = 0x7F7FFFFFu, r0 = 0x7F7FFFFFu, b1 = 0x7F7FFFFFu, r1 = 0x7F7FFFFFu;   // smallest / runner-up
+            const f32x2 qL = {pt0.L, pt1.L}, qa = {pt0.a, pt1.a}, qb = {pt0.b, pt1.b}, qC = {pt0.C, pt1.C};
+            const f32x2 qwC = {pt0.wC, pt1.wC}, qwH = {pt0.wH, pt1.wH};
+            auto cand_at = [&](uint32_t pos) { return ((pos < 4u ? w0 : (pos < 8u ? w1 : w2)) >> (8u * (pos & 3u))) & 0xFFu; };
+            for (uint32_t pos = 0; pos < n; ++pos) {
+                const float4 c = s_cent[cand_at(pos)];
+                const f32x2 dL = qL - c.x, da = qa - c.y, db = qb - c.z, dC = qC - c.w;
+                const f32x2 dC2 = dC * dC;
+                const f32x2 t = __builtin_elementwise_fma(db, db, da * da);
+                f32x2 h = t - dC2;
+                h.x = fmaxf(h.x, 0.0f); h.y = fmaxf(h.y, 0.0f);
+                const f32x2 key = __builtin_elementwise_fma(h, qwH, __builtin_elementwise_fma(dC2, qwC, dL * dL));
+                uint32_t u0, u1;                                   // (key & ~31) | pos (pos is wave-uniform)
+                asm("v_bfi_b32 %0, 31, %1, %2" : "=v"(u0) : "s"(pos), "v"(float_to_bits(key.x)));
+                asm("v_bfi_b32 %0, 31, %1, %2" : "=v"(u1) : "s"(pos), "v"(float_to_bits(key.y)));
+                r0 = umed3(u0, b0, r0); b0 = min(b0, u0);
+                r1 = umed3(u1, b1, r1); b1 = min(b1, u1);
+            }
+            uint32_t p0 = b0 & 31u, p1 = b1 & 31u;
+            // near-tie repair (kmg_math.h): rare; decided by the literal distance, first minimum wins
+            const float thr0 = tie_threshold(bits_to_float(b0 & ~31u)), thr1 = tie_threshold(bits_to_float(b1 & ~31u));
+            const bool near0 = bits_to_float(r0 & ~31u) <= thr0, near1 = bits_to_float(r1 & ~31u) <= thr1;
+            if (__ballot(near0 || near1)) {
+                float lb0 = 100000.0f, lb1 = 100000.0f;           // find_centroid.wgsl:29-30
+                uint32_t li0 = 0u, li1 = 0u;
+                for (uint32_t pos = 0; pos < n; ++pos) {
+                    const float4 c = s_cent[cand_at(pos)];
+                    if (near0 && cie94_key(pt0, c.x, c.y, c.z, c.w) <= thr0) {
+                        const float d = cie94_c(v0.x, v0.y, v0.z, v0.w, c.x, c.y, c.z, c.w);
+                        if (d < lb0) { lb0 = d; li0 = pos; }
+                    }
+                    if (near1 && cie94_key(pt1, c.x, c.y, c.z, c.w) <= thr1) {
+                        const float d = cie94_c(v1.x, v1.y, v1.z, v1.w, c.x, c.y, c.z, c.w);
+                        if (d < lb1) { lb1 = d; li1 = pos; }
+                    }
+                }
+                p0 = near0 ? li0 : p0;
+                p1 = near1 ? li1 : p1;
+            }
+            const uint32_t ix0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(p0 << 2), (int)my_cand);
+            const uint32_t ix1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(p1 << 2), (int)my_cand);
+            LabelT *cell_labels = colour_labels + (uint64_t)cell * kCellColours;
+            // what a scanned sub-cell leaves behind: its 64 labels and its sums (as the cells' loop below)
+            auto finish = [&](uint32_t s, uint32_t ix, uint32_t cnt, float vL, float va, float vb) {
+                if (!KMG_KNOCK(flags, 0x2000u)) store_labels64(cell_labels + s * 64u, ix, lane);
+                if (!SUMS || KMG_KNOCK(flags, 0x200u)) return;
+                const bool counts = cnt != 0u;
+                const unsigned long long occm = __ballot(counts);
+                if (!occm) return;
+                const uint32_t X0 = lane_value(ix, (uint32_t)__builtin_ctzll(occm));
+                const unsigned long long other = __ballot(counts && ix != X0);
+                uint32_t R = X0;
+                if (other) {
+                    const uint32_t X1 = lane_value(ix, (uint32_t)__builtin_ctzll(other));
+                    if (__builtin_popcountll(__ballot(counts && ix == X1)) > __builtin_popcountll(occm & ~other)) R = X1;
+                }
+                if ((lane >> 2) == s) atomicAdd(bins + 4ull * R + (lane & 3u), (unsigned long long)sagg);
+                if (other && counts && ix != R) {
+                    const long long m = (long long)cnt;
+                    const long long c0 = m * (long long)lab_fix(vL), c1 = m * (long long)lab_fix(va), c2 = m * (long long)lab_fix(vb);
+                    unsigned long long *to = my_bins + 4ull * ix, *from = my_bins + 4ull * R;
+                    atomicAdd(to + 0, (unsigned long long)c0); atomicAdd(from + 0, (unsigned long long)(-c0));
+                    atomicAdd(to + 1, (unsigned long long)c1); atomicAdd(from + 1, (unsigned long long)(-c1));
+                    atomicAdd(to + 2, (unsigned long long)c2); atomicAdd(from + 2, (unsigned long long)(-c2));
+                    atomicAdd(to + 3, (unsigned long long)m);  atomicAdd(from + 3, (unsigned long long)(-m));
+                }
+            };
+            finish(s0, ix0, cnt0, v0.x, v0.y, v0.z);
+            if (s1 < 8u) finish(s1, ix1, cnt1, v1.x, v1.y, v1.z);
+        };
+        if (it < n_items) {
+            KMG_REQUEST_ITEM(A);
+            for (;;) {
+                // (unconditional: past the end the request repeats item 0 of the segment, unused -- a conditional request makes
+                // the compiler wait for the registers it has just requested)
+                KMG_REQUEST_ITEM(B);
+                scan_item(A_h, A_w0, A_w1, A_w2, A_v0, A_v1, A_c0, A_c1, A_g);
+                it += step;
+                if (it >= n_items) break;
+                KMG_REQUEST_ITEM(A);
+                scan_item(B_h, B_w0, B_w1, B_w2, B_v0, B_v1, B_c0, B_c1, B_g);
+                it += step;
+                if (it >= n_items) break;
+            }
+        }
+#undef KMG_REQUEST_ITEM
+    }
     if (SUMS) flush_bins(bins, k, repl, bin_stride, sums, n_rows);
 }
 
@@ -861,7 +1249,8 @@ __global__ __launch_bounds__(kBlock) void k_cube_pairs(const uint32_t *__restric
                                                        const uint8_t *__restrict__ occ_bits,
                                                        const LabelT *__restrict__ colour_labels,
                                                        uint16_t *__restrict__ sub_table, uint32_t flags,
-                                                       int64_t *__restrict__ sums, uint32_t k, CubeTail tail)
+                                                       int64_t *__restrict__ sums, uint32_t k, CubeTail tail,
+                                                       const uint32_t *__restrict__ lists)
 {
     // the tail of the pass (kmg_table.h CubeTail): the stage and scan launches have completed, so the sums are final
     if (tail.acc_out && blockIdx.x == gridDim.x - 1u) {
@@ -875,10 +1264,16 @@ __global__ __launch_bounds__(kBlock) void k_cube_pairs(const uint32_t *__restric
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
     const uint32_t n_waves = gridDim.x * (kBlock / 64);
-    const uint32_t n_work = with_work ? __builtin_amdgcn_readfirstlane(work[0]) : kCells;
+    // kCubePruned (k <= 256): the cells k_cube_prune left without an entry -- segment wave % kListSegs of its second list
+    const bool from_list = (flags & kCubePruned) != 0u;
+    const uint32_t seg = wave & (kListSegs - 1u);
+    const uint32_t n_work = from_list ? __builtin_amdgcn_readfirstlane(lists[2u * seg + 1u]) >> 10
+                                      : (with_work ? __builtin_amdgcn_readfirstlane(work[0]) : kCells);
+    const uint32_t *cells = from_list ? lists + kListEntries + seg * kListSegCap : (with_work ? work + 1 : nullptr);
+    const uint32_t wi_step = from_list ? n_waves / kListSegs : n_waves;
     // (Requesting the next cell's flag, labels and occupancy ahead was measured: no change, 21.5 us either way.)
-    for (uint32_t wi = wave; wi < n_work; wi += n_waves) {
-        const uint32_t cell = with_work ? __builtin_amdgcn_readfirstlane(work[1u + wi]) : wi;
+    for (uint32_t wi = from_list ? wave / kListSegs : wave; wi < n_work; wi += wi_step) {
+        const uint32_t cell = cells ? __builtin_amdgcn_readfirstlane(cells[wi]) : wi;
         if (sizeof(LabelT) == 1) {
             uint32_t *pair_entry_ptr = reinterpret_cast<uint32_t *>(sub_table + kSubCells + kCells) + cell;
             if (__builtin_amdgcn_readfirstlane(*pair_entry_ptr) != kPairPending) continue;
@@ -949,30 +1344,6 @@ constexpr uint32_t kSmallWaves = kSmallBlock / 64;
 constexpr uint32_t kSmallCells = kSmallWaves * 8u;               // cells of a workgroup
 constexpr uint32_t kSmallEmit = 0x100u;                           // k_cube_small: stage only, records for k_cube_scan / k_cube_pairs
 constexpr uint32_t kSmallTests = 2048;                           // dominance tests a workgroup lists per round
-
-__device__ __forceinline__ uint32_t group8_or(uint32_t v)
-{
-    v |= dpp_u32<kDppXor1>(v);
-    v |= dpp_u32<kDppXor2>(v);
-    v |= dpp_u32<kDppHalfMirror>(v);
-    return v;
-}
-
-__device__ __forceinline__ uint32_t group8_min_u32(uint32_t v)
-{
-    v = min(v, dpp_u32<kDppXor1>(v));
-    v = min(v, dpp_u32<kDppXor2>(v));
-    v = min(v, dpp_u32<kDppHalfMirror>(v));
-    return v;
-}
-
-__device__ __forceinline__ uint32_t group8_max_u32(uint32_t v)
-{
-    v = max(v, dpp_u32<kDppXor1>(v));
-    v = max(v, dpp_u32<kDppXor2>(v));
-    v = max(v, dpp_u32<kDppHalfMirror>(v));
-    return v;
-}
 
 // the 7 features of one colour (exact products of binary32 values in binary64)
 __device__ __forceinline__ void affine_features(const float4 v, double F[7])
@@ -1486,7 +1857,14 @@ uint32_t cube_replicas(uint32_t k)
     return r;
 }
 
-size_t cube_work_bytes() { return sizeof(CellWork) * (size_t)kCells; }
+size_t cube_work_bytes() { return sizeof(CellWork) * (size_t)kCells + sizeof(uint32_t) * kListsWords; }
+
+// the dominance phase of the general pass (k_cube_prune): needs the sub_affine table of the processor
+bool cube_prune_wanted(uint32_t k)
+{
+    static const bool on = tools_env_int(KMG_TOOLS_ENV("KMG_CUBE_PRUNE"), 1) != 0;     // (tools build: 0 = the pass without it)
+    return on && k > kSmallMaxK && k <= 256u;
+}
 
 hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *sub_agg, const uint8_t *occ_bits,
                        const uint32_t *work, const CellBounds *bounds, const CellBounds *sub_bounds, const Centroid *cent,
@@ -1498,7 +1876,7 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
     const uint32_t kpad = (k + 63u) & ~63u;
     const bool with_sums = hist != nullptr;
     const uint32_t repl = with_sums ? cube_replicas(k) : 1u;
-    if (const char *e = KMG_TOOLS_ENV("KMG_CUBE_FLAGS")) flags |= (uint32_t)strtoul(e, nullptr, 0) & 0x10FF00u;   // (tools build only)
+    if (const char *e = KMG_TOOLS_ENV("KMG_CUBE_FLAGS")) flags |= (uint32_t)strtoul(e, nullptr, 0) & 0xF0FF00u;   // (tools build only)
     const size_t lds_stage = sizeof(float4) * kpad + (with_sums ? sizeof(unsigned long long) * 4ull * k : 0) +
                              sizeof(uint32_t) * (kBlock / 64) * kMaxListed + sizeof(unsigned long long) * (kBlock / 64) * (kpad / 64u) +
                              (k <= 256 ? (kBlock / 64) * (32u * sizeof(unsigned long long) + kMaxLong * sizeof(uint16_t)) : 0u);
@@ -1545,12 +1923,13 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
                 hipLaunchKernelGGL((k_cube_scan<uint8_t, false>), dim3(g_scan2), dim3(kBlock), lds_scan2, st, hist, sub_agg, work, cent, k,
                                    lab_table, masks, (const CellWork *)cell_work, (uint8_t *)colour_labels, sub_table, sums, n_rows, repl2, flags);
             hipLaunchKernelGGL((k_cube_pairs<uint8_t>), dim3((flags & kCubeNoEntries) ? 1u : g_pairs2), dim3(kBlock), 0, st, work,
-                               with_sums ? 1 : 0, occ_bits, (const uint8_t *)colour_labels, sub_table, flags, sums, k, tl);
+                               with_sums ? 1 : 0, occ_bits, (const uint8_t *)colour_labels, sub_table, flags, sums, k, tl,
+                               (const uint32_t *)nullptr);
             return hipGetLastError();
         }
         if (tl.acc_out)
             hipLaunchKernelGGL((k_cube_pairs<uint8_t>), dim3(1), dim3(kBlock), 0, st, work, 1, occ_bits,
-                               (const uint8_t *)colour_labels, sub_table, flags | kCubeNoEntries, sums, k, tl);
+                               (const uint8_t *)colour_labels, sub_table, flags | kCubeNoEntries, sums, k, tl, (const uint32_t *)nullptr);
         return hipGetLastError();
     }
     // (the scan kernel's cells differ a lot in cost: finer hand-out, 2 cells per wave, measured 83 -> 75 us)
@@ -1559,15 +1938,27 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
                           g_pairs = env_grid("KMG_PAIRS_GRID", kCubeGrid);
     CellWork *cw = (CellWork *)cell_work;
     if (!n_rows) n_rows = 1u;
+    // 32 < k <= 256: the dominance phase and its compact lists between the stage and the scan (sub_affine == NULL: lists only)
+    const bool prune = cube_prune_wanted(k) && !(flags & kCubeNoPrune) && !KMG_KNOCK(flags, 0x800u);
+    if (prune) flags |= kCubePruned;
+    const uint32_t g_prune = kCells / kPruneCells;                 // (one batch of cells per workgroup)
+    // (the scan over items: one round of resident workgroups, each wave a few items with the next one's colours in flight)
+    static const uint32_t g_items = env_grid("KMG_ITEMS_GRID", 1792u) & ~15u;
+    const uint32_t *lists = reinterpret_cast<const uint32_t *>(cw + kCells);
+    const size_t lds_prune = with_sums ? sizeof(unsigned long long) * 4ull * k : 0;
 #define KMG_CUBE(T, S)                                                                                                      \
     do {                                                                                                                    \
         hipLaunchKernelGGL((k_cube_stage<T, S>), dim3(g_stage), dim3(kBlock), lds_stage, st, agg, sub_agg, work, bounds,    \
                            sub_bounds, cent, k, masks, cw, (T *)colour_labels, sub_table, sums, n_rows, flags, stats);      \
+        if (prune)                                                                                                          \
+            hipLaunchKernelGGL((k_cube_prune<S>), dim3(g_prune), dim3(kBlock), lds_prune, st, work, sub_agg, cent, k,       \
+                               sub_affine, cw, (uint8_t *)colour_labels, sub_table, const_cast<uint32_t *>(lists), sums,    \
+                               n_rows, flags, stats);                                                                       \
         if (!KMG_KNOCK(flags, 0xC00u))                                                                                      \
-            hipLaunchKernelGGL((k_cube_scan<T, S>), dim3(g_scan), dim3(kBlock), lds_scan, st, hist, sub_agg, work, cent, k, \
+            hipLaunchKernelGGL((k_cube_scan<T, S>), dim3(prune ? g_items : g_scan), dim3(kBlock), lds_scan, st, hist, sub_agg, work, cent, k, \
                                lab_table, masks, cw, (T *)colour_labels, sub_table, sums, n_rows, repl, flags);             \
         hipLaunchKernelGGL((k_cube_pairs<T>), dim3((flags & kCubeNoEntries) ? 1u : g_pairs), dim3(kBlock), 0, st, work,   \
-                           S ? 1 : 0, occ_bits, (const T *)colour_labels, sub_table, flags, sums, k, tl);                   \
+                           S ? 1 : 0, occ_bits, (const T *)colour_labels, sub_table, flags, sums, k, tl, lists);            \
     } while (0)
     if (k <= 256) { if (with_sums) KMG_CUBE(uint8_t, true); else KMG_CUBE(uint8_t, false); }
     else          { if (with_sums) KMG_CUBE(uint16_t, true); else KMG_CUBE(uint16_t, false); }
@@ -1581,10 +1972,10 @@ hipError_t launch_cube_entries(const uint32_t *work, const uint8_t *occ_bits, co
     static const uint32_t g_pairs = env_grid("KMG_PAIRS_GRID", kCubeGrid);
     if (k <= 256)
         hipLaunchKernelGGL((k_cube_pairs<uint8_t>), dim3(g_pairs), dim3(kBlock), 0, st, work, work ? 1 : 0, occ_bits,
-                           (const uint8_t *)colour_labels, sub_table, 0u, (int64_t *)nullptr, k, CubeTail());
+                           (const uint8_t *)colour_labels, sub_table, 0u, (int64_t *)nullptr, k, CubeTail(), (const uint32_t *)nullptr);
     else
         hipLaunchKernelGGL((k_cube_pairs<uint16_t>), dim3(g_pairs), dim3(kBlock), 0, st, work, work ? 1 : 0, occ_bits,
-                           (const uint16_t *)colour_labels, sub_table, 0u, (int64_t *)nullptr, k, CubeTail());
+                           (const uint16_t *)colour_labels, sub_table, 0u, (int64_t *)nullptr, k, CubeTail(), (const uint32_t *)nullptr);
     return hipGetLastError();
 }
 

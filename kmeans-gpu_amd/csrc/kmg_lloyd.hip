@@ -10,7 +10,7 @@
 // ---------------------------------------------------------------------------------------------
 static void drop_events(kmg_lloyd *s);
 static void destroy_events(kmg_lloyd *s);
-static int debug_refresh(kmg_lloyd *s, hipStream_t st, unsigned long long stage[6]);
+static int debug_refresh(kmg_lloyd *s, hipStream_t st, unsigned long long stage[8]);
 static int side_flush(kmg_lloyd *s, hipStream_t st);
 // The table's blocks go back to the processor for the next image.  The caller has made sure that no kernel still uses them.
 static void free_table(kmg_processor *p, ColourTable &t)
@@ -87,7 +87,7 @@ int ensure_bounds(kmg_processor *p, hipStream_t st)
 // NULL when it cannot be had -- the pass is exact without it, only slower.
 const float *affine_for(kmg_processor *p, uint32_t k, hipStream_t st)
 {
-    if (k > 32u) return nullptr;                                     // (only k_cube_small makes the test)
+    if (k > kCubeSmallMaxK && !cube_prune_wanted(k)) return nullptr;   // (k_cube_small and k_cube_prune make the test)
     std::lock_guard<std::mutex> lock(p->mu);
     if (p->d_sub_affine || p->affine_failed || !p->d_lab_table) return p->d_sub_affine;
     float *a = nullptr;
@@ -279,15 +279,16 @@ extern "C" int kmg_debug_check_table(kmg_lloyd *s, uint64_t out[3], void *stream
 // candidate, [3] largest candidate count, [4] cells whose occupied colours share one label,
 // [5] occupied sub-cells, [6] sub-cells whose occupied colours share one label, [7] distinct colours,
 // [8] sub-cells the cube pass decided from their bounds, [9] sub-cells whose colours it scanned,
-// [10] candidates summed over the scanned sub-cells, [11] cells with too many candidates for the sub-cell stage
-extern "C" int kmg_debug_table_stats(kmg_lloyd *s, uint64_t out[12], void *stream)
+// [10] candidates summed over the scanned sub-cells, [11] cells with too many candidates for the sub-cell stage,
+// [12] candidates the dominance phase removed from scanned sub-cells, [13] scanned sub-cells it left with one candidate
+extern "C" int kmg_debug_table_stats(kmg_lloyd *s, uint64_t out[14], void *stream)
 {
     if (!s || !out) return fail(KMG_ERR_INVALID_ARGUMENT, "bad table_stats arguments");
     if (!s->tab.rgba || !s->tab.tables_valid) return fail(KMG_ERR_INVALID_ARGUMENT, "no current colour table");
     HIP_TRY(hipSetDevice(s->p->device));
     HIP_TRY(hipStreamSynchronize(S(stream)));
     int rc_;
-    unsigned long long stage[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long stage[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if ((rc_ = debug_refresh(s, S(stream), stage)) != KMG_OK) return rc_;
     const uint32_t words = mask_words(s->k);
     std::vector<uint64_t> masks((size_t)kCells * words);
@@ -305,7 +306,7 @@ extern "C" int kmg_debug_table_stats(kmg_lloyd *s, uint64_t out[12], void *strea
         HIP_TRY(hipMemcpy(labels.data(), s->tab.d_colour_labels, labels.size() * 2, hipMemcpyDeviceToHost));
     }
     for (int i = 0; i < 8; ++i) out[i] = 0;
-    out[8] = stage[2]; out[9] = stage[3]; out[10] = stage[4]; out[11] = stage[5];
+    out[8] = stage[2]; out[9] = stage[3]; out[10] = stage[4]; out[11] = stage[5]; out[12] = stage[6]; out[13] = stage[7];
     for (uint32_t c = 0; c < kCells; ++c) {
         if (agg[4ull * c + 3] == 0) continue;
         uint64_t pop = 0;
@@ -381,7 +382,7 @@ extern "C" int kmg_debug_check_pairs(kmg_lloyd *s, uint64_t out[3], void *stream
 
 // statistics / checks read the cell masks and the per-colour labels of EVERY cell, which the normal pass does
 // not store: repeat the cube pass of the bound image for the current centroids with both switched on
-static int debug_refresh(kmg_lloyd *s, hipStream_t st, unsigned long long stage[6] = nullptr)
+static int debug_refresh(kmg_lloyd *s, hipStream_t st, unsigned long long stage[8] = nullptr)
 {
     ColourTable &t = s->tab;
     int rc_;
@@ -389,12 +390,12 @@ static int debug_refresh(kmg_lloyd *s, hipStream_t st, unsigned long long stage[
     if ((rc_ = side_flush(s, st)) != KMG_OK) return rc_;
     // d_partials is scratch here: the sums of this repeat pass and, behind them, the stage counters
     unsigned long long *d_stage = reinterpret_cast<unsigned long long *>(s->d_partials) + 4ull * s->k;
-    HIP_TRY(hipMemsetAsync(s->d_partials, 0, sizeof(int64_t) * (4ull * s->k + 6ull), st));
+    HIP_TRY(hipMemsetAsync(s->d_partials, 0, sizeof(int64_t) * (4ull * s->k + 8ull), st));
     HIP_TRY(launch_cube(t.d_hist, t.d_agg, t.d_sub_agg, t.d_occ, t.d_work, s->p->d_bounds, s->p->d_sub_bounds, s->d_cent, s->k,
-                        s->p->d_lab_table, t.d_masks, t.d_cell_work, t.d_colour_labels, t.d_sub, s->d_partials, 1u, 1u, d_stage, st,
+                        s->p->d_lab_table, t.d_masks, t.d_cell_work, t.d_colour_labels, t.d_sub, s->d_partials, 1u, 1u | (t.n_hot ? kCubeNoPrune : 0u), d_stage, st,
                         nullptr, affine_for(s->p, s->k, st)));
     t.entries_valid = true;
-    if (stage) HIP_TRY(hipMemcpyAsync(stage, d_stage, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    if (stage) HIP_TRY(hipMemcpyAsync(stage, d_stage, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return KMG_OK;
 }
@@ -459,7 +460,7 @@ static int table_assign(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_
         PROF_LAUNCH(s, KMG_K_CUBE, st, launch_cube(t.d_hist, t.d_agg, t.d_sub_agg, t.d_occ, t.d_work_share ? t.d_work_share : t.d_work,
                                                    s->p->d_bounds, s->p->d_sub_bounds,
                                                    s->d_cent, s->k, s->p->d_lab_table, t.d_masks, t.d_cell_work, t.d_colour_labels, t.d_sub,
-                                                   s->d_acc_int, 1u, defer_entries ? kCubeNoEntries : 0u, nullptr, st,
+                                                   s->d_acc_int, 1u, (defer_entries ? kCubeNoEntries : 0u) | (t.n_hot ? kCubeNoPrune : 0u), nullptr, st,
                                                    tail_on_labels ? nullptr : &tail, affine_for(s->p, s->k, st)));
         t.entries_valid = !defer_entries;
         if (tail_on_labels) {
@@ -476,7 +477,7 @@ static int table_assign(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_
         HIP_TRY(hipMemsetAsync(d_sums, 0, sizeof(int64_t) * 4ull * s->k * rows, st));
         PROF_LAUNCH(s, KMG_K_CUBE, st, launch_cube(t.d_hist, t.d_agg, t.d_sub_agg, t.d_occ, t.d_work, s->p->d_bounds, s->p->d_sub_bounds,
                                                    s->d_cent, s->k, s->p->d_lab_table, t.d_masks, t.d_cell_work, t.d_colour_labels, t.d_sub,
-                                                   d_sums, rows, 0u, nullptr, st, nullptr, affine_for(s->p, s->k, st)));
+                                                   d_sums, rows, t.n_hot ? kCubeNoPrune : 0u, nullptr, st, nullptr, affine_for(s->p, s->k, st)));
         t.entries_valid = true;
     }
     // (a share's pass leaves the tables current for ITS cells only: kmg_lloyd_labels refuses them, _labels_from_tables -- after
@@ -1057,7 +1058,7 @@ extern "C" int kmg_lloyd_iterate(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n
         HIP_TRY(hipMemsetAsync(d_acc4, 0, sizeof(int64_t) * 4ull * s->k, st));
         PROF_LAUNCH(s, KMG_K_CUBE, st, launch_cube(t.d_hist, t.d_agg, t.d_sub_agg, t.d_occ, t.d_work, s->p->d_bounds, s->p->d_sub_bounds,
                                                    s->d_cent, s->k, s->p->d_lab_table, t.d_masks, t.d_cell_work, t.d_colour_labels, t.d_sub,
-                                                   d_acc4, 1u, 0u, nullptr, st, nullptr, affine_for(s->p, s->k, st)));
+                                                   d_acc4, 1u, t.n_hot ? kCubeNoPrune : 0u, nullptr, st, nullptr, affine_for(s->p, s->k, st)));
         return KMG_OK;
     };
     if ((rc = issue()) != KMG_OK) {

@@ -183,12 +183,19 @@ hipError_t launch_init_pass_cells(const uint32_t *tie, const uint8_t *occ_bits, 
 // per row, zero on entry; n_rows = 1: the final sums).  hist == NULL: output pass of replace mode -- every
 // colour of every cell is labelled, nothing is accumulated (agg, sub_agg, occ_bits, work, sums unused).
 // flags bit 0: also write the per-colour labels of single-candidate cells (the label passes never read them).
-// stats (optional, 6 x u64, zero on entry): single-candidate cells, other cells, sub-cells decided by their
-// bounds, sub-cells scanned, candidates summed over the scanned sub-cells, cells beyond the listing limit.
+// stats (optional, 8 x u64, zero on entry): single-candidate cells, other cells, sub-cells decided by their
+// bounds, sub-cells scanned, candidates summed over the scanned sub-cells, cells beyond the listing limit, candidates the
+// dominance phase removed, scanned sub-cells it left with one candidate.
 size_t cube_work_bytes();
 // flags bit 16: the pass leaves the cells' pair entries / summaries (what the LABEL pass reads first) to a later
 // launch_cube_entries -- a loop that only needs the sums (kmg_lloyd_run) pays for them once, after its last iteration
 constexpr uint32_t kCubeNoEntries = 0x10000u;
+// flags bit 18 (callers): no dominance phase for this pass.  Set for a bound image with hot cells (a photograph): its scan
+// kernel waits for the few cells with long candidate lists, which the phase does not touch, so the phase only costs
+// (measured: +12 us per pass on the test photograph, -8 us on noise; profiles/NOTES.md round 5).
+constexpr uint32_t kCubeNoPrune = 0x40000u;
+constexpr uint32_t kCubePruned = 0x20000u;   // (set by launch_cube itself: k_cube_prune has run between the stage and the scan)
+bool cube_prune_wanted(uint32_t k);          // the general pass makes the dominance test: launch_cube wants sub_affine for this k
 constexpr uint32_t kCubeSmallMaxK = 32;      // k up to which the cube pass is the one-launch k_cube_small
 hipError_t launch_cube_entries(const uint32_t *work, const uint8_t *occ_bits, const void *colour_labels, uint16_t *sub_table,
                                uint32_t k, hipStream_t st);

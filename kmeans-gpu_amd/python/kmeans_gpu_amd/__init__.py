@@ -594,11 +594,12 @@ class Lloyd:
         return int(out[0]), int(out[1]), int(out[2])
 
     def debug_table_stats(self, stream=0):
-        out = (C.c_uint64 * 12)()
+        out = (C.c_uint64 * 14)()
         _check(lib().kmg_debug_table_stats(self._h, out, C.c_void_p(stream)))
         names = ["occupied_cells", "candidates_total", "cells_one_candidate", "max_candidates",
                  "cells_one_label", "occupied_sub_cells", "sub_cells_one_label", "distinct_colours",
-                 "sub_cells_decided", "sub_cells_scanned", "scan_candidates", "cells_unlisted"]
+                 "sub_cells_decided", "sub_cells_scanned", "scan_candidates", "cells_unlisted",
+                 "candidates_pruned", "sub_cells_pruned_to_one"]
         return dict(zip(names, (int(v) for v in out)))
 
     def debug_check_pairs(self, stream=0):

@@ -39,6 +39,9 @@ def _centroid_sets(oracle, rng):
     sets["far"] = np.array([[5000, 0, 0], [50, 2000, -2000], [1e6, 1e6, 1e6], [50, 0, 0], [60, 10, 10]], np.float32)
     sets["edge1024"] = np.array([[1000, 1000, -1000], [50, 5, 5], [52, 5, 5], [-1000, -1000, 1000], [50, 1023, 0],
                                  [51, -3, 4], [1023, 0, 0]], np.float32)
+    # the same two for the general pass (k > 32), whose dominance test is a phase of its own (k_cube_prune)
+    sets["far64"] = np.concatenate([lab[:59], sets["far"]])
+    sets["edge64"] = np.concatenate([lab[:57], sets["edge1024"]])
     sets["k512"] = oracle.rgb_to_lab(rng.integers(0, 256, (512, 4), dtype=np.uint8))                                   # two byte lists per cell
     sets["crowded_high"] = np.concatenate([lab[:260], (lab[9] + rng.normal(0, 0.3, (90, 3))).astype(np.float32)])        # > 63 in the second
     sets["crowded100"] = np.concatenate([(lab[7] + rng.normal(0, 0.3, (100, 3))).astype(np.float32), lab[100:256]])   # > 63 candidates
@@ -109,10 +112,11 @@ def test_table_pass_equals_pixel_scan(torch_cuda, processor, oracle, tokyo, kind
     assert np.array_equal(table[0][0].view(np.uint32), wl) and np.array_equal(table[0][1], wa)
 
 
-@pytest.mark.parametrize("name", ["far", "edge1024", "outside", "duplicates"])
+@pytest.mark.parametrize("name", ["far", "edge1024", "outside", "duplicates", "far64", "edge64"])
 def test_table_pass_with_centroids_far_outside_the_gamut(torch_cuda, processor, oracle, name):
-    """small tables (the one-launch cube pass with its dominance test) with centroids no image produces: labels and sums of
-    the table pass == the per-pixel scan == the oracle (find_centroid.wgsl:29-41: first minimum, strict <)"""
+    """tables (the one-launch cube pass of k <= 32 with its dominance test; k = 64: the dominance phase of the general pass) with
+    centroids no image produces: labels and sums of the table pass == the per-pixel scan == the oracle
+    (find_centroid.wgsl:29-41: first minimum, strict <)"""
     import kmeans_gpu_amd as kg
     torch = torch_cuda
     cent = _centroid_sets(oracle, np.random.default_rng(11))[name]
@@ -1222,3 +1226,37 @@ def test_cell_share_refuses_what_it_cannot_answer(torch_cuda, oracle, monkeypatc
     assert np.array_equal(labels.cpu().numpy().view(np.uint32), want_l) and np.array_equal(acc.cpu().numpy(), want_a)
     s.close()
     p.close()
+
+
+def test_dominance_phase_runs_on_spread_images_only(torch_cuda, processor, oracle):
+    """32 < k <= 256: the cube pass of an image WITHOUT hot cells (noise) takes the dominance phase (k_cube_prune) -- it removes
+    candidates, decides sub-cells, and the tables stay exactly right (exhaustive check, pair entries, labels and sums against the
+    oracle); an image with hot cells (flat areas: the photograph case) skips it"""
+    import kmeans_gpu_amd as kg
+    torch = torch_cuda
+    st = _stream(torch)
+    k, n = 200, 1_500_000
+    for kind in ("uniform", "hot"):
+        rgba = oracle.synth_uniform(777, n)
+        if kind == "hot":
+            rgba[: n // 2, :3] = (rgba[: n // 2, :3] & 3) + 40       # half of the pixels in one cell
+        cent = oracle.centroids4(oracle.rgb_to_lab(rgba[n // 2::(n // 2) // k][:k]))
+        wl, wa = oracle.assign_accumulate_rgba(rgba, cent)
+        d = _dev(torch, rgba)
+        s = kg.Lloyd(processor, k)
+        s.set_centroids(cent)
+        s.bind_image(d.data_ptr(), n, st)
+        labels = torch.zeros(n, dtype=torch.int32, device="cuda")
+        acc = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
+        s.assign_accumulate(d.data_ptr(), n, labels.data_ptr(), acc.data_ptr(), st)
+        torch.cuda.synchronize()
+        assert np.array_equal(labels.cpu().numpy().view(np.uint32), wl), kind
+        assert np.array_equal(acc.cpu().numpy(), wa), kind
+        stats = s.debug_table_stats(st)
+        assert s.debug_check_pairs(st)[0] == 0
+        assert s.debug_check_table(st) == (0, 0, 0)
+        if kind == "uniform":
+            assert stats["candidates_pruned"] > 0 and stats["sub_cells_pruned_to_one"] > 0, stats
+        else:
+            assert stats["candidates_pruned"] == 0 and stats["sub_cells_pruned_to_one"] == 0, stats
+        s.close()
