@@ -1276,7 +1276,8 @@ __global__ __launch_bounds__(kBlock) void k_cube_pairs(const uint32_t *__restric
         const uint32_t cell = cells ? __builtin_amdgcn_readfirstlane(cells[wi]) : wi;
         if (sizeof(LabelT) == 1) {
             uint32_t *pair_entry_ptr = reinterpret_cast<uint32_t *>(sub_table + kSubCells + kCells) + cell;
-            if (__builtin_amdgcn_readfirstlane(*pair_entry_ptr) != kPairPending) continue;
+            // (a cell of k_cube_prune's list is pending by construction: no flag to wait for before its labels are requested)
+            if (!from_list && __builtin_amdgcn_readfirstlane(*pair_entry_ptr) != kPairPending) continue;
             const uint2 lv = *reinterpret_cast<const uint2 *>(colour_labels + (uint64_t)cell * kCellColours + lane * 8u);
             const uint32_t occ = occ_bits ? (uint32_t)occ_bits[(uint64_t)cell * 64u + lane] : 0xFFu;
             uint32_t idx[8];
