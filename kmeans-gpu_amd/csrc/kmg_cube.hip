@@ -1,29 +1,37 @@
 // kmg_cube.hip -- the per-iteration pass of the colour-table strategy over the colour cube (kmg_table.h), in
-// three launches of one wave per 8x8x8 colour cell each.  Every one of them is a chain of dependent steps per
-// wave, so what they need is many resident waves: split this way each keeps few registers.
+// three or four launches.  Every one of them is a chain of dependent steps per wave, so what they need is many
+// resident waves: split this way each keeps few registers.
 //
-//   k_cube_stage  1. cell candidates -- lanes strided over the centroids: interval bounds [lo_j, hi_j] of the key
-//                    over the cell (static bounds, kmg_table_dev.h key_range), U = min_j hi_j, keep
-//                    lo_j <= U (1 + slack).  One candidate -> the whole cell belongs to it: sums from the
+//   k_cube_stage  1. cell candidates (one wave per 8x8x8 cell) -- lanes strided over the centroids: interval bounds
+//                    [lo_j, hi_j] of the key over the cell (static bounds, kmg_table_dev.h key_range), U = min_j hi_j,
+//                    keep lo_j <= U (1 + slack).  One candidate -> the whole cell belongs to it: sums from the
 //                    per-cell table of the image, one pair entry, NO per-colour traffic at all.
 //                 2. sub-cell stage -- the (<= 32) candidates are listed; lane (s, c) bounds candidate c over the
 //                    4x4x4 sub-cell s with the sub-cell's own static bounds; per sub-cell the same U / lo test.
 //                    One candidate -> the sub-cell belongs to it: sums from the per-sub-cell table, 64 labels.
 //                    What is left goes into the cell's work record (candidate list, per-sub-cell sets).
+//   k_cube_prune  2b. (32 < k <= 256, images without hot cells) the dominance test per sub-cell -- a candidate that
+//                    another one beats on EVERY colour of the sub-cell (an affine model of the key difference with exact
+//                    residual ranges) leaves its set; sub-cells left with one candidate are decided, cells with one
+//                    label get their pair entry; what remains leaves as compact ITEMS (two sub-cells + their candidates,
+//                    16 bytes) for the scan and a list of cells for the entries.
 //   k_cube_scan   3. undecided sub-cells, two per step, ONE colour of each per lane: (L, a, b, C) and the count
 //                    are fully coalesced 1 KiB + 256 B loads per sub-cell; the colour scans the candidates of the
 //                    two sub-cells in index order (a centroid outside a sub-cell's own set is provably neither its
-//                    arg-min nor a near-tie, so visiting it changes nothing).
-//   k_cube_pairs  4. (k <= 256) the pair entry of every cell with more than one candidate, from its 512
+//                    arg-min nor a near-tie, so visiting it changes nothing).  From items (one wave per item) after
+//                    k_cube_prune, from the cells' work records otherwise.
+//   k_cube_pairs  4. (k <= 256) the pair entry of every cell with more than one label, from its 512
 //                    per-colour labels and the image's occupancy bits; (k > 256) the cell summary.
 // Exactness: bounds are float-monotone interval evaluations of the very operations of cie94_key, so the
-// arg-min of every colour (and everything within the near-tie threshold of it) survives both prunings; sums are
-// integers.  tests/test_gpu_table.py compares every label / sum with the per-pixel scan and the oracle.
+// arg-min of every colour (and everything within the near-tie threshold of it) survives both prunings; the dominance
+// test charges its own rounding explicitly (`dominated`); sums are integers.  tests/test_gpu_table.py compares every
+// label / sum with the per-pixel scan and the oracle, and all 2^24 colours with the brute-force arg-min.
 // Compile with -ffp-contract=off.
 
 #include "kmg_internal.h"
 #include "kmg_table_dev.h"
 
+#include <hip/hip_fp16.h>
 #include <stdlib.h>
 
 namespace kmg {
@@ -303,11 +311,33 @@ __device__ __forceinline__ uint2 long_list_stage(const float4 *s_cent, const uns
 }
 
 
-constexpr uint32_t kAffineFloats = 48;                            // per sub-cell: 7 features x (alpha, 3 beta, Rmin, Rmax) = 42, then
-                                                                  // [42] = C1, [43] = wH1 of the sub-cell's bounds, 4 of padding
+constexpr uint32_t kAffineFloats = 24;                            // per sub-cell, in 32-bit words: 7 features x (alpha, 3 beta, Rmin, Rmax) as
+                                                                  // 42 binary16 values (words 0 .. 20), [21] = C1, [22] = wH1 of the
+                                                                  // sub-cell's bounds (binary32), one word of padding: 96 bytes
+// A sub-cell's model as the test reads it: element i < 42 = the binary16 value i widened (exact), [42] = C1, [43] = wH1.
+// Binary16 costs the test nothing: the residual ranges are taken against the STORED (rounded) model and rounded outward
+// (k_sub_affine), so any stored model is a valid one; what the coarser coefficients lose in fit is ~2^-11 of the residuals.
+struct HalfModel {
+    uint32_t q[kAffineFloats];
+    __device__ __forceinline__ float operator[](int i) const
+    {
+        if (i >= 42) return bits_to_float(q[21 + (i - 42)]);
+        const uint32_t h = (i & 1) ? q[i >> 1] >> 16 : q[i >> 1] & 0xFFFFu;
+        return __half2float(__ushort_as_half((unsigned short)h));
+    }
+    __device__ __forceinline__ void load(const float *table, uint64_t sub_cell)
+    {
+        const uint4 *mp = reinterpret_cast<const uint4 *>(table + sub_cell * kAffineFloats);
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            const uint4 v = mp[t];
+            q[4 * t] = v.x; q[4 * t + 1] = v.y; q[4 * t + 2] = v.z; q[4 * t + 3] = v.w;
+        }
+    }
+};
 
 // The dominance test (see k_cube_small's header for the derivation): true when, for every colour of the sub-cell whose model
-// is at `mdl` (kAffineFloats floats, LDS or registers), K_j - K_i >= 2^-11 U, U >= the float upper bound of key_i over the
+// is `mdl` (HalfModel), K_j - K_i >= 2^-11 U, U >= the float upper bound of key_i over the
 // sub-cell.  Binary32 throughout: the lower bound is accumulated together with `mag`, the sum of the magnitudes of everything
 // that enters it; the evaluation performs fewer than 40 roundings, each relative to a partial sum <= mag, and the inputs' own
 // errors -- differences of squares (w2, c0), N = a^2 + b^2 - C^2 -- are bounded by 3u times sums of squares that mag holds as
@@ -670,8 +700,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
 // k_cube_prune (32 < k <= 256, between k_cube_stage and k_cube_scan): the DOMINANCE test of k_cube_small's header for the
 // listed cells of the general pass, as a phase of its own, and the compact work of the two launches that follow.
 // A workgroup takes kPruneCells cells of the work list, one sub-cell per thread:
-//   1. every (sub-cell to scan, candidate other than the one with the smallest upper bound) goes into ONE compact list in
-//      LDS, one test per lane; a candidate another candidate beats on every colour of the sub-cell leaves the sub-cell's set
+//   1. a sub-cell to scan requests its affine model (96 B) with the cell's record and leaves it in LDS; every (sub-cell to
+//      scan, candidate other than the one with the smallest upper bound) goes into ONE compact list in LDS, one test per lane; a candidate another candidate beats on every colour of the sub-cell leaves the sub-cell's set
 //      (exact: what the test removes is neither the arg-min nor within the tie threshold of it for any colour of the
 //      sub-cell -- `dominated`; a list that overflows drops tests, i.e. keeps candidates);
 //   2. a sub-cell left with ONE candidate is decided here as the stage kernel decides its own: 64 labels, the sums of the
@@ -698,10 +728,13 @@ __global__ __launch_bounds__(kBlock) void k_cube_prune(const uint32_t *__restric
     __shared__ uint32_t s_mask[kBlock];                            // [sub-cell]: candidates (list positions)
     __shared__ uint32_t s_ref[kBlock];                             // [sub-cell]: upper bound (16 high bits) | position of the reference candidate
     __shared__ uint16_t s_list[kPruneCells * kMaxListed];          // [cell][position]: centroid
-    __shared__ uint32_t s_cell[kPruneCells];
     __shared__ uint16_t s_test[kPruneTests];                       // (sub-cell << 5) | position
     __shared__ uint32_t s_count;                                   // tests
-    extern __shared__ unsigned long long bins[];                   // k x 4 u64 (SUMS): sums of the sub-cells decided here
+    // the models of the workgroup's sub-cells (each thread requests its own with the cell's record, the tests read them from
+    // here: no second round trip to memory); after the tests the same bytes are the bins (k x 4 u64) of the sub-cells decided here
+    constexpr uint32_t kModelStride = 28;                          // words per model in LDS (16-byte rows, 8 start banks)
+    __shared__ uint4 s_model4[kBlock * kModelStride / 4];
+    unsigned long long *bins = reinterpret_cast<unsigned long long *>(s_model4);
     const uint32_t vz = opaque_vgpr_zero();
     const uint32_t n_work_v = SUMS ? work[vz] : kCells;
     const uint32_t far_v = lists[kListFar + vz];
@@ -709,8 +742,6 @@ __global__ __launch_bounds__(kBlock) void k_cube_prune(const uint32_t *__restric
     // (the first batch's cells are requested with the list's length, not after it: entries beyond it are readable)
     const uint32_t cell_first = SUMS ? work[1u + blockIdx.x * kPruneCells + slot] : blockIdx.x * kPruneCells + slot;
     if (threadIdx.x == 0u) s_count = 0u;
-    // (straight global atomics instead of LDS bins were measured: 420 K of them per pass, the kernel 25 -> 137 us)
-    if (SUMS) for (uint32_t i = threadIdx.x; i < 4u * k; i += kBlock) bins[i] = 0ull;
     __syncthreads();
     const uint32_t n_work = __builtin_amdgcn_readfirstlane(n_work_v);
     const bool dominance = sub_affine != nullptr && __builtin_amdgcn_readfirstlane(far_v) == 0u && !KMG_KNOCK(flags, 0x200000u);
@@ -741,9 +772,14 @@ __global__ __launch_bounds__(kBlock) void k_cube_prune(const uint32_t *__restric
                 const longlong2 *sp = reinterpret_cast<const longlong2 *>(sub_agg + ((uint64_t)cell * 8u + sub) * 4u);
                 g01 = sp[0]; g23 = sp[1];
             }
+            if (mine && dominance) {
+                const uint4 *mp = reinterpret_cast<const uint4 *>(sub_affine + ((uint64_t)cell * 8u + sub) * kAffineFloats);
+                uint4 *dst = s_model4 + threadIdx.x * (kModelStride / 4u);
+#pragma unroll
+                for (int t = 0; t < 6; ++t) dst[t] = mp[t];
+            }
         }
         s_mask[threadIdx.x] = sm;
-        if (sub == 0u) s_cell[slot] = cell;
         const uint32_t others = (mine && dominance) ? sm & ~(1u << istar) : 0u;
         if (others) {
             s_ref[threadIdx.x] = (u16 << 16) | istar;
@@ -756,19 +792,22 @@ __global__ __launch_bounds__(kBlock) void k_cube_prune(const uint32_t *__restric
         const uint32_t n_tests = min(s_count, kPruneTests);
         for (uint32_t t = threadIdx.x; t < n_tests; t += kBlock) {
             const uint32_t e = (uint32_t)s_test[t] >> 5, pos = (uint32_t)s_test[t] & 31u;
-            const uint32_t tsc = s_cell[e >> 3] * 8u + (e & 7u);
-            const float4 *mp = reinterpret_cast<const float4 *>(sub_affine + (uint64_t)tsc * kAffineFloats);
             const uint32_t r = s_ref[e];
+            // (the centroids from memory: a copy in LDS is 4 KiB more per workgroup -- three instead of four per CU, 22.5 -> 25 us)
             const Centroid cj = cent[s_list[(e >> 3) * kMaxListed + pos]], ci = cent[s_list[(e >> 3) * kMaxListed + (r & 31u)]];
-            float mdl[44];
+            HalfModel mdl;
 #pragma unroll
-            for (int q = 0; q < 11; ++q) {
-                const float4 v = mp[q];
-                mdl[4 * q] = v.x; mdl[4 * q + 1] = v.y; mdl[4 * q + 2] = v.z; mdl[4 * q + 3] = v.w;
+            for (int q = 0; q < 6; ++q) {
+                const uint4 v = s_model4[e * (kModelStride / 4u) + q];
+                mdl.q[4 * q] = v.x; mdl.q[4 * q + 1] = v.y; mdl.q[4 * q + 2] = v.z; mdl.q[4 * q + 3] = v.w;
             }
             if (dominated(mdl, make_float4(cj.L, cj.a, cj.b, cj.C), make_float4(ci.L, ci.a, ci.b, ci.C), bits_to_float(r & 0xFFFF0000u)))
                 atomicAnd(&s_mask[e], ~(1u << pos));
         }
+        __syncthreads();
+        // (the models have been read: their bytes become the bins -- straight global atomics instead of LDS bins were measured:
+        // 420 K of them per pass, the kernel 25 -> 137 us)
+        if (SUMS) for (uint32_t i = threadIdx.x; i < 4u * k; i += kBlock) bins[i] = 0ull;
         __syncthreads();
         // ---- what is left of every sub-cell's set ----
         const uint32_t nm = s_mask[threadIdx.x];
@@ -1375,8 +1414,9 @@ __global__ __launch_bounds__(kBlock) void k_sub_affine(const float4 *__restrict_
     double rmin[7], rmax[7];
 #pragma unroll
     for (int m = 0; m < 7; ++m) {
-        // least squares on the regular grid: sum (x - 1.5)^2 over the 64 colours = 80
-        al[m] = (float)(S0[m] / 64.0); bx[m] = (float)(Sx[m] / 80.0); by[m] = (float)(Sy[m] / 80.0); bz[m] = (float)(Sz[m] / 80.0);
+        // least squares on the regular grid: sum (x - 1.5)^2 over the 64 colours = 80; then to binary16, the precision it is stored in
+        al[m] = __half2float(__float2half_rn((float)(S0[m] / 64.0))); bx[m] = __half2float(__float2half_rn((float)(Sx[m] / 80.0)));
+        by[m] = __half2float(__float2half_rn((float)(Sy[m] / 80.0))); bz[m] = __half2float(__float2half_rn((float)(Sz[m] / 80.0)));
         rmin[m] = 1.0e300; rmax[m] = -1.0e300;
     }
     // residuals against the ROUNDED model (the one the test uses)
@@ -1390,22 +1430,25 @@ __global__ __launch_bounds__(kBlock) void k_sub_affine(const float4 *__restrict_
             rmin[m] = fmin(rmin[m], r); rmax[m] = fmax(rmax[m], r);
         }
     }
-    float *out = affine + (uint64_t)sc * kAffineFloats;
+    uint32_t *out = reinterpret_cast<uint32_t *>(affine) + (uint64_t)sc * kAffineFloats;
+    unsigned short h[42];
 #pragma unroll
     for (int m = 0; m < 7; ++m) {
-        // outward: the binary64 evaluation above is off by < 1e-15 of the terms; then one directed rounding to binary32
+        // outward: the binary64 evaluation above is off by < 1e-15 of the terms; then directed roundings to binary32 and on to binary16
         const double pad = 1.0e-12 * (fabs((double)al[m]) + 1.5 * (fabs((double)bx[m]) + fabs((double)by[m]) + fabs((double)bz[m])) + 1.0);
         const double lo = rmin[m] - pad, hi = rmax[m] + pad;
         float flo = (float)lo, fhi = (float)hi;
         if ((double)flo > lo) flo = nextafterf(flo, -3.0e38f);
         if ((double)fhi < hi) fhi = nextafterf(fhi, 3.0e38f);
-        out[6 * m + 0] = al[m]; out[6 * m + 1] = bx[m]; out[6 * m + 2] = by[m]; out[6 * m + 3] = bz[m];
-        out[6 * m + 4] = flo; out[6 * m + 5] = fhi;
+        h[6 * m + 0] = __half_as_ushort(__float2half_rn(al[m])); h[6 * m + 1] = __half_as_ushort(__float2half_rn(bx[m]));
+        h[6 * m + 2] = __half_as_ushort(__float2half_rn(by[m])); h[6 * m + 3] = __half_as_ushort(__float2half_rn(bz[m]));
+        h[6 * m + 4] = __half_as_ushort(__float2half_rd(flo)); h[6 * m + 5] = __half_as_ushort(__float2half_ru(fhi));
     }
-    out[42] = sub_bounds[sc].C1;                                   // what the clamp correction of the test needs
-    out[43] = sub_bounds[sc].wH1;
 #pragma unroll
-    for (int m = 44; m < (int)kAffineFloats; ++m) out[m] = 0.0f;
+    for (int w = 0; w < 21; ++w) out[w] = (uint32_t)h[2 * w] | ((uint32_t)h[2 * w + 1] << 16);
+    out[21] = float_to_bits(sub_bounds[sc].C1);                    // what the clamp correction of the test needs
+    out[22] = float_to_bits(sub_bounds[sc].wH1);
+    out[23] = 0u;
 }
 
 size_t sub_affine_bytes() { return sizeof(float) * (size_t)kAffineFloats * kSubCells; }
@@ -1555,13 +1598,8 @@ __global__ __launch_bounds__(kSmallBlock) __attribute__((amdgpu_waves_per_eu(4, 
             for (uint32_t t = threadIdx.x; t < n_tests; t += kSmallBlock) {
                 const uint32_t e = (uint32_t)s_test[t] >> 5, j = (uint32_t)s_test[t] & 31u;
                 const uint32_t tsc = s_cell[e >> 3] * 8u + (e & 7u);
-                const float4 *mp = reinterpret_cast<const float4 *>(sub_affine + (uint64_t)tsc * kAffineFloats);
-                float mdl[44];
-#pragma unroll
-                for (int q = 0; q < 11; ++q) {
-                    const float4 v = mp[q];
-                    mdl[4 * q] = v.x; mdl[4 * q + 1] = v.y; mdl[4 * q + 2] = v.z; mdl[4 * q + 3] = v.w;
-                }
+                HalfModel mdl;
+                mdl.load(sub_affine, tsc);
                 if (dominated(mdl, s_cent[j], s_cent[s_istar[e]], s_U[e])) atomicAnd(&s_mask[e], ~(1u << j));
             }
             __syncthreads();
@@ -1946,13 +1984,12 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
     // (the scan over items: one round of resident workgroups, each wave a few items with the next one's colours in flight)
     static const uint32_t g_items = env_grid("KMG_ITEMS_GRID", 1792u) & ~15u;
     const uint32_t *lists = reinterpret_cast<const uint32_t *>(cw + kCells);
-    const size_t lds_prune = with_sums ? sizeof(unsigned long long) * 4ull * k : 0;
 #define KMG_CUBE(T, S)                                                                                                      \
     do {                                                                                                                    \
         hipLaunchKernelGGL((k_cube_stage<T, S>), dim3(g_stage), dim3(kBlock), lds_stage, st, agg, sub_agg, work, bounds,    \
                            sub_bounds, cent, k, masks, cw, (T *)colour_labels, sub_table, sums, n_rows, flags, stats);      \
         if (prune)                                                                                                          \
-            hipLaunchKernelGGL((k_cube_prune<S>), dim3(g_prune), dim3(kBlock), lds_prune, st, work, sub_agg, cent, k,       \
+            hipLaunchKernelGGL((k_cube_prune<S>), dim3(g_prune), dim3(kBlock), 0, st, work, sub_agg, cent, k,               \
                                sub_affine, cw, (uint8_t *)colour_labels, sub_table, const_cast<uint32_t *>(lists), sums,    \
                                n_rows, flags, stats);                                                                       \
         if (!KMG_KNOCK(flags, 0xC00u))                                                                                      \

@@ -83,7 +83,7 @@ int ensure_bounds(kmg_processor *p, hipStream_t st)
     return KMG_OK;
 }
 
-// The dominance test's table (kmg_table.h), image independent, for passes with k <= 32: built once, after ensure_bounds.
+// The dominance test's table (kmg_table.h), image independent, for passes with k <= 256: built once, after ensure_bounds.
 // NULL when it cannot be had -- the pass is exact without it, only slower.
 const float *affine_for(kmg_processor *p, uint32_t k, hipStream_t st)
 {

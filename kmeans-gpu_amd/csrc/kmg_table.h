@@ -175,10 +175,10 @@ hipError_t launch_init_records(const uint32_t *work, const CellBounds *bounds, v
 hipError_t launch_init_pass_cells(const uint32_t *tie, const uint8_t *occ_bits, const float4 *lab_table, Centroid *cent,
                                   uint32_t j, int do_pass, float *dist, void *init_scratch, unsigned long long *band_key,
                                   const uint32_t *pick_rgba, const float *lut, hipStream_t st);
-// per iteration (kmg_cube.hip): candidates + sub-cell stage, colour scan, pair entries -- three launches.
+// per iteration (kmg_cube.hip): candidates + sub-cell stage, (dominance phase,) colour scan, pair entries -- three or four launches.
 // work: [0] = number of occupied cells of the bound image, [1..] = their indices (built at bind time).
 // masks: the cell candidate masks, mask_words(k) u64 per cell; cell_work: cube_work_bytes() of scratch (the
-// stage kernel's records for the scan kernel).
+// stage kernel's records for the scan kernel and, behind them, the items / lists of k_cube_prune).
 // Every workgroup adds the sums of the clusters it met into row (workgroup % n_rows) of `sums` (k x 4 int64
 // per row, zero on entry; n_rows = 1: the final sums).  hist == NULL: output pass of replace mode -- every
 // colour of every cell is labelled, nothing is accumulated (agg, sub_agg, occ_bits, work, sums unused).
@@ -214,10 +214,11 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
                        uint32_t k, const float4 *lab_table, uint64_t *masks, void *cell_work, void *colour_labels,
                        uint16_t *sub_table, int64_t *sums, uint32_t n_rows, uint32_t flags, unsigned long long *stats,
                        hipStream_t st, const CubeTail *tail = nullptr, const float *sub_affine = nullptr);
-// k <= 32 takes the pass in ONE launch (k_cube_small, kmg_cube.hip).  sub_affine (optional, once per processor,
-// sub_affine_bytes() of them, image independent): per sub-cell affine models of the seven per-colour features the difference
-// of two keys is linear in, with exact residual ranges -- the dominance test that removes, from a sub-cell's candidates, those
-// another candidate beats on every colour of the sub-cell (3x fewer scanned sub-cells at k = 16).
+// k <= 32 takes the pass in ONE launch (k_cube_small, kmg_cube.hip); 32 < k <= 256 in four (k_cube_prune between the stage and
+// the scan, unless kCubeNoPrune).  sub_affine (optional, once per processor, sub_affine_bytes() = 24 MiB, image independent):
+// per sub-cell affine models (binary16) of the seven per-colour features the difference of two keys is linear in, with exact
+// residual ranges -- the dominance test that removes, from a sub-cell's candidates, those another candidate beats on every
+// colour of the sub-cell (3x fewer scanned sub-cells at k = 16, 2.3x fewer at k = 256).
 size_t sub_affine_bytes();
 hipError_t launch_sub_affine(const float4 *lab_table, const CellBounds *sub_bounds, float *affine, hipStream_t st);
 // pal == NULL: labels[i] = label; pal != NULL: labels[i] = pal[label] (RGBA8 output of replace mode).
