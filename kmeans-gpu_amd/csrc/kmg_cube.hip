@@ -241,6 +241,10 @@ constexpr uint32_t kListSegs = 64, kListSegCap = kCells / kListSegs, kItemSegCap
 constexpr uint32_t kListFar = 2 * kListSegs, kListsHead = 2 * kListSegs + 64;
 constexpr uint32_t kListItems = kListsHead, kListWhole = kListItems + 4u * kListSegs * kItemSegCap, kListEntries = kListWhole + kCells;
 constexpr size_t kListsWords = kListEntries + kCells;
+// Without k_cube_prune (images with hot cells): the cells with LONG candidate lists -- a photograph's few hundred heavy cells, each
+// minutes of a wave's time compared with the others -- are listed by the stage kernel (kLongSegs counters behind kListFar, the cells in
+// the `whole` region, kLongSegCap per segment) and scanned first, a PAIR of sub-cells per wave instead of the whole cell.
+constexpr uint32_t kLongSegs = 16, kLongSegCap = kCells / kLongSegs, kLongCount = kListFar + 1;
 
 // LDS bins: repl copies of k x 4 u64, consecutive copies 32 B further along the bank row
 __device__ __forceinline__ void flush_bins(const unsigned long long *bins, uint32_t k, uint32_t repl, uint32_t bin_stride,
@@ -685,6 +689,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
             cw->npop = npop;
             cw->scan_set = scan_set | (listed ? 0x100u : 0u) | (long_cell ? kLongFlag : 0u) | (decided_set << 16);
             if (sizeof(LabelT) == 1) *pair_entry_ptr = kPairPending;
+            if (long_cell && scan_set && (flags & kCubeSplitLong)) {
+                uint32_t *lists = reinterpret_cast<uint32_t *>(cell_work + kCells);
+                const uint32_t ls = wave & (kLongSegs - 1u);
+                lists[kListWhole + ls * kLongSegCap + atomicAdd(lists + kLongCount + ls, 1u)] = cell;
+            }
         }
     }
 #undef KMG_REQUEST_CELL
@@ -950,16 +959,49 @@ __global__ __launch_bounds__(kBlock) void k_cube_scan(const uint32_t *__restrict
     const uint32_t n_work = from_list ? n_whole : (SUMS ? __builtin_amdgcn_readfirstlane(work[0]) : kCells);
     const uint32_t *cells = from_list ? lists + kListWhole + seg * kListSegCap : (SUMS ? work + 1 : nullptr);
     const uint32_t wi_step = from_list ? n_waves / kListSegs : n_waves;
+    // kCubeSplitLong: the stage kernel's list of cells with long candidate lists comes first, FOUR waves per cell (a pair of its
+    // sub-cells each); the walk over the work list then skips those cells
+    const bool split_long = !from_list && (flags & kCubeSplitLong) != 0u;
+    uint32_t long_end = 0u, n_long4 = 0u;                           // lane s < kLongSegs: entries of the segments 0 .. s; 4 x all of them
+    if (split_long) {
+        long_end = lane < kLongSegs ? lists[kLongCount + lane] : 0u;
+        for (uint32_t off = 1; off < kLongSegs; off <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)long_end, off, 64);
+            if (lane >= off) long_end += up;
+        }
+        n_long4 = 4u * lane_value(long_end, kLongSegs - 1u);
+    }
     // (Requesting the NEXT cell's work record ahead -- one vector load, lane i = dword i -- was measured: the 8 registers
     // it holds cost a wave per SIMD, 73.6 -> 76.6 us.)
-    for (uint32_t wi = from_list ? wave / kListSegs : wave; wi < n_work; wi += wi_step) {
-        const uint32_t cell = cells ? __builtin_amdgcn_readfirstlane(cells[wi]) : wi;
+    const uint32_t wi_end = n_work + (from_list ? 0u : n_long4);
+    for (uint32_t wi = from_list ? wave / kListSegs : wave; wi < wi_end; wi += wi_step) {
+        uint32_t cell, quarter = 4u;                                // quarter < 4: only that pair of the cell's sub-cells to scan
+        if (wi < n_long4) {
+            const uint32_t e = wi >> 2;
+            const uint32_t ls = (uint32_t)__builtin_popcountll(__ballot(lane < kLongSegs && long_end <= e));
+            const uint32_t first = ls ? lane_value(long_end, ls - 1u) : 0u;
+            cell = __builtin_amdgcn_readfirstlane(lists[kListWhole + ls * kLongSegCap + (e - first)]);
+            quarter = wi & 3u;
+        } else {
+            const uint32_t wj = wi - n_long4;
+            cell = cells ? __builtin_amdgcn_readfirstlane(cells[wj]) : wj;
+        }
         const CellWork *cw = cell_work + cell;
         uint32_t scan_set = __builtin_amdgcn_readfirstlane(cw->scan_set);
         if ((scan_set & 0xFFu) == 0u) continue;                     // one candidate, or every sub-cell decided
         const bool listed = (scan_set & 0x100u) != 0u;
         const bool long_cell = (scan_set & kLongFlag) != 0u;
         scan_set &= 0xFFu;
+        if (quarter < 4u) {
+            uint32_t m = scan_set;
+            for (uint32_t t = 0; t < 2u * quarter; ++t) m &= m - 1u;
+            const uint32_t b0 = m & (0u - m);
+            m &= m - 1u;
+            scan_set = b0 | (m & (0u - m));
+            if (scan_set == 0u) continue;
+        } else if (split_long && long_cell) {
+            continue;                                               // (taken by four waves above)
+        }
         const uint32_t npop = __builtin_amdgcn_readfirstlane(cw->npop);
         const uint32_t my_cand = listed ? (uint32_t)cw->list[lane & (kMaxListed - 1u)] : 0u;   // lane p: the p-th candidate ...
         const unsigned long long br0 = listed ? uniform_u64(cw->br[0]) : 0ull, br1 = listed ? uniform_u64(cw->br[1]) : 0ull;
@@ -1980,6 +2022,13 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
     // 32 < k <= 256: the dominance phase and its compact lists between the stage and the scan (sub_affine == NULL: lists only)
     const bool prune = cube_prune_wanted(k) && !(flags & kCubeNoPrune) && !KMG_KNOCK(flags, 0x800u);
     if (prune) flags |= kCubePruned;
+    else if (k <= 256u && tools_env_int(KMG_TOOLS_ENV("KMG_SPLIT_LONG"), 1) != 0) {
+        // (the stage kernel's workgroups append to the list of long-list cells as they meet them: its counters are cleared ahead of
+        // the launch, not by one of its workgroups)
+        flags |= kCubeSplitLong;
+        hipError_t e = hipMemsetAsync(reinterpret_cast<uint32_t *>((CellWork *)cell_work + kCells) + kLongCount, 0, sizeof(uint32_t) * kLongSegs, st);
+        if (e != hipSuccess) return e;
+    }
     const uint32_t g_prune = kCells / kPruneCells;                 // (one batch of cells per workgroup)
     // (the scan over items: one round of resident workgroups, each wave a few items with the next one's colours in flight)
     static const uint32_t g_items = env_grid("KMG_ITEMS_GRID", 1792u) & ~15u;

@@ -33,7 +33,7 @@ static inline void *carve(void *base, size_t &off, size_t bytes)
 // Cost model (seconds per iteration on MI355X; constants fitted to tools/strategy_sweep.py, refitted in round 2 --
 // the cube pass got cheaper, the per-pixel scan tracks the runner-up key for the literal arg-min):
 //   per-pixel scan : 1.4e-5 + 3.3e-7 k + n * (6.8e-12 + 2.45e-13 k)     (the k term: partial-sum slab and its reduction)
-//   colour table   : 8.6e-5 + 1.85e-7 k                      cube pass (independent of n; k <= 32: 5.6e-5 + 2.0e-7 k, one launch)
+//   colour table   : 8.0e-5 + 8.5e-8 k                       cube pass (independent of n; k <= 32: 4.4e-5 + 3.5e-7 k, one launch; k > 256: 8.6e-5 + 2.3e-7 k)
 //                    + n * (1.8e-12 + 2.0e-15 k)              label pass, k <= 256 (6.7e-12 for u16 labels)
 //                    + bind_seconds(n) / 16                   one-off histogram + cell sums, spread over ~16 passes
 // one-off cost of binding an image: partitioned histogram (n >= 2^21) or one global atomic per pixel, + cell sums
@@ -51,11 +51,17 @@ static bool table_pays(uint64_t n, uint32_t k, bool labels)
     }
     const double N = (double)n;
     // (per-pixel scan: assign + reduce + update launches 11 us + 0.09 us per cluster, then 7.5 + 0.245 k ps per pixel --
-    // round 4, after k_assign's pixels per thread followed the image size: tools/strategy_sweep.py, profiles/r04_strategy_sweep.txt)
-    const double brute = 1.1e-5 + 9.3e-8 * k + N * (7.5e-12 + 2.45e-13 * k);
+    // round 4, after k_assign's pixels per thread followed the image size: tools/strategy_sweep.py, profiles/r04_strategy_sweep.txt.
+    // Those are NOISE images.  A photograph near the crossover runs the scan slower (crowded centroids: more near-tie repairs,
+    // +30 % at 1 Mpx, k = 256) and the table faster (fewer occupied cells; since round 5 its heavy cells are scanned by four
+    // waves each: -30 %), and the model cannot see the image: for k > 32 it leans towards the photograph -- the scan's estimate
+    // times 1.15, the cube pass between its two costs -- which costs a 1 Mpx noise image at k = 256 the wrong answer by 37 %
+    // (93 against 127 us) and nothing elsewhere on the grid of profiles/r05_strategy_sweep.txt.)
+    const double brute = (1.1e-5 + 9.3e-8 * k + N * (7.5e-12 + 2.45e-13 * k)) * (k > 32u ? 1.15 : 1.0);
     const double label_pass = labels ? N * (k <= 256 ? 1.8e-12 + 2.0e-15 * k : 6.7e-12) : 0.0;
-    // (k <= 32: the one-launch cube pass of small centroid tables, k_cube_small -- 58 us at k = 16, round 4)
-    const double cube = k <= 32u ? 5.6e-5 + 2.0e-7 * k : 8.6e-5 + 1.85e-7 * k;
+    // (cube pass on noise, round 5: k <= 32 one launch, 38 / 50 / 51 / 56 us at k = 4 / 8 / 16 / 32; 32 < k <= 256 with the
+    // dominance phase 95 / 100 / 111 us at k = 64 / 128 / 256 -- a photograph ~93 at k = 256; k = 512: 203)
+    const double cube = k <= 32u ? 4.4e-5 + 3.5e-7 * k : (k <= 256u ? 8.0e-5 + 8.5e-8 * k : 8.6e-5 + 2.3e-7 * k);
     const double table = cube + label_pass + bind_seconds(n) / 16.0;
     return table < brute;
 }

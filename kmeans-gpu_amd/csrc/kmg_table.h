@@ -194,6 +194,7 @@ constexpr uint32_t kCubeNoEntries = 0x10000u;
 // kernel waits for the few cells with long candidate lists, which the phase does not touch, so the phase only costs
 // (measured: +12 us per pass on the test photograph, -8 us on noise; profiles/NOTES.md round 5).
 constexpr uint32_t kCubeNoPrune = 0x40000u;
+constexpr uint32_t kCubeSplitLong = 0x80000u;  // (set by launch_cube itself, k <= 256 without k_cube_prune: long-list cells are scanned by four waves each)
 constexpr uint32_t kCubePruned = 0x20000u;   // (set by launch_cube itself: k_cube_prune has run between the stage and the scan)
 bool cube_prune_wanted(uint32_t k);          // the general pass makes the dominance test: launch_cube wants sub_affine for this k
 constexpr uint32_t kCubeSmallMaxK = 32;      // k up to which the cube pass is the one-launch k_cube_small
