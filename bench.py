@@ -767,14 +767,25 @@ def main():
                 variants["bands"] = 0
             if not args.no_overlap:
                 variants["bands, all-reduce beside the label pass"] = kg.GROUP_OVERLAP
-        trial = {}
+        trial, failed = {}, {}
         for name, fl in variants.items():
-            bind_loop(gl, fl, bands, label_maps, rows, height, cent)
-            trial[name] = max_over_ranks(timed(gl, 5)) / 5 * 1e3
+            # (a candidate that raises on this rank counts as infinitely slow on all of them: the MAX over the ranks carries it, so
+            # every rank drops it together and the next candidate is tried with the ranks still in step)
+            try:
+                bind_loop(gl, fl, bands, label_maps, rows, height, cent)
+                t_local = timed(gl, 5)
+            except Exception as e:                             # noqa: BLE001 -- reported below, not swallowed
+                t_local = float("inf")
+                failed[name] = f"{type(e).__name__}: {e}"
+            trial[name] = max_over_ranks(t_local) / 5 * 1e3
         best = min(trial, key=trial.get)                     # (the same on every rank: the times were all-reduced)
+        if trial[best] == float("inf"):
+            raise RuntimeError(f"no sharding of the image over {world} GPUs ran: {failed or 'another rank failed'}")
         flags = variants[best]
-        if len(variants) > 1:
-            picked = {"picked": best, **{f"{nm}_ms_per_step": ms for nm, ms in trial.items()}}
+        if len(variants) > 1 or failed:
+            picked = {"picked": best, **{f"{nm}_ms_per_step": (ms if ms != float("inf") else None) for nm, ms in trial.items()}}
+            if failed:
+                picked["failed_on_this_rank"] = failed
     else:
         flags = kg.GROUP_FUSED_UPDATE if fused else 0
     bind_loop(gl, flags, bands, label_maps, rows, height, cent)
