@@ -710,9 +710,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
 // listed cells of the general pass, as a phase of its own, and the compact work of the two launches that follow.
 // A workgroup takes kPruneCells cells of the work list, one sub-cell per thread:
 //   1. a sub-cell to scan requests its affine model (96 B) with the cell's record and leaves it in LDS; every (sub-cell to
-//      scan, candidate other than the one with the smallest upper bound) goes into ONE compact list in LDS, one test per lane; a candidate another candidate beats on every colour of the sub-cell leaves the sub-cell's set
-//      (exact: what the test removes is neither the arg-min nor within the tie threshold of it for any colour of the
-//      sub-cell -- `dominated`; a list that overflows drops tests, i.e. keeps candidates);
+//      scan, candidate other than the one with the smallest upper bound) goes into ONE compact list in LDS, one test per
+//      lane; a candidate another candidate beats on every colour of the sub-cell leaves the sub-cell's set (exact: what the
+//      test removes is neither the arg-min nor within the tie threshold of it for any colour of the sub-cell -- `dominated`;
+//      a list that overflows drops tests, i.e. keeps candidates);
 //   2. a sub-cell left with ONE candidate is decided here as the stage kernel decides its own: 64 labels, the sums of the
 //      sub-cell table; a cell whose occupied sub-cells all went to one centroid gets its pair entry at once;
 //   3. what is still to scan leaves as ITEMS (two sub-cells of a cell and the union of their candidates, 16 bytes: all the
@@ -944,9 +945,9 @@ __global__ __launch_bounds__(kBlock) void k_cube_scan(const uint32_t *__restrict
     float4 *s_cc = s_cc_all + wv * kMaxListed;
     LabelT *s_lbl = s_lbl_all + wv * kCellColours;
 
-    // kCubePruned: what k_cube_prune left -- segment wave % kListSegs of its lists, every (n_waves / kListSegs)-th entry: first
-    // the ITEMS (two sub-cells and their candidates each: nothing else is read), then the cells that are scanned from their
-    // work records; otherwise the whole work list
+    // kCubePruned: what k_cube_prune left -- segment wave % kListSegs of its lists, every (n_waves / kListSegs)-th entry: the
+    // cells that are scanned from their work records (few, heavy) and then the ITEMS (two sub-cells and their candidates each:
+    // nothing else is read); otherwise the whole work list
     const bool from_list = (flags & kCubePruned) != 0u;
     const uint32_t *lists = reinterpret_cast<const uint32_t *>(cell_work + kCells);
     const uint32_t seg = wave & (kListSegs - 1u);

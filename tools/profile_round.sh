@@ -4,6 +4,7 @@
 #   gpurun_out/<tag>_kernel_stats.csv       rocprofv3 --kernel-trace --stats of bench.py --no-cpu-baseline --no-extras
 #   gpurun_out/<tag>_pmc_fetch_write.csv    two separate passes: --pmc FETCH_SIZE / --pmc WRITE_SIZE (rows of our kernels)
 #   gpurun_out/<tag>_pmc_units.txt          TA / TCP / TCC / LDS / SQ counter groups, one pass each (tools/pmc_labels.sh)
+#   gpurun_out/<tag>_photo_phases.txt       rocprofv3 --kernel-trace --stats of tools/photo_phases.py (the tiled photograph)
 #   gpurun_out/<tag>_cfg2_bench.json, _cfg2_kernel_stats.csv, _cfg2_pmc.txt   BASELINE config 2 (4096^2, k = 16): bench.py --only cfg2,
 #                                           rocprofv3 --kernel-trace --stats and the counter groups of the same loop (tools/pmc_cfg2.sh)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -35,3 +36,6 @@ cp $OUT/${TAG}_cfg2run/cfg2_bench.json $OUT/${TAG}_cfg2_bench.json
 cp $OUT/${TAG}_cfg2run/cfg2_kernel_stats.csv $OUT/${TAG}_cfg2_kernel_stats.csv
 bash tools/pmc_cfg2.sh ${TAG}_cfg2pmc >> $OUT/${TAG}_cfg2.log 2>&1
 cp $OUT/${TAG}_cfg2pmc/summary.txt $OUT/${TAG}_cfg2_pmc.txt
+# the iteration on bench.py's tiled photograph, per kernel (the pass without the dominance phase, long-list cells split)
+cd $ROOT && bash tools/photo_phases.sh ${TAG} > /dev/null 2>&1
+cp $OUT/${TAG}_photo.txt $OUT/${TAG}_photo_phases.txt

@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 for name in ("bench.json", "kernel_stats.csv", "pmc_fetch_write.csv", "pmc_units.txt", "init.txt", "table_stats.txt",
              "dither_knock.txt", "dither_stats.txt", "lab_rate.txt", "apply_kernel_stats.csv", "apply_pmc.txt", "apply_host.txt",
-             "strong_cells_per_rank.json", "cfg2_bench.json", "cfg2_kernel_stats.csv", "cfg2_pmc.txt"):
+             "strong_cells_per_rank.json", "cfg2_bench.json", "cfg2_kernel_stats.csv", "cfg2_pmc.txt", "photo_phases.txt"):
     src = os.path.join(G, f"{tag}_{name}")
     if os.path.exists(src):
         shutil.copy(src, os.path.join(P, f"{tag}_{name}"))
