@@ -1260,3 +1260,35 @@ def test_dominance_phase_runs_on_spread_images_only(torch_cuda, processor, oracl
         else:
             assert stats["candidates_pruned"] == 0 and stats["sub_cells_pruned_to_one"] == 0, stats
         s.close()
+
+
+def test_dominance_phase_with_crowded_centroids(torch_cuda, processor, oracle):
+    """k_cube_prune where its items do not fit: 100 of 200 centroids crowded around one colour give the cells near it more than
+    12 candidates per pair of sub-cells (scanned from their work records, the sets rewritten by the phase) and some more than 32
+    (long lists, untouched by the phase) -- labels and sums of a noise image == the oracle, the tables exhaustively right"""
+    import kmeans_gpu_amd as kg
+    torch = torch_cuda
+    st = _stream(torch)
+    rng = np.random.default_rng(23)
+    n = 1_200_000
+    rgba = oracle.synth_uniform(4711, n)
+    lab = oracle.rgb_to_lab(rgba[:100])
+    crowd = (oracle.rgb_to_lab(np.array([[120, 130, 90, 255]], np.uint8))[0] + rng.normal(0, 0.6, (100, 3))).astype(np.float32)
+    cent = oracle.centroids4(np.concatenate([crowd, lab]))
+    k = cent.shape[0]
+    wl, wa = oracle.assign_accumulate_rgba(rgba, cent)
+    d = _dev(torch, rgba)
+    s = kg.Lloyd(processor, k)
+    s.set_centroids(cent)
+    s.bind_image(d.data_ptr(), n, st)
+    labels = torch.zeros(n, dtype=torch.int32, device="cuda")
+    acc = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
+    s.assign_accumulate(d.data_ptr(), n, labels.data_ptr(), acc.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert np.array_equal(labels.cpu().numpy().view(np.uint32), wl)
+    assert np.array_equal(acc.cpu().numpy(), wa)
+    stats = s.debug_table_stats(st)
+    assert stats["candidates_pruned"] > 0 and stats["max_candidates"] > 32 and stats["cells_unlisted"] > 0, stats
+    assert s.debug_check_pairs(st)[0] == 0
+    assert s.debug_check_table(st) == (0, 0, 0)
+    s.close()
