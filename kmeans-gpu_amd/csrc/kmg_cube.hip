@@ -725,7 +725,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
 // flags (tools build, results WRONG): bit 21 no tests, 22 no decisions, 23 no reservation.
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kPruneCells = kBlock / 8;                      // 32 cells of a workgroup
-constexpr uint32_t kPruneTests = 2048;
+constexpr uint32_t kPruneTests = 1024;                            // tests a workgroup lists (~340-520 on the benchmark image; more are dropped = kept candidates)
 
 template <bool SUMS>
 __global__ __launch_bounds__(kBlock) void k_cube_prune(const uint32_t *__restrict__ work, const int64_t *__restrict__ sub_agg,
@@ -740,6 +740,7 @@ __global__ __launch_bounds__(kBlock) void k_cube_prune(const uint32_t *__restric
     __shared__ uint16_t s_list[kPruneCells * kMaxListed];          // [cell][position]: centroid
     __shared__ uint16_t s_test[kPruneTests];                       // (sub-cell << 5) | position
     __shared__ uint32_t s_count;                                   // tests
+    __shared__ float4 s_cent[256];                                 // (with the rest 38.9 KiB: four workgroups per CU, the whole grid resident)
     // the models of the workgroup's sub-cells (each thread requests its own with the cell's record, the tests read them from
     // here: no second round trip to memory); after the tests the same bytes are the bins (k x 4 u64) of the sub-cells decided here
     constexpr uint32_t kModelStride = 28;                          // words per model in LDS (16-byte rows, 8 start banks)
@@ -752,6 +753,11 @@ __global__ __launch_bounds__(kBlock) void k_cube_prune(const uint32_t *__restric
     // (the first batch's cells are requested with the list's length, not after it: entries beyond it are readable)
     const uint32_t cell_first = SUMS ? work[1u + blockIdx.x * kPruneCells + slot] : blockIdx.x * kPruneCells + slot;
     if (threadIdx.x == 0u) s_count = 0u;
+    {
+        float4 v = make_float4(1.0e18f, 0.0f, 0.0f, 0.0f);
+        if (threadIdx.x < k) { const Centroid c = cent[threadIdx.x]; v = make_float4(c.L, c.a, c.b, c.C); }
+        s_cent[threadIdx.x] = v;
+    }
     __syncthreads();
     const uint32_t n_work = __builtin_amdgcn_readfirstlane(n_work_v);
     const bool dominance = sub_affine != nullptr && __builtin_amdgcn_readfirstlane(far_v) == 0u && !KMG_KNOCK(flags, 0x200000u);
@@ -803,15 +809,14 @@ __global__ __launch_bounds__(kBlock) void k_cube_prune(const uint32_t *__restric
         for (uint32_t t = threadIdx.x; t < n_tests; t += kBlock) {
             const uint32_t e = (uint32_t)s_test[t] >> 5, pos = (uint32_t)s_test[t] & 31u;
             const uint32_t r = s_ref[e];
-            // (the centroids from memory: a copy in LDS is 4 KiB more per workgroup -- three instead of four per CU, 22.5 -> 25 us)
-            const Centroid cj = cent[s_list[(e >> 3) * kMaxListed + pos]], ci = cent[s_list[(e >> 3) * kMaxListed + (r & 31u)]];
+            const float4 cj = s_cent[s_list[(e >> 3) * kMaxListed + pos]], ci = s_cent[s_list[(e >> 3) * kMaxListed + (r & 31u)]];
             HalfModel mdl;
 #pragma unroll
             for (int q = 0; q < 6; ++q) {
                 const uint4 v = s_model4[e * (kModelStride / 4u) + q];
                 mdl.q[4 * q] = v.x; mdl.q[4 * q + 1] = v.y; mdl.q[4 * q + 2] = v.z; mdl.q[4 * q + 3] = v.w;
             }
-            if (dominated(mdl, make_float4(cj.L, cj.a, cj.b, cj.C), make_float4(ci.L, ci.a, ci.b, ci.C), bits_to_float(r & 0xFFFF0000u)))
+            if (dominated(mdl, cj, ci, bits_to_float(r & 0xFFFF0000u)))
                 atomicAnd(&s_mask[e], ~(1u << pos));
         }
         __syncthreads();
