@@ -253,7 +253,7 @@ __device__ __forceinline__ void flush_bins(const unsigned long long *bins, uint3
     __syncthreads();
     // only the clusters this workgroup met are non-zero
     unsigned long long *row = reinterpret_cast<unsigned long long *>(sums) + (uint64_t)(blockIdx.x % n_rows) * 4ull * k;
-    for (uint32_t i = threadIdx.x; i < 4u * k; i += kBlock) {
+    for (uint32_t i = threadIdx.x; i < 4u * k; i += blockDim.x) {
         unsigned long long v = 0ull;
         for (uint32_t r = 0; r < repl; ++r) v += bins[(uint64_t)r * bin_stride + i];
         if (v) atomicAdd(row + i, v);
@@ -913,8 +913,11 @@ __global__ __launch_bounds__(kBlock) void k_cube_prune(const uint32_t *__restric
 //                    [labels 4 waves x 512]
 // flags bits: 9 no sums, 13 no label stores
 // ------------------------------------------------------------------------------------------
+// (eight waves per workgroup: they share the centroid table and FOUR copies of the bins in the LDS two workgroups of four waves
+// spent on two copies each -- the same waves per CU, half the same-address atomics per copy)
+constexpr int kScanBlock = 512;
 template <typename LabelT, bool SUMS>
-__global__ __launch_bounds__(kBlock) void k_cube_scan(const uint32_t *__restrict__ hist,
+__global__ __launch_bounds__(kScanBlock) void k_cube_scan(const uint32_t *__restrict__ hist,
                                                       const int64_t *__restrict__ sub_agg,
                                                       const uint32_t *__restrict__ work,
                                                       const Centroid *__restrict__ cent, uint32_t k,
@@ -933,19 +936,19 @@ __global__ __launch_bounds__(kBlock) void k_cube_scan(const uint32_t *__restrict
     const uint32_t bin_stride = 4u * k + 4u;                      // u64 per copy (+ 32 B: next copy, other banks)
     const uint32_t n_bins = SUMS ? repl * bin_stride : 0u;
     float4 *s_cc_all = reinterpret_cast<float4 *>(bins + n_bins);              // [4 waves][kMaxListed]: listed candidates by position
-    LabelT *s_lbl_all = reinterpret_cast<LabelT *>(s_cc_all + (kBlock / 64) * kMaxListed);   // [4 waves][512]: labels of the cell
-    for (uint32_t i = threadIdx.x; i < kpad; i += kBlock) {
+    LabelT *s_lbl_all = reinterpret_cast<LabelT *>(s_cc_all + (kScanBlock / 64) * kMaxListed);   // [4 waves][512]: labels of the cell
+    for (uint32_t i = threadIdx.x; i < kpad; i += kScanBlock) {
         float4 v = make_float4(1.0e18f, 0.0f, 0.0f, 0.0f);
         if (i < k) { const Centroid c = cent[i]; v = make_float4(c.L, c.a, c.b, c.C); }
         s_cent[i] = v;
     }
-    for (uint32_t i = threadIdx.x; i < n_bins; i += kBlock) bins[i] = 0ull;
+    for (uint32_t i = threadIdx.x; i < n_bins; i += kScanBlock) bins[i] = 0ull;
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wv = threadIdx.x >> 6;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / 64) + wv);
-    const uint32_t n_waves = gridDim.x * (kBlock / 64);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (kScanBlock / 64) + wv);
+    const uint32_t n_waves = gridDim.x * (kScanBlock / 64);
     unsigned long long *my_bins = bins + (uint64_t)(lane & (repl - 1u)) * bin_stride;
     float4 *s_cc = s_cc_all + wv * kMaxListed;
     LabelT *s_lbl = s_lbl_all + wv * kCellColours;
@@ -1938,7 +1941,7 @@ uint32_t cube_replicas(uint32_t k)
 {
     // copies of the scan kernel's LDS bins (lanes spread their atomic adds over them).  Measured at k = 256 (round 3,
     // profiles/r03_*): 1 copy 73.4 us, 2 copies 69.5 us, 4 copies 97.6 us (the bins then take the LDS of a workgroup per CU)
-    uint32_t r = 2;
+    uint32_t r = 4;
     if (const char *e = KMG_TOOLS_ENV("KMG_CUBE_REPL")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) r = (uint32_t)v; }
     while (r > 1u && (uint64_t)r * (k * 32ull + 32ull) > 33024ull) r >>= 1;
     return r;
@@ -1968,7 +1971,7 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
                              sizeof(uint32_t) * (kBlock / 64) * kMaxListed + sizeof(unsigned long long) * (kBlock / 64) * (kpad / 64u) +
                              (k <= 256 ? (kBlock / 64) * (32u * sizeof(unsigned long long) + kMaxLong * sizeof(uint16_t)) : 0u);
     const size_t lds_scan = sizeof(float4) * kpad + (with_sums ? sizeof(unsigned long long) * (4ull * k + 4ull) * repl : 0) +
-                            sizeof(float4) * (kBlock / 64) * kMaxListed + (k <= 256 ? 1u : 2u) * (kBlock / 64) * kCellColours;
+                            sizeof(float4) * (kScanBlock / 64) * kMaxListed + (k <= 256 ? 1u : 2u) * (kScanBlock / 64) * kCellColours;
     {
         // the largest k (KMG_MAX_K) takes ~150 KiB per workgroup: refuse a launch the device cannot hold instead of failing in it
         static const size_t lds_max = [] {
@@ -1999,15 +2002,15 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
         else           { if (kp == 8u) KMG_SMALL(8, false); else if (kp == 16u) KMG_SMALL(16, false); else KMG_SMALL(32, false); }
 #undef KMG_SMALL
         if (split) {
-            static const uint32_t g_scan2 = env_grid("KMG_SCAN_GRID", 2u * kCubeGrid), g_pairs2 = env_grid("KMG_PAIRS_GRID", kCubeGrid);
+            static const uint32_t g_scan2 = env_grid("KMG_SCAN_GRID", kCubeGrid), g_pairs2 = env_grid("KMG_PAIRS_GRID", kCubeGrid);
             const uint32_t kpad2 = (k + 63u) & ~63u, repl2 = with_sums ? cube_replicas(k) : 1u;
             const size_t lds_scan2 = sizeof(float4) * kpad2 + (with_sums ? sizeof(unsigned long long) * (4ull * k + 4ull) * repl2 : 0) +
-                                     sizeof(float4) * (kBlock / 64) * kMaxListed + (kBlock / 64) * kCellColours;
+                                     sizeof(float4) * (kScanBlock / 64) * kMaxListed + (kScanBlock / 64) * kCellColours;
             if (with_sums)
-                hipLaunchKernelGGL((k_cube_scan<uint8_t, true>), dim3(g_scan2), dim3(kBlock), lds_scan2, st, hist, sub_agg, work, cent, k,
+                hipLaunchKernelGGL((k_cube_scan<uint8_t, true>), dim3(g_scan2), dim3(kScanBlock), lds_scan2, st, hist, sub_agg, work, cent, k,
                                    lab_table, masks, (const CellWork *)cell_work, (uint8_t *)colour_labels, sub_table, sums, n_rows, repl2, flags);
             else
-                hipLaunchKernelGGL((k_cube_scan<uint8_t, false>), dim3(g_scan2), dim3(kBlock), lds_scan2, st, hist, sub_agg, work, cent, k,
+                hipLaunchKernelGGL((k_cube_scan<uint8_t, false>), dim3(g_scan2), dim3(kScanBlock), lds_scan2, st, hist, sub_agg, work, cent, k,
                                    lab_table, masks, (const CellWork *)cell_work, (uint8_t *)colour_labels, sub_table, sums, n_rows, repl2, flags);
             hipLaunchKernelGGL((k_cube_pairs<uint8_t>), dim3((flags & kCubeNoEntries) ? 1u : g_pairs2), dim3(kBlock), 0, st, work,
                                with_sums ? 1 : 0, occ_bits, (const uint8_t *)colour_labels, sub_table, flags, sums, k, tl,
@@ -2021,7 +2024,7 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
     }
     // (the scan kernel's cells differ a lot in cost: finer hand-out, 2 cells per wave, measured 83 -> 75 us)
     // (stage: 1536 workgroups = one full round at its 6 waves per SIMD: 33 -> 30-31 us against 2048, round 3)
-    static const uint32_t g_stage = env_grid("KMG_CUBE_GRID", 1536u), g_scan = env_grid("KMG_SCAN_GRID", 2u * kCubeGrid),
+    static const uint32_t g_stage = env_grid("KMG_CUBE_GRID", 1536u), g_scan = env_grid("KMG_SCAN_GRID", kCubeGrid),
                           g_pairs = env_grid("KMG_PAIRS_GRID", kCubeGrid);
     CellWork *cw = (CellWork *)cell_work;
     if (!n_rows) n_rows = 1u;
@@ -2037,7 +2040,7 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
     }
     const uint32_t g_prune = kCells / kPruneCells;                 // (one batch of cells per workgroup)
     // (the scan over items: one round of resident workgroups, each wave a few items with the next one's colours in flight)
-    static const uint32_t g_items = env_grid("KMG_ITEMS_GRID", 1792u) & ~15u;
+    static const uint32_t g_items = env_grid("KMG_ITEMS_GRID", 896u) & ~7u;
     const uint32_t *lists = reinterpret_cast<const uint32_t *>(cw + kCells);
 #define KMG_CUBE(T, S)                                                                                                      \
     do {                                                                                                                    \
@@ -2048,7 +2051,7 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
                                sub_affine, cw, (uint8_t *)colour_labels, sub_table, const_cast<uint32_t *>(lists), sums,    \
                                n_rows, flags, stats);                                                                       \
         if (!KMG_KNOCK(flags, 0xC00u))                                                                                      \
-            hipLaunchKernelGGL((k_cube_scan<T, S>), dim3(prune ? g_items : g_scan), dim3(kBlock), lds_scan, st, hist, sub_agg, work, cent, k, \
+            hipLaunchKernelGGL((k_cube_scan<T, S>), dim3(prune ? g_items : g_scan), dim3(kScanBlock), lds_scan, st, hist, sub_agg, work, cent, k, \
                                lab_table, masks, cw, (T *)colour_labels, sub_table, sums, n_rows, repl, flags);             \
         hipLaunchKernelGGL((k_cube_pairs<T>), dim3((flags & kCubeNoEntries) ? 1u : g_pairs), dim3(kBlock), 0, st, work,   \
                            S ? 1 : 0, occ_bits, (const T *)colour_labels, sub_table, flags, sums, k, tl, lists);            \
