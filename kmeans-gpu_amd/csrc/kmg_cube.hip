@@ -48,6 +48,7 @@ constexpr uint32_t kMaxListed = 32;       // candidates per cell the sub-cell st
 // cube_masks_bytes), and the scan kernel visits a sub-cell's own set instead of every candidate of the cell.  k <= 256.
 constexpr uint32_t kMaxLong = 256;
 constexpr uint32_t kLongFlag = 0x200u;    // CellWork::scan_set: the cell's sub-cells have masks of their own
+constexpr uint32_t kDeferFlag = 0x800u;   // CellWork::scan_set: a listed cell whose sub-cell stage is left to k_cube_prune (k_cube_stage<.., DEFER>)
 
 __device__ __forceinline__ uint32_t sel3(uint32_t i, uint32_t x0, uint32_t x1, uint32_t x2)
 {
@@ -395,7 +396,9 @@ __device__ __forceinline__ bool dominated(const Model &mdl, const float4 cj, con
 // ------------------------------------------------------------------------------------------
 // (6 waves per SIMD = 80 VGPRs, no spills: 35.9 -> 34.9 us against the 87 the allocator takes by itself; the scan kernel
 // forced from 71 to 64 VGPRs spills 7 dwords and loses 2 us)
-template <typename LabelT, bool SUMS>
+// DEFER (k <= 256, k_cube_prune follows): a cell with 2 .. kMaxListed candidates only gets its candidate list written; bounding the
+// candidates over its sub-cells, the decisions and everything after are k_cube_prune's, which has a thread per sub-cell.
+template <typename LabelT, bool SUMS, bool DEFER>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_cube_stage(const int64_t *__restrict__ agg,
                                                        const int64_t *__restrict__ sub_agg,
                                                        const uint32_t *__restrict__ work,
@@ -472,7 +475,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         const uint32_t w2_ = (wi_) + n_waves < n_work ? (wi_) + n_waves : safe_w;   /* past the end: a harmless repeat */ \
         cell_nn = SUMS ? work[1u + w2_ + vz] : w2_;                                                              \
         cbv_n = reinterpret_cast<const float *>(bounds + cell_n)[lane & 15u];   /* lane i: float i (VMEM: not tied to LDS waits) */ \
-        if (SUMS) {                                                                                              \
+        if (SUMS && !DEFER) {   /* (DEFER: only single-candidate and long-list cells need sums, and ask when they know) */ \
             sagg_n = sub_agg[(uint64_t)cell_n * 32u + (lane & 31u)];        /* lane 4 s + j: sum j of sub-cell s */ \
             scnt_n = sub_agg[(uint64_t)cell_n * 32u + 4u * (lane & 7u) + 3u];   /* lane s < 8: pixels in sub-cell s */ \
             cagg_n = agg[4ull * cell_n + (lane & 3u)];                                                           \
@@ -485,11 +488,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         cb.L0 = lane_value(cbv_n, 0); cb.L1 = lane_value(cbv_n, 1); cb.a0 = lane_value(cbv_n, 2); cb.a1 = lane_value(cbv_n, 3);
         cb.b0 = lane_value(cbv_n, 4); cb.b1 = lane_value(cbv_n, 5); cb.C0 = lane_value(cbv_n, 6); cb.C1 = lane_value(cbv_n, 7);
         cb.wC0 = lane_value(cbv_n, 8); cb.wC1 = lane_value(cbv_n, 9); cb.wH0 = lane_value(cbv_n, 10); cb.wH1 = lane_value(cbv_n, 11);
-        const long long sagg = sagg_n, cagg = cagg_n, scnt = scnt_n;
+        long long sagg = sagg_n, cagg = cagg_n, scnt = scnt_n;
         KMG_REQUEST_CELL(wi + n_waves);
         // the sub-cell bounds of THIS cell: requested now, needed after the cell's candidates are known
         const float4 *sbp = reinterpret_cast<const float4 *>(sub_bounds + (uint64_t)cell * 8u + sub_of_lane);
-        const float4 sb0 = sbp[0], sb1 = sbp[1], sb2 = sbp[2];
+        float4 sb0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), sb1 = sb0, sb2 = sb0;
+        if (!DEFER) { sb0 = sbp[0]; sb1 = sbp[1]; sb2 = sbp[2]; }   // (DEFER: only the rare long-list cells need them, and ask below)
 
         uint16_t *sub = sub_table + cell * 8u;
         uint16_t *cell_entry = sub_table + kSubCells + cell;       // 8x8x8 summary, same encoding
@@ -557,6 +561,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
                 if (lane == 0u) *cell_entry = (uint16_t)first;
             }
             if (lane == 0u) { cw->npop = 1u; cw->scan_set = 0u; }
+            if (SUMS && DEFER) cagg = agg[4ull * cell + (lane & 3u)];
             if (SUMS && lane < 4u) atomicAdd(bins + 4ull * first + lane, (unsigned long long)cagg);
             if (flags & 1u) {
 #pragma unroll
@@ -566,6 +571,27 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
             continue;
         }
         st_multi += 1;
+        if (DEFER && npop <= kMaxListed) {
+            // the candidate list (k <= 256: the masks are in registers), nothing else
+            uint32_t base = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < 4u; ++w) {
+                if (w < words) {
+                    if ((mw[w] >> lane) & 1ull) s_list[base + bits_below_lane(mw[w])] = w * 64u + lane;
+                    base += (uint32_t)__builtin_popcountll(mw[w]);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t cand = s_list[lane & (kMaxListed - 1u)];
+            __builtin_amdgcn_wave_barrier();
+            if (lane < kMaxListed) cw->list[lane] = (uint16_t)(lane < npop ? cand : 0u);
+            if (lane == 0u) {
+                cw->npop = npop;
+                cw->scan_set = 0x100u | kDeferFlag;
+                *pair_entry_ptr = kPairPending;
+            }
+            continue;
+        }
 
         // ---- 2. sub-cell stage: list the candidates, bound each over each sub-cell ----
         const bool listed = npop <= kMaxListed && !KMG_KNOCK(flags, 0x1000u);
@@ -632,6 +658,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         } else if (words <= 4u && npop <= kMaxLong && !KMG_KNOCK(flags, 0x1000u)) {
             // long list (rare on noise, the heavy cells of a photograph): long_list_stage
             long_cell = true;
+            if (DEFER) {
+                sb0 = sbp[0]; sb1 = sbp[1]; sb2 = sbp[2];
+                if (SUMS) {
+                    sagg = sub_agg[(uint64_t)cell * 32u + (lane & 31u)];
+                    scnt = sub_agg[(uint64_t)cell * 32u + 4u * (lane & 7u) + 3u];
+                }
+            }
 #pragma unroll
             for (uint32_t w = 0; w < 4u; ++w)
                 if (w < words && lane == 0u) s_masks[w] = mw[w];
@@ -729,6 +762,7 @@ constexpr uint32_t kPruneTests = 1024;                            // tests a wor
 
 template <bool SUMS>
 __global__ __launch_bounds__(kBlock) void k_cube_prune(const uint32_t *__restrict__ work, const int64_t *__restrict__ sub_agg,
+                                                       const CellBounds *__restrict__ sub_bounds,
                                                        const Centroid *__restrict__ cent, uint32_t k,
                                                        const float *__restrict__ sub_affine, CellWork *__restrict__ cell_work,
                                                        uint8_t *__restrict__ colour_labels, uint16_t *__restrict__ sub_table,
@@ -736,7 +770,7 @@ __global__ __launch_bounds__(kBlock) void k_cube_prune(const uint32_t *__restric
                                                        uint32_t flags, unsigned long long *__restrict__ stats)
 {
     __shared__ uint32_t s_mask[kBlock];                            // [sub-cell]: candidates (list positions)
-    __shared__ uint32_t s_ref[kBlock];                             // [sub-cell]: upper bound (16 high bits) | position of the reference candidate
+    __shared__ uint32_t s_ref[kBlock];                             // [sub-cell]: upper bound (27 high bits) | position of the reference candidate
     __shared__ uint16_t s_list[kPruneCells * kMaxListed];          // [cell][position]: centroid
     __shared__ uint16_t s_test[kPruneTests];                       // (sub-cell << 5) | position
     __shared__ uint32_t s_count;                                   // tests
@@ -762,7 +796,7 @@ __global__ __launch_bounds__(kBlock) void k_cube_prune(const uint32_t *__restric
     const uint32_t n_work = __builtin_amdgcn_readfirstlane(n_work_v);
     const bool dominance = sub_affine != nullptr && __builtin_amdgcn_readfirstlane(far_v) == 0u && !KMG_KNOCK(flags, 0x200000u);
     uint32_t *pair_entries = reinterpret_cast<uint32_t *>(sub_table + kSubCells + kCells);
-    unsigned long long st_removed = 0, st_single = 0;
+    unsigned long long st_removed = 0, st_single = 0, st_decided = 0, st_scanned = 0, st_cands = 0;
     // (one batch per workgroup: the grid is kCells / kPruneCells whatever the list's length)
     const uint32_t base = blockIdx.x * kPruneCells;
     if (base >= n_work) return;
@@ -773,32 +807,53 @@ __global__ __launch_bounds__(kBlock) void k_cube_prune(const uint32_t *__restric
         CellWork *cw = cell_work + cell;
         const uint32_t ss = valid ? cw->scan_set : 0u;
         const uint32_t npop = valid ? cw->npop : 1u;
-        const bool listed = (ss & 0x100u) != 0u;
-        const bool mine = listed && ((ss >> sub) & 1u) != 0u;       // a sub-cell the stage kernel left to the scan
-        uint32_t sm = 0u, istar = 0u, u16 = 0u;
-        longlong2 g01 = {0, 0}, g23 = {0, 0};
+        const bool listed = (ss & kDeferFlag) != 0u;                 // 2 .. kMaxListed candidates: everything below the list is done here
+        uint32_t sm = 0u, istar = 0u, ubits = 0u;
+        longlong2 g01 = {0, 0}, g23 = {0, 1};
+        bool occupied = false;
         if (listed) {
-            const unsigned long long b0 = cw->br[0], b1 = cw->br[1], b2 = cw->br[2], b3 = cw->br[3];
-            sm = ((uint32_t)(b0 >> (8u * sub)) & 0xFFu) | (((uint32_t)(b1 >> (8u * sub)) & 0xFFu) << 8) |
-                 (((uint32_t)(b2 >> (8u * sub)) & 0xFFu) << 16) | (((uint32_t)(b3 >> (8u * sub)) & 0xFFu) << 24);
+            // requested together: the list, the sub-cell's bounds, its sums (their count = is it occupied) and its model
+            const float4 *sbp = reinterpret_cast<const float4 *>(sub_bounds + (uint64_t)cell * 8u + sub);
+            const float4 sb0 = sbp[0], sb1 = sbp[1], sb2 = sbp[2];
             *reinterpret_cast<uint2 *>(s_list + slot * kMaxListed + 4u * sub) = *reinterpret_cast<const uint2 *>(cw->list + 4u * sub);
-            istar = (uint32_t)cw->istar[sub];
-            u16 = (uint32_t)cw->U16[sub];
-            if (SUMS && mine) {                                     // (what a sub-cell decided here hands over)
+            if (SUMS) {
                 const longlong2 *sp = reinterpret_cast<const longlong2 *>(sub_agg + ((uint64_t)cell * 8u + sub) * 4u);
                 g01 = sp[0]; g23 = sp[1];
             }
-            if (mine && dominance) {
+            if (dominance) {
                 const uint4 *mp = reinterpret_cast<const uint4 *>(sub_affine + ((uint64_t)cell * 8u + sub) * kAffineFloats);
                 uint4 *dst = s_model4 + threadIdx.x * (kModelStride / 4u);
 #pragma unroll
                 for (int t = 0; t < 6; ++t) dst[t] = mp[t];
             }
+            occupied = g23.y != 0;
+            __builtin_amdgcn_wave_barrier();                        // (s_list: written and read by the 8 lanes of the cell)
+            // the sub-cell stage: the cell's candidates bounded over THIS sub-cell (kmg_table_dev.h key_range), two sweeps -- the
+            // smallest upper bound and who has it, then the lower bounds against the threshold
+            CellBounds sb;
+            sb.L0 = sb0.x; sb.L1 = sb0.y; sb.a0 = sb0.z; sb.a1 = sb0.w;
+            sb.b0 = sb1.x; sb.b1 = sb1.y; sb.C0 = sb1.z; sb.C1 = sb1.w;
+            sb.wC0 = sb2.x; sb.wC1 = sb2.y; sb.wH0 = sb2.z; sb.wH1 = sb2.w;
+            uint32_t Ubest = 0x7F7FFFE0u;                           // (upper bound rounded up to a multiple of 32 ulps) | position
+            for (uint32_t p = 0; p < npop; ++p) {
+                const float4 c = s_cent[s_list[slot * kMaxListed + p]];
+                Ubest = min(Ubest, ((float_to_bits(key_range(sb, c.x, c.y, c.z, c.w).hi) + 31u) & ~31u) | p);
+            }
+            const float Us = mask_threshold(bits_to_float(Ubest & ~31u));
+            for (uint32_t p = 0; p < npop; ++p) {
+                const float4 c = s_cent[s_list[slot * kMaxListed + p]];
+                sm |= (key_range(sb, c.x, c.y, c.z, c.w).lo <= Us ? 1u : 0u) << p;
+            }
+            istar = Ubest & 31u;
+            ubits = Ubest & ~31u;
         }
+        const uint32_t np0 = (uint32_t)__builtin_popcount(sm);
+        const bool was_decided = listed && occupied && np0 == 1u;   // decided by its bounds
+        const bool mine = listed && occupied && np0 > 1u;            // open: the dominance tests, then the scan if still open
         s_mask[threadIdx.x] = sm;
         const uint32_t others = (mine && dominance) ? sm & ~(1u << istar) : 0u;
         if (others) {
-            s_ref[threadIdx.x] = (u16 << 16) | istar;
+            s_ref[threadIdx.x] = ubits | istar;
             const uint32_t nt = (uint32_t)__builtin_popcount(others);
             uint32_t at = atomicAdd(&s_count, nt);
             for (uint32_t m = others; m && at < kPruneTests; m &= m - 1u, ++at)
@@ -816,8 +871,7 @@ __global__ __launch_bounds__(kBlock) void k_cube_prune(const uint32_t *__restric
                 const uint4 v = s_model4[e * (kModelStride / 4u) + q];
                 mdl.q[4 * q] = v.x; mdl.q[4 * q + 1] = v.y; mdl.q[4 * q + 2] = v.z; mdl.q[4 * q + 3] = v.w;
             }
-            if (dominated(mdl, cj, ci, bits_to_float(r & 0xFFFF0000u)))
-                atomicAnd(&s_mask[e], ~(1u << pos));
+            if (dominated(mdl, cj, ci, bits_to_float(r & ~31u))) atomicAnd(&s_mask[e], ~(1u << pos));
         }
         __syncthreads();
         // (the models have been read: their bytes become the bins -- straight global atomics instead of LDS bins were measured:
@@ -828,7 +882,6 @@ __global__ __launch_bounds__(kBlock) void k_cube_prune(const uint32_t *__restric
         const uint32_t nm = s_mask[threadIdx.x];
         const uint32_t np = (uint32_t)__builtin_popcount(nm);
         const bool one = mine && np == 1u, still = mine && np > 1u;
-        const bool was_decided = listed && ((ss >> (16u + sub)) & 1u) != 0u;            // (by the stage kernel: its set has one member)
         const uint32_t X = (uint32_t)s_list[slot * kMaxListed + (nm ? (uint32_t)__builtin_ctz(nm) : 0u)];
         const uint32_t scan8 = group8_or(still ? 1u << sub : 0u);
         const bool settled = one || was_decided;
@@ -861,7 +914,8 @@ __global__ __launch_bounds__(kBlock) void k_cube_prune(const uint32_t *__restric
                 iw0 |= q < 4u ? c : 0u; iw1 |= (q >= 4u && q < 8u) ? c : 0u; iw2 |= q >= 8u ? c : 0u;
             }
         }
-        if (one && !KMG_KNOCK(flags, 0x400000u)) {
+        if (settled && !KMG_KNOCK(flags, 0x400000u)) {
+            // decided by its bounds or by the tests: 64 labels, the sums of the sub-cell table
             const uint32_t x4 = X * 0x01010101u;
             uint4 *dst = reinterpret_cast<uint4 *>(colour_labels + (uint64_t)cell * kCellColours + sub * 64u);
             dst[0] = dst[1] = dst[2] = dst[3] = make_uint4(x4, x4, x4, x4);
@@ -871,9 +925,9 @@ __global__ __launch_bounds__(kBlock) void k_cube_prune(const uint32_t *__restric
                 atomicAdd(to + 2, (unsigned long long)g23.x); atomicAdd(to + 3, (unsigned long long)g23.y);
             }
         }
-        if (listed && scan8 != 0u && !as_items && group8_or(nm != sm ? 1u : 0u)) {
-            // a cell that is scanned from its record after all: the sub-cells' sets back into it (round r: bit 8 s + c = sub-cell s
-            // keeps candidate 8 r + c)
+        if (listed && scan8 != 0u && !as_items) {
+            // a cell that is scanned from its record after all (a pair of its sub-cells has more than kItemCands candidates): the
+            // sub-cells' sets into it (round r: bit 8 s + c = sub-cell s keeps candidate 8 r + c)
             uint32_t lo_w[4], hi_w[4];
 #pragma unroll
             for (uint32_t r = 0; r < 4u; ++r) {
@@ -886,12 +940,15 @@ __global__ __launch_bounds__(kBlock) void k_cube_prune(const uint32_t *__restric
                 const uint32_t h = sub == 0u ? hi_w[0] : (sub == 1u ? hi_w[1] : (sub == 2u ? hi_w[2] : hi_w[3]));
                 cw->br[sub] = ((unsigned long long)h << 32) | l;
             }
-            if (sub == 0u) cw->scan_set = (ss & ~0xFFu) | scan8;
+            if (sub == 0u) cw->scan_set = 0x100u | scan8;
         }
         if (uniform && sub == 0u) pair_entries[cell] = pair_entry(xmin, xmin, 0u, 0u, 0u);
         if (stats) {
             st_removed += wave_add_u32((uint32_t)__builtin_popcount(sm & ~nm));
             st_single += (uint32_t)__builtin_popcountll(__ballot(one));
+            st_decided += (uint32_t)__builtin_popcountll(__ballot(was_decided));
+            st_scanned += (uint32_t)__builtin_popcountll(__ballot(mine));
+            st_cands += wave_add_u32(mine ? np0 : 0u);
         }
         // (the sums leave while the reservation is on its way)
         if (SUMS) flush_bins(bins, k, 1u, 4u * k, sums, n_rows);
@@ -905,7 +962,10 @@ __global__ __launch_bounds__(kBlock) void k_cube_prune(const uint32_t *__restric
             if (need_entry) lists[kListEntries + seg * kListSegCap + a_ent + bits_below_lane(ent_b)] = cell;
         }
     }
-    if (stats && lane == 0u) { atomicAdd(stats + 6, st_removed); atomicAdd(stats + 7, st_single); }
+    if (stats && lane == 0u) {
+        atomicAdd(stats + 2, st_decided); atomicAdd(stats + 3, st_scanned); atomicAdd(stats + 4, st_cands);
+        atomicAdd(stats + 6, st_removed); atomicAdd(stats + 7, st_single);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2044,10 +2104,14 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
     const uint32_t *lists = reinterpret_cast<const uint32_t *>(cw + kCells);
 #define KMG_CUBE(T, S)                                                                                                      \
     do {                                                                                                                    \
-        hipLaunchKernelGGL((k_cube_stage<T, S>), dim3(g_stage), dim3(kBlock), lds_stage, st, agg, sub_agg, work, bounds,    \
-                           sub_bounds, cent, k, masks, cw, (T *)colour_labels, sub_table, sums, n_rows, flags, stats);      \
         if (prune)                                                                                                          \
-            hipLaunchKernelGGL((k_cube_prune<S>), dim3(g_prune), dim3(kBlock), 0, st, work, sub_agg, cent, k,               \
+            hipLaunchKernelGGL((k_cube_stage<T, S, true>), dim3(g_stage), dim3(kBlock), lds_stage, st, agg, sub_agg, work, bounds, \
+                               sub_bounds, cent, k, masks, cw, (T *)colour_labels, sub_table, sums, n_rows, flags, stats);  \
+        else                                                                                                                \
+            hipLaunchKernelGGL((k_cube_stage<T, S, false>), dim3(g_stage), dim3(kBlock), lds_stage, st, agg, sub_agg, work, bounds, \
+                               sub_bounds, cent, k, masks, cw, (T *)colour_labels, sub_table, sums, n_rows, flags, stats);  \
+        if (prune)                                                                                                          \
+            hipLaunchKernelGGL((k_cube_prune<S>), dim3(g_prune), dim3(kBlock), 0, st, work, sub_agg, sub_bounds, cent, k,   \
                                sub_affine, cw, (uint8_t *)colour_labels, sub_table, const_cast<uint32_t *>(lists), sums,    \
                                n_rows, flags, stats);                                                                       \
         if (!KMG_KNOCK(flags, 0xC00u))                                                                                      \
