@@ -48,7 +48,7 @@ constexpr uint32_t kMaxListed = 32;       // candidates per cell the sub-cell st
 // cube_masks_bytes), and the scan kernel visits a sub-cell's own set instead of every candidate of the cell.  k <= 256.
 constexpr uint32_t kMaxLong = 256;
 constexpr uint32_t kLongFlag = 0x200u;    // CellWork::scan_set: the cell's sub-cells have masks of their own
-constexpr uint32_t kDeferFlag = 0x800u;   // CellWork::scan_set: a listed cell whose sub-cell stage is left to k_cube_prune (k_cube_stage<.., DEFER>)
+constexpr uint32_t kDeferFlag = 0x800u;   // CellWork::scan_set: a listed cell whose sub-cell stage is left to k_cube_prune (k_cube_lean wrote its list)
 
 __device__ __forceinline__ uint32_t sel3(uint32_t i, uint32_t x0, uint32_t x1, uint32_t x2)
 {
@@ -235,12 +235,15 @@ constexpr uint32_t kPairPending = 0xFFFFFFFEu;   // pair entry of a cell k_cube_
 //   kListsHead ...  items   [kListSegs][kItemSegCap] x 16 B: TWO sub-cells of one cell to scan and the union of their candidate
 //                           sets -- {cell | s0 << 15 | s1 << 18 (8: none) | n << 22, 12 centroids (u8, ascending)}: the scan
 //                           kernel needs nothing else, one wave per item
-//                   whole   [kListSegs][kListSegCap] cells scanned from their work records as before (unlisted / long cells, unions
-//                           of more than kItemCands candidates)
+//                   whole   [kListSegs][kWholeSegCap] cells scanned from their work records as before: cell | quarter << 16 -- quarter
+//                           4 = the whole cell (a listed cell with a union of more than kItemCands candidates), 0 .. 3 = that pair of
+//                           its sub-cells (a cell with more than kMaxListed candidates: no per-sub-cell sets, every colour against all
+//                           the cell's candidates, four waves)
 //                   entries [kListSegs][kListSegCap] cells that need a pair entry derived from their labels
 constexpr uint32_t kListSegs = 64, kListSegCap = kCells / kListSegs, kItemSegCap = 4u * kListSegCap, kItemCands = 12;
 constexpr uint32_t kListFar = 2 * kListSegs, kListsHead = 2 * kListSegs + 64;
-constexpr uint32_t kListItems = kListsHead, kListWhole = kListItems + 4u * kListSegs * kItemSegCap, kListEntries = kListWhole + kCells;
+constexpr uint32_t kWholeSegCap = 4u * kListSegCap;                // (a cell without per-sub-cell sets takes four places: a pair of sub-cells each)
+constexpr uint32_t kListItems = kListsHead, kListWhole = kListItems + 4u * kListSegs * kItemSegCap, kListEntries = kListWhole + kListSegs * kWholeSegCap;
 constexpr size_t kListsWords = kListEntries + kCells;
 // Without k_cube_prune (images with hot cells): the cells with LONG candidate lists -- a photograph's few hundred heavy cells, each
 // minutes of a wave's time compared with the others -- are listed by the stage kernel (kLongSegs counters behind kListFar, the cells in
@@ -396,9 +399,7 @@ __device__ __forceinline__ bool dominated(const Model &mdl, const float4 cj, con
 // ------------------------------------------------------------------------------------------
 // (6 waves per SIMD = 80 VGPRs, no spills: 35.9 -> 34.9 us against the 87 the allocator takes by itself; the scan kernel
 // forced from 71 to 64 VGPRs spills 7 dwords and loses 2 us)
-// DEFER (k <= 256, k_cube_prune follows): a cell with 2 .. kMaxListed candidates only gets its candidate list written; bounding the
-// candidates over its sub-cells, the decisions and everything after are k_cube_prune's, which has a thread per sub-cell.
-template <typename LabelT, bool SUMS, bool DEFER>
+template <typename LabelT, bool SUMS>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_cube_stage(const int64_t *__restrict__ agg,
                                                        const int64_t *__restrict__ sub_agg,
                                                        const uint32_t *__restrict__ work,
@@ -431,20 +432,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
     }
     for (uint32_t i = threadIdx.x; i < n_bins; i += kBlock) bins[i] = 0ull;
     __syncthreads();
-    if ((flags & kCubePruned) && blockIdx.x == 0u) {
-        // the head of k_cube_prune's lists: counters zero, and whether its test applies to this centroid table at all
-        uint32_t *lists = reinterpret_cast<uint32_t *>(cell_work + kCells);
-        bool far = false;
-        for (uint32_t i = threadIdx.x; i < k; i += kBlock) {
-            const float4 c = s_cent[i];
-            far = far || !(fabsf(c.x) <= 1024.0f && fabsf(c.y) <= 1024.0f && fabsf(c.z) <= 1024.0f);
-        }
-        const unsigned long long any_far = __ballot(far);
-        if (threadIdx.x < kListsHead) lists[threadIdx.x] = 0u;
-        __syncthreads();
-        if (any_far && (threadIdx.x & 63u) == 0u) lists[kListFar] = 1u;
-    }
-
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wv = threadIdx.x >> 6;
     uint32_t *s_list = s_list_all + wv * kMaxListed;
@@ -475,7 +462,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         const uint32_t w2_ = (wi_) + n_waves < n_work ? (wi_) + n_waves : safe_w;   /* past the end: a harmless repeat */ \
         cell_nn = SUMS ? work[1u + w2_ + vz] : w2_;                                                              \
         cbv_n = reinterpret_cast<const float *>(bounds + cell_n)[lane & 15u];   /* lane i: float i (VMEM: not tied to LDS waits) */ \
-        if (SUMS && !DEFER) {   /* (DEFER: only single-candidate and long-list cells need sums, and ask when they know) */ \
+        if (SUMS) {                                                                                              \
             sagg_n = sub_agg[(uint64_t)cell_n * 32u + (lane & 31u)];        /* lane 4 s + j: sum j of sub-cell s */ \
             scnt_n = sub_agg[(uint64_t)cell_n * 32u + 4u * (lane & 7u) + 3u];   /* lane s < 8: pixels in sub-cell s */ \
             cagg_n = agg[4ull * cell_n + (lane & 3u)];                                                           \
@@ -488,12 +475,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         cb.L0 = lane_value(cbv_n, 0); cb.L1 = lane_value(cbv_n, 1); cb.a0 = lane_value(cbv_n, 2); cb.a1 = lane_value(cbv_n, 3);
         cb.b0 = lane_value(cbv_n, 4); cb.b1 = lane_value(cbv_n, 5); cb.C0 = lane_value(cbv_n, 6); cb.C1 = lane_value(cbv_n, 7);
         cb.wC0 = lane_value(cbv_n, 8); cb.wC1 = lane_value(cbv_n, 9); cb.wH0 = lane_value(cbv_n, 10); cb.wH1 = lane_value(cbv_n, 11);
-        long long sagg = sagg_n, cagg = cagg_n, scnt = scnt_n;
+        const long long sagg = sagg_n, cagg = cagg_n, scnt = scnt_n;
         KMG_REQUEST_CELL(wi + n_waves);
         // the sub-cell bounds of THIS cell: requested now, needed after the cell's candidates are known
         const float4 *sbp = reinterpret_cast<const float4 *>(sub_bounds + (uint64_t)cell * 8u + sub_of_lane);
-        float4 sb0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), sb1 = sb0, sb2 = sb0;
-        if (!DEFER) { sb0 = sbp[0]; sb1 = sbp[1]; sb2 = sbp[2]; }   // (DEFER: only the rare long-list cells need them, and ask below)
+        const float4 sb0 = sbp[0], sb1 = sbp[1], sb2 = sbp[2];
 
         uint16_t *sub = sub_table + cell * 8u;
         uint16_t *cell_entry = sub_table + kSubCells + cell;       // 8x8x8 summary, same encoding
@@ -561,7 +547,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
                 if (lane == 0u) *cell_entry = (uint16_t)first;
             }
             if (lane == 0u) { cw->npop = 1u; cw->scan_set = 0u; }
-            if (SUMS && DEFER) cagg = agg[4ull * cell + (lane & 3u)];
             if (SUMS && lane < 4u) atomicAdd(bins + 4ull * first + lane, (unsigned long long)cagg);
             if (flags & 1u) {
 #pragma unroll
@@ -571,28 +556,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
             continue;
         }
         st_multi += 1;
-        if (DEFER && npop <= kMaxListed) {
-            // the candidate list (k <= 256: the masks are in registers), nothing else
-            uint32_t base = 0;
-#pragma unroll
-            for (uint32_t w = 0; w < 4u; ++w) {
-                if (w < words) {
-                    if ((mw[w] >> lane) & 1ull) s_list[base + bits_below_lane(mw[w])] = w * 64u + lane;
-                    base += (uint32_t)__builtin_popcountll(mw[w]);
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            const uint32_t cand = s_list[lane & (kMaxListed - 1u)];
-            __builtin_amdgcn_wave_barrier();
-            if (lane < kMaxListed) cw->list[lane] = (uint16_t)(lane < npop ? cand : 0u);
-            if (lane == 0u) {
-                cw->npop = npop;
-                cw->scan_set = 0x100u | kDeferFlag;
-                *pair_entry_ptr = kPairPending;
-            }
-            continue;
-        }
-
         // ---- 2. sub-cell stage: list the candidates, bound each over each sub-cell ----
         const bool listed = npop <= kMaxListed && !KMG_KNOCK(flags, 0x1000u);
         uint32_t my_cand = 0;                                       // lane p < npop: the p-th candidate
@@ -658,13 +621,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         } else if (words <= 4u && npop <= kMaxLong && !KMG_KNOCK(flags, 0x1000u)) {
             // long list (rare on noise, the heavy cells of a photograph): long_list_stage
             long_cell = true;
-            if (DEFER) {
-                sb0 = sbp[0]; sb1 = sbp[1]; sb2 = sbp[2];
-                if (SUMS) {
-                    sagg = sub_agg[(uint64_t)cell * 32u + (lane & 31u)];
-                    scnt = sub_agg[(uint64_t)cell * 32u + 4u * (lane & 7u) + 3u];
-                }
-            }
 #pragma unroll
             for (uint32_t w = 0; w < 4u; ++w)
                 if (w < words && lane == 0u) s_masks[w] = mw[w];
@@ -735,6 +691,130 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         atomicAdd(stats + 0, st_single); atomicAdd(stats + 1, st_multi); atomicAdd(stats + 2, st_decided);
         atomicAdd(stats + 3, st_scanned); atomicAdd(stats + 4, st_cands); atomicAdd(stats + 5, st_unlisted);
     }
+    if (SUMS) flush_bins(bins, k, 1u, 4u * k, sums, n_rows);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_cube_lean (32 < k <= 256, k_cube_prune follows): steps 1 of the stage kernel and no more -- the candidates of every cell of
+// the work list (one wave per cell, a lane's four centroids in registers for all its cells: 54 registers, 8 waves per SIMD),
+// then by their number: one -> the cell is decided as the stage kernel decides it; 2 .. kMaxListed -> the candidate list into
+// the cell's record, the rest is k_cube_prune's; more -> the cell is scanned without per-sub-cell sets (below).  Inside the
+// stage kernel this part took ~22 of its 32 us (80 registers, 6 waves, 44 spilled SGPRs, every cell a chain through code it does
+// not need).
+// Workgroup 0 also prepares the head of k_cube_prune's lists.
+// ------------------------------------------------------------------------------------------
+template <bool SUMS>
+__global__ __launch_bounds__(kBlock) void k_cube_lean(const int64_t *__restrict__ agg, const int64_t *__restrict__ sub_agg,
+                                                      const uint32_t *__restrict__ work,
+                                                      const CellBounds *__restrict__ bounds, const Centroid *__restrict__ cent,
+                                                      uint32_t k, uint64_t *__restrict__ masks_out, CellWork *__restrict__ cell_work,
+                                                      uint8_t *__restrict__ colour_labels, uint16_t *__restrict__ sub_table,
+                                                      int64_t *__restrict__ sums, uint32_t n_rows, uint32_t flags,
+                                                      unsigned long long *__restrict__ stats)
+{
+    extern __shared__ unsigned long long bins[];                   // k x 4 u64 (SUMS): the sums of single-candidate cells
+    __shared__ float4 s_cent[256];
+    __shared__ uint32_t s_list_all[(kBlock / 64) * kMaxListed];
+    {
+        float4 v = make_float4(1.0e18f, 0.0f, 0.0f, 0.0f);           // key ~ 1e36: never a candidate
+        if (threadIdx.x < k) { const Centroid c = cent[threadIdx.x]; v = make_float4(c.L, c.a, c.b, c.C); }
+        s_cent[threadIdx.x] = v;
+    }
+    if (SUMS) for (uint32_t i = threadIdx.x; i < 4u * k; i += kBlock) bins[i] = 0ull;
+    __syncthreads();
+    uint32_t *lists = reinterpret_cast<uint32_t *>(cell_work + kCells);
+    if (blockIdx.x == 0u) {
+        // the head of k_cube_prune's lists: counters zero, and whether its test applies to this centroid table at all
+        const float4 c = s_cent[threadIdx.x];
+        const bool far = threadIdx.x < k && !(fabsf(c.x) <= 1024.0f && fabsf(c.y) <= 1024.0f && fabsf(c.z) <= 1024.0f);
+        const unsigned long long any_far = __ballot(far);
+        if (threadIdx.x < kListsHead) lists[threadIdx.x] = 0u;
+        __syncthreads();
+        if (any_far && (threadIdx.x & 63u) == 0u) lists[kListFar] = 1u;
+    }
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    uint32_t *s_list = s_list_all + wv * kMaxListed;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / 64) + wv);
+    const uint32_t n_waves = gridDim.x * (kBlock / 64);
+    const uint32_t n_work = SUMS ? __builtin_amdgcn_readfirstlane(work[0]) : kCells;
+    const uint32_t words = (k + 63u) / 64u;
+    const uint32_t vz = opaque_vgpr_zero();
+    uint32_t *pair_entries = reinterpret_cast<uint32_t *>(sub_table + kSubCells + kCells);
+    float4 c4[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) c4[w] = s_cent[w * 64 + lane];      // this lane's four centroids: the same for every cell
+    unsigned long long st_single = 0, st_multi = 0, st_unlisted = 0;
+    // the next cell's index and bounds are requested while the current one is worked on
+    uint32_t cell_n = SUMS ? work[1u + (wave < n_work ? wave : 0u) + vz] : wave;
+    cell_n = __builtin_amdgcn_readfirstlane(cell_n);
+    float cbv_n = reinterpret_cast<const float *>(bounds + cell_n)[lane & 15u];
+    for (uint32_t wi = wave; wi < n_work; wi += n_waves) {
+        const uint32_t cell = cell_n;
+        const float cbv = cbv_n;
+        {
+            const uint32_t w2 = wi + n_waves < n_work ? wi + n_waves : wi;
+            cell_n = SUMS ? work[1u + w2 + vz] : w2;
+            cell_n = __builtin_amdgcn_readfirstlane(cell_n);
+            cbv_n = reinterpret_cast<const float *>(bounds + cell_n)[lane & 15u];
+        }
+        CellBounds cb;
+        cb.L0 = lane_value(cbv, 0); cb.L1 = lane_value(cbv, 1); cb.a0 = lane_value(cbv, 2); cb.a1 = lane_value(cbv, 3);
+        cb.b0 = lane_value(cbv, 4); cb.b1 = lane_value(cbv, 5); cb.C0 = lane_value(cbv, 6); cb.C1 = lane_value(cbv, 7);
+        cb.wC0 = lane_value(cbv, 8); cb.wC1 = lane_value(cbv, 9); cb.wH0 = lane_value(cbv, 10); cb.wH1 = lane_value(cbv, 11);
+        float lo[4], U = 3.0e38f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const KeyRange r = key_range(cb, c4[w].x, c4[w].y, c4[w].z, c4[w].w);
+            lo[w] = r.lo;
+            U = fminf(U, r.hi);                                     // padding entries: hi ~ 1e36
+        }
+        const float Us = mask_threshold(wave_min(U));
+        unsigned long long mw[4];
+        uint32_t npop = 0, first = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 4u; ++w) {
+            mw[w] = __ballot(w * 64u + lane < k && lo[w] <= Us);
+            if (npop == 0u && mw[w]) first = w * 64u + (uint32_t)__builtin_ctzll(mw[w]);
+            npop += (uint32_t)__builtin_popcountll(mw[w]);
+            if (lane == 0u && w < words) masks_out[(uint64_t)cell * words + w] = mw[w];
+        }
+        CellWork *cw = cell_work + cell;
+        if (npop == 1u) {
+            // the whole cell belongs to `first`: sums from the cell table, no per-colour traffic
+            if (lane == 0u) { pair_entries[cell] = pair_entry(first, first, 0u, 0u, 0u); cw->npop = 1u; cw->scan_set = 0u; }
+            if (SUMS && lane < 4u) atomicAdd(bins + 4ull * first + lane, (unsigned long long)agg[4ull * cell + lane]);
+            if (flags & 1u) {
+                uint8_t *cell_labels = colour_labels + (uint64_t)cell * kCellColours;
+#pragma unroll
+                for (uint32_t s = 0; s < 8u; ++s) store_labels64(cell_labels + s * 64u, first, lane);
+            }
+            st_single += 1;
+            continue;
+        }
+        st_multi += 1;
+        if (npop <= kMaxListed) {
+            uint32_t base = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < 4u; ++w) {
+                if ((mw[w] >> lane) & 1ull) s_list[base + bits_below_lane(mw[w])] = w * 64u + lane;
+                base += (uint32_t)__builtin_popcountll(mw[w]);
+            }
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t cand = s_list[lane & (kMaxListed - 1u)];
+            __builtin_amdgcn_wave_barrier();
+            if (lane < kMaxListed) cw->list[lane] = (uint16_t)(lane < npop ? cand : 0u);
+            if (lane == 0u) { cw->npop = npop; cw->scan_set = 0x100u | kDeferFlag; pair_entries[cell] = kPairPending; }
+        } else {
+            // more candidates than the sub-cell stage lists (a handful of cells on the benchmark image; photographs, where there
+            // are hundreds and they matter, have hot cells and take the pass without k_cube_prune): no per-sub-cell sets -- the
+            // scan takes every colour of the cell's occupied sub-cells against all its candidates, a pair of sub-cells per wave
+            const bool occ = lane < 8u && (SUMS ? sub_agg[(uint64_t)cell * 32u + 4u * (lane & 7u) + 3u] != 0 : true);
+            const uint32_t occ8 = (uint32_t)__ballot(occ);
+            if (lane == 0u) { cw->npop = npop; cw->scan_set = occ8; pair_entries[cell] = kPairPending; }
+            st_unlisted += 1;
+        }
+    }
+    if (stats && lane == 0u) { atomicAdd(stats + 0, st_single); atomicAdd(stats + 1, st_multi); atomicAdd(stats + 5, st_unlisted); }
     if (SUMS) flush_bins(bins, k, 1u, 4u * k, sums, n_rows);
 }
 
@@ -897,7 +977,9 @@ __global__ __launch_bounds__(kBlock) void k_cube_prune(const uint32_t *__restric
         const uint32_t n_un = (uint32_t)__builtin_popcount(un);
         const bool as_items = listed && group8_or((head && n_un > kItemCands) ? 1u : 0u) == 0u;
         const bool emit = head && as_items && !KMG_KNOCK(flags, 0x400u);
-        const bool need_whole = valid && sub == 0u && !KMG_KNOCK(flags, 0x400u) && (listed ? (scan8 != 0u && !as_items) : (ss & 0xFFu) != 0u);
+        // (a cell without per-sub-cell sets: lanes 0 .. 3 of its group each announce a pair of its sub-cells to scan)
+        const bool need_whole = valid && !KMG_KNOCK(flags, 0x400u) &&
+                                (listed ? (sub == 0u && scan8 != 0u && !as_items) : (sub < 4u && (uint32_t)__builtin_popcount(ss & 0xFFu) > 2u * sub));
         const bool need_entry = valid && sub == 0u && npop != 1u && !uniform;
         const unsigned long long item_b = __ballot(emit), whole_b = __ballot(need_whole), ent_b = __ballot(need_entry);
         const uint32_t seg = (base / 8u + (threadIdx.x >> 6)) & (kListSegs - 1u);
@@ -958,7 +1040,7 @@ __global__ __launch_bounds__(kBlock) void k_cube_prune(const uint32_t *__restric
             if (emit)
                 reinterpret_cast<uint4 *>(lists + kListItems)[seg * kItemSegCap + a_item + bits_below_lane(item_b)] =
                     make_uint4(cell | (sub << 15) | (s1 << 18) | (n_un << 22), iw0, iw1, iw2);
-            if (need_whole) lists[kListWhole + seg * kListSegCap + a_whole + bits_below_lane(whole_b)] = cell;
+            if (need_whole) lists[kListWhole + seg * kWholeSegCap + a_whole + bits_below_lane(whole_b)] = cell | ((listed ? 4u : sub) << 16);
             if (need_entry) lists[kListEntries + seg * kListSegCap + a_ent + bits_below_lane(ent_b)] = cell;
         }
     }
@@ -1026,7 +1108,7 @@ __global__ __launch_bounds__(kScanBlock) void k_cube_scan(const uint32_t *__rest
         n_whole = ((cnt_lo >> 21) | (cnt_hi << 11)) & 0x1FFFFFu;
     }
     const uint32_t n_work = from_list ? n_whole : (SUMS ? __builtin_amdgcn_readfirstlane(work[0]) : kCells);
-    const uint32_t *cells = from_list ? lists + kListWhole + seg * kListSegCap : (SUMS ? work + 1 : nullptr);
+    const uint32_t *cells = from_list ? lists + kListWhole + seg * kWholeSegCap : (SUMS ? work + 1 : nullptr);
     const uint32_t wi_step = from_list ? n_waves / kListSegs : n_waves;
     // kCubeSplitLong: the stage kernel's list of cells with long candidate lists comes first, FOUR waves per cell (a pair of its
     // sub-cells each); the walk over the work list then skips those cells
@@ -1054,6 +1136,7 @@ __global__ __launch_bounds__(kScanBlock) void k_cube_scan(const uint32_t *__rest
         } else {
             const uint32_t wj = wi - n_long4;
             cell = cells ? __builtin_amdgcn_readfirstlane(cells[wj]) : wj;
+            if (from_list) { quarter = cell >> 16; cell &= 0xFFFFu; }   // (k_cube_prune's entries: cell | quarter << 16)
         }
         const CellWork *cw = cell_work + cell;
         uint32_t scan_set = __builtin_amdgcn_readfirstlane(cw->scan_set);
@@ -2102,14 +2185,18 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
     // (the scan over items: one round of resident workgroups, each wave a few items with the next one's colours in flight)
     static const uint32_t g_items = env_grid("KMG_ITEMS_GRID", 896u) & ~7u;
     const uint32_t *lists = reinterpret_cast<const uint32_t *>(cw + kCells);
+    static const uint32_t g_lean = env_grid("KMG_LEAN_GRID", 2048u);
+    const size_t lds_lean = with_sums ? sizeof(unsigned long long) * 4ull * k : 0;
 #define KMG_CUBE(T, S)                                                                                                      \
     do {                                                                                                                    \
-        if (prune)                                                                                                          \
-            hipLaunchKernelGGL((k_cube_stage<T, S, true>), dim3(g_stage), dim3(kBlock), lds_stage, st, agg, sub_agg, work, bounds, \
+        if (prune) {                                                                                                        \
+            /* candidates + lists by k_cube_lean, the sub-cell stage by k_cube_prune */                                     \
+            hipLaunchKernelGGL((k_cube_lean<S>), dim3(g_lean), dim3(kBlock), lds_lean, st, agg, sub_agg, work, bounds, cent, k,    \
+                               masks, cw, (uint8_t *)colour_labels, sub_table, sums, n_rows, flags, stats);                  \
+        } else {                                                                                                            \
+            hipLaunchKernelGGL((k_cube_stage<T, S>), dim3(g_stage), dim3(kBlock), lds_stage, st, agg, sub_agg, work, bounds, \
                                sub_bounds, cent, k, masks, cw, (T *)colour_labels, sub_table, sums, n_rows, flags, stats);  \
-        else                                                                                                                \
-            hipLaunchKernelGGL((k_cube_stage<T, S, false>), dim3(g_stage), dim3(kBlock), lds_stage, st, agg, sub_agg, work, bounds, \
-                               sub_bounds, cent, k, masks, cw, (T *)colour_labels, sub_table, sums, n_rows, flags, stats);  \
+        }                                                                                                                   \
         if (prune)                                                                                                          \
             hipLaunchKernelGGL((k_cube_prune<S>), dim3(g_prune), dim3(kBlock), 0, st, work, sub_agg, sub_bounds, cent, k,   \
                                sub_affine, cw, (uint8_t *)colour_labels, sub_table, const_cast<uint32_t *>(lists), sums,    \
