@@ -10,11 +10,12 @@
 //                    4x4x4 sub-cell s with the sub-cell's own static bounds; per sub-cell the same U / lo test.
 //                    One candidate -> the sub-cell belongs to it: sums from the per-sub-cell table, 64 labels.
 //                    What is left goes into the cell's work record (candidate list, per-sub-cell sets).
-//   k_cube_prune  2b. (32 < k <= 256, images without hot cells) the dominance test per sub-cell -- a candidate that
-//                    another one beats on EVERY colour of the sub-cell (an affine model of the key difference with exact
-//                    residual ranges) leaves its set; sub-cells left with one candidate are decided, cells with one
-//                    label get their pair entry; what remains leaves as compact ITEMS (two sub-cells + their candidates,
-//                    16 bytes) for the scan and a list of cells for the entries.
+//   k_cube_lean   (32 < k <= 256, images without hot cells: instead of k_cube_stage) step 1 alone, a lane's four
+//   k_cube_prune  centroids in registers; then a thread per SUB-CELL: step 2 without a cross-lane operation, and 2b. the
+//                    dominance test -- a candidate that another one beats on EVERY colour of the sub-cell (an affine
+//                    model of the key difference with exact residual ranges) leaves its set; sub-cells left with one
+//                    candidate are decided, cells with one label get their pair entry; what remains leaves as compact
+//                    ITEMS (two sub-cells + their candidates, 16 bytes) for the scan and a list of cells for the entries.
 //   k_cube_scan   3. undecided sub-cells, two per step, ONE colour of each per lane: (L, a, b, C) and the count
 //                    are fully coalesced 1 KiB + 256 B loads per sub-cell; the colour scans the candidates of the
 //                    two sub-cells in index order (a centroid outside a sub-cell's own set is provably neither its
