@@ -517,9 +517,9 @@ def cpu_baseline(k, centroids4, seed, target_seconds=12.0):
 
 
 # speed-up of ONE 8192 x 8192, k = 256 image over N GPUs expected from this design (per-rank emulation on one
-# GPU, tools/strong_cells_per_rank.py, profiles/r05o_strong_cells_per_rank.json; the all-gather of the label tables / the all-reduce are not in these figures: with a
+# GPU, tools/strong_cells_per_rank.py, profiles/r05s_strong_cells_per_rank.json; the all-gather of the label tables / the all-reduce are not in these figures: with a
 # 2 MiB-per-peer all-gather over xGMI the cells estimate at N = 8 is ~2.5x)
-EXPECTED_SPEEDUP = {"cells": {2: 1.66, 4: 2.48, 8: 3.36}, "bands": {2: 1.35, 4: 1.60, 8: 1.83}}
+EXPECTED_SPEEDUP = {"cells": {2: 1.64, 4: 2.42, 8: 3.19}, "bands": {2: 1.35, 4: 1.60, 8: 1.83}}
 
 
 def _free_port():
