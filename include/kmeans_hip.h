@@ -22,6 +22,8 @@
  *  - every entry point is re-entrant on one kmg_processor (per-call workspace + stream), like
  *    the reference's Send+Sync ImageProcessor (core/examples/parallel.rs:36-50).
  *  - there is NO CPU fallback: without a usable HIP device kmg_processor_create fails.
+ *  - no C++ exception leaves the library (every entry point is a function-try-block): host allocation failures come back
+ *    as KMG_ERR_OUT_OF_MEMORY, any other internal exception as KMG_ERR_HIP -- the reference's anyhow::Result (lib.rs:38).
  */
 #ifndef KMEANS_HIP_H
 #define KMEANS_HIP_H
@@ -348,7 +350,15 @@ KMG_API int kmg_dither_threshold(const float *centroids4, uint32_t k, float *thr
  *   one process per GPU      rank 0 calls kmg_group_unique_id, the host runtime hands the 128 bytes to every process (MPI,
  *                            a file, torch.distributed ...), each calls kmg_group_create_rank(first_rank = its rank): the
  *                            kmg_group_lloyd_* calls then drive THIS process's band(s) of the sharded image.
- * Ranks are numbered first_rank + i for the group's local device i; `world` = ranks over all processes.                  */
+ * Ranks are numbered first_rank + i for the group's local device i; `world` = ranks over all processes.
+ *
+ * Failures.  A call that issues no collective (kmg_group_find, kmg_group_reduce_batch, kmg_group_palette / _reduce unless the
+ * k-means itself runs sharded) fails like its single-device counterpart: the error is returned, the group stays usable.  A rank
+ * that fails where a collective may be in flight (kmg_group_lloyd_*, the sharded full-resolution k-means) would leave its peers
+ * waiting inside RCCL for ever, so the communicators of this process are aborted (ncclCommAbort) and the group is BROKEN: every
+ * later call on it returns KMG_ERR_HIP at once; destroy it and create a new one (the other processes of a multi-process world
+ * see their own collectives fail or time out and must do the same).  No C++ exception crosses this ABI: std::bad_alloc comes
+ * back as KMG_ERR_OUT_OF_MEMORY, anything else as KMG_ERR_HIP with the text in kmg_last_error().                              */
 #define KMG_MAX_DEVICES 16
 #define KMG_UNIQUE_ID_BYTES 128
 /* kmg_group_options.flags */

@@ -100,9 +100,15 @@ hipError_t kmg::copy_host_image(kmg_processor *p, void *dst, const void *src, si
         if (r == hipSuccess) r = hipMemcpyWithStream((uint8_t *)dst + off, (const uint8_t *)src + off, nb, kind, streams[i]);
         results[i] = r;
     };
-    for (size_t i = 1; i < kCopyParts; ++i) workers[i - 1] = std::thread(copy_part, i);
+    // (a std::thread that cannot start throws std::system_error: the part is then copied on this thread, and the workers
+    // already running are joined whatever happens -- a joinable std::thread that goes out of scope ends the process)
+    for (size_t i = 1; i < kCopyParts; ++i) {
+        results[i] = hipErrorUnknown;
+        try { workers[i - 1] = std::thread(copy_part, i); } catch (const std::exception &) { copy_part(i); }
+    }
     copy_part(0);
-    for (size_t i = 1; i < kCopyParts; ++i) workers[i - 1].join();
+    for (size_t i = 1; i < kCopyParts; ++i)
+        if (workers[i - 1].joinable()) workers[i - 1].join();
     for (size_t i = 0; i < kCopyParts; ++i)
         if (results[i] != hipSuccess) return results[i];
     return hipSuccess;
@@ -194,17 +200,18 @@ void kmg::sorted_palette_of(const float *c4, uint32_t color_count, uint8_t *out_
 // ColorTree::{add_color, reduce} (core/src/octree.rs): host helper, needs no device
 extern "C" int kmg_octree_palette(const uint8_t *rgba, uint64_t n_pixels, uint32_t color_count, uint8_t *out_rgba,
                                   uint32_t *out_count)
-{
+try {
     if (!rgba || !out_rgba || !out_count || n_pixels == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad octree arguments");
     const std::vector<std::array<uint8_t, 4>> c = octree_palette(rgba, n_pixels, color_count);
     for (size_t i = 0; i < c.size(); ++i) memcpy(out_rgba + 4 * i, c[i].data(), 4);
     *out_count = (uint32_t)c.size();
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 extern "C" int kmg_find(kmg_processor *p, const uint8_t *rgba, uint32_t w, uint32_t h, const uint8_t *palette_rgba,
                         uint32_t n_colors, int mode, uint8_t *out_rgba)
-{
+try {
     int rc;
     if ((rc = check_image(p, rgba, w, h)) != KMG_OK) return rc;
     if (!palette_rgba || n_colors == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "palette is empty");
@@ -218,10 +225,11 @@ extern "C" int kmg_find(kmg_processor *p, const uint8_t *rgba, uint32_t w, uint3
     if ((rc = upload_image(p, rgba, w, h, sg.st, img)) != KMG_OK) return rc;
     return apply_and_download(p, (const uint8_t *)img.ptr, w, h, c4.data(), n_colors, mode, sg.st, out_rgba);
 }
+KMG_ABI_CATCH
 
 extern "C" int kmg_reduce(kmg_processor *p, const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t color_count,
                           int algo, int mode, uint8_t *out_rgba)
-{
+try {
     int rc;
     if ((rc = check_image(p, rgba, w, h)) != KMG_OK) return rc;
     if (color_count == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "k must be an integer higher than 0");
@@ -240,6 +248,8 @@ extern "C" int kmg_reduce(kmg_processor *p, const uint8_t *rgba, uint32_t w, uin
     if (algo == KMG_ALGO_OCTREE) {                                     // lib.rs:133-136
         std::vector<std::array<uint8_t, 4>> colors;
         if ((rc = octree_palette_of(p, (const uint8_t *)img.ptr, w, h, color_count, sg.st, colors)) != KMG_OK) return rc;
+        if (colors.empty()) return fail(KMG_ERR_INVALID_ARGUMENT, "the octree returned no colour");
+        if (colors.size() > KMG_MAX_K) return fail(KMG_ERR_UNSUPPORTED, "the octree returned %zu colours, more than KMG_MAX_K = %u", colors.size(), KMG_MAX_K);
         std::vector<float> oc4(4 * colors.size());
         if ((rc = kmg_palette_to_centroids(colors[0].data(), (uint32_t)colors.size(), oc4.data())) != KMG_OK) return rc;
         return apply_and_download(p, (const uint8_t *)img.ptr, w, h, oc4.data(), (uint32_t)colors.size(), mode, sg.st, out_rgba);
@@ -257,10 +267,11 @@ extern "C" int kmg_reduce(kmg_processor *p, const uint8_t *rgba, uint32_t w, uin
     }
     return rc;
 }
+KMG_ABI_CATCH
 
 extern "C" int kmg_palette(kmg_processor *p, const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t color_count,
                            int algo, uint8_t *out_rgba, uint32_t *out_count)
-{
+try {
     int rc;
     if ((rc = check_image(p, rgba, w, h)) != KMG_OK) return rc;
     if (color_count == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "k must be an integer higher than 0");
@@ -286,4 +297,5 @@ extern "C" int kmg_palette(kmg_processor *p, const uint8_t *rgba, uint32_t w, ui
     *out_count = color_count;
     return KMG_OK;
 }
+KMG_ABI_CATCH
 

@@ -57,7 +57,7 @@ static bool dither_takes_lists(uint32_t k)
 }
 
 extern "C" int kmg_debug_check_dither_masks(kmg_processor *p, const float *c4, uint32_t k, uint64_t *violations, void *stream)
-{
+try {
     if (!p || !c4 || !violations || k < 2 || k > KMG_MAX_K) return fail(KMG_ERR_INVALID_ARGUMENT, "bad check_dither_masks arguments");
     HIP_TRY(hipSetDevice(p->device));
     int rc;
@@ -114,11 +114,12 @@ extern "C" int kmg_debug_check_dither_masks(kmg_processor *p, const float *c4, u
     }
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 // test support: exhaustive validation of the meld candidate masks for a centroid table (k >= 2): over all
 // 2^24 colours the two closest centroids found among the cell's candidates must be those of the full scan.
 extern "C" int kmg_debug_check_meld_masks(kmg_processor *p, const float *c4, uint32_t k, uint64_t *violations, void *stream)
-{
+try {
     if (!p || !c4 || !violations || k < 2 || k > KMG_MAX_K) return fail(KMG_ERR_INVALID_ARGUMENT, "bad check_meld_masks arguments");
     HIP_TRY(hipSetDevice(p->device));
     int rc;
@@ -150,6 +151,7 @@ extern "C" int kmg_debug_check_meld_masks(kmg_processor *p, const float *c4, uin
     *violations = h;
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 // ---- the output pass as a PLAN: everything that depends on the centroid table only -- the device copy of centroids and palette,
 // the threshold, the candidate lists / masks or the label tables of the colour cube -- is built once (asynchronously on the
@@ -175,7 +177,7 @@ struct kmg_apply_plan {
 
 extern "C" int kmg_apply_plan_create(kmg_processor *p, const float *c4, uint32_t k, int mode, uint64_t n_pixels_hint, void *stream,
                                      kmg_apply_plan **out)
-{
+try {
     if (!p || !c4 || !out || k == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad apply_plan arguments");
     *out = nullptr;
     if (k > KMG_MAX_K) return fail(KMG_ERR_UNSUPPORTED, "k = %u exceeds KMG_MAX_K = %u", k, KMG_MAX_K);
@@ -287,10 +289,11 @@ extern "C" int kmg_apply_plan_create(kmg_processor *p, const float *c4, uint32_t
     *out = pl;
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 extern "C" int kmg_apply_plan_run(kmg_apply_plan *pl, const uint8_t *d_rgba, uint32_t w, uint32_t rows, uint32_t row0, uint8_t *d_out,
                                   void *stream)
-{
+try {
     if (!pl || !d_rgba || !d_out || !w || !rows) return fail(KMG_ERR_INVALID_ARGUMENT, "bad apply_plan_run arguments");
     // the output kernels keep the pixel index (and from it the Bayer coordinates) in 32 bits
     if ((uint64_t)w * rows > 0xFFFFFFFFull) return fail(KMG_ERR_UNSUPPORTED, "band has more than 2^32-1 pixels");
@@ -326,21 +329,23 @@ extern "C" int kmg_apply_plan_run(kmg_apply_plan *pl, const uint8_t *d_rgba, uin
     if (e != hipSuccess) return fail(KMG_ERR_HIP, "apply failed: %s", hipGetErrorString(e));
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 // The plan's scratch block goes back to the processor: every stream that ran the plan must have been synchronised by the caller,
 // or `synchronise` != 0 makes this call wait for the whole device first.
 extern "C" void kmg_apply_plan_destroy(kmg_apply_plan *pl, int synchronise)
-{
+try {
     if (!pl) return;
     (void)hipSetDevice(pl->p->device);
     if (synchronise) (void)hipDeviceSynchronize();
     if (pl->ready) (void)hipEventDestroy(pl->ready);
     delete pl;                                                        // (~ArenaGuard returns the block)
 }
+KMG_ABI_CATCH_VOID
 
 extern "C" int kmg_dev_apply(kmg_processor *p, const uint8_t *d_rgba, uint32_t w, uint32_t rows, uint32_t row0,
                              const float *c4, uint32_t k, int mode, uint8_t *d_out, void *stream)
-{
+try {
     if (!p || !d_rgba || !d_out || !c4 || !w || !rows || k == 0)
         return fail(KMG_ERR_INVALID_ARGUMENT, "bad apply arguments");
     if ((uint64_t)w * rows > 0xFFFFFFFFull) return fail(KMG_ERR_UNSUPPORTED, "band has more than 2^32-1 pixels");
@@ -354,4 +359,5 @@ extern "C" int kmg_dev_apply(kmg_processor *p, const uint8_t *d_rgba, uint32_t w
     if (e2 != hipSuccess) return fail(KMG_ERR_HIP, "apply failed: %s", hipGetErrorString(e2));
     return KMG_OK;
 }
+KMG_ABI_CATCH
 

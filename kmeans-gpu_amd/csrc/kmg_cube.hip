@@ -2118,12 +2118,7 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
                             sizeof(float4) * (kScanBlock / 64) * kMaxListed + (k <= 256 ? 1u : 2u) * (kScanBlock / 64) * kCellColours;
     {
         // the largest k (KMG_MAX_K) takes ~150 KiB per workgroup: refuse a launch the device cannot hold instead of failing in it
-        static const size_t lds_max = [] {
-            int dev = 0, v = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v <= 0)
-                v = 65536;
-            return (size_t)v;
-        }();
+        const size_t lds_max = device_info().lds_max;
         if (lds_stage > lds_max || lds_scan > lds_max) return hipErrorInvalidValue;
     }
     // small centroid tables: the whole pass in one launch (k_cube_small) + the tail workgroup

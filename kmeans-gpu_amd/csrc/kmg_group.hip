@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -176,7 +177,8 @@ struct GroupRank {
     hipStream_t st_comm = nullptr;   // KMG_GROUP_OVERLAP: the all-reduce of the sums beside the label pass
     hipEvent_t ev_sums = nullptr, ev_done = nullptr, ev_comm = nullptr;
     hipStream_t comm_last = nullptr; // the stream this rank's communicator was last used on (its operations stay ordered)
-    ncclComm_t comm = nullptr;
+    ncclComm_t comm = nullptr;       // written once, at creation (worker threads read it without a lock)
+    bool comm_aborted = false;       // ncclCommAbort has taken it (kmg_group::abort_mu)
     void *lb_tmp = nullptr;          // loopback: the reduction's result before it replaces the operand
     size_t lb_cap = 0;
     // host-buffer calls: the band, its output, the shrunk working image (grow-only, kept between calls)
@@ -195,8 +197,8 @@ struct kmg_group {
     Barrier barrier;                 // the local ranks' host rendezvous (loopback exchange, host-buffer calls)
     std::vector<const void *> lb_ptrs;
     std::mutex call_mu;              // one group operation at a time: the ranks' collectives must pair up
-    std::mutex abort_mu;
-    bool broken = false;
+    std::mutex abort_mu;             // group_abort: two ranks may fail at once
+    std::atomic<bool> broken{false}; // a rank failed while a collective may have been in flight: the communicators are gone
 };
 
 namespace {
@@ -217,7 +219,7 @@ void worker_main(GroupRank *r)
             task.swap(w.task);
             w.has_task = false;
         }
-        const int rc = task();
+        const int rc = task();                                      // (run_all's task: catches everything)
         {
             std::lock_guard<std::mutex> lock(w.mu);
             w.rc = rc;
@@ -228,40 +230,59 @@ void worker_main(GroupRank *r)
     }
 }
 
-// a rank that fails leaves the others waiting in a collective or at the barrier: release them, the group is finished
+// A rank that fails while a collective may be in flight leaves the others waiting inside RCCL or at the barrier: release
+// them -- the communicators are aborted and the group is finished (every later call returns KMG_ERR_HIP; kmeans_hip.h).
 void group_abort(kmg_group *g)
 {
-    std::lock_guard<std::mutex> lock(g->abort_mu);                  // (two ranks may fail at once)
+    std::lock_guard<std::mutex> lock(g->abort_mu);
+    g->broken.store(true);
     g->barrier.abort();
     if (g->rccl)
         for (GroupRank &r : g->ranks)
-            if (r.comm) { (void)g->rccl->CommAbort(r.comm); r.comm = nullptr; }
-    g->broken = true;
+            if (r.comm && !r.comm_aborted) { (void)g->rccl->CommAbort(r.comm); r.comm_aborted = true; }
+}
+
+// what a failing rank does for the others: with a collective possibly in flight the group is aborted; a call without one
+// (the host-buffer calls over row bands: upload, shrink, output pass, download) only releases the ranks that wait at THIS
+// call's barrier -- run_all resets it at the next call and the group stays usable, like a kmg_processor after a failed call.
+void rank_failed(kmg_group *g, bool collective)
+{
+    if (collective && g->collectives) group_abort(g);
+    else g->barrier.abort();
+}
+
+int guarded(const std::function<int(GroupRank &)> &fn, GroupRank &r) noexcept
+{
+    try { return fn(r); } catch (...) { return abi_trap(); }
 }
 
 // fn(rank) on every local rank -- on the calling thread for a group of one, else on the ranks' worker threads, side by
-// side -- and the first failure (with its message on the CALLING thread) as the result
-int run_all(kmg_group *g, const std::function<int(GroupRank &)> &fn)
+// side -- and the first failure (with its message on the CALLING thread) as the result.  `collective`: fn may issue RCCL calls.
+int run_all(kmg_group *g, bool collective, const std::function<int(GroupRank &)> &fn)
 {
-    if (g->broken) return fail(KMG_ERR_HIP, "the group is broken: an earlier call failed on one of its ranks");
+    if (g->broken.load()) return fail(KMG_ERR_HIP, "the group is broken: an earlier call failed on one of its ranks while a collective was in flight");
+    g->barrier.reset();
     if (g->n_local == 1) {
         GroupRank &r = g->ranks[0];
         int rc = hipSetDevice(r.device) == hipSuccess ? KMG_OK : fail(KMG_ERR_HIP, "hipSetDevice(%d) failed", r.device);
-        if (rc == KMG_OK) rc = fn(r);
-        if (rc != KMG_OK && g->collectives) group_abort(g);
+        if (rc == KMG_OK) rc = guarded(fn, r);
+        if (rc != KMG_OK) {
+            const std::string msg = kmg_last_error();
+            rank_failed(g, collective);
+            return fail(rc, "%s", msg.c_str());
+        }
         return rc;
     }
-    g->barrier.reset();
     for (GroupRank &r : g->ranks) {
         Worker &w = *r.w;
         std::lock_guard<std::mutex> lock(w.mu);
         GroupRank *rp = &r;
-        w.task = [rp, &fn, g]() {
-            const int rc = fn(*rp);
+        w.task = [rp, &fn, g, collective]() {
+            const int rc = guarded(fn, *rp);
             if (rc != KMG_OK) {
-                // keep this rank's message: aborting the others must not replace it
+                // keep this rank's message: releasing the others must not replace it
                 const std::string msg = kmg_last_error();
-                group_abort(g);
+                rank_failed(g, collective);
                 return fail(rc, "%s", msg.c_str());
             }
             return rc;
@@ -276,9 +297,9 @@ int run_all(kmg_group *g, const std::function<int(GroupRank &)> &fn)
         Worker &w = *r.w;
         std::unique_lock<std::mutex> lock(w.mu);
         w.cv.wait(lock, [&] { return w.done; });
-        // (the rank that failed FIRST aborted the others, whose own failures are consequences: prefer a message that does
-        // not speak of an abort)
-        if (w.rc != KMG_OK && (rc == KMG_OK || err.find("broken") != std::string::npos)) { rc = w.rc; err = w.err; }
+        // (the rank that failed FIRST released the others, whose own failures are consequences: prefer a message that does
+        // not speak of another rank)
+        if (w.rc != KMG_OK && (rc == KMG_OK || err.find("another rank failed") != std::string::npos)) { rc = w.rc; err = w.err; }
     }
     if (rc != KMG_OK) return fail(rc, "%s", err.c_str());
     return KMG_OK;
@@ -316,7 +337,7 @@ size_t op_bytes(Op op) { return op == Op::SumU32 ? 4u : 8u; }
 int lb_rendezvous(GroupRank &r, hipStream_t st)
 {
     HIP_TRY(hipStreamSynchronize(st));
-    if (!r.g->barrier.wait()) return fail(KMG_ERR_HIP, "the group is broken: another rank failed");
+    if (!r.g->barrier.wait()) return fail(KMG_ERR_HIP, "another rank failed");
     return KMG_OK;
 }
 
@@ -363,6 +384,7 @@ int allreduce(GroupRank &r, void *buf, size_t count, Op op, hipStream_t st)
     kmg_group *g = r.g;
     if (!g->collectives) return KMG_OK;
     if (g->loopback) return lb_allreduce(r, buf, count, op, st);
+    if (g->broken.load()) return fail(KMG_ERR_HIP, "another rank failed");      // (its communicator may be gone)
     KMG_TRY(comm_on(r, st));
     const ncclDataType_t dt = op == Op::SumI64 ? ncclInt64 : op == Op::MaxU64 ? ncclUint64 : ncclUint32;
     NCCL_TRY(g->rccl, g->rccl->AllReduce(buf, buf, count, dt, op == Op::MaxU64 ? ncclMax : ncclSum, r.comm, st));
@@ -388,6 +410,7 @@ int allgather_shares(GroupRank &r, void *buf, uint64_t units, size_t unit, hipSt
         KMG_TRY(lb_rendezvous(r, st));
         return KMG_OK;
     }
+    if (g->broken.load()) return fail(KMG_ERR_HIP, "another rank failed");
     KMG_TRY(comm_on(r, st));
     if (units % world == 0) {
         const size_t share = off(1);
@@ -423,15 +446,16 @@ void band_of(uint32_t height, uint32_t rank, uint32_t world, uint32_t *r0, uint3
 // kmg_group: creation
 // ---------------------------------------------------------------------------------------------
 extern "C" void kmg_default_group_options(kmg_group_options *opt)
-{
+try {
     if (!opt) return;
     memset(opt, 0, sizeof *opt);
     opt->struct_size = sizeof(kmg_group_options);
     kmg_default_options(&opt->processor);
 }
+KMG_ABI_CATCH_VOID
 
 extern "C" int kmg_group_unique_id(uint8_t id[KMG_UNIQUE_ID_BYTES])
-{
+try {
     static_assert(sizeof(ncclUniqueId) == KMG_UNIQUE_ID_BYTES, "KMG_UNIQUE_ID_BYTES");
     if (!id) return fail(KMG_ERR_INVALID_ARGUMENT, "id is NULL");
     const Rccl *rccl = nullptr;
@@ -441,6 +465,7 @@ extern "C" int kmg_group_unique_id(uint8_t id[KMG_UNIQUE_ID_BYTES])
     memcpy(id, &u, sizeof u);
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 static int group_create_impl(const kmg_group_options *opt, const uint8_t *id, uint32_t first_rank, uint32_t world, kmg_group **out)
 {
@@ -528,17 +553,20 @@ static int group_create_impl(const kmg_group_options *opt, const uint8_t *id, ui
     return KMG_OK;
 }
 
-extern "C" int kmg_group_create(const kmg_group_options *opt, kmg_group **out) { return group_create_impl(opt, nullptr, 0, 0, out); }
+extern "C" int kmg_group_create(const kmg_group_options *opt, kmg_group **out)
+try { return group_create_impl(opt, nullptr, 0, 0, out); }
+KMG_ABI_CATCH
 
 extern "C" int kmg_group_create_rank(const kmg_group_options *opt, const uint8_t id[KMG_UNIQUE_ID_BYTES], uint32_t first_rank,
                                      uint32_t world, kmg_group **out)
-{
+try {
     if (!id) return fail(KMG_ERR_INVALID_ARGUMENT, "id is NULL (kmg_group_unique_id on rank 0, handed to every process)");
     return group_create_impl(opt, id, first_rank, world, out);
 }
+KMG_ABI_CATCH
 
 extern "C" void kmg_group_destroy(kmg_group *g)
-{
+try {
     if (!g) return;
     for (GroupRank &r : g->ranks) {
         if (r.w) {
@@ -550,7 +578,7 @@ extern "C" void kmg_group_destroy(kmg_group *g)
         (void)hipSetDevice(r.device);
         if (r.st) (void)hipStreamSynchronize(r.st);
         if (r.st_comm) (void)hipStreamSynchronize(r.st_comm);
-        if (r.comm && g->rccl) (void)g->rccl->CommDestroy(r.comm);
+        if (r.comm && g->rccl && !r.comm_aborted) (void)g->rccl->CommDestroy(r.comm);
         for (void *ptr : {r.lb_tmp, r.d_in, r.d_out, r.d_small})
             if (ptr) (void)hipFree(ptr);
         if (r.ev_sums) (void)hipEventDestroy(r.ev_sums);
@@ -562,9 +590,10 @@ extern "C" void kmg_group_destroy(kmg_group *g)
     }
     delete g;
 }
+KMG_ABI_CATCH_VOID
 
 extern "C" int kmg_group_info(kmg_group *g, uint32_t *n_local, uint32_t *first_rank, uint32_t *world, int *rccl_version)
-{
+try {
     if (!g) return fail(KMG_ERR_INVALID_ARGUMENT, "group is NULL");
     if (n_local) *n_local = g->n_local;
     if (first_rank) *first_rank = g->first_rank;
@@ -572,6 +601,7 @@ extern "C" int kmg_group_info(kmg_group *g, uint32_t *n_local, uint32_t *first_r
     if (rccl_version) *rccl_version = g->rccl_version;
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 extern "C" kmg_processor *kmg_group_processor(kmg_group *g, uint32_t i) { return g && i < g->n_local ? g->ranks[i].p : nullptr; }
 extern "C" void *kmg_group_stream(kmg_group *g, uint32_t i) { return g && i < g->n_local ? (void *)g->ranks[i].st : nullptr; }
@@ -811,51 +841,57 @@ int group_lloyd_bind(kmg_group_lloyd *gl, const uint8_t *const *d_rgba, const ui
 }  // namespace
 
 extern "C" int kmg_group_lloyd_create(kmg_group *g, uint32_t k, kmg_group_lloyd **out)
-{
+try {
     if (!g || !out) return fail(KMG_ERR_INVALID_ARGUMENT, "bad group_lloyd_create arguments");
     *out = nullptr;
     std::lock_guard<std::mutex> lock(g->call_mu);
     return group_lloyd_new(g, k, out);
 }
+KMG_ABI_CATCH
 
 extern "C" void kmg_group_lloyd_destroy(kmg_group_lloyd *gl)
-{
+try {
     if (!gl) return;
     std::lock_guard<std::mutex> lock(gl->g->call_mu);
     group_lloyd_free(gl);
 }
+KMG_ABI_CATCH_VOID
 
 extern "C" int kmg_group_lloyd_bind(kmg_group_lloyd *gl, const uint8_t *const *d_rgba, const uint32_t *row0, const uint32_t *rows,
                                     uint32_t width, uint32_t height, uint32_t *const *d_labels, uint32_t flags)
-{
+try {
     if (!gl) return fail(KMG_ERR_INVALID_ARGUMENT, "group_lloyd is NULL");
     std::lock_guard<std::mutex> lock(gl->g->call_mu);
     return group_lloyd_bind(gl, d_rgba, row0, rows, width, height, d_labels, flags);
 }
+KMG_ABI_CATCH
 
 extern "C" int kmg_group_lloyd_set_centroids(kmg_group_lloyd *gl, const float *centroids4)
-{
+try {
     if (!gl || !centroids4) return fail(KMG_ERR_INVALID_ARGUMENT, "bad group_lloyd_set_centroids arguments");
     std::lock_guard<std::mutex> lock(gl->g->call_mu);
     for (uint32_t i = 0; i < gl->g->n_local; ++i) KMG_TRY(kmg_lloyd_set_centroids(gl->r[i].s, centroids4, gl->g->ranks[i].st));
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 extern "C" int kmg_group_lloyd_get_centroids(kmg_group_lloyd *gl, float *centroids4)
-{
+try {
     if (!gl || !centroids4) return fail(KMG_ERR_INVALID_ARGUMENT, "bad group_lloyd_get_centroids arguments");
     std::lock_guard<std::mutex> lock(gl->g->call_mu);
     return kmg_lloyd_get_centroids(gl->r[0].s, centroids4, gl->g->ranks[0].st);      // (identical on every rank)
 }
+KMG_ABI_CATCH
 
 #define KMG_GROUP_CALL(name, body)                                                                     \
     extern "C" int name(kmg_group_lloyd *gl)                                                           \
-    {                                                                                                  \
+    try {                                                                                              \
         if (!gl) return fail(KMG_ERR_INVALID_ARGUMENT, #name ": group_lloyd is NULL");                 \
         if (!gl->bound) return fail(KMG_ERR_INVALID_ARGUMENT, #name ": no bands (kmg_group_lloyd_bind)"); \
         std::lock_guard<std::mutex> lock(gl->g->call_mu);                                              \
-        return run_all(gl->g, [gl](GroupRank &r) -> int { (void)gl; body; });                                    \
-    }
+        return run_all(gl->g, true, [gl](GroupRank &r) -> int { (void)gl; body; });                    \
+    }                                                                                                  \
+    KMG_ABI_CATCH
 
 KMG_GROUP_CALL(kmg_group_lloyd_init, return rank_init(gl, r))
 KMG_GROUP_CALL(kmg_group_lloyd_prime, return rank_prime(gl, r))
@@ -863,24 +899,26 @@ KMG_GROUP_CALL(kmg_group_lloyd_step, return rank_step(gl, r))
 KMG_GROUP_CALL(kmg_group_lloyd_sync, HIP_TRY(hipStreamSynchronize(r.st)); return KMG_OK)
 
 extern "C" int kmg_group_lloyd_run(kmg_group_lloyd *gl, uint32_t *iterations)
-{
+try {
     if (!gl) return fail(KMG_ERR_INVALID_ARGUMENT, "kmg_group_lloyd_run: group_lloyd is NULL");
     if (!gl->bound) return fail(KMG_ERR_INVALID_ARGUMENT, "kmg_group_lloyd_run: no bands (kmg_group_lloyd_bind)");
     if (gl->flags & KMG_GROUP_FUSED_UPDATE)
         return fail(KMG_ERR_INVALID_ARGUMENT, "kmg_group_lloyd_run: KMG_GROUP_FUSED_UPDATE is for _prime / _step (the loop reads the convergence count between update and re-assignment)");
     std::lock_guard<std::mutex> lock(gl->g->call_mu);
     std::vector<uint32_t> its(gl->g->n_local, 0u);
-    KMG_TRY(run_all(gl->g, [&](GroupRank &r) { return rank_run(gl, r, &its[r.idx]); }));
+    KMG_TRY(run_all(gl->g, true, [&](GroupRank &r) { return rank_run(gl, r, &its[r.idx]); }));
     if (iterations) *iterations = its[0];
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 extern "C" kmg_lloyd *kmg_group_lloyd_member(kmg_group_lloyd *gl, uint32_t i, int *strategy)
-{
+try {
     if (!gl || i >= gl->r.size()) return nullptr;
     if (strategy) *strategy = gl->r[i].table ? 1 : 0;
     return gl->r[i].s;
 }
+KMG_ABI_CATCH_NULL
 
 // ---------------------------------------------------------------------------------------------
 // host-buffer API over a one-process group (ImageProcessor::{palette, find, reduce}, lib.rs:67-164)
@@ -925,7 +963,7 @@ int host_call_rank(kmg_group *g, HostCall &c, GroupRank &r)
     const size_t row_bytes = (size_t)c.w * 4u;
     const uint32_t halo = (c.shrink && rows && r1 < c.h) ? 1u : 0u;  // the bilinear shrink samples the row below a band's last
     auto meet = [&]() -> int {
-        if (g->n_local > 1 && !g->barrier.wait()) return fail(KMG_ERR_HIP, "the group is broken: another rank failed");
+        if (g->n_local > 1 && !g->barrier.wait()) return fail(KMG_ERR_HIP, "another rank failed");
         return KMG_OK;
     };
     if (rows) {
@@ -960,6 +998,8 @@ int host_call_rank(kmg_group *g, HostCall &c, GroupRank &r)
             const uint8_t *host_img = c.shrink ? c.shrunk.data() : c.rgba;
             if (c.algo == KMG_ALGO_OCTREE) {
                 c.colors = octree_sorted_palette(host_img, (uint64_t)c.sw * c.sh, c.k);            // lib.rs:288-331
+                if (c.colors.empty()) return fail(KMG_ERR_INVALID_ARGUMENT, "the octree returned no colour");
+                if (c.colors.size() > KMG_MAX_K) return fail(KMG_ERR_UNSUPPORTED, "the octree returned %zu colours, more than KMG_MAX_K = %u", c.colors.size(), KMG_MAX_K);
                 c.k = (uint32_t)c.colors.size();
                 c.c4.resize(4u * (size_t)c.k);
                 KMG_TRY(kmg_palette_to_centroids(c.colors[0].data(), c.k, c.c4.data()));
@@ -1024,14 +1064,15 @@ int host_call(kmg_group *g, HostCall &c)
         guard.gl = c.gl;
         KMG_TRY(group_lloyd_bind(c.gl, (const uint8_t *const *)bands.data(), row0.data(), rows.data(), c.w, c.h, nullptr, 0u));
     }
-    return run_all(g, [&](GroupRank &r) { return host_call_rank(g, c, r); });
+    // (only the sharded full-resolution k-means issues collectives: everything else is per-band work with host rendezvous)
+    return run_all(g, c.sharded_kmeans, [&](GroupRank &r) { return host_call_rank(g, c, r); });
 }
 
 }  // namespace
 
 extern "C" int kmg_group_palette(kmg_group *g, const uint8_t *rgba, uint32_t width, uint32_t height, uint32_t color_count, int algo,
                                  uint8_t *out_rgba, uint32_t *out_count)
-{
+try {
     if (color_count == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "k must be an integer higher than 0");
     if (!out_rgba || !out_count) return fail(KMG_ERR_INVALID_ARGUMENT, "output pointer is NULL");
     if (algo != KMG_ALGO_KMEANS && algo != KMG_ALGO_OCTREE) return fail(KMG_ERR_INVALID_ARGUMENT, "unknown algorithm %d", algo);
@@ -1048,10 +1089,11 @@ extern "C" int kmg_group_palette(kmg_group *g, const uint8_t *rgba, uint32_t wid
     *out_count = color_count;
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 extern "C" int kmg_group_find(kmg_group *g, const uint8_t *rgba, uint32_t width, uint32_t height, const uint8_t *palette_rgba,
                               uint32_t n_colors, int mode, uint8_t *out_rgba)
-{
+try {
     if (!palette_rgba || n_colors == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "palette is empty");
     if (!out_rgba) return fail(KMG_ERR_INVALID_ARGUMENT, "output pointer is NULL");
     if (mode < KMG_MODE_REPLACE || mode > KMG_MODE_MELD) return fail(KMG_ERR_INVALID_ARGUMENT, "unknown mode %d", mode);
@@ -1062,10 +1104,11 @@ extern "C" int kmg_group_find(kmg_group *g, const uint8_t *rgba, uint32_t width,
     KMG_TRY(kmg_palette_to_centroids(palette_rgba, n_colors, c.c4.data()));     // lib.rs:86-87
     return host_call(g, c);
 }
+KMG_ABI_CATCH
 
 extern "C" int kmg_group_reduce(kmg_group *g, const uint8_t *rgba, uint32_t width, uint32_t height, uint32_t color_count, int algo,
                                 int mode, uint8_t *out_rgba)
-{
+try {
     if (color_count == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "k must be an integer higher than 0");
     if (!out_rgba) return fail(KMG_ERR_INVALID_ARGUMENT, "output pointer is NULL");
     if (algo != KMG_ALGO_KMEANS && algo != KMG_ALGO_OCTREE) return fail(KMG_ERR_INVALID_ARGUMENT, "unknown algorithm %d", algo);
@@ -1076,10 +1119,11 @@ extern "C" int kmg_group_reduce(kmg_group *g, const uint8_t *rgba, uint32_t widt
     c.want_palette = true; c.want_output = true; c.out = out_rgba;
     return host_call(g, c);
 }
+KMG_ABI_CATCH
 
 extern "C" int kmg_group_reduce_batch(kmg_group *g, uint32_t n_images, const uint8_t *const *rgba, const uint32_t *widths,
                                       const uint32_t *heights, uint32_t color_count, int algo, int mode, uint8_t *const *out_rgba)
-{
+try {
     if (!g || !rgba || !widths || !heights || !out_rgba) return fail(KMG_ERR_INVALID_ARGUMENT, "bad group_reduce_batch arguments");
     if (g->world != g->n_local) return fail(KMG_ERR_UNSUPPORTED, "the host-buffer calls of a group need all its ranks in one process");
     std::lock_guard<std::mutex> lock(g->call_mu);
@@ -1087,7 +1131,7 @@ extern "C" int kmg_group_reduce_batch(kmg_group *g, uint32_t n_images, const uin
     // anywhere, so the ranks report instead of aborting the group
     std::vector<int> rcs(g->n_local, KMG_OK);
     std::vector<std::string> errs(g->n_local);
-    const int rc = run_all(g, [&](GroupRank &r) {
+    const int rc = run_all(g, false, [&](GroupRank &r) {
         for (uint32_t i = r.idx; i < n_images; i += g->n_local) {
             const int one = kmg_reduce(r.p, rgba[i], widths[i], heights[i], color_count, algo, mode, out_rgba[i]);
             if (one != KMG_OK && rcs[r.idx] == KMG_OK) { rcs[r.idx] = one; errs[r.idx] = "image " + std::to_string(i) + ": " + kmg_last_error(); }
@@ -1099,3 +1143,4 @@ extern "C" int kmg_group_reduce_batch(kmg_group *g, uint32_t n_images, const uin
         if (rcs[i] != KMG_OK) return fail(rcs[i], "%s", errs[i].c_str());
     return KMG_OK;
 }
+KMG_ABI_CATCH

@@ -33,6 +33,16 @@ namespace kmg {
 int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 bool log_debug();
 
+// No C++ exception leaves the library: the callers of this ABI are C, Rust (rust-shim/) and ctypes, for which an exception that
+// unwinds through an extern "C" frame is undefined behaviour, where the reference returns anyhow::Result (core/src/lib.rs:38).
+// Every extern "C" definition is a function-try-block closed by one of the macros below; abi_trap() names what was caught:
+// std::bad_alloc -> KMG_ERR_OUT_OF_MEMORY, any other std::exception -> KMG_ERR_HIP with what() in kmg_last_error(), anything
+// else -> KMG_ERR_HIP.  (tests/test_abi.py checks that no definition is left out.)
+int abi_trap() noexcept;
+#define KMG_ABI_CATCH      catch (...) { return kmg::abi_trap(); }
+#define KMG_ABI_CATCH_VOID catch (...) { (void)kmg::abi_trap(); }
+#define KMG_ABI_CATCH_NULL catch (...) { (void)kmg::abi_trap(); return nullptr; }
+
 // lib.rs:255-286 kmeans_palette: CentroidsBuffer::pull_values (palette-crate Lab -> sRGB8) of a k-means centroid table, then
 // sorted ascending by the palette-crate Lab L of the 8-bit colour.  out_rgba: k x 4 bytes.
 void sorted_palette_of(const float *centroids4, uint32_t k, uint8_t *out_rgba);

@@ -12,6 +12,11 @@ struct alignas(16) Centroid { float L, a, b, C; };
 
 constexpr int kBlock = 256;          // threads per workgroup (4 waves of 64)
 
+// What the launchers size grids and LDS requests by, per device ORDINAL: a process may drive several devices (kmg_group's worker
+// threads) and they need not be alike (a partitioned or mixed node).  Of the calling thread's current device; read once per ordinal.
+struct DeviceInfo { uint32_t cus; size_t lds_max; };
+const DeviceInfo &device_info();
+
 
 
 // Number of workgroups the assign/accumulate pass uses for n pixels (also the number of rows of

@@ -12,6 +12,8 @@
 // Compile with -ffp-contract=off: arithmetic must match kmg_math.h operation for operation.
 
 #include "kmg_internal.h"
+#include <mutex>
+
 #include "kmg_kernels.h"
 
 #include <stdlib.h>
@@ -357,6 +359,23 @@ static int assign_ppt(uint64_t n)
     static const int forced = tools_env_int(KMG_TOOLS_ENV("KMG_ASSIGN_PPT"), 0);      // tools build only
     if (forced == 1 || forced == 2 || forced == 4 || forced == 8) return forced;
     return n >= (1ull << 21) ? 8 : (n >= (1ull << 20) ? 4 : (n >= (1ull << 19) ? 2 : 1));
+}
+
+const DeviceInfo &device_info()
+{
+    constexpr int kMaxOrdinals = 64;
+    static DeviceInfo info[kMaxOrdinals];
+    static std::once_flag once[kMaxOrdinals];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxOrdinals) dev = 0;
+    std::call_once(once[dev], [dev] {
+        int cus = 0, lds = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;   // MI355X
+        if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || lds <= 0) lds = 65536;
+        info[dev].cus = (uint32_t)cus;
+        info[dev].lds_max = (size_t)lds;
+    });
+    return info[dev];
 }
 
 uint32_t assign_grid(uint64_t n)

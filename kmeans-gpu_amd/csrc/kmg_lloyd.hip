@@ -206,11 +206,12 @@ static int bind_image_impl(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, void
 }
 
 extern "C" int kmg_lloyd_bind_image(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, void *stream)
-{
+try {
     const int rc = bind_image_impl(s, d_rgba, n, stream, false, 0);
     if (rc == KMG_OK) s->tab.bound_by_caller = true;
     return rc;
 }
+KMG_ABI_CATCH
 
 // caller = true: the public entry point (the binding then lasts until the caller unbinds or binds again);
 // false: made on behalf of one kmg_lloyd_run, which drops it before it returns
@@ -236,12 +237,13 @@ static int prepare_impl(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, int wan
 }
 
 extern "C" int kmg_lloyd_prepare(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, int want_labels, int *strategy, void *stream)
-{
+try {
     return prepare_impl(s, d_rgba, n, want_labels, strategy, stream, true);
 }
+KMG_ABI_CATCH
 
 extern "C" int kmg_lloyd_unbind_image(kmg_lloyd *s)
-{
+try {
     if (!s) return fail(KMG_ERR_INVALID_ARGUMENT, "bad unbind_image arguments");
     HIP_TRY(hipSetDevice(s->p->device));
     HIP_TRY(hipDeviceSynchronize());                                 // nothing uses the tables any more
@@ -249,6 +251,7 @@ extern "C" int kmg_lloyd_unbind_image(kmg_lloyd *s)
     free_table(s->p, s->tab);
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 // test support: exhaustive validation, over all 2^24 colours, of the cube pass for the current centroid
 // table (run without an image: every colour counts).  out[0] = (colour, centroid) pairs whose key lies outside
@@ -256,7 +259,7 @@ extern "C" int kmg_lloyd_unbind_image(kmg_lloyd *s)
 // cell's candidate mask, out[2] = colours whose label in the per-colour table differs from the brute-force
 // arg-min (this covers the sub-cell stage and the near-tie repair).
 extern "C" int kmg_debug_check_table(kmg_lloyd *s, uint64_t out[3], void *stream)
-{
+try {
     if (!s || !out) return fail(KMG_ERR_INVALID_ARGUMENT, "bad check_table arguments");
     HIP_TRY(hipSetDevice(s->p->device));
     int rc;
@@ -279,6 +282,7 @@ extern "C" int kmg_debug_check_table(kmg_lloyd *s, uint64_t out[3], void *stream
     out[0] = h[0]; out[1] = h[1]; out[2] = h[2];
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 // test / tuning support: statistics of the last colour-table pass of the bound image.
 // out[0] occupied cells, [1] sum of candidate counts over occupied cells, [2] occupied cells with one
@@ -288,7 +292,7 @@ extern "C" int kmg_debug_check_table(kmg_lloyd *s, uint64_t out[3], void *stream
 // [10] candidates summed over the scanned sub-cells, [11] cells with too many candidates for the sub-cell stage,
 // [12] candidates the dominance phase removed from scanned sub-cells, [13] scanned sub-cells it left with one candidate
 extern "C" int kmg_debug_table_stats(kmg_lloyd *s, uint64_t out[14], void *stream)
-{
+try {
     if (!s || !out) return fail(KMG_ERR_INVALID_ARGUMENT, "bad table_stats arguments");
     if (!s->tab.rgba || !s->tab.tables_valid) return fail(KMG_ERR_INVALID_ARGUMENT, "no current colour table");
     HIP_TRY(hipSetDevice(s->p->device));
@@ -339,13 +343,14 @@ extern "C" int kmg_debug_table_stats(kmg_lloyd *s, uint64_t out[14], void *strea
     for (uint32_t v : hist) out[7] += v != 0;
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 // test / tuning support (k <= 256): validates the pair entries of the last colour-table pass against
 // the per-colour labels.  out[0] = occupied colours whose pair entry gives a label different from the
 // per-colour table (must be 0), out[1] = pixels the label pass resolves from the pair entry alone,
 // out[2] = pixels of the bound image.
 extern "C" int kmg_debug_check_pairs(kmg_lloyd *s, uint64_t out[3], void *stream)
-{
+try {
     if (!s || !out) return fail(KMG_ERR_INVALID_ARGUMENT, "bad check_pairs arguments");
     if (!s->tab.rgba || !s->tab.tables_valid) return fail(KMG_ERR_INVALID_ARGUMENT, "no current colour table");
     if (s->k > 256) return fail(KMG_ERR_INVALID_ARGUMENT, "pair entries exist for k <= 256 only");
@@ -385,6 +390,7 @@ extern "C" int kmg_debug_check_pairs(kmg_lloyd *s, uint64_t out[3], void *stream
     }
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 // statistics / checks read the cell masks and the per-colour labels of EVERY cell, which the normal pass does
 // not store: repeat the cube pass of the bound image for the current centroids with both switched on
@@ -550,12 +556,13 @@ int lloyd_create_impl(kmg_processor *p, uint32_t k, kmg_lloyd **out, hipStream_t
 }
 
 extern "C" int kmg_lloyd_create(kmg_processor *p, uint32_t k, kmg_lloyd **out)
-{
+try {
     return lloyd_create_impl(p, k, out, nullptr);
 }
+KMG_ABI_CATCH
 
 extern "C" void kmg_lloyd_destroy(kmg_lloyd *s)
-{
+try {
     if (!s) return;
     (void)hipSetDevice(s->p->device);
     if (s->side) {
@@ -573,9 +580,10 @@ extern "C" void kmg_lloyd_destroy(kmg_lloyd *s)
     host_slot_give(s->p, s->h_slot);
     delete s;
 }
+KMG_ABI_CATCH_VOID
 
 extern "C" int kmg_lloyd_set_centroids(kmg_lloyd *s, const float *c4, void *stream)
-{
+try {
     if (!s || !c4) return fail(KMG_ERR_INVALID_ARGUMENT, "bad set_centroids arguments");
     HIP_TRY(hipSetDevice(s->p->device));
     std::vector<Centroid> h(s->k);
@@ -588,9 +596,10 @@ extern "C" int kmg_lloyd_set_centroids(kmg_lloyd *s, const float *c4, void *stre
     HIP_TRY(hipStreamSynchronize(S(stream)));
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 extern "C" int kmg_lloyd_get_centroids(kmg_lloyd *s, float *c4, void *stream)
-{
+try {
     if (!s || !c4) return fail(KMG_ERR_INVALID_ARGUMENT, "bad get_centroids arguments");
     HIP_TRY(hipSetDevice(s->p->device));
     std::vector<Centroid> own;
@@ -603,6 +612,7 @@ extern "C" int kmg_lloyd_get_centroids(kmg_lloyd *s, float *c4, void *stream)
     }
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 // Farthest-point init: k - 1 passes over the pixels (two launches, ~8e-6 s, + n * 7.0e-12 s each: sRGB->Lab + literal
 // CIE94 per pixel) or over the image's colours (one launch per pass: ~1.05e-5 s once most cells are skipped, ~3e-5 s
@@ -658,7 +668,7 @@ static int init_over_colours(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, ui
 }
 
 extern "C" int kmg_lloyd_init_centroids(kmg_lloyd *s, const uint8_t *d_rgba, uint32_t w, uint32_t h, void *stream)
-{
+try {
     if (!s || !d_rgba || !w || !h) return fail(KMG_ERR_INVALID_ARGUMENT, "bad init_centroids arguments");
     HIP_TRY(hipSetDevice(s->p->device));
     const uint64_t n = (uint64_t)w * h;
@@ -722,6 +732,7 @@ extern "C" int kmg_lloyd_init_centroids(kmg_lloyd *s, const uint8_t *d_rgba, uin
     }
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 // ---- the same initialisation for an image sharded in row bands (last row) ----
 // One step = local pass (running min-distance map of this band, arg-max key over IMAGE-wide pixel
@@ -730,7 +741,7 @@ extern "C" int kmg_lloyd_init_centroids(kmg_lloyd *s, const uint8_t *d_rgba, uin
 // kmg_lloyd_set_centroid_rgba.  No host synchronisation is involved.
 extern "C" int kmg_lloyd_init_step(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n_local, uint64_t first_index,
                                    uint32_t j, uint64_t *d_key, void *stream)
-{
+try {
     if (!s || !d_key || j == 0 || j >= s->k || (n_local && !d_rgba))
         return fail(KMG_ERR_INVALID_ARGUMENT, "bad init_step arguments");
     if (first_index + n_local > 0xFFFFFFFFull) return fail(KMG_ERR_UNSUPPORTED, "image has more than 2^32-1 pixels");
@@ -764,25 +775,28 @@ extern "C" int kmg_lloyd_init_step(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t
                              (unsigned long long *)d_key, first_index, S(stream)));
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 extern "C" int kmg_lloyd_init_pick_band(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n_local, uint64_t first_index,
                                         const uint64_t *d_key, uint32_t *d_colour2, void *stream)
-{
+try {
     if (!s || !d_key || !d_colour2 || (n_local && !d_rgba)) return fail(KMG_ERR_INVALID_ARGUMENT, "bad init_pick_band arguments");
     HIP_TRY(hipSetDevice(s->p->device));
     HIP_TRY(launch_init_pick_band((const uint32_t *)d_rgba, n_local, first_index, (const unsigned long long *)d_key,
                                   d_colour2, S(stream)));
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 extern "C" int kmg_lloyd_set_centroid_rgba(kmg_lloyd *s, uint32_t j, const uint32_t *d_colour, void *stream)
-{
+try {
     if (!s || !d_colour || j >= s->k) return fail(KMG_ERR_INVALID_ARGUMENT, "bad set_centroid_rgba arguments");
     HIP_TRY(hipSetDevice(s->p->device));
     s->tab.tables_valid = false;
     HIP_TRY(launch_set_centroid_rgba(d_colour, s->p->d_lut, s->d_cent, j, S(stream)));
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 extern "C" uint64_t kmg_init_first_key(uint32_t width, uint32_t height)
 {
@@ -813,7 +827,7 @@ static int assign_pass(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_t
 
 extern "C" int kmg_lloyd_assign_accumulate(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_t *d_labels,
                                            int64_t *d_acc4, void *stream)
-{
+try {
     if (!s || !d_rgba || n == 0 || (!d_labels && !d_acc4))
         return fail(KMG_ERR_INVALID_ARGUMENT, "bad assign_accumulate arguments");
     HIP_TRY(hipSetDevice(s->p->device));
@@ -824,23 +838,26 @@ extern "C" int kmg_lloyd_assign_accumulate(kmg_lloyd *s, const uint8_t *d_rgba, 
     if (d_acc4) PROF_LAUNCH(s, KMG_K_REDUCE, S(stream), launch_reduce_partials(s->d_partials, s->last_rows, s->k, d_acc4, S(stream)));
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 extern "C" int kmg_lloyd_assign_partials(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_t *d_labels, void *stream)
-{
+try {
     if (!s || !d_rgba || n == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad assign_partials arguments");
     HIP_TRY(hipSetDevice(s->p->device));
     return assign_pass(s, d_rgba, n, d_labels, true, S(stream));
 }
+KMG_ABI_CATCH
 
 extern "C" int kmg_lloyd_reserve_cus(kmg_lloyd *s, uint32_t n_cus)
-{
+try {
     if (!s || n_cus > 128u) return fail(KMG_ERR_INVALID_ARGUMENT, "bad reserve_cus arguments");
     s->reserve_cus = n_cus;
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 extern "C" int kmg_lloyd_labels(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_t *d_labels, void *stream)
-{
+try {
     if (!s || !d_rgba || !d_labels || n == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad labels arguments");
     HIP_TRY(hipSetDevice(s->p->device));
     int rc_;
@@ -856,10 +873,11 @@ extern "C" int kmg_lloyd_labels(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n,
                                                           d_labels, nullptr, S(stream)));
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 // Cell-sharded cube pass (include/kmeans_hip.h)
 extern "C" int kmg_lloyd_set_cell_share(kmg_lloyd *s, uint32_t part, uint32_t parts, void *stream)
-{
+try {
     if (!s || parts == 0 || part >= parts) return fail(KMG_ERR_INVALID_ARGUMENT, "bad set_cell_share arguments");
     if (!s->tab.rgba || !s->tab.d_hist) return fail(KMG_ERR_INVALID_ARGUMENT, "set_cell_share: no bound image");
     HIP_TRY(hipSetDevice(s->p->device));
@@ -869,9 +887,10 @@ extern "C" int kmg_lloyd_set_cell_share(kmg_lloyd *s, uint32_t part, uint32_t pa
     t.d_work_share = t.share_buf;
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 extern "C" int kmg_lloyd_labels_from_tables(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_t *d_labels, void *stream)
-{
+try {
     if (!s || !d_rgba || !d_labels || n == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad labels_from_tables arguments");
     if (!s->tab.rgba || !s->tab.d_hist) return fail(KMG_ERR_INVALID_ARGUMENT, "labels_from_tables: no bound image");
     HIP_TRY(hipSetDevice(s->p->device));
@@ -883,17 +902,19 @@ extern "C" int kmg_lloyd_labels_from_tables(kmg_lloyd *s, const uint8_t *d_rgba,
                                                           s->tab.n_hot ? s->tab.d_work + kCells + 1 : nullptr));
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 extern "C" int kmg_lloyd_histogram_buffer(kmg_lloyd *s, void **hist, uint64_t *bytes)
-{
+try {
     if (!s || !s->tab.d_hist || !s->tab.rgba) return fail(KMG_ERR_INVALID_ARGUMENT, "histogram_buffer: no bound image");
     if (hist) *hist = s->tab.d_hist;
     if (bytes) *bytes = sizeof(uint32_t) << 24;
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 extern "C" int kmg_lloyd_rebuild_from_histogram(kmg_lloyd *s, uint64_t n_pixels, void *stream)
-{
+try {
     if (!s || !s->tab.d_hist || !s->tab.rgba || n_pixels == 0 || n_pixels > 0xFFFFFFFFull)
         return fail(KMG_ERR_INVALID_ARGUMENT, "bad rebuild_from_histogram arguments");
     HIP_TRY(hipSetDevice(s->p->device));
@@ -903,10 +924,11 @@ extern "C" int kmg_lloyd_rebuild_from_histogram(kmg_lloyd *s, uint64_t n_pixels,
     s->tab.tie_valid = false;                                        // the init's tie keys belong to the band's own histogram
     return tables_from_histogram(s, n_pixels, S(stream));
 }
+KMG_ABI_CATCH
 
 extern "C" int kmg_lloyd_table_buffers(kmg_lloyd *s, void **colour_labels, uint64_t *colour_label_bytes, void **entries,
                                        uint64_t *entry_bytes)
-{
+try {
     if (!s || !s->tab.d_hist) return fail(KMG_ERR_INVALID_ARGUMENT, "table_buffers: no bound image");
     if (colour_labels) *colour_labels = s->tab.d_colour_labels;
     if (colour_label_bytes) *colour_label_bytes = (uint64_t)(s->k <= 256 ? 1 : 2) << 24;
@@ -914,15 +936,17 @@ extern "C" int kmg_lloyd_table_buffers(kmg_lloyd *s, void **colour_labels, uint6
     if (entry_bytes) *entry_bytes = sub_table_bytes();
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 extern "C" int kmg_lloyd_reduce_partials(kmg_lloyd *s, uint64_t n, int64_t *d_acc4, void *stream)
-{
+try {
     if (!s || !d_acc4 || n == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad reduce_partials arguments");
     if (s->last_rows == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "reduce_partials without a preceding assign_partials");
     HIP_TRY(hipSetDevice(s->p->device));
     PROF_LAUNCH(s, KMG_K_REDUCE, S(stream), launch_reduce_partials(s->d_partials, s->last_rows, s->k, d_acc4, S(stream)));
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 static void drop_events(kmg_lloyd *s)
 {
@@ -944,7 +968,7 @@ extern "C" const char *kmg_kernel_name(int id)
 }
 
 extern "C" int kmg_lloyd_profile(kmg_lloyd *s, int enable)
-{
+try {
     if (!s) return fail(KMG_ERR_INVALID_ARGUMENT, "bad profile arguments");
     HIP_TRY(hipSetDevice(s->p->device));
     drop_events(s);
@@ -957,9 +981,10 @@ extern "C" int kmg_lloyd_profile(kmg_lloyd *s, int enable)
         }
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 extern "C" int kmg_lloyd_profile_read(kmg_lloyd *s, double total_ms[KMG_K_COUNT], uint32_t launches[KMG_K_COUNT])
-{
+try {
     if (!s || !total_ms || !launches) return fail(KMG_ERR_INVALID_ARGUMENT, "bad profile_read arguments");
     HIP_TRY(hipSetDevice(s->p->device));
     for (int i = 0; i < KMG_K_COUNT; ++i) { total_ms[i] = 0.0; launches[i] = 0; }
@@ -973,15 +998,17 @@ extern "C" int kmg_lloyd_profile_read(kmg_lloyd *s, double total_ms[KMG_K_COUNT]
     drop_events(s);
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 extern "C" int kmg_lloyd_update(kmg_lloyd *s, const int64_t *d_acc4, void *stream)
-{
+try {
     if (!s || !d_acc4) return fail(KMG_ERR_INVALID_ARGUMENT, "bad update arguments");
     HIP_TRY(hipSetDevice(s->p->device));
     s->tab.tables_valid = false;
     PROF_LAUNCH(s, KMG_K_UPDATE, S(stream), launch_update(d_acc4, s->k, s->p->opt.convergence, s->d_cent, s->d_nconv, S(stream)));
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 // Assign, then update (include/kmeans_hip.h).  With a bound image the update rides on the last launch of the cube pass.
 static int assign_update_impl(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_t *d_labels, int64_t *d_acc4,
@@ -1005,9 +1032,10 @@ static int assign_update_impl(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, u
 
 extern "C" int kmg_lloyd_assign_update(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_t *d_labels, int64_t *d_acc4,
                                        int do_update, void *stream)
-{
+try {
     return assign_update_impl(s, d_rgba, n, d_labels, d_acc4, do_update, stream, false);
 }
+KMG_ABI_CATCH
 
 // One Lloyd iteration with the label pass taken off the critical path (modules.rs:769-800: update, then
 // re-assign).  The loop only depends on the sums; with the colour table they come from the cube pass, and the
@@ -1017,7 +1045,7 @@ extern "C" int kmg_lloyd_assign_update(kmg_lloyd *s, const uint8_t *d_rgba, uint
 // alternate; the cube pass that is about to overwrite a set first waits for the label pass that read it.
 extern "C" int kmg_lloyd_iterate(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_t *d_labels, int64_t *d_acc4,
                                  int update_first, void *stream)
-{
+try {
     if (!s || !d_rgba || n == 0 || !d_acc4) return fail(KMG_ERR_INVALID_ARGUMENT, "bad iterate arguments");
     HIP_TRY(hipSetDevice(s->p->device));
     int rc;
@@ -1083,16 +1111,18 @@ extern "C" int kmg_lloyd_iterate(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n
     s->lab_pending[s->set] = true;
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 extern "C" int kmg_lloyd_flush(kmg_lloyd *s, void *stream)
-{
+try {
     if (!s) return fail(KMG_ERR_INVALID_ARGUMENT, "bad flush arguments");
     HIP_TRY(hipSetDevice(s->p->device));
     return side_flush(s, S(stream));
 }
+KMG_ABI_CATCH
 
 extern "C" int kmg_lloyd_converged_count(kmg_lloyd *s, uint32_t *count, void *stream)
-{
+try {
     if (!s || !count) return fail(KMG_ERR_INVALID_ARGUMENT, "bad converged_count arguments");
     HIP_TRY(hipSetDevice(s->p->device));
     if (s->h_slot) {
@@ -1105,10 +1135,11 @@ extern "C" int kmg_lloyd_converged_count(kmg_lloyd *s, uint32_t *count, void *st
     HIP_TRY(hipStreamSynchronize(S(stream)));
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 extern "C" int kmg_lloyd_run(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_t *d_labels,
                              uint32_t *iterations, void *stream)
-{
+try {
     if (!s || !d_rgba || n == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad lloyd_run arguments");
     if (s->tab.d_work_share && table_bound(s, d_rgba, n))
         return fail(KMG_ERR_INVALID_ARGUMENT, "lloyd_run: a cell share is set (kmg_lloyd_set_cell_share): the loop would update from one share's sums");
@@ -1200,4 +1231,5 @@ extern "C" int kmg_lloyd_run(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, ui
     if (iterations) *iterations = it < o.max_iterations ? it : o.max_iterations - 1;
     return KMG_OK;
 }
+KMG_ABI_CATCH
 

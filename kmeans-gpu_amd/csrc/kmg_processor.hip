@@ -21,6 +21,20 @@ int kmg::fail(int code, const char *fmt, ...)
     return code;
 }
 
+// called inside a catch (...) handler: rethrows to classify (kmg_internal.h)
+int kmg::abi_trap() noexcept
+{
+    try {
+        throw;
+    } catch (const std::bad_alloc &) {
+        return fail(KMG_ERR_OUT_OF_MEMORY, "host allocation failed (std::bad_alloc)");
+    } catch (const std::exception &e) {
+        return fail(KMG_ERR_HIP, "internal error: %s", e.what());
+    } catch (...) {
+        return fail(KMG_ERR_HIP, "internal error: unknown C++ exception");
+    }
+}
+
 bool kmg::log_debug()
 {
     const char *lv = getenv("KMG_LOG");
@@ -31,7 +45,7 @@ extern "C" const char *kmg_last_error(void) { return g_err; }
 extern "C" const char *kmg_version(void) { return "kmeans_hip 0.1 (gfx950)"; }
 
 extern "C" void kmg_default_options(kmg_options *opt)
-{
+try {
     if (!opt) return;
     opt->struct_size = sizeof(kmg_options);
     opt->device = -1;
@@ -40,6 +54,7 @@ extern "C" void kmg_default_options(kmg_options *opt)
     opt->check_period = 8;       // modules.rs:766
     opt->convergence = 1.0f;     // lib.rs:189-194
 }
+KMG_ABI_CATCH_VOID
 
 // ---------------------------------------------------------------------------------------------
 // processor
@@ -127,10 +142,12 @@ void block_give(kmg_processor *p, void *ptr, size_t cap)
     for (void *v : victims) (void)hipFree(v);                         // (outside the lock: hipFree synchronises the device)
 }
 
-extern "C" int kmg_processor_create(kmg_processor **out) { return kmg_processor_create_ex(nullptr, out); }
+extern "C" int kmg_processor_create(kmg_processor **out)
+try { return kmg_processor_create_ex(nullptr, out); }
+KMG_ABI_CATCH
 
 extern "C" int kmg_processor_create_ex(const kmg_options *opt, kmg_processor **out)
-{
+try {
     if (!out) return fail(KMG_ERR_INVALID_ARGUMENT, "out is NULL");
     *out = nullptr;
     kmg_options o;
@@ -198,31 +215,35 @@ extern "C" int kmg_processor_create_ex(const kmg_options *opt, kmg_processor **o
     *out = p;
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 extern "C" int kmg_host_alloc(size_t bytes, void **out)
-{
+try {
     if (!out || bytes == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad host_alloc arguments");
     *out = nullptr;
     HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocDefault));
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 extern "C" void kmg_host_free(void *ptr)
-{
+try {
     if (ptr) (void)hipHostFree(ptr);
 }
+KMG_ABI_CATCH_VOID
 
 extern "C" int kmg_debug_block_counts(kmg_processor *p, uint64_t out[2])
-{
+try {
     if (!p || !out) return fail(KMG_ERR_INVALID_ARGUMENT, "bad block_counts arguments");
     std::lock_guard<std::mutex> lock(p->mu);
     out[0] = p->n_block_malloc;
     out[1] = p->n_block_reuse;
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 extern "C" int kmg_debug_idle_blocks(kmg_processor *p, uint64_t out[2])
-{
+try {
     if (!p || !out) return fail(KMG_ERR_INVALID_ARGUMENT, "bad idle_blocks arguments");
     std::lock_guard<std::mutex> lock(p->mu);
     out[0] = p->idle_arenas.size();
@@ -230,9 +251,10 @@ extern "C" int kmg_debug_idle_blocks(kmg_processor *p, uint64_t out[2])
     for (auto &a : p->idle_arenas) out[1] += a.second;
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 extern "C" int kmg_debug_encode_table_check(kmg_processor *p, uint64_t *mismatches)
-{
+try {
     if (!p || !mismatches) return fail(KMG_ERR_INVALID_ARGUMENT, "bad encode_table_check arguments");
     unsigned long long *d_bad = nullptr, bad = 0;
     hipError_t e = hipMalloc((void **)&d_bad, sizeof bad);
@@ -244,9 +266,10 @@ extern "C" int kmg_debug_encode_table_check(kmg_processor *p, uint64_t *mismatch
     *mismatches = bad;
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 extern "C" int kmg_debug_division_check(kmg_processor *p, float c, uint64_t out[3])
-{
+try {
     if (!p || !out) return fail(KMG_ERR_INVALID_ARGUMENT, "bad division_check arguments");
     HIP_TRY(hipSetDevice(p->device));
     unsigned long long *d = nullptr, h[3] = {0ull, ~0ull, 0ull};
@@ -259,9 +282,10 @@ extern "C" int kmg_debug_division_check(kmg_processor *p, float c, uint64_t out[
     out[0] = h[0]; out[1] = h[1]; out[2] = h[2];
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 extern "C" void kmg_processor_destroy(kmg_processor *p)
-{
+try {
     if (!p) return;
     (void)hipSetDevice(p->device);
     if (p->d_lut) (void)hipFree(p->d_lut);
@@ -275,12 +299,13 @@ extern "C" void kmg_processor_destroy(kmg_processor *p)
     if (p->h_page) (void)hipHostFree(p->h_page);
     delete p;
 }
+KMG_ABI_CATCH_VOID
 
 // ---------------------------------------------------------------------------------------------
 // host colour helpers
 // ---------------------------------------------------------------------------------------------
 extern "C" int kmg_palette_to_centroids(const uint8_t *palette_rgba, uint32_t n, float *c4)
-{
+try {
     if (!palette_rgba || !c4 || n == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad palette arguments");
     for (uint32_t i = 0; i < n; ++i) {
         crate_srgb8_to_lab(palette_rgba + 4 * i, c4 + 4 * i);
@@ -288,9 +313,10 @@ extern "C" int kmg_palette_to_centroids(const uint8_t *palette_rgba, uint32_t n,
     }
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 extern "C" int kmg_centroids_to_palette(const float *c4, uint32_t k, uint8_t *out)
-{
+try {
     if (!c4 || !out || k == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad centroid arguments");
     for (uint32_t i = 0; i < k; ++i) {
         crate_lab_to_srgb8(c4 + 4 * i, out + 4 * i);
@@ -298,16 +324,18 @@ extern "C" int kmg_centroids_to_palette(const float *c4, uint32_t k, uint8_t *ou
     }
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 extern "C" int kmg_dither_threshold(const float *c4, uint32_t k, float *thr)
-{
+try {
     if (!c4 || !thr || k < 2) return fail(KMG_ERR_INVALID_ARGUMENT, "dither threshold needs k >= 2");
     *thr = dither_threshold(c4, k);
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 extern "C" void kmg_resized_dims(uint32_t w, uint32_t h, uint32_t max_size, uint32_t *nw, uint32_t *nh)
-{
+try {
     // structures.rs:79-89
     uint32_t a, b;
     if (w > h) {
@@ -320,24 +348,27 @@ extern "C" void kmg_resized_dims(uint32_t w, uint32_t h, uint32_t max_size, uint
     if (nw) *nw = a;
     if (nh) *nh = b;
 }
+KMG_ABI_CATCH_VOID
 
 // ---------------------------------------------------------------------------------------------
 // device-pointer API: conversions that need no kmg_lloyd
 // ---------------------------------------------------------------------------------------------
 extern "C" int kmg_dev_rgb_to_lab(kmg_processor *p, const uint8_t *d_rgba, uint64_t n, float *d_lab3, void *stream)
-{
+try {
     if (!p || !d_rgba || !d_lab3 || n == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad rgb_to_lab arguments");
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(launch_rgb_to_lab((const uint32_t *)d_rgba, n, p->d_lut, d_lab3, S(stream)));
     return KMG_OK;
 }
+KMG_ABI_CATCH
 
 extern "C" int kmg_dev_resize(kmg_processor *p, const uint8_t *d_rgba, uint32_t w, uint32_t h, uint32_t nw,
                               uint32_t nh, uint8_t *d_out, void *stream)
-{
+try {
     if (!p || !d_rgba || !d_out || !w || !h || !nw || !nh) return fail(KMG_ERR_INVALID_ARGUMENT, "bad resize arguments");
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(launch_resize((const uint32_t *)d_rgba, w, h, nw, nh, (uint32_t *)d_out, S(stream)));
     return KMG_OK;
 }
+KMG_ABI_CATCH
 

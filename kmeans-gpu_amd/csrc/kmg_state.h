@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <exception>
 #include <mutex>
 #include <thread>
 #include <new>

@@ -1116,15 +1116,6 @@ __global__ __launch_bounds__(kLabelBlock) void k_labels_pairs(const uint32_t *__
     }
 }
 
-// compute units of the current device (256 on MI355X)
-static uint32_t device_cus()
-{
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-        n = 256;
-    return (uint32_t)n;
-}
-
 hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_labels, const uint16_t *sub_table,
                          uint32_t k, const uint32_t *pal, uint32_t *labels, hipStream_t st, uint32_t reserve_cus, const uint32_t *hot,
                          const CubeTail *tail, int64_t *tail_sums)
@@ -1132,7 +1123,7 @@ hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_la
     const CubeTail tl = (tail && tail_sums && k <= 256) ? *tail : CubeTail();
     if (k <= 256) {
         const uint64_t tiles = (n + kLabelBlock * 8 - 1) / (kLabelBlock * 8);
-        static const uint32_t all = device_cus();
+        const uint32_t all = device_info().cus;
         // 1 workgroup per CU (its 130 KiB of LDS see to that); reserve_cus fewer workgroups than CUs -- which leaves that
         // many CUs without one only as long as nothing else occupies them first
         const uint32_t cus = all - (reserve_cus < all / 2u ? reserve_cus : all / 2u);

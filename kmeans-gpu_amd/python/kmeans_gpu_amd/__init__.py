@@ -723,6 +723,8 @@ class Group:
         if unique_id is None:
             _check(lib().kmg_group_create(C.byref(o), C.byref(self._h)))
         else:
+            if world is None:
+                raise ValueError("Group(unique_id=...) is one process of a multi-process world: pass world (and first_rank)")
             uid = (C.c_uint8 * UNIQUE_ID_BYTES).from_buffer_copy(bytes(unique_id))
             _check(lib().kmg_group_create_rank(C.byref(o), uid, int(first_rank), int(world), C.byref(self._h)))
         a, b, c, v = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_int()

@@ -11,7 +11,7 @@ TOOLS_LIB = os.path.join(PKG, "lib", "libkmeans_hip_tools.so")
 
 
 def use_tools_library(env=None):
-    subprocess.run(["make", "-C", PKG, "tools"], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run(["make", "-j8", "-C", PKG, "tools"], check=True, stdout=subprocess.DEVNULL)
     target = os.environ if env is None else env
     target["KMG_LIBRARY"] = TOOLS_LIB
     return TOOLS_LIB

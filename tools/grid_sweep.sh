@@ -1,6 +1,6 @@
-make -C ${GRAFT_REPO_ROOT:-$(pwd)}/kmeans-gpu_amd tools > /dev/null && export KMG_LIBRARY=${GRAFT_REPO_ROOT:-$(pwd)}/kmeans-gpu_amd/lib/libkmeans_hip_tools.so   # the grid switches exist in the tools build only
 #!/bin/bash
 # kernel times of the cube launches for a few grid sizes (run on the GPU box): bash tools/grid_sweep.sh
+make -C ${GRAFT_REPO_ROOT:-$(pwd)}/kmeans-gpu_amd tools > /dev/null && export KMG_LIBRARY=${GRAFT_REPO_ROOT:-$(pwd)}/kmeans-gpu_amd/lib/libkmeans_hip_tools.so   # the grid switches exist in the tools build only
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/r02_grid_sweep.txt
 : > $OUT
