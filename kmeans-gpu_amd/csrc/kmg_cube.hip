@@ -2074,6 +2074,560 @@ __global__ __launch_bounds__(kSmallBlock) __attribute__((amdgpu_waves_per_eu(4, 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_cube_one (32 < k <= 256, images without hot cells; round 6): the whole cube pass in ONE launch -- the three or four
+// launches above with nothing but their results leaving the workgroup: no work records, items or lists in memory, no
+// reservation atomics, one prologue / flush instead of four, no launch boundaries (the pass was lean 16.5 + prune 27 +
+// scan 35 + pairs 16 us with ~3 us between them).  k_cube_small's shape with k_cube_lean's candidates and k_cube_prune's
+// list positions: a workgroup of 8 waves owns 64 cells (a wave's 8 cells dealt with stride n_work / 8 over the work list);
+//   1a. candidates   a wave takes its 8 cells one after the other exactly as k_cube_lean does (a lane's four centroids in
+//                    registers, interval bounds over the cell, U, ballots); the list goes to LDS.  One candidate: the cell is
+//                    decided.  More than kMaxListed: no per-sub-cell sets, every colour against the cell's mask (rare).
+//   1b. sub-cells    a thread per sub-cell (its bounds, sums and affine model were requested BEFORE 1a: the candidates hide
+//                    the round trip): k_cube_prune's two sweeps over the list, then its dominance tests as one compact LDS
+//                    list dealt to all 512 threads (`dominated`, unchanged);
+//   1c. decisions    sub-cells with one candidate take their sums and their 64 labels (LDS); cells whose occupied sub-cells
+//                    agree take the per-cell sums and their pair entry; what is open becomes ITEMS in LDS -- two sub-cells of
+//                    a cell and the union of their candidates (<= 12: packed as k_cube_prune packs them; more: by position);
+//   2.  scan         the items dealt to the 8 waves, one colour per lane and sub-cell, three items' colours in flight (k_cube_scan's
+//                    item loop: same keys, same near-tie repair, same sums), labels into LDS;
+//   3.  entries      the pair entry of every cell with more than one label from the 512 labels in LDS (cell_pair_entry), the
+//                    labels leave as one 8-byte store per lane.
+// Same arithmetic as the launches it replaces, step for step -- results are bit-identical (tests/test_gpu_table.py runs both).
+// The tail of the pass (sums hand-over, centroid update) rides on the label pass's last workgroup, or is k_cube_pairs' tail
+// workgroup launched alone, as for k_cube_small.  LDS (k = 256): ~75 KiB, two workgroups per CU.
+// stats as k_cube_lean + k_cube_prune.  flags: bit 0, kCubeNoEntries.
+// ------------------------------------------------------------------------------------------
+constexpr int kOneBlock = 512;
+constexpr uint32_t kOneWaves = kOneBlock / 64, kOneCells = kOneWaves * 8u;
+constexpr uint32_t kOneTests = 2048;                             // dominance tests a workgroup lists (more are dropped = kept candidates)
+constexpr uint32_t kOneRepl = 2;                                 // copies of the LDS bins
+constexpr uint32_t kOneModelStride = 24;                         // words per model in LDS: [wave][chunk of 16 B][lane], written by global_load_lds
+constexpr uint32_t kOneItems = kOneCells * 4u;                   // at most four pairs of sub-cells per cell
+
+__host__ __device__ constexpr size_t one_max(size_t a, size_t b) { return a > b ? a : b; }
+// the two regions of k_cube_one's LDS that live twice: models -> bins + labels, tests -> items
+__host__ __device__ inline size_t one_union_bytes(uint32_t k, bool with_sums)
+{
+    const size_t bins = with_sums ? sizeof(unsigned long long) * kOneRepl * (4ull * k + 4ull) : 0u;
+    return one_max(sizeof(uint32_t) * kOneBlock * kOneModelStride, bins + (size_t)kOneCells * kCellColours);
+}
+constexpr size_t kOneTestItemBytes = one_max(sizeof(uint16_t) * kOneTests, sizeof(uint4) * kOneItems);
+
+static size_t cube_one_lds_bytes(uint32_t k, bool with_sums)
+{
+    const size_t un = one_union_bytes(k, with_sums), ti = kOneTestItemBytes;
+    return sizeof(float4) * 256u + un + ti + sizeof(uint16_t) * kOneCells * kMaxListed + sizeof(uint32_t) * kOneBlock * 2u +
+           sizeof(unsigned long long) * kOneCells * 4u + sizeof(uint32_t) * kOneCells * 2u + sizeof(uint16_t) * kOneCells + sizeof(uint32_t) * 8u;
+}
+
+#ifdef KMG_TOOLS
+// tools build: phase stamps of k_cube_one (s_memrealtime, 100 MHz), [workgroup][8]: start, 1a done (wave 0), 1b swept, tests done, 1c done,
+// scan done (wave 0), scan done (all), entries done (wave 0); [8..10] items, pending cells, tests of the workgroup
+__device__ unsigned long long g_one_stamps[(kCells / kOneCells) * 12u];
+#define KMG_STAMP(i) do { if (threadIdx.x == 0u) g_one_stamps[blockIdx.x * 12u + (i)] = wall_clock64(); } while (0)
+#define KMG_STAMP_VALUE(i, v) do { if (threadIdx.x == 0u) g_one_stamps[blockIdx.x * 12u + (i)] = (v); } while (0)
+#else
+#define KMG_STAMP(i) do { } while (0)
+#define KMG_STAMP_VALUE(i, v) do { } while (0)
+#endif
+
+template <bool SUMS>
+__global__ __launch_bounds__(kOneBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_cube_one(
+    const uint32_t *__restrict__ hist, const int64_t *__restrict__ agg, const int64_t *__restrict__ sub_agg,
+    const uint8_t *__restrict__ occ_bits, const uint32_t *__restrict__ work, const CellBounds *__restrict__ bounds,
+    const CellBounds *__restrict__ sub_bounds, const float *__restrict__ sub_affine, const Centroid *__restrict__ cent, uint32_t k,
+    const float4 *__restrict__ lab_table, uint64_t *__restrict__ masks_out, uint8_t *__restrict__ colour_labels,
+    uint16_t *__restrict__ sub_table, int64_t *__restrict__ sums, uint32_t n_rows, uint32_t flags,
+    unsigned long long *__restrict__ stats)
+{
+    extern __shared__ float4 smem4[];
+    float4 *s_cent = smem4;                                                            // [256]
+    // one region, two lives: the sub-cells' affine models (until the tests are done), then the bins and the cells' labels
+    uint4 *s_model4 = reinterpret_cast<uint4 *>(smem4 + 256);
+    unsigned long long *bins = reinterpret_cast<unsigned long long *>(s_model4);
+    const uint32_t bin_stride = 4u * k + 4u;
+    const uint32_t n_bins = SUMS ? kOneRepl * bin_stride : 0u;
+    uint8_t *s_lbl = reinterpret_cast<uint8_t *>(bins + n_bins);                       // [cells][512]
+    const size_t un_bytes = one_union_bytes(k, SUMS);
+    // likewise: the tests, then the items
+    uint16_t *s_test = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(s_model4) + un_bytes);
+    uint4 *s_item = reinterpret_cast<uint4 *>(s_test);
+    unsigned long long *s_cmask = reinterpret_cast<unsigned long long *>(reinterpret_cast<uint8_t *>(s_test) + kOneTestItemBytes);   // [cells][4]
+    uint32_t *s_mask = reinterpret_cast<uint32_t *>(s_cmask + kOneCells * 4u);          // [sub-cells]: candidates (list positions)
+    uint32_t *s_ref = s_mask + kOneBlock;                                              // [sub-cells]: upper bound | reference position
+    uint32_t *s_cell = s_ref + kOneBlock;                                              // [cells]
+    uint32_t *s_npop = s_cell + kOneCells;                                             // [cells]: candidates | first << 16
+    uint32_t *s_count = s_npop + kOneCells;                                            // [0] items, [1] pending cells, [2] far centroid, [3] tests
+    uint16_t *s_list = reinterpret_cast<uint16_t *>(s_count + 8);                      // [cells][kMaxListed]: centroid by position
+    uint16_t *s_pend = s_list + kOneCells * kMaxListed;                                // [cells]: slots whose cell needs an entry
+
+    const uint32_t vz = opaque_vgpr_zero();
+    const uint32_t n_work_v = SUMS ? work[vz] : kCells;
+    if (threadIdx.x < 256u) {
+        float4 v = make_float4(1.0e18f, 0.0f, 0.0f, 0.0f);           // key ~ 1e36: never a candidate
+        if (threadIdx.x < k) { const Centroid c = cent[threadIdx.x]; v = make_float4(c.L, c.a, c.b, c.C); }
+        s_cent[threadIdx.x] = v;
+    }
+    if (threadIdx.x < 8u) s_count[threadIdx.x] = 0u;
+    __syncthreads();
+    if (threadIdx.x < k) {
+        const float4 c = s_cent[threadIdx.x];
+        if (!(fabsf(c.x) <= 1024.0f && fabsf(c.y) <= 1024.0f && fabsf(c.z) <= 1024.0f)) s_count[2] = 1u;
+    }
+    __syncthreads();
+    const bool dominance = sub_affine != nullptr && s_count[2] == 0u;
+
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t ci = lane >> 3, sub = lane & 7u, slot = wv * 8u + ci;
+    unsigned long long *my_bins = bins + (uint64_t)(lane & (kOneRepl - 1u)) * bin_stride;
+    uint32_t *pair_entries = reinterpret_cast<uint32_t *>(sub_table + kSubCells + kCells);
+    const uint32_t words = (k + 63u) / 64u;
+    unsigned long long st_single = 0, st_multi = 0, st_unlisted = 0, st_decided = 0, st_scanned = 0, st_cands = 0, st_removed = 0, st_one = 0;
+    float4 c4[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) c4[w] = s_cent[w * 64 + lane];      // this lane's four centroids: the same for every cell
+
+    const uint32_t n_work = __builtin_amdgcn_readfirstlane(n_work_v);
+    const uint32_t tasks = (n_work + 7u) >> 3;                     // wave tasks: task t = cells t, t + tasks, ... of the work list
+    // (one batch per workgroup: the grid is kCells / kOneCells whatever the list's length, and the bins share their LDS with the
+    // models of the batch)
+    const uint32_t base = blockIdx.x * kOneWaves;
+    if (base >= tasks) return;
+    {
+        KMG_STAMP(0);
+        // (wave task t -> place (t P) mod tasks of the work list, P a prime that does not divide tasks: the 64 cells of a workgroup
+        // are spread over the whole cube instead of lying along eight lines of it -- the cost of a cell follows its position)
+        const uint32_t task = base + wv;
+        const uint32_t prime = tasks % 2053u ? 2053u : 1031u;
+        const uint32_t pos = (uint32_t)(((uint64_t)task * prime) % tasks) + ci * tasks;
+        const bool valid = task < tasks && pos < n_work;
+        const uint32_t cell = valid ? ((SUMS && n_work != kCells) ? work[1u + pos] : pos) : 0u;
+        const uint32_t sc = cell * 8u + sub;
+        // ---- requests: the bounds of the wave's eight cells (lane 16 c + i: float i of cell c / c + 4), then everything 1b needs ----
+        const uint32_t cell_a = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane >> 4) * 8u) << 2), (int)cell);
+        const uint32_t cell_b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((4u + (lane >> 4)) * 8u) << 2), (int)cell);
+        const float cbv_a = reinterpret_cast<const float *>(bounds + cell_a)[lane & 15u];
+        const float cbv_b = reinterpret_cast<const float *>(bounds + cell_b)[lane & 15u];
+        const float4 *sbp = reinterpret_cast<const float4 *>(sub_bounds + sc);
+        const float4 sb0 = sbp[0], sb1 = sbp[1], sb2 = sbp[2];
+        longlong2 g01 = {0, 0}, g23 = {0, 1};
+        long long cell_sum = 0;
+        if (SUMS) {
+            const longlong2 *sp = reinterpret_cast<const longlong2 *>(sub_agg + (uint64_t)sc * 4u);
+            g01 = sp[0]; g23 = sp[1];
+            cell_sum = agg[4ull * cell + (sub & 3u)];
+        }
+        if (dominance) {
+            // the model goes straight to LDS (global_load_lds_dwordx4: no registers held over 1a, nothing to write later):
+            // chunk t of the wave's 64 sub-cells = 1 KiB at [wave][t][lane]
+            const uint4 *mp = reinterpret_cast<const uint4 *>(sub_affine + (uint64_t)sc * kAffineFloats);
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(mp + t),
+                                                 (__attribute__((address_space(3))) void *)(s_model4 + (wv * 6u + (uint32_t)t) * 64u), 16, 0, 0);
+        }
+        if (sub == 0u) s_cell[slot] = cell;
+
+        // ---- 1a. the candidates of the wave's cells, one cell at a time (k_cube_lean) ----
+        for (uint32_t c = 0; c < 8u; ++c) {
+            const uint32_t ccell = lane_value(cell, c * 8u);
+            const bool cvalid = lane_value((uint32_t)valid, c * 8u) != 0u;
+            const float cbv = c < 4u ? cbv_a : cbv_b;
+            const uint32_t l0 = (c & 3u) * 16u;
+            CellBounds cb;
+            cb.L0 = lane_value(cbv, l0 + 0u); cb.L1 = lane_value(cbv, l0 + 1u); cb.a0 = lane_value(cbv, l0 + 2u); cb.a1 = lane_value(cbv, l0 + 3u);
+            cb.b0 = lane_value(cbv, l0 + 4u); cb.b1 = lane_value(cbv, l0 + 5u); cb.C0 = lane_value(cbv, l0 + 6u); cb.C1 = lane_value(cbv, l0 + 7u);
+            cb.wC0 = lane_value(cbv, l0 + 8u); cb.wC1 = lane_value(cbv, l0 + 9u); cb.wH0 = lane_value(cbv, l0 + 10u); cb.wH1 = lane_value(cbv, l0 + 11u);
+            float lo[4], U = 3.0e38f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const KeyRange r = key_range(cb, c4[w].x, c4[w].y, c4[w].z, c4[w].w);
+                lo[w] = r.lo;
+                U = fminf(U, r.hi);                                 // padding entries: hi ~ 1e36
+            }
+            const float Us = mask_threshold(wave_min(U));
+            unsigned long long mw[4];
+            uint32_t npop = 0, first = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < 4u; ++w) {
+                mw[w] = __ballot(w * 64u + lane < k && lo[w] <= Us);
+                if (npop == 0u && mw[w]) first = w * 64u + (uint32_t)__builtin_ctzll(mw[w]);
+                npop += (uint32_t)__builtin_popcountll(mw[w]);
+            }
+            const uint32_t cslot = wv * 8u + c;
+            if (cvalid && lane < words) masks_out[(uint64_t)ccell * words + lane] = lane == 0u ? mw[0] : (lane == 1u ? mw[1] : (lane == 2u ? mw[2] : mw[3]));
+            if (lane == 0u) s_npop[cslot] = npop | (first << 16);
+            if (npop > 1u && npop <= kMaxListed) {
+                uint32_t at = 0;
+#pragma unroll
+                for (uint32_t w = 0; w < 4u; ++w) {
+                    if ((mw[w] >> lane) & 1ull) s_list[cslot * kMaxListed + at + bits_below_lane(mw[w])] = (uint16_t)(w * 64u + lane);
+                    at += (uint32_t)__builtin_popcountll(mw[w]);
+                }
+            } else if (npop > kMaxListed) {
+                if (lane < 4u) s_cmask[cslot * 4u + lane] = lane == 0u ? mw[0] : (lane == 1u ? mw[1] : (lane == 2u ? mw[2] : mw[3]));
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                            // (s_list / s_npop of a cell: written and read by this wave only)
+        KMG_STAMP(1);
+
+        // ---- 1b. the sub-cell stage of the listed cells (k_cube_prune): the thread's own sub-cell, two sweeps over the list ----
+        const uint32_t np_first = s_npop[slot];
+        const uint32_t npop = valid ? (np_first & 0xFFFFu) : 1u, first = np_first >> 16;
+        const bool listed = valid && npop > 1u && npop <= kMaxListed;
+        const bool unlisted = valid && npop > kMaxListed;
+        const bool occupied = valid && (SUMS ? g23.y != 0 : true);
+        uint32_t sm = 0u, istar = 0u, ubits = 0u;
+        if (listed) {
+            CellBounds sb;
+            sb.L0 = sb0.x; sb.L1 = sb0.y; sb.a0 = sb0.z; sb.a1 = sb0.w;
+            sb.b0 = sb1.x; sb.b1 = sb1.y; sb.C0 = sb1.z; sb.C1 = sb1.w;
+            sb.wC0 = sb2.x; sb.wC1 = sb2.y; sb.wH0 = sb2.z; sb.wH1 = sb2.w;
+            uint32_t Ubest = 0x7F7FFFE0u;                           // (upper bound rounded up to a multiple of 32 ulps) | position
+            for (uint32_t p = 0; p < npop; ++p) {
+                const float4 c = s_cent[s_list[slot * kMaxListed + p]];
+                Ubest = min(Ubest, ((float_to_bits(key_range(sb, c.x, c.y, c.z, c.w).hi) + 31u) & ~31u) | p);
+            }
+            const float Us = mask_threshold(bits_to_float(Ubest & ~31u));
+            for (uint32_t p = 0; p < npop; ++p) {
+                const float4 c = s_cent[s_list[slot * kMaxListed + p]];
+                sm |= (key_range(sb, c.x, c.y, c.z, c.w).lo <= Us ? 1u : 0u) << p;
+            }
+            istar = Ubest & 31u;
+            ubits = Ubest & ~31u;
+        }
+        const uint32_t np0 = (uint32_t)__builtin_popcount(sm);
+        const bool was_decided = listed && occupied && np0 == 1u;   // decided by its bounds
+        const bool mine = listed && occupied && np0 > 1u;            // open: the dominance tests, then the scan if still open
+        s_mask[threadIdx.x] = sm;
+        const uint32_t others = (mine && dominance) ? sm & ~(1u << istar) : 0u;
+        if (others) {
+            s_ref[threadIdx.x] = ubits | istar;
+            const uint32_t nt = (uint32_t)__builtin_popcount(others);
+            uint32_t at = atomicAdd(&s_count[3], nt);
+            for (uint32_t m = others; m && at < kOneTests; m &= m - 1u, ++at)
+                s_test[at] = (uint16_t)((threadIdx.x << 5) | (uint32_t)__builtin_ctz(m));
+        }
+        KMG_STAMP(2);
+        __syncthreads();
+        if (dominance) {
+            const uint32_t n_tests = min(s_count[3], kOneTests);
+            for (uint32_t t = threadIdx.x; t < n_tests; t += kOneBlock) {
+                const uint32_t e = (uint32_t)s_test[t] >> 5, tp = (uint32_t)s_test[t] & 31u;
+                const uint32_t r = s_ref[e];
+                const float4 cj = s_cent[s_list[(e >> 3) * kMaxListed + tp]], ci4 = s_cent[s_list[(e >> 3) * kMaxListed + (r & 31u)]];
+                HalfModel mdl;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    const uint4 v = s_model4[((e >> 6) * 6u + (uint32_t)q) * 64u + (e & 63u)];
+                    mdl.q[4 * q] = v.x; mdl.q[4 * q + 1] = v.y; mdl.q[4 * q + 2] = v.z; mdl.q[4 * q + 3] = v.w;
+                }
+                if (dominated(mdl, cj, ci4, bits_to_float(r & ~31u))) atomicAnd(&s_mask[e], ~(1u << tp));
+            }
+            __syncthreads();
+        }
+        KMG_STAMP(3);
+        // (the models have been read: their bytes become the bins and the labels)
+        if (SUMS) for (uint32_t i = threadIdx.x; i < n_bins; i += kOneBlock) bins[i] = 0ull;
+        __syncthreads();
+
+        // ---- 1c. what is left of every sub-cell's set: decided / open; uniform cells; items and pending cells ----
+        const uint32_t nm = s_mask[threadIdx.x];
+        const uint32_t np = (uint32_t)__builtin_popcount(nm);
+        const bool one = mine && np == 1u, still = mine && np > 1u;
+        const uint32_t X = listed ? (uint32_t)s_list[slot * kMaxListed + (nm ? (uint32_t)__builtin_ctz(nm) : 0u)] : first;
+        const bool open = still || (unlisted && occupied);
+        const uint32_t scan8 = group8_or(open ? 1u << sub : 0u);
+        const bool settled = one || was_decided;
+        const uint32_t xmin = group8_min_u32(settled ? X : 255u), xmax = group8_max_u32(settled ? X : 0u);
+        const bool single = valid && npop == 1u;
+        // every occupied sub-cell of the cell went to one centroid (a cell without occupied sub-cells does not occur: the work list)
+        const bool uniform = single || (listed && scan8 == 0u && xmin == xmax);
+        const uint32_t Xu = single ? first : xmin;
+        if (SUMS) {
+            if (uniform) {
+                if (sub < 4u) atomicAdd(my_bins + 4ull * Xu + sub, (unsigned long long)cell_sum);
+            } else if (settled) {
+                unsigned long long *to = my_bins + 4ull * X;
+                atomicAdd(to + 0, (unsigned long long)g01.x); atomicAdd(to + 1, (unsigned long long)g01.y);
+                atomicAdd(to + 2, (unsigned long long)g23.x); atomicAdd(to + 3, (unsigned long long)g23.y);
+            }
+        }
+        {
+            const uint32_t x4 = (settled ? X : 0u) * 0x01010101u;
+            const uint4 xv = make_uint4(x4, x4, x4, x4);
+            if (uniform) {
+                if (sub == 0u) pair_entries[cell] = pair_entry(Xu, Xu, 0u, 0u, 0u);
+                if (flags & 1u) {
+                    const uint32_t m4 = Xu * 0x01010101u;
+                    uint4 *dst = reinterpret_cast<uint4 *>(colour_labels + (uint64_t)cell * kCellColours + sub * 64u);
+                    dst[0] = dst[1] = dst[2] = dst[3] = make_uint4(m4, m4, m4, m4);
+                }
+            } else if (valid) {
+                uint4 *dst = reinterpret_cast<uint4 *>(s_lbl + slot * kCellColours + sub * 64u);
+                dst[0] = xv; dst[1] = xv; dst[2] = xv; dst[3] = xv;
+            }
+        }
+        {
+            // items: the open sub-cells of a cell, two per item in ascending order; the lane that heads a pair builds the item
+            const uint32_t rank = (uint32_t)__builtin_popcount(scan8 & ((1u << sub) - 1u));
+            const bool head = open && (rank & 1u) == 0u;
+            const uint32_t after = scan8 & ~((2u << sub) - 1u);
+            const uint32_t s1 = after ? (uint32_t)__builtin_ctz(after) : 8u;
+            const uint32_t un = listed ? (nm | ((head && s1 < 8u) ? s_mask[threadIdx.x - sub + s1] : 0u)) : 0u;
+            const uint32_t n_un = (uint32_t)__builtin_popcount(un);
+            const uint32_t type = unlisted ? 2u : (n_un > kItemCands ? 1u : 0u);
+            const bool pend = valid && !uniform && sub == 0u;
+            const unsigned long long item_b = __ballot(head), pend_b = __ballot(pend);
+            uint32_t i_base = 0u, p_base = 0u;
+            if (lane == 0u) {
+                if (item_b) i_base = atomicAdd(&s_count[0], (uint32_t)__builtin_popcountll(item_b));
+                if (pend_b) p_base = atomicAdd(&s_count[1], (uint32_t)__builtin_popcountll(pend_b));
+            }
+            i_base = __builtin_amdgcn_readfirstlane(i_base);
+            p_base = __builtin_amdgcn_readfirstlane(p_base);
+            if (head) {
+                uint32_t iw0 = un, iw1 = 0u, iw2 = 0u;                // (type 1: the positions; type 2: unused)
+                if (type == 0u) {
+                    iw0 = 0u;
+                    uint32_t q = 0u;
+                    for (uint32_t m = un; m; m &= m - 1u, ++q) {
+                        const uint32_t cc = (uint32_t)s_list[slot * kMaxListed + (uint32_t)__builtin_ctz(m)] << (8u * (q & 3u));
+                        iw0 |= q < 4u ? cc : 0u; iw1 |= (q >= 4u && q < 8u) ? cc : 0u; iw2 |= q >= 8u ? cc : 0u;
+                    }
+                }
+                s_item[i_base + bits_below_lane(item_b)] = make_uint4(slot | (sub << 6) | (s1 << 9) | (n_un << 13) | (type << 30), iw0, iw1, iw2);
+            }
+            if (pend) s_pend[p_base + bits_below_lane(pend_b)] = (uint16_t)slot;
+            if (stats) {
+                st_single += (uint32_t)__builtin_popcountll(__ballot(single && sub == 0u));
+                st_multi += (uint32_t)__builtin_popcountll(__ballot(valid && !single && sub == 0u));
+                st_unlisted += (uint32_t)__builtin_popcountll(__ballot(unlisted && sub == 0u));
+                st_decided += (uint32_t)__builtin_popcountll(__ballot(was_decided));
+                st_scanned += (uint32_t)__builtin_popcountll(__ballot(mine || (unlisted && occupied)));
+                st_cands += wave_add_u32(mine ? np0 : ((unlisted && occupied) ? npop : 0u));
+                st_removed += wave_add_u32((uint32_t)__builtin_popcount(sm & ~nm));
+                st_one += (uint32_t)__builtin_popcountll(__ballot(one));
+            }
+        }
+        KMG_STAMP(4);
+        __syncthreads();
+        const uint32_t n_items = s_count[0];
+        const uint32_t n_pend = s_count[1];
+        KMG_STAMP_VALUE(8, n_items); KMG_STAMP_VALUE(9, n_pend); KMG_STAMP_VALUE(10, s_count[3]);
+
+        // ---- 2. scan: item i to wave i % 8, one colour of each of its two sub-cells per lane ----
+        // (the occupancy bytes of phase 3 are requested now: the scan hides their latency)
+        constexpr uint32_t kOccEarly = 6;
+        uint32_t occ_early[kOccEarly];
+#pragma unroll
+        for (uint32_t q = 0; q < kOccEarly; ++q) {
+            occ_early[q] = 0xFFu;
+            const uint32_t pi = wv + q * kOneWaves;
+            if (occ_bits && !(flags & kCubeNoEntries) && pi < n_pend) occ_early[q] = (uint32_t)occ_bits[(uint64_t)s_cell[s_pend[pi]] * 64u + lane];
+        }
+        if (wv < n_items) {
+            uint32_t A_h = 0u, A_w0 = 0u, A_w1 = 0u, A_w2 = 0u, B_h = 0u, B_w0 = 0u, B_w1 = 0u, B_w2 = 0u, C_h = 0u, C_w0 = 0u, C_w1 = 0u, C_w2 = 0u;
+            float4 A_v0, A_v1, B_v0, B_v1, C_v0, C_v1;
+            uint32_t A_c0 = 1u, A_c1 = 1u, B_c0 = 1u, B_c1 = 1u, C_c0 = 1u, C_c1 = 1u;
+            long long A_g = 0, B_g = 0, C_g = 0;
+            bool A_ok = false, B_ok = false, C_ok = false;
+            uint32_t next = wv;
+            // (an exhausted set re-requests item 0, unused: a conditional request makes the compiler wait for the registers)
+#define KMG_REQUEST_ITEM(X)                                                                                       \
+            do {                                                                                                  \
+                X##_ok = next < n_items;                                                                          \
+                const uint4 it_ = s_item[next < n_items ? next : 0u];                                             \
+                next += kOneWaves;                                                                                \
+                X##_h = __builtin_amdgcn_readfirstlane(it_.x); X##_w0 = __builtin_amdgcn_readfirstlane(it_.y);    \
+                X##_w1 = __builtin_amdgcn_readfirstlane(it_.z); X##_w2 = __builtin_amdgcn_readfirstlane(it_.w);   \
+                const uint32_t cell_ = __builtin_amdgcn_readfirstlane(s_cell[X##_h & 63u]);                       \
+                const uint32_t c0_ = cell_ * kCellColours + ((X##_h >> 6) & 7u) * 64u + lane;                     \
+                const uint32_t c1_ = cell_ * kCellColours + ((X##_h >> 9) & 7u) * 64u + lane;   /* s1 == 8: sub-cell 0, unused */ \
+                X##_v0 = lab_table[c0_]; X##_v1 = lab_table[c1_];                                                 \
+                if (SUMS) { X##_c0 = hist[c0_]; X##_c1 = hist[c1_]; X##_g = sub_agg[(uint64_t)cell_ * 32u + (lane & 31u)]; } \
+            } while (0)
+            auto scan_item = [&](const uint32_t hdr, const uint32_t w0, const uint32_t w1, const uint32_t w2, const float4 v0, const float4 v1,
+                                 const uint32_t cnt0, const uint32_t cnt1, const long long sagg) {
+                const uint32_t islot = hdr & 63u, s0 = (hdr >> 6) & 7u, s1 = (hdr >> 9) & 15u, n = (hdr >> 13) & 63u, type = hdr >> 30;
+                const PixelTerms pt0 = pixel_terms_fast(v0.x, v0.y, v0.z, v0.w), pt1 = pixel_terms_fast(v1.x, v1.y, v1.z, v1.w);
+                uint32_t ix0 = 0u, ix1 = 0u;
+                if (type == 0u) {
+                    // (k_cube_scan's item loop: lane p < n holds the p-th candidate; key | position, one integer min / med3 per visit)
+                    const uint32_t my_cand = ((lane < 4u ? w0 : (lane < 8u ? w1 : w2)) >> (8u * (lane & 3u))) & 0xFFu;
+                    uint32_t b0 = 0x7F7FFFFFu, r0 = 0x7F7FFFFFu, b1 = 0x7F7FFFFFu, r1 = 0x7F7FFFFFu;   // smallest / runner-up
+                    const f32x2 qL = {pt0.L, pt1.L}, qa = {pt0.a, pt1.a}, qb = {pt0.b, pt1.b}, qC = {pt0.C, pt1.C};
+                    const f32x2 qwC = {pt0.wC, pt1.wC}, qwH = {pt0.wH, pt1.wH};
+                    auto cand_at = [&](uint32_t p) { return ((p < 4u ? w0 : (p < 8u ? w1 : w2)) >> (8u * (p & 3u))) & 0xFFu; };
+                    for (uint32_t p = 0; p < n; ++p) {
+                        const float4 c = s_cent[cand_at(p)];
+                        const f32x2 dL = qL - c.x, da = qa - c.y, db = qb - c.z, dC = qC - c.w;
+                        const f32x2 dC2 = dC * dC;
+                        const f32x2 t = __builtin_elementwise_fma(db, db, da * da);
+                        f32x2 h = t - dC2;
+                        h.x = fmaxf(h.x, 0.0f); h.y = fmaxf(h.y, 0.0f);
+                        const f32x2 key = __builtin_elementwise_fma(h, qwH, __builtin_elementwise_fma(dC2, qwC, dL * dL));
+                        uint32_t u0, u1;                               // (key & ~31) | position (wave-uniform)
+                        asm("v_bfi_b32 %0, 31, %1, %2" : "=v"(u0) : "s"(p), "v"(float_to_bits(key.x)));
+                        asm("v_bfi_b32 %0, 31, %1, %2" : "=v"(u1) : "s"(p), "v"(float_to_bits(key.y)));
+                        r0 = umed3(u0, b0, r0); b0 = min(b0, u0);
+                        r1 = umed3(u1, b1, r1); b1 = min(b1, u1);
+                    }
+                    uint32_t p0 = b0 & 31u, p1 = b1 & 31u;
+                    // near-tie repair (kmg_math.h): rare; decided by the literal distance, first minimum wins
+                    const float thr0 = tie_threshold(bits_to_float(b0 & ~31u)), thr1 = tie_threshold(bits_to_float(b1 & ~31u));
+                    const bool near0 = bits_to_float(r0 & ~31u) <= thr0, near1 = bits_to_float(r1 & ~31u) <= thr1;
+                    if (__ballot(near0 || near1)) {
+                        float lb0 = 100000.0f, lb1 = 100000.0f;       // find_centroid.wgsl:29-30
+                        uint32_t li0 = 0u, li1 = 0u;
+                        for (uint32_t p = 0; p < n; ++p) {
+                            const float4 c = s_cent[cand_at(p)];
+                            if (near0 && cie94_key(pt0, c.x, c.y, c.z, c.w) <= thr0) {
+                                const float d = cie94_c(v0.x, v0.y, v0.z, v0.w, c.x, c.y, c.z, c.w);
+                                if (d < lb0) { lb0 = d; li0 = p; }
+                            }
+                            if (near1 && cie94_key(pt1, c.x, c.y, c.z, c.w) <= thr1) {
+                                const float d = cie94_c(v1.x, v1.y, v1.z, v1.w, c.x, c.y, c.z, c.w);
+                                if (d < lb1) { lb1 = d; li1 = p; }
+                            }
+                        }
+                        p0 = near0 ? li0 : p0;
+                        p1 = near1 ? li1 : p1;
+                    }
+                    ix0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(p0 << 2), (int)my_cand);
+                    ix1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(p1 << 2), (int)my_cand);
+                } else {
+                    // rare: more than kItemCands candidates for the pair (by list position, w0 = their mask), or a cell without a
+                    // list (every candidate of the cell's mask) -- k_cube_scan's general loop: float keys, compare and select
+                    float best0 = 1.0e10f, second0 = 1.0e10f, best1 = 1.0e10f, second1 = 1.0e10f;
+                    const uint32_t rounds = type == 1u ? 1u : words;
+                    auto cand_word = [&](uint32_t w) -> unsigned long long { return type == 1u ? (unsigned long long)w0 : uniform_u64(s_cmask[islot * 4u + w]); };
+                    auto cand_of = [&](uint32_t w, uint32_t bit) -> uint32_t {
+                        return type == 1u ? __builtin_amdgcn_readfirstlane((uint32_t)s_list[islot * kMaxListed + bit]) : w * 64u + bit;
+                    };
+                    for (uint32_t w = 0; w < rounds; ++w) {
+                        for (unsigned long long m = cand_word(w); m; m &= m - 1ull) {
+                            const uint32_t j = cand_of(w, (uint32_t)__builtin_ctzll(m));
+                            const float4 c = s_cent[j];
+                            const float d0 = cie94_key(pt0, c.x, c.y, c.z, c.w), d1 = cie94_key(pt1, c.x, c.y, c.z, c.w);
+                            second0 = __builtin_amdgcn_fmed3f(d0, best0, second0);
+                            second1 = __builtin_amdgcn_fmed3f(d1, best1, second1);
+                            if (d0 < best0) { best0 = d0; ix0 = j; }
+                            if (d1 < best1) { best1 = d1; ix1 = j; }
+                        }
+                    }
+                    const float thr0 = tie_threshold(best0), thr1 = tie_threshold(best1);
+                    const bool near0 = second0 <= thr0, near1 = second1 <= thr1;
+                    if (__ballot(near0 || near1)) {
+                        float lb0 = 100000.0f, lb1 = 100000.0f;
+                        uint32_t li0 = 0u, li1 = 0u;
+                        for (uint32_t w = 0; w < rounds; ++w) {
+                            for (unsigned long long m = cand_word(w); m; m &= m - 1ull) {
+                                const uint32_t j = cand_of(w, (uint32_t)__builtin_ctzll(m));
+                                const float4 c = s_cent[j];
+                                if (near0 && cie94_key(pt0, c.x, c.y, c.z, c.w) <= thr0) {
+                                    const float d = cie94_c(v0.x, v0.y, v0.z, v0.w, c.x, c.y, c.z, c.w);
+                                    if (d < lb0) { lb0 = d; li0 = j; }
+                                }
+                                if (near1 && cie94_key(pt1, c.x, c.y, c.z, c.w) <= thr1) {
+                                    const float d = cie94_c(v1.x, v1.y, v1.z, v1.w, c.x, c.y, c.z, c.w);
+                                    if (d < lb1) { lb1 = d; li1 = j; }
+                                }
+                            }
+                        }
+                        ix0 = near0 ? li0 : ix0;
+                        ix1 = near1 ? li1 : ix1;
+                    }
+                }
+                // what a scanned sub-cell leaves behind: its 64 labels (LDS) and its sums -- the sub-cell's total goes to a reference
+                // label R, a colour with another label moves its own contribution from R to that label
+                auto finish = [&](uint32_t s, uint32_t ix, uint32_t cnt, float vL, float va, float vb) {
+                    s_lbl[islot * kCellColours + s * 64u + lane] = (uint8_t)ix;
+                    if (!SUMS) return;
+                    const bool counts = cnt != 0u;
+                    const unsigned long long occm = __ballot(counts);
+                    if (!occm) return;
+                    const uint32_t X0 = lane_value(ix, (uint32_t)__builtin_ctzll(occm));
+                    const unsigned long long other = __ballot(counts && ix != X0);
+                    uint32_t R = X0;
+                    if (other) {
+                        const uint32_t X1 = lane_value(ix, (uint32_t)__builtin_ctzll(other));
+                        if (__builtin_popcountll(__ballot(counts && ix == X1)) > __builtin_popcountll(occm & ~other)) R = X1;
+                    }
+                    if ((lane >> 2) == s) atomicAdd(bins + 4ull * R + (lane & 3u), (unsigned long long)sagg);
+                    if (other && counts && ix != R) {
+                        const long long m = (long long)cnt;
+                        const long long c0 = m * (long long)lab_fix(vL), c1 = m * (long long)lab_fix(va), c2 = m * (long long)lab_fix(vb);
+                        unsigned long long *to = my_bins + 4ull * ix, *from = my_bins + 4ull * R;
+                        atomicAdd(to + 0, (unsigned long long)c0); atomicAdd(from + 0, (unsigned long long)(-c0));
+                        atomicAdd(to + 1, (unsigned long long)c1); atomicAdd(from + 1, (unsigned long long)(-c1));
+                        atomicAdd(to + 2, (unsigned long long)c2); atomicAdd(from + 2, (unsigned long long)(-c2));
+                        atomicAdd(to + 3, (unsigned long long)m);  atomicAdd(from + 3, (unsigned long long)(-m));
+                    }
+                };
+                finish(s0, ix0, cnt0, v0.x, v0.y, v0.z);
+                if (s1 < 8u) finish(s1, ix1, cnt1, v1.x, v1.y, v1.z);
+            };
+            KMG_REQUEST_ITEM(A);
+            KMG_REQUEST_ITEM(B);
+            KMG_REQUEST_ITEM(C);
+            for (;;) {
+                scan_item(A_h, A_w0, A_w1, A_w2, A_v0, A_v1, A_c0, A_c1, A_g);
+                if (!B_ok) break;
+                KMG_REQUEST_ITEM(A);
+                scan_item(B_h, B_w0, B_w1, B_w2, B_v0, B_v1, B_c0, B_c1, B_g);
+                if (!C_ok) break;
+                KMG_REQUEST_ITEM(B);
+                scan_item(C_h, C_w0, C_w1, C_w2, C_v0, C_v1, C_c0, C_c1, C_g);
+                if (!A_ok) break;
+                KMG_REQUEST_ITEM(C);
+            }
+#undef KMG_REQUEST_ITEM
+        }
+        KMG_STAMP(5);
+        __syncthreads();
+        KMG_STAMP(6);
+
+        // ---- 3. entries: the pair entry of every cell with more than one label from its 512 labels in LDS; the labels leave ----
+        for (uint32_t pi = wv; pi < n_pend; pi += kOneWaves) {
+            const uint32_t ps = __builtin_amdgcn_readfirstlane((uint32_t)s_pend[pi]);
+            const uint32_t pcell = __builtin_amdgcn_readfirstlane(s_cell[ps]);
+            const uint2 lv = *reinterpret_cast<const uint2 *>(s_lbl + ps * kCellColours + lane * 8u);
+            uint32_t e = kPairPending;
+            if (!(flags & kCubeNoEntries)) {
+                const uint32_t round = (pi - wv) / kOneWaves;
+                uint32_t occ = 0xFFu;
+                if (round < kOccEarly) {
+#pragma unroll
+                    for (uint32_t q = 0; q < kOccEarly; ++q) occ = round == q ? occ_early[q] : occ;
+                } else if (occ_bits) {
+                    occ = (uint32_t)occ_bits[(uint64_t)pcell * 64u + lane];
+                }
+                uint32_t idx[8];
+#pragma unroll
+                for (uint32_t q = 0; q < 4u; ++q) { idx[q] = (lv.x >> (8u * q)) & 0xFFu; idx[4u + q] = (lv.y >> (8u * q)) & 0xFFu; }
+                e = cell_pair_entry(idx, occ, lane);
+            }
+            if (lane == 0u) pair_entries[pcell] = e;
+            *reinterpret_cast<uint2 *>(colour_labels + (uint64_t)pcell * kCellColours + lane * 8u) = lv;
+        }
+        KMG_STAMP(7);
+    }
+    if (stats && lane == 0u) {
+        atomicAdd(stats + 0, st_single); atomicAdd(stats + 1, st_multi); atomicAdd(stats + 2, st_decided); atomicAdd(stats + 3, st_scanned);
+        atomicAdd(stats + 4, st_cands); atomicAdd(stats + 5, st_unlisted); atomicAdd(stats + 6, st_removed); atomicAdd(stats + 7, st_one);
+    }
+    if (SUMS) flush_bins(bins, k, kOneRepl, bin_stride, sums, n_rows);
+}
+
+#ifdef KMG_TOOLS
+extern "C" KMG_API int kmg_tools_cube_one_stamps(unsigned long long *out, uint32_t n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_one_stamps), sizeof(unsigned long long) * std::min<size_t>(n, (kCells / kOneCells) * 12u));
+}
+#endif
+
 static uint32_t grid_or(const char *e, uint32_t dflt)
 {
     if (e) { const int v = atoi(e); if (v >= 1 && v <= 65536) return (uint32_t)v; }
@@ -2100,6 +2654,14 @@ bool cube_prune_wanted(uint32_t k)
     return on && k > kSmallMaxK && k <= 256u;
 }
 
+// the cube pass of this k (and these caller flags) is ONE launch: k_cube_small, or k_cube_one -- its tail can ride on a label pass
+bool cube_single_launch(uint32_t k, uint32_t flags)
+{
+    if (k <= kSmallMaxK) return true;
+    static const bool one_on = tools_env_int(KMG_TOOLS_ENV("KMG_CUBE_ONE"), 1) != 0;      // (tools build: 0 = the four launches)
+    return one_on && cube_prune_wanted(k) && !(flags & kCubeNoPrune);
+}
+
 hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *sub_agg, const uint8_t *occ_bits,
                        const uint32_t *work, const CellBounds *bounds, const CellBounds *sub_bounds, const Centroid *cent,
                        uint32_t k, const float4 *lab_table, uint64_t *masks, void *cell_work, void *colour_labels,
@@ -2121,6 +2683,7 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
         const size_t lds_max = device_info().lds_max;
         if (lds_stage > lds_max || lds_scan > lds_max) return hipErrorInvalidValue;
     }
+    const size_t lds_max_dev = device_info().lds_max;
     // small centroid tables: the whole pass in one launch (k_cube_small) + the tail workgroup
     static const bool small_on = tools_env_int(KMG_TOOLS_ENV("KMG_CUBE_SMALL"), 1) != 0;
     if (k <= kSmallMaxK && small_on) {
@@ -2156,6 +2719,22 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
                                (const uint32_t *)nullptr);
             return hipGetLastError();
         }
+        if (tl.acc_out)
+            hipLaunchKernelGGL((k_cube_pairs<uint8_t>), dim3(1), dim3(kBlock), 0, st, work, 1, occ_bits,
+                               (const uint8_t *)colour_labels, sub_table, flags | kCubeNoEntries, sums, k, tl, (const uint32_t *)nullptr);
+        return hipGetLastError();
+    }
+    // 32 < k <= 256 without hot cells: the whole pass in one launch (k_cube_one) + the tail workgroup
+    if (cube_single_launch(k, flags)) {
+        const size_t lds = cube_one_lds_bytes(k, with_sums);
+        if (lds > lds_max_dev) return hipErrorInvalidValue;
+        if (!n_rows) n_rows = 1u;
+        if (with_sums)
+            hipLaunchKernelGGL((k_cube_one<true>), dim3(kCells / kOneCells), dim3(kOneBlock), lds, st, hist, agg, sub_agg, occ_bits, work, bounds,
+                               sub_bounds, sub_affine, cent, k, lab_table, masks, (uint8_t *)colour_labels, sub_table, sums, n_rows, flags, stats);
+        else
+            hipLaunchKernelGGL((k_cube_one<false>), dim3(kCells / kOneCells), dim3(kOneBlock), lds, st, hist, agg, sub_agg, occ_bits, work, bounds,
+                               sub_bounds, sub_affine, cent, k, lab_table, masks, (uint8_t *)colour_labels, sub_table, sums, n_rows, flags, stats);
         if (tl.acc_out)
             hipLaunchKernelGGL((k_cube_pairs<uint8_t>), dim3(1), dim3(kBlock), 0, st, work, 1, occ_bits,
                                (const uint8_t *)colour_labels, sub_table, flags | kCubeNoEntries, sums, k, tl, (const uint32_t *)nullptr);

@@ -467,8 +467,8 @@ static int table_assign(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_
         tail.convergence = s->p->opt.convergence;
         tail.cent = s->d_cent;
         tail.n_converged = s->d_nconv;
-        // (small centroid tables: the cube pass is one launch, and when a label pass follows, its tail rides on that one)
-        const bool tail_on_labels = d_labels != nullptr && s->k <= kCubeSmallMaxK;
+        // (k <= 32, and 32 < k <= 256 without hot cells: the cube pass is one launch, and when a label pass follows, its tail rides on that one)
+        const bool tail_on_labels = d_labels != nullptr && s->k <= 256u && cube_single_launch(s->k, t.n_hot ? kCubeNoPrune : 0u);
         PROF_LAUNCH(s, KMG_K_CUBE, st, launch_cube(t.d_hist, t.d_agg, t.d_sub_agg, t.d_occ, t.d_work_share ? t.d_work_share : t.d_work,
                                                    s->p->d_bounds, s->p->d_sub_bounds,
                                                    s->d_cent, s->k, s->p->d_lab_table, t.d_masks, t.d_cell_work, t.d_colour_labels, t.d_sub,

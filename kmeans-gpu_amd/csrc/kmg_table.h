@@ -198,6 +198,9 @@ constexpr uint32_t kCubeSplitLong = 0x80000u;  // (set by launch_cube itself, k 
 constexpr uint32_t kCubePruned = 0x20000u;   // (set by launch_cube itself: k_cube_prune has run between the stage and the scan)
 bool cube_prune_wanted(uint32_t k);          // the general pass makes the dominance test: launch_cube wants sub_affine for this k
 constexpr uint32_t kCubeSmallMaxK = 32;      // k up to which the cube pass is the one-launch k_cube_small
+// the cube pass of this k with these caller flags (kCubeNoPrune) is ONE launch -- k_cube_small, or k_cube_one for 32 < k <= 256
+// on images without hot cells: when a label pass follows, the pass's tail (CubeTail) rides on that one
+bool cube_single_launch(uint32_t k, uint32_t flags);
 hipError_t launch_cube_entries(const uint32_t *work, const uint8_t *occ_bits, const void *colour_labels, uint16_t *sub_table,
                                uint32_t k, hipStream_t st);
 // What the LAST launch of the cube pass does on top (one of its workgroups, once the sums are complete): hand the k x 4
