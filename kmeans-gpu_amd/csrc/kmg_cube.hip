@@ -2098,33 +2098,23 @@ __global__ __launch_bounds__(kSmallBlock) __attribute__((amdgpu_waves_per_eu(4, 
 // workgroup launched alone, as for k_cube_small.  LDS (k = 256): ~75 KiB, two workgroups per CU.
 // stats as k_cube_lean + k_cube_prune.  flags: bit 0, kCubeNoEntries.
 // ------------------------------------------------------------------------------------------
-constexpr int kOneBlock = 512;
-constexpr uint32_t kOneWaves = kOneBlock / 64, kOneCells = kOneWaves * 8u;
-constexpr uint32_t kOneTests = 2048;                             // dominance tests a workgroup lists (more are dropped = kept candidates)
+constexpr int kOneBlockMax = 1024;                               // (tools build: 512 as well, two workgroups per CU)
+constexpr uint32_t kOneTests = 384;                              // dominance tests a WAVE lists (~120 on the benchmark image; more are dropped = kept candidates)
 constexpr uint32_t kOneRepl = 2;                                 // copies of the LDS bins
-constexpr uint32_t kOneModelStride = 24;                         // words per model in LDS: [wave][chunk of 16 B][lane], written by global_load_lds
-constexpr uint32_t kOneItems = kOneCells * 4u;                   // at most four pairs of sub-cells per cell
 
-__host__ __device__ constexpr size_t one_max(size_t a, size_t b) { return a > b ? a : b; }
-// the two regions of k_cube_one's LDS that live twice: models -> bins + labels, tests -> items
-__host__ __device__ inline size_t one_union_bytes(uint32_t k, bool with_sums)
+static size_t cube_one_lds_bytes(uint32_t k, bool with_sums, uint32_t kOneBlock)
 {
+    const uint32_t kOneWaves = kOneBlock / 64u, kOneCells = kOneWaves * 8u, kOneItems = kOneCells * 4u;
     const size_t bins = with_sums ? sizeof(unsigned long long) * kOneRepl * (4ull * k + 4ull) : 0u;
-    return one_max(sizeof(uint32_t) * kOneBlock * kOneModelStride, bins + (size_t)kOneCells * kCellColours);
-}
-constexpr size_t kOneTestItemBytes = one_max(sizeof(uint16_t) * kOneTests, sizeof(uint4) * kOneItems);
-
-static size_t cube_one_lds_bytes(uint32_t k, bool with_sums)
-{
-    const size_t un = one_union_bytes(k, with_sums), ti = kOneTestItemBytes;
-    return sizeof(float4) * 256u + un + ti + sizeof(uint16_t) * kOneCells * kMaxListed + sizeof(uint32_t) * kOneBlock * 2u +
-           sizeof(unsigned long long) * kOneCells * 4u + sizeof(uint32_t) * kOneCells * 2u + sizeof(uint16_t) * kOneCells + sizeof(uint32_t) * 8u;
+    return sizeof(float4) * 256u + bins + (size_t)kOneCells * kCellColours + sizeof(uint4) * kOneItems + sizeof(uint16_t) * kOneWaves * kOneTests +
+           sizeof(unsigned long long) * kOneCells * 4u + sizeof(uint32_t) * kOneBlock * 2u + (size_t)kOneCells * 64u +
+           sizeof(uint32_t) * kOneCells * 3u + sizeof(uint32_t) * (8u + kOneWaves) + sizeof(uint16_t) * kOneCells * kMaxListed;
 }
 
 #ifdef KMG_TOOLS
 // tools build: phase stamps of k_cube_one (s_memrealtime, 100 MHz), [workgroup][8]: start, 1a done (wave 0), 1b swept, tests done, 1c done,
 // scan done (wave 0), scan done (all), entries done (wave 0); [8..10] items, pending cells, tests of the workgroup
-__device__ unsigned long long g_one_stamps[(kCells / kOneCells) * 12u];
+__device__ unsigned long long g_one_stamps[512 * 12u];
 #define KMG_STAMP(i) do { if (threadIdx.x == 0u) g_one_stamps[blockIdx.x * 12u + (i)] = wall_clock64(); } while (0)
 #define KMG_STAMP_VALUE(i, v) do { if (threadIdx.x == 0u) g_one_stamps[blockIdx.x * 12u + (i)] = (v); } while (0)
 #else
@@ -2132,7 +2122,7 @@ __device__ unsigned long long g_one_stamps[(kCells / kOneCells) * 12u];
 #define KMG_STAMP_VALUE(i, v) do { } while (0)
 #endif
 
-template <bool SUMS>
+template <bool SUMS, int kOneBlock>
 __global__ __launch_bounds__(kOneBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_cube_one(
     const uint32_t *__restrict__ hist, const int64_t *__restrict__ agg, const int64_t *__restrict__ sub_agg,
     const uint8_t *__restrict__ occ_bits, const uint32_t *__restrict__ work, const CellBounds *__restrict__ bounds,
@@ -2141,26 +2131,25 @@ __global__ __launch_bounds__(kOneBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
     uint16_t *__restrict__ sub_table, int64_t *__restrict__ sums, uint32_t n_rows, uint32_t flags,
     unsigned long long *__restrict__ stats)
 {
+    constexpr uint32_t kOneWaves = kOneBlock / 64, kOneCells = kOneWaves * 8u;       // a wave: 8 cells
+    constexpr uint32_t kOneItems = kOneCells * 4u;                                   // at most four pairs of sub-cells per cell
     extern __shared__ float4 smem4[];
     float4 *s_cent = smem4;                                                            // [256]
-    // one region, two lives: the sub-cells' affine models (until the tests are done), then the bins and the cells' labels
-    uint4 *s_model4 = reinterpret_cast<uint4 *>(smem4 + 256);
-    unsigned long long *bins = reinterpret_cast<unsigned long long *>(s_model4);
+    unsigned long long *bins = reinterpret_cast<unsigned long long *>(smem4 + 256);
     const uint32_t bin_stride = 4u * k + 4u;
     const uint32_t n_bins = SUMS ? kOneRepl * bin_stride : 0u;
     uint8_t *s_lbl = reinterpret_cast<uint8_t *>(bins + n_bins);                       // [cells][512]
-    const size_t un_bytes = one_union_bytes(k, SUMS);
-    // likewise: the tests, then the items
-    uint16_t *s_test = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(s_model4) + un_bytes);
-    uint4 *s_item = reinterpret_cast<uint4 *>(s_test);
-    unsigned long long *s_cmask = reinterpret_cast<unsigned long long *>(reinterpret_cast<uint8_t *>(s_test) + kOneTestItemBytes);   // [cells][4]
+    uint4 *s_item = reinterpret_cast<uint4 *>(s_lbl + kOneCells * kCellColours);        // [kOneItems]
+    uint16_t *s_test = reinterpret_cast<uint16_t *>(s_item + kOneItems);               // [waves][kOneTests]: (lane << 5) | position
+    unsigned long long *s_cmask = reinterpret_cast<unsigned long long *>(s_test + kOneWaves * kOneTests);   // [cells][4]
     uint32_t *s_mask = reinterpret_cast<uint32_t *>(s_cmask + kOneCells * 4u);          // [sub-cells]: candidates (list positions)
     uint32_t *s_ref = s_mask + kOneBlock;                                              // [sub-cells]: upper bound | reference position
-    uint32_t *s_cell = s_ref + kOneBlock;                                              // [cells]
+    uint8_t *s_occ = reinterpret_cast<uint8_t *>(s_ref + kOneBlock);                   // [cells][64]: occupancy bits of the cell's colours
+    uint32_t *s_cell = reinterpret_cast<uint32_t *>(s_occ + kOneCells * 64u);           // [cells]
     uint32_t *s_npop = s_cell + kOneCells;                                             // [cells]: candidates | first << 16
-    uint32_t *s_count = s_npop + kOneCells;                                            // [0] items, [1] pending cells, [2] far centroid, [3] tests
-    uint16_t *s_list = reinterpret_cast<uint16_t *>(s_count + 8);                      // [cells][kMaxListed]: centroid by position
-    uint16_t *s_pend = s_list + kOneCells * kMaxListed;                                // [cells]: slots whose cell needs an entry
+    uint32_t *s_left = s_npop + kOneCells;                                             // [cells]: items of the cell still to scan
+    uint32_t *s_count = s_left + kOneCells;                                            // [0] items, [2] far centroid, [4] next item, [8 + w] tests of wave w
+    uint16_t *s_list = reinterpret_cast<uint16_t *>(s_count + 8 + kOneWaves);                     // [cells][kMaxListed]: centroid by position
 
     const uint32_t vz = opaque_vgpr_zero();
     const uint32_t n_work_v = SUMS ? work[vz] : kCells;
@@ -2169,7 +2158,8 @@ __global__ __launch_bounds__(kOneBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
         if (threadIdx.x < k) { const Centroid c = cent[threadIdx.x]; v = make_float4(c.L, c.a, c.b, c.C); }
         s_cent[threadIdx.x] = v;
     }
-    if (threadIdx.x < 8u) s_count[threadIdx.x] = 0u;
+    if (threadIdx.x < 8u + kOneWaves) s_count[threadIdx.x] = 0u;
+    if (SUMS) for (uint32_t i = threadIdx.x; i < n_bins; i += kOneBlock) bins[i] = 0ull;
     __syncthreads();
     if (threadIdx.x < k) {
         const float4 c = s_cent[threadIdx.x];
@@ -2218,15 +2208,9 @@ __global__ __launch_bounds__(kOneBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
             g01 = sp[0]; g23 = sp[1];
             cell_sum = agg[4ull * cell + (sub & 3u)];
         }
-        if (dominance) {
-            // the model goes straight to LDS (global_load_lds_dwordx4: no registers held over 1a, nothing to write later):
-            // chunk t of the wave's 64 sub-cells = 1 KiB at [wave][t][lane]
-            const uint4 *mp = reinterpret_cast<const uint4 *>(sub_affine + (uint64_t)sc * kAffineFloats);
-#pragma unroll
-            for (int t = 0; t < 6; ++t)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(mp + t),
-                                                 (__attribute__((address_space(3))) void *)(s_model4 + (wv * 6u + (uint32_t)t) * 64u), 16, 0, 0);
-        }
+        // (the occupancy bits of the thread's 8 x 8 colours: phase 3 reads them from LDS)
+        uint2 occ8 = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+        if (occ_bits) occ8 = *reinterpret_cast<const uint2 *>(occ_bits + (uint64_t)cell * 64u + sub * 8u);
         if (sub == 0u) s_cell[slot] = cell;
 
         // ---- 1a. the candidates of the wave's cells, one cell at a time (k_cube_lean) ----
@@ -2301,36 +2285,38 @@ __global__ __launch_bounds__(kOneBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
         const bool was_decided = listed && occupied && np0 == 1u;   // decided by its bounds
         const bool mine = listed && occupied && np0 > 1u;            // open: the dominance tests, then the scan if still open
         s_mask[threadIdx.x] = sm;
+        *reinterpret_cast<uint2 *>(s_occ + slot * 64u + sub * 8u) = occ8;
+        // the dominance tests of the WAVE's sub-cells: (sub-cell, candidate other than the reference) as one compact list, a test per
+        // lane; the sub-cell's model comes from memory (L2: 96 bytes, read by the one or two lanes that test it).  No workgroup barrier:
+        // a wave's cells are its own until their items are listed.
         const uint32_t others = (mine && dominance) ? sm & ~(1u << istar) : 0u;
         if (others) {
             s_ref[threadIdx.x] = ubits | istar;
             const uint32_t nt = (uint32_t)__builtin_popcount(others);
-            uint32_t at = atomicAdd(&s_count[3], nt);
+            uint32_t at = atomicAdd(&s_count[8u + wv], nt);
             for (uint32_t m = others; m && at < kOneTests; m &= m - 1u, ++at)
-                s_test[at] = (uint16_t)((threadIdx.x << 5) | (uint32_t)__builtin_ctz(m));
+                s_test[wv * kOneTests + at] = (uint16_t)((lane << 5) | (uint32_t)__builtin_ctz(m));
         }
         KMG_STAMP(2);
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if (dominance) {
-            const uint32_t n_tests = min(s_count[3], kOneTests);
-            for (uint32_t t = threadIdx.x; t < n_tests; t += kOneBlock) {
-                const uint32_t e = (uint32_t)s_test[t] >> 5, tp = (uint32_t)s_test[t] & 31u;
+            const uint32_t n_tests = min(__builtin_amdgcn_readfirstlane(s_count[8u + wv]), kOneTests);
+            for (uint32_t t = lane; t < n_tests; t += 64u) {
+                const uint32_t ent = (uint32_t)s_test[wv * kOneTests + t];
+                const uint32_t e = wv * 64u + (ent >> 5), tp = ent & 31u;
                 const uint32_t r = s_ref[e];
                 const float4 cj = s_cent[s_list[(e >> 3) * kMaxListed + tp]], ci4 = s_cent[s_list[(e >> 3) * kMaxListed + (r & 31u)]];
                 HalfModel mdl;
-#pragma unroll
-                for (int q = 0; q < 6; ++q) {
-                    const uint4 v = s_model4[((e >> 6) * 6u + (uint32_t)q) * 64u + (e & 63u)];
-                    mdl.q[4 * q] = v.x; mdl.q[4 * q + 1] = v.y; mdl.q[4 * q + 2] = v.z; mdl.q[4 * q + 3] = v.w;
-                }
+                mdl.load(sub_affine, (uint64_t)s_cell[e >> 3] * 8u + (e & 7u));
                 if (dominated(mdl, cj, ci4, bits_to_float(r & ~31u))) atomicAnd(&s_mask[e], ~(1u << tp));
             }
-            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
         KMG_STAMP(3);
-        // (the models have been read: their bytes become the bins and the labels)
-        if (SUMS) for (uint32_t i = threadIdx.x; i < n_bins; i += kOneBlock) bins[i] = 0ull;
-        __syncthreads();
 
         // ---- 1c. what is left of every sub-cell's set: decided / open; uniform cells; items and pending cells ----
         const uint32_t nm = s_mask[threadIdx.x];
@@ -2369,6 +2355,7 @@ __global__ __launch_bounds__(kOneBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
                 dst[0] = xv; dst[1] = xv; dst[2] = xv; dst[3] = xv;
             }
         }
+        unsigned long long pend0_b = 0ull;
         {
             // items: the open sub-cells of a cell, two per item in ascending order; the lane that heads a pair builds the item
             const uint32_t rank = (uint32_t)__builtin_popcount(scan8 & ((1u << sub) - 1u));
@@ -2378,15 +2365,15 @@ __global__ __launch_bounds__(kOneBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
             const uint32_t un = listed ? (nm | ((head && s1 < 8u) ? s_mask[threadIdx.x - sub + s1] : 0u)) : 0u;
             const uint32_t n_un = (uint32_t)__builtin_popcount(un);
             const uint32_t type = unlisted ? 2u : (n_un > kItemCands ? 1u : 0u);
+            // a cell that needs an entry gets it from the wave that scans the LAST of its items (s_left counts them down);
+            // one without items (its sub-cells were all decided, to different centroids) from its own wave, after the scan
             const bool pend = valid && !uniform && sub == 0u;
-            const unsigned long long item_b = __ballot(head), pend_b = __ballot(pend);
-            uint32_t i_base = 0u, p_base = 0u;
-            if (lane == 0u) {
-                if (item_b) i_base = atomicAdd(&s_count[0], (uint32_t)__builtin_popcountll(item_b));
-                if (pend_b) p_base = atomicAdd(&s_count[1], (uint32_t)__builtin_popcountll(pend_b));
-            }
+            if (pend) s_left[slot] = ((uint32_t)__builtin_popcount(scan8) + 1u) >> 1;
+            pend0_b = __ballot(pend && scan8 == 0u);
+            const unsigned long long item_b = __ballot(head);
+            uint32_t i_base = 0u;
+            if (lane == 0u && item_b) i_base = atomicAdd(&s_count[0], (uint32_t)__builtin_popcountll(item_b));
             i_base = __builtin_amdgcn_readfirstlane(i_base);
-            p_base = __builtin_amdgcn_readfirstlane(p_base);
             if (head) {
                 uint32_t iw0 = un, iw1 = 0u, iw2 = 0u;                // (type 1: the positions; type 2: unused)
                 if (type == 0u) {
@@ -2397,9 +2384,8 @@ __global__ __launch_bounds__(kOneBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
                         iw0 |= q < 4u ? cc : 0u; iw1 |= (q >= 4u && q < 8u) ? cc : 0u; iw2 |= q >= 8u ? cc : 0u;
                     }
                 }
-                s_item[i_base + bits_below_lane(item_b)] = make_uint4(slot | (sub << 6) | (s1 << 9) | (n_un << 13) | (type << 30), iw0, iw1, iw2);
+                s_item[i_base + bits_below_lane(item_b)] = make_uint4(slot | (sub << 7) | (s1 << 10) | (n_un << 14) | (type << 30), iw0, iw1, iw2);
             }
-            if (pend) s_pend[p_base + bits_below_lane(pend_b)] = (uint16_t)slot;
             if (stats) {
                 st_single += (uint32_t)__builtin_popcountll(__ballot(single && sub == 0u));
                 st_multi += (uint32_t)__builtin_popcountll(__ballot(valid && !single && sub == 0u));
@@ -2414,43 +2400,51 @@ __global__ __launch_bounds__(kOneBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
         KMG_STAMP(4);
         __syncthreads();
         const uint32_t n_items = s_count[0];
-        const uint32_t n_pend = s_count[1];
-        KMG_STAMP_VALUE(8, n_items); KMG_STAMP_VALUE(9, n_pend); KMG_STAMP_VALUE(10, s_count[3]);
+        KMG_STAMP_VALUE(8, n_items); KMG_STAMP_VALUE(10, s_count[8]);
 
-        // ---- 2. scan: item i to wave i % 8, one colour of each of its two sub-cells per lane ----
-        // (the occupancy bytes of phase 3 are requested now: the scan hides their latency)
-        constexpr uint32_t kOccEarly = 6;
-        uint32_t occ_early[kOccEarly];
+        // ---- 3. (defined first: 2. calls it) the pair entry of a cell from its 512 labels in LDS; the labels leave ----
+        auto cell_entry = [&](const uint32_t ps) {
+            const uint32_t pcell = __builtin_amdgcn_readfirstlane(s_cell[ps]);
+            const uint2 lv = *reinterpret_cast<const uint2 *>(s_lbl + ps * kCellColours + lane * 8u);
+            uint32_t e = kPairPending;
+            if (!(flags & kCubeNoEntries)) {
+                const uint32_t occ = (uint32_t)s_occ[ps * 64u + lane];
+                uint32_t idx[8];
 #pragma unroll
-        for (uint32_t q = 0; q < kOccEarly; ++q) {
-            occ_early[q] = 0xFFu;
-            const uint32_t pi = wv + q * kOneWaves;
-            if (occ_bits && !(flags & kCubeNoEntries) && pi < n_pend) occ_early[q] = (uint32_t)occ_bits[(uint64_t)s_cell[s_pend[pi]] * 64u + lane];
-        }
-        if (wv < n_items) {
+                for (uint32_t q = 0; q < 4u; ++q) { idx[q] = (lv.x >> (8u * q)) & 0xFFu; idx[4u + q] = (lv.y >> (8u * q)) & 0xFFu; }
+                e = cell_pair_entry(idx, occ, lane);
+            }
+            if (lane == 0u) pair_entries[pcell] = e;
+            *reinterpret_cast<uint2 *>(colour_labels + (uint64_t)pcell * kCellColours + lane * 8u) = lv;
+        };
+
+        // ---- 2. scan: the items handed out one by one (an LDS counter: whoever is free takes the next), one colour of each of the
+        // item's two sub-cells per lane, three items' colours in flight ----
+        {
             uint32_t A_h = 0u, A_w0 = 0u, A_w1 = 0u, A_w2 = 0u, B_h = 0u, B_w0 = 0u, B_w1 = 0u, B_w2 = 0u, C_h = 0u, C_w0 = 0u, C_w1 = 0u, C_w2 = 0u;
             float4 A_v0, A_v1, B_v0, B_v1, C_v0, C_v1;
             uint32_t A_c0 = 1u, A_c1 = 1u, B_c0 = 1u, B_c1 = 1u, C_c0 = 1u, C_c1 = 1u;
             long long A_g = 0, B_g = 0, C_g = 0;
             bool A_ok = false, B_ok = false, C_ok = false;
-            uint32_t next = wv;
             // (an exhausted set re-requests item 0, unused: a conditional request makes the compiler wait for the registers)
 #define KMG_REQUEST_ITEM(X)                                                                                       \
             do {                                                                                                  \
-                X##_ok = next < n_items;                                                                          \
-                const uint4 it_ = s_item[next < n_items ? next : 0u];                                             \
-                next += kOneWaves;                                                                                \
+                uint32_t next_ = 0u;                                                                              \
+                if (lane == 0u) next_ = atomicAdd(&s_count[4], 1u);                                               \
+                next_ = __builtin_amdgcn_readfirstlane(next_);                                                    \
+                X##_ok = next_ < n_items;                                                                         \
+                const uint4 it_ = s_item[next_ < n_items ? next_ : 0u];                                           \
                 X##_h = __builtin_amdgcn_readfirstlane(it_.x); X##_w0 = __builtin_amdgcn_readfirstlane(it_.y);    \
                 X##_w1 = __builtin_amdgcn_readfirstlane(it_.z); X##_w2 = __builtin_amdgcn_readfirstlane(it_.w);   \
-                const uint32_t cell_ = __builtin_amdgcn_readfirstlane(s_cell[X##_h & 63u]);                       \
-                const uint32_t c0_ = cell_ * kCellColours + ((X##_h >> 6) & 7u) * 64u + lane;                     \
-                const uint32_t c1_ = cell_ * kCellColours + ((X##_h >> 9) & 7u) * 64u + lane;   /* s1 == 8: sub-cell 0, unused */ \
+                const uint32_t cell_ = __builtin_amdgcn_readfirstlane(s_cell[X##_h & 127u]);                       \
+                const uint32_t c0_ = cell_ * kCellColours + ((X##_h >> 7) & 7u) * 64u + lane;                     \
+                const uint32_t c1_ = cell_ * kCellColours + ((X##_h >> 10) & 7u) * 64u + lane;   /* s1 == 8: sub-cell 0, unused */ \
                 X##_v0 = lab_table[c0_]; X##_v1 = lab_table[c1_];                                                 \
                 if (SUMS) { X##_c0 = hist[c0_]; X##_c1 = hist[c1_]; X##_g = sub_agg[(uint64_t)cell_ * 32u + (lane & 31u)]; } \
             } while (0)
             auto scan_item = [&](const uint32_t hdr, const uint32_t w0, const uint32_t w1, const uint32_t w2, const float4 v0, const float4 v1,
                                  const uint32_t cnt0, const uint32_t cnt1, const long long sagg) {
-                const uint32_t islot = hdr & 63u, s0 = (hdr >> 6) & 7u, s1 = (hdr >> 9) & 15u, n = (hdr >> 13) & 63u, type = hdr >> 30;
+                const uint32_t islot = hdr & 127u, s0 = (hdr >> 7) & 7u, s1 = (hdr >> 10) & 15u, n = (hdr >> 14) & 63u, type = hdr >> 30;
                 const PixelTerms pt0 = pixel_terms_fast(v0.x, v0.y, v0.z, v0.w), pt1 = pixel_terms_fast(v1.x, v1.y, v1.z, v1.w);
                 uint32_t ix0 = 0u, ix1 = 0u;
                 if (type == 0u) {
@@ -2568,11 +2562,22 @@ __global__ __launch_bounds__(kOneBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
                 };
                 finish(s0, ix0, cnt0, v0.x, v0.y, v0.z);
                 if (s1 < 8u) finish(s1, ix1, cnt1, v1.x, v1.y, v1.z);
+                // the cell's items count down: the wave that scans the last one finds all 512 labels in LDS (the release / acquire
+                // pair orders this wave's label writes before its decrement, and the other waves' before this wave's reads)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                uint32_t left = 0u;
+                if (lane == 0u) left = atomicSub(&s_left[islot], 1u);
+                left = __builtin_amdgcn_readfirstlane(left);
+                if (left == 1u) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    cell_entry(islot);
+                }
             };
             KMG_REQUEST_ITEM(A);
             KMG_REQUEST_ITEM(B);
             KMG_REQUEST_ITEM(C);
             for (;;) {
+                if (!A_ok) break;
                 scan_item(A_h, A_w0, A_w1, A_w2, A_v0, A_v1, A_c0, A_c1, A_g);
                 if (!B_ok) break;
                 KMG_REQUEST_ITEM(A);
@@ -2580,38 +2585,13 @@ __global__ __launch_bounds__(kOneBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
                 if (!C_ok) break;
                 KMG_REQUEST_ITEM(B);
                 scan_item(C_h, C_w0, C_w1, C_w2, C_v0, C_v1, C_c0, C_c1, C_g);
-                if (!A_ok) break;
                 KMG_REQUEST_ITEM(C);
             }
 #undef KMG_REQUEST_ITEM
         }
         KMG_STAMP(5);
-        __syncthreads();
-        KMG_STAMP(6);
-
-        // ---- 3. entries: the pair entry of every cell with more than one label from its 512 labels in LDS; the labels leave ----
-        for (uint32_t pi = wv; pi < n_pend; pi += kOneWaves) {
-            const uint32_t ps = __builtin_amdgcn_readfirstlane((uint32_t)s_pend[pi]);
-            const uint32_t pcell = __builtin_amdgcn_readfirstlane(s_cell[ps]);
-            const uint2 lv = *reinterpret_cast<const uint2 *>(s_lbl + ps * kCellColours + lane * 8u);
-            uint32_t e = kPairPending;
-            if (!(flags & kCubeNoEntries)) {
-                const uint32_t round = (pi - wv) / kOneWaves;
-                uint32_t occ = 0xFFu;
-                if (round < kOccEarly) {
-#pragma unroll
-                    for (uint32_t q = 0; q < kOccEarly; ++q) occ = round == q ? occ_early[q] : occ;
-                } else if (occ_bits) {
-                    occ = (uint32_t)occ_bits[(uint64_t)pcell * 64u + lane];
-                }
-                uint32_t idx[8];
-#pragma unroll
-                for (uint32_t q = 0; q < 4u; ++q) { idx[q] = (lv.x >> (8u * q)) & 0xFFu; idx[4u + q] = (lv.y >> (8u * q)) & 0xFFu; }
-                e = cell_pair_entry(idx, occ, lane);
-            }
-            if (lane == 0u) pair_entries[pcell] = e;
-            *reinterpret_cast<uint2 *>(colour_labels + (uint64_t)pcell * kCellColours + lane * 8u) = lv;
-        }
+        // the wave's own cells without items
+        for (unsigned long long m = pend0_b; m; m &= m - 1ull) cell_entry(wv * 8u + ((uint32_t)__builtin_ctzll(m) >> 3));
         KMG_STAMP(7);
     }
     if (stats && lane == 0u) {
@@ -2624,7 +2604,7 @@ __global__ __launch_bounds__(kOneBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
 #ifdef KMG_TOOLS
 extern "C" KMG_API int kmg_tools_cube_one_stamps(unsigned long long *out, uint32_t n)
 {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_one_stamps), sizeof(unsigned long long) * std::min<size_t>(n, (kCells / kOneCells) * 12u));
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_one_stamps), sizeof(unsigned long long) * std::min<size_t>(n, 512 * 12u));
 }
 #endif
 
@@ -2726,15 +2706,19 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
     }
     // 32 < k <= 256 without hot cells: the whole pass in one launch (k_cube_one) + the tail workgroup
     if (cube_single_launch(k, flags)) {
-        const size_t lds = cube_one_lds_bytes(k, with_sums);
+        // one workgroup of 16 waves per CU (133 KiB of LDS at k = 256): its 128 cells share one item pool -- two workgroups of 8
+        // waves finish at different times (measured, tools/cube_one_phases.py)
+        static const uint32_t one_block = tools_env_int(KMG_TOOLS_ENV("KMG_ONE_BLOCK"), kOneBlockMax) == 512 ? 512u : (uint32_t)kOneBlockMax;
+        const size_t lds = cube_one_lds_bytes(k, with_sums, one_block);
         if (lds > lds_max_dev) return hipErrorInvalidValue;
         if (!n_rows) n_rows = 1u;
-        if (with_sums)
-            hipLaunchKernelGGL((k_cube_one<true>), dim3(kCells / kOneCells), dim3(kOneBlock), lds, st, hist, agg, sub_agg, occ_bits, work, bounds,
-                               sub_bounds, sub_affine, cent, k, lab_table, masks, (uint8_t *)colour_labels, sub_table, sums, n_rows, flags, stats);
-        else
-            hipLaunchKernelGGL((k_cube_one<false>), dim3(kCells / kOneCells), dim3(kOneBlock), lds, st, hist, agg, sub_agg, occ_bits, work, bounds,
-                               sub_bounds, sub_affine, cent, k, lab_table, masks, (uint8_t *)colour_labels, sub_table, sums, n_rows, flags, stats);
+        const uint32_t grid = kCells / (one_block / 8u);
+#define KMG_ONE(S, B)                                                                                                       \
+        hipLaunchKernelGGL((k_cube_one<S, B>), dim3(grid), dim3(B), lds, st, hist, agg, sub_agg, occ_bits, work, bounds,     \
+                           sub_bounds, sub_affine, cent, k, lab_table, masks, (uint8_t *)colour_labels, sub_table, sums, n_rows, flags, stats)
+        if (one_block == 512u) { if (with_sums) KMG_ONE(true, 512); else KMG_ONE(false, 512); }
+        else                   { if (with_sums) KMG_ONE(true, 1024); else KMG_ONE(false, 1024); }
+#undef KMG_ONE
         if (tl.acc_out)
             hipLaunchKernelGGL((k_cube_pairs<uint8_t>), dim3(1), dim3(kBlock), 0, st, work, 1, occ_bits,
                                (const uint8_t *)colour_labels, sub_table, flags | kCubeNoEntries, sums, k, tl, (const uint32_t *)nullptr);

@@ -28,15 +28,18 @@ for _ in range(4):
     s.assign_update(rgba.data_ptr(), n, labels.data_ptr(), acc.data_ptr(), True, st)
 torch.cuda.synchronize()
 L = kg.lib()
-buf = np.zeros((512, 12), np.uint64)
+buf = np.zeros((512, 12), np.uint64)  # (only the first grid-size rows are written)
 rc = L.kmg_tools_cube_one_stamps(C.c_void_p(buf.ctypes.data), C.c_uint32(buf.size))
 assert rc == 0, rc
 t = buf.astype(np.int64)
+t = t[t[:, 0] > 0]            # (rows of workgroups that ran)
 t0 = t[:, 0].min()
 counts = t[:, 8:11]
 t = t[:, :8]
 us = (t - t0) / 100.0
-names = ["start", "1a candidates (wave 0)", "1b sweeps (thread 0)", "tests + barriers", "1c decisions", "scan (wave 0)", "scan (all waves)", "entries (wave 0)"]
+names = ["start", "1a candidates (wave 0)", "1b sweeps (wave 0)", "tests (wave 0)", "1c decisions (wave 0)", "scan + entries (wave 0)", "-", "own cells without items (wave 0)"]
+t[:, 6] = t[:, 5]
+print(f"{len(t)} workgroups")
 print(f"k={k}: pass span {us[:, 7].max():.1f} us (first start -> last workgroup's wave 0 done); starts spread over {us[:, 0].max():.1f} us")
 for i in range(1, 8):
     d = us[:, i] - us[:, i - 1]
