@@ -1,28 +1,21 @@
-// kmg_cube.hip -- the per-iteration pass of the colour-table strategy over the colour cube (kmg_table.h), in
-// three or four launches.  Every one of them is a chain of dependent steps per wave, so what they need is many
-// resident waves: split this way each keeps few registers.
+// kmg_cube.hip -- the per-iteration pass of the colour-table strategy over the colour cube (kmg_table.h).  Every phase of it is a
+// chain of dependent steps per wave, so what it needs is many resident waves and no waiting for each other.
 //
-//   k_cube_stage  1. cell candidates (one wave per 8x8x8 cell) -- lanes strided over the centroids: interval bounds
-//                    [lo_j, hi_j] of the key over the cell (static bounds, kmg_table_dev.h key_range), U = min_j hi_j,
-//                    keep lo_j <= U (1 + slack).  One candidate -> the whole cell belongs to it: sums from the
-//                    per-cell table of the image, one pair entry, NO per-colour traffic at all.
-//                 2. sub-cell stage -- the (<= 32) candidates are listed; lane (s, c) bounds candidate c over the
-//                    4x4x4 sub-cell s with the sub-cell's own static bounds; per sub-cell the same U / lo test.
-//                    One candidate -> the sub-cell belongs to it: sums from the per-sub-cell table, 64 labels.
-//                    What is left goes into the cell's work record (candidate list, per-sub-cell sets).
-//   k_cube_lean   (32 < k <= 256, images without hot cells: instead of k_cube_stage) step 1 alone, a lane's four
-//   k_cube_prune  centroids in registers; then a thread per SUB-CELL: step 2 without a cross-lane operation, and 2b. the
-//                    dominance test -- a candidate that another one beats on EVERY colour of the sub-cell (an affine
-//                    model of the key difference with exact residual ranges) leaves its set; sub-cells left with one
-//                    candidate are decided, cells with one label get their pair entry; what remains leaves as compact
-//                    ITEMS (two sub-cells + their candidates, 16 bytes) for the scan and a list of cells for the entries.
-//   k_cube_scan   3. undecided sub-cells, two per step, ONE colour of each per lane: (L, a, b, C) and the count
-//                    are fully coalesced 1 KiB + 256 B loads per sub-cell; the colour scans the candidates of the
-//                    two sub-cells in index order (a centroid outside a sub-cell's own set is provably neither its
-//                    arg-min nor a near-tie, so visiting it changes nothing).  From items (one wave per item) after
-//                    k_cube_prune, from the cells' work records otherwise.
-//   k_cube_pairs  4. (k <= 256) the pair entry of every cell with more than one label, from its 512
-//                    per-colour labels and the image's occupancy bits; (k > 256) the cell summary.
+//   k_cube_small  k <= 32: the whole pass in ONE launch, a workgroup owns 64 cells from bounds to pair entries.
+//   k_cube_one    32 < k <= 256, images without hot cells (round 6): the same for centroid tables that need candidate LISTS --
+//                 1a. cell candidates (one wave per 8x8x8 cell) -- lanes strided over the centroids: interval bounds
+//                     [lo_j, hi_j] of the key over the cell (static bounds, kmg_table_dev.h key_range), U = min_j hi_j,
+//                     keep lo_j <= U (1 + slack).  One candidate -> the whole cell belongs to it: sums from the
+//                     per-cell table of the image, one pair entry, NO per-colour traffic at all.
+//                 1b. sub-cell stage -- a thread per 4x4x4 sub-cell bounds the (<= 32) listed candidates over the sub-cell's own
+//                     static bounds, then the DOMINANCE test: a candidate that another one beats on EVERY colour of the sub-cell
+//                     (an affine model of the key difference with exact residual ranges) leaves its set.  One candidate -> the
+//                     sub-cell belongs to it: sums from the per-sub-cell table, 64 labels.
+//                 2.  scan of the undecided sub-cells, two per step, ONE colour of each per lane, handed out by an LDS counter;
+//                 3.  the pair entry of every cell with more than one label, by the wave that scans the cell's last item.
+//   k_cube_stage  everything else (k > 256; images with hot cells -- a photograph's few hundred cells with long candidate
+//   k_cube_scan   lists are spread over the device, four waves each): steps 1a + 1b without the dominance test, the scan from
+//   k_cube_pairs  the cells' work records, the pair entries (k <= 256) / cell summaries (k > 256) -- three launches.
 // Exactness: bounds are float-monotone interval evaluations of the very operations of cie94_key, so the
 // arg-min of every colour (and everything within the near-tie threshold of it) survives both prunings; the dominance
 // test charges its own rounding explicitly (`dominated`); sums are integers.  tests/test_gpu_table.py compares every
@@ -49,7 +42,6 @@ constexpr uint32_t kMaxListed = 32;       // candidates per cell the sub-cell st
 // cube_masks_bytes), and the scan kernel visits a sub-cell's own set instead of every candidate of the cell.  k <= 256.
 constexpr uint32_t kMaxLong = 256;
 constexpr uint32_t kLongFlag = 0x200u;    // CellWork::scan_set: the cell's sub-cells have masks of their own
-constexpr uint32_t kDeferFlag = 0x800u;   // CellWork::scan_set: a listed cell whose sub-cell stage is left to k_cube_prune (k_cube_lean wrote its list)
 
 __device__ __forceinline__ uint32_t sel3(uint32_t i, uint32_t x0, uint32_t x1, uint32_t x2)
 {
@@ -219,37 +211,18 @@ struct alignas(16) CellWork {
     uint32_t npop;                 // number of candidates of the cell
     uint32_t scan_set;             // bits 0..7: sub-cells whose colours are scanned; bit 8: the cell is listed; bit 9: long list;
                                    // bits 16..23: sub-cells the stage decided as a whole (one candidate)
-    // (listed cells) per sub-cell, for k_cube_prune: the candidate with the smallest upper bound of its key over the sub-cell
-    // (list position) and that bound, rounded UP to the 16 high bits of its binary32 pattern
-    uint16_t U16[8];
-    uint8_t istar[8];
+    uint32_t pad[6];
 };
 static_assert(sizeof(CellWork) == 128, "CellWork layout");
 
 constexpr uint32_t kPairPending = 0xFFFFFFFEu;   // pair entry of a cell k_cube_pairs still has to derive
 
-// What k_cube_prune leaves for k_cube_scan / k_cube_pairs, behind the cells' work records (u32 words):
-//   [2 s, 2 s + 1], s < kListSegs: one u64 counter per segment = items | whole cells << 21 | entry cells << 42 (one atomic of a
-//                   wave of k_cube_prune -- 8 cells -- reserves its places in all three; same-address atomics retire one by
-//                   one, 12-15 ns each: 64 per segment)
-//   [kListFar]      a centroid is outside the dominance test's error budget (set by the stage kernel)
-//   kListsHead ...  items   [kListSegs][kItemSegCap] x 16 B: TWO sub-cells of one cell to scan and the union of their candidate
-//                           sets -- {cell | s0 << 15 | s1 << 18 (8: none) | n << 22, 12 centroids (u8, ascending)}: the scan
-//                           kernel needs nothing else, one wave per item
-//                   whole   [kListSegs][kWholeSegCap] cells scanned from their work records as before: cell | quarter << 16 -- quarter
-//                           4 = the whole cell (a listed cell with a union of more than kItemCands candidates), 0 .. 3 = that pair of
-//                           its sub-cells (a cell with more than kMaxListed candidates: no per-sub-cell sets, every colour against all
-//                           the cell's candidates, four waves)
-//                   entries [kListSegs][kListSegCap] cells that need a pair entry derived from their labels
-constexpr uint32_t kListSegs = 64, kListSegCap = kCells / kListSegs, kItemSegCap = 4u * kListSegCap, kItemCands = 12;
-constexpr uint32_t kListFar = 2 * kListSegs, kListsHead = 2 * kListSegs + 64;
-constexpr uint32_t kWholeSegCap = 4u * kListSegCap;                // (a cell without per-sub-cell sets takes four places: a pair of sub-cells each)
-constexpr uint32_t kListItems = kListsHead, kListWhole = kListItems + 4u * kListSegs * kItemSegCap, kListEntries = kListWhole + kListSegs * kWholeSegCap;
-constexpr size_t kListsWords = kListEntries + kCells;
-// Without k_cube_prune (images with hot cells): the cells with LONG candidate lists -- a photograph's few hundred heavy cells, each
-// minutes of a wave's time compared with the others -- are listed by the stage kernel (kLongSegs counters behind kListFar, the cells in
-// the `whole` region, kLongSegCap per segment) and scanned first, a PAIR of sub-cells per wave instead of the whole cell.
-constexpr uint32_t kLongSegs = 16, kLongSegCap = kCells / kLongSegs, kLongCount = kListFar + 1;
+// Behind the cells' work records (u32 words), for images with hot cells: the cells with LONG candidate lists -- a photograph's few hundred
+// heavy cells, each minutes of a wave's time compared with the others -- are listed by the stage kernel (kLongSegs counters, then the cells,
+// kLongSegCap per segment) and scanned first, a PAIR of sub-cells per wave instead of the whole cell.
+constexpr uint32_t kLongSegs = 16, kLongSegCap = kCells / kLongSegs, kLongCount = 0, kLongCells = 64;
+constexpr size_t kListsWords = kLongCells + kCells;
+constexpr uint32_t kItemCands = 12;                               // k_cube_one: candidates an item carries as bytes
 
 // LDS bins: repl copies of k x 4 u64, consecutive copies 32 B further along the bank row
 __device__ __forceinline__ void flush_bins(const unsigned long long *bins, uint32_t k, uint32_t repl, uint32_t bin_stride,
@@ -615,10 +588,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
             for (uint32_t r = 0; r < 4u; ++r)
                 if (r < rounds) br[r] = __ballot(lo[r] <= Us);
             if (lane < 4u) cw->br[lane] = lane == 0u ? br[0] : (lane == 1u ? br[1] : (lane == 2u ? br[2] : br[3]));
-            if (cand_of_lane == 0u) {
-                cw->U16[sub_of_lane] = (uint16_t)((Ubest + 0xFFFFu) >> 16);
-                cw->istar[sub_of_lane] = (uint8_t)(Ubest & 31u);
-            }
         } else if (words <= 4u && npop <= kMaxLong && !KMG_KNOCK(flags, 0x1000u)) {
             // long list (rare on noise, the heavy cells of a photograph): long_list_stage
             long_cell = true;
@@ -682,7 +651,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
             if (long_cell && scan_set && (flags & kCubeSplitLong)) {
                 uint32_t *lists = reinterpret_cast<uint32_t *>(cell_work + kCells);
                 const uint32_t ls = wave & (kLongSegs - 1u);
-                lists[kListWhole + ls * kLongSegCap + atomicAdd(lists + kLongCount + ls, 1u)] = cell;
+                lists[kLongCells + ls * kLongSegCap + atomicAdd(lists + kLongCount + ls, 1u)] = cell;
             }
         }
     }
@@ -693,362 +662,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         atomicAdd(stats + 3, st_scanned); atomicAdd(stats + 4, st_cands); atomicAdd(stats + 5, st_unlisted);
     }
     if (SUMS) flush_bins(bins, k, 1u, 4u * k, sums, n_rows);
-}
-
-// ------------------------------------------------------------------------------------------
-// k_cube_lean (32 < k <= 256, k_cube_prune follows): steps 1 of the stage kernel and no more -- the candidates of every cell of
-// the work list (one wave per cell, a lane's four centroids in registers for all its cells: 54 registers, 8 waves per SIMD),
-// then by their number: one -> the cell is decided as the stage kernel decides it; 2 .. kMaxListed -> the candidate list into
-// the cell's record, the rest is k_cube_prune's; more -> the cell is scanned without per-sub-cell sets (below).  Inside the
-// stage kernel this part took ~22 of its 32 us (80 registers, 6 waves, 44 spilled SGPRs, every cell a chain through code it does
-// not need).
-// Workgroup 0 also prepares the head of k_cube_prune's lists.
-// ------------------------------------------------------------------------------------------
-template <bool SUMS>
-__global__ __launch_bounds__(kBlock) void k_cube_lean(const int64_t *__restrict__ agg, const int64_t *__restrict__ sub_agg,
-                                                      const uint32_t *__restrict__ work,
-                                                      const CellBounds *__restrict__ bounds, const Centroid *__restrict__ cent,
-                                                      uint32_t k, uint64_t *__restrict__ masks_out, CellWork *__restrict__ cell_work,
-                                                      uint8_t *__restrict__ colour_labels, uint16_t *__restrict__ sub_table,
-                                                      int64_t *__restrict__ sums, uint32_t n_rows, uint32_t flags,
-                                                      unsigned long long *__restrict__ stats)
-{
-    extern __shared__ unsigned long long bins[];                   // k x 4 u64 (SUMS): the sums of single-candidate cells
-    __shared__ float4 s_cent[256];
-    __shared__ uint32_t s_list_all[(kBlock / 64) * kMaxListed];
-    {
-        float4 v = make_float4(1.0e18f, 0.0f, 0.0f, 0.0f);           // key ~ 1e36: never a candidate
-        if (threadIdx.x < k) { const Centroid c = cent[threadIdx.x]; v = make_float4(c.L, c.a, c.b, c.C); }
-        s_cent[threadIdx.x] = v;
-    }
-    if (SUMS) for (uint32_t i = threadIdx.x; i < 4u * k; i += kBlock) bins[i] = 0ull;
-    __syncthreads();
-    uint32_t *lists = reinterpret_cast<uint32_t *>(cell_work + kCells);
-    if (blockIdx.x == 0u) {
-        // the head of k_cube_prune's lists: counters zero, and whether its test applies to this centroid table at all
-        const float4 c = s_cent[threadIdx.x];
-        const bool far = threadIdx.x < k && !(fabsf(c.x) <= 1024.0f && fabsf(c.y) <= 1024.0f && fabsf(c.z) <= 1024.0f);
-        const unsigned long long any_far = __ballot(far);
-        if (threadIdx.x < kListsHead) lists[threadIdx.x] = 0u;
-        __syncthreads();
-        if (any_far && (threadIdx.x & 63u) == 0u) lists[kListFar] = 1u;
-    }
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    uint32_t *s_list = s_list_all + wv * kMaxListed;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / 64) + wv);
-    const uint32_t n_waves = gridDim.x * (kBlock / 64);
-    const uint32_t n_work = SUMS ? __builtin_amdgcn_readfirstlane(work[0]) : kCells;
-    const uint32_t words = (k + 63u) / 64u;
-    const uint32_t vz = opaque_vgpr_zero();
-    uint32_t *pair_entries = reinterpret_cast<uint32_t *>(sub_table + kSubCells + kCells);
-    float4 c4[4];
-#pragma unroll
-    for (int w = 0; w < 4; ++w) c4[w] = s_cent[w * 64 + lane];      // this lane's four centroids: the same for every cell
-    unsigned long long st_single = 0, st_multi = 0, st_unlisted = 0;
-    // the next cell's index and bounds are requested while the current one is worked on
-    uint32_t cell_n = SUMS ? work[1u + (wave < n_work ? wave : 0u) + vz] : wave;
-    cell_n = __builtin_amdgcn_readfirstlane(cell_n);
-    float cbv_n = reinterpret_cast<const float *>(bounds + cell_n)[lane & 15u];
-    for (uint32_t wi = wave; wi < n_work; wi += n_waves) {
-        const uint32_t cell = cell_n;
-        const float cbv = cbv_n;
-        {
-            const uint32_t w2 = wi + n_waves < n_work ? wi + n_waves : wi;
-            cell_n = SUMS ? work[1u + w2 + vz] : w2;
-            cell_n = __builtin_amdgcn_readfirstlane(cell_n);
-            cbv_n = reinterpret_cast<const float *>(bounds + cell_n)[lane & 15u];
-        }
-        CellBounds cb;
-        cb.L0 = lane_value(cbv, 0); cb.L1 = lane_value(cbv, 1); cb.a0 = lane_value(cbv, 2); cb.a1 = lane_value(cbv, 3);
-        cb.b0 = lane_value(cbv, 4); cb.b1 = lane_value(cbv, 5); cb.C0 = lane_value(cbv, 6); cb.C1 = lane_value(cbv, 7);
-        cb.wC0 = lane_value(cbv, 8); cb.wC1 = lane_value(cbv, 9); cb.wH0 = lane_value(cbv, 10); cb.wH1 = lane_value(cbv, 11);
-        float lo[4], U = 3.0e38f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const KeyRange r = key_range(cb, c4[w].x, c4[w].y, c4[w].z, c4[w].w);
-            lo[w] = r.lo;
-            U = fminf(U, r.hi);                                     // padding entries: hi ~ 1e36
-        }
-        const float Us = mask_threshold(wave_min(U));
-        unsigned long long mw[4];
-        uint32_t npop = 0, first = 0;
-#pragma unroll
-        for (uint32_t w = 0; w < 4u; ++w) {
-            mw[w] = __ballot(w * 64u + lane < k && lo[w] <= Us);
-            if (npop == 0u && mw[w]) first = w * 64u + (uint32_t)__builtin_ctzll(mw[w]);
-            npop += (uint32_t)__builtin_popcountll(mw[w]);
-            if (lane == 0u && w < words) masks_out[(uint64_t)cell * words + w] = mw[w];
-        }
-        CellWork *cw = cell_work + cell;
-        if (npop == 1u) {
-            // the whole cell belongs to `first`: sums from the cell table, no per-colour traffic
-            if (lane == 0u) { pair_entries[cell] = pair_entry(first, first, 0u, 0u, 0u); cw->npop = 1u; cw->scan_set = 0u; }
-            if (SUMS && lane < 4u) atomicAdd(bins + 4ull * first + lane, (unsigned long long)agg[4ull * cell + lane]);
-            if (flags & 1u) {
-                uint8_t *cell_labels = colour_labels + (uint64_t)cell * kCellColours;
-#pragma unroll
-                for (uint32_t s = 0; s < 8u; ++s) store_labels64(cell_labels + s * 64u, first, lane);
-            }
-            st_single += 1;
-            continue;
-        }
-        st_multi += 1;
-        if (npop <= kMaxListed) {
-            uint32_t base = 0;
-#pragma unroll
-            for (uint32_t w = 0; w < 4u; ++w) {
-                if ((mw[w] >> lane) & 1ull) s_list[base + bits_below_lane(mw[w])] = w * 64u + lane;
-                base += (uint32_t)__builtin_popcountll(mw[w]);
-            }
-            __builtin_amdgcn_wave_barrier();
-            const uint32_t cand = s_list[lane & (kMaxListed - 1u)];
-            __builtin_amdgcn_wave_barrier();
-            if (lane < kMaxListed) cw->list[lane] = (uint16_t)(lane < npop ? cand : 0u);
-            if (lane == 0u) { cw->npop = npop; cw->scan_set = 0x100u | kDeferFlag; pair_entries[cell] = kPairPending; }
-        } else {
-            // more candidates than the sub-cell stage lists (a handful of cells on the benchmark image; photographs, where there
-            // are hundreds and they matter, have hot cells and take the pass without k_cube_prune): no per-sub-cell sets -- the
-            // scan takes every colour of the cell's occupied sub-cells against all its candidates, a pair of sub-cells per wave
-            const bool occ = lane < 8u && (SUMS ? sub_agg[(uint64_t)cell * 32u + 4u * (lane & 7u) + 3u] != 0 : true);
-            const uint32_t occ8 = (uint32_t)__ballot(occ);
-            if (lane == 0u) { cw->npop = npop; cw->scan_set = occ8; pair_entries[cell] = kPairPending; }
-            st_unlisted += 1;
-        }
-    }
-    if (stats && lane == 0u) { atomicAdd(stats + 0, st_single); atomicAdd(stats + 1, st_multi); atomicAdd(stats + 5, st_unlisted); }
-    if (SUMS) flush_bins(bins, k, 1u, 4u * k, sums, n_rows);
-}
-
-// ------------------------------------------------------------------------------------------
-// k_cube_prune (32 < k <= 256, between k_cube_stage and k_cube_scan): the DOMINANCE test of k_cube_small's header for the
-// listed cells of the general pass, as a phase of its own, and the compact work of the two launches that follow.
-// A workgroup takes kPruneCells cells of the work list, one sub-cell per thread:
-//   1. a sub-cell to scan requests its affine model (96 B) with the cell's record and leaves it in LDS; every (sub-cell to
-//      scan, candidate other than the one with the smallest upper bound) goes into ONE compact list in LDS, one test per
-//      lane; a candidate another candidate beats on every colour of the sub-cell leaves the sub-cell's set (exact: what the
-//      test removes is neither the arg-min nor within the tie threshold of it for any colour of the sub-cell -- `dominated`;
-//      a list that overflows drops tests, i.e. keeps candidates);
-//   2. a sub-cell left with ONE candidate is decided here as the stage kernel decides its own: 64 labels, the sums of the
-//      sub-cell table; a cell whose occupied sub-cells all went to one centroid gets its pair entry at once;
-//   3. what is still to scan leaves as ITEMS (two sub-cells of a cell and the union of their candidates, 16 bytes: all the
-//      scan kernel reads), the cells that need a pair entry derived from their labels as a list of cells (the layout above);
-//      one 64-bit atomic per wave reserves the places of its 8 cells.
-// sub_affine == NULL or a centroid outside the test's error budget (lists[kListFar], set by the stage kernel): no tests,
-// the items and lists all the same.
-// stats (optional): [6] candidates removed, [7] sub-cells left with one candidate.
-// flags (tools build, results WRONG): bit 21 no tests, 22 no decisions, 23 no reservation.
-// ------------------------------------------------------------------------------------------
-constexpr uint32_t kPruneCells = kBlock / 8;                      // 32 cells of a workgroup
-constexpr uint32_t kPruneTests = 1024;                            // tests a workgroup lists (~340-520 on the benchmark image; more are dropped = kept candidates)
-
-template <bool SUMS>
-__global__ __launch_bounds__(kBlock) void k_cube_prune(const uint32_t *__restrict__ work, const int64_t *__restrict__ sub_agg,
-                                                       const CellBounds *__restrict__ sub_bounds,
-                                                       const Centroid *__restrict__ cent, uint32_t k,
-                                                       const float *__restrict__ sub_affine, CellWork *__restrict__ cell_work,
-                                                       uint8_t *__restrict__ colour_labels, uint16_t *__restrict__ sub_table,
-                                                       uint32_t *__restrict__ lists, int64_t *__restrict__ sums, uint32_t n_rows,
-                                                       uint32_t flags, unsigned long long *__restrict__ stats)
-{
-    __shared__ uint32_t s_mask[kBlock];                            // [sub-cell]: candidates (list positions)
-    __shared__ uint32_t s_ref[kBlock];                             // [sub-cell]: upper bound (27 high bits) | position of the reference candidate
-    __shared__ uint16_t s_list[kPruneCells * kMaxListed];          // [cell][position]: centroid
-    __shared__ uint16_t s_test[kPruneTests];                       // (sub-cell << 5) | position
-    __shared__ uint32_t s_count;                                   // tests
-    __shared__ float4 s_cent[256];                                 // (with the rest 38.9 KiB: four workgroups per CU, the whole grid resident)
-    // the models of the workgroup's sub-cells (each thread requests its own with the cell's record, the tests read them from
-    // here: no second round trip to memory); after the tests the same bytes are the bins (k x 4 u64) of the sub-cells decided here
-    constexpr uint32_t kModelStride = 28;                          // words per model in LDS (16-byte rows, 8 start banks)
-    __shared__ uint4 s_model4[kBlock * kModelStride / 4];
-    unsigned long long *bins = reinterpret_cast<unsigned long long *>(s_model4);
-    const uint32_t vz = opaque_vgpr_zero();
-    const uint32_t n_work_v = SUMS ? work[vz] : kCells;
-    const uint32_t far_v = lists[kListFar + vz];
-    const uint32_t slot = threadIdx.x >> 3, sub = threadIdx.x & 7u, lane = threadIdx.x & 63u;
-    // (the first batch's cells are requested with the list's length, not after it: entries beyond it are readable)
-    const uint32_t cell_first = SUMS ? work[1u + blockIdx.x * kPruneCells + slot] : blockIdx.x * kPruneCells + slot;
-    if (threadIdx.x == 0u) s_count = 0u;
-    {
-        float4 v = make_float4(1.0e18f, 0.0f, 0.0f, 0.0f);
-        if (threadIdx.x < k) { const Centroid c = cent[threadIdx.x]; v = make_float4(c.L, c.a, c.b, c.C); }
-        s_cent[threadIdx.x] = v;
-    }
-    __syncthreads();
-    const uint32_t n_work = __builtin_amdgcn_readfirstlane(n_work_v);
-    const bool dominance = sub_affine != nullptr && __builtin_amdgcn_readfirstlane(far_v) == 0u && !KMG_KNOCK(flags, 0x200000u);
-    uint32_t *pair_entries = reinterpret_cast<uint32_t *>(sub_table + kSubCells + kCells);
-    unsigned long long st_removed = 0, st_single = 0, st_decided = 0, st_scanned = 0, st_cands = 0;
-    // (one batch per workgroup: the grid is kCells / kPruneCells whatever the list's length)
-    const uint32_t base = blockIdx.x * kPruneCells;
-    if (base >= n_work) return;
-    {
-        const uint32_t wi = base + slot;
-        const bool valid = wi < n_work;
-        const uint32_t cell = valid ? cell_first : 0u;
-        CellWork *cw = cell_work + cell;
-        const uint32_t ss = valid ? cw->scan_set : 0u;
-        const uint32_t npop = valid ? cw->npop : 1u;
-        const bool listed = (ss & kDeferFlag) != 0u;                 // 2 .. kMaxListed candidates: everything below the list is done here
-        uint32_t sm = 0u, istar = 0u, ubits = 0u;
-        longlong2 g01 = {0, 0}, g23 = {0, 1};
-        bool occupied = false;
-        if (listed) {
-            // requested together: the list, the sub-cell's bounds, its sums (their count = is it occupied) and its model
-            const float4 *sbp = reinterpret_cast<const float4 *>(sub_bounds + (uint64_t)cell * 8u + sub);
-            const float4 sb0 = sbp[0], sb1 = sbp[1], sb2 = sbp[2];
-            *reinterpret_cast<uint2 *>(s_list + slot * kMaxListed + 4u * sub) = *reinterpret_cast<const uint2 *>(cw->list + 4u * sub);
-            if (SUMS) {
-                const longlong2 *sp = reinterpret_cast<const longlong2 *>(sub_agg + ((uint64_t)cell * 8u + sub) * 4u);
-                g01 = sp[0]; g23 = sp[1];
-            }
-            if (dominance) {
-                const uint4 *mp = reinterpret_cast<const uint4 *>(sub_affine + ((uint64_t)cell * 8u + sub) * kAffineFloats);
-                uint4 *dst = s_model4 + threadIdx.x * (kModelStride / 4u);
-#pragma unroll
-                for (int t = 0; t < 6; ++t) dst[t] = mp[t];
-            }
-            occupied = g23.y != 0;
-            __builtin_amdgcn_wave_barrier();                        // (s_list: written and read by the 8 lanes of the cell)
-            // the sub-cell stage: the cell's candidates bounded over THIS sub-cell (kmg_table_dev.h key_range), two sweeps -- the
-            // smallest upper bound and who has it, then the lower bounds against the threshold
-            CellBounds sb;
-            sb.L0 = sb0.x; sb.L1 = sb0.y; sb.a0 = sb0.z; sb.a1 = sb0.w;
-            sb.b0 = sb1.x; sb.b1 = sb1.y; sb.C0 = sb1.z; sb.C1 = sb1.w;
-            sb.wC0 = sb2.x; sb.wC1 = sb2.y; sb.wH0 = sb2.z; sb.wH1 = sb2.w;
-            uint32_t Ubest = 0x7F7FFFE0u;                           // (upper bound rounded up to a multiple of 32 ulps) | position
-            for (uint32_t p = 0; p < npop; ++p) {
-                const float4 c = s_cent[s_list[slot * kMaxListed + p]];
-                Ubest = min(Ubest, ((float_to_bits(key_range(sb, c.x, c.y, c.z, c.w).hi) + 31u) & ~31u) | p);
-            }
-            const float Us = mask_threshold(bits_to_float(Ubest & ~31u));
-            for (uint32_t p = 0; p < npop; ++p) {
-                const float4 c = s_cent[s_list[slot * kMaxListed + p]];
-                sm |= (key_range(sb, c.x, c.y, c.z, c.w).lo <= Us ? 1u : 0u) << p;
-            }
-            istar = Ubest & 31u;
-            ubits = Ubest & ~31u;
-        }
-        const uint32_t np0 = (uint32_t)__builtin_popcount(sm);
-        const bool was_decided = listed && occupied && np0 == 1u;   // decided by its bounds
-        const bool mine = listed && occupied && np0 > 1u;            // open: the dominance tests, then the scan if still open
-        s_mask[threadIdx.x] = sm;
-        const uint32_t others = (mine && dominance) ? sm & ~(1u << istar) : 0u;
-        if (others) {
-            s_ref[threadIdx.x] = ubits | istar;
-            const uint32_t nt = (uint32_t)__builtin_popcount(others);
-            uint32_t at = atomicAdd(&s_count, nt);
-            for (uint32_t m = others; m && at < kPruneTests; m &= m - 1u, ++at)
-                s_test[at] = (uint16_t)((threadIdx.x << 5) | (uint32_t)__builtin_ctz(m));
-        }
-        __syncthreads();
-        const uint32_t n_tests = min(s_count, kPruneTests);
-        for (uint32_t t = threadIdx.x; t < n_tests; t += kBlock) {
-            const uint32_t e = (uint32_t)s_test[t] >> 5, pos = (uint32_t)s_test[t] & 31u;
-            const uint32_t r = s_ref[e];
-            const float4 cj = s_cent[s_list[(e >> 3) * kMaxListed + pos]], ci = s_cent[s_list[(e >> 3) * kMaxListed + (r & 31u)]];
-            HalfModel mdl;
-#pragma unroll
-            for (int q = 0; q < 6; ++q) {
-                const uint4 v = s_model4[e * (kModelStride / 4u) + q];
-                mdl.q[4 * q] = v.x; mdl.q[4 * q + 1] = v.y; mdl.q[4 * q + 2] = v.z; mdl.q[4 * q + 3] = v.w;
-            }
-            if (dominated(mdl, cj, ci, bits_to_float(r & ~31u))) atomicAnd(&s_mask[e], ~(1u << pos));
-        }
-        __syncthreads();
-        // (the models have been read: their bytes become the bins -- straight global atomics instead of LDS bins were measured:
-        // 420 K of them per pass, the kernel 25 -> 137 us)
-        if (SUMS) for (uint32_t i = threadIdx.x; i < 4u * k; i += kBlock) bins[i] = 0ull;
-        __syncthreads();
-        // ---- what is left of every sub-cell's set ----
-        const uint32_t nm = s_mask[threadIdx.x];
-        const uint32_t np = (uint32_t)__builtin_popcount(nm);
-        const bool one = mine && np == 1u, still = mine && np > 1u;
-        const uint32_t X = (uint32_t)s_list[slot * kMaxListed + (nm ? (uint32_t)__builtin_ctz(nm) : 0u)];
-        const uint32_t scan8 = group8_or(still ? 1u << sub : 0u);
-        const bool settled = one || was_decided;
-        const uint32_t xmin = group8_min_u32(settled ? X : 255u), xmax = group8_max_u32(settled ? X : 0u);
-        const bool uniform = listed && scan8 == 0u && xmin == xmax;   // every occupied sub-cell of the cell went to centroid xmin
-        // ---- what the scan and the entries launches get: one 64-bit atomic per wave reserves the places of its cells ----
-        // items: the sub-cells still to scan, two per item in ascending order; a lane that heads a pair builds the item
-        const uint32_t rank = (uint32_t)__builtin_popcount(scan8 & ((1u << sub) - 1u));
-        const bool head = still && (rank & 1u) == 0u;
-        const uint32_t after = scan8 & ~((2u << sub) - 1u);
-        const uint32_t s1 = after ? (uint32_t)__builtin_ctz(after) : 8u;
-        const uint32_t un = nm | ((head && s1 < 8u) ? s_mask[threadIdx.x - sub + s1] : 0u);
-        const uint32_t n_un = (uint32_t)__builtin_popcount(un);
-        const bool as_items = listed && group8_or((head && n_un > kItemCands) ? 1u : 0u) == 0u;
-        const bool emit = head && as_items && !KMG_KNOCK(flags, 0x400u);
-        // (a cell without per-sub-cell sets: lanes 0 .. 3 of its group each announce a pair of its sub-cells to scan)
-        const bool need_whole = valid && !KMG_KNOCK(flags, 0x400u) &&
-                                (listed ? (sub == 0u && scan8 != 0u && !as_items) : (sub < 4u && (uint32_t)__builtin_popcount(ss & 0xFFu) > 2u * sub));
-        const bool need_entry = valid && sub == 0u && npop != 1u && !uniform;
-        const unsigned long long item_b = __ballot(emit), whole_b = __ballot(need_whole), ent_b = __ballot(need_entry);
-        const uint32_t seg = (base / 8u + (threadIdx.x >> 6)) & (kListSegs - 1u);
-        unsigned long long at64 = 0ull;
-        if (lane == 0u && (item_b | whole_b | ent_b) && !KMG_KNOCK(flags, 0x800000u))
-            at64 = atomicAdd(reinterpret_cast<unsigned long long *>(lists) + seg,
-                             (unsigned long long)__builtin_popcountll(item_b) | ((unsigned long long)__builtin_popcountll(whole_b) << 21) |
-                                 ((unsigned long long)__builtin_popcountll(ent_b) << 42));
-        uint32_t iw0 = 0u, iw1 = 0u, iw2 = 0u;
-        if (emit) {
-            uint32_t q = 0u;
-            for (uint32_t m = un; m; m &= m - 1u, ++q) {
-                const uint32_t c = (uint32_t)s_list[slot * kMaxListed + (uint32_t)__builtin_ctz(m)] << (8u * (q & 3u));
-                iw0 |= q < 4u ? c : 0u; iw1 |= (q >= 4u && q < 8u) ? c : 0u; iw2 |= q >= 8u ? c : 0u;
-            }
-        }
-        if (settled && !KMG_KNOCK(flags, 0x400000u)) {
-            // decided by its bounds or by the tests: 64 labels, the sums of the sub-cell table
-            const uint32_t x4 = X * 0x01010101u;
-            uint4 *dst = reinterpret_cast<uint4 *>(colour_labels + (uint64_t)cell * kCellColours + sub * 64u);
-            dst[0] = dst[1] = dst[2] = dst[3] = make_uint4(x4, x4, x4, x4);
-            if (SUMS && !KMG_KNOCK(flags, 0x200u)) {
-                unsigned long long *to = bins + 4ull * X;
-                atomicAdd(to + 0, (unsigned long long)g01.x); atomicAdd(to + 1, (unsigned long long)g01.y);
-                atomicAdd(to + 2, (unsigned long long)g23.x); atomicAdd(to + 3, (unsigned long long)g23.y);
-            }
-        }
-        if (listed && scan8 != 0u && !as_items) {
-            // a cell that is scanned from its record after all (a pair of its sub-cells has more than kItemCands candidates): the
-            // sub-cells' sets into it (round r: bit 8 s + c = sub-cell s keeps candidate 8 r + c)
-            uint32_t lo_w[4], hi_w[4];
-#pragma unroll
-            for (uint32_t r = 0; r < 4u; ++r) {
-                const uint32_t byte = (nm >> (8u * r)) & 0xFFu;
-                lo_w[r] = group8_or(sub < 4u ? byte << (8u * sub) : 0u);
-                hi_w[r] = group8_or(sub >= 4u ? byte << (8u * (sub - 4u)) : 0u);
-            }
-            if (sub < 4u) {
-                const uint32_t l = sub == 0u ? lo_w[0] : (sub == 1u ? lo_w[1] : (sub == 2u ? lo_w[2] : lo_w[3]));
-                const uint32_t h = sub == 0u ? hi_w[0] : (sub == 1u ? hi_w[1] : (sub == 2u ? hi_w[2] : hi_w[3]));
-                cw->br[sub] = ((unsigned long long)h << 32) | l;
-            }
-            if (sub == 0u) cw->scan_set = 0x100u | scan8;
-        }
-        if (uniform && sub == 0u) pair_entries[cell] = pair_entry(xmin, xmin, 0u, 0u, 0u);
-        if (stats) {
-            st_removed += wave_add_u32((uint32_t)__builtin_popcount(sm & ~nm));
-            st_single += (uint32_t)__builtin_popcountll(__ballot(one));
-            st_decided += (uint32_t)__builtin_popcountll(__ballot(was_decided));
-            st_scanned += (uint32_t)__builtin_popcountll(__ballot(mine));
-            st_cands += wave_add_u32(mine ? np0 : 0u);
-        }
-        // (the sums leave while the reservation is on its way)
-        if (SUMS) flush_bins(bins, k, 1u, 4u * k, sums, n_rows);
-        {
-            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)at64), hi = __builtin_amdgcn_readfirstlane((uint32_t)(at64 >> 32));
-            const uint32_t a_item = lo & 0x1FFFFFu, a_whole = ((lo >> 21) | (hi << 11)) & 0x1FFFFFu, a_ent = hi >> 10;
-            if (emit)
-                reinterpret_cast<uint4 *>(lists + kListItems)[seg * kItemSegCap + a_item + bits_below_lane(item_b)] =
-                    make_uint4(cell | (sub << 15) | (s1 << 18) | (n_un << 22), iw0, iw1, iw2);
-            if (need_whole) lists[kListWhole + seg * kWholeSegCap + a_whole + bits_below_lane(whole_b)] = cell | ((listed ? 4u : sub) << 16);
-            if (need_entry) lists[kListEntries + seg * kListSegCap + a_ent + bits_below_lane(ent_b)] = cell;
-        }
-    }
-    if (stats && lane == 0u) {
-        atomicAdd(stats + 2, st_decided); atomicAdd(stats + 3, st_scanned); atomicAdd(stats + 4, st_cands);
-        atomicAdd(stats + 6, st_removed); atomicAdd(stats + 7, st_single);
-    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1096,24 +709,12 @@ __global__ __launch_bounds__(kScanBlock) void k_cube_scan(const uint32_t *__rest
     float4 *s_cc = s_cc_all + wv * kMaxListed;
     LabelT *s_lbl = s_lbl_all + wv * kCellColours;
 
-    // kCubePruned: what k_cube_prune left -- segment wave % kListSegs of its lists, every (n_waves / kListSegs)-th entry: the
-    // cells that are scanned from their work records (few, heavy) and then the ITEMS (two sub-cells and their candidates each:
-    // nothing else is read); otherwise the whole work list
-    const bool from_list = (flags & kCubePruned) != 0u;
     const uint32_t *lists = reinterpret_cast<const uint32_t *>(cell_work + kCells);
-    const uint32_t seg = wave & (kListSegs - 1u);
-    uint32_t n_whole = 0u, n_items = 0u;
-    if (from_list) {
-        const uint32_t cnt_lo = __builtin_amdgcn_readfirstlane(lists[2u * seg]), cnt_hi = __builtin_amdgcn_readfirstlane(lists[2u * seg + 1u]);
-        n_items = cnt_lo & 0x1FFFFFu;
-        n_whole = ((cnt_lo >> 21) | (cnt_hi << 11)) & 0x1FFFFFu;
-    }
-    const uint32_t n_work = from_list ? n_whole : (SUMS ? __builtin_amdgcn_readfirstlane(work[0]) : kCells);
-    const uint32_t *cells = from_list ? lists + kListWhole + seg * kWholeSegCap : (SUMS ? work + 1 : nullptr);
-    const uint32_t wi_step = from_list ? n_waves / kListSegs : n_waves;
+    const uint32_t n_work = SUMS ? __builtin_amdgcn_readfirstlane(work[0]) : kCells;
+    const uint32_t *cells = SUMS ? work + 1 : nullptr;
     // kCubeSplitLong: the stage kernel's list of cells with long candidate lists comes first, FOUR waves per cell (a pair of its
     // sub-cells each); the walk over the work list then skips those cells
-    const bool split_long = !from_list && (flags & kCubeSplitLong) != 0u;
+    const bool split_long = (flags & kCubeSplitLong) != 0u;
     uint32_t long_end = 0u, n_long4 = 0u;                           // lane s < kLongSegs: entries of the segments 0 .. s; 4 x all of them
     if (split_long) {
         long_end = lane < kLongSegs ? lists[kLongCount + lane] : 0u;
@@ -1125,19 +726,18 @@ __global__ __launch_bounds__(kScanBlock) void k_cube_scan(const uint32_t *__rest
     }
     // (Requesting the NEXT cell's work record ahead -- one vector load, lane i = dword i -- was measured: the 8 registers
     // it holds cost a wave per SIMD, 73.6 -> 76.6 us.)
-    const uint32_t wi_end = n_work + (from_list ? 0u : n_long4);
-    for (uint32_t wi = from_list ? wave / kListSegs : wave; wi < wi_end; wi += wi_step) {
+    const uint32_t wi_end = n_work + n_long4;
+    for (uint32_t wi = wave; wi < wi_end; wi += n_waves) {
         uint32_t cell, quarter = 4u;                                // quarter < 4: only that pair of the cell's sub-cells to scan
         if (wi < n_long4) {
             const uint32_t e = wi >> 2;
             const uint32_t ls = (uint32_t)__builtin_popcountll(__ballot(lane < kLongSegs && long_end <= e));
             const uint32_t first = ls ? lane_value(long_end, ls - 1u) : 0u;
-            cell = __builtin_amdgcn_readfirstlane(lists[kListWhole + ls * kLongSegCap + (e - first)]);
+            cell = __builtin_amdgcn_readfirstlane(lists[kLongCells + ls * kLongSegCap + (e - first)]);
             quarter = wi & 3u;
         } else {
             const uint32_t wj = wi - n_long4;
             cell = cells ? __builtin_amdgcn_readfirstlane(cells[wj]) : wj;
-            if (from_list) { quarter = cell >> 16; cell &= 0xFFFFu; }   // (k_cube_prune's entries: cell | quarter << 16)
         }
         const CellWork *cw = cell_work + cell;
         uint32_t scan_set = __builtin_amdgcn_readfirstlane(cw->scan_set);
@@ -1352,125 +952,6 @@ __global__ __launch_bounds__(kScanBlock) void k_cube_scan(const uint32_t *__rest
         }
         __builtin_amdgcn_wave_barrier();
     }
-    // ---- the items (after the whole cells: those are the heavy ones -- the long lists of a photograph -- and start first) ----
-    if (from_list) {
-        const uint4 *items = reinterpret_cast<const uint4 *>(lists + kListItems) + seg * kItemSegCap;
-        const uint32_t vz = opaque_vgpr_zero();
-        const uint32_t step = n_waves / kListSegs;
-        uint32_t it = wave / kListSegs;
-        uint4 item_n = items[(it < n_items ? it : 0u) + vz];        // (vector loads: see k_cube_stage)
-        // two register sets A / B, the loop body once per set (see the cells' loop below): the colours of the NEXT item are in
-        // flight while the current one is scanned, the header of the one after that is requested behind them
-        uint32_t A_h = 0u, A_w0 = 0u, A_w1 = 0u, A_w2 = 0u, B_h = 0u, B_w0 = 0u, B_w1 = 0u, B_w2 = 0u;
-        float4 A_v0, A_v1, B_v0, B_v1;
-        uint32_t A_c0 = 1u, A_c1 = 1u, B_c0 = 1u, B_c1 = 1u;
-        long long A_g = 0, B_g = 0;
-        uint32_t it_req = it;                                       // the item whose header item_n holds
-#define KMG_REQUEST_ITEM(X)                                                                                      \
-        do {                                                                                                     \
-            X##_h = __builtin_amdgcn_readfirstlane(item_n.x); X##_w0 = __builtin_amdgcn_readfirstlane(item_n.y); \
-            X##_w1 = __builtin_amdgcn_readfirstlane(item_n.z); X##_w2 = __builtin_amdgcn_readfirstlane(item_n.w); \
-            const uint32_t cell_ = X##_h & 0x7FFFu;                                                              \
-            const uint32_t c0_ = cell_ * kCellColours + ((X##_h >> 15) & 7u) * 64u + lane;                       \
-            const uint32_t c1_ = cell_ * kCellColours + ((X##_h >> 18) & 7u) * 64u + lane;   /* s1 == 8: sub-cell 0, unused */ \
-            X##_v0 = lab_table[c0_]; X##_v1 = lab_table[c1_];                                                    \
-            if (SUMS) { X##_c0 = hist[c0_]; X##_c1 = hist[c1_]; X##_g = sub_agg[(uint64_t)cell_ * 32u + (lane & 31u)]; } \
-            it_req += step;                                                                                      \
-            item_n = items[(it_req < n_items ? it_req : 0u) + vz];  /* past the end: a harmless repeat */        \
-        } while (0)
-        auto scan_item = [&](const uint32_t hdr, const uint32_t w0, const uint32_t w1, const uint32_t w2, const float4 v0, const float4 v1,
-                             const uint32_t cnt0, const uint32_t cnt1, const long long sagg) {
-            const uint32_t cell = hdr & 0x7FFFu, s0 = (hdr >> 15) & 7u, s1 = (hdr >> 18) & 15u, n = hdr >> 22;
-            // lane p < n: the p-th candidate
-            const uint32_t my_cand = ((lane < 4u ? w0 : (lane < 8u ? w1 : w2)) >> (8u * (lane & 3u))) & 0xFFu;
-            const PixelTerms pt0 = pixel_terms_fast(v0.x, v0.y, v0.z, v0.w), pt1 = pixel_terms_fast(v1.x, v1.y, v1.z, v1.w);
-            uint32_t b0 = 0x7F7FFFFFu, r0 = 0x7F7FFFFFu, b1 = 0x7F7FFFFFu, r1 = 0x7F7FFFFFu;   // smallest / runner-up
-            const f32x2 qL = {pt0.L, pt1.L}, qa = {pt0.a, pt1.a}, qb = {pt0.b, pt1.b}, qC = {pt0.C, pt1.C};
-            const f32x2 qwC = {pt0.wC, pt1.wC}, qwH = {pt0.wH, pt1.wH};
-            auto cand_at = [&](uint32_t pos) { return ((pos < 4u ? w0 : (pos < 8u ? w1 : w2)) >> (8u * (pos & 3u))) & 0xFFu; };
-            for (uint32_t pos = 0; pos < n; ++pos) {
-                const float4 c = s_cent[cand_at(pos)];
-                const f32x2 dL = qL - c.x, da = qa - c.y, db = qb - c.z, dC = qC - c.w;
-                const f32x2 dC2 = dC * dC;
-                const f32x2 t = __builtin_elementwise_fma(db, db, da * da);
-                f32x2 h = t - dC2;
-                h.x = fmaxf(h.x, 0.0f); h.y = fmaxf(h.y, 0.0f);
-                const f32x2 key = __builtin_elementwise_fma(h, qwH, __builtin_elementwise_fma(dC2, qwC, dL * dL));
-                uint32_t u0, u1;                                   // (key & ~31) | pos (pos is wave-uniform)
-                asm("v_bfi_b32 %0, 31, %1, %2" : "=v"(u0) : "s"(pos), "v"(float_to_bits(key.x)));
-                asm("v_bfi_b32 %0, 31, %1, %2" : "=v"(u1) : "s"(pos), "v"(float_to_bits(key.y)));
-                r0 = umed3(u0, b0, r0); b0 = min(b0, u0);
-                r1 = umed3(u1, b1, r1); b1 = min(b1, u1);
-            }
-            uint32_t p0 = b0 & 31u, p1 = b1 & 31u;
-            // near-tie repair (kmg_math.h): rare; decided by the literal distance, first minimum wins
-            const float thr0 = tie_threshold(bits_to_float(b0 & ~31u)), thr1 = tie_threshold(bits_to_float(b1 & ~31u));
-            const bool near0 = bits_to_float(r0 & ~31u) <= thr0, near1 = bits_to_float(r1 & ~31u) <= thr1;
-            if (__ballot(near0 || near1)) {
-                float lb0 = 100000.0f, lb1 = 100000.0f;           // find_centroid.wgsl:29-30
-                uint32_t li0 = 0u, li1 = 0u;
-                for (uint32_t pos = 0; pos < n; ++pos) {
-                    const float4 c = s_cent[cand_at(pos)];
-                    if (near0 && cie94_key(pt0, c.x, c.y, c.z, c.w) <= thr0) {
-                        const float d = cie94_c(v0.x, v0.y, v0.z, v0.w, c.x, c.y, c.z, c.w);
-                        if (d < lb0) { lb0 = d; li0 = pos; }
-                    }
-                    if (near1 && cie94_key(pt1, c.x, c.y, c.z, c.w) <= thr1) {
-                        const float d = cie94_c(v1.x, v1.y, v1.z, v1.w, c.x, c.y, c.z, c.w);
-                        if (d < lb1) { lb1 = d; li1 = pos; }
-                    }
-                }
-                p0 = near0 ? li0 : p0;
-                p1 = near1 ? li1 : p1;
-            }
-            const uint32_t ix0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(p0 << 2), (int)my_cand);
-            const uint32_t ix1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(p1 << 2), (int)my_cand);
-            LabelT *cell_labels = colour_labels + (uint64_t)cell * kCellColours;
-            // what a scanned sub-cell leaves behind: its 64 labels and its sums (as the cells' loop below)
-            auto finish = [&](uint32_t s, uint32_t ix, uint32_t cnt, float vL, float va, float vb) {
-                if (!KMG_KNOCK(flags, 0x2000u)) store_labels64(cell_labels + s * 64u, ix, lane);
-                if (!SUMS || KMG_KNOCK(flags, 0x200u)) return;
-                const bool counts = cnt != 0u;
-                const unsigned long long occm = __ballot(counts);
-                if (!occm) return;
-                const uint32_t X0 = lane_value(ix, (uint32_t)__builtin_ctzll(occm));
-                const unsigned long long other = __ballot(counts && ix != X0);
-                uint32_t R = X0;
-                if (other) {
-                    const uint32_t X1 = lane_value(ix, (uint32_t)__builtin_ctzll(other));
-                    if (__builtin_popcountll(__ballot(counts && ix == X1)) > __builtin_popcountll(occm & ~other)) R = X1;
-                }
-                if ((lane >> 2) == s) atomicAdd(bins + 4ull * R + (lane & 3u), (unsigned long long)sagg);
-                if (other && counts && ix != R) {
-                    const long long m = (long long)cnt;
-                    const long long c0 = m * (long long)lab_fix(vL), c1 = m * (long long)lab_fix(va), c2 = m * (long long)lab_fix(vb);
-                    unsigned long long *to = my_bins + 4ull * ix, *from = my_bins + 4ull * R;
-                    atomicAdd(to + 0, (unsigned long long)c0); atomicAdd(from + 0, (unsigned long long)(-c0));
-                    atomicAdd(to + 1, (unsigned long long)c1); atomicAdd(from + 1, (unsigned long long)(-c1));
-                    atomicAdd(to + 2, (unsigned long long)c2); atomicAdd(from + 2, (unsigned long long)(-c2));
-                    atomicAdd(to + 3, (unsigned long long)m);  atomicAdd(from + 3, (unsigned long long)(-m));
-                }
-            };
-            finish(s0, ix0, cnt0, v0.x, v0.y, v0.z);
-            if (s1 < 8u) finish(s1, ix1, cnt1, v1.x, v1.y, v1.z);
-        };
-        if (it < n_items) {
-            KMG_REQUEST_ITEM(A);
-            for (;;) {
-                // (unconditional: past the end the request repeats item 0 of the segment, unused -- a conditional request makes
-                // the compiler wait for the registers it has just requested)
-                KMG_REQUEST_ITEM(B);
-                scan_item(A_h, A_w0, A_w1, A_w2, A_v0, A_v1, A_c0, A_c1, A_g);
-                it += step;
-                if (it >= n_items) break;
-                KMG_REQUEST_ITEM(A);
-                scan_item(B_h, B_w0, B_w1, B_w2, B_v0, B_v1, B_c0, B_c1, B_g);
-                it += step;
-                if (it >= n_items) break;
-            }
-        }
-#undef KMG_REQUEST_ITEM
-    }
     if (SUMS) flush_bins(bins, k, repl, bin_stride, sums, n_rows);
 }
 
@@ -1483,8 +964,7 @@ __global__ __launch_bounds__(kBlock) void k_cube_pairs(const uint32_t *__restric
                                                        const uint8_t *__restrict__ occ_bits,
                                                        const LabelT *__restrict__ colour_labels,
                                                        uint16_t *__restrict__ sub_table, uint32_t flags,
-                                                       int64_t *__restrict__ sums, uint32_t k, CubeTail tail,
-                                                       const uint32_t *__restrict__ lists)
+                                                       int64_t *__restrict__ sums, uint32_t k, CubeTail tail)
 {
     // the tail of the pass (kmg_table.h CubeTail): the stage and scan launches have completed, so the sums are final
     if (tail.acc_out && blockIdx.x == gridDim.x - 1u) {
@@ -1498,20 +978,14 @@ __global__ __launch_bounds__(kBlock) void k_cube_pairs(const uint32_t *__restric
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
     const uint32_t n_waves = gridDim.x * (kBlock / 64);
-    // kCubePruned (k <= 256): the cells k_cube_prune left without an entry -- segment wave % kListSegs of its second list
-    const bool from_list = (flags & kCubePruned) != 0u;
-    const uint32_t seg = wave & (kListSegs - 1u);
-    const uint32_t n_work = from_list ? __builtin_amdgcn_readfirstlane(lists[2u * seg + 1u]) >> 10
-                                      : (with_work ? __builtin_amdgcn_readfirstlane(work[0]) : kCells);
-    const uint32_t *cells = from_list ? lists + kListEntries + seg * kListSegCap : (with_work ? work + 1 : nullptr);
-    const uint32_t wi_step = from_list ? n_waves / kListSegs : n_waves;
+    const uint32_t n_work = with_work ? __builtin_amdgcn_readfirstlane(work[0]) : kCells;
+    const uint32_t *cells = with_work ? work + 1 : nullptr;
     // (Requesting the next cell's flag, labels and occupancy ahead was measured: no change, 21.5 us either way.)
-    for (uint32_t wi = from_list ? wave / kListSegs : wave; wi < n_work; wi += wi_step) {
+    for (uint32_t wi = wave; wi < n_work; wi += n_waves) {
         const uint32_t cell = cells ? __builtin_amdgcn_readfirstlane(cells[wi]) : wi;
         if (sizeof(LabelT) == 1) {
             uint32_t *pair_entry_ptr = reinterpret_cast<uint32_t *>(sub_table + kSubCells + kCells) + cell;
-            // (a cell of k_cube_prune's list is pending by construction: no flag to wait for before its labels are requested)
-            if (!from_list && __builtin_amdgcn_readfirstlane(*pair_entry_ptr) != kPairPending) continue;
+            if (__builtin_amdgcn_readfirstlane(*pair_entry_ptr) != kPairPending) continue;
             const uint2 lv = *reinterpret_cast<const uint2 *>(colour_labels + (uint64_t)cell * kCellColours + lane * 8u);
             const uint32_t occ = occ_bits ? (uint32_t)occ_bits[(uint64_t)cell * 64u + lane] : 0xFFu;
             uint32_t idx[8];
@@ -2075,36 +1549,44 @@ __global__ __launch_bounds__(kSmallBlock) __attribute__((amdgpu_waves_per_eu(4, 
 }
 
 // ------------------------------------------------------------------------------------------
-// k_cube_one (32 < k <= 256, images without hot cells; round 6): the whole cube pass in ONE launch -- the three or four
-// launches above with nothing but their results leaving the workgroup: no work records, items or lists in memory, no
-// reservation atomics, one prologue / flush instead of four, no launch boundaries (the pass was lean 16.5 + prune 27 +
-// scan 35 + pairs 16 us with ~3 us between them).  k_cube_small's shape with k_cube_lean's candidates and k_cube_prune's
-// list positions: a workgroup of 8 waves owns 64 cells (a wave's 8 cells dealt with stride n_work / 8 over the work list);
-//   1a. candidates   a wave takes its 8 cells one after the other exactly as k_cube_lean does (a lane's four centroids in
-//                    registers, interval bounds over the cell, U, ballots); the list goes to LDS.  One candidate: the cell is
-//                    decided.  More than kMaxListed: no per-sub-cell sets, every colour against the cell's mask (rare).
-//   1b. sub-cells    a thread per sub-cell (its bounds, sums and affine model were requested BEFORE 1a: the candidates hide
-//                    the round trip): k_cube_prune's two sweeps over the list, then its dominance tests as one compact LDS
-//                    list dealt to all 512 threads (`dominated`, unchanged);
+// k_cube_one (32 < k <= 256, images without hot cells; round 6): the whole cube pass in ONE launch.  Rounds 3-5 ran it as four
+// (candidates 16.5 + sub-cell stage and dominance tests 27 + scan 35 + pair entries 16 us, ~3 us between them: 94 us by rocprofv3)
+// with work records, items and balanced lists in memory between them; here nothing but the results leaves the workgroup: no
+// records, no reservation atomics, one prologue / flush instead of four, no launch boundaries -- 76-79 us on the same box
+// (profiles/r06_cube_one_ab.txt).  k_cube_small's shape with candidate lists; a workgroup of 16 waves (ONE per CU) owns 128
+// cells, dealt pseudo-randomly over the work list (the cost of a cell follows its place in the cube):
+//   1a. candidates   a wave takes its 8 cells one after the other (a lane's four centroids in registers, interval bounds over
+//                    the cell, U, ballots); the list goes to LDS.  One candidate: the cell is decided.  More than
+//                    kMaxListed: no per-sub-cell sets, every colour against the cell's mask (a handful of cells).
+//   1b. sub-cells    a thread per sub-cell (its bounds and sums were requested BEFORE 1a: the candidates hide the round
+//                    trip): two sweeps over the list, then the dominance tests of the WAVE's sub-cells as one compact LDS
+//                    list, a test per lane (`dominated`; the 96-byte model from L2);
 //   1c. decisions    sub-cells with one candidate take their sums and their 64 labels (LDS); cells whose occupied sub-cells
 //                    agree take the per-cell sums and their pair entry; what is open becomes ITEMS in LDS -- two sub-cells of
-//                    a cell and the union of their candidates (<= 12: packed as k_cube_prune packs them; more: by position);
-//   2.  scan         the items dealt to the 8 waves, one colour per lane and sub-cell, three items' colours in flight (k_cube_scan's
-//                    item loop: same keys, same near-tie repair, same sums), labels into LDS;
-//   3.  entries      the pair entry of every cell with more than one label from the 512 labels in LDS (cell_pair_entry), the
-//                    labels leave as one 8-byte store per lane.
-// Same arithmetic as the launches it replaces, step for step -- results are bit-identical (tests/test_gpu_table.py runs both).
-// The tail of the pass (sums hand-over, centroid update) rides on the label pass's last workgroup, or is k_cube_pairs' tail
-// workgroup launched alone, as for k_cube_small.  LDS (k = 256): ~75 KiB, two workgroups per CU.
-// stats as k_cube_lean + k_cube_prune.  flags: bit 0, kCubeNoEntries.
+//                    a cell and the union of their candidates (<= 12: as bytes; more: by list position);
+//   -- the ONE workgroup barrier between prologue and flush: every wave's items are listed --
+//   2.  scan         whoever is free takes the next item (an LDS counter), one colour per lane and sub-cell, three items'
+//                    colours in flight: key | position, one integer min / med3 per visit, literal near-tie repair, sums by
+//                    moving minority colours between copies of the LDS bins; labels into LDS;
+//   3.  entries      a cell's items count down in LDS: the wave that scans the last one derives the pair entry from the 512
+//                    labels (cell_pair_entry) and stores them, 8 bytes per lane.
+// Waves never wait for each other inside a phase: with a barrier per phase (the first version) a workgroup paid the slowest of
+// its waves five times -- 92 us; handing out items dynamically and counting cells down: 82 us; one workgroup of 16 waves per
+// CU instead of two of 8 (one pool for 128 cells): 79 us; four copies of the bins instead of two: 76.5 us
+// (tools/cube_one_phases.py stamps the phases; profiles/r06_cube_one_phases_*.txt).  What is left is the spread BETWEEN
+// workgroups -- the slowest of 256 has 1.2 x the items of the average one.
+// Same arithmetic as the launches it replaces, step for step: results are bit-identical.  The tail of the pass (sums hand-over,
+// centroid update) rides on the label pass's last workgroup, or is k_cube_pairs' tail workgroup launched alone.
+// stats: as k_cube_stage.  flags: bit 0, kCubeNoEntries.
 // ------------------------------------------------------------------------------------------
-constexpr int kOneBlockMax = 1024;                               // (tools build: 512 as well, two workgroups per CU)
+constexpr int kOneBlock = 1024;                                  // 16 waves: ONE workgroup per CU
+constexpr uint32_t kOneWaves = kOneBlock / 64, kOneCells = kOneWaves * 8u;   // a wave: 8 cells
+constexpr uint32_t kOneItems = kOneCells * 4u;                   // at most four pairs of sub-cells per cell
 constexpr uint32_t kOneTests = 384;                              // dominance tests a WAVE lists (~120 on the benchmark image; more are dropped = kept candidates)
-constexpr uint32_t kOneRepl = 2;                                 // copies of the LDS bins
+constexpr uint32_t kOneRepl = 4;                                 // copies of the LDS bins
 
-static size_t cube_one_lds_bytes(uint32_t k, bool with_sums, uint32_t kOneBlock)
+static size_t cube_one_lds_bytes(uint32_t k, bool with_sums)
 {
-    const uint32_t kOneWaves = kOneBlock / 64u, kOneCells = kOneWaves * 8u, kOneItems = kOneCells * 4u;
     const size_t bins = with_sums ? sizeof(unsigned long long) * kOneRepl * (4ull * k + 4ull) : 0u;
     return sizeof(float4) * 256u + bins + (size_t)kOneCells * kCellColours + sizeof(uint4) * kOneItems + sizeof(uint16_t) * kOneWaves * kOneTests +
            sizeof(unsigned long long) * kOneCells * 4u + sizeof(uint32_t) * kOneBlock * 2u + (size_t)kOneCells * 64u +
@@ -2114,7 +1596,7 @@ static size_t cube_one_lds_bytes(uint32_t k, bool with_sums, uint32_t kOneBlock)
 #ifdef KMG_TOOLS
 // tools build: phase stamps of k_cube_one (s_memrealtime, 100 MHz), [workgroup][8]: start, 1a done (wave 0), 1b swept, tests done, 1c done,
 // scan done (wave 0), scan done (all), entries done (wave 0); [8..10] items, pending cells, tests of the workgroup
-__device__ unsigned long long g_one_stamps[512 * 12u];
+__device__ unsigned long long g_one_stamps[(kCells / kOneCells) * 12u];
 #define KMG_STAMP(i) do { if (threadIdx.x == 0u) g_one_stamps[blockIdx.x * 12u + (i)] = wall_clock64(); } while (0)
 #define KMG_STAMP_VALUE(i, v) do { if (threadIdx.x == 0u) g_one_stamps[blockIdx.x * 12u + (i)] = (v); } while (0)
 #else
@@ -2122,7 +1604,7 @@ __device__ unsigned long long g_one_stamps[512 * 12u];
 #define KMG_STAMP_VALUE(i, v) do { } while (0)
 #endif
 
-template <bool SUMS, int kOneBlock>
+template <bool SUMS>
 __global__ __launch_bounds__(kOneBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_cube_one(
     const uint32_t *__restrict__ hist, const int64_t *__restrict__ agg, const int64_t *__restrict__ sub_agg,
     const uint8_t *__restrict__ occ_bits, const uint32_t *__restrict__ work, const CellBounds *__restrict__ bounds,
@@ -2131,8 +1613,6 @@ __global__ __launch_bounds__(kOneBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
     uint16_t *__restrict__ sub_table, int64_t *__restrict__ sums, uint32_t n_rows, uint32_t flags,
     unsigned long long *__restrict__ stats)
 {
-    constexpr uint32_t kOneWaves = kOneBlock / 64, kOneCells = kOneWaves * 8u;       // a wave: 8 cells
-    constexpr uint32_t kOneItems = kOneCells * 4u;                                   // at most four pairs of sub-cells per cell
     extern __shared__ float4 smem4[];
     float4 *s_cent = smem4;                                                            // [256]
     unsigned long long *bins = reinterpret_cast<unsigned long long *>(smem4 + 256);
@@ -2213,7 +1693,7 @@ __global__ __launch_bounds__(kOneBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
         if (occ_bits) occ8 = *reinterpret_cast<const uint2 *>(occ_bits + (uint64_t)cell * 64u + sub * 8u);
         if (sub == 0u) s_cell[slot] = cell;
 
-        // ---- 1a. the candidates of the wave's cells, one cell at a time (k_cube_lean) ----
+        // ---- 1a. the candidates of the wave's cells, one cell at a time ----
         for (uint32_t c = 0; c < 8u; ++c) {
             const uint32_t ccell = lane_value(cell, c * 8u);
             const bool cvalid = lane_value((uint32_t)valid, c * 8u) != 0u;
@@ -2256,7 +1736,7 @@ __global__ __launch_bounds__(kOneBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
         __builtin_amdgcn_wave_barrier();                            // (s_list / s_npop of a cell: written and read by this wave only)
         KMG_STAMP(1);
 
-        // ---- 1b. the sub-cell stage of the listed cells (k_cube_prune): the thread's own sub-cell, two sweeps over the list ----
+        // ---- 1b. the sub-cell stage of the listed cells: the thread's own sub-cell, two sweeps over the list ----
         const uint32_t np_first = s_npop[slot];
         const uint32_t npop = valid ? (np_first & 0xFFFFu) : 1u, first = np_first >> 16;
         const bool listed = valid && npop > 1u && npop <= kMaxListed;
@@ -2603,9 +2083,10 @@ __global__ __launch_bounds__(kOneBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
 
 #ifdef KMG_TOOLS
 extern "C" KMG_API int kmg_tools_cube_one_stamps(unsigned long long *out, uint32_t n)
-{
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_one_stamps), sizeof(unsigned long long) * std::min<size_t>(n, 512 * 12u));
+try {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_one_stamps), sizeof(unsigned long long) * std::min<size_t>(n, (kCells / kOneCells) * 12u));
 }
+KMG_ABI_CATCH
 #endif
 
 static uint32_t grid_or(const char *e, uint32_t dflt)
@@ -2627,19 +2108,12 @@ uint32_t cube_replicas(uint32_t k)
 
 size_t cube_work_bytes() { return sizeof(CellWork) * (size_t)kCells + sizeof(uint32_t) * kListsWords; }
 
-// the dominance phase of the general pass (k_cube_prune): needs the sub_affine table of the processor
-bool cube_prune_wanted(uint32_t k)
-{
-    static const bool on = tools_env_int(KMG_TOOLS_ENV("KMG_CUBE_PRUNE"), 1) != 0;     // (tools build: 0 = the pass without it)
-    return on && k > kSmallMaxK && k <= 256u;
-}
-
-// the cube pass of this k (and these caller flags) is ONE launch: k_cube_small, or k_cube_one -- its tail can ride on a label pass
+// the cube pass of this k (and these caller flags) is ONE launch: k_cube_small, or k_cube_one (32 < k <= 256, images without hot
+// cells: a photograph's few hundred cells with long candidate lists want the stage / scan launches, which spread them over the
+// device) -- its tail can ride on a label pass
 bool cube_single_launch(uint32_t k, uint32_t flags)
 {
-    if (k <= kSmallMaxK) return true;
-    static const bool one_on = tools_env_int(KMG_TOOLS_ENV("KMG_CUBE_ONE"), 1) != 0;      // (tools build: 0 = the four launches)
-    return one_on && cube_prune_wanted(k) && !(flags & kCubeNoPrune);
+    return k <= kSmallMaxK || (k <= 256u && !(flags & kCubeHot));
 }
 
 hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *sub_agg, const uint8_t *occ_bits,
@@ -2695,33 +2169,29 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
                 hipLaunchKernelGGL((k_cube_scan<uint8_t, false>), dim3(g_scan2), dim3(kScanBlock), lds_scan2, st, hist, sub_agg, work, cent, k,
                                    lab_table, masks, (const CellWork *)cell_work, (uint8_t *)colour_labels, sub_table, sums, n_rows, repl2, flags);
             hipLaunchKernelGGL((k_cube_pairs<uint8_t>), dim3((flags & kCubeNoEntries) ? 1u : g_pairs2), dim3(kBlock), 0, st, work,
-                               with_sums ? 1 : 0, occ_bits, (const uint8_t *)colour_labels, sub_table, flags, sums, k, tl,
-                               (const uint32_t *)nullptr);
+                               with_sums ? 1 : 0, occ_bits, (const uint8_t *)colour_labels, sub_table, flags, sums, k, tl);
             return hipGetLastError();
         }
         if (tl.acc_out)
             hipLaunchKernelGGL((k_cube_pairs<uint8_t>), dim3(1), dim3(kBlock), 0, st, work, 1, occ_bits,
-                               (const uint8_t *)colour_labels, sub_table, flags | kCubeNoEntries, sums, k, tl, (const uint32_t *)nullptr);
+                               (const uint8_t *)colour_labels, sub_table, flags | kCubeNoEntries, sums, k, tl);
         return hipGetLastError();
     }
     // 32 < k <= 256 without hot cells: the whole pass in one launch (k_cube_one) + the tail workgroup
     if (cube_single_launch(k, flags)) {
-        // one workgroup of 16 waves per CU (133 KiB of LDS at k = 256): its 128 cells share one item pool -- two workgroups of 8
-        // waves finish at different times (measured, tools/cube_one_phases.py)
-        static const uint32_t one_block = tools_env_int(KMG_TOOLS_ENV("KMG_ONE_BLOCK"), kOneBlockMax) == 512 ? 512u : (uint32_t)kOneBlockMax;
-        const size_t lds = cube_one_lds_bytes(k, with_sums, one_block);
+        // one workgroup of 16 waves per CU (150 KiB of LDS at k = 256): its 128 cells share one item pool
+        const size_t lds = cube_one_lds_bytes(k, with_sums);
         if (lds > lds_max_dev) return hipErrorInvalidValue;
         if (!n_rows) n_rows = 1u;
-        const uint32_t grid = kCells / (one_block / 8u);
-#define KMG_ONE(S, B)                                                                                                       \
-        hipLaunchKernelGGL((k_cube_one<S, B>), dim3(grid), dim3(B), lds, st, hist, agg, sub_agg, occ_bits, work, bounds,     \
-                           sub_bounds, sub_affine, cent, k, lab_table, masks, (uint8_t *)colour_labels, sub_table, sums, n_rows, flags, stats)
-        if (one_block == 512u) { if (with_sums) KMG_ONE(true, 512); else KMG_ONE(false, 512); }
-        else                   { if (with_sums) KMG_ONE(true, 1024); else KMG_ONE(false, 1024); }
-#undef KMG_ONE
+        if (with_sums)
+            hipLaunchKernelGGL((k_cube_one<true>), dim3(kCells / kOneCells), dim3(kOneBlock), lds, st, hist, agg, sub_agg, occ_bits, work, bounds,
+                               sub_bounds, sub_affine, cent, k, lab_table, masks, (uint8_t *)colour_labels, sub_table, sums, n_rows, flags, stats);
+        else
+            hipLaunchKernelGGL((k_cube_one<false>), dim3(kCells / kOneCells), dim3(kOneBlock), lds, st, hist, agg, sub_agg, occ_bits, work, bounds,
+                               sub_bounds, sub_affine, cent, k, lab_table, masks, (uint8_t *)colour_labels, sub_table, sums, n_rows, flags, stats);
         if (tl.acc_out)
             hipLaunchKernelGGL((k_cube_pairs<uint8_t>), dim3(1), dim3(kBlock), 0, st, work, 1, occ_bits,
-                               (const uint8_t *)colour_labels, sub_table, flags | kCubeNoEntries, sums, k, tl, (const uint32_t *)nullptr);
+                               (const uint8_t *)colour_labels, sub_table, flags | kCubeNoEntries, sums, k, tl);
         return hipGetLastError();
     }
     // (the scan kernel's cells differ a lot in cost: finer hand-out, 2 cells per wave, measured 83 -> 75 us)
@@ -2730,41 +2200,22 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
                           g_pairs = env_grid("KMG_PAIRS_GRID", kCubeGrid);
     CellWork *cw = (CellWork *)cell_work;
     if (!n_rows) n_rows = 1u;
-    // 32 < k <= 256: the dominance phase and its compact lists between the stage and the scan (sub_affine == NULL: lists only)
-    const bool prune = cube_prune_wanted(k) && !(flags & kCubeNoPrune) && !KMG_KNOCK(flags, 0x800u);
-    if (prune) flags |= kCubePruned;
-    else if (k <= 256u && tools_env_int(KMG_TOOLS_ENV("KMG_SPLIT_LONG"), 1) != 0) {
+    if (k <= 256u && tools_env_int(KMG_TOOLS_ENV("KMG_SPLIT_LONG"), 1) != 0) {
         // (the stage kernel's workgroups append to the list of long-list cells as they meet them: its counters are cleared ahead of
         // the launch, not by one of its workgroups)
         flags |= kCubeSplitLong;
         hipError_t e = hipMemsetAsync(reinterpret_cast<uint32_t *>((CellWork *)cell_work + kCells) + kLongCount, 0, sizeof(uint32_t) * kLongSegs, st);
         if (e != hipSuccess) return e;
     }
-    const uint32_t g_prune = kCells / kPruneCells;                 // (one batch of cells per workgroup)
-    // (the scan over items: one round of resident workgroups, each wave a few items with the next one's colours in flight)
-    static const uint32_t g_items = env_grid("KMG_ITEMS_GRID", 896u) & ~7u;
-    const uint32_t *lists = reinterpret_cast<const uint32_t *>(cw + kCells);
-    static const uint32_t g_lean = env_grid("KMG_LEAN_GRID", 2048u);
-    const size_t lds_lean = with_sums ? sizeof(unsigned long long) * 4ull * k : 0;
 #define KMG_CUBE(T, S)                                                                                                      \
     do {                                                                                                                    \
-        if (prune) {                                                                                                        \
-            /* candidates + lists by k_cube_lean, the sub-cell stage by k_cube_prune */                                     \
-            hipLaunchKernelGGL((k_cube_lean<S>), dim3(g_lean), dim3(kBlock), lds_lean, st, agg, sub_agg, work, bounds, cent, k,    \
-                               masks, cw, (uint8_t *)colour_labels, sub_table, sums, n_rows, flags, stats);                  \
-        } else {                                                                                                            \
-            hipLaunchKernelGGL((k_cube_stage<T, S>), dim3(g_stage), dim3(kBlock), lds_stage, st, agg, sub_agg, work, bounds, \
-                               sub_bounds, cent, k, masks, cw, (T *)colour_labels, sub_table, sums, n_rows, flags, stats);  \
-        }                                                                                                                   \
-        if (prune)                                                                                                          \
-            hipLaunchKernelGGL((k_cube_prune<S>), dim3(g_prune), dim3(kBlock), 0, st, work, sub_agg, sub_bounds, cent, k,   \
-                               sub_affine, cw, (uint8_t *)colour_labels, sub_table, const_cast<uint32_t *>(lists), sums,    \
-                               n_rows, flags, stats);                                                                       \
+        hipLaunchKernelGGL((k_cube_stage<T, S>), dim3(g_stage), dim3(kBlock), lds_stage, st, agg, sub_agg, work, bounds,     \
+                           sub_bounds, cent, k, masks, cw, (T *)colour_labels, sub_table, sums, n_rows, flags, stats);      \
         if (!KMG_KNOCK(flags, 0xC00u))                                                                                      \
-            hipLaunchKernelGGL((k_cube_scan<T, S>), dim3(prune ? g_items : g_scan), dim3(kScanBlock), lds_scan, st, hist, sub_agg, work, cent, k, \
+            hipLaunchKernelGGL((k_cube_scan<T, S>), dim3(g_scan), dim3(kScanBlock), lds_scan, st, hist, sub_agg, work, cent, k, \
                                lab_table, masks, cw, (T *)colour_labels, sub_table, sums, n_rows, repl, flags);             \
         hipLaunchKernelGGL((k_cube_pairs<T>), dim3((flags & kCubeNoEntries) ? 1u : g_pairs), dim3(kBlock), 0, st, work,   \
-                           S ? 1 : 0, occ_bits, (const T *)colour_labels, sub_table, flags, sums, k, tl, lists);            \
+                           S ? 1 : 0, occ_bits, (const T *)colour_labels, sub_table, flags, sums, k, tl);                   \
     } while (0)
     if (k <= 256) { if (with_sums) KMG_CUBE(uint8_t, true); else KMG_CUBE(uint8_t, false); }
     else          { if (with_sums) KMG_CUBE(uint16_t, true); else KMG_CUBE(uint16_t, false); }
@@ -2778,10 +2229,10 @@ hipError_t launch_cube_entries(const uint32_t *work, const uint8_t *occ_bits, co
     static const uint32_t g_pairs = env_grid("KMG_PAIRS_GRID", kCubeGrid);
     if (k <= 256)
         hipLaunchKernelGGL((k_cube_pairs<uint8_t>), dim3(g_pairs), dim3(kBlock), 0, st, work, work ? 1 : 0, occ_bits,
-                           (const uint8_t *)colour_labels, sub_table, 0u, (int64_t *)nullptr, k, CubeTail(), (const uint32_t *)nullptr);
+                           (const uint8_t *)colour_labels, sub_table, 0u, (int64_t *)nullptr, k, CubeTail());
     else
         hipLaunchKernelGGL((k_cube_pairs<uint16_t>), dim3(g_pairs), dim3(kBlock), 0, st, work, work ? 1 : 0, occ_bits,
-                           (const uint16_t *)colour_labels, sub_table, 0u, (int64_t *)nullptr, k, CubeTail(), (const uint32_t *)nullptr);
+                           (const uint16_t *)colour_labels, sub_table, 0u, (int64_t *)nullptr, k, CubeTail());
     return hipGetLastError();
 }
 

@@ -93,7 +93,7 @@ int ensure_bounds(kmg_processor *p, hipStream_t st)
 // NULL when it cannot be had -- the pass is exact without it, only slower.
 const float *affine_for(kmg_processor *p, uint32_t k, hipStream_t st)
 {
-    if (k > kCubeSmallMaxK && !cube_prune_wanted(k)) return nullptr;   // (k_cube_small and k_cube_prune make the test)
+    if (k > 256u) return nullptr;                                      // (k_cube_small and k_cube_one make the test)
     std::lock_guard<std::mutex> lock(p->mu);
     if (p->d_sub_affine || p->affine_failed || !p->d_lab_table) return p->d_sub_affine;
     float *a = nullptr;
@@ -404,7 +404,7 @@ static int debug_refresh(kmg_lloyd *s, hipStream_t st, unsigned long long stage[
     unsigned long long *d_stage = reinterpret_cast<unsigned long long *>(s->d_partials) + 4ull * s->k;
     HIP_TRY(hipMemsetAsync(s->d_partials, 0, sizeof(int64_t) * (4ull * s->k + 8ull), st));
     HIP_TRY(launch_cube(t.d_hist, t.d_agg, t.d_sub_agg, t.d_occ, t.d_work, s->p->d_bounds, s->p->d_sub_bounds, s->d_cent, s->k,
-                        s->p->d_lab_table, t.d_masks, t.d_cell_work, t.d_colour_labels, t.d_sub, s->d_partials, 1u, 1u | (t.n_hot ? kCubeNoPrune : 0u), d_stage, st,
+                        s->p->d_lab_table, t.d_masks, t.d_cell_work, t.d_colour_labels, t.d_sub, s->d_partials, 1u, 1u | (t.n_hot ? kCubeHot : 0u), d_stage, st,
                         nullptr, affine_for(s->p, s->k, st)));
     t.entries_valid = true;
     if (stage) HIP_TRY(hipMemcpyAsync(stage, d_stage, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
@@ -468,11 +468,11 @@ static int table_assign(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_
         tail.cent = s->d_cent;
         tail.n_converged = s->d_nconv;
         // (k <= 32, and 32 < k <= 256 without hot cells: the cube pass is one launch, and when a label pass follows, its tail rides on that one)
-        const bool tail_on_labels = d_labels != nullptr && s->k <= 256u && cube_single_launch(s->k, t.n_hot ? kCubeNoPrune : 0u);
+        const bool tail_on_labels = d_labels != nullptr && s->k <= 256u && cube_single_launch(s->k, t.n_hot ? kCubeHot : 0u);
         PROF_LAUNCH(s, KMG_K_CUBE, st, launch_cube(t.d_hist, t.d_agg, t.d_sub_agg, t.d_occ, t.d_work_share ? t.d_work_share : t.d_work,
                                                    s->p->d_bounds, s->p->d_sub_bounds,
                                                    s->d_cent, s->k, s->p->d_lab_table, t.d_masks, t.d_cell_work, t.d_colour_labels, t.d_sub,
-                                                   s->d_acc_int, 1u, (defer_entries ? kCubeNoEntries : 0u) | (t.n_hot ? kCubeNoPrune : 0u), nullptr, st,
+                                                   s->d_acc_int, 1u, (defer_entries ? kCubeNoEntries : 0u) | (t.n_hot ? kCubeHot : 0u), nullptr, st,
                                                    tail_on_labels ? nullptr : &tail, affine_for(s->p, s->k, st)));
         t.entries_valid = !defer_entries;
         if (tail_on_labels) {
@@ -489,7 +489,7 @@ static int table_assign(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_
         HIP_TRY(hipMemsetAsync(d_sums, 0, sizeof(int64_t) * 4ull * s->k * rows, st));
         PROF_LAUNCH(s, KMG_K_CUBE, st, launch_cube(t.d_hist, t.d_agg, t.d_sub_agg, t.d_occ, t.d_work, s->p->d_bounds, s->p->d_sub_bounds,
                                                    s->d_cent, s->k, s->p->d_lab_table, t.d_masks, t.d_cell_work, t.d_colour_labels, t.d_sub,
-                                                   d_sums, rows, t.n_hot ? kCubeNoPrune : 0u, nullptr, st, nullptr, affine_for(s->p, s->k, st)));
+                                                   d_sums, rows, t.n_hot ? kCubeHot : 0u, nullptr, st, nullptr, affine_for(s->p, s->k, st)));
         t.entries_valid = true;
     }
     // (a share's pass leaves the tables current for ITS cells only: kmg_lloyd_labels refuses them, _labels_from_tables -- after
@@ -1092,7 +1092,7 @@ try {
         HIP_TRY(hipMemsetAsync(d_acc4, 0, sizeof(int64_t) * 4ull * s->k, st));
         PROF_LAUNCH(s, KMG_K_CUBE, st, launch_cube(t.d_hist, t.d_agg, t.d_sub_agg, t.d_occ, t.d_work, s->p->d_bounds, s->p->d_sub_bounds,
                                                    s->d_cent, s->k, s->p->d_lab_table, t.d_masks, t.d_cell_work, t.d_colour_labels, t.d_sub,
-                                                   d_acc4, 1u, t.n_hot ? kCubeNoPrune : 0u, nullptr, st, nullptr, affine_for(s->p, s->k, st)));
+                                                   d_acc4, 1u, t.n_hot ? kCubeHot : 0u, nullptr, st, nullptr, affine_for(s->p, s->k, st)));
         return KMG_OK;
     };
     if ((rc = issue()) != KMG_OK) {

@@ -67,7 +67,7 @@ struct kmg_processor {
     CellBounds *d_bounds;    // kCells static cell bounds of the colour-table strategy
     CellBounds *d_sub_bounds;   // kSubCells static bounds of the 4x4x4 sub-cells
     float4 *d_lab_table;     // 2^24 x (L, a, b, C): Lab of every colour (256 MiB, built with d_bounds)
-    float *d_sub_affine;     // sub_affine_bytes(): affine feature models per sub-cell (dominance test of k_cube_small / k_cube_prune),
+    float *d_sub_affine;     // sub_affine_bytes(): affine feature models per sub-cell (dominance test of k_cube_small / k_cube_one),
                              // built on the first colour-table pass with k <= 256
     bool affine_failed;      // ... or not at all (allocation failed: the pass runs without the test)
     std::vector<hipStream_t> idle_streams;   // streams of finished host-buffer calls, reused by the next ones (mu)

@@ -175,10 +175,11 @@ hipError_t launch_init_records(const uint32_t *work, const CellBounds *bounds, v
 hipError_t launch_init_pass_cells(const uint32_t *tie, const uint8_t *occ_bits, const float4 *lab_table, Centroid *cent,
                                   uint32_t j, int do_pass, float *dist, void *init_scratch, unsigned long long *band_key,
                                   const uint32_t *pick_rgba, const float *lut, hipStream_t st);
-// per iteration (kmg_cube.hip): candidates + sub-cell stage, (dominance phase,) colour scan, pair entries -- three or four launches.
+// per iteration (kmg_cube.hip): candidates + sub-cell stage, dominance tests, colour scan, pair entries -- ONE launch for k <= 256
+// on images without hot cells (k_cube_small, k_cube_one), three otherwise (k_cube_stage, k_cube_scan, k_cube_pairs).
 // work: [0] = number of occupied cells of the bound image, [1..] = their indices (built at bind time).
 // masks: the cell candidate masks, mask_words(k) u64 per cell; cell_work: cube_work_bytes() of scratch (the
-// stage kernel's records for the scan kernel and, behind them, the items / lists of k_cube_prune).
+// stage kernel's records for the scan kernel and, behind them, its list of cells with long candidate lists).
 // Every workgroup adds the sums of the clusters it met into row (workgroup % n_rows) of `sums` (k x 4 int64
 // per row, zero on entry; n_rows = 1: the final sums).  hist == NULL: output pass of replace mode -- every
 // colour of every cell is labelled, nothing is accumulated (agg, sub_agg, occ_bits, work, sums unused).
@@ -190,15 +191,13 @@ size_t cube_work_bytes();
 // flags bit 16: the pass leaves the cells' pair entries / summaries (what the LABEL pass reads first) to a later
 // launch_cube_entries -- a loop that only needs the sums (kmg_lloyd_run) pays for them once, after its last iteration
 constexpr uint32_t kCubeNoEntries = 0x10000u;
-// flags bit 18 (callers): no dominance phase for this pass.  Set for a bound image with hot cells (a photograph): its scan
-// kernel waits for the few cells with long candidate lists, which the phase does not touch, so the phase only costs
-// (measured: +12 us per pass on the test photograph, -8 us on noise; profiles/NOTES.md round 5).
-constexpr uint32_t kCubeNoPrune = 0x40000u;
-constexpr uint32_t kCubeSplitLong = 0x80000u;  // (set by launch_cube itself, k <= 256 without k_cube_prune: long-list cells are scanned by four waves each)
-constexpr uint32_t kCubePruned = 0x20000u;   // (set by launch_cube itself: k_cube_prune has run between the stage and the scan)
-bool cube_prune_wanted(uint32_t k);          // the general pass makes the dominance test: launch_cube wants sub_affine for this k
+// flags bit 18 (callers): the bound image has hot cells (a photograph).  Its pass is the few hundred cells with long candidate lists --
+// up to 215 candidates at k = 256, crowded into the dark corner of the cube -- which the three-launch pass spreads over the whole
+// device (kCubeSplitLong: four waves per such cell); the one-launch pass would leave them to the few workgroups that own them.
+constexpr uint32_t kCubeHot = 0x40000u;
+constexpr uint32_t kCubeSplitLong = 0x80000u;  // (set by launch_cube itself, k <= 256, three launches: long-list cells are scanned by four waves each)
 constexpr uint32_t kCubeSmallMaxK = 32;      // k up to which the cube pass is the one-launch k_cube_small
-// the cube pass of this k with these caller flags (kCubeNoPrune) is ONE launch -- k_cube_small, or k_cube_one for 32 < k <= 256
+// the cube pass of this k with these caller flags (kCubeHot) is ONE launch -- k_cube_small (k <= 32), or k_cube_one for 32 < k <= 256
 // on images without hot cells: when a label pass follows, the pass's tail (CubeTail) rides on that one
 bool cube_single_launch(uint32_t k, uint32_t flags);
 hipError_t launch_cube_entries(const uint32_t *work, const uint8_t *occ_bits, const void *colour_labels, uint16_t *sub_table,
@@ -218,8 +217,7 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
                        uint32_t k, const float4 *lab_table, uint64_t *masks, void *cell_work, void *colour_labels,
                        uint16_t *sub_table, int64_t *sums, uint32_t n_rows, uint32_t flags, unsigned long long *stats,
                        hipStream_t st, const CubeTail *tail = nullptr, const float *sub_affine = nullptr);
-// k <= 32 takes the pass in ONE launch (k_cube_small, kmg_cube.hip); 32 < k <= 256 in four (k_cube_prune between the stage and
-// the scan, unless kCubeNoPrune).  sub_affine (optional, once per processor, sub_affine_bytes() = 24 MiB, image independent):
+// sub_affine (optional, once per processor, sub_affine_bytes() = 24 MiB, image independent; k_cube_small and k_cube_one use it):
 // per sub-cell affine models (binary16) of the seven per-colour features the difference of two keys is linear in, with exact
 // residual ranges -- the dominance test that removes, from a sub-cell's candidates, those another candidate beats on every
 // colour of the sub-cell (3x fewer scanned sub-cells at k = 16, 2.3x fewer at k = 256).

@@ -120,7 +120,8 @@ def test_every_entry_point_is_a_function_try_block():
             if name not in _NO_THROW and "try" not in body.split("{")[0]:
                 unguarded.append(f"{f}:{i + 1} {name}")
     assert not unguarded, unguarded
-    assert defined == set(_declared())
+    # (kmg_tools_*: entry points of the tools build only, -DKMG_TOOLS -- not in the header, not in the product library)
+    assert {d for d in defined if not d.startswith("kmg_tools_")} == set(_declared())
     for f in ("kmg_api.hip", "kmg_apply.hip", "kmg_group.hip", "kmg_lloyd.hip", "kmg_processor.hip"):
         text = open(os.path.join(CSRC, f)).read()
         assert text.count("\ntry {") + text.count("\ntry { ") >= 1

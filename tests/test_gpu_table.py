@@ -39,7 +39,7 @@ def _centroid_sets(oracle, rng):
     sets["far"] = np.array([[5000, 0, 0], [50, 2000, -2000], [1e6, 1e6, 1e6], [50, 0, 0], [60, 10, 10]], np.float32)
     sets["edge1024"] = np.array([[1000, 1000, -1000], [50, 5, 5], [52, 5, 5], [-1000, -1000, 1000], [50, 1023, 0],
                                  [51, -3, 4], [1023, 0, 0]], np.float32)
-    # the same two for the general pass (k > 32), whose dominance test is a phase of its own (k_cube_prune)
+    # the same two for 32 < k <= 256 (k_cube_one: the test over candidate LISTS)
     sets["far64"] = np.concatenate([lab[:59], sets["far"]])
     sets["edge64"] = np.concatenate([lab[:57], sets["edge1024"]])
     sets["k512"] = oracle.rgb_to_lab(rng.integers(0, 256, (512, 4), dtype=np.uint8))                                   # two byte lists per cell
@@ -1229,9 +1229,9 @@ def test_cell_share_refuses_what_it_cannot_answer(torch_cuda, oracle, monkeypatc
 
 
 def test_dominance_phase_runs_on_spread_images_only(torch_cuda, processor, oracle):
-    """32 < k <= 256: the cube pass of an image WITHOUT hot cells (noise) takes the dominance phase (k_cube_prune) -- it removes
-    candidates, decides sub-cells, and the tables stay exactly right (exhaustive check, pair entries, labels and sums against the
-    oracle); an image with hot cells (flat areas: the photograph case) skips it"""
+    """32 < k <= 256: the cube pass of an image WITHOUT hot cells (noise) is the one-launch k_cube_one with its dominance tests --
+    they remove candidates, decide sub-cells, and the tables stay exactly right (exhaustive check, pair entries, labels and sums
+    against the oracle); an image with hot cells (flat areas: the photograph case) takes the three launches, which make none"""
     import kmeans_gpu_amd as kg
     torch = torch_cuda
     st = _stream(torch)
@@ -1263,9 +1263,9 @@ def test_dominance_phase_runs_on_spread_images_only(torch_cuda, processor, oracl
 
 
 def test_dominance_phase_with_crowded_centroids(torch_cuda, processor, oracle):
-    """k_cube_prune where its items do not fit: 100 of 200 centroids crowded around one colour give the cells near it more than
-    12 candidates per pair of sub-cells (scanned from their work records, the sets rewritten by the phase) and some more than 32
-    (long lists, untouched by the phase) -- labels and sums of a noise image == the oracle, the tables exhaustively right"""
+    """k_cube_one where its packed items do not fit: 100 of 200 centroids crowded around one colour give the cells near it more
+    than 12 candidates per pair of sub-cells (items by list position) and some more than 32 (no list: every colour against the
+    cell's mask) -- labels and sums of a noise image == the oracle, the tables exhaustively right"""
     import kmeans_gpu_amd as kg
     torch = torch_cuda
     st = _stream(torch)
