@@ -963,11 +963,11 @@ constexpr uint32_t kHotCode = 127u;                                // direction 
 constexpr size_t kLabelLdsPlain = sizeof(uint32_t) * (kCells + 256 + 128);
 constexpr size_t kLabelLdsHot = kLabelLdsPlain + (size_t)kHotMax * kCellColours + sizeof(uint32_t) * 64;
 
-// KNOCK (tools only, results wrong): 1 = gathers from a 64 KiB window of the table, 2 = from LDS instead, 3 = none,
-// 4 = plain non-temporal gathers, 5 = gathers from a table a quarter the size, 6 = the cheaper colour index of a
-// (cell, r & 7, g & 7, b & 7)-ordered table, 7 = three quarters of the pixel bytes read, 8 = half the pair
-// table in LDS and two workgroups per CU (round 4 probes, profiles/NOTES.md)
-template <bool HOT, int KNOCK = 0>
+// (The knock-outs this kernel carried in rounds 3-5 -- gathers from a window / from LDS / none, a cheaper colour index, three
+// quarters of the pixel bytes, half the pair table, a second-plane extension entry, one more LDS read per pixel -- have served
+// their measurements (profiles/r03_label_knock.txt, r05_label_knock.txt: ~0.5 us per vector instruction and pixel, +4.5 us per
+// LDS read) and live on as tools/experiments/r06_label_pass_knockouts.patch.)
+template <bool HOT>
 __global__ __launch_bounds__(kLabelBlock) void k_labels_pairs(const uint32_t *__restrict__ rgba, uint64_t n,
                                                               const uint8_t *__restrict__ colour_labels,
                                                               const uint32_t *__restrict__ pair_table,
@@ -986,8 +986,7 @@ __global__ __launch_bounds__(kLabelBlock) void k_labels_pairs(const uint32_t *__
         for (uint32_t i = threadIdx.x; i < 4u * k; i += kLabelBlock) tail_sums[i] = 0;      // ready for the next pass
         __syncthreads();
     }
-    // (KNOCK 8: half the pair table -- 64 KiB, two workgroups per CU; cells share entries, i.e. wrong results)
-    constexpr uint32_t kPairWords = KNOCK == 8 ? kCells / 2u : kCells;
+    constexpr uint32_t kPairWords = kCells;
     uint32_t *s_pair = s_label_lds, *s_pal = s_label_lds + kPairWords, *s_dir = s_label_lds + kPairWords + 256;
     uint8_t *s_hot = reinterpret_cast<uint8_t *>(s_label_lds + kPairWords + 256 + 128);
     uint32_t *s_hcell = reinterpret_cast<uint32_t *>(s_hot + (size_t)kHotMax * kCellColours);
@@ -1027,17 +1026,10 @@ __global__ __launch_bounds__(kLabelBlock) void k_labels_pairs(const uint32_t *__
         for (int g = 0; g < 2; ++g) {
             i0[g] = tile * TILE + (uint64_t)g * (kLabelBlock * 4) + (uint64_t)threadIdx.x * 4;
             uint32_t px[4];
-            // (KNOCK 7: three quarters of the pixel bytes are read, aligned -- the bandwidth a packed 3-byte stream would save)
-            load4_stream(rgba, KNOCK == 7 ? ((i0[g] * 3u / 4u) & ~3ull) : i0[g], n, aligned != 0, px);
+            load4_stream(rgba, i0[g], n, aligned != 0, px);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                if (KNOCK == 6) {        // the index a (cell, r & 7, g & 7, b & 7)-ordered table would take: 11 operations instead of 18
-                    const uint32_t v = px[q];
-                    const uint32_t cell = ((v >> 3) & 31u) << 10 | ((v >> 11) & 31u) << 5 | ((v >> 19) & 31u);
-                    ci[g * 4 + q] = cell << 9 | (v & 7u) << 6 | ((v >> 8) & 7u) << 3 | ((v >> 16) & 7u);
-                } else {
-                    ci[g * 4 + q] = colour_index(px[q]);
-                }
+                ci[g * 4 + q] = colour_index(px[q]);
                 xyz[g * 4 + q] = (px[q] & 0x00070707u) | 0x01000000u;   // (r & 7, g & 7, b & 7, 1)
             }
         }
@@ -1045,19 +1037,9 @@ __global__ __launch_bounds__(kLabelBlock) void k_labels_pairs(const uint32_t *__
         bool fine[8];
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
-            const uint32_t e = s_pair[(ci[p] >> 9) & (kPairWords - 1u)];
+            const uint32_t e = s_pair[ci[p] >> 9];
             const uint32_t code = (e >> 16) & 127u;
-            uint32_t dirw;
-            if (KNOCK == 10) {
-                // probe (round 5, results RIGHT): the direction word computed from its code instead of read from LDS
-                const uint32_t qx = (code * 41u) >> 10, rem = code - 25u * qx;      // code / 25, code < 128
-                const uint32_t qy = (rem * 13u) >> 6, qz = rem - 5u * qy;           // rem / 5, rem < 28
-                const int nx = (int)qx - 2, ny = (int)qy - 2, nz = (int)qz - 2;
-                const int bias = 7 * (max(-nx, 0) + max(-ny, 0) + max(-nz, 0));
-                dirw = ((uint32_t)nx & 255u) | (((uint32_t)ny & 255u) << 8) | (((uint32_t)nz & 255u) << 16) | ((uint32_t)bias << 24);
-            } else {
-                dirw = s_dir[code];
-            }
+            const uint32_t dirw = s_dir[code];
             const int proj = __builtin_amdgcn_sdot4((int)xyz[p], (int)dirw, 0, false);
             const int tlo = (int)((e >> 23) & 63u), w = (int)(e >> 29);
             const bool inA = proj < tlo, inB = proj >= tlo + w + (w == 7 ? 64 : 0);
@@ -1067,46 +1049,9 @@ __global__ __launch_bounds__(kLabelBlock) void k_labels_pairs(const uint32_t *__
                 lab[p] = (uint32_t)s_hot[(e & 0xFFu) * kCellColours + (ci[p] & (kCellColours - 1u))];
             }
         }
-        if (KNOCK == 11) {
-            // probe (round 5): what ONE more random LDS read per pixel costs (the label is xor-ed with a bit that is always 0)
-#pragma unroll
-            for (int p = 0; p < 8; ++p) lab[p] ^= s_pair[(ci[p] >> 7) & (kPairWords - 1u)] >> 31 & (lab[p] >> 30);
-        }
-        if (KNOCK == 9) {
-            // probe (round 5, results wrong): the COST of a second-plane extension entry -- bitmap word, prefix count, rank, the
-            // entry and its plane test, all from LDS, for the pixels the first entry leaves to the gather -- and the GAIN it is
-            // simulated to have on the benchmark image (tools/pair_schemes.py: 2.9 of the 15.8 points of gathering pixels)
-            // (branch-free: every slot's chain of four dependent LDS reads is in flight beside the others'; as eight
-            // divergent branches the pass went from 158 to 237 us)
-            uint32_t word[8], pre[8], e2[8], d2[8];
-#pragma unroll
-            for (int p = 0; p < 8; ++p) { const uint32_t cell = ci[p] >> 9; word[p] = s_pair[(cell >> 5) & 1023u]; pre[p] = s_pair[1024u + ((cell >> 6) & 511u)]; }
-#pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                const uint32_t cell = ci[p] >> 9;
-                const uint32_t rank = (pre[p] & 0x1FFFu) + (uint32_t)__builtin_popcount(word[p] & ((1u << (cell & 31u)) - 1u));
-                e2[p] = s_pair[2048u + (rank & 8191u)];
-            }
-#pragma unroll
-            for (int p = 0; p < 8; ++p) d2[p] = s_dir[(e2[p] >> 16) & 127u];
-#pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                const int proj2 = __builtin_amdgcn_sdot4((int)xyz[p], (int)d2[p], 0, false);
-                const int tlo2 = (int)((e2[p] >> 23) & 63u), w2 = (int)(e2[p] >> 29);
-                const bool resolved = fine[p] && (proj2 < tlo2 || proj2 >= tlo2 + w2) && ((ci[p] * 2654435761u) >> 25) < 24u;    // 24 / 128 = 18.75 %
-                lab[p] = resolved ? (proj2 < tlo2 ? (e2[p] & 0xFFu) : ((e2[p] >> 8) & 0xFFu)) : lab[p];
-                fine[p] = fine[p] && !resolved;
-            }
-        }
 #pragma unroll
         for (int p = 0; p < 8; ++p)
-            if (fine[p]) {
-                if (KNOCK == 0 || KNOCK >= 6) lab[p] = (uint32_t)colour_labels[ci[p]];
-                else if (KNOCK == 1) lab[p] = (uint32_t)colour_labels[ci[p] & 0xFFFFu];
-                else if (KNOCK == 2) lab[p] = (uint32_t)reinterpret_cast<const uint8_t *>(s_pair)[ci[p] & 0x1FFFFu];
-                else if (KNOCK == 4) lab[p] = (uint32_t)__builtin_nontemporal_load(colour_labels + ci[p]);
-                else if (KNOCK == 5) lab[p] = (uint32_t)colour_labels[ci[p] >> 2];        // a table a quarter the size (2 bits per colour)
-            }
+            if (fine[p]) lab[p] = (uint32_t)colour_labels[ci[p]];
         if (pal) {
 #pragma unroll
             for (int p = 0; p < 8; ++p) lab[p] = s_pal[lab[p]];
@@ -1131,18 +1076,6 @@ hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_la
         const int aligned = ((reinterpret_cast<uintptr_t>(rgba) & 15u) == 0 &&
                              (reinterpret_cast<uintptr_t>(labels) & 15u) == 0) ? 1 : 0;
         const uint32_t *pairs = reinterpret_cast<const uint32_t *>(sub_table + kSubCells + kCells);
-#ifdef KMG_TOOLS
-        static const int knock = getenv("KMG_LABEL_KNOCK") ? atoi(getenv("KMG_LABEL_KNOCK")) : 0;       // tools build only
-#define KMG_LK(K) hipLaunchKernelGGL((k_labels_pairs<false, K>), dim3(grid), dim3(kLabelBlock), kLabelLdsPlain, st, rgba, n, \
-                                     (const uint8_t *)colour_labels, pairs, pal, k, labels, aligned, hot, tail_sums, tl)
-        if (knock == 1) KMG_LK(1); else if (knock == 2) KMG_LK(2); else if (knock == 3) KMG_LK(3); else if (knock == 4) KMG_LK(4);
-        else if (knock == 5) KMG_LK(5); else if (knock == 6) KMG_LK(6); else if (knock == 7) KMG_LK(7); else if (knock == 9) KMG_LK(9); else if (knock == 10) KMG_LK(10); else if (knock == 11) KMG_LK(11);
-        else if (knock == 8)
-            hipLaunchKernelGGL((k_labels_pairs<false, 8>), dim3(2u * grid), dim3(kLabelBlock), kLabelLdsPlain - sizeof(uint32_t) * kCells / 2u,
-                               st, rgba, n, (const uint8_t *)colour_labels, pairs, pal, k, labels, aligned, hot, tail_sums, tl);
-        else
-#undef KMG_LK
-#endif
         if (hot)
             hipLaunchKernelGGL(k_labels_pairs<true>, dim3(grid), dim3(kLabelBlock), kLabelLdsHot, st, rgba, n,
                                (const uint8_t *)colour_labels, pairs, pal, k, labels, aligned, hot, tail_sums, tl);
