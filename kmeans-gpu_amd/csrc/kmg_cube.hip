@@ -366,8 +366,6 @@ __device__ __forceinline__ bool dominated(const Model &mdl, const float4 cj, con
 // SUMS = false (output pass of find / reduce in replace mode): no image -- every colour of every cell counts
 // once, nothing is accumulated; agg, sub_agg, work and sums are unused.
 // flags bit 0: also write the 512 per-colour labels of single-candidate cells (debug / statistics).
-// flags bits 8..: knock-outs for tools/cube_knockout.py (results are then WRONG; never set by the library):
-//   9 no sums, 10 no colour scan, 11 every cell handled as a single-candidate cell, 12 no sub-cell stage
 // stats (optional, u64[6]): single-candidate cells, other cells, sub-cells decided by their bounds, sub-cells
 // scanned, candidates summed over the scanned sub-cells, cells with more than kMaxListed candidates
 // ------------------------------------------------------------------------------------------
@@ -512,7 +510,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
             }
         }
 
-        if (npop == 1u || KMG_KNOCK(flags, 0x800u)) {
+        if (npop == 1u) {
             // the whole cell belongs to `first`: sums from the cell table, no per-colour traffic
             if (sizeof(LabelT) == 1) {
                 if (lane == 0u) *pair_entry_ptr = pair_entry(first, first, 0u, 0u, 0u);
@@ -531,7 +529,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         }
         st_multi += 1;
         // ---- 2. sub-cell stage: list the candidates, bound each over each sub-cell ----
-        const bool listed = npop <= kMaxListed && !KMG_KNOCK(flags, 0x1000u);
+        const bool listed = npop <= kMaxListed;
         uint32_t my_cand = 0;                                       // lane p < npop: the p-th candidate
         unsigned long long br[4] = {0ull, 0ull, 0ull, 0ull};       // round r: bit 8 s + c = sub-cell s keeps candidate 8 r + c
         bool long_cell = false;
@@ -588,7 +586,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
             for (uint32_t r = 0; r < 4u; ++r)
                 if (r < rounds) br[r] = __ballot(lo[r] <= Us);
             if (lane < 4u) cw->br[lane] = lane == 0u ? br[0] : (lane == 1u ? br[1] : (lane == 2u ? br[2] : br[3]));
-        } else if (words <= 4u && npop <= kMaxLong && !KMG_KNOCK(flags, 0x1000u)) {
+        } else if (words <= 4u && npop <= kMaxLong) {
             // long list (rare on noise, the heavy cells of a photograph): long_list_stage
             long_cell = true;
 #pragma unroll
@@ -613,7 +611,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         const bool occupied_v = lane < 8u && (SUMS ? scnt != 0 : true);
         const bool decided_v = occupied_v && ((listed && __builtin_popcount(sm_v) == 1) || (long_cell && long_cnt == 1u));
         const uint32_t decided_set = (uint32_t)__ballot(decided_v);
-        const uint32_t scan_set = KMG_KNOCK(flags, 0x400u) ? 0u : (uint32_t)__ballot(occupied_v && !decided_v);
+        const uint32_t scan_set = (uint32_t)__ballot(occupied_v && !decided_v);
         // label of a decided sub-cell, at lane s
         uint32_t X_v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((sm_v ? (uint32_t)__builtin_ctz(sm_v) : 0u)) << 2), (int)my_cand);
         if (long_cell) X_v = long_one;
@@ -631,7 +629,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
             }
             // its sums: lane 4 s + j holds sum j of sub-cell s
             const uint32_t Xs = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane >> 2) & 7u) << 2), (int)X_v);
-            if (SUMS && !KMG_KNOCK(flags, 0x200u) && lane < 32u && ((decided_set >> (lane >> 2)) & 1u))
+            if (SUMS && lane < 32u && ((decided_set >> (lane >> 2)) & 1u))
                 atomicAdd(bins + 4ull * Xs + (lane & 3u), (unsigned long long)sagg);
         }
         if (sizeof(LabelT) != 1) {
@@ -667,7 +665,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
 // ------------------------------------------------------------------------------------------
 // k_cube_scan.  LDS: [centroids kpad x 16 B][bins repl x (k x 32 + 32) B (SUMS)][candidates 4 waves x 32 x 16 B]
 //                    [labels 4 waves x 512]
-// flags bits: 9 no sums, 13 no label stores
 // ------------------------------------------------------------------------------------------
 // (eight waves per workgroup: they share the centroid table and FOUR copies of the bins in the LDS two workgroups of four waves
 // spent on two copies each -- the same waves per CU, half the same-address atomics per copy)
@@ -785,10 +782,8 @@ __global__ __launch_bounds__(kScanBlock) void k_cube_scan(const uint32_t *__rest
             scan_set &= scan_set - 1u;                                                                           \
             const uint32_t c0_ = cell * kCellColours + (X##_s0 & 7u) * 64u + lane;                               \
             const uint32_t c1_ = cell * kCellColours + (X##_s1 & 7u) * 64u + lane;                               \
-            /* (knock-out, tools only, results wrong: flag bit 20 = the Lab rows from a cache-resident 64 KiB window) */ \
-            const uint32_t km_ = KMG_KNOCK(flags, 0x100000u) ? 0xFFFu : 0xFFFFFFFFu;                                     \
-            X##_v0 = lab_table[c0_ & km_];                                                                       \
-            X##_v1 = lab_table[c1_ & km_];                          /* s1 == 8: sub-cell 0 again, unused */      \
+            X##_v0 = lab_table[c0_];                                                                             \
+            X##_v1 = lab_table[c1_];                                /* s1 == 8: sub-cell 0 again, unused */      \
             if (SUMS) { X##_c0 = hist[c0_]; X##_c1 = hist[c1_]; }                                                \
         } while (0)
         KMG_REQUEST_COLOURS(A);
@@ -915,7 +910,7 @@ __global__ __launch_bounds__(kScanBlock) void k_cube_scan(const uint32_t *__rest
                         if (__builtin_popcountll(__ballot(counts && ix == X1)) > __builtin_popcountll(occm & ~other)) R = X1;
                     }
                     st = other ? (uint32_t)kSubMixed : X0;
-                    if (SUMS && !KMG_KNOCK(flags, 0x200u)) {
+                    if (SUMS) {
                         if ((lane >> 2) == s) atomicAdd(bins + 4ull * R + (lane & 3u), (unsigned long long)sagg);
                         if (other && counts && ix != R) {
                             const long long m = (long long)cnt;
@@ -944,7 +939,7 @@ __global__ __launch_bounds__(kScanBlock) void k_cube_scan(const uint32_t *__rest
 #undef KMG_REQUEST_COLOURS
         // the labels of the scanned sub-cells: lane l owns the colours 8 l .. 8 l + 7 (sub-cell l >> 3), one store
         __builtin_amdgcn_wave_barrier();
-        if (!KMG_KNOCK(flags, 0x2000u) && ((label_set >> (lane >> 3)) & 1u)) {
+        if ((label_set >> (lane >> 3)) & 1u) {
             if (sizeof(LabelT) == 1)
                 *reinterpret_cast<uint2 *>(cell_labels + lane * 8u) = *reinterpret_cast<const uint2 *>(s_lbl + lane * 8u);
             else
@@ -991,7 +986,7 @@ __global__ __launch_bounds__(kBlock) void k_cube_pairs(const uint32_t *__restric
             uint32_t idx[8];
 #pragma unroll
             for (uint32_t q = 0; q < 4u; ++q) { idx[q] = (lv.x >> (8u * q)) & 0xFFu; idx[4u + q] = (lv.y >> (8u * q)) & 0xFFu; }
-            const uint32_t e = KMG_KNOCK(flags, 0x100u) ? pair_entry(idx[0], idx[0], 0u, 0u, 0u) : cell_pair_entry(idx, occ, lane);
+            const uint32_t e = cell_pair_entry(idx, occ, lane);
             if (lane == 0u) *pair_entry_ptr = e;
         } else {
             // cell summary = merge of the eight sub-cell summaries (k_cube_stage wrote the decided / empty ones,
@@ -1043,8 +1038,7 @@ __global__ __launch_bounds__(kBlock) void k_cube_pairs(const uint32_t *__restric
 // for every colour, and with |key - K| <= 560u K for the scan's keys (kmg_math.h) key_j > key_i (1 + 2^-12) -- j is neither
 // the arg-min nor within the tie threshold of it, exactly the property the interval test guarantees for what IT removes.
 // Skipped when a centroid lies outside |L|, |a|, |b| <= 1024 (the error budget above assumes colour-like magnitudes).
-// Honoured flags: bit 0 (labels of uniform cells too), kCubeNoEntries; knock-outs (tools, results WRONG): 9 no sums in the
-// scan, 10 no colour scan, 14 no entries phase, 15 no dominance test (that one is exact).
+// Honoured flags: bit 0 (labels of uniform cells too), kCubeNoEntries.
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kSmallMaxK = kCubeSmallMaxK;
 constexpr uint32_t kSmallRepl = 16;
@@ -1174,7 +1168,7 @@ __global__ __launch_bounds__(kSmallBlock) __attribute__((amdgpu_waves_per_eu(4, 
         if (!(fabsf(c.x) <= 1024.0f && fabsf(c.y) <= 1024.0f && fabsf(c.z) <= 1024.0f)) s_count[2] = 1u;
     }
     __syncthreads();
-    const bool dominance = sub_affine != nullptr && s_count[2] == 0u && !KMG_KNOCK(flags, 0x8000u);
+    const bool dominance = sub_affine != nullptr && s_count[2] == 0u;
 
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     unsigned long long *my_bins = bins + (uint64_t)(lane & (kSmallRepl - 1u)) * bin_stride;
@@ -1374,8 +1368,8 @@ __global__ __launch_bounds__(kSmallBlock) __attribute__((amdgpu_waves_per_eu(4, 
             }
         }
         __syncthreads();
-        const uint32_t n_ent = KMG_KNOCK(flags, 0x400u) ? 0u : s_count[0];
-        const uint32_t n_pend = KMG_KNOCK(flags, 0x4000u) ? 0u : s_count[1];
+        const uint32_t n_ent = s_count[0];
+        const uint32_t n_pend = s_count[1];
 
         // ---- 2. scan: the undecided sub-cells of the workgroup, pair p to wave p % 8, one colour per lane ----
         // (its occupancy bytes for phase 3 are requested now: the scan hides their latency)
@@ -1466,7 +1460,7 @@ __global__ __launch_bounds__(kSmallBlock) __attribute__((amdgpu_waves_per_eu(4, 
                 // label R, a colour with another label moves its own contribution from R to that label
                 auto finish = [&](uint32_t e, uint32_t ix, uint32_t cnt, long long g, float vL, float va, float vb) {
                     s_lbl[(e >> 3) * kCellColours + (e & 7u) * 64u + lane] = (uint8_t)ix;
-                    if (!SUMS || KMG_KNOCK(flags, 0x200u)) return;
+                    if (!SUMS) return;
                     const bool counts = cnt != 0u;
                     const unsigned long long occm = __ballot(counts);
                     if (!occm) return;
@@ -2126,7 +2120,6 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
     const uint32_t kpad = (k + 63u) & ~63u;
     const bool with_sums = hist != nullptr;
     const uint32_t repl = with_sums ? cube_replicas(k) : 1u;
-    if (const char *e = KMG_TOOLS_ENV("KMG_CUBE_FLAGS")) flags |= (uint32_t)strtoul(e, nullptr, 0) & 0xF0FF00u;   // (tools build only)
     const size_t lds_stage = sizeof(float4) * kpad + (with_sums ? sizeof(unsigned long long) * 4ull * k : 0) +
                              sizeof(uint32_t) * (kBlock / 64) * kMaxListed + sizeof(unsigned long long) * (kBlock / 64) * (kpad / 64u) +
                              (k <= 256 ? (kBlock / 64) * (32u * sizeof(unsigned long long) + kMaxLong * sizeof(uint16_t)) : 0u);
@@ -2211,9 +2204,8 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
     do {                                                                                                                    \
         hipLaunchKernelGGL((k_cube_stage<T, S>), dim3(g_stage), dim3(kBlock), lds_stage, st, agg, sub_agg, work, bounds,     \
                            sub_bounds, cent, k, masks, cw, (T *)colour_labels, sub_table, sums, n_rows, flags, stats);      \
-        if (!KMG_KNOCK(flags, 0xC00u))                                                                                      \
-            hipLaunchKernelGGL((k_cube_scan<T, S>), dim3(g_scan), dim3(kScanBlock), lds_scan, st, hist, sub_agg, work, cent, k, \
-                               lab_table, masks, cw, (T *)colour_labels, sub_table, sums, n_rows, repl, flags);             \
+        hipLaunchKernelGGL((k_cube_scan<T, S>), dim3(g_scan), dim3(kScanBlock), lds_scan, st, hist, sub_agg, work, cent, k,   \
+                           lab_table, masks, cw, (T *)colour_labels, sub_table, sums, n_rows, repl, flags);                 \
         hipLaunchKernelGGL((k_cube_pairs<T>), dim3((flags & kCubeNoEntries) ? 1u : g_pairs), dim3(kBlock), 0, st, work,   \
                            S ? 1 : 0, occ_bits, (const T *)colour_labels, sub_table, flags, sums, k, tl);                   \
     } while (0)

@@ -1297,7 +1297,7 @@ __global__ __launch_bounds__(kBlock) void k_dither_pruned(const uint32_t *__rest
                                                           uint32_t row0, const Centroid *__restrict__ cent, uint32_t k,
                                                           const float *__restrict__ lut, const uint32_t *__restrict__ pal,
                                                           float threshold, const uint64_t *__restrict__ masks,
-                                                          uint32_t *__restrict__ out, int aligned, uint32_t knock)
+                                                          uint32_t *__restrict__ out, int aligned)
 {
     extern __shared__ float4 smem4[];
     const uint32_t kpad = (k + 3u) & ~3u;
@@ -1329,7 +1329,7 @@ __global__ __launch_bounds__(kBlock) void k_dither_pruned(const uint32_t *__rest
             const uint32_t cell = (((px[q] >> 3) & 31u) << 10) | (((px[q] >> 11) & 31u) << 5) | ((px[q] >> 19) & 31u);
             slot[q] = cell * 16u + bi;
 #pragma unroll
-            for (int u = 0; u < UP; ++u) m0[q][u] = KMG_KNOCK(knock, 1u) ? (0x0000100000100001ull << (px[q] & 7u)) : masks[(uint64_t)slot[q] * words + u];   // gathers in flight during the Lab conversion
+            for (int u = 0; u < UP; ++u) m0[q][u] = masks[(uint64_t)slot[q] * words + u];   // gathers in flight during the Lab conversion
             gx += 1;
             if (gx == w) { gx = 0; gy += 1; }
         }
@@ -1337,8 +1337,7 @@ __global__ __launch_bounds__(kBlock) void k_dither_pruned(const uint32_t *__rest
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float L, a, b;
-            if KMG_KNOCK(knock, 4u) { L = s_lut[px[q] & 255u]; a = s_lut[(px[q] >> 8) & 255u]; b = s_lut[(px[q] >> 16) & 255u]; }
-            else px_to_lab(s_lut, px[q], L, a, b);
+            px_to_lab(s_lut, px[q], L, a, b);
             const float off = s_off[slot[q] & 15u];
             L = L + off; a = a + off; b = b + off;                   // mix_colors.wgsl:72
             // (the weights only order the candidates: hardware reciprocals, near-ties are settled by the literal distance)
@@ -1356,7 +1355,7 @@ __global__ __launch_bounds__(kBlock) void k_dither_pruned(const uint32_t *__rest
                 }
             };
 #pragma unroll
-            for (int u = 0; u < UP; ++u) scan_word(KMG_KNOCK(knock, 2u) ? 0ull : m0[q][u], (uint32_t)u);
+            for (int u = 0; u < UP; ++u) scan_word(m0[q][u], (uint32_t)u);
             if (WORDS == 0)
                 for (uint32_t wd = 1; wd < words; ++wd) scan_word(masks[(uint64_t)slot[q] * words + wd], wd);
             if (kLiteralArgmin && second <= tie_threshold(best)) {
@@ -1381,7 +1380,7 @@ __global__ __launch_bounds__(kBlock) void k_dither_pruned(const uint32_t *__rest
                     for (uint32_t wd = 1; wd < words; ++wd) rescan_word(masks[(uint64_t)slot[q] * words + wd], wd);
                 idx = li;
             }
-            res[q] = KMG_KNOCK(knock, 8u) ? idx : pal[idx];
+            res[q] = pal[idx];
         }
         store4_stream(out, i0, n, aligned != 0, res);
     }
@@ -1572,13 +1571,11 @@ hipError_t launch_dither_pruned(const uint32_t *rgba, uint32_t w, uint32_t rows,
     const size_t lds = sizeof(float4) * kpad + (256 + 16) * sizeof(float);
     const int aligned = ((reinterpret_cast<uintptr_t>(rgba) & 15u) == 0 &&
                          (reinterpret_cast<uintptr_t>(out) & 15u) == 0) ? 1 : 0;
-    uint32_t knock = 0;
-    if (const char *e = KMG_TOOLS_ENV("KMG_DITHER_KNOCK")) knock = (uint32_t)atoi(e);      // (tools build only)
 #define KMG_DP(W) hipLaunchKernelGGL(k_dither_pruned<W>, dim3(grid), dim3(kBlock), lds, st, rgba, w, n, row0, cent, k, lut, \
-                                     pal, threshold, masks, out, aligned, knock)
+                                     pal, threshold, masks, out, aligned)
     const uint32_t n_words = (k + 63u) / 64u;
     static const bool sorted = tools_env_int(KMG_TOOLS_ENV("KMG_DITHER_SORT"), 1) != 0;
-    if (sorted && !knock && n_words == 1u) {
+    if (sorted && n_words == 1u) {
         // the pixels of a tile sorted by candidate-list length (k_dither_sorted): 8192^2, 64-entry palette 0.95 -> 0.88 ms.
         // With more mask words the records outgrow the LDS a well-occupied CU can give them (k = 256, 2 pixels per
         // thread: 1.56 -> 1.72 ms); k <= 256 takes the byte lists of kmg_lists.hip.

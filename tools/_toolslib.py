@@ -1,4 +1,4 @@
-"""Tools that flip tuning switches or knock-outs (KMG_LABEL_KNOCK, KMG_CUBE_FLAGS, KMG_DITHER_KNOCK, KMG_ASSIGN_PPT, KMG_HOT_CELLS,
+"""Tools that flip tuning switches or knock-outs (KMG_ASSIGN_PPT, KMG_HOT_CELLS,
 KMG_*_GRID, KMG_CUBE_REPL, KMG_CUBE_SMALL, KMG_DITHER_SORT, KMG_DITHER_STATS) need the TOOLS build of the library: the product
 library does not read them.  use_tools_library() builds lib/libkmeans_hip_tools.so when it is missing or stale (make tools) and
 points the binding at it (KMG_LIBRARY) -- call it before importing kmeans_gpu_amd, or pass its result in a child's environment."""
