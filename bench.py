@@ -243,7 +243,7 @@ CFG2_WIDTH, CFG2_HEIGHT, CFG2_K = 4096, 4096, 16
 VALU_LANE_OPS_PEAK = 78.6e12             # fp32 vector lane-operations per second (157.3 TF/s counts an FMA as two)
 
 
-def cfg2_timing(proc, stream, steps=20, strategies=("table", "scan"), profile_kernels=True):
+def cfg2_timing(proc, stream, steps=20, strategies=("table", "scan"), profile_kernels=True, default_strategy="auto"):
     """BASELINE config 2: synthetic 4096 x 4096 (seed 0x5EED0002), k = 16, assign + update only -- the configuration of
     tests/test_gpu_table.py::test_cfg2_full_size_assign_update (centroids = shader Lab of the pixels at j * floor(N/k)).
     One step = one assignment with its label map and sums + the centroid update.  Both strategies are timed (the library's
@@ -264,15 +264,14 @@ def cfg2_timing(proc, stream, steps=20, strategies=("table", "scan"), profile_ke
     cent = np.ones((k, 4), np.float32)
     cent[:, :3] = lab.cpu().numpy()
     out = {}
-    old = os.environ.get("KMG_STRATEGY")
     try:
-        os.environ.pop("KMG_STRATEGY", None)
+        kg.set_strategy("auto")
         s = kg.Lloyd(proc, k)
         s.set_centroids(cent, stream)
         out["cfg2_strategy_auto"] = s.prepare(rgba.data_ptr(), n, True, stream)
         s.close()
         for strategy in strategies:
-            os.environ["KMG_STRATEGY"] = {"scan": "brute", "table": "table"}[strategy]
+            kg.set_strategy(strategy)
             s = kg.Lloyd(proc, k)
             s.set_centroids(cent, stream)
             torch.cuda.synchronize()
@@ -300,10 +299,7 @@ def cfg2_timing(proc, stream, steps=20, strategies=("table", "scan"), profile_ke
                 s.profile(False)
             s.close()
     finally:
-        if old is None:
-            os.environ.pop("KMG_STRATEGY", None)
-        else:
-            os.environ["KMG_STRATEGY"] = old
+        kg.set_strategy(default_strategy)
     auto = out["cfg2_strategy_auto"]
     if f"cfg2_{auto}_ms_per_step" in out:
         out["cfg2_ms_per_step"] = out[f"cfg2_{auto}_ms_per_step"]
@@ -483,7 +479,7 @@ def output_pass_timing(proc, rgba, n_pixels, stream, sh=None, steps=3, prep_ms=N
         if n_pixels == WIDTH * ROWS_PER_GPU:
             extra.update(cfg4_native_batch(k3, WIDTH, n_pixels // WIDTH))
         extra.update(reduce_end_to_end(proc, rgba, WIDTH, n_pixels // WIDTH, k3))
-        extra.update(cfg2_timing(proc, stream, steps=max(steps, 2) * 5))
+        extra.update(cfg2_timing(proc, stream, steps=max(steps, 2) * 5, default_strategy=kg._default_strategy))
         extra.update(default_call_timing())
     except Exception as e:      # the extras must never break the benchmark line (tests/test_gpu_bench.py fails on it instead)
         import traceback
@@ -671,8 +667,7 @@ def main():
     n_local = WIDTH * rows
     height = rows * world
     seed = synth.SEED_CFG3
-    if args.strategy != "auto":
-        os.environ["KMG_STRATEGY"] = {"scan": "brute", "table": "table"}[args.strategy]
+    kg.set_strategy(args.strategy)                            # (kmg_options.strategy of every processor this run creates)
 
     # ---- the group: ImageProcessor::new over this job's devices (include/kmeans_hip.h kmg_group_*) ----
     with _StdoutToStderr():
@@ -693,7 +688,6 @@ def main():
     if args.only == "cfg2":
         st = torch.cuda.current_stream().cuda_stream
         which = ("table", "scan") if args.strategy == "auto" else (args.strategy,)
-        os.environ.pop("KMG_STRATEGY", None)
         res = cfg2_timing(proc, st, steps=args.steps, strategies=which, profile_kernels=not args.no_extras)
         group.close()
         print(json.dumps(res), flush=True)

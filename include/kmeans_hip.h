@@ -62,7 +62,19 @@ typedef struct kmg_options {
     uint32_t max_iterations;  /* MAX_ITERATION = 128 (core/src/modules.rs:765)                  */
     uint32_t check_period;    /* MAX_ITERATION_BEFORE_CONVERGENCE_CHECK = 8 (modules.rs:766)    */
     float    convergence;     /* ColorSpace::Lab.convergence() = 1.0 (core/src/lib.rs:189-194)  */
+    int32_t  strategy;        /* KMG_STRATEGY_*: 0 = the library's cost models pick per call (default)                     */
 } kmg_options;
+
+/* kmg_options.strategy / kmg_processor_set_strategy: which of the library's interchangeable strategies a call takes.  Results are
+ * IDENTICAL either way (that is what the tests use the switch for); only the time differs.  The low two bits choose between the
+ * per-pixel scans and the colour-table / candidate-list passes for every decision the cost models otherwise make (Lloyd
+ * iteration, initialisation, output passes); KMG_STRATEGY_MASK_WORDS sends the pruned dither / meld passes of every k through
+ * the mask words per (RGB cell, Bayer index) instead of the byte lists over Lab cells (the path of k > 512).  (An options
+ * struct of the previous size -- without this field -- is accepted and means KMG_STRATEGY_AUTO.)                                */
+#define KMG_STRATEGY_AUTO       0
+#define KMG_STRATEGY_SCAN       1
+#define KMG_STRATEGY_TABLE      2
+#define KMG_STRATEGY_MASK_WORDS 4
 
 typedef struct kmg_processor kmg_processor;
 typedef struct kmg_lloyd kmg_lloyd;
@@ -76,6 +88,9 @@ KMG_API void kmg_default_options(kmg_options *opt);
 KMG_API int kmg_processor_create(kmg_processor **out);
 KMG_API int kmg_processor_create_ex(const kmg_options *opt, kmg_processor **out);
 KMG_API void kmg_processor_destroy(kmg_processor *p);
+/* changes kmg_options.strategy of a live processor (tests and tuning: one processor, both strategies); calls that are
+ * already running keep the strategy they started with                                                                        */
+KMG_API int kmg_processor_set_strategy(kmg_processor *p, int strategy);
 /* Page-locked host memory for images that cross the boundary often (a frame loop): a result buffer from kmg_host_alloc has
  * its pages resident and is copied to by DMA directly -- kmg_reduce of 8192 x 8192 into a fresh pageable buffer spends 30-50 ms
  * in the caller's page faults, 10 ms into one of these.  Plain memory otherwise; release with kmg_host_free.  (No counterpart
@@ -178,12 +193,17 @@ KMG_API int kmg_lloyd_assign_accumulate(kmg_lloyd *s, const uint8_t *d_rgba, uin
  * sums) once.  Subsequent assign passes on the SAME (d_rgba, n_pixels) then iterate over distinct
  * colours with conservatively pruned candidate sets and materialise labels with one gather pass;
  * labels, sums and centroids are bit-identical to the per-pixel scan.  kmg_lloyd_run binds by
- * itself when its cost model says it pays (env KMG_STRATEGY=brute|table overrides).  The caller
+ * itself when its cost model says it pays (kmg_options.strategy overrides).  The caller
  * must not modify the pixel buffer while it is bound.  kmg_lloyd_init_centroids / _init_step (j = 1)
  * start a new problem: they drop any earlier binding of the buffer (and bind it afresh when the
  * initialisation itself runs over the colour table).                                             */
 KMG_API int kmg_lloyd_bind_image(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n_pixels, void *stream);
 KMG_API int kmg_lloyd_unbind_image(kmg_lloyd *s);
+/* Tuning support: what the binding found in the image -- out[0] = occupied cells of the 32^3 grid over the colour cube (the cube
+ * pass's work list), out[1] = hot cells (the few cells that hold a tenth or more of the pixels: a photograph's dark corner; 0
+ * on noise).  These are what the cost model looks at AFTER a binding (kmg_lloyd_prepare): a sparse image has a cheaper cube pass
+ * than the noise the model was fitted on, an image with hot cells a dearer per-pixel scan (near-tie repairs).                  */
+KMG_API int kmg_debug_bound_image(kmg_lloyd *s, uint64_t out[2]);
 /* One-time preparation of (d_rgba, n_pixels) for repeated assign passes: applies the library's cost
  * model (want_labels = whether the passes will materialise labels) and binds the image if the colour
  * table pays.  *strategy (optional) receives 0 = per-pixel scan, 1 = colour table.              */

@@ -5,12 +5,9 @@
 
 // Same model for the replace-mode output pass (no histogram: every cell is labelled; scratch from the processor's
 // blocks).
-static bool replace_table_pays(uint64_t n, uint32_t k)
+static bool replace_table_pays(const kmg_processor *p, uint64_t n, uint32_t k)
 {
-    if (const char *e = getenv("KMG_STRATEGY")) {
-        if (!strcmp(e, "brute")) return false;
-        if (!strcmp(e, "table")) return true;
-    }
+    if (const int f = forced_strategy(p)) return f > 0;
     const double N = (double)n;
     const double brute = N * (8.1e-12 + 2.45e-13 * k);
     const double table = 9.0e-5 + 1.85e-7 * k + N * (k <= 256 ? 1.8e-12 + 2.0e-15 * k : 6.6e-12);
@@ -22,12 +19,9 @@ static bool replace_table_pays(uint64_t n, uint32_t k)
 // random palettes (tools/dither_crossover.py -> profiles/r03_dither_crossover.txt): the scan costs 6.5 + 0.275 k ps per pixel,
 // the list pass 6.8 + 0.02 k ps per pixel after ~45 us for the lists and their launch; with k >= 128 the scan's own latency
 // (one wave walks all k) makes the lists win on any image.
-static bool dither_pruning_pays(uint64_t n, uint32_t k)
+static bool dither_pruning_pays(const kmg_processor *p, uint64_t n, uint32_t k)
 {
-    if (const char *e = getenv("KMG_STRATEGY")) {
-        if (!strcmp(e, "brute")) return false;
-        if (!strcmp(e, "table")) return true;
-    }
+    if (const int f = forced_strategy(p)) return f > 0;
     if (k > kLabListMaxK) return n >= 4000000ull;          // mask words: 0.55 ms of masks at k = 512
     if (k >= 128u) return n >= 16384ull;
     return (double)n * (0.255 * k - 0.3) > 45.0e6;          // ps saved per pixel x pixels > 45 us
@@ -35,12 +29,9 @@ static bool dither_pruning_pays(uint64_t n, uint32_t k)
 
 // Meld output pass: ordered scan of all k centroids per pixel, or of the candidates of the pixel's colour
 // cell only (k_meld_candidates: ~0.03 ms per 64 centroids; tools/dither_probe.py).
-static bool meld_pruning_pays(uint64_t n, uint32_t k)
+static bool meld_pruning_pays(const kmg_processor *p, uint64_t n, uint32_t k)
 {
-    if (const char *e = getenv("KMG_STRATEGY")) {
-        if (!strcmp(e, "brute")) return false;
-        if (!strcmp(e, "table")) return true;
-    }
+    if (const int f = forced_strategy(p)) return f > 0;
     return k >= 16 && n >= (1ull << 20);
 }
 
@@ -48,12 +39,10 @@ static bool meld_pruning_pays(uint64_t n, uint32_t k)
 // table: over all 2^24 colours x 16 Bayer offsets, the arg-min over the candidates must equal the
 // brute-force arg-min.  *violations must come back 0.
 // Which pruned dither / meld pass?  k <= 512: byte lists per cell of a grid over Lab (kmg_lists.hip); larger k: mask words per (RGB
-// cell, Bayer index) (kmg_table.hip).  KMG_DITHER_LISTS = 0 sends every k to the mask words, 1 (tools) keeps k <= 64 there.
-static bool dither_takes_lists(uint32_t k)
+// cell, Bayer index) (kmg_table.hip).  KMG_STRATEGY_MASK_WORDS (kmg_options.strategy) sends every k to the mask words.
+static bool dither_takes_lists(const kmg_processor *p, uint32_t k)
 {
-    const char *e = getenv("KMG_DITHER_LISTS");                     // (read per call: the tests switch it)
-    const int mode = e ? atoi(e) : 2;
-    return mode != 0 && k <= kLabListMaxK && (k > 64u || mode == 2);
+    return !(p->strategy.load(std::memory_order_relaxed) & KMG_STRATEGY_MASK_WORDS) && k <= kLabListMaxK;
 }
 
 extern "C" int kmg_debug_check_dither_masks(kmg_processor *p, const float *c4, uint32_t k, uint64_t *violations, void *stream)
@@ -211,16 +200,16 @@ try {
 
     // which route (by the number of pixels the plan is made for), and how much scratch it needs: one block per plan
     const uint64_t n_px = n_pixels_hint;
-    const bool meld_masks_pay = mode == KMG_MODE_MELD && k >= 2 && meld_pruning_pays(n_px, k);
-    const bool replace_table = mode != KMG_MODE_MELD && !dither && replace_table_pays(n_px, k);
-    const bool dither_pruned = mode != KMG_MODE_MELD && dither && dither_pruning_pays(n_px, k);
+    const bool meld_masks_pay = mode == KMG_MODE_MELD && k >= 2 && meld_pruning_pays(p, n_px, k);
+    const bool replace_table = mode != KMG_MODE_MELD && !dither && replace_table_pays(p, n_px, k);
+    const bool dither_pruned = mode != KMG_MODE_MELD && dither && dither_pruning_pays(p, n_px, k);
     const size_t tables_bytes = sizeof(Centroid) * k + sizeof(uint32_t) * (k + 1);
     const size_t sub_bytes = sizeof(uint16_t) * (kSubCells + kCells) + sizeof(uint32_t) * kCells;
     const size_t labels_bytes = (size_t)(k <= 256 ? 1 : 2) << 24;
     const size_t masks_bytes = sizeof(uint64_t) * (size_t)kCells * mask_words(k) * (dither_pruned ? 16u : 1u);
     size_t need = ArenaGuard::padded(tables_bytes);
-    const bool dither_lists = dither_pruned && dither_takes_lists(k);      // byte lists over Lab cells instead of mask words
-    const bool meld_lists = meld_masks_pay && dither_takes_lists(k);       // the same for the meld pass's two closest
+    const bool dither_lists = dither_pruned && dither_takes_lists(p, k);      // byte lists over Lab cells instead of mask words
+    const bool meld_lists = meld_masks_pay && dither_takes_lists(p, k);       // the same for the meld pass's two closest
     if ((meld_masks_pay && !meld_lists) || (dither_pruned && !dither_lists)) need += ArenaGuard::padded(masks_bytes);
     if (dither_lists || meld_lists) need += ArenaGuard::padded(lab_list_bytes(k));
     if (replace_table) need += ArenaGuard::padded(labels_bytes) + ArenaGuard::padded(sub_bytes) + ArenaGuard::padded(cube_masks_bytes(k)) +

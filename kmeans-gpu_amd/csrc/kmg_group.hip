@@ -13,6 +13,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>          // types and prototypes only: every call goes through the table below
+#include <stddef.h>
 #include <string.h>
 
 #include <algorithm>
@@ -474,8 +475,12 @@ static int group_create_impl(const kmg_group_options *opt, const uint8_t *id, ui
     kmg_group_options o;
     kmg_default_group_options(&o);
     if (opt) {
-        if (opt->struct_size != sizeof(kmg_group_options)) return fail(KMG_ERR_INVALID_ARGUMENT, "kmg_group_options.struct_size mismatch");
-        o = *opt;
+        // (kmg_options, the last member, grew by `strategy` in round 6: a caller compiled against the previous header passes the old size)
+        constexpr uint32_t kOldSize = (uint32_t)(offsetof(kmg_group_options, processor) + offsetof(kmg_options, strategy));
+        if (opt->struct_size != sizeof(kmg_group_options) && opt->struct_size != kOldSize)
+            return fail(KMG_ERR_INVALID_ARGUMENT, "kmg_group_options.struct_size mismatch");
+        memcpy(&o, opt, opt->struct_size);
+        o.struct_size = sizeof(kmg_group_options);
     }
     if (o.n_devices > KMG_MAX_DEVICES) return fail(KMG_ERR_INVALID_ARGUMENT, "more than KMG_MAX_DEVICES = %d devices", KMG_MAX_DEVICES);
     int count = 0;

@@ -3,6 +3,8 @@
 // passes and the loop of ChooseCentroidModule::compute (modules.rs:763-840), with their test and statistics support.  Every
 // per-pixel and per-colour step is a kernel launch.
 
+#include <math.h>
+
 #include "kmg_state.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -30,40 +32,63 @@ static inline void *carve(void *base, size_t &off, size_t bytes)
     return r;
 }
 
-// Cost model (seconds per iteration on MI355X; constants fitted to tools/strategy_sweep.py, refitted in round 2 --
-// the cube pass got cheaper, the per-pixel scan tracks the runner-up key for the literal arg-min):
-//   per-pixel scan : 1.4e-5 + 3.3e-7 k + n * (6.8e-12 + 2.45e-13 k)     (the k term: partial-sum slab and its reduction)
-//   colour table   : 8.0e-5 + 8.5e-8 k                       cube pass (independent of n; k <= 32: 4.4e-5 + 3.5e-7 k, one launch; k > 256: 8.6e-5 + 2.3e-7 k)
-//                    + n * (1.8e-12 + 2.0e-15 k)              label pass, k <= 256 (6.7e-12 for u16 labels)
-//                    + bind_seconds(n) / 16                   one-off histogram + cell sums, spread over ~16 passes
-// one-off cost of binding an image: partitioned histogram (n >= 2^21) or one global atomic per pixel, + cell sums
+// Cost model of one Lloyd iteration (seconds on MI355X), refitted in round 6 to tools/costmodel_sweep.py
+// (profiles/r06_costmodel_sweep.txt: noise, Gaussian blobs and the tiled photograph, 2^18 .. 2^24 pixels, k = 8 .. 256, the
+// one-launch cube pass).  It is asked TWICE: before anything is known about the image (`facts` = NULL) it answers with the
+// cheapest cube pass an image of this size can have -- "is a binding worth trying" -- and after the binding, whose histogram
+// says how many of the 32^3 cells the image occupies and whether it has hot cells, it answers for THIS image (the binding
+// is paid by then: it no longer counts).  Rounds 2-5 asked once, blind, and leaned towards the photograph: a 1 Mpx noise
+// image at k = 256 got the slower strategy by 37 %.
+//   per-pixel scan : 12 us (k < 16: 18) + 0.04 k us + n (6 + 0.36 k - 0.00052 k^2) ps   k <= 256 (above: 1.1e-5 + 9.3e-8 k + n (7.5 + 0.245 k) ps);
+//                    x 1.3 for k >= 64 on an image with hot cells (crowded centroids: more near-tie repairs)
+//   cube pass      : k <= 32 (one launch)            4.3 + 0.15 k + (22 + 0.35 k) occ / 32768 us, + 10 us with hot cells
+//                    32 < k <= 256, no hot cells     48.5 + 0.07 k us (k_cube_one: noise and blobs alike, whatever they occupy)
+//                    32 < k <= 256, hot cells        26 + 0.2 k us (three launches; 1.9 K .. 12 K occupied cells alike)
+//                    k > 256                         86 + 0.23 k us
+//   label pass     : k <= 256: 3 us + 4.4 ps per pixel up to 2^22 pixels (one 1024-thread workgroup per CU stages the 128 KiB pair
+//                    table whatever the image), 2.2 ps per pixel beyond; u16 labels (k > 256): 6.7 ps per pixel
+//   binding        : bind_seconds(n) / 16            one-off histogram + cell sums, spread over ~16 passes
+struct ImageFacts { uint32_t occupied, hot; };
+
 static double bind_seconds(uint64_t n)
 {
     const double N = (double)n;
     return n >= (1ull << 21) ? 2.5e-4 + N * 4.1e-12 : 2.0e-4 + N * 4.0e-11;
 }
 
-static bool table_pays(uint64_t n, uint32_t k, bool labels)
+static double scan_seconds(uint64_t n, uint32_t k, bool hot)
 {
-    if (const char *e = getenv("KMG_STRATEGY")) {
-        if (!strcmp(e, "brute")) return false;
-        if (!strcmp(e, "table")) return true;
+    const double N = (double)n, K = (double)k;
+    const double t = k <= 256u ? (k < 16u ? 1.8e-5 : 1.2e-5) + 4.0e-8 * K + N * (6.0e-12 + 3.6e-13 * K - 5.2e-16 * K * K)
+                               : 1.1e-5 + 9.3e-8 * K + N * (7.5e-12 + 2.45e-13 * K);
+    return t * ((hot && k >= 64u) ? 1.3 : 1.0);
+}
+
+static double cube_seconds(uint32_t k, const ImageFacts *facts)
+{
+    const double K = (double)k;
+    if (k > 256u) return 8.6e-5 + 2.3e-7 * K;
+    if (k <= kCubeSmallMaxK) {
+        // (unknown image: a sparse one -- a third of the cells)
+        const double occ = facts ? (double)facts->occupied / (double)kCells : 0.33;
+        return 4.3e-6 + 1.5e-7 * K + (2.2e-5 + 3.5e-7 * K) * occ + ((facts && facts->hot) ? 1.0e-5 : 0.0);
     }
+    const double one_launch = 4.85e-5 + 7.0e-8 * K, three_launches = 2.6e-5 + 2.0e-7 * K;
+    if (!facts) return one_launch < three_launches ? one_launch : three_launches;
+    return facts->hot ? three_launches : one_launch;
+}
+
+// facts == NULL: before a binding (its cost counts); else: the image is bound (its cost is spent)
+static bool table_pays(const kmg_processor *p, uint64_t n, uint32_t k, bool labels, const ImageFacts *facts)
+{
+    if (const int f = forced_strategy(p)) return f > 0;
     const double N = (double)n;
-    // (per-pixel scan: assign + reduce + update launches 11 us + 0.09 us per cluster, then 7.5 + 0.245 k ps per pixel --
-    // round 4, after k_assign's pixels per thread followed the image size: tools/strategy_sweep.py, profiles/r04_strategy_sweep.txt.
-    // Those are NOISE images.  A photograph near the crossover runs the scan slower (crowded centroids: more near-tie repairs,
-    // +30 % at 1 Mpx, k = 256) and the table faster (fewer occupied cells; since round 5 its heavy cells are scanned by four
-    // waves each: -30 %), and the model cannot see the image: for k > 32 it leans towards the photograph -- the scan's estimate
-    // times 1.15, the cube pass between its two costs -- which costs a 1 Mpx noise image at k = 256 the wrong answer by 37 %
-    // (93 against 127 us) and nothing elsewhere on the grid of profiles/r05_strategy_sweep.txt.)
-    const double brute = (1.1e-5 + 9.3e-8 * k + N * (7.5e-12 + 2.45e-13 * k)) * (k > 32u ? 1.15 : 1.0);
-    const double label_pass = labels ? N * (k <= 256 ? 1.8e-12 + 2.0e-15 * k : 6.7e-12) : 0.0;
-    // (cube pass on noise, round 5: k <= 32 one launch, 38 / 50 / 51 / 56 us at k = 4 / 8 / 16 / 32; 32 < k <= 256 with the
-    // dominance phase 95 / 100 / 111 us at k = 64 / 128 / 256 -- a photograph ~93 at k = 256; k = 512: 203)
-    const double cube = k <= 32u ? 4.4e-5 + 3.5e-7 * k : (k <= 256u ? 8.0e-5 + 8.5e-8 * k : 8.6e-5 + 2.3e-7 * k);
-    const double table = cube + label_pass + bind_seconds(n) / 16.0;
-    return table < brute;
+    const double N22 = (double)(1u << 22);
+    const double label_pass = !labels ? 0.0 : (k > 256u ? N * 6.7e-12 : (N <= N22 ? 3.0e-6 + N * 4.4e-12 : 2.15e-5 + (N - N22) * 2.2e-12));
+    const double table = cube_seconds(k, facts) + label_pass + (facts ? 0.0 : bind_seconds(n) / 16.0);
+    // (blind: the scan at its dearest -- an image with hot cells -- against the table at its cheapest)
+    const double scan = scan_seconds(n, k, facts ? facts->hot != 0u : true);
+    return table < scan;
 }
 
 int ensure_bounds(kmg_processor *p, hipStream_t st)
@@ -120,6 +145,7 @@ static int tables_from_histogram(kmg_lloyd *s, uint64_t n_pixels, hipStream_t st
     // images with hot cells, so the host needs their number: 4 bytes back, the one synchronisation of a binding
     HIP_TRY(launch_work_list(t.d_agg, t.d_work, s->k <= 256 ? n_pixels : 0, st));
     HIP_TRY(hipMemcpyAsync(&t.n_hot, t.d_work + kCells + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&t.n_occ, t.d_work, sizeof(uint32_t), hipMemcpyDeviceToHost, st));      // (the cost model wants it)
     HIP_TRY(hipStreamSynchronize(st));
     if (const char *e = KMG_TOOLS_ENV("KMG_HOT_CELLS")) { if (e[0] == '0') t.n_hot = 0; }      // (tools build only)
     t.d_work_share = nullptr;
@@ -219,16 +245,49 @@ static int prepare_impl(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, int wan
 {
     if (!s || !d_rgba || n == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad prepare arguments");
     int chosen = 0;
-    if (n <= 0xFFFFFFFFull && table_pays(n, s->k, want_labels != 0)) {
-        // the initialisation of this problem may have bound the image a moment ago: keep that binding
-        const bool fresh = s->tab.rgba == d_rgba && s->tab.n == n && s->tab.bound_by_init;
-        s->tab.bound_by_init = false;
+    // the initialisation of this problem may have bound the image a moment ago: that binding is kept, and its facts are known
+    const bool fresh = s->tab.rgba == d_rgba && s->tab.n == n && s->tab.bound_by_init;
+    s->tab.bound_by_init = false;
+    const ImageFacts before = {s->tab.n_occ, s->tab.n_hot};
+    // Where the blind model's two ends disagree -- the table wins on the cheapest image of this size and loses on the dearest --
+    // 16384 sampled pixels say which kind this one is (one workgroup + 12 bytes back: ~20 us, a tenth of a binding).
+    bool try_table = n <= 0xFFFFFFFFull && table_pays(s->p, n, s->k, want_labels != 0, fresh ? &before : nullptr);
+    if (try_table && !fresh && forced_strategy(s->p) == 0) {
+        const ImageFacts dense = {kCells, 0u};
+        const double N = (double)n, N22 = (double)(1u << 22);
+        // (the dearest table of this size: every cell occupied, no hot cells to make the scan dearer -- with the binding on top)
+        const double label_pass = !want_labels ? 0.0 : (s->k > 256u ? N * 6.7e-12 : (N <= N22 ? 3.0e-6 + N * 4.4e-12 : 2.15e-5 + (N - N22) * 2.2e-12));
+        const bool sure = cube_seconds(s->k, &dense) + label_pass + bind_seconds(n) / 16.0 < scan_seconds(n, s->k, false);
+        if (!sure) {
+            uint32_t *d_probe = reinterpret_cast<uint32_t *>(s->d_nconv) + 1;     // (three words behind the convergence count)
+            uint32_t h[3] = {0u, 0u, 1u};
+            HIP_TRY(launch_sparsity_probe((const uint32_t *)d_rgba, n, d_probe, S(stream)));
+            HIP_TRY(hipMemcpyAsync(h, d_probe, sizeof h, hipMemcpyDeviceToHost, S(stream)));
+            HIP_TRY(hipStreamSynchronize(S(stream)));
+            // occupied cells of the IMAGE from those of the sample: d = M (1 - exp(-S / M)) solved for M by fixed-point steps
+            double M = (double)h[0];
+            for (int it = 0; it < 8 && h[0] < h[2]; ++it) M = (double)h[0] / (1.0 - exp(-(double)h[2] / (M > 1.0 ? M : 1.0)));
+            const ImageFacts guess = {(uint32_t)(M < (double)kCells ? M : (double)kCells), h[1] * 10u >= h[2] ? 1u : 0u};
+            const double table = cube_seconds(s->k, &guess) + label_pass + bind_seconds(n) / 16.0;
+            try_table = table < scan_seconds(n, s->k, guess.hot != 0u);
+            if (log_debug()) fprintf(stderr, "[kmeans_hip] prepare: %u of %u samples' cells, %u in crowded cells -> ~%u occupied%s: %s\n", h[0], h[2], h[1],
+                                     guess.occupied, guess.hot ? ", hot" : "", try_table ? "bind" : "per-pixel scan");
+        }
+    }
+    if (try_table) {
         if (!fresh) {
             int rc = bind_image_impl(s, d_rgba, n, stream, false, 0);
             if (rc != KMG_OK) return rc;
         }
-        s->tab.bound_by_caller = caller;
-        chosen = 1;
+        // now the histogram has been seen: occupied cells, hot cells -- the model answers for THIS image
+        const ImageFacts facts = {s->tab.n_occ, s->tab.n_hot};
+        if (fresh || table_pays(s->p, n, s->k, want_labels != 0, &facts)) {
+            s->tab.bound_by_caller = caller;
+            chosen = 1;
+        } else {
+            s->tab.rgba = nullptr;   // (the blocks stay with the object: the next image may want them)
+            if (log_debug()) fprintf(stderr, "[kmeans_hip] prepare: %u occupied cells, %u hot cells -- the per-pixel scan after all\n", facts.occupied, facts.hot);
+        }
     } else if (s->tab.rgba == d_rgba) {
         s->tab.rgba = nullptr;   // the cost model prefers the per-pixel scan for this problem
     }
@@ -239,6 +298,16 @@ static int prepare_impl(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, int wan
 extern "C" int kmg_lloyd_prepare(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, int want_labels, int *strategy, void *stream)
 try {
     return prepare_impl(s, d_rgba, n, want_labels, strategy, stream, true);
+}
+KMG_ABI_CATCH
+
+extern "C" int kmg_debug_bound_image(kmg_lloyd *s, uint64_t out[2])
+try {
+    if (!s || !out) return fail(KMG_ERR_INVALID_ARGUMENT, "bad bound_image arguments");
+    if (!s->tab.rgba) return fail(KMG_ERR_INVALID_ARGUMENT, "no image is bound");
+    out[0] = s->tab.n_occ;
+    out[1] = s->tab.n_hot;
+    return KMG_OK;
 }
 KMG_ABI_CATCH
 
@@ -619,12 +688,9 @@ KMG_ABI_CATCH
 // more for each of the first ~16 passes, which reach every cell) after binding the image (bind_seconds, x 1.5 with the
 // tie keys that come with the partitioned histogram, or another atomic per pixel on small images); MI355X,
 // tools/cfg3_probe.py / tools/init_phases.sh, round 2.
-static bool init_table_pays(uint64_t n, uint32_t k)
+static bool init_table_pays(const kmg_processor *p, uint64_t n, uint32_t k)
 {
-    if (const char *e = getenv("KMG_STRATEGY")) {
-        if (!strcmp(e, "brute")) return false;
-        if (!strcmp(e, "table")) return true;
-    }
+    if (const int f = forced_strategy(p)) return f > 0;
     const double N = (double)n, passes = (double)(k - 1);
     // (k >= 32: k_init_multi picks up to four centroids per launch -- ~0.3 k + 18 launches -- on a grid of at most 256
     // workgroups, four literal distances per pixel and launch: 9 us + 30 ps per pixel; tools/init_crossover.py,
@@ -643,7 +709,7 @@ static int init_over_colours(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, ui
     *colours = false;
     // an initialisation starts a new problem: the image is (re)bound from the buffer's current contents,
     // so the loop that follows never works from the histogram of an earlier image in the same buffer
-    if (first_index + n > 0xFFFFFFF0ull || !init_table_pays(n, s->k)) {
+    if (first_index + n > 0xFFFFFFF0ull || !init_table_pays(s->p, n, s->k)) {
         if (s->tab.rgba == d_rgba) s->tab.rgba = nullptr;
         return KMG_OK;
     }

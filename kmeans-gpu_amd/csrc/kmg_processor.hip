@@ -3,6 +3,8 @@
 // colour helpers the reference takes from the `palette` crate.  There is no CPU data path: without a HIP device the processor
 // cannot be created.
 
+#include <stddef.h>
+
 #include "kmg_state.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -53,6 +55,7 @@ try {
     opt->max_iterations = 128;   // modules.rs:765
     opt->check_period = 8;       // modules.rs:766
     opt->convergence = 1.0f;     // lib.rs:189-194
+    opt->strategy = KMG_STRATEGY_AUTO;
 }
 KMG_ABI_CATCH_VOID
 
@@ -153,9 +156,13 @@ try {
     kmg_options o;
     kmg_default_options(&o);
     if (opt) {
-        if (opt->struct_size != sizeof(kmg_options))
+        // (the struct grew by `strategy` in round 6: a caller compiled against the previous header passes the old size)
+        constexpr uint32_t kOldSize = (uint32_t)offsetof(kmg_options, strategy);
+        if (opt->struct_size != sizeof(kmg_options) && opt->struct_size != kOldSize)
             return fail(KMG_ERR_INVALID_ARGUMENT, "kmg_options.struct_size mismatch");
-        o = *opt;
+        memcpy(&o, opt, opt->struct_size);
+        o.struct_size = sizeof(kmg_options);
+        if ((o.strategy & 3) == 3 || (o.strategy & ~7) != 0) return fail(KMG_ERR_INVALID_ARGUMENT, "kmg_options.strategy: unknown value %d", o.strategy);
         if (o.max_iterations == 0 || o.check_period == 0)
             return fail(KMG_ERR_INVALID_ARGUMENT, "max_iterations and check_period must be > 0");
     }
@@ -174,6 +181,7 @@ try {
     if (!p) return fail(KMG_ERR_OUT_OF_MEMORY, "host allocation failed");
     p->device = dev;
     p->opt = o;
+    p->strategy.store(o.strategy);
     p->d_lut = nullptr;
     p->d_bounds = nullptr;
     p->d_sub_bounds = nullptr;
@@ -280,6 +288,15 @@ try {
     if (d) (void)hipFree(d);
     if (e != hipSuccess) return fail(KMG_ERR_HIP, "division check failed: %s", hipGetErrorString(e));
     out[0] = h[0]; out[1] = h[1]; out[2] = h[2];
+    return KMG_OK;
+}
+KMG_ABI_CATCH
+
+extern "C" int kmg_processor_set_strategy(kmg_processor *p, int strategy)
+try {
+    if (!p) return fail(KMG_ERR_INVALID_ARGUMENT, "processor is NULL");
+    if ((strategy & 3) == 3 || (strategy & ~7) != 0) return fail(KMG_ERR_INVALID_ARGUMENT, "unknown strategy %d", strategy);
+    p->strategy.store(strategy);
     return KMG_OK;
 }
 KMG_ABI_CATCH

@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <exception>
 #include <mutex>
@@ -62,6 +63,7 @@ using namespace kmg;
 struct kmg_processor {
     int device;
     kmg_options opt;
+    std::atomic<int> strategy{0};   // KMG_STRATEGY_* (kmg_options.strategy, kmg_processor_set_strategy)
     float *d_lut;            // 256 x f32: sRGB decode * 100, then 256 x f32: thresholds of the sRGB8 encode (k_meld)
     std::mutex mu;           // guards the lazily built static tables below
     CellBounds *d_bounds;    // kCells static cell bounds of the colour-table strategy
@@ -111,6 +113,7 @@ struct ColourTable {
     uint64_t *d_masks = nullptr;     // kCells x words candidate masks
     uint32_t *d_work = nullptr;      // kWorkWords: dense list of the occupied cells, then the hot cells (kmg_table.h)
     uint32_t n_hot = 0;              // host copy of the number of hot cells of the bound image
+    uint32_t n_occ = 0;              // host copy of the number of occupied cells of the bound image (d_work[0])
     uint32_t *share_buf = nullptr;   // storage of d_work_share
     uint32_t *d_work_share = nullptr;   // 1 + kCells: this rank's share of the work list (kmg_lloyd_set_cell_share), or NULL = all of it
     bool tables_valid = false;       // label tables describe the CURRENT centroid table
@@ -171,6 +174,18 @@ struct kmg_lloyd {
 };
 
 static inline hipStream_t S(void *s) { return (hipStream_t)s; }
+
+// What a cost model's decision is overridden with: +1 = colour table / candidate lists, -1 = per-pixel scan, 0 = the model decides
+// (kmg_options.strategy; the tools build also honours the environment variable KMG_STRATEGY = brute | table)
+static inline int forced_strategy(const kmg_processor *p)
+{
+    if (const char *e = KMG_TOOLS_ENV("KMG_STRATEGY")) {
+        if (!strcmp(e, "brute")) return -1;
+        if (!strcmp(e, "table")) return 1;
+    }
+    const int st = p->strategy.load(std::memory_order_relaxed) & 3;
+    return st == KMG_STRATEGY_TABLE ? 1 : (st == KMG_STRATEGY_SCAN ? -1 : 0);
+}
 
 namespace {
 struct DevBuf {

@@ -155,6 +155,9 @@ hipError_t launch_cell_aggregates(const uint32_t *hist, const float4 *lab_table,
 // once per image: work[0] = number of occupied cells, work[1..] = their indices in ascending order;
 // work[kCells + 1] = number of hot cells (n_pixels = 0: none wanted), work[kCells + 2 ..] = their indices (kWorkWords in all)
 hipError_t launch_work_list(const int64_t *agg, uint32_t *work, uint64_t n_pixels, hipStream_t st);
+// before anything is built for an image (the cost model's look at it): 16384 pixels at equal strides, one workgroup -- out3[0] = cells of
+// the 32^3 grid the sample occupies, out3[1] = samples in crowded cells (>= 1 / 560 of the samples each), out3[2] = samples taken
+hipError_t launch_sparsity_probe(const uint32_t *rgba, uint64_t n, uint32_t *out3, hipStream_t st);
 // a share of the work list: out[0] = its number of cells, out[1..] = the occupied cells with index in
 // [kCells part / parts, kCells (part + 1) / parts) (cell-sharded cube pass: every rank of a sharded image labels one share of the cube)
 hipError_t launch_work_share(const uint32_t *work, uint32_t part, uint32_t parts, uint32_t *out, hipStream_t st);

@@ -885,6 +885,47 @@ hipError_t launch_work_share(const uint32_t *work, uint32_t part, uint32_t parts
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// What a cost model may know about an image before anything is built for it: kProbeSamples pixels at equal strides, counted per
+// 8x8x8 cell in LDS (ONE workgroup, ~10 us).  out[0] = cells the sample occupies, out[1] = samples that fall into crowded cells
+// (a cell with at least 1 / 560 of the samples: the dark corner of a photograph), out[2] = samples taken.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kProbeSamples = 16384;
+
+__global__ __launch_bounds__(1024) void k_sparsity_probe(const uint32_t *__restrict__ rgba, uint64_t n, uint32_t *__restrict__ out)
+{
+    __shared__ uint32_t s_cnt[kCells / 2];                         // two 16-bit counters per word
+    __shared__ uint32_t s_tot[2];
+    for (uint32_t i = threadIdx.x; i < kCells / 2; i += 1024u) s_cnt[i] = 0u;
+    if (threadIdx.x < 2u) s_tot[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t samples = n < kProbeSamples ? (uint32_t)n : kProbeSamples;
+    const uint64_t stride = n / samples;
+    for (uint32_t i = threadIdx.x; i < samples; i += 1024u) {
+        const uint32_t cell = colour_index(rgba[(uint64_t)i * stride]) >> 9;
+        atomicAdd(&s_cnt[cell >> 1], (cell & 1u) ? 0x10000u : 1u);
+    }
+    __syncthreads();
+    const uint32_t crowded = samples / 560u + 1u;
+    uint32_t occ = 0u, hot = 0u;
+    for (uint32_t i = threadIdx.x; i < kCells / 2; i += 1024u) {
+        const uint32_t lo = s_cnt[i] & 0xFFFFu, hi = s_cnt[i] >> 16;
+        occ += (lo != 0u) + (hi != 0u);
+        hot += (lo >= crowded ? lo : 0u) + (hi >= crowded ? hi : 0u);
+    }
+    occ = wave_add_u32(occ);                                         // (per-lane <= 32 cells, <= 16384 samples: no overflow)
+    hot = wave_add_u32(hot);
+    if ((threadIdx.x & 63u) == 0u) { atomicAdd(&s_tot[0], occ); atomicAdd(&s_tot[1], hot); }
+    __syncthreads();
+    if (threadIdx.x == 0u) { out[0] = s_tot[0]; out[1] = s_tot[1]; out[2] = samples; }
+}
+
+hipError_t launch_sparsity_probe(const uint32_t *rgba, uint64_t n, uint32_t *out3, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_sparsity_probe, dim3(1), dim3(1024), 0, st, rgba, n, out3);
+    return hipGetLastError();
+}
+
 hipError_t launch_work_list(const int64_t *agg, uint32_t *work, uint64_t n_pixels, hipStream_t st)
 {
     hipLaunchKernelGGL(k_work_list, dim3(1), dim3(1024), 0, st, agg, work, n_pixels);

@@ -63,7 +63,48 @@ class ReduceMode(enum.IntEnum):         # core/src/lib.rs:234-239
 
 class Options(C.Structure):             # include/kmeans_hip.h kmg_options
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("shrink_max_dim", C.c_uint32),
-                ("max_iterations", C.c_uint32), ("check_period", C.c_uint32), ("convergence", C.c_float)]
+                ("max_iterations", C.c_uint32), ("check_period", C.c_uint32), ("convergence", C.c_float),
+                ("strategy", C.c_int32)]
+
+
+# kmg_options.strategy (include/kmeans_hip.h KMG_STRATEGY_*): results are identical either way, only the time differs
+STRATEGY_AUTO, STRATEGY_SCAN, STRATEGY_TABLE, STRATEGY_MASK_WORDS = 0, 1, 2, 4
+_STRATEGY_NAMES = {"auto": STRATEGY_AUTO, "scan": STRATEGY_SCAN, "brute": STRATEGY_SCAN, "table": STRATEGY_TABLE}
+_default_strategy = STRATEGY_AUTO
+_live = None            # weak set of the live ImageProcessor / Group objects (set_strategy reaches them)
+
+
+def _strategy_value(strategy):
+    if isinstance(strategy, str):
+        v = 0
+        for part in strategy.replace("|", "+").split("+"):
+            part = part.strip().lower()
+            if part == "mask_words":
+                v |= STRATEGY_MASK_WORDS
+            elif part in _STRATEGY_NAMES:
+                v |= _STRATEGY_NAMES[part]
+            else:
+                raise ValueError(f"unknown strategy {strategy!r}")
+        return v
+    return int(strategy)
+
+
+def set_strategy(strategy):
+    """kmg_processor_set_strategy on every live processor of this process (ImageProcessor objects and the members of Group
+    objects) and the default of the ones created later: "auto" (the library's cost models), "scan" (alias "brute": per-pixel
+    scans), "table" (colour table / candidate lists), optionally "+mask_words".  What the tests and tools flip between runs."""
+    global _default_strategy
+    _default_strategy = _strategy_value(strategy)
+    for obj in list(_live or ()):
+        obj.set_strategy(_default_strategy)
+
+
+def _register(obj):
+    global _live
+    if _live is None:
+        import weakref
+        _live = weakref.WeakSet()
+    _live.add(obj)
 
 
 MAX_DEVICES = 16                        # KMG_MAX_DEVICES
@@ -86,14 +127,14 @@ _lib = None
 # every symbol include/kmeans_hip.h declares
 SYMBOLS = [
     "kmg_last_error", "kmg_version", "kmg_host_alloc", "kmg_host_free", "kmg_default_options", "kmg_processor_create",
-    "kmg_processor_create_ex", "kmg_processor_destroy", "kmg_palette", "kmg_find", "kmg_reduce",
+    "kmg_processor_create_ex", "kmg_processor_destroy", "kmg_processor_set_strategy", "kmg_palette", "kmg_find", "kmg_reduce",
     "kmg_palette_to_centroids", "kmg_centroids_to_palette", "kmg_octree_palette", "kmg_dev_rgb_to_lab",
     "kmg_resized_dims",
     "kmg_dev_resize", "kmg_lloyd_create", "kmg_lloyd_destroy", "kmg_lloyd_set_centroids",
     "kmg_lloyd_get_centroids", "kmg_lloyd_init_centroids", "kmg_lloyd_init_step", "kmg_lloyd_init_pick_band",
     "kmg_lloyd_set_centroid_rgba", "kmg_init_first_key", "kmg_lloyd_assign_accumulate",
     "kmg_lloyd_assign_partials", "kmg_lloyd_reduce_partials", "kmg_lloyd_labels", "kmg_lloyd_reserve_cus", "kmg_lloyd_bind_image",
-    "kmg_lloyd_unbind_image", "kmg_lloyd_prepare", "kmg_debug_check_table", "kmg_debug_table_stats", "kmg_debug_check_pairs", "kmg_debug_check_dither_masks", "kmg_debug_check_meld_masks", "kmg_kernel_name",
+    "kmg_lloyd_unbind_image", "kmg_debug_bound_image", "kmg_lloyd_prepare", "kmg_debug_check_table", "kmg_debug_table_stats", "kmg_debug_check_pairs", "kmg_debug_check_dither_masks", "kmg_debug_check_meld_masks", "kmg_kernel_name",
     "kmg_lloyd_profile", "kmg_lloyd_profile_read",
     "kmg_lloyd_update", "kmg_lloyd_assign_update", "kmg_lloyd_set_cell_share", "kmg_lloyd_labels_from_tables",
     "kmg_lloyd_table_buffers", "kmg_lloyd_histogram_buffer", "kmg_lloyd_rebuild_from_histogram", "kmg_debug_block_counts", "kmg_debug_idle_blocks", "kmg_debug_encode_table_check", "kmg_debug_division_check", "kmg_lloyd_converged_count", "kmg_lloyd_iterate", "kmg_lloyd_flush", "kmg_lloyd_run", "kmg_dev_apply", "kmg_apply_plan_create", "kmg_apply_plan_run", "kmg_apply_plan_destroy",
@@ -165,6 +206,7 @@ def lib():
     L.kmg_lloyd_bind_image.argtypes = [vp, u8p, C.c_uint64, vp]
     L.kmg_debug_table_stats.argtypes = [vp, C.POINTER(C.c_uint64), vp]
     L.kmg_debug_check_pairs.argtypes = [vp, C.POINTER(C.c_uint64), vp]
+    L.kmg_debug_bound_image.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.kmg_debug_check_dither_masks.argtypes = [vp, f32p, C.c_uint32, C.POINTER(C.c_uint64), vp]
     L.kmg_debug_check_meld_masks.argtypes = [vp, f32p, C.c_uint32, C.POINTER(C.c_uint64), vp]
     L.kmg_kernel_name.argtypes = [C.c_int]
@@ -195,6 +237,7 @@ def lib():
     L.kmg_apply_plan_destroy.argtypes = [vp, C.c_int]
     L.kmg_apply_plan_destroy.restype = None
     L.kmg_dither_threshold.argtypes = [f32p, C.c_uint32, C.POINTER(C.c_float)]
+    L.kmg_processor_set_strategy.argtypes = [vp, C.c_int]
     L.kmg_default_group_options.argtypes = [C.POINTER(GroupOptions)]
     L.kmg_default_group_options.restype = None
     L.kmg_group_create.argtypes = [C.POINTER(GroupOptions), C.POINTER(vp)]
@@ -339,7 +382,7 @@ class ImageProcessor:
     """Mirror of `kmeans_color_gpu::ImageProcessor` (core/src/lib.rs:24-165)."""
 
     def __init__(self, device=-1, shrink_max_dim=256, max_iterations=128, check_period=8,
-                 convergence=1.0):
+                 convergence=1.0, strategy=None):
         self._h = C.c_void_p()
         o = default_options()
         o.device = device
@@ -347,8 +390,15 @@ class ImageProcessor:
         o.max_iterations = max_iterations
         o.check_period = check_period
         o.convergence = convergence
+        o.strategy = _default_strategy if strategy is None else _strategy_value(strategy)
         _check(lib().kmg_processor_create_ex(C.byref(o), C.byref(self._h)))
         self.options = o
+        _register(self)
+
+    def set_strategy(self, strategy):
+        """kmg_processor_set_strategy: "auto" | "scan" | "table" [+ "mask_words"] (or the KMG_STRATEGY_* bits)"""
+        if self._h.value:
+            _check(lib().kmg_processor_set_strategy(self._h, _strategy_value(strategy)))
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -602,6 +652,12 @@ class Lloyd:
                  "candidates_pruned", "sub_cells_pruned_to_one"]
         return dict(zip(names, (int(v) for v in out)))
 
+    def debug_bound_image(self):
+        """(occupied cells, hot cells) of the bound image"""
+        out = (C.c_uint64 * 2)()
+        _check(lib().kmg_debug_bound_image(self._h, out))
+        return int(out[0]), int(out[1])
+
     def debug_check_pairs(self, stream=0):
         """(mismatching colours, pixels resolved by the LDS pair entries, pixels) of the last table pass"""
         out = (C.c_uint64 * 3)()
@@ -704,7 +760,7 @@ class Group:
     palette / find / reduce mirror ImageProcessor's and give the same bytes."""
 
     def __init__(self, devices=None, flags=0, unique_id=None, first_rank=0, world=None, shrink_max_dim=256, max_iterations=128,
-                 check_period=8, convergence=1.0):
+                 check_period=8, convergence=1.0, strategy=None):
         o = GroupOptions()
         lib().kmg_default_group_options(C.byref(o))
         if devices is not None:
@@ -719,6 +775,7 @@ class Group:
         o.processor.max_iterations = max_iterations
         o.processor.check_period = check_period
         o.processor.convergence = convergence
+        o.processor.strategy = _default_strategy if strategy is None else _strategy_value(strategy)
         self._h = C.c_void_p()
         if unique_id is None:
             _check(lib().kmg_group_create(C.byref(o), C.byref(self._h)))
@@ -731,6 +788,15 @@ class Group:
         _check(lib().kmg_group_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(v)))
         self.n_local, self.first_rank, self.world, self.rccl_version = a.value, b.value, c.value, v.value
         self.options = o
+        _register(self)
+
+    def set_strategy(self, strategy):
+        """kmg_processor_set_strategy on every member processor"""
+        if not self._h.value:
+            return
+        L = lib()
+        for i in range(self.n_local):
+            _check(L.kmg_processor_set_strategy(L.kmg_group_processor(self._h, i), _strategy_value(strategy)))
 
     @staticmethod
     def unique_id():

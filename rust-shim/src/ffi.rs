@@ -22,7 +22,14 @@ pub struct kmg_options {
     pub max_iterations: u32,
     pub check_period: u32,
     pub convergence: f32,
+    pub strategy: i32,
 }
+
+/// `kmg_options.strategy` (KMG_STRATEGY_*): 0 = the library's cost models decide per call; results are identical either way.
+pub const KMG_STRATEGY_AUTO: i32 = 0;
+pub const KMG_STRATEGY_SCAN: i32 = 1;
+pub const KMG_STRATEGY_TABLE: i32 = 2;
+pub const KMG_STRATEGY_MASK_WORDS: i32 = 4;
 
 /// Opaque `kmg_group`: a processor + RCCL rank per device of a list (include/kmeans_hip.h, "a group of devices").
 #[repr(C)]
@@ -58,6 +65,7 @@ extern "C" {
     pub fn kmg_processor_create(out: *mut *mut kmg_processor) -> c_int;
     pub fn kmg_processor_create_ex(opt: *const kmg_options, out: *mut *mut kmg_processor) -> c_int;
     pub fn kmg_processor_destroy(p: *mut kmg_processor);
+    pub fn kmg_processor_set_strategy(p: *mut kmg_processor, strategy: c_int) -> c_int;
     // ImageProcessor::palette -- lib.rs:67-77
     pub fn kmg_palette(
         p: *mut kmg_processor,

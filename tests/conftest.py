@@ -53,3 +53,18 @@ def processor(torch_cuda):
     p = kg.ImageProcessor()
     yield p
     p.close()
+
+
+def set_strategy(strategy):
+    """kmg_options.strategy of every live processor of this process and of the ones created later (kmeans_gpu_amd.set_strategy):
+    "auto" | "scan" (alias "brute") | "table" [+ "mask_words"].  Results are identical either way -- which is what the tests that
+    call this assert.  Reset to "auto" after every test (below)."""
+    import kmeans_gpu_amd as kg
+    kg.set_strategy(strategy)
+
+
+@pytest.fixture(autouse=True)
+def _strategy_back_to_auto():
+    yield
+    if "kmeans_gpu_amd" in sys.modules:
+        sys.modules["kmeans_gpu_amd"].set_strategy("auto")

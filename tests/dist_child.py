@@ -31,7 +31,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
     else:
         dist.init_process_group("gloo")
-    os.environ["KMG_STRATEGY"] = "table"
+    kg.set_strategy("table")
     st = torch.cuda.current_stream().cuda_stream
     w, h, k, iters = 1024, 768, 24, 3
     n = w * h

@@ -74,6 +74,8 @@ int main(int argc, char **argv)
         kmg_default_options(&po);
         po.device = 0;
         po.shrink_max_dim = shrink;
+        // (the TEST's own switch: the library reads no environment variable for this -- kmg_options.strategy)
+        if (const char *e = getenv("CHECK_GROUP_STRATEGY")) po.strategy = !strcmp(e, "table") ? KMG_STRATEGY_TABLE : (!strcmp(e, "scan") ? KMG_STRATEGY_SCAN : KMG_STRATEGY_AUTO);
         kmg_processor *p = nullptr;
         CHECK(kmg_processor_create_ex(&po, &p));
         kmg_group_options go;

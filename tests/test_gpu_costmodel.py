@@ -1,24 +1,23 @@
-"""The strategy choice of kmg_lloyd_prepare (csrc/kmg_lloyd.hip table_pays) on a PHOTOGRAPH near its crossover (-m gpu): the cost
-model was fitted on uniform noise (tools/strategy_sweep.py); a photograph has fewer occupied cells (a cheaper cube pass) and
-crowded ones (more candidates per colour).  Both strategies are timed on the tiled test photograph at 1, 2 and 4 Mpx for
-k = 16 and k = 256; the test fails when the library's own choice is more than 20 % slower than the other strategy.
-
-The model cannot see the image: its cube-pass term is the cost on noise (every cell occupied), a photograph occupies fewer cells and
-its pass is cheaper.  At 4 Mpx, k = 16 the two images want different answers -- photograph: table 56 us against scan 65 (16 %),
-noise: scan 65 against table 83 (28 %) -- and the model's answer (scan) is the one with the smaller regret; the bound was 15 % until
-the one-launch cube pass of small tables got faster on the photograph (round 5: binary16 affine models, 58 -> 56 us)."""
+"""The strategy choice of kmg_lloyd_prepare (csrc/kmg_lloyd.hip table_pays) near its crossover (-m gpu).  Since round 6 the model is
+asked twice: blind (is a binding worth trying: the cheapest cube pass an image of this size can have, against the dearest scan) and,
+after the binding, with what its histogram says about THIS image -- occupied cells, hot cells.  Both strategies are timed on the tiled
+test photograph (few occupied cells, hot ones) AND on noise (every cell occupied) at 1, 2 and 4 Mpx for k = 16 and k = 256; the test
+fails when the library's own choice is more than 15 % slower than the other strategy (rounds 4-5: 20 %, photograph only -- the blind
+model took the slower strategy by 37 % on 1 Mpx of noise at k = 256).  The binding, spread over ~16 passes, counts against the table."""
 import os
 import time
 
 import numpy as np
 import pytest
 
+from conftest import set_strategy as _set_strategy
+
 pytestmark = pytest.mark.gpu
 
 
 def _time_strategy(torch, kg, proc, rgba, n, k, cent, strategy, monkeypatch, iters=30, repeats=3):
     st = torch.cuda.current_stream().cuda_stream
-    monkeypatch.setenv("KMG_STRATEGY", {"scan": "brute", "table": "table"}[strategy])
+    _set_strategy({"scan": "brute", "table": "table"}[strategy])
     labels = torch.empty(n, dtype=torch.int32, device="cuda")
     acc = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
     s = kg.Lloyd(proc, k)
@@ -46,7 +45,8 @@ def _time_strategy(torch, kg, proc, rgba, n, k, cent, strategy, monkeypatch, ite
     return best + (prep / 16.0 if strategy == "table" else 0.0)
 
 
-def test_prepare_picks_the_faster_strategy_on_a_photograph_near_the_crossover(torch_cuda, monkeypatch):
+@pytest.mark.parametrize("kind", ["photo", "uniform"])
+def test_prepare_picks_the_faster_strategy_near_the_crossover(torch_cuda, monkeypatch, kind):
     import bench
     import kmeans_gpu_amd as kg
     torch = torch_cuda
@@ -56,7 +56,7 @@ def test_prepare_picks_the_faster_strategy_on_a_photograph_near_the_crossover(to
     failures = []
     for mpx in (1, 2, 4):
         n = mpx << 20
-        rgba = bench.synthetic_image("photo", n, 0, 0, 1)
+        rgba = bench.synthetic_image(kind, n, 0, 0, 1)
         for k in (16, 256):
             sel = rgba[(torch.arange(k, device="cuda") * (n // k))].contiguous()
             lab = torch.empty((k, 3), dtype=torch.float32, device="cuda")
@@ -64,7 +64,7 @@ def test_prepare_picks_the_faster_strategy_on_a_photograph_near_the_crossover(to
             torch.cuda.synchronize()
             cent = np.ones((k, 4), np.float32)
             cent[:, :3] = lab.cpu().numpy()
-            monkeypatch.delenv("KMG_STRATEGY", raising=False)
+            _set_strategy("auto")
             s = kg.Lloyd(proc, k)
             s.set_centroids(cent, st)
             auto = s.prepare(rgba.data_ptr(), n, True, st)
@@ -72,15 +72,15 @@ def test_prepare_picks_the_faster_strategy_on_a_photograph_near_the_crossover(to
             t = {name: _time_strategy(torch, kg, proc, rgba, n, k, cent, name, monkeypatch) for name in ("scan", "table")}
             other = "table" if auto == "scan" else "scan"
             rows.append(f"{mpx} Mpx k={k}: auto={auto} scan {t['scan'] * 1e6:.1f} us table {t['table'] * 1e6:.1f} us")
-            if t[auto] > 1.20 * t[other]:
+            if t[auto] > 1.15 * t[other]:
                 failures.append(rows[-1])
     print("\n".join(rows))
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out):
-        with open(os.path.join(out, "costmodel_photo.txt"), "w") as f:
+        with open(os.path.join(out, f"costmodel_{kind}.txt"), "w") as f:
             f.write("\n".join(rows) + "\n")
     proc.close()
-    assert not failures, "kmg_lloyd_prepare's choice is > 20 % slower than the other strategy:\n" + "\n".join(failures)
+    assert not failures, "kmg_lloyd_prepare's choice is > 15 % slower than the other strategy:\n" + "\n".join(failures)
 
 
 def test_initialisation_picks_a_sane_strategy_across_sizes(torch_cuda, monkeypatch):
@@ -102,9 +102,9 @@ def test_initialisation_picks_a_sane_strategy_across_sizes(torch_cuda, monkeypat
             t = {}
             for name, env in (("pixels", "brute"), ("colours", "table"), ("auto", None)):
                 if env is None:
-                    monkeypatch.delenv("KMG_STRATEGY", raising=False)
+                    _set_strategy("auto")
                 else:
-                    monkeypatch.setenv("KMG_STRATEGY", env)
+                    _set_strategy(env)
                 s = kg.Lloyd(proc, k)
                 s.init_centroids(rgba.data_ptr(), w, h, st)
                 torch.cuda.synchronize()

@@ -27,7 +27,6 @@ def _run(backend, world):
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        env.pop("KMG_STRATEGY", None)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_child.py"), backend], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -62,7 +61,7 @@ def test_bench_multi_gpu_path_rehearsed_on_one_gpu(torch_cuda):
     import json
     root = os.path.dirname(HERE)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    for name in ("KMG_STRATEGY", "WORLD_SIZE", "RANK", "LOCAL_RANK"):
+    for name in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(name, None)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--rehearse"],
                        env=env, capture_output=True, text=True, timeout=600)
@@ -93,7 +92,6 @@ def test_bench_one_rank_under_the_launcher_with_real_rccl(torch_cuda):
     import json
     root = os.path.dirname(HERE)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    env.pop("KMG_STRATEGY", None)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                         "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
                         "--force-dist", "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)

@@ -32,8 +32,10 @@ def test_product_library_does_not_contain_the_tools_switches():
     assert b"KNOCK" not in blob
     for name in TOOLS_SWITCHES:
         assert name.encode() not in blob, name
-    for name in (b"KMG_STRATEGY", b"KMG_LOG", b"KMG_RCCL_LIBRARY"):          # what the product does read
+    for name in (b"KMG_LOG", b"KMG_RCCL_LIBRARY"):                            # what the product does read: logging, the RCCL path
         assert name in blob
+    for name in (b"KMG_STRATEGY", b"KMG_DITHER_LISTS"):                       # kmg_options.strategy since round 6
+        assert name not in blob, name
 
 
 @pytest.mark.gpu
@@ -68,7 +70,6 @@ def test_random_group_calls_equal_the_single_processor(seed):
     """tools/fuzz_group.py: palette / find / reduce through kmg_group_* (one rank with forced RCCL collectives, two to five ranks
     sharing the GPU through the loopback exchange; the reference's shrink and full resolution) against the single processor"""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    env.pop("KMG_STRATEGY", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_group.py"), "24", str(seed)], capture_output=True, text=True,
                        timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

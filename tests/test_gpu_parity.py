@@ -4,7 +4,7 @@ bit-exactly as well because the sums are exact integers and the update uses the 
 import numpy as np
 import pytest
 
-from conftest import load_rgba, sorted_palette
+from conftest import load_rgba, sorted_palette, set_strategy as _set_strategy
 
 pytestmark = pytest.mark.gpu
 
@@ -185,7 +185,7 @@ def test_lloyd_loop_per_pixel_scan_on_mid_size_images(torch_cuda, oracle, monkey
     separate reduce / update launches): iteration count, centroids and labels equal the oracle's"""
     import kmeans_gpu_amd as kg
     torch = torch_cuda
-    monkeypatch.setenv("KMG_STRATEGY", "brute")
+    _set_strategy("brute")
     rng = np.random.default_rng(w + k)
     c = rng.integers(0, 256, (11, 3))
     px = c[rng.integers(0, 11, w * h)] + rng.normal(0, 20.0, (w * h, 3))

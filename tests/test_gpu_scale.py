@@ -6,6 +6,8 @@ import os
 import numpy as np
 import pytest
 
+from conftest import set_strategy as _set_strategy
+
 pytestmark = pytest.mark.gpu
 
 
@@ -26,7 +28,7 @@ def test_cfg3_full_pass_every_label_and_sum_vs_oracle(torch_cuda, oracle, monkey
     import kmeans_gpu_amd as kg
     from kmeans_gpu_amd import synth
     torch = torch_cuda
-    monkeypatch.setenv("KMG_STRATEGY", "table")
+    _set_strategy("table")
     n, k = 8192 * 8192, 256
     st = _stream(torch)
     rgba = synth.uniform_rgba_torch(synth.SEED_CFG3, n, device="cuda")
@@ -71,7 +73,7 @@ def test_photograph_at_full_size_hot_cells_and_long_lists_vs_oracle(torch_cuda, 
     import bench
     import kmeans_gpu_amd as kg
     torch = torch_cuda
-    monkeypatch.setenv("KMG_STRATEGY", "table")
+    _set_strategy("table")
     st = _stream(torch)
     n, k = 8192 * 8192, 256
     rgba = bench.synthetic_image("photo", n, 0, k, 0x5EED0B10)
@@ -141,7 +143,7 @@ def test_cfg3_labels_equal_the_literal_cie94_argmin_on_every_pixel(torch_cuda, o
     import kmeans_gpu_amd as kg
     from kmeans_gpu_amd import synth
     torch = torch_cuda
-    monkeypatch.setenv("KMG_STRATEGY", "table")
+    _set_strategy("table")
     n, k = 8192 * 8192, 256
     st = _stream(torch)
     rgba = synth.uniform_rgba_torch(synth.SEED_CFG3, n, device="cuda")
@@ -199,7 +201,7 @@ def test_every_colour_gets_the_literal_argmin(torch_cuda, oracle, monkeypatch, s
     colours where the key alone would decide differently."""
     import kmeans_gpu_amd as kg
     torch = torch_cuda
-    monkeypatch.setenv("KMG_STRATEGY", strategy)
+    _set_strategy(strategy)
     st = _stream(torch)
     cube = _colour_cube()
     lab = oracle.rgb_to_lab(cube)
@@ -241,7 +243,7 @@ def test_dither_of_every_colour_takes_the_literal_argmin(torch_cuda, oracle, mon
     want = oracle.find(img, pal, oracle.MODE_DITHER)
     d = torch.from_numpy(img.reshape(-1, 4)).cuda()
     for strategy in ("brute", "table"):
-        monkeypatch.setenv("KMG_STRATEGY", strategy)
+        _set_strategy(strategy)
         p = kg.ImageProcessor()
         out = torch.zeros((w * h, 4), dtype=torch.uint8, device="cuda")
         p.apply(d.data_ptr(), w, h, 0, cent, kg.ReduceMode.Dither, out.data_ptr(), st)
@@ -269,7 +271,7 @@ def test_cfg3_init_at_full_resolution_vs_oracle(torch_cuda, oracle, monkeypatch)
     want = oracle.init_centroids(lab, w, h, k)
     del lab
     for strategy in ("table", "brute"):
-        monkeypatch.setenv("KMG_STRATEGY", strategy)
+        _set_strategy(strategy)
         p = kg.ImageProcessor(shrink_max_dim=0)
         s = kg.Lloyd(p, k)
         s.init_centroids(rgba.data_ptr(), w, h, st)
@@ -310,7 +312,7 @@ def test_cfg3_dither_k256_rows_vs_oracle(torch_cuda, oracle, monkeypatch):
         if first_want is None:
             first_want = want
     # the same band through the per-pixel scan of all centroids (k_apply<DITHER>)
-    monkeypatch.setenv("KMG_STRATEGY", "brute")
+    _set_strategy("brute")
     p.apply(rgba.data_ptr(), w, 1024, 0, cent, kg.ReduceMode.Dither, out.data_ptr(), st)
     torch.cuda.synchronize()
     got = out[:1024 * w].cpu().numpy().reshape(1024, w, 4)
@@ -467,7 +469,7 @@ def test_band_with_random_alpha_equals_the_oracle_and_the_opaque_band(torch_cuda
     p = kg.ImageProcessor(shrink_max_dim=0)
     results = {}
     for strategy in ("table", "brute"):
-        monkeypatch.setenv("KMG_STRATEGY", strategy)
+        _set_strategy(strategy)
         for name, src in (("alpha", rgba), ("opaque", opaque)):
             s = kg.Lloyd(p, k)
             s.set_centroids(cent, st)

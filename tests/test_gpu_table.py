@@ -4,6 +4,8 @@ candidate masks must be conservative for every one of the 2^24 colours."""
 import numpy as np
 import pytest
 
+from conftest import set_strategy as _set_strategy
+
 pytestmark = pytest.mark.gpu
 
 
@@ -184,7 +186,7 @@ def test_lloyd_run_with_table_matches_oracle(torch_cuda, oracle, monkeypatch):
     """the whole loop (init on device, table strategy forced) == oracle, full-resolution mode"""
     import kmeans_gpu_amd as kg
     torch = torch_cuda
-    monkeypatch.setenv("KMG_STRATEGY", "table")
+    _set_strategy("table")
     w, h, k = 640, 480, 12
     img = _blobs(np.random.default_rng(3), w * h, 9).reshape(h, w, 4)
     lab = oracle.rgb_to_lab(img)
@@ -254,7 +256,7 @@ def test_two_bands_on_one_gpu_equal_unsharded(torch_cuda, oracle, monkeypatch, s
     import kmeans_gpu_amd as kg
     from kmeans_gpu_amd.sharded import band_rows
     torch = torch_cuda
-    monkeypatch.setenv("KMG_STRATEGY", strategy)
+    _set_strategy(strategy)
     w, h, k = 512, 301, 24
     img = _blobs(np.random.default_rng(17), w * h, 30).reshape(h, w, 4)
     lab = oracle.rgb_to_lab(img)
@@ -334,7 +336,7 @@ def test_cfg3_full_lloyd_both_strategies(torch_cuda, oracle, monkeypatch):
     st = _stream(torch)
     out = {}
     for strategy in ("brute", "table"):
-        monkeypatch.setenv("KMG_STRATEGY", strategy)
+        _set_strategy(strategy)
         p = kg.ImageProcessor(shrink_max_dim=0, max_iterations=24)     # 24 iterations keep the scan run short
         s = kg.Lloyd(p, k)
         s.init_centroids(rgba.data_ptr(), w, h, st)
@@ -376,7 +378,7 @@ def test_replace_output_pass_table_equals_scan(torch_cuda, oracle, monkeypatch, 
     st = _stream(torch)
     outs = {}
     for strategy in ("brute", "table"):
-        monkeypatch.setenv("KMG_STRATEGY", strategy)
+        _set_strategy(strategy)
         p = kg.ImageProcessor()
         out = torch.zeros((w * h, 4), dtype=torch.uint8, device="cuda")
         p.apply(d.data_ptr(), w, h, 0, cent, kg.ReduceMode.Replace, out.data_ptr(), st)
@@ -426,7 +428,7 @@ def test_sharded_init_steps_equal_unsharded_init(torch_cuda, processor, oracle, 
     from kmeans_gpu_amd.sharded import band_rows
     torch = torch_cuda
     st = _stream(torch)
-    monkeypatch.setenv("KMG_STRATEGY", strategy)
+    _set_strategy(strategy)
     if (w, h) == (256, 171):
         img = oracle.resize(tokyo, w, h)
     else:
@@ -516,7 +518,7 @@ def test_dither_output_pass_pruned_equals_scan(torch_cuda, oracle, monkeypatch, 
     want = oracle.find(img, pal, oracle.MODE_DITHER)
     r0, r1 = 333, 512
     for strategy in ("brute", "table"):
-        monkeypatch.setenv("KMG_STRATEGY", strategy)
+        _set_strategy(strategy)
         p = kg.ImageProcessor()
         out = torch.zeros((w * h, 4), dtype=torch.uint8, device="cuda")
         p.apply(d.data_ptr(), w, h, 0, cent, kg.ReduceMode.Dither, out.data_ptr(), st)
@@ -534,8 +536,8 @@ def test_mask_word_output_passes_for_small_k_still_equal_the_oracle(torch_cuda, 
     with its sorted (k <= 64) and multi-word kernels -- stay selectable (KMG_DITHER_LISTS=0) and stay right: dither and meld"""
     import kmeans_gpu_amd as kg
     torch = torch_cuda
-    monkeypatch.setenv("KMG_STRATEGY", "table")
-    monkeypatch.setenv("KMG_DITHER_LISTS", str(mode))
+    _set_strategy("table")
+    _set_strategy("table+mask_words" if mode == 0 else "table")
     w, h = 777, 400
     img = np.concatenate([_blobs(np.random.default_rng(k), w * 200, 20, sigma=20.0), oracle.synth_uniform(k, w * 200)]).reshape(h, w, 4)
     pal = np.array(sorted(set(map(tuple, oracle.synth_uniform(k + 3, k)))), np.uint8)
@@ -576,7 +578,7 @@ def test_dither_lists_continued_overflowing_and_missing(torch_cuda, oracle, monk
         pal = np.array(sorted(set(map(tuple, np.concatenate([block, rest])))), np.uint8)
         img[:100, :, :3] = np.clip(rng.normal((122, 132, 92), 6.0, (100, w, 3)), 0, 255).astype(np.uint8)   # pixels among the crowd
     cent = kg.palette_to_centroids(pal)
-    monkeypatch.setenv("KMG_STRATEGY", "table")
+    _set_strategy("table")
     p = kg.ImageProcessor()
     d = _dev(torch, img.reshape(-1, 4))
     out = torch.zeros((w * h, 4), dtype=torch.uint8, device="cuda")
@@ -608,7 +610,7 @@ def test_init_over_colours_equals_init_over_pixels(torch_cuda, oracle, tokyo, mo
     want = oracle.init_centroids(oracle.rgb_to_lab(img), w, h, k)
     d = _dev(torch, img.reshape(-1, 4))
     for strategy in ("brute", "table"):
-        monkeypatch.setenv("KMG_STRATEGY", strategy)
+        _set_strategy(strategy)
         p = kg.ImageProcessor(shrink_max_dim=0)
         s = kg.Lloyd(p, k)
         s.init_centroids(d.data_ptr(), w, h, st)
@@ -630,7 +632,7 @@ def test_buffer_reused_for_a_second_image(torch_cuda, oracle, monkeypatch):
     import kmeans_gpu_amd as kg
     torch = torch_cuda
     st = _stream(torch)
-    monkeypatch.setenv("KMG_STRATEGY", "table")
+    _set_strategy("table")
     w, h, k = 160, 90, 7
     p = kg.ImageProcessor(shrink_max_dim=0)
     s = kg.Lloyd(p, k)
@@ -657,7 +659,7 @@ def test_run_twice_on_one_buffer_with_set_centroids(torch_cuda, oracle, monkeypa
     import kmeans_gpu_amd as kg
     torch = torch_cuda
     st = _stream(torch)
-    monkeypatch.setenv("KMG_STRATEGY", "table")
+    _set_strategy("table")
     w, h, k = 200, 120, 9
     p = kg.ImageProcessor(shrink_max_dim=0)
     s = kg.Lloyd(p, k)
@@ -695,7 +697,7 @@ def test_pipelined_iterate_equals_step_by_step(torch_cuda, oracle, monkeypatch, 
     import kmeans_gpu_amd as kg
     torch = torch_cuda
     st = _stream(torch)
-    monkeypatch.setenv("KMG_STRATEGY", "table")
+    _set_strategy("table")
     w, h = 700, 500
     n = w * h
     img = _blobs(np.random.default_rng(k), n, 40, sigma=25.0) if kind == "blobs" else oracle.synth_uniform(k, n)
@@ -760,7 +762,7 @@ def test_meld_output_pass_pruned_equals_scan(torch_cuda, oracle, monkeypatch, k)
     st = _stream(torch)
     outs = {}
     for strategy in ("brute", "table"):
-        monkeypatch.setenv("KMG_STRATEGY", strategy)
+        _set_strategy(strategy)
         p = kg.ImageProcessor()
         out = torch.zeros((w * h, 4), dtype=torch.uint8, device="cuda")
         p.apply(d.data_ptr(), w, h, 0, cent, kg.ReduceMode.Meld, out.data_ptr(), st)
@@ -776,7 +778,7 @@ def test_partitioned_histogram_with_crowded_partitions(torch_cuda, oracle, monke
     import kmeans_gpu_amd as kg
     torch = torch_cuda
     st = _stream(torch)
-    monkeypatch.setenv("KMG_STRATEGY", "table")
+    _set_strategy("table")
     w, h, k = 2048, 1537, 4
     rng = np.random.default_rng(77)
     pal = np.array([[10, 20, 30, 255], [10, 20, 31, 255], [200, 100, 50, 255], [0, 0, 0, 255], [255, 255, 255, 255]], np.uint8)
@@ -811,7 +813,7 @@ def test_cfg2_full_size_assign_update(torch_cuda, oracle, monkeypatch):
     cent0 = oracle.centroids4(oracle.rgb_to_lab(sel))
     res = {}
     for strategy in ("brute", "table"):
-        monkeypatch.setenv("KMG_STRATEGY", strategy)
+        _set_strategy(strategy)
         p = kg.ImageProcessor(shrink_max_dim=0)
         s = kg.Lloyd(p, k)
         s.set_centroids(cent0, st)
@@ -859,7 +861,7 @@ def test_cfg5_full_size_find_dither(torch_cuda, oracle, monkeypatch):
     rgba = synth.uniform_rgba_torch(synth.SEED_CFG5, n, device="cuda")
     outs = {}
     for strategy in ("brute", "table"):
-        monkeypatch.setenv("KMG_STRATEGY", strategy)
+        _set_strategy(strategy)
         p = kg.ImageProcessor()
         out = torch.zeros((n, 4), dtype=torch.uint8, device="cuda")
         p.apply(rgba.data_ptr(), w, h, 0, cent, kg.ReduceMode.Dither, out.data_ptr(), st)
@@ -883,7 +885,7 @@ def test_concurrent_output_passes_share_one_processor(torch_cuda, oracle, monkey
     processor must return what the same calls return one after the other."""
     import threading
     import kmeans_gpu_amd as kg
-    monkeypatch.setenv("KMG_STRATEGY", "table")
+    _set_strategy("table")
     rng = np.random.default_rng(11)
     img = rng.integers(0, 256, (384, 512, 4), dtype=np.uint8)
     img[..., 3] = 255
@@ -919,7 +921,7 @@ def test_label_pass_with_reserved_compute_units(torch_cuda, oracle, monkeypatch)
     """kmg_lloyd_reserve_cus: the label pass on fewer CUs (room for a collective beside it) writes the same label map."""
     import kmeans_gpu_amd as kg
     torch = torch_cuda
-    monkeypatch.setenv("KMG_STRATEGY", "table")
+    _set_strategy("table")
     rng = np.random.default_rng(5)
     n, k = 3_000_017, 200                                     # not a multiple of the tile size
     rgba = rng.integers(0, 256, (n, 4), dtype=np.uint8)
@@ -953,7 +955,7 @@ def test_large_k_through_the_colour_table(torch_cuda, oracle, monkeypatch, k):
     import kmeans_gpu_amd as kg
     torch = torch_cuda
     st = _stream(torch)
-    monkeypatch.setenv("KMG_STRATEGY", "table")
+    _set_strategy("table")
     n = 300_000
     img = oracle.synth_uniform(5, n)
     cent = oracle.centroids4(oracle.rgb_to_lab(img[:k]))
@@ -983,7 +985,7 @@ def test_assign_update_equals_the_two_calls(torch_cuda, oracle, monkeypatch, k, 
     import kmeans_gpu_amd as kg
     torch = torch_cuda
     st = _stream(torch)
-    monkeypatch.setenv("KMG_STRATEGY", strategy)
+    _set_strategy(strategy)
     w, h = 640, 400
     n = w * h
     img = _blobs(np.random.default_rng(7 * k), n, 40, sigma=25.0)
@@ -1035,7 +1037,7 @@ def test_cell_sharded_cube_pass_equals_unsharded(torch_cuda, oracle, tokyo, monk
     from kmeans_gpu_amd.sharded import band_rows, cell_range
     torch = torch_cuda
     st = _stream(torch)
-    monkeypatch.setenv("KMG_STRATEGY", "table")
+    _set_strategy("table")
     k = 40
     img = tokyo[:500, :700].copy()
     h, w = img.shape[:2]
@@ -1096,7 +1098,7 @@ def test_second_image_binds_without_a_hipmalloc(torch_cuda, oracle, monkeypatch)
     import kmeans_gpu_amd as kg
     torch = torch_cuda
     st = _stream(torch)
-    monkeypatch.setenv("KMG_STRATEGY", "table")
+    _set_strategy("table")
     w, h, k = 640, 480, 32
     imgs = [_blobs(np.random.default_rng(s), w * h, 30, sigma=20.0) for s in (1, 2)]
     p = kg.ImageProcessor(shrink_max_dim=0)
@@ -1131,7 +1133,7 @@ def test_crowded_centroids_take_the_long_candidate_lists(torch_cuda, oracle, mon
     import kmeans_gpu_amd as kg
     torch = torch_cuda
     st = _stream(torch)
-    monkeypatch.setenv("KMG_STRATEGY", "table")
+    _set_strategy("table")
     rng = np.random.default_rng(77)
     k, n = 256, 400_000
     pal = np.zeros((k, 4), np.uint8); pal[:, :3] = rng.integers(0, 48, (k, 3)); pal[:, 3] = 255
@@ -1171,7 +1173,7 @@ def test_idle_blocks_stay_bounded_when_images_grow(torch_cuda, oracle, monkeypat
     p = kg.ImageProcessor(shrink_max_dim=0)
     k = 8
     for i, n in enumerate([40_000 + 25_000 * j for j in range(40)]):
-        monkeypatch.setenv("KMG_STRATEGY", "table" if i % 2 else "brute")
+        _set_strategy("table" if i % 2 else "brute")
         img = synth.uniform_rgba_torch(900 + i, n, device="cuda")
         s = kg.Lloyd(p, k + i)                                   # growing workspaces too
         s.init_centroids(img.data_ptr(), n // 100, 100, st)      # growing distance maps (per-pixel init on the brute rounds)
@@ -1198,7 +1200,7 @@ def test_cell_share_refuses_what_it_cannot_answer(torch_cuda, oracle, monkeypatc
     from kmeans_gpu_amd import synth
     torch = torch_cuda
     st = _stream(torch)
-    monkeypatch.setenv("KMG_STRATEGY", "table")
+    _set_strategy("table")
     n, k = 300_000, 12
     img = synth.uniform_rgba_torch(4711, n, device="cuda")
     p = kg.ImageProcessor(shrink_max_dim=0)

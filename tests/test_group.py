@@ -47,7 +47,7 @@ def test_group_binding_argument_checks():
 
 def _run(exe, *args, env=None):
     e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    e.pop("KMG_STRATEGY", None)
+    e.pop("CHECK_GROUP_STRATEGY", None)
     e.update(env or {})
     r = subprocess.run([exe, "run", *map(str, args)], capture_output=True, text=True, env=e, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
@@ -63,7 +63,7 @@ def test_one_rank_group_with_forced_rccl_collectives_equals_one_processor(tmp_pa
     exe = _build(tmp_path)
     out = _run(exe, 1, 16, 1536, 1024)
     assert "rccl version" in out and "rccl version 0" not in out
-    out = _run(exe, 1, 200, 1200, 900, env={"KMG_STRATEGY": "table"})
+    out = _run(exe, 1, 200, 1200, 900, env={"CHECK_GROUP_STRATEGY": "table"})
     assert "strategy of rank 0: table" in out
 
 
@@ -72,7 +72,7 @@ def test_one_rank_group_with_forced_rccl_collectives_equals_one_processor(tmp_pa
 def test_ranks_of_one_process_sharing_the_gpu_equal_one_processor(tmp_path, torch_cuda, ranks):
     exe = _build(tmp_path)
     _run(exe, ranks, 16, 1536, 1025)                               # uneven bands
-    out = _run(exe, ranks, 64, 1100, 960, env={"KMG_STRATEGY": "table"})
+    out = _run(exe, ranks, 64, 1100, 960, env={"CHECK_GROUP_STRATEGY": "table"})
     assert "strategy of rank 0: table" in out
 
 

@@ -29,7 +29,7 @@ def main():
     torch.cuda.synchronize()
     cent = np.ones((k, 4), np.float32)
     cent[:, :3] = lab.cpu().numpy()
-    os.environ["KMG_STRATEGY"] = "table"
+    kg.set_strategy("table")
     s = kg.Lloyd(proc, k)
     s.set_centroids(cent, st)
     s.prepare(rgba.data_ptr(), n, True, st)

@@ -19,7 +19,7 @@ for k in (4, 8, 12, 16, 24, 32, 64, 128, 256, 512):
     for side in (128, 256, 512, 1024, 2048, 4096, 8192):
         res = {}
         for strat in ("brute", "table"):
-            os.environ["KMG_STRATEGY"] = strat
+            kg.set_strategy(strat)
             proc = kg.ImageProcessor(shrink_max_dim=0)
             reps = 3 if side >= 2048 else 20
             proc.apply(rgba.data_ptr(), side, side, 0, cent, kg.ReduceMode.Dither, out.data_ptr(), st)

@@ -31,7 +31,7 @@ for name, pal in (("resurrect64", pal64), ("random16", rng.integers(0, 256, (16,
       for (w, h) in sizes:
         res = {}
         for strat in ("brute", "table"):
-            os.environ["KMG_STRATEGY"] = strat
+            kg.set_strategy(strat)
             proc = kg.ImageProcessor(shrink_max_dim=0)
             proc.apply(img.data_ptr(), w, h, 0, cent, kg.ReduceMode.Dither, out.data_ptr(), st)
             torch.cuda.synchronize(); t = time.perf_counter()
@@ -45,7 +45,7 @@ for name, pal in (("resurrect64", pal64), ("random16", rng.integers(0, 256, (16,
         if (w, h) in ((W, W), (2048, 2048)):
             meld = {}
             for strat in ("brute", "table"):
-                os.environ["KMG_STRATEGY"] = strat
+                kg.set_strategy(strat)
                 proc = kg.ImageProcessor(shrink_max_dim=0)
                 proc.apply(img.data_ptr(), w, h, 0, cent, kg.ReduceMode.Meld, out.data_ptr(), st)
                 torch.cuda.synchronize(); t = time.perf_counter()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised cross-check of the two strategy families through the C ABI: for random images, sizes, k and
-centroid tables, the colour-table / pruned paths (KMG_STRATEGY=table) must return exactly what the per-pixel
-scans (KMG_STRATEGY=brute) return -- initialisation, Lloyd run (labels, centroids, iteration count) and the
+centroid tables, the colour-table / pruned paths (kmg_options.strategy = table) must return exactly what the per-pixel
+scans (strategy = scan) return -- initialisation, Lloyd run (labels, centroids, iteration count) and the
 three output modes.  usage: fuzz_parity.py [cases] [seed]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -34,7 +34,7 @@ def image(kind, w, h):
 
 
 def run(strategy, rgba, w, h, k, cent_fixed):
-    os.environ["KMG_STRATEGY"] = strategy
+    kg.set_strategy(strategy)
     n = w * h
     p = kg.ImageProcessor(shrink_max_dim=0, max_iterations=12)
     d = torch.from_numpy(rgba).cuda()

@@ -19,9 +19,9 @@ for mpx in (0.25, 0.5, 1, 2, 4, 8):
         res = {}
         for name, env in (("pixels", "brute"), ("colours", "table"), ("auto", None)):
             if env is None:
-                os.environ.pop("KMG_STRATEGY", None)
+                kg.set_strategy("auto")
             else:
-                os.environ["KMG_STRATEGY"] = env
+                kg.set_strategy(env)
             s = kg.Lloyd(p, k)
             s.init_centroids(rgba.data_ptr(), w, h, st)
             torch.cuda.synchronize()

@@ -75,12 +75,12 @@ def analyse(name, rgba):
     cent = s.get_centroids(st)
     s.close()
     # labels of all colours under these centroids (per-pixel scan of the cube image)
-    os.environ["KMG_STRATEGY"] = "brute"
+    kg.set_strategy("scan")
     b = kg.Lloyd(proc, k); b.set_centroids(cent, st)
     labels = torch.zeros(1 << 24, dtype=torch.int32, device=dev)
     b.assign_accumulate(cube.data_ptr(), 1 << 24, labels.data_ptr(), 0, st)
     torch.cuda.synchronize(); b.close()
-    os.environ.pop("KMG_STRATEGY")
+    kg.set_strategy("auto")
     # histogram of the image over r | g << 8 | b << 16
     col = (rgba.view(torch.int32).reshape(-1) & 0xFFFFFF).long()
     hist = torch.bincount(col, minlength=1 << 24).float()

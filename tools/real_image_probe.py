@@ -16,7 +16,7 @@ st = torch.cuda.current_stream().cuda_stream
 res = {}
 for k in (16, 256):
     for strat in ("scan", "table"):
-        os.environ["KMG_STRATEGY"] = "brute" if strat == "scan" else "table"
+        kg.set_strategy(strat)
         s = kg.Lloyd(p, k)
         s.init_centroids(d.data_ptr(), 8192, 8192, st) if k == 16 else s.set_centroids(np.concatenate([np.random.default_rng(1).uniform([0,-60,-60],[100,60,60],(k,3)), np.ones((k,1))],1).astype(np.float32), st)
         if strat == "table": s.bind_image(d.data_ptr(), n, st)

@@ -25,7 +25,7 @@ W = H = 8192
 n = W * H
 k = 256
 ITERS, WARM = 8, 2
-os.environ["KMG_STRATEGY"] = "table"
+kg.set_strategy("table")
 proc = kg.ImageProcessor(shrink_max_dim=0)
 st = torch.cuda.current_stream().cuda_stream
 rgba = synth.uniform_rgba_torch(synth.SEED_CFG3, n, device="cuda")
