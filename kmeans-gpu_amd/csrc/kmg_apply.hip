@@ -105,6 +105,34 @@ try {
 }
 KMG_ABI_CATCH
 
+#ifdef KMG_TOOLS
+namespace kmg {
+hipError_t launch_dither_list_stats(const uint32_t *rgba, uint32_t w, uint32_t rows, uint32_t row0, const float *lut, float threshold,
+                                    const uint8_t *lists, unsigned long long *out68, hipStream_t st);
+}
+// tools build: list lengths of the dither pass over an image (k <= 256): out[68] as k_dither_list_stats leaves them
+extern "C" KMG_API int kmg_tools_dither_list_stats(kmg_processor *p, const uint8_t *d_rgba, uint32_t w, uint32_t rows, const float *c4, uint32_t k,
+                                                  unsigned long long *out68)
+try {
+    if (!p || !d_rgba || !c4 || !out68 || k < 2 || k > 256) return fail(KMG_ERR_INVALID_ARGUMENT, "bad dither_list_stats arguments");
+    HIP_TRY(hipSetDevice(p->device));
+    std::vector<Centroid> hc(k);
+    for (uint32_t i = 0; i < k; ++i) hc[i] = {c4[4 * i], c4[4 * i + 1], c4[4 * i + 2], chroma(c4[4 * i + 1], c4[4 * i + 2])};
+    const float thr = dither_threshold(c4, k);
+    DevBuf cent, lists, acc;
+    HIP_TRY(cent.alloc(sizeof(Centroid) * k));
+    HIP_TRY(lists.alloc(lab_list_bytes(k)));
+    HIP_TRY(acc.alloc(sizeof(unsigned long long) * 68));
+    HIP_TRY(hipMemcpy(cent.ptr, hc.data(), sizeof(Centroid) * k, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(acc.ptr, 0, sizeof(unsigned long long) * 68));
+    HIP_TRY(launch_lab_candidates((const Centroid *)cent.ptr, k, thr, false, (uint8_t *)lists.ptr, nullptr));
+    HIP_TRY(launch_dither_list_stats((const uint32_t *)d_rgba, w, rows, 0u, p->d_lut, thr, (const uint8_t *)lists.ptr, (unsigned long long *)acc.ptr, nullptr));
+    HIP_TRY(hipMemcpy(out68, acc.ptr, sizeof(unsigned long long) * 68, hipMemcpyDeviceToHost));
+    return KMG_OK;
+}
+KMG_ABI_CATCH
+#endif
+
 // test support: exhaustive validation of the meld candidate masks for a centroid table (k >= 2): over all
 // 2^24 colours the two closest centroids found among the cell's candidates must be those of the full scan.
 extern "C" int kmg_debug_check_meld_masks(kmg_processor *p, const float *c4, uint32_t k, uint64_t *violations, void *stream)

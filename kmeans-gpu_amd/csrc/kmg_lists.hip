@@ -17,6 +17,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include "kmg_internal.h"
 #include "kmg_table_dev.h"
 
 namespace kmg {
@@ -404,6 +405,12 @@ __global__ __launch_bounds__(kBlock) void k_dither_lists(const uint32_t *__restr
     }
 }
 
+// (Round 6 measured how much of the walk is padding -- tools/dither_list_lengths.py: the lanes' lists hold 4.4 entries on average,
+// the longest of a wave 11-12: lanes' words / (64 x the wave's longest) = 0.50 on the benchmark image -- and built the pass with the
+// pixels of a 1024-pixel tile sorted by list length through LDS (counting sort by ballots, the walk over lanes of equal length,
+// results back through LDS): byte-identical and SLOWER, 0.92 against 0.67 ms -- four workgroup barriers and a second dependent
+// memory round trip (the length, then the record) per tile cost more than half a walk saves.  tools/experiments/
+// r06_dither_sorted_by_list_length.patch; profiles/r06_dither_list_lengths.txt.)
 hipError_t launch_dither_lists(const uint32_t *rgba, uint32_t w, uint32_t rows, uint32_t row0, const Centroid *cent, uint32_t k,
                                const float *lut, const uint32_t *pal, float threshold, const uint8_t *lists, uint32_t *out,
                                hipStream_t st)
@@ -423,6 +430,63 @@ hipError_t launch_dither_lists(const uint32_t *rgba, uint32_t w, uint32_t rows, 
                            aligned);
     return hipGetLastError();
 }
+
+#ifdef KMG_TOOLS
+// tools build: how much of the list walk's issue time is padding.  The walk of k_dither_lists is paid by a wave for its LONGEST list
+// (unrolled by words, lanes with shorter lists masked off); this kernel visits the pixels in k_dither_lists' own lane layout and
+// adds up, per wave and pixel slot, the words each lane's list has and 64 x the words the wave walks.
+// out: [0] sum of the lanes' words, [1] sum over waves of 64 x the longest, [2] pixels, [3] pixels with count 255 (no list),
+// [4 + c] pixels whose list has c entries (c < 64).
+__global__ __launch_bounds__(kBlock) void k_dither_list_stats(const uint32_t *__restrict__ rgba, uint32_t w, uint64_t n, uint32_t row0,
+                                                              const float *__restrict__ lut, float threshold,
+                                                              const uint8_t *__restrict__ lists, unsigned long long *__restrict__ out)
+{
+    __shared__ float s_lut[256], s_off[16];
+    __shared__ unsigned long long s_acc[4 + 64];
+    s_lut[threadIdx.x] = lut[threadIdx.x];
+    if (threadIdx.x < 16) s_off[threadIdx.x] = threshold * (bayer16(threadIdx.x) / 16.0f - 0.5f);
+    if (threadIdx.x < 68) s_acc[threadIdx.x] = 0ull;
+    __syncthreads();
+    constexpr uint64_t TILE = (uint64_t)kBlock * 4;
+    const uint64_t tiles = (n + TILE - 1) / TILE;
+    for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const uint64_t i0 = tile * TILE + (uint64_t)threadIdx.x * 4;
+        uint32_t gy = (uint32_t)i0 / w, gx = (uint32_t)i0 - gy * w;
+        gy += row0;
+        for (int q = 0; q < 4; ++q) {
+            const bool in = i0 + (uint64_t)q < n;
+            uint32_t cnt = 0;
+            if (in) {
+                float L, a, b;
+                px_to_lab(s_lut, rgba[i0 + q], L, a, b);
+                const float off = s_off[(gx & 3u) + ((gy & 3u) << 2)];
+                cnt = lists[list_record_offset(1u, 0u, 0u, lab_cell_index(L + off, a + off, b + off))];
+            }
+            const bool over = cnt == 255u;
+            const uint32_t c = over ? 0u : cnt;
+            const uint32_t words = c ? 1u + c / 4u : 0u;
+            const uint32_t longest = wave_max_u32_dpp(c);
+            const uint32_t wave_words = longest ? 1u + longest / 4u : 0u;
+            const uint32_t sum = wave_add_u32(in ? words : 0u);
+            if ((threadIdx.x & 63u) == 0u) { atomicAdd(&s_acc[0], (unsigned long long)sum); atomicAdd(&s_acc[1], 64ull * wave_words); }
+            if (in) { atomicAdd(&s_acc[2], 1ull); if (over) atomicAdd(&s_acc[3], 1ull); else atomicAdd(&s_acc[4 + (c < 63u ? c : 63u)], 1ull); }
+            gx += 1;
+            if (gx == w) { gx = 0; gy += 1; }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 68 && s_acc[threadIdx.x]) atomicAdd(out + threadIdx.x, s_acc[threadIdx.x]);
+}
+
+hipError_t launch_dither_list_stats(const uint32_t *rgba, uint32_t w, uint32_t rows, uint32_t row0, const float *lut, float threshold,
+                                    const uint8_t *lists, unsigned long long *out68, hipStream_t st)
+{
+    const uint64_t n = (uint64_t)w * rows;
+    const uint64_t tiles = (n + kBlock * 4 - 1) / (kBlock * 4);
+    hipLaunchKernelGGL(k_dither_list_stats, dim3((uint32_t)(tiles < 4096 ? tiles : 4096)), dim3(kBlock), 0, st, rgba, w, n, row0, lut, threshold, lists, out68);
+    return hipGetLastError();
+}
+#endif
 
 // ---- the meld pass ----------------------------------------------------------------------------------------------------------
 // mix_colors.wgsl:29-48 keeps, over an ordered scan with `<`, the two closest centroids of a pixel under the literal distance:
