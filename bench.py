@@ -9,7 +9,7 @@ for N > 1 the RCCL all-reduce of the k x 4 int64 accumulators.
 
 N = 1: synthetic 8192x8192 RGBA (splitmix64 seed 0x5EED0003), k = 256.
 N > 1 (default --scaling strong): the SAME 8192x8192 image over the N GPUs -- row bands of 8192/N rows for the label map and,
-       with the colour table, the cube pass sharded by cells (ShardedLloyd(cells=True): histogram all-reduce once, per iteration
+       with the colour table, the cube pass sharded by cells (KMG_GROUP_CELLS: histogram all-reduce once, per iteration
        the k x 4 all-reduce and an all-gather of the label tables).  The weak-scaling figure (one 8192-row band per GPU, one
        k-means problem over the 8192 x 8192 N image) is measured right after and reported under `extra.weak_scaling_*`.
 N > 1, --scaling weak: only that.
@@ -77,17 +77,23 @@ def synthetic_image(kind, n_pixels, first, k, seed):
     return torch.from_numpy(big.reshape(-1, 4)).cuda()
 
 
+def _step(s, strategy, rgba, n_pixels, labels, acc, stream):
+    """one Lloyd iteration of a single-GPU problem with its label map: assign, then the update (on the assign pass's last launch with
+    the colour table -- kmg_lloyd_assign_update; the per-pixel scan does the same in its own launches)"""
+    s.assign_update(rgba.data_ptr(), n_pixels, labels.data_ptr(), acc.data_ptr(), True, stream)
+
+
 def other_distributions(proc, k, n_pixels, stream, steps=10):
     """SURVEY 8d secondary inputs, not part of `value`: the same iteration on `blobs` and on a tiled
     photograph, with the share of the pixels the label pass resolves from its LDS table alone."""
     import numpy as np
     import torch
     import kmeans_gpu_amd as kg
-    from kmeans_gpu_amd.sharded import ShardedLloyd
     extra = {}
     for kind in ("blobs", "photo"):
         rgba = synthetic_image(kind, n_pixels, 0, k, 0x5EED0B10)
         labels = torch.empty(n_pixels, dtype=torch.int32, device="cuda")
+        acc = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
         sel = rgba[(torch.arange(k, device="cuda") * (n_pixels // k))].contiguous()
         lab = torch.empty((k, 3), dtype=torch.float32, device="cuda")
         proc.rgb_to_lab(sel.data_ptr(), k, lab.data_ptr(), stream)
@@ -97,23 +103,17 @@ def other_distributions(proc, k, n_pixels, stream, steps=10):
         s = kg.Lloyd(proc, k)
         s.set_centroids(cent, stream)
         strategy = s.prepare(rgba.data_ptr(), n_pixels, True, stream)
-        sh = ShardedLloyd(s, k, rgba, labels, stream=stream)
-        sh.split_labels = strategy == "table"
-        sh.pipeline = False
-        sh.fused = True
-        sh.prime()
-        for _ in range(3):
-            sh.iterate()
+        for _ in range(4):
+            _step(s, strategy, rgba, n_pixels, labels, acc, stream)
         torch.cuda.synchronize()
         t = time.perf_counter()
         for _ in range(steps):
-            sh.iterate()
-        sh.flush()
+            _step(s, strategy, rgba, n_pixels, labels, acc, stream)
         torch.cuda.synchronize()
         extra[f"{kind}_ms_per_step"] = (time.perf_counter() - t) / steps * 1e3
         extra[f"{kind}_strategy"] = strategy
         if strategy == "table" and k <= 256:
-            s.assign_accumulate(rgba.data_ptr(), n_pixels, 0, sh.acc.data_ptr(), stream)    # label tables of the current centroids
+            s.assign_accumulate(rgba.data_ptr(), n_pixels, 0, acc.data_ptr(), stream)    # label tables of the current centroids
             _, resolved, total = s.debug_check_pairs(stream)
             extra[f"{kind}_pixels_resolved_in_lds"] = resolved / max(total, 1)
         s.close()
@@ -123,17 +123,17 @@ def other_distributions(proc, k, n_pixels, stream, steps=10):
 
 def cfg4_rank_share(proc, k, n_pixels, stream, steps=5):
     """BASELINE config 4 (16 images of 8192 x 8192 over 8 GPUs) as this build places it: WHOLE images per GPU, zero
-    collectives (sharded.PlacedBatch).  One rank's share = two images; time of one Lloyd iteration of both, label maps
+    collectives (kmg_group_reduce_batch's split).  One rank's share = two images; time of one Lloyd iteration of both, label maps
     included.  Not part of `value`."""
     import numpy as np
     import torch
     import kmeans_gpu_amd as kg
     from kmeans_gpu_amd import synth
-    from kmeans_gpu_amd.sharded import PlacedBatch, images_of_rank
-    mine = images_of_rank(16, 0, 8)
+    mine = [0, 8]                                                # image i on device i % 8
     images = [synth.uniform_rgba_torch(0x5EED0400 + i, n_pixels, device="cuda") for i in mine]
     labels = [torch.empty(n_pixels, dtype=torch.int32, device="cuda") for _ in mine]
-    lloyds, split = [], []
+    accs = [torch.zeros((k, 4), dtype=torch.int64, device="cuda") for _ in mine]
+    lloyds, strategies = [], []
     for img in images:
         sel = img[(torch.arange(k, device="cuda") * (n_pixels // k))].contiguous()
         lab = torch.empty((k, 3), dtype=torch.float32, device="cuda")
@@ -143,21 +143,17 @@ def cfg4_rank_share(proc, k, n_pixels, stream, steps=5):
         cent[:, :3] = lab.cpu().numpy()
         s = kg.Lloyd(proc, k)
         s.set_centroids(cent, stream)
-        split.append(s.prepare(img.data_ptr(), n_pixels, True, stream) == "table")
+        strategies.append(s.prepare(img.data_ptr(), n_pixels, True, stream))
         lloyds.append(s)
-    batch = PlacedBatch(lloyds, k, images, labels, stream=stream, split_labels=split)
-    for loop in batch.loops:
-        loop.pipeline = False
-        loop.fused = True
-        loop.prime()
-        loop.iterate()
+
+    def iteration():
+        for s, how, img, lab, acc in zip(lloyds, strategies, images, labels, accs):
+            _step(s, how, img, n_pixels, lab, acc, stream)
+    iteration(); iteration()
     torch.cuda.synchronize()
     t = time.perf_counter()
     for _ in range(steps):
-        for loop in batch.loops:
-            loop.iterate()
-    for loop in batch.loops:
-        loop.flush()
+        iteration()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t) / steps * 1e3
     for s in lloyds:
@@ -186,22 +182,29 @@ def cfg4_native_batch(k, width, height, images=2):
             "cfg4_native_batch_host_to_host_warm_ms": min(times[1:])}
 
 
-def cfg4_tiled_rank_share(proc, k, width, height, stream, steps=3, images=16, world=8, rank=3):
-    """BASELINE config 4 split the way north_star words it: every image tiled over the 8 GPUs in row bands, one all-reduce
-    of images x k x 4 int64 per iteration (sharded.ShardedBatch) -- exactly the configuration of
-    tests/test_gpu_scale.py::test_cfg4_one_ranks_share_of_the_batch: rank 3's 16 bands of 8192 x 1024, one batched
-    accumulator tensor; the collective is replaced by the addition of a precomputed tensor of the same shape (one GPU
-    here).  Time of one Lloyd iteration of the rank's share, label maps included.  Not part of `value`."""
+def cfg4_tiled_rank_share(k, width, height, steps=3, images=16, world=8, rank=3):
+    """BASELINE config 4 split the way north_star words it, through the C ABI (kmg_group_lloyd_create_batch / _bind_batch): every image
+    tiled over the 8 GPUs in row bands, ONE all-reduce of images x k x 4 int64 per iteration.  This is rank 3's share -- its 16 bands
+    of 8192 x 1024 -- in a group of one rank with KMG_GROUP_FORCE_COLLECTIVES: the all-reduce is a real ncclAllReduce (of one rank:
+    the other seven ranks' sums are missing from the numbers, not from the clock).  Time of one iteration of the rank's share, label
+    maps included.  Not part of `value`."""
     import numpy as np
     import torch
     import kmeans_gpu_amd as kg
     from kmeans_gpu_amd import synth
-    from kmeans_gpu_amd.sharded import ShardedBatch, band_rows
-    r0, r1 = band_rows(height, rank, world)
+    r0, r1 = rank * height // world, (rank + 1) * height // world
     n_band, n = (r1 - r0) * width, width * height
-    bands, labels, backends = [], [], []
+    with _StdoutToStderr():
+        group = kg.Group(devices=[torch.cuda.current_device()], flags=kg.GROUP_FORCE_COLLECTIVES, shrink_max_dim=0)
+    proc = group.processor(0)
+    stream = torch.cuda.current_stream().cuda_stream
+    gl = kg.GroupLloyd(group, k, n_images=images)
+    bands, labels = [], []
     for i in range(images):
-        band = synth.uniform_rgba_torch(0x5EED0400 + i, n_band, first=r0 * width, device="cuda")
+        bands.append(synth.uniform_rgba_torch(0x5EED0400 + i, n_band, first=r0 * width, device="cuda"))
+        labels.append(torch.empty(n_band, dtype=torch.int32, device="cuda"))
+    gl.bind_batch([[b.data_ptr()] for b in bands], [[r0]] * images, [[r1 - r0]] * images, width, height, [[l.data_ptr()] for l in labels])
+    for i in range(images):
         sel = synth.uniform_rgba_at(0x5EED0400 + i, np.arange(k, dtype=np.uint64) * np.uint64(n // k))
         d_sel = torch.from_numpy(sel).cuda()
         lab = torch.empty((k, 3), dtype=torch.float32, device="cuda")
@@ -209,34 +212,21 @@ def cfg4_tiled_rank_share(proc, k, width, height, stream, steps=3, images=16, wo
         torch.cuda.synchronize()
         cent = np.ones((k, 4), np.float32)
         cent[:, :3] = lab.cpu().numpy()
-        s = kg.Lloyd(proc, k)
-        s.set_centroids(cent, stream)
-        s.prepare(band.data_ptr(), n_band, True, stream)
-        bands.append(band); backends.append(s)
-        labels.append(torch.empty(n_band, dtype=torch.int32, device="cuda"))
-    others = torch.ones((images, k, 4), dtype=torch.int64, device="cuda")     # stand-in for the other seven ranks' sums
-
-    def exchange(acc, active):
-        acc += others
-
-    batch = ShardedBatch(backends, k, bands, labels, stream=stream, collective=exchange)
-
-    def iteration():
-        for i, be in enumerate(batch.backends):
-            be.update(batch.acc[i].data_ptr(), stream)
-        batch._pass()
-    batch._pass()
-    iteration()
-    torch.cuda.synchronize()
+        gl.set_centroids(cent, image=i)
+    with _StdoutToStderr():
+        gl.prime()
+        gl.step()
+        gl.sync()
     t = time.perf_counter()
     for _ in range(steps):
-        iteration()
-    torch.cuda.synchronize()
+        gl.step()
+    gl.sync()
     ms = (time.perf_counter() - t) / steps * 1e3
-    for s in backends:
-        s.close()
+    gl.close()
+    group.close()
     return {"cfg4_tiled_rank_share_ms_per_iteration": ms, "cfg4_tiled_bands_per_rank": images,
-            "cfg4_tiled_collectives_per_iteration": 1}
+            "cfg4_tiled_collectives_per_iteration": 1,
+            "cfg4_tiled_driver": "kmg_group_lloyd_create_batch / _bind_batch / _step (C ABI), one ncclAllReduce of 16 x k x 4 int64 per iteration"}
 
 
 CFG2_WIDTH, CFG2_HEIGHT, CFG2_K = 4096, 4096, 16
@@ -475,7 +465,7 @@ def output_pass_timing(proc, rgba, n_pixels, stream, sh=None, steps=3, prep_ms=N
         del labels, out
         extra.update(other_distributions(proc, k3, n_pixels, stream, steps=max(steps, 2) * 3))
         extra.update(cfg4_rank_share(proc, k3, n_pixels, stream, steps=steps))
-        extra.update(cfg4_tiled_rank_share(proc, k3, WIDTH, n_pixels // WIDTH, stream, steps=steps))
+        extra.update(cfg4_tiled_rank_share(k3, WIDTH, n_pixels // WIDTH, steps=steps))
         if n_pixels == WIDTH * ROWS_PER_GPU:
             extra.update(cfg4_native_batch(k3, WIDTH, n_pixels // WIDTH))
         extra.update(reduce_end_to_end(proc, rgba, WIDTH, n_pixels // WIDTH, k3))

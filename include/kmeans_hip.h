@@ -464,6 +464,28 @@ KMG_API int kmg_group_lloyd_run(kmg_group_lloyd *gl, uint32_t *iterations);
 /* local device i's kmg_lloyd (profiling, statistics) and "table" (1) / "scan" (0) strategy of its band, once primed          */
 KMG_API kmg_lloyd *kmg_group_lloyd_member(kmg_group_lloyd *gl, uint32_t i, int *strategy);
 
+/* ---- a BATCH of images, each tiled over ALL ranks in row bands (BASELINE config 4 as north_star words it: "16 x 8192^2 tiled across 8
+ * GPUs with one centroid all-reduce"; SURVEY 8e: "batch the 16 images' accumulators into one collective").  Every image is an
+ * independent k-means problem with the same k; the accumulators of the whole batch are ONE block of n_images x k x 4 int64 per
+ * rank, so an iteration costs a single ncclAllReduce of n_images * k * 32 bytes instead of one per image; the sharded
+ * initialisation batches its keys and colours the same way.  (kmg_group_reduce_batch PLACES whole images instead -- zero
+ * collectives, the faster split whenever the batch has at least as many images as the node has GPUs; this is for batches of fewer,
+ * larger images, and for the configuration as worded.)
+ *   _create_batch   like _create, n_images >= 1 (1 = kmg_group_lloyd_create)
+ *   _bind_batch     d_rgba / row0 / rows / d_labels are indexed [image * n_local + local device], widths / heights [image];
+ *                   KMG_GROUP_CELLS is refused (it shards ONE image's cube pass; a batch's cube passes already fill the ranks)
+ *   _set / _get_centroids_image     one image's centroid table
+ *   _init / _prime / _step / _sync  as above, over all images: one collective per exchange
+ *   _run_batch      ChooseCentroidModule::compute for every image: an image whose convergence count reaches k at one of its
+ *                   every-check_period checks stops being updated (its rows stay in the collective, zero); iterations[image] as
+ *                   kmg_lloyd_run.  Results per image are those of kmg_lloyd_run on the whole image, bit for bit.              */
+KMG_API int kmg_group_lloyd_create_batch(kmg_group *g, uint32_t k, uint32_t n_images, kmg_group_lloyd **out);
+KMG_API int kmg_group_lloyd_bind_batch(kmg_group_lloyd *gl, const uint8_t *const *d_rgba, const uint32_t *row0, const uint32_t *rows,
+                                       const uint32_t *widths, const uint32_t *heights, uint32_t *const *d_labels, uint32_t flags);
+KMG_API int kmg_group_lloyd_set_centroids_image(kmg_group_lloyd *gl, uint32_t image, const float *centroids4);
+KMG_API int kmg_group_lloyd_get_centroids_image(kmg_group_lloyd *gl, uint32_t image, float *centroids4);
+KMG_API int kmg_group_lloyd_run_batch(kmg_group_lloyd *gl, uint32_t *iterations);
+
 #ifdef __cplusplus
 }
 #endif

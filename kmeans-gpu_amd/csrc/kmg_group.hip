@@ -612,48 +612,59 @@ extern "C" kmg_processor *kmg_group_processor(kmg_group *g, uint32_t i) { return
 extern "C" void *kmg_group_stream(kmg_group *g, uint32_t i) { return g && i < g->n_local ? (void *)g->ranks[i].st : nullptr; }
 
 // ---------------------------------------------------------------------------------------------
-// kmg_group_lloyd: the Lloyd loop over row bands (modules.rs:763-840 + the exchange step)
+// kmg_group_lloyd: the Lloyd loop over row bands (modules.rs:763-840 + the exchange step), for ONE image or a BATCH of images
+// that are each tiled over all ranks (BASELINE config 4 as north_star words it): the accumulators of the whole batch are one
+// block of n_images x k x 4 int64 per rank, so an iteration costs ONE all-reduce whatever the number of images.
 // ---------------------------------------------------------------------------------------------
 namespace {
-struct RankLloyd {
+struct RankLloyd {                       // one image's band on one rank
     kmg_lloyd *s = nullptr;
-    void *blk = nullptr;                 // the three small device buffers below
-    int64_t *d_acc = nullptr;            // k x 4: this band's sums, then the image's
-    uint64_t *d_key = nullptr;           // init: the arg-max key
+    int64_t *d_acc = nullptr;            // k x 4 inside the rank's block: this band's sums, then the image's
+    uint64_t *d_key = nullptr;           // init: the arg-max key (inside the rank's block, one per image)
     uint32_t *d_colour = nullptr;        // init: {colour of the winning pixel, 1} on its owner
-    uint32_t *d_dummy = nullptr;         // one pixel: what a rank without rows binds in a cell-sharded loop
     const uint8_t *band = nullptr;
     uint32_t *labels = nullptr;
-    uint32_t row0 = 0, rows = 0;
+    uint32_t row0 = 0, rows = 0, width = 0, height = 0;
     uint64_t n_local = 0, first = 0;
     bool prepared = false, table = false, cells = false;
     void *lab_t = nullptr, *ent_t = nullptr;
+};
+struct RankBlock {                       // what the images of one rank share: one device block, one collective per exchange
+    void *blk = nullptr;
+    int64_t *d_acc = nullptr;            // n_images x k x 4
+    uint64_t *d_key = nullptr;           // n_images
+    uint32_t *d_colour = nullptr;        // n_images x 2
+    uint32_t *d_dummy = nullptr;         // one pixel: what a rank without rows binds in a cell-sharded loop
 };
 }  // namespace
 
 struct kmg_group_lloyd {
     kmg_group *g = nullptr;
-    uint32_t k = 0, width = 0, height = 0, flags = 0;
+    uint32_t k = 0, n_images = 1, flags = 0;
     bool bound = false;
-    std::vector<RankLloyd> r;
+    std::vector<RankLloyd> r;            // [local rank][image]
+    std::vector<RankBlock> blocks;       // [local rank]
+    std::vector<uint8_t> active;         // [image]: still iterating (kmg_group_lloyd_run_batch); the same on every rank
+    RankLloyd &at(uint32_t rank_idx, uint32_t image) { return r[(size_t)rank_idx * n_images + image]; }
 };
 
 namespace {
 
-int rank_prepare(kmg_group_lloyd *gl, GroupRank &r)
+int rank_prepare(kmg_group_lloyd *gl, GroupRank &r, uint32_t image)
 {
-    RankLloyd &q = gl->r[r.idx];
+    RankLloyd &q = gl->at(r.idx, image);
     if (q.prepared) return KMG_OK;
     kmg_group *g = gl->g;
     q.cells = (gl->flags & KMG_GROUP_CELLS) != 0 && gl->k <= 256 && g->collectives;
     q.table = false;
     if (q.cells) {
         // once per image: the band's histogram, all-reduced into the image's; this rank's share of the colour cube
-        const uint64_t n_total = (uint64_t)gl->width * gl->height;
+        const uint64_t n_total = (uint64_t)q.width * q.height;
         if (n_total > 0xFFFFFFFFull) return fail(KMG_ERR_UNSUPPORTED, "image has more than 2^32-1 pixels");
         // (a rank without rows still takes its share of the cube: the table of ONE dummy pixel, its count taken out again)
+        const uint8_t *dummy = (const uint8_t *)gl->blocks[r.idx].d_dummy;
         if (q.n_local) KMG_TRY(kmg_lloyd_bind_image(q.s, q.band, q.n_local, r.st));
-        else KMG_TRY(kmg_lloyd_bind_image(q.s, (const uint8_t *)q.d_dummy, 1, r.st));
+        else KMG_TRY(kmg_lloyd_bind_image(q.s, dummy, 1, r.st));
         void *hist = nullptr;
         uint64_t hist_bytes = 0;
         KMG_TRY(kmg_lloyd_histogram_buffer(q.s, &hist, &hist_bytes));
@@ -675,110 +686,174 @@ int rank_prepare(kmg_group_lloyd *gl, GroupRank &r)
     return KMG_OK;
 }
 
-// labels + sums of the current centroids, and the exchange of the sums
+bool image_active(const kmg_group_lloyd *gl, uint32_t image) { return gl->active.empty() || gl->active[image] != 0; }
+
+// labels + sums of the current centroids for every (active) image of the batch, and ONE exchange of all their sums
 int rank_pass(kmg_group_lloyd *gl, GroupRank &r)
 {
-    RankLloyd &q = gl->r[r.idx];
     kmg_group *g = gl->g;
     const size_t acc_count = 4u * (size_t)gl->k;
-    KMG_TRY(rank_prepare(gl, r));
-    if (q.cells) {
-        const uint8_t *bound = q.n_local ? q.band : (const uint8_t *)q.d_dummy;
-        KMG_TRY(kmg_lloyd_assign_accumulate(q.s, bound, q.n_local ? q.n_local : 1, nullptr, q.d_acc, r.st));
-        KMG_TRY(allreduce(r, q.d_acc, acc_count, Op::SumI64, r.st));
+    RankBlock &blk = gl->blocks[r.idx];
+    for (uint32_t im = 0; im < gl->n_images; ++im) KMG_TRY(rank_prepare(gl, r, im));
+    RankLloyd &q0 = gl->at(r.idx, 0);
+    if (q0.cells) {
+        // (strong scaling of ONE image: kmg_group_lloyd_bind refuses KMG_GROUP_CELLS for a batch)
+        const uint8_t *bound = q0.n_local ? q0.band : (const uint8_t *)blk.d_dummy;
+        KMG_TRY(kmg_lloyd_assign_accumulate(q0.s, bound, q0.n_local ? q0.n_local : 1, nullptr, q0.d_acc, r.st));
+        KMG_TRY(allreduce(r, q0.d_acc, acc_count, Op::SumI64, r.st));
         // every rank's share of the per-colour labels (512 per cell) and of the cells' pair entries -> all ranks, in place
-        KMG_TRY(allgather_shares(r, q.lab_t, kCells, kCellColours, r.st));
-        KMG_TRY(allgather_shares(r, q.ent_t, kCells, sizeof(uint32_t), r.st));
-        if (q.labels && q.n_local) KMG_TRY(kmg_lloyd_labels_from_tables(q.s, q.band, q.n_local, q.labels, r.st));
+        KMG_TRY(allgather_shares(r, q0.lab_t, kCells, kCellColours, r.st));
+        KMG_TRY(allgather_shares(r, q0.ent_t, kCells, sizeof(uint32_t), r.st));
+        if (q0.labels && q0.n_local) KMG_TRY(kmg_lloyd_labels_from_tables(q0.s, q0.band, q0.n_local, q0.labels, r.st));
         return KMG_OK;
     }
-    if (q.n_local == 0) {
-        HIP_TRY(hipMemsetAsync(q.d_acc, 0, sizeof(int64_t) * acc_count, r.st));
-        return allreduce(r, q.d_acc, acc_count, Op::SumI64, r.st);
-    }
-    if (q.table && q.labels) {
-        // colour table: the sums come from the cube pass, the label map from a gather pass that feeds nothing in the loop
-        KMG_TRY(kmg_lloyd_assign_accumulate(q.s, q.band, q.n_local, nullptr, q.d_acc, r.st));
-        const bool beside = (gl->flags & KMG_GROUP_OVERLAP) != 0 && g->collectives && !g->loopback;
-        if (beside) {
-            HIP_TRY(hipEventRecord(r.ev_sums, r.st));
-            HIP_TRY(hipStreamWaitEvent(r.st_comm, r.ev_sums, 0));
-            KMG_TRY(allreduce(r, q.d_acc, acc_count, Op::SumI64, r.st_comm));
-            HIP_TRY(hipEventRecord(r.ev_done, r.st_comm));
+    // 1. the sums of every image's band (colour table: the cube pass; per-pixel scan: with its label map)
+    bool labels_later = false;
+    for (uint32_t im = 0; im < gl->n_images; ++im) {
+        RankLloyd &q = gl->at(r.idx, im);
+        if (!image_active(gl, im)) continue;                   // (its rows stay in the block, zero: the collective's shape is fixed)
+        if (q.n_local == 0) { HIP_TRY(hipMemsetAsync(q.d_acc, 0, sizeof(int64_t) * acc_count, r.st)); continue; }
+        if (q.table && q.labels) {
+            // colour table: the sums come from the cube pass, the label map from a gather pass that feeds nothing in the loop
+            KMG_TRY(kmg_lloyd_assign_accumulate(q.s, q.band, q.n_local, nullptr, q.d_acc, r.st));
+            labels_later = true;
         } else {
-            KMG_TRY(allreduce(r, q.d_acc, acc_count, Op::SumI64, r.st));
+            KMG_TRY(kmg_lloyd_assign_accumulate(q.s, q.band, q.n_local, q.labels, q.d_acc, r.st));
         }
-        KMG_TRY(kmg_lloyd_labels(q.s, q.band, q.n_local, q.labels, r.st));
-        if (beside) HIP_TRY(hipStreamWaitEvent(r.st, r.ev_done, 0));     // the compute stream waits for the collective, not the host
-        return KMG_OK;
     }
-    KMG_TRY(kmg_lloyd_assign_accumulate(q.s, q.band, q.n_local, q.labels, q.d_acc, r.st));
-    return allreduce(r, q.d_acc, acc_count, Op::SumI64, r.st);
+    // 2. ONE all-reduce of the batch's n_images x k x 4 sums (in line, or on the second stream beside the label passes)
+    const bool beside = labels_later && (gl->flags & KMG_GROUP_OVERLAP) != 0 && g->collectives && !g->loopback;
+    if (beside) {
+        HIP_TRY(hipEventRecord(r.ev_sums, r.st));
+        HIP_TRY(hipStreamWaitEvent(r.st_comm, r.ev_sums, 0));
+        KMG_TRY(allreduce(r, blk.d_acc, acc_count * gl->n_images, Op::SumI64, r.st_comm));
+        HIP_TRY(hipEventRecord(r.ev_done, r.st_comm));
+    } else {
+        KMG_TRY(allreduce(r, blk.d_acc, acc_count * gl->n_images, Op::SumI64, r.st));
+    }
+    // 3. the label maps of the colour-table images
+    if (labels_later)
+        for (uint32_t im = 0; im < gl->n_images; ++im) {
+            RankLloyd &q = gl->at(r.idx, im);
+            if (image_active(gl, im) && q.n_local && q.table && q.labels) KMG_TRY(kmg_lloyd_labels(q.s, q.band, q.n_local, q.labels, r.st));
+        }
+    if (beside) HIP_TRY(hipStreamWaitEvent(r.st, r.ev_done, 0));         // the compute stream waits for the collective, not the host
+    return KMG_OK;
 }
 
 bool fused_update(const kmg_group_lloyd *gl) { return (gl->flags & KMG_GROUP_FUSED_UPDATE) != 0 && !gl->g->collectives; }
 
+int rank_fused(kmg_group_lloyd *gl, GroupRank &r)
+{
+    for (uint32_t im = 0; im < gl->n_images; ++im) {
+        RankLloyd &q = gl->at(r.idx, im);
+        KMG_TRY(rank_prepare(gl, r, im));
+        if (q.n_local) KMG_TRY(kmg_lloyd_assign_update(q.s, q.band, q.n_local, q.labels, q.d_acc, 1, r.st));
+    }
+    return KMG_OK;
+}
+
+int rank_update(kmg_group_lloyd *gl, GroupRank &r)
+{
+    // modules.rs:773-788, from the image's sums: identical on every rank
+    for (uint32_t im = 0; im < gl->n_images; ++im)
+        if (image_active(gl, im)) KMG_TRY(kmg_lloyd_update(gl->at(r.idx, im).s, gl->at(r.idx, im).d_acc, r.st));
+    return KMG_OK;
+}
+
 int rank_prime(kmg_group_lloyd *gl, GroupRank &r)
 {
-    RankLloyd &q = gl->r[r.idx];
-    if (fused_update(gl) && q.n_local) {
-        KMG_TRY(rank_prepare(gl, r));
-        return kmg_lloyd_assign_update(q.s, q.band, q.n_local, q.labels, q.d_acc, 1, r.st);
-    }
+    if (fused_update(gl)) return rank_fused(gl, r);
     return rank_pass(gl, r);                                   // operations.rs:75-83
 }
 
 int rank_step(kmg_group_lloyd *gl, GroupRank &r)
 {
-    RankLloyd &q = gl->r[r.idx];
-    if (fused_update(gl) && q.n_local) return kmg_lloyd_assign_update(q.s, q.band, q.n_local, q.labels, q.d_acc, 1, r.st);
-    KMG_TRY(kmg_lloyd_update(q.s, q.d_acc, r.st));             // modules.rs:773-788, from the image's sums: identical on every rank
+    if (fused_update(gl)) return rank_fused(gl, r);
+    KMG_TRY(rank_update(gl, r));
     return rank_pass(gl, r);                                   // modules.rs:793-800
 }
 
+// ChooseCentroidModule::compute for every image of the batch: an image that has converged at one of its every-check_period
+// checks stops being updated (exactly like the single-image loop); its rows stay in the collective and carry nothing.
+// iterations[image] = the reference's `current_iteration` when that image's loop stopped.
 int rank_run(kmg_group_lloyd *gl, GroupRank &r, uint32_t *iterations)
 {
-    RankLloyd &q = gl->r[r.idx];
     const kmg_options &o = gl->g->opt.processor;
+    const size_t acc_count = 4u * (size_t)gl->k;
+    // (`active` is shared by the local ranks: every rank reads the same convergence counts -- all updated from the same sums -- and
+    // rank 0 alone writes it, between two meetings of the ranks)
+    auto meet = [&]() -> int {
+        if (gl->g->n_local > 1 && !gl->g->barrier.wait()) return fail(KMG_ERR_HIP, "another rank failed");
+        return KMG_OK;
+    };
     KMG_TRY(rank_pass(gl, r));
+    std::vector<uint32_t> its(gl->n_images, 0u);
     uint32_t it = 0;
     for (it = 0; it < o.max_iterations; ++it) {                // modules.rs:769
-        KMG_TRY(kmg_lloyd_update(q.s, q.d_acc, r.st));
+        bool any = false;
+        for (uint32_t im = 0; im < gl->n_images; ++im)
+            if (image_active(gl, im)) { any = true; its[im] = it; }
+        if (!any) break;
+        KMG_TRY(rank_update(gl, r));
         KMG_TRY(rank_pass(gl, r));
-        if (it > 0 && it % o.check_period == 0) {              // :802 -- the same count on every rank: all updated from the same sums
-            uint32_t conv = 0;
-            KMG_TRY(kmg_lloyd_converged_count(q.s, &conv, r.st));
-            if (conv >= gl->k) {
-                if (log_debug() && r.rank == 0) fprintf(stderr, "[kmeans_hip] We have convergence, checked at iteration %u (%u ranks)\n", it, gl->g->world);
-                break;
+        if (it > 0 && it % o.check_period == 0) {              // :802
+            std::vector<uint8_t> done(gl->n_images, 0);
+            for (uint32_t im = 0; im < gl->n_images; ++im) {
+                if (!image_active(gl, im)) continue;
+                uint32_t conv = 0;
+                KMG_TRY(kmg_lloyd_converged_count(gl->at(r.idx, im).s, &conv, r.st));
+                if (conv >= gl->k) {
+                    done[im] = 1;
+                    if (log_debug() && r.rank == 0) fprintf(stderr, "[kmeans_hip] image %u: we have convergence, checked at iteration %u (%u ranks)\n", im, it, gl->g->world);
+                }
             }
+            if (gl->n_images == 1u) { if (done[0]) break; continue; }
+            KMG_TRY(meet());                                   // nobody still reads `active` for this iteration
+            for (uint32_t im = 0; im < gl->n_images; ++im)
+                if (done[im]) {
+                    if (r.idx == 0) gl->active[im] = 0;
+                    HIP_TRY(hipMemsetAsync(gl->at(r.idx, im).d_acc, 0, sizeof(int64_t) * acc_count, r.st));
+                }
+            KMG_TRY(meet());
         }
     }
     HIP_TRY(hipStreamSynchronize(r.st));
-    if (iterations) *iterations = it < o.max_iterations ? it : o.max_iterations - 1;
+    if (iterations)
+        for (uint32_t im = 0; im < gl->n_images; ++im)
+            iterations[im] = gl->n_images == 1u ? (it < o.max_iterations ? it : o.max_iterations - 1) : its[im];
     return KMG_OK;
 }
 
-// PlusPlusInitModule::compute (modules.rs:946-1246) for an image sharded in row bands: every rank runs the pass of its band;
+// PlusPlusInitModule::compute (modules.rs:946-1246) for images sharded in row bands: every rank runs the pass of its band;
 // the arg-max is a MAX all-reduce of the 64-bit key (distance bits | image-wide position under the reference's tie rule),
 // the winning pixel's colour reaches all ranks with a SUM all-reduce of {colour, 1}, every rank sets the same centroid.
+// A batch does this for all its images at once: n_images keys / colours per collective.
 int rank_init(kmg_group_lloyd *gl, GroupRank &r)
 {
-    RankLloyd &q = gl->r[r.idx];
-    const uint8_t *band = q.n_local ? q.band : nullptr;
-    q.prepared = false;                                        // the initialisation starts a new problem (and may bind the band itself)
+    RankBlock &blk = gl->blocks[r.idx];
+    const uint32_t ni = gl->n_images;
+    for (uint32_t im = 0; im < ni; ++im) gl->at(r.idx, im).prepared = false;   // the initialisation starts a new problem (and may bind the band itself)
     auto publish = [&](uint32_t j) -> int {
-        KMG_TRY(kmg_lloyd_init_pick_band(q.s, band, q.n_local, q.first, q.d_key, q.d_colour, r.st));
-        KMG_TRY(allreduce(r, q.d_colour, 2, Op::SumU32, r.st));
-        return kmg_lloyd_set_centroid_rgba(q.s, j, q.d_colour, r.st);
+        for (uint32_t im = 0; im < ni; ++im) {
+            RankLloyd &q = gl->at(r.idx, im);
+            KMG_TRY(kmg_lloyd_init_pick_band(q.s, q.n_local ? q.band : nullptr, q.n_local, q.first, q.d_key, q.d_colour, r.st));
+        }
+        KMG_TRY(allreduce(r, blk.d_colour, 2u * ni, Op::SumU32, r.st));
+        for (uint32_t im = 0; im < ni; ++im) KMG_TRY(kmg_lloyd_set_centroid_rgba(gl->at(r.idx, im).s, j, gl->at(r.idx, im).d_colour, r.st));
+        return KMG_OK;
     };
-    const uint64_t key0 = kmg_init_first_key(gl->width, gl->height);   // plus_plus_init.wgsl:161-168 `initial`
-    HIP_TRY(hipMemcpyAsync(q.d_key, &key0, sizeof key0, hipMemcpyHostToDevice, r.st));
+    std::vector<uint64_t> key0(ni);
+    for (uint32_t im = 0; im < ni; ++im) key0[im] = kmg_init_first_key(gl->at(r.idx, im).width, gl->at(r.idx, im).height);   // plus_plus_init.wgsl:161-168 `initial`
+    HIP_TRY(hipMemcpyAsync(blk.d_key, key0.data(), sizeof(uint64_t) * ni, hipMemcpyHostToDevice, r.st));
     HIP_TRY(hipStreamSynchronize(r.st));                       // (key0 lives on this stack frame)
     KMG_TRY(publish(0));
     for (uint32_t j = 1; j < gl->k; ++j) {
-        KMG_TRY(kmg_lloyd_init_step(q.s, band, q.n_local, q.first, j, q.d_key, r.st));
-        KMG_TRY(allreduce(r, q.d_key, 1, Op::MaxU64, r.st));
+        for (uint32_t im = 0; im < ni; ++im) {
+            RankLloyd &q = gl->at(r.idx, im);
+            KMG_TRY(kmg_lloyd_init_step(q.s, q.n_local ? q.band : nullptr, q.n_local, q.first, j, q.d_key, r.st));
+        }
+        KMG_TRY(allreduce(r, blk.d_key, ni, Op::MaxU64, r.st));
         KMG_TRY(publish(j));
     }
     return KMG_OK;
@@ -787,58 +862,80 @@ int rank_init(kmg_group_lloyd *gl, GroupRank &r)
 void group_lloyd_free(kmg_group_lloyd *gl)
 {
     if (!gl) return;
-    for (uint32_t i = 0; i < gl->r.size(); ++i) {
+    for (uint32_t i = 0; i < gl->blocks.size(); ++i) {
         (void)hipSetDevice(gl->g->ranks[i].device);
-        if (gl->r[i].s) kmg_lloyd_destroy(gl->r[i].s);
-        if (gl->r[i].blk) (void)hipFree(gl->r[i].blk);
+        for (uint32_t im = 0; im < gl->n_images; ++im)
+            if (gl->at(i, im).s) kmg_lloyd_destroy(gl->at(i, im).s);
+        if (gl->blocks[i].blk) (void)hipFree(gl->blocks[i].blk);
     }
     delete gl;
 }
 
-int group_lloyd_new(kmg_group *g, uint32_t k, kmg_group_lloyd **out)
+int group_lloyd_new(kmg_group *g, uint32_t k, uint32_t n_images, kmg_group_lloyd **out)
 {
+    if (n_images == 0u || n_images > 4096u) return fail(KMG_ERR_INVALID_ARGUMENT, "a batch has 1 .. 4096 images");
     kmg_group_lloyd *gl = new (std::nothrow) kmg_group_lloyd();
     if (!gl) return fail(KMG_ERR_OUT_OF_MEMORY, "host allocation failed");
-    gl->g = g; gl->k = k;
-    gl->r.resize(g->n_local);
+    gl->g = g; gl->k = k; gl->n_images = n_images;
+    gl->r.resize((size_t)g->n_local * n_images);
+    gl->blocks.resize(g->n_local);
     struct Undo { kmg_group_lloyd *gl; ~Undo() { group_lloyd_free(gl); } } undo{gl};
     for (uint32_t i = 0; i < g->n_local; ++i) {
-        RankLloyd &q = gl->r[i];
-        KMG_TRY(kmg_lloyd_create(g->ranks[i].p, k, &q.s));
+        RankBlock &b = gl->blocks[i];
         HIP_TRY(hipSetDevice(g->ranks[i].device));
-        const size_t acc_bytes = (sizeof(int64_t) * 4u * k + 255u) & ~(size_t)255u;
-        HIP_TRY(hipMalloc(&q.blk, acc_bytes + 3 * 256));
-        HIP_TRY(hipMemset(q.blk, 0, acc_bytes + 3 * 256));
-        uint8_t *b = static_cast<uint8_t *>(q.blk);
-        q.d_acc = (int64_t *)b;
-        q.d_key = (uint64_t *)(b + acc_bytes);
-        q.d_colour = (uint32_t *)(b + acc_bytes + 256);
-        q.d_dummy = (uint32_t *)(b + acc_bytes + 512);
+        const size_t acc_bytes = (sizeof(int64_t) * 4u * k * n_images + 255u) & ~(size_t)255u;
+        const size_t key_bytes = (sizeof(uint64_t) * n_images + 255u) & ~(size_t)255u, col_bytes = (sizeof(uint32_t) * 2u * n_images + 255u) & ~(size_t)255u;
+        HIP_TRY(hipMalloc(&b.blk, acc_bytes + key_bytes + col_bytes + 256));
+        HIP_TRY(hipMemset(b.blk, 0, acc_bytes + key_bytes + col_bytes + 256));
+        uint8_t *base = static_cast<uint8_t *>(b.blk);
+        b.d_acc = (int64_t *)base;
+        b.d_key = (uint64_t *)(base + acc_bytes);
+        b.d_colour = (uint32_t *)(base + acc_bytes + key_bytes);
+        b.d_dummy = (uint32_t *)(base + acc_bytes + key_bytes + col_bytes);
+        for (uint32_t im = 0; im < n_images; ++im) {
+            RankLloyd &q = gl->at(i, im);
+            KMG_TRY(kmg_lloyd_create(g->ranks[i].p, k, &q.s));
+            q.d_acc = b.d_acc + (size_t)im * 4u * k;
+            q.d_key = b.d_key + im;
+            q.d_colour = b.d_colour + 2u * im;
+        }
     }
     undo.gl = nullptr;
     *out = gl;
     return KMG_OK;
 }
 
-int group_lloyd_bind(kmg_group_lloyd *gl, const uint8_t *const *d_rgba, const uint32_t *row0, const uint32_t *rows, uint32_t width,
-                     uint32_t height, uint32_t *const *d_labels, uint32_t flags)
+// d_rgba / row0 / rows / d_labels: [image * n_local + local rank]; widths / heights: [image]
+int group_lloyd_bind(kmg_group_lloyd *gl, const uint8_t *const *d_rgba, const uint32_t *row0, const uint32_t *rows, const uint32_t *widths,
+                     const uint32_t *heights, uint32_t *const *d_labels, uint32_t flags)
 {
-    if (!gl || !d_rgba || !row0 || !rows || !width || !height) return fail(KMG_ERR_INVALID_ARGUMENT, "bad group_lloyd_bind arguments");
-    if ((uint64_t)width * height > 0xFFFFFFFFull) return fail(KMG_ERR_UNSUPPORTED, "image has more than 2^32-1 pixels");
-    for (uint32_t i = 0; i < gl->g->n_local; ++i) {
-        if (rows[i] && !d_rgba[i]) return fail(KMG_ERR_INVALID_ARGUMENT, "band %u has rows but no pixels", i);
-        if ((uint64_t)row0[i] + rows[i] > height) return fail(KMG_ERR_INVALID_ARGUMENT, "band %u leaves the image", i);
+    if (!gl || !d_rgba || !row0 || !rows || !widths || !heights) return fail(KMG_ERR_INVALID_ARGUMENT, "bad group_lloyd_bind arguments");
+    const uint32_t nl = gl->g->n_local;
+    if ((flags & KMG_GROUP_CELLS) && gl->n_images > 1u)
+        return fail(KMG_ERR_INVALID_ARGUMENT, "KMG_GROUP_CELLS shards the cube pass of ONE image: not for a batch (its images' cube passes already fill the ranks)");
+    for (uint32_t im = 0; im < gl->n_images; ++im) {
+        if (!widths[im] || !heights[im]) return fail(KMG_ERR_INVALID_ARGUMENT, "image %u has zero width or height", im);
+        if ((uint64_t)widths[im] * heights[im] > 0xFFFFFFFFull) return fail(KMG_ERR_UNSUPPORTED, "image %u has more than 2^32-1 pixels", im);
+        for (uint32_t i = 0; i < nl; ++i) {
+            const size_t e = (size_t)im * nl + i;
+            if (rows[e] && !d_rgba[e]) return fail(KMG_ERR_INVALID_ARGUMENT, "band %u of image %u has rows but no pixels", i, im);
+            if ((uint64_t)row0[e] + rows[e] > heights[im]) return fail(KMG_ERR_INVALID_ARGUMENT, "band %u of image %u leaves the image", i, im);
+        }
     }
-    gl->width = width; gl->height = height; gl->flags = flags;
-    for (uint32_t i = 0; i < gl->g->n_local; ++i) {
-        RankLloyd &q = gl->r[i];
-        q.band = d_rgba[i];
-        q.labels = d_labels ? d_labels[i] : nullptr;
-        q.row0 = row0[i]; q.rows = rows[i];
-        q.n_local = (uint64_t)rows[i] * width;
-        q.first = (uint64_t)row0[i] * width;
-        q.prepared = false;
-    }
+    gl->flags = flags;
+    for (uint32_t im = 0; im < gl->n_images; ++im)
+        for (uint32_t i = 0; i < nl; ++i) {
+            const size_t e = (size_t)im * nl + i;
+            RankLloyd &q = gl->at(i, im);
+            q.band = d_rgba[e];
+            q.labels = d_labels ? d_labels[e] : nullptr;
+            q.row0 = row0[e]; q.rows = rows[e];
+            q.width = widths[im]; q.height = heights[im];
+            q.n_local = (uint64_t)rows[e] * widths[im];
+            q.first = (uint64_t)row0[e] * widths[im];
+            q.prepared = false;
+        }
+    gl->active.assign(gl->n_images > 1u ? gl->n_images : 0u, 1);
     gl->bound = true;
     return KMG_OK;
 }
@@ -850,7 +947,16 @@ try {
     if (!g || !out) return fail(KMG_ERR_INVALID_ARGUMENT, "bad group_lloyd_create arguments");
     *out = nullptr;
     std::lock_guard<std::mutex> lock(g->call_mu);
-    return group_lloyd_new(g, k, out);
+    return group_lloyd_new(g, k, 1u, out);
+}
+KMG_ABI_CATCH
+
+extern "C" int kmg_group_lloyd_create_batch(kmg_group *g, uint32_t k, uint32_t n_images, kmg_group_lloyd **out)
+try {
+    if (!g || !out) return fail(KMG_ERR_INVALID_ARGUMENT, "bad group_lloyd_create_batch arguments");
+    *out = nullptr;
+    std::lock_guard<std::mutex> lock(g->call_mu);
+    return group_lloyd_new(g, k, n_images, out);
 }
 KMG_ABI_CATCH
 
@@ -866,26 +972,54 @@ extern "C" int kmg_group_lloyd_bind(kmg_group_lloyd *gl, const uint8_t *const *d
                                     uint32_t width, uint32_t height, uint32_t *const *d_labels, uint32_t flags)
 try {
     if (!gl) return fail(KMG_ERR_INVALID_ARGUMENT, "group_lloyd is NULL");
+    if (gl->n_images != 1u) return fail(KMG_ERR_INVALID_ARGUMENT, "a batch is bound with kmg_group_lloyd_bind_batch");
     std::lock_guard<std::mutex> lock(gl->g->call_mu);
-    return group_lloyd_bind(gl, d_rgba, row0, rows, width, height, d_labels, flags);
+    return group_lloyd_bind(gl, d_rgba, row0, rows, &width, &height, d_labels, flags);
 }
 KMG_ABI_CATCH
 
-extern "C" int kmg_group_lloyd_set_centroids(kmg_group_lloyd *gl, const float *centroids4)
+extern "C" int kmg_group_lloyd_bind_batch(kmg_group_lloyd *gl, const uint8_t *const *d_rgba, const uint32_t *row0, const uint32_t *rows,
+                                          const uint32_t *widths, const uint32_t *heights, uint32_t *const *d_labels, uint32_t flags)
 try {
-    if (!gl || !centroids4) return fail(KMG_ERR_INVALID_ARGUMENT, "bad group_lloyd_set_centroids arguments");
+    if (!gl) return fail(KMG_ERR_INVALID_ARGUMENT, "group_lloyd is NULL");
     std::lock_guard<std::mutex> lock(gl->g->call_mu);
-    for (uint32_t i = 0; i < gl->g->n_local; ++i) KMG_TRY(kmg_lloyd_set_centroids(gl->r[i].s, centroids4, gl->g->ranks[i].st));
+    return group_lloyd_bind(gl, d_rgba, row0, rows, widths, heights, d_labels, flags);
+}
+KMG_ABI_CATCH
+
+static int group_lloyd_set_centroids(kmg_group_lloyd *gl, uint32_t image, const float *centroids4)
+{
+    if (!gl || !centroids4 || image >= gl->n_images) return fail(KMG_ERR_INVALID_ARGUMENT, "bad group_lloyd_set_centroids arguments");
+    std::lock_guard<std::mutex> lock(gl->g->call_mu);
+    for (uint32_t i = 0; i < gl->g->n_local; ++i) {
+        HIP_TRY(hipSetDevice(gl->g->ranks[i].device));
+        KMG_TRY(kmg_lloyd_set_centroids(gl->at(i, image).s, centroids4, gl->g->ranks[i].st));
+    }
     return KMG_OK;
 }
+
+static int group_lloyd_get_centroids(kmg_group_lloyd *gl, uint32_t image, float *centroids4)
+{
+    if (!gl || !centroids4 || image >= gl->n_images) return fail(KMG_ERR_INVALID_ARGUMENT, "bad group_lloyd_get_centroids arguments");
+    std::lock_guard<std::mutex> lock(gl->g->call_mu);
+    HIP_TRY(hipSetDevice(gl->g->ranks[0].device));
+    return kmg_lloyd_get_centroids(gl->at(0, image).s, centroids4, gl->g->ranks[0].st);      // (identical on every rank)
+}
+
+extern "C" int kmg_group_lloyd_set_centroids(kmg_group_lloyd *gl, const float *centroids4)
+try { return group_lloyd_set_centroids(gl, 0u, centroids4); }
 KMG_ABI_CATCH
 
 extern "C" int kmg_group_lloyd_get_centroids(kmg_group_lloyd *gl, float *centroids4)
-try {
-    if (!gl || !centroids4) return fail(KMG_ERR_INVALID_ARGUMENT, "bad group_lloyd_get_centroids arguments");
-    std::lock_guard<std::mutex> lock(gl->g->call_mu);
-    return kmg_lloyd_get_centroids(gl->r[0].s, centroids4, gl->g->ranks[0].st);      // (identical on every rank)
-}
+try { return group_lloyd_get_centroids(gl, 0u, centroids4); }
+KMG_ABI_CATCH
+
+extern "C" int kmg_group_lloyd_set_centroids_image(kmg_group_lloyd *gl, uint32_t image, const float *centroids4)
+try { return group_lloyd_set_centroids(gl, image, centroids4); }
+KMG_ABI_CATCH
+
+extern "C" int kmg_group_lloyd_get_centroids_image(kmg_group_lloyd *gl, uint32_t image, float *centroids4)
+try { return group_lloyd_get_centroids(gl, image, centroids4); }
 KMG_ABI_CATCH
 
 #define KMG_GROUP_CALL(name, body)                                                                     \
@@ -903,25 +1037,39 @@ KMG_GROUP_CALL(kmg_group_lloyd_prime, return rank_prime(gl, r))
 KMG_GROUP_CALL(kmg_group_lloyd_step, return rank_step(gl, r))
 KMG_GROUP_CALL(kmg_group_lloyd_sync, HIP_TRY(hipStreamSynchronize(r.st)); return KMG_OK)
 
-extern "C" int kmg_group_lloyd_run(kmg_group_lloyd *gl, uint32_t *iterations)
-try {
+static int group_lloyd_run(kmg_group_lloyd *gl, uint32_t *iterations)
+{
     if (!gl) return fail(KMG_ERR_INVALID_ARGUMENT, "kmg_group_lloyd_run: group_lloyd is NULL");
     if (!gl->bound) return fail(KMG_ERR_INVALID_ARGUMENT, "kmg_group_lloyd_run: no bands (kmg_group_lloyd_bind)");
     if (gl->flags & KMG_GROUP_FUSED_UPDATE)
         return fail(KMG_ERR_INVALID_ARGUMENT, "kmg_group_lloyd_run: KMG_GROUP_FUSED_UPDATE is for _prime / _step (the loop reads the convergence count between update and re-assignment)");
     std::lock_guard<std::mutex> lock(gl->g->call_mu);
-    std::vector<uint32_t> its(gl->g->n_local, 0u);
-    KMG_TRY(run_all(gl->g, true, [&](GroupRank &r) { return rank_run(gl, r, &its[r.idx]); }));
-    if (iterations) *iterations = its[0];
+    if (gl->n_images > 1u) gl->active.assign(gl->n_images, 1);
+    std::vector<uint32_t> its((size_t)gl->g->n_local * gl->n_images, 0u);
+    const int rc = run_all(gl->g, true, [&](GroupRank &r) { return rank_run(gl, r, &its[(size_t)r.idx * gl->n_images]); });
+    if (gl->n_images > 1u) gl->active.assign(gl->n_images, 1);           // (_prime / _step after the loop act on every image again)
+    KMG_TRY(rc);
+    if (iterations)
+        for (uint32_t im = 0; im < gl->n_images; ++im) iterations[im] = its[im];
     return KMG_OK;
 }
+
+extern "C" int kmg_group_lloyd_run(kmg_group_lloyd *gl, uint32_t *iterations)
+try {
+    if (gl && gl->n_images != 1u) return fail(KMG_ERR_INVALID_ARGUMENT, "a batch runs with kmg_group_lloyd_run_batch (one iteration count per image)");
+    return group_lloyd_run(gl, iterations);
+}
+KMG_ABI_CATCH
+
+extern "C" int kmg_group_lloyd_run_batch(kmg_group_lloyd *gl, uint32_t *iterations)
+try { return group_lloyd_run(gl, iterations); }
 KMG_ABI_CATCH
 
 extern "C" kmg_lloyd *kmg_group_lloyd_member(kmg_group_lloyd *gl, uint32_t i, int *strategy)
 try {
-    if (!gl || i >= gl->r.size()) return nullptr;
-    if (strategy) *strategy = gl->r[i].table ? 1 : 0;
-    return gl->r[i].s;
+    if (!gl || i >= gl->blocks.size()) return nullptr;
+    if (strategy) *strategy = gl->at(i, 0).table ? 1 : 0;
+    return gl->at(i, 0).s;
 }
 KMG_ABI_CATCH_NULL
 
@@ -997,7 +1145,7 @@ int host_call_rank(kmg_group *g, HostCall &c, GroupRank &r)
             KMG_TRY(rank_init(c.gl, r));
             uint32_t it = 0;
             KMG_TRY(rank_run(c.gl, r, &it));
-            if (r.idx == 0) KMG_TRY(kmg_lloyd_get_centroids(c.gl->r[0].s, c.c4.data(), r.st));
+            if (r.idx == 0) KMG_TRY(kmg_lloyd_get_centroids(c.gl->at(0, 0).s, c.c4.data(), r.st));
         } else if (r.idx == 0) {
             // the working image is tiny (<= 256 x 256, or the whole small image): one device, launch-bound
             const uint8_t *host_img = c.shrink ? c.shrunk.data() : c.rgba;
@@ -1065,9 +1213,9 @@ int host_call(kmg_group *g, HostCall &c)
             if (b > a) KMG_TRY(grow(&r.d_in, &r.in_cap, (size_t)(b - a + 1u) * c.w * 4u, r.st));
             bands[i] = r.d_in;
         }
-        KMG_TRY(group_lloyd_new(g, c.k, &c.gl));
+        KMG_TRY(group_lloyd_new(g, c.k, 1u, &c.gl));
         guard.gl = c.gl;
-        KMG_TRY(group_lloyd_bind(c.gl, (const uint8_t *const *)bands.data(), row0.data(), rows.data(), c.w, c.h, nullptr, 0u));
+        KMG_TRY(group_lloyd_bind(c.gl, (const uint8_t *const *)bands.data(), row0.data(), rows.data(), &c.w, &c.h, nullptr, 0u));
     }
     // (only the sharded full-resolution k-means issues collectives: everything else is per-band work with host rendezvous)
     return run_all(g, c.sharded_kmeans, [&](GroupRank &r) { return host_call_rank(g, c, r); });

@@ -9,7 +9,7 @@ It mirrors the reference crate's public surface (core/src/lib.rs:24-165):
 
 Images are numpy uint8 arrays of shape (height, width, 4) (tightly packed RGBA8,
 core/src/image.rs:20-48).  `Lloyd` exposes the device-pointer building blocks used by the
-sharded (one process per GPU) driver in `kmeans_gpu_amd.sharded` and by bench.py; PyTorch only
+multi-GPU layer (Group / GroupLloyd over kmg_group_*) and by bench.py; PyTorch only
 supplies device memory, streams and torch.distributed there.
 
 There is no CPU fallback: if the shared library is missing or no HIP device is usable, the
@@ -143,7 +143,8 @@ SYMBOLS = [
     "kmg_group_info", "kmg_group_processor", "kmg_group_stream", "kmg_group_palette", "kmg_group_find", "kmg_group_reduce",
     "kmg_group_reduce_batch", "kmg_group_lloyd_create", "kmg_group_lloyd_destroy", "kmg_group_lloyd_bind",
     "kmg_group_lloyd_set_centroids", "kmg_group_lloyd_get_centroids", "kmg_group_lloyd_init", "kmg_group_lloyd_prime",
-    "kmg_group_lloyd_step", "kmg_group_lloyd_sync", "kmg_group_lloyd_run", "kmg_group_lloyd_member",
+    "kmg_group_lloyd_step", "kmg_group_lloyd_sync", "kmg_group_lloyd_run", "kmg_group_lloyd_member", "kmg_group_lloyd_create_batch", "kmg_group_lloyd_bind_batch", "kmg_group_lloyd_set_centroids_image",
+    "kmg_group_lloyd_get_centroids_image", "kmg_group_lloyd_run_batch",
 ]
 
 
@@ -267,6 +268,12 @@ def lib():
     L.kmg_group_lloyd_run.argtypes = [vp, C.POINTER(C.c_uint32)]
     L.kmg_group_lloyd_member.argtypes = [vp, C.c_uint32, C.POINTER(C.c_int)]
     L.kmg_group_lloyd_member.restype = vp
+    L.kmg_group_lloyd_create_batch.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+    L.kmg_group_lloyd_bind_batch.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                             C.POINTER(C.c_uint32), C.POINTER(vp), C.c_uint32]
+    L.kmg_group_lloyd_set_centroids_image.argtypes = [vp, C.c_uint32, f32p]
+    L.kmg_group_lloyd_get_centroids_image.argtypes = [vp, C.c_uint32, f32p]
+    L.kmg_group_lloyd_run_batch.argtypes = [vp, C.POINTER(C.c_uint32)]
     _lib = L
     return L
 
@@ -562,7 +569,7 @@ class Lloyd:
     def init_centroids(self, d_rgba, width, height, stream=0):
         _check(lib().kmg_lloyd_init_centroids(self._h, C.c_void_p(d_rgba), width, height, C.c_void_p(stream)))
 
-    # sharded (row band) initialisation steps -- see kmeans_gpu_amd.sharded.sharded_init
+    # sharded (row band) initialisation steps -- what kmg_group_lloyd_init drives (tests/sharded_harness.py sharded_init)
     def init_step(self, d_rgba, n_local, first_index, j, d_key, stream=0):
         _check(lib().kmg_lloyd_init_step(self._h, C.c_void_p(d_rgba or None), n_local, first_index, j,
                                          C.c_void_p(d_key), C.c_void_p(stream)))
@@ -687,7 +694,7 @@ class Lloyd:
 
     def histogram_tensor(self):
         """the bound image's colour histogram as a torch tensor that ALIASES the library's buffer (int32 [2^24]) -- for the
-        all-reduce of a cell-sharded loop (kmeans_gpu_amd.sharded)"""
+        all-reduce of a cell-sharded loop (kmg_group_lloyd_* with KMG_GROUP_CELLS; tests/sharded_harness.py)"""
         ptr, nbytes = self.histogram_buffer()
         return _alias_tensor(ptr, nbytes // 4, "<i4")
 
@@ -870,14 +877,19 @@ class Group:
 
 
 class GroupLloyd:
-    """kmg_group_lloyd_*: one Lloyd problem over row bands resident on the group's devices (modules.rs:763-840 + the RCCL
-    all-reduce of the k x 4 int64 sums).  Pointers are raw device addresses, one per local device."""
+    """kmg_group_lloyd_*: one Lloyd problem -- or a BATCH of n_images problems, each image tiled over all ranks -- over row bands
+    resident on the group's devices (modules.rs:763-840 + ONE RCCL all-reduce of the n_images x k x 4 int64 sums per iteration).
+    Pointers are raw device addresses."""
 
-    def __init__(self, group, k):
+    def __init__(self, group, k, n_images=1):
         self._g = group
         self.k = int(k)
+        self.n_images = int(n_images)
         self._h = C.c_void_p()
-        _check(lib().kmg_group_lloyd_create(group.handle, self.k, C.byref(self._h)))
+        if self.n_images == 1:
+            _check(lib().kmg_group_lloyd_create(group.handle, self.k, C.byref(self._h)))
+        else:
+            _check(lib().kmg_group_lloyd_create_batch(group.handle, self.k, self.n_images, C.byref(self._h)))
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -900,14 +912,44 @@ class GroupLloyd:
         lab = (C.c_void_p * n)(*[int(p) or None for p in d_labels]) if d_labels is not None else None
         _check(lib().kmg_group_lloyd_bind(self._h, px, r0, rs, int(width), int(height), lab, int(flags)))
 
-    def set_centroids(self, centroids4):
-        c = np.ascontiguousarray(centroids4, np.float32).reshape(self.k, 4)
-        _check(lib().kmg_group_lloyd_set_centroids(self._h, _np_ptr(c)))
+    def bind_batch(self, d_rgba, row0, rows, widths, heights, d_labels=None, flags=0):
+        """d_rgba / row0 / rows / d_labels: [image][local device]; widths / heights: per image (or one number for all)"""
+        n, m = self._g.n_local, self.n_images
+        if isinstance(widths, int):
+            widths = [widths] * m
+        if isinstance(heights, int):
+            heights = [heights] * m
+        flat = lambda a: [v for per_image in a for v in per_image]
+        if not (len(d_rgba) == len(row0) == len(rows) == m) or any(len(x) != n for x in d_rgba):
+            raise ValueError("one band per image and local device")
+        px = (C.c_void_p * (n * m))(*[int(p) or None for p in flat(d_rgba)])
+        r0 = (C.c_uint32 * (n * m))(*[int(v) for v in flat(row0)])
+        rs = (C.c_uint32 * (n * m))(*[int(v) for v in flat(rows)])
+        ws = (C.c_uint32 * m)(*[int(v) for v in widths])
+        hs = (C.c_uint32 * m)(*[int(v) for v in heights])
+        lab = (C.c_void_p * (n * m))(*[int(p) or None for p in flat(d_labels)]) if d_labels is not None else None
+        _check(lib().kmg_group_lloyd_bind_batch(self._h, px, r0, rs, ws, hs, lab, int(flags)))
 
-    def get_centroids(self):
+    def set_centroids(self, centroids4, image=None):
+        c = np.ascontiguousarray(centroids4, np.float32).reshape(self.k, 4)
+        if image is None:
+            _check(lib().kmg_group_lloyd_set_centroids(self._h, _np_ptr(c)))
+        else:
+            _check(lib().kmg_group_lloyd_set_centroids_image(self._h, int(image), _np_ptr(c)))
+
+    def get_centroids(self, image=None):
         out = np.empty((self.k, 4), np.float32)
-        _check(lib().kmg_group_lloyd_get_centroids(self._h, _np_ptr(out)))
+        if image is None:
+            _check(lib().kmg_group_lloyd_get_centroids(self._h, _np_ptr(out)))
+        else:
+            _check(lib().kmg_group_lloyd_get_centroids_image(self._h, int(image), _np_ptr(out)))
         return out
+
+    def run_batch(self):
+        """every image to its own convergence; the iteration each one stopped at"""
+        its = (C.c_uint32 * self.n_images)()
+        _check(lib().kmg_group_lloyd_run_batch(self._h, its))
+        return [int(v) for v in its]
 
     def init(self):
         _check(lib().kmg_group_lloyd_init(self._h))

@@ -1,5 +1,5 @@
 """Child process of tests/test_gpu_dist.py (not a test module): one rank of a torch.distributed group that drives
-kmeans_gpu_amd.sharded.ShardedLloyd with the REAL library (libkmeans_hip.so) on cuda:0 and compares it with the unsharded
+tests/sharded_harness.py ShardedLloyd with the REAL library (libkmeans_hip.so) on cuda:0 and compares it with the unsharded
 loop computed in the same process.
 
     RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT from the environment;  argv: backend (nccl | gloo)
@@ -24,7 +24,7 @@ def main():
     import torch.distributed as dist
     import kmeans_gpu_amd as kg
     from kmeans_gpu_amd import synth
-    from kmeans_gpu_amd.sharded import ShardedLloyd, band_rows
+    from sharded_harness import ShardedLloyd, band_rows
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     if backend == "nccl":

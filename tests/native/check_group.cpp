@@ -229,6 +229,71 @@ int main(int argc, char **argv)
                 printf("flags %u: %u iterations, strategy of rank 0: %s\n", flags, it_group, strategy ? "table" : "scan");
                 kmg_group_lloyd_destroy(gl);
             }
+            // ---- a BATCH of three images, each tiled over all ranks (BASELINE config 4 as north_star words it): one accumulator block, one
+            // all-reduce per iteration, per-image convergence = three single-processor runs, byte for byte ----
+            {
+                const uint32_t bw[3] = {w, w / 2 + 3, 300}, bh[3] = {h, h / 2 + 1, 2 * ranks + 1};     // (the third: bands of two or three rows)
+                const size_t off_px[3] = {0, 5, 11};                                                  // (any readable pixels of the image)
+                std::vector<std::vector<float>> c_want(3, std::vector<float>(4 * k)), c0(3, std::vector<float>(4 * k));
+                std::vector<std::vector<uint32_t>> lab_want(3);
+                uint32_t it_want[3] = {0, 0, 0};
+                std::vector<const uint8_t *> b_px(3 * ranks);
+                std::vector<uint32_t *> b_lab(3 * ranks);
+                std::vector<uint32_t> b_row0(3 * ranks), b_rows(3 * ranks);
+                size_t lab_off = 0;
+                for (int im = 0; im < 3; ++im) {
+                    const uint8_t *d_im = d_img + off_px[im] * 4;
+                    const uint64_t nn = (uint64_t)bw[im] * bh[im];
+                    CHECK(kmg_lloyd_init_centroids(s, d_im, bw[im], bh[im], nullptr));
+                    CHECK(kmg_lloyd_get_centroids(s, c0[im].data(), nullptr));
+                    CHECK(kmg_lloyd_run(s, d_im, nn, d_lab_one, &it_want[im], nullptr));
+                    CHECK(kmg_lloyd_get_centroids(s, c_want[im].data(), nullptr));
+                    lab_want[im].resize(nn);
+                    HIPCHECK(hipMemcpy(lab_want[im].data(), d_lab_one, nn * 4, hipMemcpyDeviceToHost));
+                    for (uint32_t i = 0; i < ranks; ++i) {
+                        const uint32_t a = (uint32_t)((uint64_t)i * bh[im] / ranks), b = (uint32_t)((uint64_t)(i + 1) * bh[im] / ranks);
+                        b_row0[im * ranks + i] = a; b_rows[im * ranks + i] = b - a;
+                        b_px[im * ranks + i] = d_im + (size_t)a * bw[im] * 4;
+                        b_lab[im * ranks + i] = d_lab_group + lab_off + (size_t)a * bw[im];
+                    }
+                    lab_off += nn;
+                }
+                EXPECT(lab_off <= n);
+                kmg_group_lloyd *gb = nullptr;
+                CHECK(kmg_group_lloyd_create_batch(g, k, 3, &gb));
+                EXPECT(kmg_group_lloyd_bind_batch(gb, b_px.data(), b_row0.data(), b_rows.data(), bw, bh, b_lab.data(), KMG_GROUP_CELLS) == KMG_ERR_INVALID_ARGUMENT);
+                uint32_t it3[3] = {9, 9, 9};
+                EXPECT(kmg_group_lloyd_run(gb, it3) == KMG_ERR_INVALID_ARGUMENT);                    // (no bands yet)
+                CHECK(kmg_group_lloyd_bind_batch(gb, b_px.data(), b_row0.data(), b_rows.data(), bw, bh, b_lab.data(), 0u));
+                EXPECT(kmg_group_lloyd_run(gb, it3) == KMG_ERR_INVALID_ARGUMENT && strstr(kmg_last_error(), "run_batch"));
+                CHECK(kmg_group_lloyd_init(gb));                                                     // the sharded initialisation, batched collectives
+                for (uint32_t im = 0; im < 3; ++im) {
+                    CHECK(kmg_group_lloyd_get_centroids_image(gb, im, c_group.data()));
+                    EXPECT(!memcmp(c0[im].data(), c_group.data(), sizeof(float) * 4 * k));
+                }
+                HIPCHECK(hipMemset(d_lab_group, 0xFF, n * 4));
+                CHECK(kmg_group_lloyd_run_batch(gb, it3));
+                lab_off = 0;
+                for (uint32_t im = 0; im < 3; ++im) {
+                    const uint64_t nn = (uint64_t)bw[im] * bh[im];
+                    CHECK(kmg_group_lloyd_get_centroids_image(gb, im, c_group.data()));
+                    EXPECT(it3[im] == it_want[im]);
+                    EXPECT(!memcmp(c_want[im].data(), c_group.data(), sizeof(float) * 4 * k));
+                    std::vector<uint32_t> got(nn);
+                    HIPCHECK(hipMemcpy(got.data(), d_lab_group + lab_off, nn * 4, hipMemcpyDeviceToHost));
+                    EXPECT(got == lab_want[im]);
+                    lab_off += nn;
+                }
+                // set_centroids_image + prime + steps: the same centroids as the loop after the same number of updates (image 1)
+                for (uint32_t im = 0; im < 3; ++im) CHECK(kmg_group_lloyd_set_centroids_image(gb, im, c0[im].data()));
+                CHECK(kmg_group_lloyd_prime(gb));
+                for (uint32_t i = 0; i <= it_want[1]; ++i) CHECK(kmg_group_lloyd_step(gb));
+                CHECK(kmg_group_lloyd_sync(gb));
+                CHECK(kmg_group_lloyd_get_centroids_image(gb, 1, c_group.data()));
+                EXPECT(!memcmp(c_want[1].data(), c_group.data(), sizeof(float) * 4 * k));
+                printf("batch of 3 tiled images: iterations %u %u %u\n", it3[0], it3[1], it3[2]);
+                kmg_group_lloyd_destroy(gb);
+            }
             kmg_lloyd_destroy(s);
             HIPCHECK(hipFree(d_img)); HIPCHECK(hipFree(d_lab_one)); HIPCHECK(hipFree(d_lab_group));
         }

@@ -1,5 +1,9 @@
-"""Row-band data-parallel Lloyd loop: one process per GPU, torch.distributed (RCCL) for the single
-exchange step of the path.
+"""TEST HARNESS (since round 6; rounds 1-4: kmeans_gpu_amd/sharded.py, the product's multi-GPU layer -- superseded by the C ABI's
+kmg_group_*, csrc/kmg_group.hip).  What is left of it serves the CPU tests: tests/test_sharded_gloo.py drives these classes with an
+oracle-backed stand-in over gloo (world 2 and 3) -- the data flow of row bands, cell shares, batches and the sharded initialisation --
+and tests/dist_child.py / test_gpu_table.py reuse band_rows / cell_range / ShardedBatch around the real kernels.
+
+Row-band data-parallel Lloyd loop: one process per GPU, torch.distributed for the single exchange step of the path.
 
 The reference has no multi-device path.  Sharding rule: rank g of G owns the
 image rows [g*H//G, (g+1)*H//G).  Assignment and the per-pixel half of the update are independent

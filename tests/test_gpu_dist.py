@@ -1,4 +1,4 @@
-"""The multi-rank code of kmeans_gpu_amd.sharded on the GPU box, with real collectives (-m gpu).  Every rank is a FRESH
+"""The multi-rank code of tests/sharded_harness.py on the GPU box, with real collectives (-m gpu).  Every rank is a FRESH
 child process (started before it touches the GPU: tests/dist_child.py) -- one rank through RCCL, and two / three ranks that
 share the box's one GPU through gloo -- and compares ShardedLloyd (row bands; cells=True) with the unsharded loop."""
 import os

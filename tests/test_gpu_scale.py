@@ -374,29 +374,30 @@ def test_full_size_find_meld_rows_vs_oracle(torch_cuda, oracle):
     p.close()
 
 
-def test_cfg4_one_ranks_share_of_the_batch(torch_cuda, oracle):
-    """BASELINE config 4: 16 images of 8192x8192 (seeds 0x5EED0400 + i), k=256, each tiled over 8 GPUs in row
-    bands; this is rank 3's share -- 16 bands of 8192x1024 through ShardedBatch (one accumulator tensor, one
-    exchange per iteration).  The exchange is emulated on the same GPU: the other seven ranks' contribution
-    = the sums of the complementary 7168 rows under the rank's current centroids.  After three iterations the
-    centroids and the band's labels equal the unsharded run on the whole image, and image 0 equals the oracle."""
+def test_cfg4_batch_tiled_over_the_ranks_through_the_c_abi(torch_cuda, oracle):
+    """BASELINE config 4 as north_star words it, behind the C ABI (kmg_group_lloyd_create_batch / _bind_batch / _run_batch): 16 images
+    of 8192x8192 (seeds 0x5EED0400 + i), k=256, each TILED over the ranks in row bands, ONE all-reduce of the batch's 16 x k x 4
+    sums per iteration.  The rank under test holds rows [3072, 4096) of every image -- rank 3 of 8 -- and two more ranks of the
+    same loopback group on this GPU hold the rows above and below (the other seven ranks' share), so the exchange is the library's
+    own.  After three iterations every image's centroids and labels equal the unsharded run on the whole image, and image 0's
+    band equals the oracle."""
     import kmeans_gpu_amd as kg
     from kmeans_gpu_amd import synth
-    from kmeans_gpu_amd.sharded import ShardedBatch, band_rows
     torch = torch_cuda
     st = _stream(torch)
     w = h = 8192
-    k, images, world, rank, iters = 256, 16, 8, 3, 3
-    r0, r1 = band_rows(h, rank, world)
-    n_band, n = (r1 - r0) * w, w * h
+    k, images, iters = 256, 16, 3
+    bands_rows = [(0, 3072), (3072, 4096), (4096, 8192)]           # rank 3 of 8's band in the middle
+    r0, r1 = bands_rows[1]
+    n = w * h
     p = kg.ImageProcessor(shrink_max_dim=0, max_iterations=iters, check_period=8)
     cent0 = []
     for i in range(images):
         sel = synth.uniform_rgba_at(synth.SEED_CFG4 + i, np.arange(k, dtype=np.uint64) * np.uint64(n // k))
         cent0.append(oracle.centroids4(oracle.rgb_to_lab(sel)))
 
-    # unsharded runs, one image at a time (centroids + the band's labels kept)
-    want = []
+    # unsharded runs, one image at a time (centroids + the band's labels kept); the images stay resident for the batch
+    want, imgs = [], []
     for i in range(images):
         img = synth.uniform_rgba_torch(synth.SEED_CFG4 + i, n, device="cuda")
         s = kg.Lloyd(p, k)
@@ -404,47 +405,31 @@ def test_cfg4_one_ranks_share_of_the_batch(torch_cuda, oracle):
         labels = torch.zeros(n, dtype=torch.int32, device="cuda")
         s.run(img.data_ptr(), n, labels.data_ptr(), st)
         want.append((s.get_centroids(st), labels[r0 * w:r1 * w].clone()))
-        if i == 0:                                                  # the oracle on image 0's band, final centroids' predecessor
+        if i == 0:
             host_band = img[r0 * w:r1 * w].cpu().numpy()
         s.close()
-        del img, labels
-    torch.cuda.empty_cache()
-
-    # the rank's share: its band of every image + a helper over the complementary rows (the other 7 ranks)
-    bands, others, backends, helpers, labels = [], [], [], [], []
-    for i in range(images):
-        band = synth.uniform_rgba_torch(synth.SEED_CFG4 + i, n_band, first=r0 * w, device="cuda")
-        top = synth.uniform_rgba_torch(synth.SEED_CFG4 + i, r0 * w, first=0, device="cuda")
-        bottom = synth.uniform_rgba_torch(synth.SEED_CFG4 + i, n - r1 * w, first=r1 * w, device="cuda")
-        other = torch.cat([top, bottom])
-        s = kg.Lloyd(p, k)
-        s.set_centroids(cent0[i], st)
-        s.prepare(band.data_ptr(), n_band, True, st)
-        hlp = kg.Lloyd(p, k)
-        hlp.bind_image(other.data_ptr(), n - n_band, st)
-        bands.append(band); others.append(other); backends.append(s); helpers.append(hlp)
-        labels.append(torch.zeros(n_band, dtype=torch.int32, device="cuda"))
-    rest = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
-
-    def other_ranks(acc, active):
-        for i in range(images):
-            if not active[i]:
-                continue
-            helpers[i].set_centroids(backends[i].get_centroids(st), st)
-            helpers[i].assign_accumulate(others[i].data_ptr(), n - n_band, 0, rest.data_ptr(), st)
-            acc[i] += rest
-
-    batch = ShardedBatch(backends, k, bands, labels, stream=st, collective=other_ranks)
-    batch.run(iters, 8)
+        imgs.append(img)
+        del labels
     torch.cuda.synchronize()
-    for i in range(images):
-        assert np.array_equal(backends[i].get_centroids(st).view(np.uint32), want[i][0].view(np.uint32)), f"image {i}"
-        assert torch.equal(labels[i], want[i][1]), f"image {i}"
-    wl, _ = oracle.assign_accumulate_rgba(host_band, backends[0].get_centroids(st))
-    assert np.array_equal(labels[0].cpu().numpy().view(np.uint32), wl)
-    for s in backends + helpers:
-        s.close()
     p.close()
+
+    with kg.Group(devices=[0, 0, 0], flags=kg.GROUP_LOOPBACK, shrink_max_dim=0, max_iterations=iters, check_period=8) as group:
+        gl = kg.GroupLloyd(group, k, n_images=images)
+        labels = [torch.zeros(n, dtype=torch.int32, device="cuda") for _ in range(images)]
+        gl.bind_batch([[img.data_ptr() + a * w * 4 for a, _ in bands_rows] for img in imgs],
+                      [[a for a, _ in bands_rows]] * images, [[b - a for a, b in bands_rows]] * images, w, h,
+                      [[lab.data_ptr() + a * w * 4 for a, _ in bands_rows] for lab in labels])
+        for i in range(images):
+            gl.set_centroids(cent0[i], image=i)
+        its = gl.run_batch()
+        assert its == [iters - 1] * images, its
+        for i in range(images):
+            got = gl.get_centroids(image=i)
+            assert np.array_equal(got.view(np.uint32), want[i][0].view(np.uint32)), f"image {i}"
+            assert torch.equal(labels[i][r0 * w:r1 * w], want[i][1]), f"image {i}"
+        wl, _ = oracle.assign_accumulate_rgba(host_band, gl.get_centroids(image=0))
+        assert np.array_equal(labels[0][r0 * w:r1 * w].cpu().numpy().view(np.uint32), wl)
+        gl.close()
 
 
 def test_band_with_random_alpha_equals_the_oracle_and_the_opaque_band(torch_cuda, oracle, monkeypatch):

@@ -254,7 +254,7 @@ def test_two_bands_on_one_gpu_equal_unsharded(torch_cuda, oracle, monkeypatch, s
     accumulators summed (what the RCCL all-reduce does), both updated from the sum -- must equal the
     unsharded run and the oracle bit-for-bit, for either strategy."""
     import kmeans_gpu_amd as kg
-    from kmeans_gpu_amd.sharded import band_rows
+    from sharded_harness import band_rows
     torch = torch_cuda
     _set_strategy(strategy)
     w, h, k = 512, 301, 24
@@ -392,7 +392,7 @@ def test_replace_output_pass_table_equals_scan(torch_cuda, oracle, monkeypatch, 
 def test_batch_of_images_on_one_gpu(torch_cuda, processor, oracle):
     """ShardedBatch with the real kernels (one rank): three images, one accumulator tensor"""
     import kmeans_gpu_amd as kg
-    from kmeans_gpu_amd.sharded import ShardedBatch
+    from sharded_harness import ShardedBatch
     torch = torch_cuda
     st = _stream(torch)
     k, shapes = 6, [(200, 150), (333, 77), (64, 64)]
@@ -425,7 +425,7 @@ def test_sharded_init_steps_equal_unsharded_init(torch_cuda, processor, oracle, 
     collectives emulated on one GPU, equals the unsharded device init and the oracle -- with the passes
     over the band's pixels ("brute") and over its colours ("table")"""
     import kmeans_gpu_amd as kg
-    from kmeans_gpu_amd.sharded import band_rows
+    from sharded_harness import band_rows
     torch = torch_cuda
     st = _stream(torch)
     _set_strategy(strategy)
@@ -1028,13 +1028,13 @@ def test_assign_update_equals_the_two_calls(torch_cuda, oracle, monkeypatch, k, 
 
 @pytest.mark.parametrize("world", [2, 4])
 def test_cell_sharded_cube_pass_equals_unsharded(torch_cuda, oracle, tokyo, monkeypatch, world):
-    """The cell-sharded loop of kmeans_gpu_amd.sharded (ShardedLloyd(cells=True)) with the real kernels, `world` ranks emulated
+    """The cell-sharded loop (tests/sharded_harness.py ShardedLloyd(cells=True)) with the real kernels, `world` ranks emulated
     on one GPU in lockstep: band histograms summed into every rank's table (histogram_tensor / rebuild_from_histogram), each
     rank's cube pass over its share of the cube (set_cell_share), the k x 4 sums added up, the ranks' shares of the label
     tables copied to all (table_tensors), every band's label map from labels_from_tables -- labels, sums and centroids
     of five iterations equal the unsharded run and the oracle.  The photograph has hot cells (kmg_table.h)."""
     import kmeans_gpu_amd as kg
-    from kmeans_gpu_amd.sharded import band_rows, cell_range
+    from sharded_harness import band_rows, cell_range
     torch = torch_cuda
     st = _stream(torch)
     _set_strategy("table")

@@ -1,4 +1,4 @@
-"""The N > 1 path on CPU: two gloo ranks drive kmeans_gpu_amd.sharded.ShardedLloyd (the host logic
+"""The N > 1 path on CPU: two gloo ranks drive tests/sharded_harness.py ShardedLloyd (the host logic
 bench.py and a multi-GPU caller use) with an oracle-backed stand-in for the per-GPU kernels, and must
 reproduce the unsharded oracle bit-for-bit (integer accumulators make the all-reduce exact)."""
 import os
@@ -52,7 +52,7 @@ def _worker(rank, world, port, q, split=False):
     sys.path.insert(0, os.path.join(ROOT, "kmeans-gpu_amd", "python"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    from kmeans_gpu_amd.sharded import ShardedLloyd, band_rows
+    from sharded_harness import ShardedLloyd, band_rows
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -106,7 +106,7 @@ def test_sharded_lloyd_equals_unsharded(oracle, world, split):
 
 
 def test_band_rows_partition():
-    from kmeans_gpu_amd.sharded import band_rows
+    from sharded_harness import band_rows
     for h in (1, 7, 513, 8192):
         for g in (1, 2, 3, 8):
             rows = [band_rows(h, r, g) for r in range(g)]
@@ -119,7 +119,7 @@ def _batch_worker(rank, world, port, q):
     sys.path.insert(0, os.path.join(ROOT, "kmeans-gpu_amd", "python"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    from kmeans_gpu_amd.sharded import ShardedBatch, band_rows
+    from sharded_harness import ShardedBatch, band_rows
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -143,7 +143,7 @@ def _batch_worker(rank, world, port, q):
 
 def test_sharded_batch_equals_per_image_oracle(oracle):
     """BASELINE config 4 in miniature: 3 images tiled over 2 ranks, one all-reduce per iteration"""
-    from kmeans_gpu_amd.sharded import band_rows
+    from sharded_harness import band_rows
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -172,7 +172,7 @@ def _placed_worker(rank, world, port, q):
     sys.path.insert(0, os.path.join(ROOT, "kmeans-gpu_amd", "python"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    from kmeans_gpu_amd.sharded import PlacedBatch, images_of_rank
+    from sharded_harness import PlacedBatch, images_of_rank
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -201,7 +201,7 @@ def _placed_worker(rank, world, port, q):
 def test_placed_batch_whole_images_no_collective(oracle, world):
     """BASELINE config 4 as shipped when the batch is at least as large as the node: image i on rank
     i % world, every image an independent loop, NO collective -- results equal the per-image oracle"""
-    from kmeans_gpu_amd.sharded import images_of_rank
+    from sharded_harness import images_of_rank
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -276,7 +276,7 @@ def _init_worker(rank, world, port, q):
     sys.path.insert(0, os.path.join(ROOT, "kmeans-gpu_amd", "python"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    from kmeans_gpu_amd.sharded import ShardedLloyd, band_rows, sharded_init
+    from sharded_harness import ShardedLloyd, band_rows, sharded_init
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -388,7 +388,7 @@ def _cells_worker(rank, world, port, q):
     sys.path.insert(0, os.path.join(ROOT, "kmeans-gpu_amd", "python"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    from kmeans_gpu_amd.sharded import ShardedLloyd, band_rows
+    from sharded_harness import ShardedLloyd, band_rows
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)

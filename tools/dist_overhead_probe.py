@@ -10,7 +10,8 @@ os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
 import numpy as np, torch, torch.distributed as dist
 import kmeans_gpu_amd as kg
 from kmeans_gpu_amd import synth
-from kmeans_gpu_amd.sharded import ShardedLloyd
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from sharded_harness import ShardedLloyd
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1)
 W = 8192; n = W * W; k = 256
