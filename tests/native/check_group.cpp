@@ -240,7 +240,10 @@ int main(int argc, char **argv)
                 std::vector<const uint8_t *> b_px(3 * ranks);
                 std::vector<uint32_t *> b_lab(3 * ranks);
                 std::vector<uint32_t> b_row0(3 * ranks), b_rows(3 * ranks);
-                size_t lab_off = 0;
+                size_t lab_off = 0, lab_total = 0;
+                for (int im = 0; im < 3; ++im) lab_total += (size_t)bw[im] * bh[im];
+                uint32_t *d_lab_batch = nullptr;                                                      // the three label maps, one after the other
+                HIPCHECK(hipMalloc((void **)&d_lab_batch, lab_total * 4));
                 for (int im = 0; im < 3; ++im) {
                     const uint8_t *d_im = d_img + off_px[im] * 4;
                     const uint64_t nn = (uint64_t)bw[im] * bh[im];
@@ -254,11 +257,11 @@ int main(int argc, char **argv)
                         const uint32_t a = (uint32_t)((uint64_t)i * bh[im] / ranks), b = (uint32_t)((uint64_t)(i + 1) * bh[im] / ranks);
                         b_row0[im * ranks + i] = a; b_rows[im * ranks + i] = b - a;
                         b_px[im * ranks + i] = d_im + (size_t)a * bw[im] * 4;
-                        b_lab[im * ranks + i] = d_lab_group + lab_off + (size_t)a * bw[im];
+                        b_lab[im * ranks + i] = d_lab_batch + lab_off + (size_t)a * bw[im];
                     }
                     lab_off += nn;
                 }
-                EXPECT(lab_off <= n);
+                EXPECT(lab_off == lab_total);
                 kmg_group_lloyd *gb = nullptr;
                 CHECK(kmg_group_lloyd_create_batch(g, k, 3, &gb));
                 EXPECT(kmg_group_lloyd_bind_batch(gb, b_px.data(), b_row0.data(), b_rows.data(), bw, bh, b_lab.data(), KMG_GROUP_CELLS) == KMG_ERR_INVALID_ARGUMENT);
@@ -271,7 +274,7 @@ int main(int argc, char **argv)
                     CHECK(kmg_group_lloyd_get_centroids_image(gb, im, c_group.data()));
                     EXPECT(!memcmp(c0[im].data(), c_group.data(), sizeof(float) * 4 * k));
                 }
-                HIPCHECK(hipMemset(d_lab_group, 0xFF, n * 4));
+                HIPCHECK(hipMemset(d_lab_batch, 0xFF, lab_total * 4));
                 CHECK(kmg_group_lloyd_run_batch(gb, it3));
                 lab_off = 0;
                 for (uint32_t im = 0; im < 3; ++im) {
@@ -280,7 +283,7 @@ int main(int argc, char **argv)
                     EXPECT(it3[im] == it_want[im]);
                     EXPECT(!memcmp(c_want[im].data(), c_group.data(), sizeof(float) * 4 * k));
                     std::vector<uint32_t> got(nn);
-                    HIPCHECK(hipMemcpy(got.data(), d_lab_group + lab_off, nn * 4, hipMemcpyDeviceToHost));
+                    HIPCHECK(hipMemcpy(got.data(), d_lab_batch + lab_off, nn * 4, hipMemcpyDeviceToHost));
                     EXPECT(got == lab_want[im]);
                     lab_off += nn;
                 }
@@ -293,6 +296,7 @@ int main(int argc, char **argv)
                 EXPECT(!memcmp(c_want[1].data(), c_group.data(), sizeof(float) * 4 * k));
                 printf("batch of 3 tiled images: iterations %u %u %u\n", it3[0], it3[1], it3[2]);
                 kmg_group_lloyd_destroy(gb);
+                HIPCHECK(hipFree(d_lab_batch));
             }
             kmg_lloyd_destroy(s);
             HIPCHECK(hipFree(d_img)); HIPCHECK(hipFree(d_lab_one)); HIPCHECK(hipFree(d_lab_group));
