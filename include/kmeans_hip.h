@@ -433,8 +433,8 @@ KMG_API int kmg_group_reduce_batch(kmg_group *g, uint32_t n_images, const uint8_
  * d_labels[i] (optional, may be NULL as a whole) receives that band's u32 label map; rows[i] may be 0.  The bands of all
  * ranks of the world tile the image.  _bind only records the bands (it may be called again for a new image); the calls below
  * enqueue on the devices' compute streams and return -- only _run, _sync and _get_centroids synchronise.
- *   _init       PlusPlusInitModule::compute (modules.rs:946-1246) sharded: per centroid a MAX all-reduce of the 64-bit
- *               arg-max key and a SUM all-reduce of {colour, 1} (kmg_lloyd_init_step / _init_pick_band)
+ *   _init       PlusPlusInitModule::compute (modules.rs:946-1246) sharded: per centroid ONE all-gather of every band's
+ *               {64-bit arg-max key, colour of the pixel it names} (kmg_lloyd_init_step / _init_pick_band); the largest key wins
  *   _prime      the initial assignment (operations.rs:75-83) with its sums, all-reduced
  *   _step       one iteration (modules.rs:769-800): centroid update from the global sums, labels + sums of the new
  *               assignment, all-reduce of the sums

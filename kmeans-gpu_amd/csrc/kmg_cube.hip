@@ -1653,19 +1653,22 @@ __global__ __launch_bounds__(kOneBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
     for (int w = 0; w < 4; ++w) c4[w] = s_cent[w * 64 + lane];      // this lane's four centroids: the same for every cell
 
     const uint32_t n_work = __builtin_amdgcn_readfirstlane(n_work_v);
-    const uint32_t tasks = (n_work + 7u) >> 3;                     // wave tasks: task t = cells t, t + tasks, ... of the work list
-    // (one batch per workgroup: the grid is kCells / kOneCells whatever the list's length, and the bins share their LDS with the
-    // models of the batch)
-    const uint32_t base = blockIdx.x * kOneWaves;
-    if (base >= tasks) return;
+    // One batch per workgroup: the grid is kCells / kOneCells whatever the list's length.  A wave takes `cpw` cells -- 8 of a full
+    // list; a SHORT list (one rank's share of the cube in a cell-sharded loop, kmg_lloyd_set_cell_share: 4096 cells at 8 ranks) is
+    // spread over ALL waves of all workgroups, fewer cells each, so that phase 1a (a wave's cells one after the other) shrinks
+    // with the share instead of leaving most waves idle behind two busy ones.
+    const uint32_t cpw = min(8u, max(1u, (n_work + gridDim.x * kOneWaves - 1u) / (gridDim.x * kOneWaves)));
+    const uint32_t tasks = (n_work + cpw - 1u) / cpw;              // wave tasks: task t = cells t, t + tasks, ... (cpw of them) of the work list
+    const uint32_t waves_used = (tasks + gridDim.x - 1u) / gridDim.x;       // <= kOneWaves: the grid holds kCells / 8 tasks
+    if (blockIdx.x * waves_used >= tasks) return;
     {
         KMG_STAMP(0);
-        // (wave task t -> place (t P) mod tasks of the work list, P a prime that does not divide tasks: the 64 cells of a workgroup
-        // are spread over the whole cube instead of lying along eight lines of it -- the cost of a cell follows its position)
-        const uint32_t task = base + wv;
+        // (wave task t -> place (t P) mod tasks of the work list, P a prime that does not divide tasks: the cells of a workgroup
+        // are spread over the whole cube instead of lying along a few lines of it -- the cost of a cell follows its position)
+        const uint32_t task = wv < waves_used ? blockIdx.x * waves_used + wv : tasks;
         const uint32_t prime = tasks % 2053u ? 2053u : 1031u;
         const uint32_t pos = (uint32_t)(((uint64_t)task * prime) % tasks) + ci * tasks;
-        const bool valid = task < tasks && pos < n_work;
+        const bool valid = task < tasks && ci < cpw && pos < n_work;
         const uint32_t cell = valid ? ((SUMS && n_work != kCells) ? work[1u + pos] : pos) : 0u;
         const uint32_t sc = cell * 8u + sub;
         // ---- requests: the bounds of the wave's eight cells (lane 16 c + i: float i of cell c / c + 4), then everything 1b needs ----
@@ -1688,7 +1691,7 @@ __global__ __launch_bounds__(kOneBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
         if (sub == 0u) s_cell[slot] = cell;
 
         // ---- 1a. the candidates of the wave's cells, one cell at a time ----
-        for (uint32_t c = 0; c < 8u; ++c) {
+        for (uint32_t c = 0; c < cpw; ++c) {
             const uint32_t ccell = lane_value(cell, c * 8u);
             const bool cvalid = lane_value((uint32_t)valid, c * 8u) != 0u;
             const float cbv = c < 4u ? cbv_a : cbv_b;

@@ -426,6 +426,54 @@ int allgather_shares(GroupRank &r, void *buf, uint64_t units, size_t unit, hipSt
     return KMG_OK;
 }
 
+// every rank's `bytes` at `send` -> all ranks' blocks in rank order at `recv` (world x bytes); `send` must not lie inside `recv`
+int allgather_blocks(GroupRank &r, const void *send, void *recv, size_t bytes, hipStream_t st)
+{
+    kmg_group *g = r.g;
+    uint8_t *out = static_cast<uint8_t *>(recv);
+    if (!g->collectives) return hipMemcpyAsync(out, send, bytes, hipMemcpyDeviceToDevice, st) == hipSuccess ? KMG_OK : fail(KMG_ERR_HIP, "copy failed");
+    if (g->loopback) {
+        g->lb_ptrs[r.idx] = send;
+        KMG_TRY(lb_rendezvous(r, st));
+        for (uint32_t q = 0; q < g->world; ++q)
+            HIP_TRY(hipMemcpyAsync(out + (size_t)q * bytes, g->lb_ptrs[q - g->first_rank], bytes, hipMemcpyDeviceToDevice, st));
+        KMG_TRY(lb_rendezvous(r, st));
+        return KMG_OK;
+    }
+    if (g->broken.load()) return fail(KMG_ERR_HIP, "another rank failed");
+    KMG_TRY(comm_on(r, st));
+    NCCL_TRY(g->rccl, g->rccl->AllGather(send, recv, bytes, ncclUint8, r.comm, st));
+    return KMG_OK;
+}
+
+// The sharded initialisation's pick: every rank offers, per image, the largest key of its band and the colour of the pixel that key
+// names; all offers are gathered (ONE collective per centroid instead of a MAX all-reduce of the key and a SUM all-reduce of the
+// colour), and every rank takes the colour of the largest key -- the reference's tie rule is in the key (image-wide pixel index).
+struct InitOffer { unsigned long long key; uint32_t colour, valid; };
+__global__ void k_init_offer(const unsigned long long *__restrict__ keys, const uint32_t *__restrict__ colours2, InitOffer *__restrict__ offers, uint32_t n_images)
+{
+    const uint32_t im = blockIdx.x * blockDim.x + threadIdx.x;
+    if (im >= n_images) return;
+    InitOffer o;
+    o.key = keys[im]; o.colour = colours2[2u * im]; o.valid = colours2[2u * im + 1u];
+    offers[im] = o;
+}
+__global__ void k_init_take(const InitOffer *__restrict__ gathered, uint32_t world, uint32_t n_images, unsigned long long *__restrict__ keys,
+                            uint32_t *__restrict__ colours2)
+{
+    const uint32_t im = blockIdx.x * blockDim.x + threadIdx.x;
+    if (im >= n_images) return;
+    InitOffer best = gathered[im];
+    for (uint32_t q = 1; q < world; ++q) {
+        const InitOffer o = gathered[(size_t)q * n_images + im];
+        // (a band without the pixel its own key names does not occur; a band without pixels offers key 0, valid 0)
+        if (o.valid && (!best.valid || o.key > best.key)) best = o;
+    }
+    keys[im] = best.key;
+    colours2[2u * im] = best.colour;
+    colours2[2u * im + 1u] = best.valid ? 1u : 0u;
+}
+
 int grow(void **ptr, size_t *cap, size_t bytes, hipStream_t st)
 {
     if (*cap >= bytes) return KMG_OK;
@@ -635,6 +683,7 @@ struct RankBlock {                       // what the images of one rank share: o
     uint64_t *d_key = nullptr;           // n_images
     uint32_t *d_colour = nullptr;        // n_images x 2
     uint32_t *d_dummy = nullptr;         // one pixel: what a rank without rows binds in a cell-sharded loop
+    void *d_offer = nullptr, *d_gathered = nullptr;   // init: n_images offers of this rank / world x n_images gathered
 };
 }  // namespace
 
@@ -826,20 +875,34 @@ int rank_run(kmg_group_lloyd *gl, GroupRank &r, uint32_t *iterations)
 }
 
 // PlusPlusInitModule::compute (modules.rs:946-1246) for images sharded in row bands: every rank runs the pass of its band;
-// the arg-max is a MAX all-reduce of the 64-bit key (distance bits | image-wide position under the reference's tie rule),
-// the winning pixel's colour reaches all ranks with a SUM all-reduce of {colour, 1}, every rank sets the same centroid.
-// A batch does this for all its images at once: n_images keys / colours per collective.
+// every rank offers the largest 64-bit key of its band (distance bits | image-wide position under the reference's tie rule) with the
+// colour of the pixel it names, ONE all-gather brings the offers to every rank, every rank takes the largest and sets the same
+// centroid.  A batch does this for all its images at once: n_images offers per collective.
 int rank_init(kmg_group_lloyd *gl, GroupRank &r)
 {
     RankBlock &blk = gl->blocks[r.idx];
     const uint32_t ni = gl->n_images;
     for (uint32_t im = 0; im < ni; ++im) gl->at(r.idx, im).prepared = false;   // the initialisation starts a new problem (and may bind the band itself)
-    auto publish = [&](uint32_t j) -> int {
+    // centroid j of every image: the bands' keys are in d_key (or, j = 0, the same `initial` key on every rank)
+    auto publish = [&](uint32_t j, bool gather) -> int {
         for (uint32_t im = 0; im < ni; ++im) {
             RankLloyd &q = gl->at(r.idx, im);
+            // {colour of the pixel the key names, 1} on the band that owns that pixel, {0, 0} elsewhere
             KMG_TRY(kmg_lloyd_init_pick_band(q.s, q.n_local ? q.band : nullptr, q.n_local, q.first, q.d_key, q.d_colour, r.st));
         }
-        KMG_TRY(allreduce(r, blk.d_colour, 2u * ni, Op::SumU32, r.st));
+        if (gather) {
+            // (every band names a pixel of its own: the offers differ, the largest key wins)
+            const uint32_t grid = (ni + 63u) / 64u;
+            hipLaunchKernelGGL(k_init_offer, dim3(grid), dim3(64), 0, r.st, (const unsigned long long *)blk.d_key, blk.d_colour, (InitOffer *)blk.d_offer, ni);
+            HIP_TRY(hipGetLastError());
+            KMG_TRY(allgather_blocks(r, blk.d_offer, blk.d_gathered, sizeof(InitOffer) * ni, r.st));
+            hipLaunchKernelGGL(k_init_take, dim3(grid), dim3(64), 0, r.st, (const InitOffer *)blk.d_gathered, gl->g->collectives ? gl->g->world : 1u, ni,
+                               (unsigned long long *)blk.d_key, blk.d_colour);
+            HIP_TRY(hipGetLastError());
+        } else {
+            // (the same key on every rank: exactly one band owns the pixel, the sum of {colour, 1} is its colour)
+            KMG_TRY(allreduce(r, blk.d_colour, 2u * ni, Op::SumU32, r.st));
+        }
         for (uint32_t im = 0; im < ni; ++im) KMG_TRY(kmg_lloyd_set_centroid_rgba(gl->at(r.idx, im).s, j, gl->at(r.idx, im).d_colour, r.st));
         return KMG_OK;
     };
@@ -847,14 +910,13 @@ int rank_init(kmg_group_lloyd *gl, GroupRank &r)
     for (uint32_t im = 0; im < ni; ++im) key0[im] = kmg_init_first_key(gl->at(r.idx, im).width, gl->at(r.idx, im).height);   // plus_plus_init.wgsl:161-168 `initial`
     HIP_TRY(hipMemcpyAsync(blk.d_key, key0.data(), sizeof(uint64_t) * ni, hipMemcpyHostToDevice, r.st));
     HIP_TRY(hipStreamSynchronize(r.st));                       // (key0 lives on this stack frame)
-    KMG_TRY(publish(0));
+    KMG_TRY(publish(0, false));
     for (uint32_t j = 1; j < gl->k; ++j) {
         for (uint32_t im = 0; im < ni; ++im) {
             RankLloyd &q = gl->at(r.idx, im);
             KMG_TRY(kmg_lloyd_init_step(q.s, q.n_local ? q.band : nullptr, q.n_local, q.first, j, q.d_key, r.st));
         }
-        KMG_TRY(allreduce(r, blk.d_key, ni, Op::MaxU64, r.st));
-        KMG_TRY(publish(j));
+        KMG_TRY(publish(j, true));                             // ONE all-gather per centroid (rounds 3-5: a MAX and a SUM all-reduce)
     }
     return KMG_OK;
 }
@@ -885,13 +947,16 @@ int group_lloyd_new(kmg_group *g, uint32_t k, uint32_t n_images, kmg_group_lloyd
         HIP_TRY(hipSetDevice(g->ranks[i].device));
         const size_t acc_bytes = (sizeof(int64_t) * 4u * k * n_images + 255u) & ~(size_t)255u;
         const size_t key_bytes = (sizeof(uint64_t) * n_images + 255u) & ~(size_t)255u, col_bytes = (sizeof(uint32_t) * 2u * n_images + 255u) & ~(size_t)255u;
-        HIP_TRY(hipMalloc(&b.blk, acc_bytes + key_bytes + col_bytes + 256));
-        HIP_TRY(hipMemset(b.blk, 0, acc_bytes + key_bytes + col_bytes + 256));
+        const size_t offer_bytes = (sizeof(InitOffer) * n_images + 255u) & ~(size_t)255u;
+        HIP_TRY(hipMalloc(&b.blk, acc_bytes + key_bytes + col_bytes + 256 + offer_bytes * (1u + g->world)));
+        HIP_TRY(hipMemset(b.blk, 0, acc_bytes + key_bytes + col_bytes + 256 + offer_bytes * (1u + g->world)));
         uint8_t *base = static_cast<uint8_t *>(b.blk);
         b.d_acc = (int64_t *)base;
         b.d_key = (uint64_t *)(base + acc_bytes);
         b.d_colour = (uint32_t *)(base + acc_bytes + key_bytes);
         b.d_dummy = (uint32_t *)(base + acc_bytes + key_bytes + col_bytes);
+        b.d_offer = base + acc_bytes + key_bytes + col_bytes + 256;
+        b.d_gathered = base + acc_bytes + key_bytes + col_bytes + 256 + offer_bytes;
         for (uint32_t im = 0; im < n_images; ++im) {
             RankLloyd &q = gl->at(i, im);
             KMG_TRY(kmg_lloyd_create(g->ranks[i].p, k, &q.s));
