@@ -516,9 +516,9 @@ def cpu_baseline(k, centroids4, seed, target_seconds=10.0, one_thread_seconds=5.
 
 
 # speed-up of ONE 8192 x 8192, k = 256 image over N GPUs expected from this design (per-rank emulation on one
-# GPU, tools/strong_cells_per_rank.py, profiles/r05s_strong_cells_per_rank.json; the all-gather of the label tables / the all-reduce are not in these figures: with a
-# 2 MiB-per-peer all-gather over xGMI the cells estimate at N = 8 is ~2.5x)
-EXPECTED_SPEEDUP = {"cells": {2: 1.64, 4: 2.42, 8: 3.19}, "bands": {2: 1.35, 4: 1.60, 8: 1.83}}
+# GPU, tools/strong_cells_per_rank.py, profiles/r06_strong_cells_per_rank.json: the worst rank's iteration, fused form; the all-gather of
+# the label tables / the all-reduce are stand-ins there -- with a 2 MiB-per-peer all-gather over xGMI the cells estimate at N = 8 is ~2.8x)
+EXPECTED_SPEEDUP = {"cells": {2: 1.71, 4: 2.66, 8: 3.74}, "bands": {2: 1.35, 4: 1.60, 8: 1.83}}
 
 
 def _free_port():
@@ -758,7 +758,9 @@ def main():
         # few iterations each, MAX over the ranks), and the fastest is the loop that is measured (config.sharding_choice).
         variants = {}
         if cells_possible and not args.no_cells and (args.scaling == "strong" or args.cells):
-            variants["cells"] = kg.GROUP_CELLS
+            # (the fused form: the cube pass adds into the accumulators, the band's label pass updates from the all-reduced sums --
+            # two launches per iteration and rank instead of four)
+            variants["cells"] = kg.GROUP_CELLS | kg.GROUP_FUSED_UPDATE
         if not args.cells:
             if not args.overlap:
                 variants["bands"] = 0
@@ -888,7 +890,8 @@ def main():
             scaling_note = {"expected_speedup": EXPECTED_SPEEDUP[shape].get(world),
                             "expected_speedup_source": "DESIGN.md section 6: per-rank emulation on one GPU (tools/strong_cells_per_rank.py), "
                                                        "collectives not included; north_star asks for >= 6x at 8 GPUs, this design does "
-                                                       "not expect it (the per-rank floor ~0.05 ms is share-independent)",
+                                                       "not expect it (at N = 8 a rank's iteration is 0.06 ms of which ~0.035 ms do not shrink with the share: "
+                                                       "profiles/r06_share_kernels.csv)",
                             "measured_speedup": (one_gpu_ms / ms_per_step) if one_gpu_ms else None,
                             "one_gpu_ms_per_step_same_run": one_gpu_ms}
         out = {
@@ -910,7 +913,8 @@ def main():
                        "collective_backend": collective_backend, "collective_ranks": group.world,
                        "strategy": strategy, "prepare_ms": t_prep * 1e3, "prepare_cold_ms": t_prep_cold * 1e3,
                        "label_pass": "before the next iteration",
-                       "update": "by the last launch of the assign pass (kmg_lloyd_assign_update)" if flags & kg.GROUP_FUSED_UPDATE
+                       "update": ("by the band's label pass, from the all-reduced sums (kmg_lloyd_labels_from_tables_update)" if cells else
+                                  "by the last launch of the assign pass (kmg_lloyd_assign_update)") if flags & kg.GROUP_FUSED_UPDATE
                                  else "k_update launch",
                        **scaling_note,
                        **({"sharding_choice": picked} if picked else {})},

@@ -264,6 +264,14 @@ KMG_API int kmg_lloyd_labels_from_tables(kmg_lloyd *s, const uint8_t *d_rgba, ui
                                          void *stream);
 KMG_API int kmg_lloyd_table_buffers(kmg_lloyd *s, void **colour_labels, uint64_t *colour_label_bytes, void **entries,
                                     uint64_t *entry_bytes);
+/* Two launches fewer per iteration of such a loop (k <= 256): the cube pass ADDS its sums to d_acc4 as it stands -- the caller keeps
+ * the buffer zero between passes; no hand-over launch -- and the label pass of the band also performs kmg_lloyd_update from
+ * d_acc4 (the all-reduced sums) and clears it for the next pass: per iteration  _accumulate_into -> all-reduce -> all-gather ->
+ * _labels_from_tables_update  instead of  _assign_accumulate -> all-reduce -> all-gather -> _labels_from_tables -> _update.
+ * One assignment with its label map and one update per iteration, shifted by half a step (as kmg_lloyd_assign_update).        */
+KMG_API int kmg_lloyd_accumulate_into(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n_pixels, int64_t *d_acc4, void *stream);
+KMG_API int kmg_lloyd_labels_from_tables_update(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n_pixels, uint32_t *d_labels,
+                                                int64_t *d_acc4, void *stream);
 
 /* The label pass of the colour-table strategy (k <= 256) runs one 1024-thread workgroup per compute unit for its whole
  * duration.  A kernel launched beside it on another stream -- the RCCL all-reduce of the sums that a sharded loop issues
@@ -446,10 +454,13 @@ KMG_API int kmg_group_reduce_batch(kmg_group *g, uint32_t n_images, const uint8_
                                 all-reduce and an in-place all-gather of the label tables (kmg_lloyd_set_cell_share)        */
 #define KMG_GROUP_OVERLAP 2u /* the all-reduce of the sums runs on a second stream beside the label pass (two cross-stream
                                 dependencies per iteration) instead of in line on the compute stream                       */
-#define KMG_GROUP_FUSED_UPDATE 4u /* a world of ONE rank without collectives: _prime and _step are kmg_lloyd_assign_update (assign,
-                                     then the update on the assign pass's last launch) -- per call still one assignment with its
-                                     label map and one update, shifted by half a step; refused by _run, which reads the
-                                     convergence count between update and re-assignment                                        */
+#define KMG_GROUP_FUSED_UPDATE 4u /* _prime and _step perform the update on the last launch of the assignment that produced its sums:
+                                     per call still one assignment with its label map and one update, shifted by half a step.  A
+                                     world of ONE rank without collectives: kmg_lloyd_assign_update.  With KMG_GROUP_CELLS (bands
+                                     with rows and label maps): the cube pass adds into the accumulators, the band's label pass
+                                     updates from the all-reduced sums and clears them (kmg_lloyd_accumulate_into /
+                                     _labels_from_tables_update: two launches per iteration instead of four).  Refused by _run,
+                                     which reads the convergence count between update and re-assignment                       */
 KMG_API int kmg_group_lloyd_create(kmg_group *g, uint32_t k, kmg_group_lloyd **out);
 KMG_API void kmg_group_lloyd_destroy(kmg_group_lloyd *gl);
 KMG_API int kmg_group_lloyd_bind(kmg_group_lloyd *gl, const uint8_t *const *d_rgba, const uint32_t *row0, const uint32_t *rows,

@@ -735,6 +735,12 @@ int rank_prepare(kmg_group_lloyd *gl, GroupRank &r, uint32_t image)
     return KMG_OK;
 }
 
+// KMG_GROUP_FUSED_UPDATE with KMG_GROUP_CELLS: every rank needs a band with rows and a label map (its label pass carries the update)
+bool fused_cells(const kmg_group_lloyd *gl, const RankLloyd &q)
+{
+    return (gl->flags & KMG_GROUP_FUSED_UPDATE) != 0 && q.cells && q.n_local != 0 && q.labels != nullptr && gl->k <= 256u;
+}
+
 bool image_active(const kmg_group_lloyd *gl, uint32_t image) { return gl->active.empty() || gl->active[image] != 0; }
 
 // labels + sums of the current centroids for every (active) image of the batch, and ONE exchange of all their sums
@@ -745,6 +751,15 @@ int rank_pass(kmg_group_lloyd *gl, GroupRank &r)
     RankBlock &blk = gl->blocks[r.idx];
     for (uint32_t im = 0; im < gl->n_images; ++im) KMG_TRY(rank_prepare(gl, r, im));
     RankLloyd &q0 = gl->at(r.idx, 0);
+    if (q0.cells && fused_cells(gl, q0)) {
+        // (KMG_GROUP_FUSED_UPDATE: the sums are added to accumulators that the previous label pass left zero, and this band's
+        // label pass updates the centroids from the all-reduced sums -- no hand-over launch, no update launch)
+        KMG_TRY(kmg_lloyd_accumulate_into(q0.s, q0.band, q0.n_local, q0.d_acc, r.st));
+        KMG_TRY(allreduce(r, q0.d_acc, acc_count, Op::SumI64, r.st));
+        KMG_TRY(allgather_shares(r, q0.lab_t, kCells, kCellColours, r.st));
+        KMG_TRY(allgather_shares(r, q0.ent_t, kCells, sizeof(uint32_t), r.st));
+        return kmg_lloyd_labels_from_tables_update(q0.s, q0.band, q0.n_local, q0.labels, q0.d_acc, r.st);
+    }
     if (q0.cells) {
         // (strong scaling of ONE image: kmg_group_lloyd_bind refuses KMG_GROUP_CELLS for a batch)
         const uint8_t *bound = q0.n_local ? q0.band : (const uint8_t *)blk.d_dummy;
@@ -813,12 +828,21 @@ int rank_update(kmg_group_lloyd *gl, GroupRank &r)
 int rank_prime(kmg_group_lloyd *gl, GroupRank &r)
 {
     if (fused_update(gl)) return rank_fused(gl, r);
+    if ((gl->flags & KMG_GROUP_FUSED_UPDATE) && (gl->flags & KMG_GROUP_CELLS)) {
+        KMG_TRY(rank_prepare(gl, r, 0));
+        RankLloyd &q = gl->at(r.idx, 0);
+        if (!fused_cells(gl, q))
+            return fail(KMG_ERR_INVALID_ARGUMENT, "KMG_GROUP_FUSED_UPDATE with KMG_GROUP_CELLS: every rank needs a band with rows and a label map, k <= 256");
+        HIP_TRY(hipMemsetAsync(q.d_acc, 0, sizeof(int64_t) * 4u * gl->k, r.st));     // (from here on every label pass leaves it zero)
+        return rank_pass(gl, r);
+    }
     return rank_pass(gl, r);                                   // operations.rs:75-83
 }
 
 int rank_step(kmg_group_lloyd *gl, GroupRank &r)
 {
     if (fused_update(gl)) return rank_fused(gl, r);
+    if ((gl->flags & KMG_GROUP_FUSED_UPDATE) && (gl->flags & KMG_GROUP_CELLS)) return rank_pass(gl, r);   // (its label pass updates)
     KMG_TRY(rank_update(gl, r));
     return rank_pass(gl, r);                                   // modules.rs:793-800
 }

@@ -511,10 +511,25 @@ static int ensure_entries(kmg_lloyd *s, hipStream_t st)
 }
 
 static int table_assign(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_t *d_labels, int64_t *d_sums,
-                        uint32_t rows, hipStream_t st, bool update_after = false, bool defer_entries = false)
+                        uint32_t rows, hipStream_t st, bool update_after = false, bool defer_entries = false, bool add_in_place = false)
 {
     if (d_labels) defer_entries = false;
     ColourTable &t = s->tab;
+    if (add_in_place) {
+        // the cube pass ADDS its sums to d_sums as it stands (the caller keeps it zero between passes, or carries other sums in
+        // it): no hand-over, no clearing -- no tail launch (kmg_lloyd_accumulate_into)
+        if (d_labels || update_after || rows != 1u) return fail(KMG_ERR_INVALID_ARGUMENT, "table_assign: in-place sums are sums only");
+        t.bound_by_init = false;
+        int rc2;
+        if ((rc2 = side_flush(s, st)) != KMG_OK) return rc2;
+        PROF_LAUNCH(s, KMG_K_CUBE, st, launch_cube(t.d_hist, t.d_agg, t.d_sub_agg, t.d_occ, t.d_work_share ? t.d_work_share : t.d_work,
+                                                   s->p->d_bounds, s->p->d_sub_bounds, s->d_cent, s->k, s->p->d_lab_table, t.d_masks, t.d_cell_work,
+                                                   t.d_colour_labels, t.d_sub, d_sums, 1u, t.n_hot ? kCubeHot : 0u, nullptr, st, nullptr,
+                                                   affine_for(s->p, s->k, st)));
+        t.entries_valid = true;
+        t.tables_valid = t.d_work_share == nullptr;
+        return KMG_OK;
+    }
     // With a cell share set (kmg_lloyd_set_cell_share) a pass labels one share of the cube and returns ITS sums: the label
     // tables are complete only after the caller's all-gather, the sums only after its all-reduce.  A label map, a centroid
     // update or the two-step partial sums from such a pass would silently be those of a fraction of the image.
@@ -906,6 +921,15 @@ try {
 }
 KMG_ABI_CATCH
 
+extern "C" int kmg_lloyd_accumulate_into(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, int64_t *d_acc4, void *stream)
+try {
+    if (!s || !d_rgba || !d_acc4 || n == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad accumulate_into arguments");
+    HIP_TRY(hipSetDevice(s->p->device));
+    if (!table_bound(s, d_rgba, n)) return fail(KMG_ERR_INVALID_ARGUMENT, "accumulate_into: the image is not bound (kmg_lloyd_bind_image / _prepare)");
+    return table_assign(s, d_rgba, n, nullptr, d_acc4, 1u, S(stream), false, false, true);
+}
+KMG_ABI_CATCH
+
 extern "C" int kmg_lloyd_assign_partials(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_t *d_labels, void *stream)
 try {
     if (!s || !d_rgba || n == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad assign_partials arguments");
@@ -966,6 +990,32 @@ try {
     PROF_LAUNCH(s, KMG_K_LABELS, S(stream), launch_labels((const uint32_t *)d_rgba, n, s->tab.d_colour_labels, s->tab.d_sub, s->k,
                                                           nullptr, d_labels, S(stream), s->reserve_cus,
                                                           s->tab.n_hot ? s->tab.d_work + kCells + 1 : nullptr));
+    return KMG_OK;
+}
+KMG_ABI_CATCH
+
+extern "C" int kmg_lloyd_labels_from_tables_update(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_t *d_labels, int64_t *d_acc4,
+                                                   void *stream)
+try {
+    if (!s || !d_rgba || !d_labels || !d_acc4 || n == 0) return fail(KMG_ERR_INVALID_ARGUMENT, "bad labels_from_tables_update arguments");
+    if (!s->tab.rgba || !s->tab.d_hist) return fail(KMG_ERR_INVALID_ARGUMENT, "labels_from_tables_update: no bound image");
+    if (s->k > 256u) return fail(KMG_ERR_UNSUPPORTED, "labels_from_tables_update: k <= 256 (the label pass that carries a tail)");
+    HIP_TRY(hipSetDevice(s->p->device));
+    int rc_;
+    if ((rc_ = side_flush(s, S(stream))) != KMG_OK) return rc_;
+    if ((rc_ = ensure_entries(s, S(stream))) != KMG_OK) return rc_;
+    // the label pass's last workgroup copies the sums to the object's own k x 4 buffer, updates the centroids from them
+    // (choose_centroid.wgsl:180-206) and clears d_acc4 (kmg_table.h CubeTail)
+    CubeTail tail;
+    tail.acc_out = s->d_acc;
+    tail.do_update = 1;
+    tail.convergence = s->p->opt.convergence;
+    tail.cent = s->d_cent;
+    tail.n_converged = s->d_nconv;
+    PROF_LAUNCH(s, KMG_K_LABELS, S(stream), launch_labels((const uint32_t *)d_rgba, n, s->tab.d_colour_labels, s->tab.d_sub, s->k,
+                                                          nullptr, d_labels, S(stream), s->reserve_cus,
+                                                          s->tab.n_hot ? s->tab.d_work + kCells + 1 : nullptr, &tail, d_acc4));
+    s->tab.tables_valid = false;                                 // (the tables describe the assignment just made, not the new centroids)
     return KMG_OK;
 }
 KMG_ABI_CATCH

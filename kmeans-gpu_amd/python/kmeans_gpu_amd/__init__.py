@@ -137,7 +137,7 @@ SYMBOLS = [
     "kmg_lloyd_unbind_image", "kmg_debug_bound_image", "kmg_lloyd_prepare", "kmg_debug_check_table", "kmg_debug_table_stats", "kmg_debug_check_pairs", "kmg_debug_check_dither_masks", "kmg_debug_check_meld_masks", "kmg_kernel_name",
     "kmg_lloyd_profile", "kmg_lloyd_profile_read",
     "kmg_lloyd_update", "kmg_lloyd_assign_update", "kmg_lloyd_set_cell_share", "kmg_lloyd_labels_from_tables",
-    "kmg_lloyd_table_buffers", "kmg_lloyd_histogram_buffer", "kmg_lloyd_rebuild_from_histogram", "kmg_debug_block_counts", "kmg_debug_idle_blocks", "kmg_debug_encode_table_check", "kmg_debug_division_check", "kmg_lloyd_converged_count", "kmg_lloyd_iterate", "kmg_lloyd_flush", "kmg_lloyd_run", "kmg_dev_apply", "kmg_apply_plan_create", "kmg_apply_plan_run", "kmg_apply_plan_destroy",
+    "kmg_lloyd_table_buffers", "kmg_lloyd_accumulate_into", "kmg_lloyd_labels_from_tables_update", "kmg_lloyd_histogram_buffer", "kmg_lloyd_rebuild_from_histogram", "kmg_debug_block_counts", "kmg_debug_idle_blocks", "kmg_debug_encode_table_check", "kmg_debug_division_check", "kmg_lloyd_converged_count", "kmg_lloyd_iterate", "kmg_lloyd_flush", "kmg_lloyd_run", "kmg_dev_apply", "kmg_apply_plan_create", "kmg_apply_plan_run", "kmg_apply_plan_destroy",
     "kmg_dither_threshold",
     "kmg_default_group_options", "kmg_group_create", "kmg_group_unique_id", "kmg_group_create_rank", "kmg_group_destroy",
     "kmg_group_info", "kmg_group_processor", "kmg_group_stream", "kmg_group_palette", "kmg_group_find", "kmg_group_reduce",
@@ -229,6 +229,8 @@ def lib():
     L.kmg_lloyd_rebuild_from_histogram.argtypes = [vp, C.c_uint64, vp]
     L.kmg_lloyd_table_buffers.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     L.kmg_lloyd_converged_count.argtypes = [vp, C.POINTER(C.c_uint32), vp]
+    L.kmg_lloyd_accumulate_into.argtypes = [vp, u8p, C.c_uint64, i64p, vp]
+    L.kmg_lloyd_labels_from_tables_update.argtypes = [vp, u8p, C.c_uint64, u32p, i64p, vp]
     L.kmg_lloyd_iterate.argtypes = [vp, u8p, C.c_uint64, u32p, i64p, C.c_int, vp]
     L.kmg_lloyd_flush.argtypes = [vp, vp]
     L.kmg_lloyd_run.argtypes = [vp, u8p, C.c_uint64, u32p, C.POINTER(C.c_uint32), vp]
@@ -677,6 +679,15 @@ class Lloyd:
     def set_cell_share(self, part, parts, stream=0):
         """cell-sharded cube pass: later assign passes of the bound image visit share `part` of `parts` of its occupied cells"""
         _check(lib().kmg_lloyd_set_cell_share(self._h, int(part), int(parts), C.c_void_p(stream)))
+
+    def accumulate_into(self, d_rgba, n_pixels, d_acc4, stream=0):
+        """the cube pass of the bound image ADDS its sums to d_acc4 as it stands (no hand-over launch)"""
+        _check(lib().kmg_lloyd_accumulate_into(self._h, C.c_void_p(d_rgba), int(n_pixels), C.c_void_p(d_acc4), C.c_void_p(stream)))
+
+    def labels_from_tables_update(self, d_rgba, n_pixels, d_labels, d_acc4, stream=0):
+        """label map from the tables as they stand + kmg_lloyd_update from d_acc4, which is left zero (one launch)"""
+        _check(lib().kmg_lloyd_labels_from_tables_update(self._h, C.c_void_p(d_rgba), int(n_pixels), C.c_void_p(d_labels), C.c_void_p(d_acc4),
+                                                         C.c_void_p(stream)))
 
     def labels_from_tables(self, d_rgba, n_pixels, d_labels, stream=0):
         """the label pass with the label tables as they stand, on any pixels whose colours occur in the bound image"""

@@ -218,6 +218,19 @@ int main(int argc, char **argv)
                 EXPECT(!memcmp(c_one.data(), c_group.data(), sizeof(float) * 4 * k));
                 HIPCHECK(hipMemcpy(lab_group.data(), d_lab_group, n * 4, hipMemcpyDeviceToHost));
                 EXPECT(lab_one == lab_group);
+                if (flags == (uint32_t)KMG_GROUP_CELLS) {
+                    // the fused form of the cell-sharded loop (the cube pass adds into the accumulators, the band's label pass updates
+                    // from the all-reduced sums and clears them): prime + n steps = n + 1 updates of the plain loop
+                    CHECK(kmg_group_lloyd_bind(gl, bands.data(), row0.data(), rows.data(), w, h, labs.data(), KMG_GROUP_CELLS | KMG_GROUP_FUSED_UPDATE));
+                    CHECK(kmg_group_lloyd_set_centroids(gl, c_init.data()));
+                    CHECK(kmg_group_lloyd_prime(gl));
+                    for (uint32_t i = 0; i < it_one; ++i) CHECK(kmg_group_lloyd_step(gl));
+                    CHECK(kmg_group_lloyd_sync(gl));
+                    CHECK(kmg_group_lloyd_get_centroids(gl, c_group.data()));
+                    EXPECT(!memcmp(c_one.data(), c_group.data(), sizeof(float) * 4 * k));
+                    EXPECT(kmg_group_lloyd_run(gl, &it_group) == KMG_ERR_INVALID_ARGUMENT && strstr(kmg_last_error(), "FUSED"));
+                    CHECK(kmg_group_lloyd_bind(gl, bands.data(), row0.data(), rows.data(), w, h, labs.data(), flags));
+                }
                 if (flags == 0u) {
                     // the loop reads the convergence count between update and re-assignment: the fused form is for _prime / _step
                     CHECK(kmg_group_lloyd_bind(gl, bands.data(), row0.data(), rows.data(), w, h, labs.data(), KMG_GROUP_FUSED_UPDATE));

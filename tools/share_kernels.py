@@ -27,10 +27,17 @@ labels = torch.empty(rows * W, dtype=torch.int32, device="cuda")
 acc = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
 s.assign_accumulate(rgba.data_ptr(), n, 0, acc.data_ptr(), st)       # the whole cube once: real sums for the updates below
 s.set_cell_share(R, N, st)
+FUSED = len(sys.argv) > 3 and sys.argv[3] == "fused"      # kmg_group_lloyd_step with KMG_GROUP_CELLS | KMG_GROUP_FUSED_UPDATE
+keep = acc.clone()
 for it in range(30):
-    s.update(acc.data_ptr(), st)
-    s.assign_accumulate(rgba.data_ptr(), n, 0, acc.data_ptr(), st)
-    s.labels_from_tables(band.data_ptr(), rows * W, labels.data_ptr(), st)
+    if FUSED:
+        s.accumulate_into(rgba.data_ptr(), n, acc.data_ptr(), st)
+        acc.copy_(keep)                                           # (the other ranks' sums are not run: the whole image's, for sane centroids)
+        s.labels_from_tables_update(band.data_ptr(), rows * W, labels.data_ptr(), acc.data_ptr(), st)
+    else:
+        s.update(acc.data_ptr(), st)
+        s.assign_accumulate(rgba.data_ptr(), n, 0, acc.data_ptr(), st)
+        s.labels_from_tables(band.data_ptr(), rows * W, labels.data_ptr(), st)
 torch.cuda.synchronize()
 s.close()
 print("done")

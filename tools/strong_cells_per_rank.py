@@ -9,6 +9,9 @@ Row bands alone leave the cube pass (which works on the image's colours, not its
   3. exchanges label tables: receives the other ranks' shares of the per-colour labels (16 MiB (N-1)/N) and cell entries --
      stand-in: one device-to-device copy of that many bytes -- and all-reduces the k x 4 sums (stand-in: a tensor add),
   4. writes the label map of ITS row band from the complete tables (kmg_lloyd_labels_from_tables).
+Since round 6 the loop is the fused form (kmg_lloyd_accumulate_into + kmg_lloyd_labels_from_tables_update, what kmg_group_lloyd_step
+runs with KMG_GROUP_CELLS | KMG_GROUP_FUSED_UPDATE): the cube pass adds into accumulators the previous label pass left zero, and the
+band's label pass performs step 1 of the NEXT iteration from the all-reduced sums -- two launches per iteration instead of four.
 Steps 1-4 are timed with HIP events on the launch stream for one rank at a time; the other ranks' shares are run on the same
 GPU between the timed segments (untimed) so that the tables and sums are those of a real N-rank run -- the centroids of
 every N are bit-identical to the unsharded loop (asserted).  The once-per-image cost is reported separately: binding a band
@@ -74,23 +77,24 @@ for N in (1, 2, 4, 8):
         # initial assignment
         total.zero_(); others()
         s.set_cell_share(r, N, st); s.assign_accumulate(rgba.data_ptr(), n, 0, acc_r.data_ptr(), st); total.add_(acc_r)
+        # (the fused loop: `mine` holds this rank's sums, then -- the all-reduce's stand-in adds the other ranks' -- the image's; the
+        # label pass updates from it and leaves it zero)
+        mine = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
+        s.update(total.data_ptr(), st)                                          # centroids after the initial assignment
         for it in range(WARM + ITERS):
             e = ev[it]
-            e[0].record()
-            s.update(total.data_ptr(), st)                                      # 1
-            e[1].record()
-            total.zero_(); others()                                             # (the other ranks, untimed)
+            total.zero_(); others()                                             # (the other ranks' shares under the current centroids, untimed)
             s.set_cell_share(r, N, st)
             e[2].record()
-            s.assign_accumulate(rgba.data_ptr(), n, 0, acc_r.data_ptr(), st)    # 2
+            s.accumulate_into(rgba.data_ptr(), n, mine.data_ptr(), st)          # 2 (no hand-over launch)
             if N > 1:
                 recv_dst.copy_(recv_src)                                        # 3: all-gather stand-in
-            total.add_(acc_r)                                                   #    all-reduce stand-in
-            s.labels_from_tables(band.data_ptr(), rows * W, labels.data_ptr(), st)   # 4
+            mine.add_(total)                                                    #    all-reduce stand-in
+            s.labels_from_tables_update(band.data_ptr(), rows * W, labels.data_ptr(), mine.data_ptr(), st)   # 4 + 1 of the next iteration
             e[3].record()
         torch.cuda.synchronize()
-        ms = [ev[i][0].elapsed_time(ev[i][1]) + ev[i][2].elapsed_time(ev[i][3]) for i in range(WARM, WARM + ITERS)]
-        s.update(total.data_ptr(), st)
+        ms = [ev[i][2].elapsed_time(ev[i][3]) for i in range(WARM, WARM + ITERS)]
+        assert int(mine.abs().sum().item()) == 0                                # the label pass left the accumulators zero
         got = s.get_centroids(st)
         # the loop above performed WARM + ITERS + 1 updates after the initial assignment; the reference WARM + ITERS
         s.close()
