@@ -711,8 +711,10 @@ static bool init_table_pays(const kmg_processor *p, uint64_t n, uint32_t k)
     // workgroups, four literal distances per pixel and launch: 9 us + 30 ps per pixel; tools/init_crossover.py,
     // profiles/r05_init_crossover.txt)
     const double pixels = k >= 32u ? (0.3 * k + 18.0) * (9.0e-6 + N * 30.0e-12) : passes * (8.0e-6 + N * 7.0e-12);
-    const double colours = passes * 1.05e-5 + (passes < 16.0 ? passes : 16.0) * 3.0e-5 + 1.5 * bind_seconds(n) +
-                           (n >= (1ull << 21) ? 0.0 : 1.0e-4 + N * 3.7e-11);
+    // (passes over the colours: 9 us each, the first 16 visit every cell: + 30 us; binding with its tie keys 1.5 x a plain bind,
+    // below 2^21 pixels 0.05 ms + 0.2 ns per pixel -- refitted in round 6, tests/test_gpu_costmodel.py prints the rows)
+    const double colours = passes * 0.9e-5 + (passes < 16.0 ? passes : 16.0) * 3.0e-5 +
+                           (n >= (1ull << 21) ? 1.5 * bind_seconds(n) : 5.0e-5 + N * 2.0e-10);
     return colours < pixels;
 }
 

@@ -2,7 +2,8 @@
 """Where the one-launch cube pass (k_cube_one, 32 < k <= 256) spends its time, on the GPU box: the tools build stamps
 s_memrealtime (100 MHz) at the phase boundaries of every workgroup (thread 0).  Prints, over the 512 workgroups of one
 pass on the benchmark image (8192^2 noise, k = 256): mean / max duration of each phase and the pass's span.
-    python tools/cube_one_phases.py > gpurun_out/cube_one_phases.txt"""
+    python tools/cube_one_phases.py > gpurun_out/cube_one_phases.txt
+    SHARE=4/8 [FUSED=1] python tools/cube_one_phases.py      the same for one rank's share of the cube (cell-sharded loop)"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from _toolslib import use_tools_library
@@ -26,6 +27,15 @@ acc = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
 labels = torch.empty(n, dtype=torch.int32, device="cuda")
 for _ in range(4):
     s.assign_update(rgba.data_ptr(), n, labels.data_ptr(), acc.data_ptr(), True, st)
+share = os.environ.get("SHARE")            # "R/N": the pass over rank R's share of the cube (the strong-scaling loop's per-rank launch)
+if share:
+    R, N = (int(x) for x in share.split("/"))
+    s.set_cell_share(R, N, st)
+    for _ in range(4):
+        if os.environ.get("FUSED"):
+            s.accumulate_into(rgba.data_ptr(), n, acc.data_ptr(), st)
+        else:
+            s.assign_accumulate(rgba.data_ptr(), n, 0, acc.data_ptr(), st)
 torch.cuda.synchronize()
 L = kg.lib()
 buf = np.zeros((512, 12), np.uint64)  # (only the first grid-size rows are written)
