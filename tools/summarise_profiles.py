@@ -35,7 +35,7 @@ if cube:
     # the cube kernels read coalesced 16-byte / 4-byte streams: reads = 2 x FETCH_SIZE (same correction), writes at face value
     tot = sum(2 * v["FETCH_SIZE_KiB"] * 1024 + v["WRITE_SIZE_KiB"] * 1024 for v in cube.values())
     t["bytes_per_launch"]["k_cube"] = tot
-    note += (f"  Cube pass (three or four launches): " + ", ".join(f"{k} {2*v['FETCH_SIZE_KiB']*1024/1e6:.1f} MB read (2 x FETCH_SIZE) + {v['WRITE_SIZE_KiB']*1024/1e6:.1f} MB written"
+    note += (f"  Cube pass (k_cube_one + the one-workgroup tail; three launches with hot cells or k > 256): " + ", ".join(f"{k} {2*v['FETCH_SIZE_KiB']*1024/1e6:.1f} MB read (2 x FETCH_SIZE) + {v['WRITE_SIZE_KiB']*1024/1e6:.1f} MB written"
                                                            for k, v in cube.items()) + f" = {tot/1e6:.1f} MB vs 80.5 MB algorithmic (2^24 counts read, 2^24 labels written).")
 src = f"profiles/{tag}_pmc_fetch_write.csv via profiles/traffic.json (separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of tools/profile_round.sh, not the run that quotes them)"
 t["source"] = {"k_labels": src, "k_cube": src}
