@@ -798,6 +798,26 @@ try {
             if (log_debug()) fprintf(stderr, "[kmeans_hip] initialisation: %u centroids in %u launches\n", s->k, launches);
             return KMG_OK;
         }
+        // Passes over the colours, k >= 32: several centroids per launch as well (kmg_table.h launch_init_cells_multi; early
+        // launches pick ~2, late ones ~3.6 of at most 4: a third of what is missing, then look)
+        if (colours && s->k >= 32u) {
+            uint32_t have = 1u, launch = 1u, launches = 0u;
+            while (have < s->k) {
+                const uint32_t chunk = (launch == 1u ? 1u : 0u) + (s->k - have + 2u) / 3u;
+                for (uint32_t q = 0; q < chunk; ++q, ++launch)
+                    HIP_TRY(launch_init_cells_multi(s->tab.d_tie, s->tab.d_occ, s->p->d_lab_table, s->d_cent, s->k, launch, s->tab.d_cdist,
+                                                    s->tab.d_init_cells, rgba, s->p->d_lut, S(stream)));
+                launches += chunk;
+                uint32_t *h = s->h_slot ? static_cast<uint32_t *>(s->h_slot) : &have;
+                HIP_TRY(hipMemcpyAsync(h, init_cells_multi_count(s->tab.d_init_cells, launch - 1u), sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                       S(stream)));
+                HIP_TRY(hipStreamSynchronize(S(stream)));
+                have = *static_cast<volatile uint32_t *>(h);
+                if (have == 0u || have > s->k) return fail(KMG_ERR_HIP, "initialisation: centroid count %u out of range", have);
+            }
+            if (log_debug()) fprintf(stderr, "[kmeans_hip] initialisation over the colours: %u centroids in %u launches\n", s->k, launches);
+            return KMG_OK;
+        }
         for (uint32_t j = 1; j < s->k + (colours ? 1u : 0u); ++j) {   // modules.rs:1211-1246
             if (colours) {
                 // launch j picks centroid j - 1 and runs pass j; launch k only picks

@@ -178,6 +178,14 @@ hipError_t launch_init_records(const uint32_t *work, const CellBounds *bounds, v
 hipError_t launch_init_pass_cells(const uint32_t *tie, const uint8_t *occ_bits, const float4 *lab_table, Centroid *cent,
                                   uint32_t j, int do_pass, float *dist, void *init_scratch, unsigned long long *band_key,
                                   const uint32_t *pick_rgba, const float *lut, hipStream_t st);
+// The same for a whole image on one device with several picks per launch (k_init_cells_multi): launch 1 sweeps against cent[0];
+// every later launch picks one to four centroids from the largest cell records the previous one left -- exactly the centroids the
+// single picks would choose -- and sweeps against them; a launch that finds the table complete does nothing.  The number of
+// centroids chosen after `launch` is *init_cells_multi_count(init_scratch, launch) (device memory; the host reads it between chunks).
+hipError_t launch_init_cells_multi(const uint32_t *tie, const uint8_t *occ_bits, const float4 *lab_table, Centroid *cent, uint32_t k,
+                                   uint32_t launch, float *dist, void *init_scratch, const uint32_t *pick_rgba, const float *lut,
+                                   hipStream_t st);
+const uint32_t *init_cells_multi_count(const void *init_scratch, uint32_t launch);
 // per iteration (kmg_cube.hip): candidates + sub-cell stage, dominance tests, colour scan, pair entries -- ONE launch for k <= 256
 // on images without hot cells (k_cube_small, k_cube_one), three otherwise (k_cube_stage, k_cube_scan, k_cube_pairs).
 // work: [0] = number of occupied cells of the bound image, [1..] = their indices (built at bind time).

@@ -13,6 +13,8 @@
 #include "kmg_internal.h"
 #include "kmg_table_dev.h"
 
+#include <hip/hip_fp16.h>
+
 namespace kmg {
 
 // ------------------------------------------------------------------------------------------
@@ -429,7 +431,7 @@ struct alignas(16) InitRecord {
 };
 static_assert(sizeof(InitSlot) == 32 && sizeof(InitRecord) == 32 + sizeof(CellBounds), "init record layout");
 
-size_t init_scratch_bytes() { return sizeof(InitRecord) * (size_t)kCells + sizeof(InitSlot) * 2u * kInitGrid; }
+// (init_scratch_bytes: behind k_init_cells_multi, whose rows it also holds)
 
 // wave-wide maxima through DPP row operations (kmg_table_dev.h): a 64-bit maximum is the maximum of the high words, then of the
 // low words of the lanes that hold it.  (Rounds 2-4 used six shuffle steps -- twelve ds_bpermute round trips for 64 bits -- in
@@ -741,6 +743,431 @@ hipError_t launch_init_pass_cells(const uint32_t *tie, const uint8_t *occ_bits, 
                            dist, records, slots, pick_rgba, lut);
     }
     return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Several centroids per launch over the cells, exactly (whole image on one device; round 6).
+//
+// A pass only LOWERS running distances.  Let R1 > R2 > ... be the largest CELL records (each the largest key of its cell's
+// colours, so they come from distinct cells X1, X2, ...) after the sweeps so far; centroid c = colour(R1) is the next pick
+// (plus_plus_init.wgsl:172-181).  Candidate R_i is the pick AFTER the picks P made in this launch so far, without sweeping first,
+// when (a) no pick lowers it -- cie94(colour(R_i), p) >= dist(R_i) for every p in P, the very comparison the sweep would make --
+// and (b) every colour that may lie above it today ends below it: such colours live in the cells X_m, m < i, only (every other
+// cell's record is below R_i), and after the sweeps a colour u of X_m has dist(u) <= min_p cie94(u, p) <= min_p FAR(X_m, p),
+// FAR^2 = the largest dL^2 + da^2 + db^2 between p and the cell's Lab box (CIE94's divisors are >= 1, so it never exceeds that;
+// the comparison leaves 1 % for the roundings of the literal form).  A candidate that fails (a) is SKIPPED, not the end of the
+// list: it sits next to a pick -- the usual case, neighbouring cells share a far corner of colour space -- and (b) then disposes
+// of its whole cell for the candidates after it.  The first failure of (b) ends the launch's picks.  Keys are distinct (they name
+// pixels); a candidate with distance 0 is never taken this way (Candidate(0, 0.0) = pixel 0).
+// Every workgroup leaves the kCellMulti largest records of its 128 cells (a ROW, sorted); the next launch merges the 256 rows in
+// every workgroup.  What a row does not show is at most its last entry, so the merged list is exact above the largest last entry
+// of all rows (`floor`): candidates at or below it are not used.  One launch =
+//   [merge -> up to kCellMulti picks from the kCellCands largest records] -> [test every cell against each pick -> visit the
+//   reached cells, each against the picks that reach it] -> [row]
+// cfg3 (8192^2 noise, k = 256): 95 launches (with the empty ones at the end of a chunk) instead of 255, same centroids bit for bit;
+// 3.5 -> 3.1 ms -- a launch is no longer a chain of round trips but the visits of ~12 reached cells per workgroup (profiles/NOTES.md round 6).
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kCellMulti = 4;          // picks per launch = entries of a workgroup's row
+constexpr uint32_t kCellCands = 8;          // candidates a launch examines
+
+struct alignas(16) CellCand {
+    unsigned long long key;                 // 0: none
+    float L, a, b;                          // Lab of the colour that holds it
+    uint32_t box[3];                        // the cell's (L0, L1), (a0, a1), (b0, b1): binary16 pairs rounded outward
+};
+static_assert(sizeof(CellCand) == 32, "CellCand layout");
+
+size_t init_scratch_bytes()
+{
+    return sizeof(InitRecord) * (size_t)kCells + sizeof(InitSlot) * 2u * kInitGrid + sizeof(CellCand) * 2u * kInitGrid * kCellMulti + 256u;
+}
+
+__device__ __forceinline__ uint32_t pack_box(float lo, float hi)
+{
+    return (uint32_t)__half_as_ushort(__float2half_rd(lo)) | ((uint32_t)__half_as_ushort(__float2half_ru(hi)) << 16);
+}
+
+// the largest dL^2 + da^2 + db^2 between (L, a, b) and a point of the box
+__device__ __forceinline__ float box_far2(const uint32_t *box, float L, float a, float b)
+{
+    float far[3];
+    const float v[3] = {L, a, b};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const float lo = __half2float(__ushort_as_half((unsigned short)(box[q] & 0xFFFFu)));
+        const float hi = __half2float(__ushort_as_half((unsigned short)(box[q] >> 16)));
+        far[q] = fmaxf(fabsf(hi - v[q]), fabsf(v[q] - lo));
+    }
+    return far[0] * far[0] + far[1] * far[1] + far[2] * far[2];
+}
+
+__device__ __forceinline__ CellCand no_cand()
+{
+    CellCand o; o.key = 0ull; o.L = 0.0f; o.a = 0.0f; o.b = 0.0f; o.box[0] = 0u; o.box[1] = 0u; o.box[2] = 0u;
+    return o;
+}
+
+// min(m, cie94(colour v, pick c)) -- v = (L, a, b, chroma) of the Lab table, c likewise.  Most colours of a reached cell are NOT
+// lowered (the reach test is a bound over the whole cell), so the literal distance with its two IEEE divides and two square roots
+// is evaluated only where the ordering key does not settle it: key and literal^2 are two float evaluations of one real quantity T
+// (kmg_math.h: |key - T| <= 63u T, + 12u with hardware reciprocals; |literal^2 - T| <= 66u T), hence
+//     key (1 - 2^-10) > m^2   =>   T > m^2 (1 + 2^-11)   =>   literal^2 > m^2   =>   sqrtf(literal^2) >= m   =>   the minimum is m.
+__device__ __forceinline__ float lowered_by(float m, const float4 &v, const float4 &c)
+{
+    const PixelTerms t = pixel_terms_fast(v.x, v.y, v.z, v.w);
+    if (!(cie94_key(t, c.x, c.y, c.z, c.w) * (1.0f - 0.0009765625f) > m * m))
+        m = fminf(m, cie94_c(v.x, v.y, v.z, v.w, c.x, c.y, c.z, c.w));
+    return m;
+}
+
+// init_visit_part against the picks of `mask` (bit r: s_pick[r]); first: the map starts at 1e6, nothing to read
+template <int N>
+__device__ __forceinline__ unsigned long long init_visit_part_multi(uint32_t cell, uint32_t part, uint32_t lane, bool first,
+                                                                    const float4 *s_pick, uint32_t mask,
+                                                                    const uint32_t *__restrict__ tie, const uint8_t *__restrict__ occ_bits,
+                                                                    const float4 *__restrict__ lab_table, float *__restrict__ dist,
+                                                                    float4 &lab_out)
+{
+    constexpr uint32_t kParts = 8u / N;
+    const uint32_t within = part * (kCellColours / kParts) + lane * N;
+    const uint32_t base = cell * kCellColours + within;
+    const uint32_t occ = ((uint32_t)occ_bits[(uint64_t)cell * 64u + (within >> 3)] >> (within & 7u)) & ((1u << N) - 1u);
+    float4 v[N];
+#pragma unroll
+    for (int q = 0; q < N; ++q) v[q] = lab_table[base + q];
+    uint32_t t[N];
+    float m[N];
+    if (N == 4) {
+        const uint4 tt = *reinterpret_cast<const uint4 *>(tie + base);
+        t[0] = tt.x; t[1] = tt.y; t[2 % N] = tt.z; t[3 % N] = tt.w;
+        float4 d = make_float4(1000000.0f, 1000000.0f, 1000000.0f, 1000000.0f);   // kmeans++_calc_diff.wgsl:26-30
+        if (!first) d = *reinterpret_cast<const float4 *>(dist + base);
+        m[0] = d.x; m[1] = d.y; m[2 % N] = d.z; m[3 % N] = d.w;
+    } else {
+        const uint2 tt = *reinterpret_cast<const uint2 *>(tie + base);
+        t[0] = tt.x; t[1] = tt.y;
+        float2 d = make_float2(1000000.0f, 1000000.0f);
+        if (!first) d = *reinterpret_cast<const float2 *>(dist + base);
+        m[0] = d.x; m[1] = d.y;
+    }
+    for (uint32_t mm = mask; mm; mm &= mm - 1u) {
+        const float4 c = s_pick[__builtin_ctz(mm)];
+#pragma unroll
+        for (int q = 0; q < N; ++q)
+            if ((occ >> q) & 1u) m[q] = lowered_by(m[q], v[q], c);
+    }
+    uint32_t md = 0u;
+#pragma unroll
+    for (int q = 0; q < N; ++q)
+        if ((occ >> q) & 1u) md = max(md, float_to_bits(m[q]));
+    if (occ || first) {
+        if (N == 4) *reinterpret_cast<float4 *>(dist + base) = make_float4(m[0], m[1], m[2 % N], m[3 % N]);
+        else *reinterpret_cast<float2 *>(dist + base) = make_float2(m[0], m[1]);
+    }
+    const uint32_t wmd = wave_max_u32(md);
+    uint32_t low1 = 0u;
+    lab_out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (occ && md == wmd) {
+#pragma unroll
+        for (int q = 0; q < N; ++q)
+            if (((occ >> q) & 1u) && float_to_bits(m[q]) == wmd && t[q] > low1) { low1 = t[q]; lab_out = v[q]; }
+    }
+    const uint32_t wlow1 = wave_max_u32(low1);
+    return (low1 == wlow1 && low1 != 0u) ? (((unsigned long long)wmd << 32) | (unsigned long long)(wlow1 - 1u)) : 0ull;
+}
+
+__global__ __launch_bounds__(kInitBlock) void k_init_cells_multi(const uint32_t *__restrict__ tie, const uint8_t *__restrict__ occ_bits,
+                                                                 const float4 *__restrict__ lab_table, Centroid *__restrict__ cent,
+                                                                 uint32_t k, uint32_t launch, float *__restrict__ dist,
+                                                                 InitRecord *__restrict__ records, CellCand *__restrict__ rows,
+                                                                 uint32_t *__restrict__ count, const uint32_t *__restrict__ rgba,
+                                                                 const float *__restrict__ lut)
+{
+    constexpr uint32_t kWaves = kInitBlock / 64, kRowWaves = kInitGrid / 64, kOwn = kWaves * 8;
+    __shared__ CellCand s_top[kRowWaves * kCellCands];
+    __shared__ CellCand s_best[kCellCands];
+    __shared__ unsigned long long s_floor[kRowWaves];
+    __shared__ float4 s_pick[kCellMulti];
+    __shared__ uint32_t s_npick;
+    __shared__ CellCand s_met[kOwn];                               // the records of the workgroup's cells as they stand
+    __shared__ uint2 s_list[kOwn];                                 // (cell, slot | picks that reach it << 8)
+    __shared__ uint32_t s_count;
+    __shared__ unsigned long long s_pkey[kWaves];
+    __shared__ float4 s_plab[kWaves];
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool first = launch == 1u;
+
+    // what the test needs does not depend on the picks: requested before them
+    const uint32_t slot = wv * 8u + (lane & 7u);
+    const bool tester = lane < 8u;
+    InitRecord rec;                                                // (lanes 8 .. 31: the same eight cells again, one pick each)
+    rec.key = 0ull; rec.cell = kNoCell;
+    if (lane < 8u * kCellMulti) rec = records[slot_work_index(blockIdx.x, slot)];
+    if (threadIdx.x == 0) s_count = 0u;
+
+    uint32_t have = 0u;
+    if (first) {
+        // centroid 0 is there (k_init_first): nothing to pick
+        if (threadIdx.x == 0) {
+            const Centroid c0 = cent[0];
+            s_pick[0] = make_float4(c0.L, c0.a, c0.b, c0.C);
+            s_npick = 1u;
+            if (blockIdx.x == 0) count[1] = 1u;
+        }
+    } else {
+        const CellCand *prev = rows + (uint64_t)((launch - 1u) & 1u) * kInitGrid * kCellMulti;
+        CellCand row[kCellMulti];
+#pragma unroll
+        for (uint32_t e = 0; e < kCellMulti; ++e) {
+            row[e] = no_cand();
+            if (threadIdx.x < kInitGrid) row[e] = prev[(uint64_t)threadIdx.x * kCellMulti + e];
+        }
+        have = count[(launch - 1u) & 1u];
+        if (have >= k) {                                           // the table is complete: an empty launch of a chunk
+            if (blockIdx.x == 0 && threadIdx.x == 0) count[launch & 1u] = have;
+            return;
+        }
+        if (wv < kRowWaves) {
+            // (what the rows hide is at most their last entries)
+            const unsigned long long fl = wave_max_u64(row[kCellMulti - 1].key);
+            if (lane == 0u) s_floor[wv] = fl;
+            // the wave's kCellCands largest heads, one at a time: the lane that holds it hands it over and moves its list up
+#pragma unroll
+            for (uint32_t r = 0; r < kCellCands; ++r) {
+                const unsigned long long g = wave_max_u64(row[0].key);
+                if (g == 0ull) {
+                    if (lane == 0u) s_top[wv * kCellCands + r] = no_cand();
+                } else if (row[0].key == g) {
+                    s_top[wv * kCellCands + r] = row[0];
+#pragma unroll
+                    for (uint32_t e = 0; e + 1 < kCellMulti; ++e) row[e] = row[e + 1];
+                    row[kCellMulti - 1] = no_cand();
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < kRowWaves * kCellCands) {
+            const CellCand mine = s_top[threadIdx.x];
+            uint32_t rank = 0;
+            for (uint32_t q = 0; q < kRowWaves * kCellCands; ++q) {
+                const unsigned long long o = s_top[q].key;
+                rank += (o > mine.key || (o == mine.key && q < threadIdx.x)) ? 1u : 0u;
+            }
+            if (rank < kCellCands) s_best[rank] = mine;
+        }
+        __syncthreads();
+        if (wv == 0u) {
+            // lane 8 x + q: how far candidate x's cell reaches from candidate q's colour, and what a sweep against candidate x's
+            // colour would make of candidate q's distance; then lane x < 8 collects its row of each
+            float far2[kCellCands], de[kCellCands];
+            {
+                const CellCand cx = s_best[lane >> 3], cq = s_best[lane & 7u];
+                const float f = box_far2(cx.box, cq.L, cq.a, cq.b);
+                const float d = cie94(cq.L, cq.a, cq.b, cx.L, cx.a, cx.b);
+#pragma unroll
+                for (uint32_t q = 0; q < kCellCands; ++q) {
+                    far2[q] = __shfl(f, (int)(((lane & 7u) << 3) | q));
+                    de[q] = __shfl(d, (int)(((lane & 7u) << 3) | q));
+                }
+            }
+            unsigned long long floor_key = s_floor[0];
+#pragma unroll
+            for (uint32_t q = 1; q < kRowWaves; ++q) floor_key = s_floor[q] > floor_key ? s_floor[q] : floor_key;
+            const uint32_t room = min(kCellMulti, k - have);
+            uint32_t picked = 1u, npick = 1u, order = 0u;
+            bool stop = (uint32_t)(s_best[0].key >> 32) == 0u;     // (all distances zero: one pick, pixel 0)
+#pragma unroll
+            for (uint32_t i = 1; i < kCellCands; ++i) {
+                const unsigned long long ki = s_best[i].key;
+                const float di = __uint_as_float((uint32_t)(ki >> 32));
+                if (npick >= room || ki <= floor_key || (uint32_t)(ki >> 32) == 0u) stop = true;
+                float m = 3.0e38f;
+#pragma unroll
+                for (uint32_t q = 0; q < kCellCands; ++q)
+                    if ((picked >> q) & 1u) m = fminf(m, far2[q]);
+                // (b) the cells of the candidates before this one end below it
+                if (__ballot(lane < i && !(m * 1.01f < di * di)) != 0ull) stop = true;
+                // (a) no pick lowers it
+                const bool lowered = __ballot(lane < kCellCands && ((picked >> lane) & 1u) && !(de[i] >= di)) != 0ull;
+                if (!stop && !lowered) { picked |= 1u << i; order |= i << (4u * npick); ++npick; }
+            }
+            if (lane < npick) {
+                const CellCand o = s_best[(order >> (4u * lane)) & 15u];
+                float4 v = make_float4(o.L, o.a, o.b, 0.0f);
+                if ((uint32_t)(o.key >> 32) == 0u) {
+                    // Candidate(0, 0.0): every distance is 0 -> pixel 0
+                    const uint32_t px = rgba[0];
+                    linear100_to_lab(lut[px & 255u], lut[(px >> 8) & 255u], lut[(px >> 16) & 255u], v.x, v.y, v.z);
+                }
+                v.w = chroma(v.y, v.z);
+                s_pick[lane] = v;
+                if (blockIdx.x == 0) { Centroid c; c.L = v.x; c.a = v.y; c.b = v.z; c.C = v.w; cent[have + lane] = c; }
+            }
+            if (lane == 0u) {
+                s_npick = npick;
+                if (blockIdx.x == 0) count[launch & 1u] = have + npick;
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t npick = s_npick;
+    if (have + npick >= k) return;                                 // the last centroids: no distances are needed any more
+
+    // ---- the test: which picks reach the cell?  lane 8 r + c: cell c of the wave against pick r ----
+    {
+        bool reached = false;
+        const uint32_t r = lane >> 3;
+        if (r < npick && rec.cell != kNoCell) {
+            reached = true;
+            if (!first) {
+                const float4 c = s_pick[r];
+                reached = cie94_lower_bound(rec.cb, c.x, c.y, c.z, c.w) < __uint_as_float((uint32_t)(rec.key >> 32));
+            }
+        }
+        const unsigned long long hits = __ballot(reached);
+        if (tester) {
+            CellCand met = no_cand();
+            if (rec.cell != kNoCell) {
+                const uint32_t mine = (uint32_t)(hits >> lane);
+                const uint32_t mask = (mine & 1u) | ((mine >> 7) & 2u) | ((mine >> 14) & 4u) | ((mine >> 21) & 8u);
+                met.key = rec.key; met.L = rec.lab.x; met.a = rec.lab.y; met.b = rec.lab.z;
+                met.box[0] = pack_box(rec.cb.L0, rec.cb.L1); met.box[1] = pack_box(rec.cb.a0, rec.cb.a1); met.box[2] = pack_box(rec.cb.b0, rec.cb.b1);
+                if (mask) s_list[atomicAdd(&s_count, 1u)] = make_uint2(rec.cell, slot | (mask << 8));
+            }
+            s_met[slot] = met;
+        }
+    }
+    __syncthreads();
+    const uint32_t count_ = s_count;
+    const bool eager = count_ <= kWaves;
+
+    if (count_ <= 8u) {
+        // few cells: 4 (count <= 4) or 2 waves per cell, each a part of its colours
+        const uint32_t shift = count_ <= 4u ? 2u : 1u;
+        const uint32_t my = wv >> shift, part = wv & ((1u << shift) - 1u);
+        unsigned long long pk = 0ull;
+        float4 pl = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (my < count_) {
+            const uint2 e = s_list[my];
+            pk = shift == 2u ? init_visit_part_multi<2>(e.x, part, lane, first, s_pick, e.y >> 8, tie, occ_bits, lab_table, dist, pl)
+                             : init_visit_part_multi<4>(e.x, part, lane, first, s_pick, e.y >> 8, tie, occ_bits, lab_table, dist, pl);
+        }
+        if (lane == 0u) s_pkey[wv] = 0ull;
+        if (pk != 0ull) { s_pkey[wv] = pk; s_plab[wv] = pl; }
+        __syncthreads();
+        if (part == 0u && my < count_ && lane == 0u) {
+            uint32_t w = wv;
+            for (uint32_t q = 1; q < (1u << shift); ++q) if (s_pkey[wv + q] > s_pkey[w]) w = wv + q;
+            const unsigned long long key = s_pkey[w];
+            const float4 lab = s_plab[w];
+            const uint32_t sl = s_list[my].y & 255u;
+            InitRecord *r = records + slot_work_index(blockIdx.x, sl);
+            r->key = key;
+            r->lab = lab;
+            s_met[sl].key = key; s_met[sl].L = lab.x; s_met[sl].a = lab.y; s_met[sl].b = lab.z;
+        }
+    }
+    uint32_t idx = count_ <= 8u ? count_ : wv;
+    uint2 ent = idx < count_ ? s_list[idx] : make_uint2(0u, 0u);
+    uint32_t base = ent.x * kCellColours + lane * 8u;
+    uint32_t occ = occ_bits[(uint64_t)ent.x * 64u + lane];
+    float4 d0 = make_float4(1000000.0f, 1000000.0f, 1000000.0f, 1000000.0f), d1 = d0;     // kmeans++_calc_diff.wgsl:26-30
+    if (!first) { d0 = *reinterpret_cast<const float4 *>(dist + base); d1 = *reinterpret_cast<const float4 *>(dist + base + 4); }
+    while (idx < count_) {
+        float4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = lab_table[base + q];
+        uint4 t0 = make_uint4(0u, 0u, 0u, 0u), t1 = t0;
+        if (eager) { t0 = *reinterpret_cast<const uint4 *>(tie + base); t1 = *reinterpret_cast<const uint4 *>(tie + base + 4); }
+        const uint32_t idx_n = idx + kWaves;
+        const uint2 ent_n = idx_n < count_ ? s_list[idx_n] : ent;
+        const uint32_t base_n = ent_n.x * kCellColours + lane * 8u;
+        const uint32_t occ_n = occ_bits[(uint64_t)ent_n.x * 64u + lane];
+        float4 d0_n = d0, d1_n = d1;
+        if (!first) { d0_n = *reinterpret_cast<const float4 *>(dist + base_n); d1_n = *reinterpret_cast<const float4 *>(dist + base_n + 4); }
+
+        float m[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+        for (uint32_t mm = ent.y >> 8; mm; mm &= mm - 1u) {
+            const float4 c = s_pick[__builtin_ctz(mm)];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if ((occ >> q) & 1u) m[q] = lowered_by(m[q], v[q], c);
+        }
+        uint32_t md = 0u;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if ((occ >> q) & 1u) md = max(md, float_to_bits(m[q]));
+        if (occ || first) {
+            *reinterpret_cast<float4 *>(dist + base) = make_float4(m[0], m[1], m[2], m[3]);
+            *reinterpret_cast<float4 *>(dist + base + 4) = make_float4(m[4], m[5], m[6], m[7]);
+        }
+        const uint32_t wmd = wave_max_u32(md);
+        uint32_t low1 = 0u;
+        float4 best_lab = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (occ && md == wmd) {
+            if (!eager) { t0 = *reinterpret_cast<const uint4 *>(tie + base); t1 = *reinterpret_cast<const uint4 *>(tie + base + 4); }
+            const uint32_t t[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (((occ >> q) & 1u) && float_to_bits(m[q]) == wmd && t[q] > low1) { low1 = t[q]; best_lab = v[q]; }
+            }
+        }
+        const uint32_t wlow1 = wave_max_u32(low1);
+        if (low1 == wlow1 && low1 != 0u) {
+            const unsigned long long key = ((unsigned long long)wmd << 32) | (unsigned long long)(wlow1 - 1u);
+            const uint32_t sl = ent.y & 255u;
+            InitRecord *r = records + slot_work_index(blockIdx.x, sl);
+            r->key = key;
+            r->lab = best_lab;
+            s_met[sl].key = key; s_met[sl].L = best_lab.x; s_met[sl].a = best_lab.y; s_met[sl].b = best_lab.z;
+        }
+        idx = idx_n; ent = ent_n; base = base_n; occ = occ_n; d0 = d0_n; d1 = d1_n;
+    }
+    // ---- the workgroup's row: the kCellMulti largest of its cells' records ----
+    __syncthreads();
+    if (wv < kOwn / 64u) {
+        CellCand mine = s_met[threadIdx.x];
+#pragma unroll
+        for (uint32_t r = 0; r < kCellMulti; ++r) {
+            const unsigned long long g = wave_max_u64(mine.key);
+            if (g == 0ull) {
+                if (lane == 0u) s_top[wv * kCellMulti + r] = no_cand();
+            } else if (mine.key == g) {
+                s_top[wv * kCellMulti + r] = mine;
+                mine.key = 0ull;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < (kOwn / 64u) * kCellMulti) {
+        const CellCand mine = s_top[threadIdx.x];
+        uint32_t rank = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < (kOwn / 64u) * kCellMulti; ++q) {
+            const unsigned long long o = s_top[q].key;
+            rank += (o > mine.key || (o == mine.key && q < threadIdx.x)) ? 1u : 0u;
+        }
+        if (rank < kCellMulti) rows[((uint64_t)(launch & 1u) * kInitGrid + blockIdx.x) * kCellMulti + rank] = mine;
+    }
+}
+
+hipError_t launch_init_cells_multi(const uint32_t *tie, const uint8_t *occ_bits, const float4 *lab_table, Centroid *cent, uint32_t k,
+                                   uint32_t launch, float *dist, void *init_scratch, const uint32_t *pick_rgba, const float *lut,
+                                   hipStream_t st)
+{
+    InitRecord *records = (InitRecord *)init_scratch;
+    CellCand *rows = (CellCand *)((InitSlot *)(records + kCells) + 2u * kInitGrid);
+    uint32_t *count = (uint32_t *)(rows + 2u * kInitGrid * kCellMulti);
+    hipLaunchKernelGGL(k_init_cells_multi, dim3(kInitGrid), dim3(kInitBlock), 0, st, tie, occ_bits, lab_table, cent, k, launch, dist,
+                       records, rows, count, pick_rgba, lut);
+    return hipGetLastError();
+}
+
+const uint32_t *init_cells_multi_count(const void *init_scratch, uint32_t launch)
+{
+    const InitRecord *records = (const InitRecord *)init_scratch;
+    const CellCand *rows = (const CellCand *)((const InitSlot *)(records + kCells) + 2u * kInitGrid);
+    return (const uint32_t *)(rows + 2u * kInitGrid * kCellMulti) + (launch & 1u);
 }
 
 // ------------------------------------------------------------------------------------------
