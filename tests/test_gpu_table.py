@@ -592,7 +592,10 @@ def test_dither_lists_continued_overflowing_and_missing(torch_cuda, oracle, monk
 
 
 @pytest.mark.parametrize("kind,w,h,k", [("tokyo", 256, 171, 2), ("tokyo", 256, 171, 33), ("few", 67, 41, 6),
-                                        ("noise", 300, 200, 17), ("noise", 1, 1, 3), ("few", 16, 1, 4)])
+                                        ("noise", 300, 200, 17), ("noise", 1, 1, 3), ("few", 16, 1, 4),
+                                        # k >= 32 over the colours: several picks per launch (k_init_cells_multi) -- more centroids
+                                        # than colours (every distance 0: pixel 0 again and again), noise, a photograph, k = 256
+                                        ("few", 67, 41, 40), ("noise", 300, 200, 64), ("tokyo", 256, 171, 150), ("noise", 96, 64, 256)])
 def test_init_over_colours_equals_init_over_pixels(torch_cuda, oracle, tokyo, monkeypatch, kind, w, h, k):
     """farthest-point init walking the image's colours (forced) == walking its pixels == oracle,
     including the arg-max tie rule on images with few colours"""
