@@ -1579,12 +1579,14 @@ constexpr uint32_t kOneItems = kOneCells * 4u;                   // at most four
 constexpr uint32_t kOneTests = 384;                              // dominance tests a WAVE lists (~120 on the benchmark image; more are dropped = kept candidates)
 constexpr uint32_t kOneRepl = 4;                                 // copies of the LDS bins
 
+constexpr uint32_t kOneTaskSlots = (kCells / kOneCells) * kOneWaves; // 4096 (workgroup, wave) places of a pass
+constexpr uint32_t kOneBalWords = 80;                              // CubeBalance: 2 x 32 (task, weight) entries + the workgroup's 16 tasks
 static size_t cube_one_lds_bytes(uint32_t k, bool with_sums)
 {
     const size_t bins = with_sums ? sizeof(unsigned long long) * kOneRepl * (4ull * k + 4ull) : 0u;
     return sizeof(float4) * 256u + bins + (size_t)kOneCells * kCellColours + sizeof(uint4) * kOneItems + sizeof(uint16_t) * kOneWaves * kOneTests +
            sizeof(unsigned long long) * kOneCells * 4u + sizeof(uint32_t) * kOneBlock * 2u + (size_t)kOneCells * 64u +
-           sizeof(uint32_t) * kOneCells * 3u + sizeof(uint32_t) * (8u + kOneWaves) + sizeof(uint16_t) * kOneCells * kMaxListed;
+           sizeof(uint32_t) * kOneCells * 3u + sizeof(uint32_t) * (8u + kOneWaves + kOneBalWords) + sizeof(uint16_t) * kOneCells * kMaxListed;
 }
 
 #ifdef KMG_TOOLS
@@ -1605,7 +1607,7 @@ __global__ __launch_bounds__(kOneBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
     const CellBounds *__restrict__ sub_bounds, const float *__restrict__ sub_affine, const Centroid *__restrict__ cent, uint32_t k,
     const float4 *__restrict__ lab_table, uint64_t *__restrict__ masks_out, uint8_t *__restrict__ colour_labels,
     uint16_t *__restrict__ sub_table, int64_t *__restrict__ sums, uint32_t n_rows, uint32_t flags,
-    unsigned long long *__restrict__ stats)
+    unsigned long long *__restrict__ stats, uint16_t *__restrict__ bal_state, uint32_t bal_pass)
 {
     extern __shared__ float4 smem4[];
     float4 *s_cent = smem4;                                                            // [256]
@@ -1623,7 +1625,8 @@ __global__ __launch_bounds__(kOneBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
     uint32_t *s_npop = s_cell + kOneCells;                                             // [cells]: candidates | first << 16
     uint32_t *s_left = s_npop + kOneCells;                                             // [cells]: items of the cell still to scan
     uint32_t *s_count = s_left + kOneCells;                                            // [0] items, [2] far centroid, [4] next item, [8 + w] tests of wave w
-    uint16_t *s_list = reinterpret_cast<uint16_t *>(s_count + 8 + kOneWaves);                     // [cells][kMaxListed]: centroid by position
+    uint32_t *s_bal = s_count + 8 + kOneWaves;                                          // [64] entries of the exchange, [16] this workgroup's tasks
+    uint16_t *s_list = reinterpret_cast<uint16_t *>(s_bal + kOneBalWords);                 // [cells][kMaxListed]: centroid by position
 
     const uint32_t vz = opaque_vgpr_zero();
     const uint32_t n_work_v = SUMS ? work[vz] : kCells;
@@ -1634,6 +1637,53 @@ __global__ __launch_bounds__(kOneBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
     }
     if (threadIdx.x < 8u + kOneWaves) s_count[threadIdx.x] = 0u;
     if (SUMS) for (uint32_t i = threadIdx.x; i < n_bins; i += kOneBlock) bins[i] = 0ull;
+    if (bal_state && (threadIdx.x >> 6) == kOneWaves - 1u) {
+        // CubeBalance (kmg_table.h): the tasks of this workgroup in this pass.  A pass costs what its slowest workgroup's scan costs, a
+        // workgroup's scan what its items cost (correlation 0.95), and a task's items change little from one Lloyd iteration to the
+        // next.  So every pass each workgroup meets one partner (bit (pass - 1) mod 8 of its index: a hypercube, all of it in eight
+        // passes): both read both rows of the PREVIOUS pass -- task ids and what their items cost -- and deal the 32 tasks out
+        // again, heaviest first, each to the lighter of the two that still has a free wave.  Both compute the same deal from the same
+        // data and each writes its own row of THIS pass's state: no task is lost or doubled, no workgroup waits for another.
+        // (Four workgroups per deal -- two bits a pass -- even the items out twice as fast and cost the pass 8 us: the deal is
+        // serial work in front of the first barrier.)
+        const uint32_t bl = threadIdx.x & 63u;
+        const uint32_t nw = __builtin_amdgcn_readfirstlane(n_work_v);
+        const uint32_t bcpw = min(8u, max(1u, (nw + gridDim.x * kOneWaves - 1u) / (gridDim.x * kOneWaves)));
+        const uint32_t btasks = (nw + bcpw - 1u) / bcpw, bused = (btasks + gridDim.x - 1u) / gridDim.x;
+        uint16_t *cur = bal_state + (bal_pass & 1u) * 2u * kOneTaskSlots;
+        const uint16_t *prev = bal_state + ((bal_pass + 1u) & 1u) * 2u * kOneTaskSlots;
+        uint32_t id = 0xFFFFu;
+        if (bal_pass == 0u) {
+            if (bl < bused && blockIdx.x * bused + bl < btasks) id = blockIdx.x * bused + bl;
+        } else {
+            const uint32_t partner = blockIdx.x ^ (1u << ((bal_pass - 1u) & 7u));
+            const uint32_t lo_wg = min(blockIdx.x, partner), hi_wg = max(blockIdx.x, partner);
+            const uint32_t src = ((bl & 16u) ? hi_wg : lo_wg) * kOneWaves + (bl & 15u);
+            uint32_t e_id = 0xFFFFu, e_w = 0u;
+            if (bl < 32u) { e_id = prev[src]; e_w = prev[kOneTaskSlots + src]; }
+            if (e_id >= btasks) { e_id = 0xFFFFu; e_w = 0u; }
+            if (bl < 32u) s_bal[bl] = (e_w << 16) | e_id;
+            __builtin_amdgcn_wave_barrier();
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < 32u; ++j) {
+                const uint32_t ow = s_bal[j] >> 16;
+                rank += (ow > e_w || (ow == e_w && j < bl)) ? 1u : 0u;
+            }
+            if (bl < 32u) s_bal[32u + rank] = (e_w << 16) | e_id;
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t sorted = bl < 32u ? s_bal[32u + bl] : 0u;
+            const bool i_am_hi = blockIdx.x == hi_wg;
+            uint32_t t0 = 0, t1 = 0, c0 = 0, c1 = 0;
+#pragma unroll
+            for (uint32_t r = 0; r < 32u; ++r) {
+                const uint32_t e = lane_value(sorted, r);
+                const bool to_hi = c0 >= kOneWaves || (c1 < kOneWaves && t1 < t0);
+                if (to_hi) { if (i_am_hi && bl == c1) id = e & 0xFFFFu; ++c1; t1 += e >> 16; }
+                else       { if (!i_am_hi && bl == c0) id = e & 0xFFFFu; ++c0; t0 += e >> 16; }
+            }
+        }
+        if (bl < kOneWaves) { cur[blockIdx.x * kOneWaves + bl] = (uint16_t)id; s_bal[64u + bl] = id; }
+    }
     __syncthreads();
     if (threadIdx.x < k) {
         const float4 c = s_cent[threadIdx.x];
@@ -1660,12 +1710,13 @@ __global__ __launch_bounds__(kOneBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
     const uint32_t cpw = min(8u, max(1u, (n_work + gridDim.x * kOneWaves - 1u) / (gridDim.x * kOneWaves)));
     const uint32_t tasks = (n_work + cpw - 1u) / cpw;              // wave tasks: task t = cells t, t + tasks, ... (cpw of them) of the work list
     const uint32_t waves_used = (tasks + gridDim.x - 1u) / gridDim.x;       // <= kOneWaves: the grid holds kCells / 8 tasks
-    if (blockIdx.x * waves_used >= tasks) return;
+    if (!bal_state && blockIdx.x * waves_used >= tasks) return;
     {
         KMG_STAMP(0);
         // (wave task t -> place (t P) mod tasks of the work list, P a prime that does not divide tasks: the cells of a workgroup
         // are spread over the whole cube instead of lying along a few lines of it -- the cost of a cell follows its position)
-        const uint32_t task = wv < waves_used ? blockIdx.x * waves_used + wv : tasks;
+        uint32_t task = wv < waves_used ? blockIdx.x * waves_used + wv : tasks;
+        if (bal_state) task = min(s_bal[64u + wv], tasks);          // (0xFFFF: a wave without a task)
         const uint32_t prime = tasks % 2053u ? 2053u : 1031u;
         const uint32_t pos = (uint32_t)(((uint64_t)task * prime) % tasks) + ci * tasks;
         const bool valid = task < tasks && ci < cpw && pos < n_work;
@@ -1848,6 +1899,11 @@ __global__ __launch_bounds__(kOneBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
             if (pend) s_left[slot] = ((uint32_t)__builtin_popcount(scan8) + 1u) >> 1;
             pend0_b = __ballot(pend && scan8 == 0u);
             const unsigned long long item_b = __ballot(head);
+            if (bal_state) {
+                // this task's weight in the next pass's deal: what its items will cost the scan (a fixed part + a part per candidate)
+                const uint32_t cost = wave_add_u32(head ? 4u + (type == 2u ? npop : n_un) : 0u);
+                if (lane == 0u) bal_state[(bal_pass & 1u) * 2u * kOneTaskSlots + kOneTaskSlots + blockIdx.x * kOneWaves + wv] = (uint16_t)min(cost, 65535u);
+            }
             uint32_t i_base = 0u;
             if (lane == 0u && item_b) i_base = atomicAdd(&s_count[0], (uint32_t)__builtin_popcountll(item_b));
             i_base = __builtin_amdgcn_readfirstlane(i_base);
@@ -2117,7 +2173,7 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
                        const uint32_t *work, const CellBounds *bounds, const CellBounds *sub_bounds, const Centroid *cent,
                        uint32_t k, const float4 *lab_table, uint64_t *masks, void *cell_work, void *colour_labels,
                        uint16_t *sub_table, int64_t *sums, uint32_t n_rows, uint32_t flags, unsigned long long *stats,
-                       hipStream_t st, const CubeTail *tail, const float *sub_affine)
+                       hipStream_t st, const CubeTail *tail, const float *sub_affine, const CubeBalance *balance)
 {
     const CubeTail tl = (tail && hist && n_rows <= 1u) ? *tail : CubeTail();
     const uint32_t kpad = (k + 63u) & ~63u;
@@ -2179,12 +2235,16 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
         const size_t lds = cube_one_lds_bytes(k, with_sums);
         if (lds > lds_max_dev) return hipErrorInvalidValue;
         if (!n_rows) n_rows = 1u;
+        static const bool balance_on = tools_env_int(KMG_TOOLS_ENV("KMG_BALANCE"), 1) != 0;      // (tools build: 0 = the fixed deal)
+        if (!balance_on) balance = nullptr;
         if (with_sums)
             hipLaunchKernelGGL((k_cube_one<true>), dim3(kCells / kOneCells), dim3(kOneBlock), lds, st, hist, agg, sub_agg, occ_bits, work, bounds,
-                               sub_bounds, sub_affine, cent, k, lab_table, masks, (uint8_t *)colour_labels, sub_table, sums, n_rows, flags, stats);
+                               sub_bounds, sub_affine, cent, k, lab_table, masks, (uint8_t *)colour_labels, sub_table, sums, n_rows, flags, stats,
+                               (balance && cell_work) ? (uint16_t *)cell_work : nullptr, balance ? balance->pass : 0u);
         else
             hipLaunchKernelGGL((k_cube_one<false>), dim3(kCells / kOneCells), dim3(kOneBlock), lds, st, hist, agg, sub_agg, occ_bits, work, bounds,
-                               sub_bounds, sub_affine, cent, k, lab_table, masks, (uint8_t *)colour_labels, sub_table, sums, n_rows, flags, stats);
+                               sub_bounds, sub_affine, cent, k, lab_table, masks, (uint8_t *)colour_labels, sub_table, sums, n_rows, flags, stats,
+                               (uint16_t *)nullptr, 0u);
         if (tl.acc_out)
             hipLaunchKernelGGL((k_cube_pairs<uint8_t>), dim3(1), dim3(kBlock), 0, st, work, 1, occ_bits,
                                (const uint8_t *)colour_labels, sub_table, flags | kCubeNoEntries, sums, k, tl);

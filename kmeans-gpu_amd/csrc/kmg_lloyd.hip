@@ -149,6 +149,7 @@ static int tables_from_histogram(kmg_lloyd *s, uint64_t n_pixels, hipStream_t st
     HIP_TRY(hipStreamSynchronize(st));
     if (const char *e = KMG_TOOLS_ENV("KMG_HOT_CELLS")) { if (e[0] == '0') t.n_hot = 0; }      // (tools build only)
     t.d_work_share = nullptr;
+    t.balance_work = nullptr;                                        // a new work list: the cube pass deals its tasks afresh
     return KMG_OK;
 }
 
@@ -192,6 +193,7 @@ static int bind_image_impl(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, void
         t.share_buf = (uint32_t *)carve(t.blk, off, sizes[9]);
     }
     t.d_work_share = nullptr;                                        // a new image: the whole work list again
+    t.balance_work = nullptr;
     t.rgba = nullptr;
     t.tables_valid = false;
     t.tie_valid = false;
@@ -463,6 +465,16 @@ KMG_ABI_CATCH
 
 // statistics / checks read the cell masks and the per-colour labels of EVERY cell, which the normal pass does
 // not store: repeat the cube pass of the bound image for the current centroids with both switched on
+// The balancing state of the next cube pass of a loop (kmg_table.h CubeBalance): the passes count on as long as the same work list is
+// walked -- the image's, or one share of it; a new list (another binding, another share) starts over.
+static CubeBalance next_balance(ColourTable &t, const uint32_t *work)
+{
+    if (t.balance_work != work) { t.balance_work = work; t.balance_pass = 0; }
+    CubeBalance b;
+    b.pass = t.balance_pass++;
+    return b;
+}
+
 static int debug_refresh(kmg_lloyd *s, hipStream_t st, unsigned long long stage[8] = nullptr)
 {
     ColourTable &t = s->tab;
@@ -522,10 +534,11 @@ static int table_assign(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_
         t.bound_by_init = false;
         int rc2;
         if ((rc2 = side_flush(s, st)) != KMG_OK) return rc2;
+        const CubeBalance bal = next_balance(t, t.d_work_share ? t.d_work_share : t.d_work);
         PROF_LAUNCH(s, KMG_K_CUBE, st, launch_cube(t.d_hist, t.d_agg, t.d_sub_agg, t.d_occ, t.d_work_share ? t.d_work_share : t.d_work,
                                                    s->p->d_bounds, s->p->d_sub_bounds, s->d_cent, s->k, s->p->d_lab_table, t.d_masks, t.d_cell_work,
                                                    t.d_colour_labels, t.d_sub, d_sums, 1u, t.n_hot ? kCubeHot : 0u, nullptr, st, nullptr,
-                                                   affine_for(s->p, s->k, st)));
+                                                   affine_for(s->p, s->k, st), &bal));
         t.entries_valid = true;
         t.tables_valid = t.d_work_share == nullptr;
         return KMG_OK;
@@ -553,11 +566,12 @@ static int table_assign(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_
         tail.n_converged = s->d_nconv;
         // (k <= 32, and 32 < k <= 256 without hot cells: the cube pass is one launch, and when a label pass follows, its tail rides on that one)
         const bool tail_on_labels = d_labels != nullptr && s->k <= 256u && cube_single_launch(s->k, t.n_hot ? kCubeHot : 0u);
+        const CubeBalance bal = next_balance(t, t.d_work_share ? t.d_work_share : t.d_work);
         PROF_LAUNCH(s, KMG_K_CUBE, st, launch_cube(t.d_hist, t.d_agg, t.d_sub_agg, t.d_occ, t.d_work_share ? t.d_work_share : t.d_work,
                                                    s->p->d_bounds, s->p->d_sub_bounds,
                                                    s->d_cent, s->k, s->p->d_lab_table, t.d_masks, t.d_cell_work, t.d_colour_labels, t.d_sub,
                                                    s->d_acc_int, 1u, (defer_entries ? kCubeNoEntries : 0u) | (t.n_hot ? kCubeHot : 0u), nullptr, st,
-                                                   tail_on_labels ? nullptr : &tail, affine_for(s->p, s->k, st)));
+                                                   tail_on_labels ? nullptr : &tail, affine_for(s->p, s->k, st), &bal));
         t.entries_valid = !defer_entries;
         if (tail_on_labels) {
             t.tables_valid = true;
@@ -994,6 +1008,7 @@ try {
     if (!s->tab.rgba || !s->tab.d_hist) return fail(KMG_ERR_INVALID_ARGUMENT, "set_cell_share: no bound image");
     HIP_TRY(hipSetDevice(s->p->device));
     ColourTable &t = s->tab;
+    t.balance_work = nullptr;                                        // (the share buffer is reused: the same pointer, another list)
     if (parts == 1u) { t.d_work_share = nullptr; return KMG_OK; }
     HIP_TRY(launch_work_share(t.d_work, part, parts, t.share_buf, S(stream)));
     t.d_work_share = t.share_buf;
@@ -1228,9 +1243,10 @@ try {
         if (update_first)
             PROF_LAUNCH(s, KMG_K_UPDATE, st, launch_update(d_acc4, s->k, s->p->opt.convergence, s->d_cent, s->d_nconv, st));
         HIP_TRY(hipMemsetAsync(d_acc4, 0, sizeof(int64_t) * 4ull * s->k, st));
+        const CubeBalance bal = next_balance(t, t.d_work);
         PROF_LAUNCH(s, KMG_K_CUBE, st, launch_cube(t.d_hist, t.d_agg, t.d_sub_agg, t.d_occ, t.d_work, s->p->d_bounds, s->p->d_sub_bounds,
                                                    s->d_cent, s->k, s->p->d_lab_table, t.d_masks, t.d_cell_work, t.d_colour_labels, t.d_sub,
-                                                   d_acc4, 1u, t.n_hot ? kCubeHot : 0u, nullptr, st, nullptr, affine_for(s->p, s->k, st)));
+                                                   d_acc4, 1u, t.n_hot ? kCubeHot : 0u, nullptr, st, nullptr, affine_for(s->p, s->k, st), &bal));
         return KMG_OK;
     };
     if ((rc = issue()) != KMG_OK) {

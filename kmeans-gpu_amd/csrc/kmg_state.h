@@ -114,6 +114,8 @@ struct ColourTable {
     uint32_t *d_work = nullptr;      // kWorkWords: dense list of the occupied cells, then the hot cells (kmg_table.h)
     uint32_t n_hot = 0;              // host copy of the number of hot cells of the bound image
     uint32_t n_occ = 0;              // host copy of the number of occupied cells of the bound image (d_work[0])
+    const uint32_t *balance_work = nullptr;   // the work list the one-launch cube pass last walked with CubeBalance, and how often
+    uint32_t balance_pass = 0;
     uint32_t *share_buf = nullptr;   // storage of d_work_share
     uint32_t *d_work_share = nullptr;   // 1 + kCells: this rank's share of the work list (kmg_lloyd_set_cell_share), or NULL = all of it
     bool tables_valid = false;       // label tables describe the CURRENT centroid table

@@ -223,11 +223,19 @@ struct CubeTail {
     Centroid *cent = nullptr;        // updated in place
     uint32_t *n_converged = nullptr;
 };
+// Load balance of the one-launch pass (k_cube_one) across the passes of a loop over ONE work list: `pass` counts the launches since
+// the list was first walked (0: the tasks are dealt out afresh); the state (32 KiB: two sets of 4 096 task ids + the items each
+// produced) lives at the start of cell_work, which that pass does not use otherwise.  Every pass each workgroup re-deals its tasks
+// with one partner by the previous pass's weights (kmg_cube.hip).  NULL: the fixed deal, the state is left alone.
+struct CubeBalance {
+    uint32_t pass = 0;
+};
 hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *sub_agg, const uint8_t *occ_bits,
                        const uint32_t *work, const CellBounds *bounds, const CellBounds *sub_bounds, const Centroid *cent,
                        uint32_t k, const float4 *lab_table, uint64_t *masks, void *cell_work, void *colour_labels,
                        uint16_t *sub_table, int64_t *sums, uint32_t n_rows, uint32_t flags, unsigned long long *stats,
-                       hipStream_t st, const CubeTail *tail = nullptr, const float *sub_affine = nullptr);
+                       hipStream_t st, const CubeTail *tail = nullptr, const float *sub_affine = nullptr,
+                       const CubeBalance *balance = nullptr);
 // sub_affine (optional, once per processor, sub_affine_bytes() = 24 MiB, image independent; k_cube_small and k_cube_one use it):
 // per sub-cell affine models (binary16) of the seven per-colour features the difference of two keys is linear in, with exact
 // residual ranges -- the dominance test that removes, from a sub-cell's candidates, those another candidate beats on every

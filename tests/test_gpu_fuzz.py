@@ -20,7 +20,7 @@ def test_random_problems_agree_across_strategies(seed):
 
 # every switch the TOOLS build of the library reads (kmg_internal.h KMG_TOOLS_ENV), set to a value that changes a launch shape there
 # (the knock-outs of rounds 2-5 -- kernel variants that skip work and return wrong results -- are patches under tools/experiments/)
-TOOLS_SWITCHES = {"KMG_ASSIGN_PPT": "1", "KMG_HOT_CELLS": "0", "KMG_CUBE_REPL": "1", "KMG_CUBE_SMALL": "0", "KMG_DITHER_SORT": "0",
+TOOLS_SWITCHES = {"KMG_ASSIGN_PPT": "1", "KMG_HOT_CELLS": "0", "KMG_CUBE_REPL": "1", "KMG_CUBE_SMALL": "0", "KMG_DITHER_SORT": "0", "KMG_BALANCE": "0",
                   "KMG_CUBE_GRID": "7", "KMG_SCAN_GRID": "5", "KMG_PAIRS_GRID": "3", "KMG_SMALL_GRID": "9", "KMG_DITHER_STATS": "1",
                   "KMG_SPLIT_LONG": "0"}
 

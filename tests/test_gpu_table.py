@@ -1029,6 +1029,77 @@ def test_assign_update_equals_the_two_calls(torch_cuda, oracle, monkeypatch, k, 
     a.close(); b.close(); p.close()
 
 
+@pytest.mark.parametrize("kind,k", [("noise", 256), ("blobs", 64), ("noise", 40)])
+def test_cube_pass_redeals_its_tasks_without_losing_a_cell(torch_cuda, oracle, monkeypatch, kind, k):
+    """The one-launch cube pass (32 < k <= 256) deals its wave tasks out again from pass to pass -- every workgroup with one
+    partner, by what the tasks' items cost in the previous pass (kmg_table.h CubeBalance).  Twenty passes walk every dimension
+    of the exchange more than twice: sums, centroids and labels of every pass == the per-pixel scan's; then a cell share (another
+    work list: the deal starts over) and a second image in the same buffer (a re-bind)."""
+    import kmeans_gpu_amd as kg
+    torch = torch_cuda
+    st = _stream(torch)
+    w, h = 1024, 1024
+    n = w * h
+    rng = np.random.default_rng(11 * k)
+    img = oracle.synth_uniform(97 + k, n) if kind == "noise" else _blobs(rng, n, 60, sigma=30.0)
+    lab = oracle.rgb_to_lab(img)
+    init = oracle.centroids4(lab[rng.choice(n, k, replace=False)])
+    d = _dev(torch, img)
+    p = kg.ImageProcessor(shrink_max_dim=0)
+    res = {}
+    for strategy in ("brute", "table"):
+        _set_strategy(strategy)
+        s = kg.Lloyd(p, k)
+        s.set_centroids(init, st)
+        s.prepare(d.data_ptr(), n, True, st)
+        lb = torch.zeros(n, dtype=torch.int32, device="cuda")
+        acc = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
+        out = []
+        for it in range(20):
+            s.assign_update(d.data_ptr(), n, lb.data_ptr() if it % 5 == 4 else 0, acc.data_ptr(), True, st)
+            torch.cuda.synchronize()
+            out.append((acc.cpu().numpy().copy(), s.get_centroids(st).view(np.uint32).copy(), lb.cpu().numpy().copy() if it % 5 == 4 else None))
+        if strategy == "table":
+            # another work list: one share of the cube, sums only, four passes; then the whole cube again
+            whole = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
+            s.assign_accumulate(d.data_ptr(), n, 0, whole.data_ptr(), st)
+            parts = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
+            for part in range(3):
+                s.set_cell_share(part, 3, st)
+                for _ in range(4):
+                    one = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
+                    s.assign_accumulate(d.data_ptr(), n, 0, one.data_ptr(), st)
+                parts += one
+            s.set_cell_share(0, 1, st)
+            torch.cuda.synchronize()
+            assert torch.equal(parts, whole), "the shares' sums do not add up to the whole cube's"
+            again = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
+            s.assign_accumulate(d.data_ptr(), n, 0, again.data_ptr(), st)
+            torch.cuda.synchronize()
+            assert torch.equal(again, whole)
+            # a second image in the same buffer: the binding, and with it the deal, starts over
+            img2 = oracle.synth_uniform(5 + k, n)
+            d.copy_(_dev(torch, img2))
+            s.set_centroids(init, st)
+            s.prepare(d.data_ptr(), n, True, st)
+            for it in range(3):
+                s.assign_update(d.data_ptr(), n, lb.data_ptr(), acc.data_ptr(), True, st)
+            torch.cuda.synchronize()
+            cent = init
+            for it in range(3):
+                wl, wa = oracle.assign_accumulate_rgba(img2, cent)
+                cent, _ = oracle.finalize(wa, cent)
+            assert np.array_equal(acc.cpu().numpy(), wa) and np.array_equal(lb.cpu().numpy().view(np.uint32), wl)
+            d.copy_(_dev(torch, img))
+        res[strategy] = out
+        s.close()
+    for it, (a, b) in enumerate(zip(res["brute"], res["table"])):
+        assert np.array_equal(a[0], b[0]), f"sums differ in pass {it}"
+        assert np.array_equal(a[1], b[1]), f"centroids differ after pass {it}"
+        assert (a[2] is None) == (b[2] is None) and (a[2] is None or np.array_equal(a[2], b[2])), f"labels differ in pass {it}"
+    p.close()
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_cell_sharded_cube_pass_equals_unsharded(torch_cuda, oracle, tokyo, monkeypatch, world):
     """The cell-sharded loop (tests/sharded_harness.py ShardedLloyd(cells=True)) with the real kernels, `world` ranks emulated

@@ -25,7 +25,7 @@ cent = np.ones((k, 4), np.float32); cent[:, :3] = lab.cpu().numpy()
 s = kg.Lloyd(proc, k); s.set_centroids(cent, st); s.bind_image(rgba.data_ptr(), n, st)
 acc = torch.zeros((k, 4), dtype=torch.int64, device="cuda")
 labels = torch.empty(n, dtype=torch.int32, device="cuda")
-for _ in range(4):
+for _ in range(int(os.environ.get("PASSES", "4"))):     # (the pass re-deals its tasks between workgroups from pass to pass: CubeBalance)
     s.assign_update(rgba.data_ptr(), n, labels.data_ptr(), acc.data_ptr(), True, st)
 share = os.environ.get("SHARE")            # "R/N": the pass over rank R's share of the cube (the strong-scaling loop's per-rank launch)
 if share:
