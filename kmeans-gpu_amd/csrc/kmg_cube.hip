@@ -1581,6 +1581,8 @@ constexpr uint32_t kOneRepl = 4;                                 // copies of th
 
 constexpr uint32_t kOneTaskSlots = (kCells / kOneCells) * kOneWaves; // 4096 (workgroup, wave) places of a pass
 constexpr uint32_t kOneBalWords = 80;                              // CubeBalance: 2 x 32 (task, weight) entries + the workgroup's 16 tasks
+size_t cube_balance_bytes() { return sizeof(uint16_t) * 4u * kOneTaskSlots; }
+
 static size_t cube_one_lds_bytes(uint32_t k, bool with_sums)
 {
     const size_t bins = with_sums ? sizeof(unsigned long long) * kOneRepl * (4ull * k + 4ull) : 0u;
@@ -2240,7 +2242,7 @@ hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *
         if (with_sums)
             hipLaunchKernelGGL((k_cube_one<true>), dim3(kCells / kOneCells), dim3(kOneBlock), lds, st, hist, agg, sub_agg, occ_bits, work, bounds,
                                sub_bounds, sub_affine, cent, k, lab_table, masks, (uint8_t *)colour_labels, sub_table, sums, n_rows, flags, stats,
-                               (balance && cell_work) ? (uint16_t *)cell_work : nullptr, balance ? balance->pass : 0u);
+                               balance ? balance->state : nullptr, balance ? balance->pass : 0u);
         else
             hipLaunchKernelGGL((k_cube_one<false>), dim3(kCells / kOneCells), dim3(kOneBlock), lds, st, hist, agg, sub_agg, occ_bits, work, bounds,
                                sub_bounds, sub_affine, cent, k, lab_table, masks, (uint8_t *)colour_labels, sub_table, sums, n_rows, flags, stats,

@@ -168,10 +168,10 @@ static int bind_image_impl(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, void
     ColourTable &t = s->tab;
     if (!t.d_hist) {
         // one block for all tables, from the processor's idle blocks when one fits (no hipMalloc on a warm processor)
-        const size_t sizes[10] = {sizeof(uint32_t) << 24, sizeof(int64_t) * 4ull * kCells, sizeof(int64_t) * 4ull * kSubCells,
+        const size_t sizes[11] = {sizeof(uint32_t) << 24, sizeof(int64_t) * 4ull * kCells, sizeof(int64_t) * 4ull * kSubCells,
                                   (size_t)1 << 21, cube_work_bytes(), cube_masks_bytes(s->k),
                                   sizeof(uint32_t) * kWorkWords, (size_t)(s->k <= 256 ? 1 : 2) << 24, sub_table_bytes(),
-                                  sizeof(uint32_t) * (kCells + 1)};
+                                  sizeof(uint32_t) * (kCells + 1), cube_balance_bytes()};
         size_t need = 0;
         for (size_t b : sizes) need += pad256(b);
         const hipError_t e = block_take(s->p, need, &t.blk, &t.blk_cap);
@@ -191,6 +191,7 @@ static int bind_image_impl(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, void
         t.d_colour_labels = carve(t.blk, off, sizes[7]);
         t.d_sub = (uint16_t *)carve(t.blk, off, sizes[8]);
         t.share_buf = (uint32_t *)carve(t.blk, off, sizes[9]);
+        t.d_balance = (uint16_t *)carve(t.blk, off, sizes[10]);
     }
     t.d_work_share = nullptr;                                        // a new image: the whole work list again
     t.balance_work = nullptr;
@@ -471,6 +472,7 @@ static CubeBalance next_balance(ColourTable &t, const uint32_t *work)
 {
     if (t.balance_work != work) { t.balance_work = work; t.balance_pass = 0; }
     CubeBalance b;
+    b.state = t.d_balance;
     b.pass = t.balance_pass++;
     return b;
 }

@@ -114,6 +114,7 @@ struct ColourTable {
     uint32_t *d_work = nullptr;      // kWorkWords: dense list of the occupied cells, then the hot cells (kmg_table.h)
     uint32_t n_hot = 0;              // host copy of the number of hot cells of the bound image
     uint32_t n_occ = 0;              // host copy of the number of occupied cells of the bound image (d_work[0])
+    uint16_t *d_balance = nullptr;   // cube_balance_bytes(): the one-launch cube pass's deal of its tasks, two sets (kmg_table.h CubeBalance)
     const uint32_t *balance_work = nullptr;   // the work list the one-launch cube pass last walked with CubeBalance, and how often
     uint32_t balance_pass = 0;
     uint32_t *share_buf = nullptr;   // storage of d_work_share

@@ -224,12 +224,14 @@ struct CubeTail {
     uint32_t *n_converged = nullptr;
 };
 // Load balance of the one-launch pass (k_cube_one) across the passes of a loop over ONE work list: `pass` counts the launches since
-// the list was first walked (0: the tasks are dealt out afresh); the state (32 KiB: two sets of 4 096 task ids + the items each
-// produced) lives at the start of cell_work, which that pass does not use otherwise.  Every pass each workgroup re-deals its tasks
-// with one partner by the previous pass's weights (kmg_cube.hip).  NULL: the fixed deal, the state is left alone.
+// the list was first walked (0: the tasks are dealt out afresh); state: cube_balance_bytes() of device memory that nothing else
+// touches between the passes (two sets of 4 096 task ids + what each task's items cost).  Every pass each workgroup re-deals its
+// tasks with one partner by the previous pass's weights (kmg_cube.hip).  NULL: the fixed deal, the state is left alone.
 struct CubeBalance {
+    uint16_t *state = nullptr;
     uint32_t pass = 0;
 };
+size_t cube_balance_bytes();
 hipError_t launch_cube(const uint32_t *hist, const int64_t *agg, const int64_t *sub_agg, const uint8_t *occ_bits,
                        const uint32_t *work, const CellBounds *bounds, const CellBounds *sub_bounds, const Centroid *cent,
                        uint32_t k, const float4 *lab_table, uint64_t *masks, void *cell_work, void *colour_labels,
