@@ -601,6 +601,9 @@ def main():
                          "N-rank loop of the library and this file's N > 1 code; its timings mean nothing")
     ap.add_argument("--force-dist", action="store_true",
                     help="load RCCL and run every collective even with one rank (KMG_GROUP_FORCE_COLLECTIVES)")
+    ap.add_argument("--fail-first-candidate", action="store_true",
+                    help="testing aid, N > 1: the first sharding candidate tried before the timed region raises, as a failed "
+                         "collective would -- the ranks must drop the group, make a new one and measure another candidate")
     ap.add_argument("--only", choices=["cfg2"], default=None,
                     help="run one secondary configuration alone and print its JSON (for rocprofv3 legs): cfg2 = 4096x4096, k=16")
     ap.add_argument("--strategy", choices=["auto", "scan", "table"], default="auto",
@@ -663,17 +666,18 @@ def main():
     kg.set_strategy(args.strategy)                            # (kmg_options.strategy of every processor this run creates)
 
     # ---- the group: ImageProcessor::new over this job's devices (include/kmeans_hip.h kmg_group_*) ----
-    with _StdoutToStderr():
-        if args.rehearse:
-            group = kg.Group(devices=[0] * world, flags=kg.GROUP_LOOPBACK, shrink_max_dim=0)
-        elif world > 1 or args.force_dist:
-            uid = [kg.Group.unique_id() if rank == 0 else None]
-            if world > 1:
-                dist.broadcast_object_list(uid, src=0)
-            group = kg.Group(devices=[local_rank], unique_id=uid[0], first_rank=rank, world=world, shrink_max_dim=0,
-                             flags=kg.GROUP_FORCE_COLLECTIVES if args.force_dist else 0)
-        else:
-            group = kg.Group(devices=[local_rank], shrink_max_dim=0)
+    def make_group():
+        with _StdoutToStderr():
+            if args.rehearse:
+                return kg.Group(devices=[0] * world, flags=kg.GROUP_LOOPBACK, shrink_max_dim=0)
+            if world > 1 or args.force_dist:
+                uid = [kg.Group.unique_id() if rank == 0 else None]
+                if world > 1:
+                    dist.broadcast_object_list(uid, src=0)
+                return kg.Group(devices=[local_rank], unique_id=uid[0], first_rank=rank, world=world, shrink_max_dim=0,
+                                flags=kg.GROUP_FORCE_COLLECTIVES if args.force_dist else 0)
+            return kg.Group(devices=[local_rank], shrink_max_dim=0)
+    group = make_group()
     proc = group.processor(0)
     collective_backend = ("loopback through device memory (rehearsal on one GPU)" if args.rehearse else
                           f"RCCL {group.rccl_version} (ncclAllReduce inside libkmeans_hip, dlopen'ed)" if group.rccl_version else
@@ -775,11 +779,25 @@ def main():
             # every rank drops it together and the next candidate is tried with the ranks still in step)
             try:
                 bind_loop(gl, fl, bands, label_maps, rows, height, cent)
+                if args.fail_first_candidate and not trial:
+                    raise RuntimeError("--fail-first-candidate")
                 t_local = timed(gl, 5)
             except Exception as e:                             # noqa: BLE001 -- reported below, not swallowed
                 t_local = float("inf")
                 failed[name] = f"{type(e).__name__}: {e}"
             trial[name] = max_over_ranks(t_local) / 5 * 1e3
+            if trial[name] == float("inf"):
+                # A rank whose collective or launch failed has marked its group broken and aborted its communicator
+                # (include/kmeans_hip.h): every rank knows by now (the MAX above), so all of them drop the group together and make
+                # a new one -- a new unique id over gloo, new communicators -- before the next candidate is tried.
+                try:
+                    gl.close()
+                    group.close()
+                except Exception:                              # noqa: BLE001 -- a broken group may refuse; it is dropped either way
+                    pass
+                group = make_group()
+                proc = group.processor(0)
+                gl = kg.GroupLloyd(group, k)
         best = min(trial, key=trial.get)                     # (the same on every rank: the times were all-reduced)
         if trial[best] == float("inf"):
             raise RuntimeError(f"no sharding of the image over {world} GPUs ran: {failed or 'another rank failed'}")

@@ -77,6 +77,14 @@ def test_bench_multi_gpu_path_rehearsed_on_one_gpu(torch_cuda):
     assert ("cube pass sharded by cells" in cfg["sharding"]) == (choice["picked"] == "cells") and line["value"] > 0
     assert cfg["expected_speedup"] in (1.70, 1.35) and cfg["measured_speedup"] > 0 and cfg["one_gpu_ms_per_step_same_run"] > 0
     assert line["extra"]["weak_scaling_value"] > 0
+    # a candidate that fails (as a broken collective would) costs the run that candidate only: the ranks drop the group, make a new
+    # one and measure another shape
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rehearse",
+                        "--no-extras", "--no-cpu-baseline", "--fail-first-candidate"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    choice = json.loads(r.stdout)["config"]["sharding_choice"]
+    assert choice["cells_ms_per_step"] is None and "fail-first-candidate" in choice["failed_on_this_rank"]["cells"]
+    assert choice["picked"] != "cells" and choice[choice["picked"] + "_ms_per_step"] > 0
     # and the cell-sharded loop when asked for, started the way the driver starts N > 1
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
