@@ -567,7 +567,8 @@ static int table_assign(kmg_lloyd *s, const uint8_t *d_rgba, uint64_t n, uint32_
         tail.cent = s->d_cent;
         tail.n_converged = s->d_nconv;
         // (k <= 32, and 32 < k <= 256 without hot cells: the cube pass is one launch, and when a label pass follows, its tail rides on that one)
-        const bool tail_on_labels = d_labels != nullptr && s->k <= 256u && cube_single_launch(s->k, t.n_hot ? kCubeHot : 0u);
+        static const bool tail_rides = tools_env_int(KMG_TOOLS_ENV("KMG_TAIL_ON_LABELS"), 1) != 0;   // (tools build: 0 = a launch of its own)
+        const bool tail_on_labels = tail_rides && d_labels != nullptr && s->k <= 256u && cube_single_launch(s->k, t.n_hot ? kCubeHot : 0u);
         const CubeBalance bal = next_balance(t, t.d_work_share ? t.d_work_share : t.d_work);
         PROF_LAUNCH(s, KMG_K_CUBE, st, launch_cube(t.d_hist, t.d_agg, t.d_sub_agg, t.d_occ, t.d_work_share ? t.d_work_share : t.d_work,
                                                    s->p->d_bounds, s->p->d_sub_bounds,
