@@ -1444,7 +1444,9 @@ __global__ __launch_bounds__(kLabelBlock) void k_labels_pairs(const uint32_t *__
                                                               const uint32_t *__restrict__ hot, int64_t *__restrict__ tail_sums,
                                                               CubeTail tail)
 {
-    extern __shared__ uint32_t s_label_lds[];
+    // Static LDS with the small tables in front: every table's address is then a compile-time constant that fits the ds_read
+    // offset field (as dynamic LDS the pair table's base was a v_add per pixel, the direction table's another).
+    __shared__ uint32_t s_label_lds[(HOT ? kLabelLdsHot : kLabelLdsPlain) / sizeof(uint32_t)];
     // The cube pass's tail (kmg_table.h CubeTail) when that pass has no launch left to carry it (k_cube_small): the sums are
     // final -- the cube pass is a launch of its own before this one -- and nothing in this pass reads them or the centroids.
     if (tail.acc_out && blockIdx.x == gridDim.x - 1u) {
@@ -1455,8 +1457,8 @@ __global__ __launch_bounds__(kLabelBlock) void k_labels_pairs(const uint32_t *__
         __syncthreads();
     }
     constexpr uint32_t kPairWords = kCells;
-    uint32_t *s_pair = s_label_lds, *s_pal = s_label_lds + kPairWords, *s_dir = s_label_lds + kPairWords + 256;
-    uint8_t *s_hot = reinterpret_cast<uint8_t *>(s_label_lds + kPairWords + 256 + 128);
+    uint32_t *s_pal = s_label_lds, *s_dir = s_label_lds + 256, *s_pair = s_label_lds + 256 + 128;
+    uint8_t *s_hot = reinterpret_cast<uint8_t *>(s_label_lds + 256 + 128 + kPairWords);
     uint32_t *s_hcell = reinterpret_cast<uint32_t *>(s_hot + (size_t)kHotMax * kCellColours);
     if (pal && threadIdx.x < k) s_pal[threadIdx.x] = pal[threadIdx.x];
     if (threadIdx.x < 128) s_dir[threadIdx.x] = threadIdx.x < kPairDirs ? pair_dir_word(threadIdx.x) : 0u;
@@ -1545,10 +1547,10 @@ hipError_t launch_labels(const uint32_t *rgba, uint64_t n, const void *colour_la
                              (reinterpret_cast<uintptr_t>(labels) & 15u) == 0) ? 1 : 0;
         const uint32_t *pairs = reinterpret_cast<const uint32_t *>(sub_table + kSubCells + kCells);
         if (hot)
-            hipLaunchKernelGGL(k_labels_pairs<true>, dim3(grid), dim3(kLabelBlock), kLabelLdsHot, st, rgba, n,
+            hipLaunchKernelGGL(k_labels_pairs<true>, dim3(grid), dim3(kLabelBlock), 0, st, rgba, n,
                                (const uint8_t *)colour_labels, pairs, pal, k, labels, aligned, hot, tail_sums, tl);
         else
-            hipLaunchKernelGGL(k_labels_pairs<false>, dim3(grid), dim3(kLabelBlock), kLabelLdsPlain, st, rgba, n,
+            hipLaunchKernelGGL(k_labels_pairs<false>, dim3(grid), dim3(kLabelBlock), 0, st, rgba, n,
                                (const uint8_t *)colour_labels, pairs, pal, k, labels, aligned, hot, tail_sums, tl);
         return hipGetLastError();
     }
