@@ -1,13 +1,13 @@
 #!/bin/bash
 # A/B of two builds of the library on ONE box: rocprofv3 kernel stats of bench.py's loop, alternating.
-#   bash tools/lib_ab.sh <tag> <lib A> <lib B> [runs]   -> gpurun_out/<tag>_lib_ab.txt
+#   RUNS=3 bash tools/lib_ab.sh <tag> <lib A> <lib B> [<lib C> ...]   -> gpurun_out/<tag>_lib_ab.txt
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-ab}; A=$2; B=$3; RUNS=${4:-3}
+TAG=${1:-ab}; shift; LIBS="$@"; RUNS=${RUNS:-3}
 OUT=$ROOT/gpurun_out/${TAG}_lib_ab.txt
 : > $OUT
 cd /tmp && export TMPDIR=/tmp
 for rep in $(seq 1 $RUNS); do
-  for lib in $A $B; do
+  for lib in $LIBS; do
     export KMG_LIBRARY=$ROOT/$lib
     rm -rf $ROOT/gpurun_out/${TAG}_abprof
     rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${TAG}_abprof -- python3 $ROOT/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-extras > $ROOT/gpurun_out/${TAG}_ab_bench.json 2> /dev/null
