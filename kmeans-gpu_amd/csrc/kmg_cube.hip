@@ -1744,15 +1744,23 @@ __global__ __launch_bounds__(kOneBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
         if (sub == 0u) s_cell[slot] = cell;
 
         // ---- 1a. the candidates of the wave's cells, one cell at a time ----
+        // The cell's twelve bounds reach every lane as VECTOR registers, through LDS (three broadcast ds_read_b128 from the wave's
+        // own label block, which nothing writes before this wave's 1c): as twelve v_readlane they cost 8 issue cycles each and
+        // then sat in scalar registers -- a scalar operand costs a vector instruction 4.1 issue cycles instead of 2.3-2.6
+        // (tools/valu_rate.hip), and most instructions of the interval evaluations had one.  73.5 -> 71.7 us.
+        float *s_cb = reinterpret_cast<float *>(s_lbl + (size_t)wv * 8u * kCellColours);
+        s_cb[lane] = cbv_a;
+        s_cb[64u + lane] = cbv_b;
+        __builtin_amdgcn_wave_barrier();
         for (uint32_t c = 0; c < cpw; ++c) {
             const uint32_t ccell = lane_value(cell, c * 8u);
             const bool cvalid = lane_value((uint32_t)valid, c * 8u) != 0u;
-            const float cbv = c < 4u ? cbv_a : cbv_b;
-            const uint32_t l0 = (c & 3u) * 16u;
+            const float4 *cq = reinterpret_cast<const float4 *>(s_cb + c * 16u);
+            const float4 q0 = cq[0], q1 = cq[1], q2 = cq[2];
             CellBounds cb;
-            cb.L0 = lane_value(cbv, l0 + 0u); cb.L1 = lane_value(cbv, l0 + 1u); cb.a0 = lane_value(cbv, l0 + 2u); cb.a1 = lane_value(cbv, l0 + 3u);
-            cb.b0 = lane_value(cbv, l0 + 4u); cb.b1 = lane_value(cbv, l0 + 5u); cb.C0 = lane_value(cbv, l0 + 6u); cb.C1 = lane_value(cbv, l0 + 7u);
-            cb.wC0 = lane_value(cbv, l0 + 8u); cb.wC1 = lane_value(cbv, l0 + 9u); cb.wH0 = lane_value(cbv, l0 + 10u); cb.wH1 = lane_value(cbv, l0 + 11u);
+            cb.L0 = q0.x; cb.L1 = q0.y; cb.a0 = q0.z; cb.a1 = q0.w;
+            cb.b0 = q1.x; cb.b1 = q1.y; cb.C0 = q1.z; cb.C1 = q1.w;
+            cb.wC0 = q2.x; cb.wC1 = q2.y; cb.wH0 = q2.z; cb.wH1 = q2.w;
             float lo[4], U = 3.0e38f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
