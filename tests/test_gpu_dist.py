@@ -75,7 +75,7 @@ def test_bench_multi_gpu_path_rehearsed_on_one_gpu(torch_cuda):
     choice = cfg["sharding_choice"]
     assert choice["cells_ms_per_step"] > 0 and choice["bands_ms_per_step"] > 0 and (choice["picked"] + "_ms_per_step") in choice
     assert ("cube pass sharded by cells" in cfg["sharding"]) == (choice["picked"] == "cells") and line["value"] > 0
-    assert cfg["expected_speedup"] in (1.70, 1.35) and cfg["measured_speedup"] > 0 and cfg["one_gpu_ms_per_step_same_run"] > 0
+    assert cfg["expected_speedup"] in (1.68, 1.35) and cfg["measured_speedup"] > 0 and cfg["one_gpu_ms_per_step_same_run"] > 0
     assert line["extra"]["weak_scaling_value"] > 0
     # a candidate that fails (as a broken collective would) costs the run that candidate only: the ranks drop the group, make a new
     # one and measure another shape
